@@ -1,0 +1,211 @@
+/*
+ * rl_engine.h — C ABI of the MI355X rate-limit counter engine.
+ *
+ * This is the drop-in boundary for ONE path of Kuadrant/limitador: the in-memory counter
+ * storage behind `trait CounterStorage` (reference limitador/src/storage/mod.rs:279-292),
+ * whose hot method is `InMemoryStorage::check_and_update`
+ * (limitador/src/storage/in_memory.rs:72-156).  The reference has no FFI for this path today
+ * (backends are compiled-in Rust modules, storage/mod.rs:10-24); these entry points are what a
+ * `GpuStorage: CounterStorage` Rust module would bind with `extern "C"` (INTEGRATION.md shows
+ * the binding).  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * Semantics contract (all entry points): the result of a batch call is bit-identical to
+ * applying the reference method to the batch's requests ONE AT A TIME IN INDEX ORDER, with every
+ * `SystemTime::now()` the reference would read during the batch (in_memory.rs:49,83;
+ * atomic_expiring_value.rs:27,72) replaced by the call's single `now_us`.
+ *
+ * Identity: the reference keys a counter by (Limit identity, resolved variables)
+ * (counter.rs:123-138, limit.rs:177-214) — strings.  The caller interns that identity to an
+ * exact 64-bit `key` (unique per counter, simple or qualified; two different counters must
+ * never share a key) and the Limit identity to a dense `limit` id.  The engine hashes `key`
+ * to a slot on the device but stores and compares the full 64-bit key, so there is no
+ * fingerprint-collision error mode.  Keys 0xFFFFFFFFFFFFFFFE/F are reserved.
+ *
+ * Threading: calls on one engine are serialised internally (one mutex, one HIP stream); any
+ * thread may call.  Errors: every function returns RL_OK (0) or a negative rl_status;
+ * rl_last_error() gives the message; rl_status_is_transient() maps to StorageErr.transient
+ * (storage/mod.rs:312-339).
+ */
+#ifndef RL_ENGINE_H
+#define RL_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rl_engine rl_engine;
+
+typedef enum {
+    RL_OK = 0,
+    RL_ERR_INVALID = -1,        /* bad argument (null pointer, size, unknown limit id, reserved key) */
+    RL_ERR_DEVICE = -2,         /* HIP runtime error (transient) */
+    RL_ERR_NO_DEVICE = -3,      /* no gfx950 device / HIP unavailable: the engine never falls back to CPU */
+    RL_ERR_TABLE_FULL = -4,     /* live cells would exceed the table's load bound; grow or sweep */
+    RL_ERR_MISSING_SIMPLE = -5, /* a simple counter has no pre-created cell: the reference panics
+                                   here (in_memory.rs:107 `.unwrap()`) */
+    RL_ERR_KEY_LIMIT = -6,      /* a hit's limit id differs from the one stored with its key */
+    RL_ERR_BATCH_TOO_LARGE = -7,
+    RL_ERR_NOMEM = -8
+} rl_status;
+
+/* bit 31 of a limit id marks a counter of a limit WITHOUT variables ("simple", the
+ * `simple_limits` BTreeMap of in_memory.rs:14); without it the counter is "qualified"
+ * (the moka cache of in_memory.rs:15). */
+#define RL_SIMPLE 0x80000000u
+#define RL_LIMIT_ID(x) ((x) & 0x7FFFFFFFu)
+
+typedef struct {
+    int32_t device;          /* HIP device ordinal */
+    uint32_t max_batch_hits; /* largest n_hits one call may carry */
+    uint64_t capacity_cells; /* table slots; rounded up to a power of two.  Live cells are bounded
+                                by capacity/2 (RL_ERR_TABLE_FULL beyond).  Replaces moka's
+                                `cache_size` (in_memory.rs:205-212) but never evicts silently. */
+    uint32_t max_limits;     /* rows of the limit table */
+    uint32_t reserved;
+    uint64_t hash_seed;
+} rl_config;
+
+/* One row per interned Limit: the request-side attributes the reference reads from
+ * `Counter.limit` (counter.rs:64-66,76-78).  max_value is NOT stored with a cell
+ * (limit.rs:207-214: not part of identity), so updating a row is what
+ * Storage::update_limit (storage/mod.rs:67-83) does. */
+typedef struct {
+    uint64_t max_value;
+    uint64_t seconds;
+} rl_limit_row;
+
+/* One (request x counter) record: 16 bytes, the unit the hot kernels stream. */
+typedef struct {
+    uint64_t key;   /* exact counter identity */
+    uint32_t limit; /* limit id | RL_SIMPLE */
+    uint32_t delta; /* hits to add; one delta per request in the reference (in_memory.rs:75):
+                       for a multi-counter request every hit carries the request's delta */
+} rl_hit;
+
+/* A stored cell as reported by rl_get_counters / rl_dump_cells. */
+typedef struct {
+    uint64_t key;
+    uint32_t limit; /* limit id | RL_SIMPLE */
+    uint32_t reserved;
+    uint64_t value;     /* rl_get_counters: value_at(now); rl_dump_cells: raw value */
+    uint64_t expiry_us; /* rl_get_counters: ttl(now) in us (>0); rl_dump_cells: raw expiry */
+} rl_cell_row;
+
+typedef struct {
+    uint64_t capacity_cells;
+    uint64_t live_cells;
+    uint64_t tombstones;
+    uint64_t batches;
+    uint64_t hits;
+    uint64_t ordered_hits;     /* hits that needed trace-order resolution */
+    uint64_t ordered_batches;  /* batches that ran the ordered resolver */
+    uint64_t probe_steps;      /* reserved (0 unless built with RL_PROBE_STATS) */
+    uint64_t rebuilds;
+} rl_stats_t;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+/* InMemoryStorage::new (in_memory.rs:205-212). */
+int32_t rl_engine_create(const rl_config *cfg, rl_engine **out);
+void rl_engine_destroy(rl_engine *e);
+const char *rl_last_error(const rl_engine *e);
+int32_t rl_status_is_transient(int32_t status);
+int32_t rl_stats(rl_engine *e, rl_stats_t *out);
+
+/* ---- limits --------------------------------------------------------------------------- */
+/* Upload rows [first, first+n) of the limit table (max_value / seconds of interned limits). */
+int32_t rl_limits_set(rl_engine *e, uint32_t first, const rl_limit_row *rows, uint32_t n);
+/* CounterStorage::add_counter (in_memory.rs:38-44): for a limit WITHOUT variables pre-create
+ * its cell as (0, UNIX_EPOCH) unless it exists; a no-op for limits with variables.
+ * `limit` carries RL_SIMPLE when the limit has no variables; `key` is that counter's key. */
+int32_t rl_add_counter(rl_engine *e, uint32_t limit, uint64_t key);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* CounterStorage::check_and_update (in_memory.rs:72-156) for a batch of requests.
+ *   hits[n_hits]        request x counter records, requests contiguous, trace order.
+ *   req_off[n_req+1]    CSR offsets of requests into hits; NULL => every hit is its own
+ *                       request (n_req must equal n_hits).  Within a request, hits must be in
+ *                       the reference's processing order: simple counters first, then
+ *                       qualified, each in Vec order (in_memory.rs:105,121).
+ *   now_us              the clock value of this batch (us since the epoch).
+ *   load_counters       as the reference flag: fill remaining/expires_in for every hit and
+ *                       defer the early return (in_memory.rs:87-95,110-116,130-136).
+ *   verdict[n_req]      0 = Authorization::Ok, 1 = Authorization::Limited.
+ *   first_limited[n_req] (may be NULL) index into hits of the counter whose limit name the
+ *                       reference reports, -1 when Ok.
+ *   remaining[n_hits], expires_in_us[n_hits] (may be NULL unless load_counters): the values
+ *                       set_remaining / set_expires_in receive (counter.rs:96-106).
+ * Host pointers; the call copies in, runs the kernels, copies out and returns when done. */
+int32_t rl_check_and_update_batch(rl_engine *e, const rl_hit *hits, uint32_t n_hits,
+                                  const uint32_t *req_off, uint32_t n_req, uint64_t now_us,
+                                  int32_t load_counters, uint8_t *verdict, int32_t *first_limited,
+                                  uint64_t *remaining, uint64_t *expires_in_us);
+/* Same, every pointer a DEVICE pointer on the engine's device (the rate quoted by bench.py).
+ * Work is enqueued on the engine's stream and the call returns after the batch has completed
+ * (it must read the batch status word to decide whether the ordered resolver is needed). */
+int32_t rl_check_and_update_batch_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits,
+                                         const uint32_t *d_req_off, uint32_t n_req,
+                                         uint64_t now_us, int32_t load_counters,
+                                         uint8_t *d_verdict, int32_t *d_first_limited,
+                                         uint64_t *d_remaining, uint64_t *d_expires_in_us);
+
+/* CounterStorage::is_within_limits (in_memory.rs:20-35), one verdict per hit, read-only:
+ * within[i] = max_value >= value_at(now) + delta; a missing cell reads as 0. */
+int32_t rl_is_within_limits_batch(rl_engine *e, const rl_hit *hits, uint32_t n_hits,
+                                  uint64_t now_us, uint8_t *within);
+/* CounterStorage::update_counter (in_memory.rs:47-69) applied to hits[0..n) in order:
+ * find-or-create then AtomicExpiringValue::update; never checks the limit. */
+int32_t rl_update_counter_batch(rl_engine *e, const rl_hit *hits, uint32_t n_hits,
+                                uint64_t now_us);
+
+/* ---- the rest of the CounterStorage surface -------------------------------------------- */
+/* CounterStorage::get_counters (in_memory.rs:159-187) for one limit: every cell of that limit
+ * with ttl(now) > 0.  Writes up to cap rows; *n_out = total matching rows. */
+int32_t rl_get_counters(rl_engine *e, uint32_t limit, uint64_t now_us, rl_cell_row *out,
+                        uint64_t cap, uint64_t *n_out);
+/* CounterStorage::delete_counters for one limit (in_memory.rs:190-195,241-257). */
+int32_t rl_delete_counters(rl_engine *e, uint32_t limit);
+/* CounterStorage::clear (in_memory.rs:198-201): removes ONLY simple cells — the reference
+ * leaves the qualified cache untouched, and so does this. */
+int32_t rl_clear(rl_engine *e);
+
+/* ---- no reference analogue ------------------------------------------------------------- */
+/* TTL sweep: drop every QUALIFIED cell with expiry <= now (an explicit eviction event; it
+ * replaces moka's capacity eviction and is replayed into the oracle by the tests), then
+ * compact the table if tombstones exceed 1/8 of capacity. */
+int32_t rl_sweep_expired(rl_engine *e, uint64_t now_us, uint64_t *n_removed);
+/* Force a compaction (rehash of live cells into a fresh table). */
+int32_t rl_compact(rl_engine *e);
+/* Snapshot: bulk insert / overwrite cells, and dump every live cell (raw value/expiry). */
+int32_t rl_load_cells(rl_engine *e, const rl_cell_row *rows, uint64_t n);
+int32_t rl_load_cells_device(rl_engine *e, const rl_cell_row *d_rows, uint64_t n);
+int32_t rl_dump_cells(rl_engine *e, rl_cell_row *out, uint64_t cap, uint64_t *n_out);
+
+/* ---- multi-GPU routing helpers (device pointers, engine's stream) ----------------------- */
+/* Owner shard of a key for a world of `world` shards (any world >= 1). */
+uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world);
+/* Stable partition of d_hits by owner shard: d_out holds the hits grouped by owner
+ * (owner 0 first), each group in original order; d_perm[j] = original index of d_out[j];
+ * d_counts[world] = group sizes.  Blocks until done. */
+int32_t rl_route_partition_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits,
+                                  uint32_t world, rl_hit *d_out, uint32_t *d_perm,
+                                  uint32_t *d_counts);
+/* d_dst[d_perm[j]] = d_src[j] for j < n (returns verdict bytes to ingress order). */
+int32_t rl_unpermute_u8_device(rl_engine *e, const uint8_t *d_src, const uint32_t *d_perm,
+                               uint32_t n, uint8_t *d_dst);
+
+/* The HIP stream (hipStream_t) the engine launches on, for callers that order their own work
+ * against it, and a per-kernel timing hook used by bench.py (HIP events on that stream). */
+void *rl_engine_stream(rl_engine *e);
+/* Enable (1) / disable (0) HIP-event timing of the dominant kernel; read accumulated
+ * milliseconds and launch count since the last reset. */
+int32_t rl_kernel_timing(rl_engine *e, int32_t enable);
+int32_t rl_kernel_timing_read(rl_engine *e, double *ms_probe, double *ms_decide, double *ms_commit,
+                              double *ms_ordered, uint64_t *launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RL_ENGINE_H */

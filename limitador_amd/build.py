@@ -1,0 +1,83 @@
+"""In-tree build of the HIP engine (and, for the tests, of the CPU oracle).
+
+``hipcc`` cross-compiles gfx950 without a GPU.  Outputs stay in-tree (``limitador_amd/lib``,
+``oracle/``) so they travel with the repo snapshot to the GPU box; they are git-ignored.
+"""
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "limitador_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "limitador_amd", "lib")
+ENGINE_SO = os.path.join(LIBDIR, "librl_engine.so")
+STORAGE_SO = os.path.join(LIBDIR, "librl_storage.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liblimitador_oracle.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _sources(dirpath, exts):
+    out = []
+    for base, _dirs, files in os.walk(dirpath):
+        for f in files:
+            if f.endswith(exts):
+                out.append(os.path.join(base, f))
+    return out
+
+
+def build_engine(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> limitador_amd/lib/librl_engine.so"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = _sources(CSRC, (".hip", ".hpp")) + [os.path.join(ROOT, "include", "rl_engine.h")]
+    if not force and _newer(ENGINE_SO, srcs):
+        return ENGINE_SO
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "rl_engine.hip"), "-o", ENGINE_SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return ENGINE_SO
+
+
+def build_storage(force=False, verbose=False):
+    """g++ -> limitador_amd/lib/librl_storage.so (C++ host mirror of CounterStorage)."""
+    src = os.path.join(CSRC, "host", "gpu_counter_storage.cpp")
+    if not os.path.exists(src):
+        return None
+    srcs = _sources(os.path.join(CSRC, "host"), (".cpp", ".hpp", ".h")) + [os.path.join(ROOT, "include", "rl_engine.h"),
+                                                                             os.path.join(ROOT, "include", "rl_storage.h")]
+    if not force and _newer(STORAGE_SO, srcs):
+        return STORAGE_SO
+    build_engine(force=False, verbose=verbose)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"), src,
+           "-o", STORAGE_SO, "-L" + LIBDIR, "-lrl_engine", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return STORAGE_SO
+
+
+def build_oracle(force=False, verbose=False):
+    """gcc -> oracle/liblimitador_oracle.so (test infrastructure, never used by the product)."""
+    srcs = [os.path.join(ORACLE_DIR, "limitador_oracle.c"), os.path.join(ORACLE_DIR, "limitador_oracle.h")]
+    if not force and _newer(ORACLE_SO, srcs):
+        return ORACLE_SO
+    cmd = ["make", "-C", ORACLE_DIR] + (["-B"] if force else [])
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+if __name__ == "__main__":
+    print(build_engine(verbose=True))
+    print(build_storage(verbose=True))
+    print(build_oracle(verbose=True))

@@ -1,0 +1,634 @@
+// rl_engine.hip — C ABI (include/rl_engine.h) over the gfx950 kernels.
+//
+// The engine owns: the counter table in HBM (64-byte cells), the device limit table, the
+// per-batch scratch (hit -> slot map, ordered list, sort buffers, verdict staging) and one HIP
+// stream.  There is no CPU implementation of any entry point: without a HIP device
+// rl_engine_create fails with RL_ERR_NO_DEVICE.
+#include "../../include/rl_engine.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rl_cell.hpp"
+#include "rl_kernels.hpp"
+#include "rl_ordered.hpp"
+#include "rl_route.hpp"
+
+using namespace rl;
+
+static_assert(sizeof(rl_hit) == sizeof(Hit), "rl_hit layout");
+static_assert(sizeof(rl_cell_row) == sizeof(CellRow), "rl_cell_row layout");
+
+struct rl_engine {
+    std::mutex mu;
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    u64 seed = 0;
+
+    Cell* table = nullptr;
+    u64 cap = 0;
+    u32 log2cap = 0;
+    u64 live = 0;
+    u64 tombs = 0;
+
+    LimitDev* d_limits = nullptr;
+    std::vector<LimitDev> h_limits;
+    u32 max_limits = 0;
+    bool any_zero_window = false;
+
+    u32 max_batch = 0;
+    Hit* d_hits = nullptr;        // staging for host-pointer calls
+    u32* d_req_off = nullptr;     // staging
+    uint8_t* d_verdict = nullptr; // staging
+    int32_t* d_first = nullptr;   // staging
+    u64* d_remaining = nullptr;   // staging
+    u64* d_expires = nullptr;     // staging
+    u32* d_hit_slot = nullptr;
+    u32* d_ord_list = nullptr;
+    u64* d_keys_a = nullptr;
+    u64* d_keys_b = nullptr;
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    Status* d_status = nullptr;
+    Status* h_status = nullptr; // pinned
+    unsigned long long* d_total = nullptr;
+    unsigned long long* h_total = nullptr; // pinned
+    // routing scratch
+    u32* d_route_cnt = nullptr;
+
+    rl_stats_t stats{};
+
+    bool timing = false;
+    hipEvent_t ev[8]{};
+    double ms_probe = 0, ms_decide = 0, ms_commit = 0, ms_ordered = 0;
+    u64 timed_launches = 0;
+};
+
+namespace {
+
+int fail(rl_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                  \
+    do {                                                                                  \
+        hipError_t _r = (call);                                                           \
+        if (_r != hipSuccess)                                                             \
+            return fail((e), RL_ERR_DEVICE, "%s failed: %s (%s:%d)", #call,               \
+                        hipGetErrorString(_r), __FILE__, __LINE__);                       \
+    } while (0)
+
+inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+u32 ceil_log2(u64 x) {
+    u32 l = 0;
+    while ((1ull << l) < x) ++l;
+    return l;
+}
+
+int status_to_error(rl_engine* e, u32 bits) {
+    if (bits & ERRBIT_BAD_LIMIT) return fail(e, RL_ERR_INVALID, "hit references a limit id outside the limit table");
+    if (bits & ERRBIT_RESERVED_KEY) return fail(e, RL_ERR_INVALID, "key 0xFFFFFFFFFFFFFFFE/F is reserved");
+    if (bits & ERRBIT_MISSING_SIMPLE)
+        return fail(e, RL_ERR_MISSING_SIMPLE,
+                    "simple counter without a pre-created cell (reference: in_memory.rs:107 unwrap panics)");
+    if (bits & ERRBIT_TABLE_FULL) return fail(e, RL_ERR_TABLE_FULL, "counter table is full");
+    if (bits & ERRBIT_KEY_LIMIT) return fail(e, RL_ERR_KEY_LIMIT, "a key was used with two different limit ids");
+    return fail(e, RL_ERR_DEVICE, "unknown device status 0x%x", bits);
+}
+
+int read_status(rl_engine* e) {
+    HIP_TRY(e, hipMemcpyAsync(e->h_status, e->d_status, sizeof(Status), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
+}
+
+int alloc_table(rl_engine* e, u64 cap, Cell** out) {
+    Cell* t = nullptr;
+    hipError_t r = hipMalloc((void**)&t, cap * sizeof(Cell));
+    if (r != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc of %llu-cell table failed: %s",
+                                     (unsigned long long)cap, hipGetErrorString(r));
+    k_table_init<<<2048, 256, 0, e->stream>>>(t, cap);
+    HIP_TRY(e, hipGetLastError());
+    *out = t;
+    return RL_OK;
+}
+
+int check_room(rl_engine* e, u64 incoming) {
+    // Linear probing stays short while (live + tombstones) <= 3/4 capacity; refuse beyond.
+    if (e->live + e->tombs + incoming > e->cap - e->cap / 4)
+        return fail(e, RL_ERR_TABLE_FULL,
+                    "table would exceed 75%% occupancy (live=%llu tombstones=%llu incoming<=%llu capacity=%llu)",
+                    (unsigned long long)e->live, (unsigned long long)e->tombs,
+                    (unsigned long long)incoming, (unsigned long long)e->cap);
+    return RL_OK;
+}
+
+int do_compact(rl_engine* e) {
+    Cell* fresh = nullptr;
+    int rc = alloc_table(e, e->cap, &fresh);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+    k_rehash<<<2048, 256, 0, e->stream>>>(e->table, e->cap, fresh, e->log2cap, e->seed, e->d_status);
+    HIP_TRY(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipFree(e->table));
+    e->table = fresh;
+    e->live = e->h_status->n_inserted;
+    e->tombs = 0;
+    e->stats.rebuilds++;
+    return RL_OK;
+}
+
+// The ordered resolver (rl_ordered.hpp).  n_ord is known on the host.
+int run_ordered(rl_engine* e, const Hit* d_hits, u32 n_ord, u64 now, uint8_t* d_verdict,
+                int32_t* d_first) {
+    const u32 g = cdiv(n_ord, 256);
+    k_ord_keys<<<g, 256, 0, e->stream>>>(e->d_ord_list, n_ord, e->d_hit_slot, e->d_keys_a);
+    size_t tmp = e->sort_tmp_bytes;
+    // Sort by (slot, idx): idx occupies the low 32 bits, slot the next log2cap bits.
+    HIP_TRY(e, rocprim::radix_sort_keys(e->d_sort_tmp, tmp, e->d_keys_a, e->d_keys_b, (size_t)n_ord, 0u,
+                                        32u + e->log2cap, e->stream));
+    k_ord_heads<<<g, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_ord);
+    k_ord_uniform<<<g, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_ord, d_hits, now);
+    k_ord_resolve<<<g, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_ord, d_hits, e->d_limits, now,
+                                            d_verdict, d_first);
+    HIP_TRY(e, hipGetLastError());
+    e->stats.ordered_hits += n_ord;
+    e->stats.ordered_batches++;
+    return RL_OK;
+}
+
+// check_and_update for single-counter requests, all pointers on the device.
+int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
+    int rc = check_room(e, n);
+    if (rc) return rc;
+    const bool t = e->timing;
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+    k_probe<PM_CHECK><<<cdiv(n, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+        e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(), now, e->d_hit_slot,
+        e->d_status);
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
+    k_decide<<<cdiv(n, DECIDE_BLOCK), DECIDE_BLOCK, 0, e->stream>>>(
+        e->table, d_hits, n, e->d_limits, now, e->d_hit_slot, d_verdict, d_first, e->d_ord_list, e->d_status);
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
+    HIP_TRY(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    e->live += e->h_status->n_inserted;
+    if (e->h_status->err) {
+        k_abort<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, n, e->d_hit_slot);
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return status_to_error(e, e->h_status->err);
+    }
+    const u32 n_ord = e->h_status->n_ord;
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream));
+    if (n_ord) {
+        rc = run_ordered(e, d_hits, n_ord, now, d_verdict, d_first);
+        if (rc) return rc;
+    }
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream));
+    k_commit<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, d_hits, n, e->d_limits, now, e->d_hit_slot);
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[5], e->stream));
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (t) {
+        float a = 0, b = 0, c = 0, d = 0;
+        HIP_TRY(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
+        HIP_TRY(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+        HIP_TRY(e, hipEventElapsedTime(&c, e->ev[3], e->ev[4]));
+        HIP_TRY(e, hipEventElapsedTime(&d, e->ev[4], e->ev[5]));
+        e->ms_probe += a;
+        e->ms_decide += b;
+        e->ms_ordered += c;
+        e->ms_commit += d;
+        e->timed_launches++;
+    }
+    e->stats.batches++;
+    e->stats.hits += n;
+    return RL_OK;
+}
+
+int validate_batch(rl_engine* e, const void* hits, u32 n_hits, const u32* req_off, u32 n_req,
+                   const void* verdict) {
+    if (!e) return RL_ERR_INVALID;
+    if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u > max_batch_hits %u", n_hits, e->max_batch);
+    if (n_hits && !hits) return fail(e, RL_ERR_INVALID, "hits is null");
+    if (n_req && !verdict) return fail(e, RL_ERR_INVALID, "verdict is null");
+    if (!req_off && n_req != n_hits) return fail(e, RL_ERR_INVALID, "req_off is null but n_req != n_hits");
+    return RL_OK;
+}
+
+}  // namespace
+
+static int32_t insert_rows_locked(rl_engine* e, const CellRow* d_rows, u64 n, int overwrite) {
+    int rc = check_room(e, n);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+    k_insert_rows<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_rows, n, overwrite,
+                                                       e->d_status);
+    HIP_TRY(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    e->live += e->h_status->n_inserted;
+    if (e->h_status->err) return status_to_error(e, e->h_status->err);
+    return RL_OK;
+}
+
+template <int MODE>
+static int32_t scan_locked(rl_engine* e, u32 limit, u64 now, rl_cell_row* out, u64 cap, uint64_t* n_out) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    CellRow* d_out = nullptr;
+    if (cap) {
+        hipError_t r = hipMalloc((void**)&d_out, cap * sizeof(CellRow));
+        if (r != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc for scan output failed");
+    }
+    auto cleanup = [&]() {
+        if (d_out) (void)hipFree(d_out);
+    };
+    hipError_t r = hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(e->d_total, 0, sizeof(unsigned long long), e->stream);
+    if (r == hipSuccess) {
+        k_scan<MODE><<<2048, 256, 0, e->stream>>>(e->table, e->cap, limit, now, d_out, cap, e->d_status, e->d_total);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess)
+        r = hipMemcpyAsync(e->h_total, e->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess)
+        r = hipMemcpyAsync(e->h_status, e->d_status, sizeof(Status), hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    if (r == hipSuccess && out && cap) {
+        const u64 n = *e->h_total < cap ? *e->h_total : cap;
+        if (n) r = hipMemcpy(out, d_out, n * sizeof(CellRow), hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (r != hipSuccess) return fail(e, RL_ERR_DEVICE, "table scan failed: %s", hipGetErrorString(r));
+    if (n_out) *n_out = *e->h_total;
+    const u32 removed = e->h_status->n_removed;
+    e->live -= removed;
+    e->tombs += removed;
+    return RL_OK;
+}
+
+extern "C" {
+
+int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
+    if (!cfg || !out) return RL_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return RL_ERR_NO_DEVICE;
+    rl_engine* e = new (std::nothrow) rl_engine();
+    if (!e) return RL_ERR_NOMEM;
+    e->device = cfg->device;
+    e->seed = cfg->hash_seed;
+    e->max_batch = cfg->max_batch_hits ? cfg->max_batch_hits : (1u << 20);
+    e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
+    e->log2cap = ceil_log2(cfg->capacity_cells < 1024 ? 1024 : cfg->capacity_cells);
+    if (e->log2cap > 31) {
+        delete e;
+        return RL_ERR_INVALID;
+    }
+    e->cap = 1ull << e->log2cap;
+    auto bail = [&](int rc) {
+        rl_engine_destroy(e);
+        return rc;
+    };
+    if (hipSetDevice(e->device) != hipSuccess) return bail(RL_ERR_NO_DEVICE);
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
+    int rc = alloc_table(e, e->cap, &e->table);
+    if (rc) return bail(rc);
+    const size_t mb = e->max_batch;
+#define ALLOC(ptr, bytes)                                                    \
+    if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) return bail(RL_ERR_NOMEM)
+    ALLOC(e->d_limits, e->max_limits * sizeof(LimitDev));
+    ALLOC(e->d_hits, mb * sizeof(Hit));
+    ALLOC(e->d_req_off, (mb + 1) * sizeof(u32));
+    ALLOC(e->d_verdict, mb);
+    ALLOC(e->d_first, mb * sizeof(int32_t));
+    ALLOC(e->d_remaining, mb * sizeof(u64));
+    ALLOC(e->d_expires, mb * sizeof(u64));
+    ALLOC(e->d_hit_slot, mb * sizeof(u32));
+    ALLOC(e->d_ord_list, mb * sizeof(u32));
+    ALLOC(e->d_keys_a, mb * sizeof(u64));
+    ALLOC(e->d_keys_b, mb * sizeof(u64));
+    ALLOC(e->d_status, sizeof(Status));
+    ALLOC(e->d_total, sizeof(unsigned long long));
+    ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
+    size_t tmp = 0;
+    if (rocprim::radix_sort_keys(nullptr, tmp, e->d_keys_a, e->d_keys_b, mb, 0u, 64u, e->stream) != hipSuccess)
+        return bail(RL_ERR_DEVICE);
+    e->sort_tmp_bytes = tmp ? tmp : 16;
+    ALLOC(e->d_sort_tmp, e->sort_tmp_bytes);
+#undef ALLOC
+    if (hipHostMalloc((void**)&e->h_status, sizeof(Status)) != hipSuccess) return bail(RL_ERR_NOMEM);
+    if (hipHostMalloc((void**)&e->h_total, sizeof(unsigned long long)) != hipSuccess) return bail(RL_ERR_NOMEM);
+    for (auto& ev : e->ev)
+        if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(RL_ERR_DEVICE);
+    e->stats.capacity_cells = e->cap;
+    *out = e;
+    return RL_OK;
+}
+
+void rl_engine_destroy(rl_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
+                    e->d_remaining, e->d_expires, e->d_hit_slot, e->d_ord_list, e->d_keys_a,  e->d_keys_b,
+                    e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->h_status) (void)hipHostFree(e->h_status);
+    if (e->h_total) (void)hipHostFree(e->h_total);
+    for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* rl_last_error(const rl_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int32_t rl_status_is_transient(int32_t status) { return status == RL_ERR_DEVICE ? 1 : 0; }
+
+int32_t rl_stats(rl_engine* e, rl_stats_t* out) {
+    if (!e || !out) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->stats.capacity_cells = e->cap;
+    e->stats.live_cells = e->live;
+    e->stats.tombstones = e->tombs;
+    *out = e->stats;
+    return RL_OK;
+}
+
+void* rl_engine_stream(rl_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n && !rows) return fail(e, RL_ERR_INVALID, "rows is null");
+    if ((u64)first + n > e->max_limits) return fail(e, RL_ERR_INVALID, "limit rows [%u,%u) exceed max_limits %u", first, first + n, e->max_limits);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (e->h_limits.size() < (size_t)first + n) e->h_limits.resize((size_t)first + n, LimitDev{0, 0});
+    for (u32 i = 0; i < n; ++i) {
+        e->h_limits[first + i].max_value = rows[i].max_value;
+        e->h_limits[first + i].window_us = rows[i].seconds * 1000000ull;
+    }
+    e->any_zero_window = false;
+    for (auto& l : e->h_limits) e->any_zero_window |= (l.window_us == 0);
+    if (!e->h_limits.empty()) {
+        HIP_TRY(e, hipMemcpyAsync(e->d_limits, e->h_limits.data(), e->h_limits.size() * sizeof(LimitDev),
+                                  hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    return RL_OK;
+}
+
+int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!(limit & RL_SIMPLE)) return RL_OK;  // in_memory.rs:39: only limits without variables
+    if (RL_LIMIT_ID(limit) >= e->h_limits.size()) return fail(e, RL_ERR_INVALID, "unknown limit id %u", RL_LIMIT_ID(limit));
+    HIP_TRY(e, hipSetDevice(e->device));
+    CellRow row{key, limit, 0, 0, 0};  // Default: (0, UNIX_EPOCH)
+    CellRow* d_row = reinterpret_cast<CellRow*>(e->d_keys_a);
+    HIP_TRY(e, hipMemcpyAsync(d_row, &row, sizeof(row), hipMemcpyHostToDevice, e->stream));
+    return insert_rows_locked(e, d_row, 1, 0);
+}
+
+int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits,
+                                         const uint32_t* d_req_off, uint32_t n_req, uint64_t now_us,
+                                         int32_t load_counters, uint8_t* d_verdict,
+                                         int32_t* d_first_limited, uint64_t* d_remaining,
+                                         uint64_t* d_expires_in_us) {
+    int rc = validate_batch(e, d_hits, n_hits, d_req_off, n_req, d_verdict);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n_hits == 0) return RL_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (d_req_off || load_counters) {
+        (void)d_remaining;
+        (void)d_expires_in_us;
+        return fail(e, RL_ERR_INVALID, "multi-counter requests / load_counters: not built yet in this round");
+    }
+    return run_check_k1(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
+}
+
+int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
+                                  uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t* verdict,
+                                  int32_t* first_limited, uint64_t* remaining, uint64_t* expires_in_us) {
+    int rc = validate_batch(e, hits, n_hits, req_off, n_req, verdict);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n_req == 0) return RL_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (req_off || load_counters) {
+        (void)remaining;
+        (void)expires_in_us;
+        return fail(e, RL_ERR_INVALID, "multi-counter requests / load_counters: not built yet in this round");
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
+    rc = run_check_k1(e, e->d_hits, n_hits, now_us, e->d_verdict, first_limited ? e->d_first : nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n_req, hipMemcpyDeviceToHost, e->stream));
+    if (first_limited)
+        HIP_TRY(e, hipMemcpyAsync(first_limited, e->d_first, (size_t)n_req * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                  e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
+}
+
+int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us,
+                                  uint8_t* within) {
+    int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, within);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n_hits == 0) return RL_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+    k_within<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_hits, n_hits,
+                                                        e->d_limits, (u32)e->h_limits.size(), now_us,
+                                                        e->d_verdict, e->d_status);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(within, e->d_verdict, n_hits, hipMemcpyDeviceToHost, e->stream));
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status->err) return status_to_error(e, e->h_status->err);
+    return RL_OK;
+}
+
+int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us) {
+    uint8_t dummy = 0;
+    int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, &dummy);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n_hits == 0) return RL_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    rc = check_room(e, n_hits);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+    k_probe<PM_UPDATE><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+        e->table, e->log2cap, e->seed, e->d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now_us,
+        e->d_hit_slot, e->d_status);
+    HIP_TRY(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    e->live += e->h_status->n_inserted;
+    if (e->h_status->err) {
+        k_abort<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, n_hits, e->d_hit_slot);
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return status_to_error(e, e->h_status->err);
+    }
+    if (e->any_zero_window)
+        k_update_aux<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, e->d_hits, n_hits, e->d_limits,
+                                                               e->d_hit_slot);
+    k_update_commit<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, n_hits, e->d_limits, now_us,
+                                                              e->d_hit_slot);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
+}
+
+int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_row* out, uint64_t cap,
+                        uint64_t* n_out) {
+    if (!e || (cap && !out)) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    return scan_locked<SCAN_GET>(e, limit, now_us, out, cap, n_out);
+}
+
+int32_t rl_dump_cells(rl_engine* e, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
+    if (!e || (cap && !out)) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    return scan_locked<SCAN_DUMP>(e, 0, 0, out, cap, n_out);
+}
+
+int32_t rl_delete_counters(rl_engine* e, uint32_t limit) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    return scan_locked<SCAN_DELETE_LIMIT>(e, limit, 0, nullptr, 0, nullptr);
+}
+
+int32_t rl_clear(rl_engine* e) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    return scan_locked<SCAN_CLEAR_SIMPLE>(e, 0, 0, nullptr, 0, nullptr);
+}
+
+int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    const u64 before = e->live;
+    int rc = scan_locked<SCAN_SWEEP>(e, 0, now_us, nullptr, 0, nullptr);
+    if (rc) return rc;
+    if (n_removed) *n_removed = before - e->live;
+    if (e->tombs > e->cap / 8) return do_compact(e);
+    return RL_OK;
+}
+
+int32_t rl_compact(rl_engine* e) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    return do_compact(e);
+}
+
+int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n) {
+    if (!e || (n && !d_rows)) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (n == 0) return RL_OK;
+    return insert_rows_locked(e, reinterpret_cast<const CellRow*>(d_rows), n, 1);
+}
+
+int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
+    if (!e || (n && !rows)) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (n == 0) return RL_OK;
+    CellRow* d_rows = nullptr;
+    if (hipMalloc((void**)&d_rows, n * sizeof(CellRow)) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc failed");
+    hipError_t r = hipMemcpy(d_rows, rows, n * sizeof(CellRow), hipMemcpyHostToDevice);
+    int rc = r == hipSuccess ? insert_rows_locked(e, d_rows, n, 1)
+                             : fail(e, RL_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(r));
+    (void)hipFree(d_rows);
+    return rc;
+}
+
+uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world) { return owner_of(key, hash_seed, world); }
+
+int32_t rl_route_partition_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint32_t world,
+                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
+    if (!e || !d_counts || (n_hits && (!d_hits || !d_out || !d_perm))) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (world == 0 || world > ROUTE_MAX_WORLD) return fail(e, RL_ERR_INVALID, "world %u not in [1,%d]", world, ROUTE_MAX_WORLD);
+    HIP_TRY(e, hipSetDevice(e->device));
+    const u32 nblk = n_hits ? cdiv(n_hits, ROUTE_TILE) : 0;
+    if (nblk > ROUTE_MAX_BLOCKS) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u too large for the router", n_hits);
+    if (nblk)
+        k_route_count<<<nblk, ROUTE_BLOCK, 0, e->stream>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed,
+                                                            world, e->d_route_cnt);
+    k_route_scan<<<1, 256, 0, e->stream>>>(e->d_route_cnt, nblk, world, d_counts);
+    if (nblk)
+        k_route_scatter<<<nblk, ROUTE_BLOCK, 0, e->stream>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed,
+                                                              world, e->d_route_cnt,
+                                                              reinterpret_cast<Hit*>(d_out), d_perm);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
+}
+
+int32_t rl_unpermute_u8_device(rl_engine* e, const uint8_t* d_src, const uint32_t* d_perm, uint32_t n,
+                               uint8_t* d_dst) {
+    if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (n) k_unpermute_u8<<<cdiv(n, 256), 256, 0, e->stream>>>(d_src, d_perm, n, d_dst);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
+}
+
+int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->timing = enable != 0;
+    return RL_OK;
+}
+
+int32_t rl_kernel_timing_read(rl_engine* e, double* ms_probe, double* ms_decide, double* ms_commit,
+                              double* ms_ordered, uint64_t* launches, int32_t reset) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (ms_probe) *ms_probe = e->ms_probe;
+    if (ms_decide) *ms_decide = e->ms_decide;
+    if (ms_commit) *ms_commit = e->ms_commit;
+    if (ms_ordered) *ms_ordered = e->ms_ordered;
+    if (launches) *launches = e->timed_launches;
+    if (reset) {
+        e->ms_probe = e->ms_decide = e->ms_commit = e->ms_ordered = 0;
+        e->timed_launches = 0;
+    }
+    return RL_OK;
+}
+
+}  // extern "C"

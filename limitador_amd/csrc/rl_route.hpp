@@ -1,0 +1,156 @@
+// rl_route.hpp — multi-GPU descriptor routing: stable partition of a batch by owner shard.
+//
+// Keys are hash-partitioned across the GPUs of a node (owner = owner_of(key)); each GPU owns a
+// private table for its share of the key space.  Before the all-to-all every ingress GPU groups
+// its hits by owner.  The partition is STABLE (original order inside each group), so that the
+// concatenation "from rank 0 | from rank 1 | ..." an owner receives is exactly the global trace
+// order restricted to its keys — the order the sequential reference semantics are defined on —
+// without shipping per-hit sequence numbers.
+//
+// Three small kernels (count per tile, scan of the tile x owner table, scatter).
+#pragma once
+#include "rl_kernels.hpp"
+
+namespace rl {
+
+constexpr int ROUTE_BLOCK = 256;
+constexpr int ROUTE_ROUNDS = 8;                         // 64-hit rounds per wave
+constexpr int ROUTE_WAVE_TILE = 64 * ROUTE_ROUNDS;      // contiguous hits owned by one wave
+constexpr int ROUTE_TILE = 4 * ROUTE_WAVE_TILE;         // hits per workgroup
+constexpr int ROUTE_MAX_WORLD = 16;
+constexpr int ROUTE_MAX_BLOCKS = 8192;
+
+// cnt layout: [owner][block], owner-major, so one linear exclusive scan yields final offsets.
+__global__ __launch_bounds__(ROUTE_BLOCK) void k_route_count(const Hit* __restrict__ hits, u32 n,
+                                                              u64 seed, u32 world,
+                                                              u32* __restrict__ cnt) {
+    __shared__ u32 s_cnt[ROUTE_MAX_WORLD];
+    const u32 tid = threadIdx.x;
+    if (tid < ROUTE_MAX_WORLD) s_cnt[tid] = 0;
+    __syncthreads();
+    const u32 base = blockIdx.x * ROUTE_TILE;
+    for (int r = 0; r < ROUTE_TILE / ROUTE_BLOCK; ++r) {
+        const u32 i = base + r * ROUTE_BLOCK + tid;
+        if (i < n) atomicAdd(&s_cnt[owner_of(hits[i].key, seed, world)], 1u);
+    }
+    __syncthreads();
+    if (tid < world) cnt[tid * gridDim.x + blockIdx.x] = s_cnt[tid];
+}
+
+// Single workgroup: exclusive scan of cnt[world * nblk] in place; counts[o] = group sizes.
+__global__ __launch_bounds__(256) void k_route_scan(u32* __restrict__ cnt, u32 nblk, u32 world,
+                                                    u32* __restrict__ counts) {
+    __shared__ u32 s_part[256];
+    __shared__ u32 s_owner_tot[ROUTE_MAX_WORLD];
+    const u32 tid = threadIdx.x;
+    const u32 total = nblk * world;
+    if (tid < ROUTE_MAX_WORLD) s_owner_tot[tid] = 0;
+    __syncthreads();
+    // each thread owns a contiguous chunk
+    const u32 chunk = (total + 255) / 256;
+    const u32 lo = tid * chunk;
+    const u32 hi = lo + chunk < total ? lo + chunk : total;
+    u32 sum = 0;
+    for (u32 q = lo; q < hi; ++q) {
+        const u32 v = cnt[q];
+        sum += v;
+        atomicAdd(&s_owner_tot[q / nblk], v);
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const u32 v = s_part[t];
+            s_part[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    u32 run = s_part[tid];
+    for (u32 q = lo; q < hi; ++q) {
+        const u32 v = cnt[q];
+        cnt[q] = run;
+        run += v;
+    }
+    if (tid < world) counts[tid] = s_owner_tot[tid];
+}
+
+__global__ __launch_bounds__(ROUTE_BLOCK) void k_route_scatter(const Hit* __restrict__ hits, u32 n,
+                                                                u64 seed, u32 world,
+                                                                const u32* __restrict__ offs,
+                                                                Hit* __restrict__ out,
+                                                                u32* __restrict__ perm) {
+    __shared__ u32 s_wcnt[4][ROUTE_MAX_WORLD];  // per wave, per owner: count, then running offset
+    const u32 tid = threadIdx.x;
+    const u32 wave = tid >> 6;
+    const u32 lane = tid & 63;
+    if (tid < 4 * ROUTE_MAX_WORLD) (&s_wcnt[0][0])[tid] = 0;
+    __syncthreads();
+    const u32 wbase = blockIdx.x * ROUTE_TILE + wave * ROUTE_WAVE_TILE;
+    Hit h[ROUTE_ROUNDS];
+    u32 own[ROUTE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUTE_ROUNDS; ++r) {
+        const u32 i = wbase + r * 64 + lane;
+        own[r] = 0xFFFFFFFFu;
+        if (i < n) {
+            h[r] = load_hit(hits, i);
+            own[r] = owner_of(h[r].key, seed, world);
+        }
+    }
+    // pass 1: per-wave counts (ballots are wave-uniform: lane 0 publishes)
+    for (u32 o = 0; o < world; ++o) {
+        u32 c = 0;
+#pragma unroll
+        for (int r = 0; r < ROUTE_ROUNDS; ++r) c += (u32)__popcll(__ballot(own[r] == o));
+        if (lane == 0) s_wcnt[wave][o] = c;
+    }
+    __syncthreads();
+    // wave offsets: block base for the owner + counts of earlier waves
+    if (tid < world) {
+        u32 run = offs[tid * gridDim.x + blockIdx.x];
+        for (int w = 0; w < 4; ++w) {
+            const u32 c = s_wcnt[w][tid];
+            s_wcnt[w][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // pass 2: stable scatter.  For each owner the running offset lives in a (wave-uniform)
+    // register, rounds are visited in order, so positions inside a group keep the input order.
+    u32 dest[ROUTE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUTE_ROUNDS; ++r) dest[r] = 0;
+    for (u32 o = 0; o < world; ++o) {
+        u32 run = s_wcnt[wave][o];
+#pragma unroll
+        for (int r = 0; r < ROUTE_ROUNDS; ++r) {
+            const u64 b = __ballot(own[r] == o);
+            if (own[r] == o) dest[r] = run + (u32)__popcll(b & ((1ull << lane) - 1ull));
+            run += (u32)__popcll(b);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUTE_ROUNDS; ++r) {
+        if (own[r] != 0xFFFFFFFFu) {
+            const u32 i = wbase + r * 64 + lane;
+            uint4 v;
+            v.x = (u32)h[r].key;
+            v.y = (u32)(h[r].key >> 32);
+            v.z = h[r].limit;
+            v.w = h[r].delta;
+            *reinterpret_cast<uint4*>(out + dest[r]) = v;
+            perm[dest[r]] = i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpermute_u8(const uint8_t* __restrict__ src,
+                                                      const u32* __restrict__ perm, u32 n,
+                                                      uint8_t* __restrict__ dst) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) dst[perm[j]] = src[j];
+}
+
+}  // namespace rl

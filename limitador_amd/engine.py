@@ -1,0 +1,192 @@
+"""Python face of the C ABI in include/rl_engine.h (ctypes; numpy arrays as host buffers).
+
+Every method maps 1:1 onto an ``rl_*`` entry point; the reference method each one stands for is
+cited in the header.  Nothing here computes a verdict: all decisions come from the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .wire import CELL_ROW_DTYPE, HIT_DTYPE, LIMIT_ROW_DTYPE
+
+RL_OK = 0
+ERR_NAMES = {
+    -1: "RL_ERR_INVALID", -2: "RL_ERR_DEVICE", -3: "RL_ERR_NO_DEVICE", -4: "RL_ERR_TABLE_FULL",
+    -5: "RL_ERR_MISSING_SIMPLE", -6: "RL_ERR_KEY_LIMIT", -7: "RL_ERR_BATCH_TOO_LARGE", -8: "RL_ERR_NOMEM",
+}
+
+
+class EngineError(RuntimeError):
+    """Mirror of StorageErr (limitador/src/storage/mod.rs:312-339): msg + transient flag."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+        self.msg = msg
+        self.transient = bool(_lib.load().rl_status_is_transient(code))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One counter table on one MI355X (InMemoryStorage::new, in_memory.rs:205-212)."""
+
+    def __init__(self, capacity_cells, max_batch_hits=1 << 20, max_limits=1024, device=0,
+                 hash_seed=0x9E3779B97F4A7C15):
+        self._lib = _lib.load()
+        cfg = _lib.RlConfig(device=device, max_batch_hits=max_batch_hits, capacity_cells=capacity_cells,
+                            max_limits=max_limits, reserved=0, hash_seed=hash_seed)
+        h = C.c_void_p()
+        rc = self._lib.rl_engine_create(C.byref(cfg), C.byref(h))
+        if rc != RL_OK:
+            raise EngineError(rc, "rl_engine_create failed (no MI355X visible?)" if rc == -3 else "rl_engine_create failed")
+        self._h = h
+        self.max_batch_hits = max_batch_hits
+        self.hash_seed = hash_seed
+        self.device = device
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rl_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != RL_OK:
+            raise EngineError(rc, self._lib.rl_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self):
+        """The engine's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        return self._lib.rl_engine_stream(self._h) or 0
+
+    def stats(self):
+        s = _lib.RlStats()
+        self._check(self._lib.rl_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+    # -- limits ------------------------------------------------------------------------------
+    def set_limits(self, rows, first=0):
+        """rows: iterable of (max_value, seconds) or a LIMIT_ROW_DTYPE array."""
+        arr = np.asarray(rows, dtype=LIMIT_ROW_DTYPE) if isinstance(rows, np.ndarray) else np.array(
+            [tuple(r) for r in rows], dtype=LIMIT_ROW_DTYPE)
+        self._check(self._lib.rl_limits_set(self._h, first, _ptr(arr), arr.shape[0]))
+
+    def add_counter(self, limit, key):
+        self._check(self._lib.rl_add_counter(self._h, int(limit), int(key)))
+
+    # -- hot path ----------------------------------------------------------------------------
+    def check_and_update(self, hits, now_us, req_off=None, load_counters=False, want_first_limited=True):
+        """CounterStorage::check_and_update for a batch.  Returns (verdict u8[n_req],
+        first_limited i32[n_req] | None, remaining u64[n_hits] | None, expires_in_us | None)."""
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        n_hits = hits.shape[0]
+        if req_off is not None:
+            req_off = np.ascontiguousarray(req_off, dtype=np.uint32)
+            n_req = req_off.shape[0] - 1
+        else:
+            n_req = n_hits
+        verdict = np.empty(n_req, dtype=np.uint8)
+        first = np.empty(n_req, dtype=np.int32) if want_first_limited else None
+        remaining = np.zeros(n_hits, dtype=np.uint64) if load_counters else None
+        expires = np.zeros(n_hits, dtype=np.uint64) if load_counters else None
+        self._check(self._lib.rl_check_and_update_batch(
+            self._h, _ptr(hits), n_hits, _ptr(req_off), n_req, int(now_us), int(bool(load_counters)),
+            _ptr(verdict), _ptr(first), _ptr(remaining), _ptr(expires)))
+        return verdict, first, remaining, expires
+
+    def check_and_update_device(self, d_hits, n_hits, now_us, d_verdict, d_req_off=None, n_req=None,
+                                load_counters=False, d_first_limited=None, d_remaining=None, d_expires=None):
+        """Same with raw device pointers (ints).  Blocks until the batch is applied."""
+        self._check(self._lib.rl_check_and_update_batch_device(
+            self._h, d_hits, n_hits, d_req_off, n_hits if n_req is None else n_req, int(now_us),
+            int(bool(load_counters)), d_verdict, d_first_limited, d_remaining, d_expires))
+
+    def is_within_limits(self, hits, now_us):
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        out = np.empty(hits.shape[0], dtype=np.uint8)
+        self._check(self._lib.rl_is_within_limits_batch(self._h, _ptr(hits), hits.shape[0], int(now_us), _ptr(out)))
+        return out
+
+    def update_counters(self, hits, now_us):
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        self._check(self._lib.rl_update_counter_batch(self._h, _ptr(hits), hits.shape[0], int(now_us)))
+
+    # -- rest of the CounterStorage surface -----------------------------------------------------
+    def get_counters(self, limit, now_us, cap=None):
+        n = C.c_uint64(0)
+        if cap is None:
+            self._check(self._lib.rl_get_counters(self._h, int(limit), int(now_us), None, 0, C.byref(n)))
+            cap = n.value
+        out = np.empty(cap, dtype=CELL_ROW_DTYPE)
+        self._check(self._lib.rl_get_counters(self._h, int(limit), int(now_us), _ptr(out), cap, C.byref(n)))
+        return out[: min(cap, n.value)]
+
+    def delete_counters(self, limit):
+        self._check(self._lib.rl_delete_counters(self._h, int(limit)))
+
+    def clear(self):
+        self._check(self._lib.rl_clear(self._h))
+
+    def sweep_expired(self, now_us):
+        n = C.c_uint64(0)
+        self._check(self._lib.rl_sweep_expired(self._h, int(now_us), C.byref(n)))
+        return n.value
+
+    def compact(self):
+        self._check(self._lib.rl_compact(self._h))
+
+    def load_cells(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=CELL_ROW_DTYPE)
+        self._check(self._lib.rl_load_cells(self._h, _ptr(rows), rows.shape[0]))
+
+    def load_cells_device(self, d_rows, n):
+        self._check(self._lib.rl_load_cells_device(self._h, d_rows, n))
+
+    def dump_cells(self):
+        n = C.c_uint64(0)
+        self._check(self._lib.rl_dump_cells(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=CELL_ROW_DTYPE)
+        self._check(self._lib.rl_dump_cells(self._h, _ptr(out), out.shape[0], C.byref(n)))
+        return out[: min(out.shape[0], n.value)]
+
+    # -- routing helpers (multi-GPU) -------------------------------------------------------------
+    def owner_of(self, key, world):
+        return self._lib.rl_owner_of(int(key), self.hash_seed, int(world))
+
+    def route_partition_device(self, d_hits, n_hits, world, d_out, d_perm, d_counts):
+        self._check(self._lib.rl_route_partition_device(self._h, d_hits, n_hits, world, d_out, d_perm, d_counts))
+
+    def unpermute_u8_device(self, d_src, d_perm, n, d_dst):
+        self._check(self._lib.rl_unpermute_u8_device(self._h, d_src, d_perm, n, d_dst))
+
+    # -- measurement -----------------------------------------------------------------------------
+    def kernel_timing(self, enable=True):
+        self._check(self._lib.rl_kernel_timing(self._h, int(bool(enable))))
+
+    def kernel_timing_read(self, reset=True):
+        a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        n = C.c_uint64()
+        self._check(self._lib.rl_kernel_timing_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d),
+                                                     C.byref(n), int(bool(reset))))
+        return {"ms_probe": a.value, "ms_decide": b.value, "ms_commit": c.value, "ms_ordered": d.value,
+                "launches": n.value}

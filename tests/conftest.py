@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    import oracle
+
+    oracle.build()
+
+
+@pytest.fixture(scope="session")
+def engine_lib():
+    """The built HIP library; building is `__graft_entry__.build()`'s job, tests only load it."""
+    from limitador_amd import _lib
+
+    return _lib.load()
