@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py — rate-limit decisions/s of the check_and_update hot path on MI355X.
+
+A step = one pass of CounterStorage::check_and_update over one batch of synthetic hits that is
+already resident in HBM (BASELINE.json configs[2]: 10 M keys, Zipf-0.99, 1 M single-counter
+requests per batch, max 1000 / 60 s fixed window, delta 1).  With N GPUs the key space is
+hash-sharded (N x 10 M keys, every rank ingests its own 1 M-hit slice: weak scaling) and each step
+includes the descriptor all-to-all and the verdict all-to-all over RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the
+engine's stream inside the timed region; `cpu_baseline` is the CPU oracle (a C restatement of the
+reference path, kind "port") timed on a bounded sample of the same workload, rank 0, N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# Algorithmic bytes per (request x counter), SURVEY.md §8(d): 16 B descriptor read + 24 B cell read
+# (key, value, expiry) + 8 B value write-back + 1 B verdict = 49 B, split over the three kernels
+# of the pipeline as stated in DESIGN.md §Measurement.
+ALGO_BYTES = {"probe": 16 + 8, "decide": 16 + 1, "commit": 8}
+ALGO_BYTES_TOTAL = 49
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--keys", type=int, default=10_000_000, help="keys per GPU")
+    ap.add_argument("--batch", type=int, default=1_000_000, help="hits per GPU per step")
+    ap.add_argument("--zipf", type=float, default=0.99, help="0 => uniform keys")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, budget_s):
+    """The CPU oracle on the same workload shape (same universe, same Zipf batches), one thread."""
+    import numpy as np
+
+    import oracle
+    from limitador_amd import workloads as W
+
+    orc = oracle.OracleStorage()
+    orc.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+    chunk = 1 << 21
+    for lo in range(0, args.keys, chunk):
+        c = W.universe_rows(args.keys, lo=lo, hi=min(args.keys, lo + chunk))
+        orc.load_cells(c["key"], c["limit"], c["value"], c["expiry_us"])
+    rng = np.random.default_rng(W.SEED)
+    cdf = W.zipf_cdf(args.keys, args.zipf) if args.zipf > 0 else None
+    n = min(args.batch, 1_000_000)
+    batches = []
+    for _ in range(3):
+        batches.append(W.zipf_batch(args.keys, n, rng, cdf) if cdf is not None else W.uniform_batch(args.keys, n, rng))
+    done, spent, now, i = 0, 0.0, W.NOW0_US, 0
+    while spent < budget_s and i < 64:
+        h = batches[i % len(batches)]
+        t0 = time.perf_counter()
+        orc.check_and_update(h, now, want_first_limited=False)
+        spent += time.perf_counter() - t0
+        done += n
+        now += 1000
+        i += 1
+    orc.close()
+    return {"value": done / spent, "unit": "decisions/s", "cores": 1, "kind": "port",
+            "sample": f"{i} batches x {n} hits, {args.keys} keys, zipf {args.zipf}, single thread, "
+                      f"oracle/limitador_oracle.c (hash-map table, no CEL/moka/tracing)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from limitador_amd import workloads as W
+    from limitador_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_keys_total = args.keys * world
+    cap = 1 << (int(n_keys_total / world * 2.2 - 1).bit_length())
+    max_batch = args.batch if world == 1 else int(args.batch * 2)
+    eng = Engine(capacity_cells=cap, max_batch_hits=max_batch, device=local_rank)
+    eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+
+    # ---- pre-populate this rank's shard -----------------------------------------------------
+    if world == 1:
+        rows = W.torch_universe_rows(n_keys_total, dev)
+    else:
+        from limitador_amd.sharded import owner_mask
+
+        rows = W.torch_universe_rows(n_keys_total, dev, keep=lambda k: owner_mask(k, eng.hash_seed, world, rank))
+    chunk = 1 << 20
+    for lo in range(0, rows.shape[0], chunk):
+        part = rows[lo:lo + chunk].contiguous()
+        eng.load_cells_device(part.data_ptr(), part.shape[0])
+    del rows
+    torch.cuda.synchronize()
+
+    # ---- synthetic batches, resident in HBM before the timed region --------------------------
+    gen = torch.Generator(device=dev).manual_seed(W.SEED + rank)
+    cdf = W.torch_zipf_cdf(n_keys_total, dev, args.zipf) if args.zipf > 0 else None
+    total_steps = args.warmup + args.steps
+    batches = [W.torch_batch(n_keys_total, args.batch, dev, gen, cdf) for _ in range(total_steps)]
+    del cdf
+    verdict = torch.empty(args.batch, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    if world > 1:
+        from limitador_amd.sharded import ShardedEngine
+
+        sh = ShardedEngine(eng, dist.group.WORLD, dev, max_local_hits=args.batch)
+
+        def step(i, now):
+            sh.check_and_update(batches[i], now, verdict)
+    else:
+        def step(i, now):
+            eng.check_and_update_device(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
+
+    now = W.NOW0_US
+    for i in range(args.warmup):
+        step(i, now)
+        now += 1000
+    eng.kernel_timing(True)
+    eng.kernel_timing_read(reset=True)
+    denied = 0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        step(i, now)
+        now += 1000
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = eng.kernel_timing_read(reset=True)
+    eng.kernel_timing(False)
+    denied = int(verdict.sum().item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        st = eng.stats()
+        decisions = args.batch * world * args.steps
+        launches = max(1, kt["launches"])
+        per = {k: kt["ms_" + k] / launches for k in ("probe", "decide", "commit", "ordered")}
+        hits_per_launch = st["hits"] / max(1, st["batches"])
+        dom = max(("probe", "decide", "commit"), key=lambda k: per[k])
+        dom_gbps = ALGO_BYTES[dom] * hits_per_launch / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+        pipe_ms = sum(per.values())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_" + dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "rate-limit decisions/sec", "value": decisions / dt, "unit": "decisions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[2]: 10M keys/GPU, Zipf-0.99 1M-hit batch/GPU, fixed window 1000/60s, "
+                                   "delta=1, single-counter requests" if (args.keys, args.batch, args.zipf) == (10_000_000, 1_000_000, 0.99)
+                       else f"{args.keys} keys/GPU, zipf {args.zipf}, {args.batch}-hit batch/GPU",
+                       "keys_per_gpu": args.keys, "batch_per_gpu": args.batch, "zipf_s": args.zipf,
+                       "table_capacity_cells": cap, "cell_bytes": 64,
+                       "parallelism": "single GPU" if world == 1 else f"hash-sharded x{world}, RCCL all-to-all",
+                       "denied_in_last_batch": denied},
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_hit": ALGO_BYTES[dom], "hits_per_launch": hits_per_launch,
+                         "avg_launch_ms": per[dom]},
+            "pipeline": {"kernel_ms_per_batch": per, "device_ms_per_batch": pipe_ms,
+                         "achieved_GBps_49B": ALGO_BYTES_TOTAL * hits_per_launch / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
+                         "ordered_hits_per_batch": st["ordered_hits"] / max(1, st["batches"])},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <mutex>
 #include <new>
 #include <string>
@@ -20,6 +21,7 @@
 #include "rl_cell.hpp"
 #include "rl_kernels.hpp"
 #include "rl_ordered.hpp"
+#include "rl_general.hpp"
 #include "rl_route.hpp"
 
 using namespace rl;
@@ -58,6 +60,14 @@ struct rl_engine {
     u64* d_keys_b = nullptr;
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    // general resolver (rl_general.hpp)
+    u32* d_hit_req = nullptr;
+    Contrib* d_contrib = nullptr;
+    Contrib* d_scan = nullptr;
+    uint8_t* d_pass = nullptr;
+    uint8_t* d_admitted = nullptr;
+    void* d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
     Status* d_status = nullptr;
     Status* h_status = nullptr; // pinned
     unsigned long long* d_total = nullptr;
@@ -130,10 +140,14 @@ int alloc_table(rl_engine* e, u64 cap, Cell** out) {
 }
 
 int check_room(rl_engine* e, u64 incoming) {
-    // Linear probing stays short while (live + tombstones) <= 3/4 capacity; refuse beyond.
-    if (e->live + e->tombs + incoming > e->cap - e->cap / 4)
+    // Linear probing stays short while (live + tombstones) <= 3/4 capacity.  Refuse new work once
+    // the table is past that, and refuse a batch that could not fit even if every hit were a new
+    // key; in between, the probe loop's own bound reports RL_ERR_TABLE_FULL if it ever runs out.
+    const u64 used = e->live + e->tombs;
+    if (used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap)
         return fail(e, RL_ERR_TABLE_FULL,
-                    "table would exceed 75%% occupancy (live=%llu tombstones=%llu incoming<=%llu capacity=%llu)",
+                    "table past 75%% occupancy (live=%llu tombstones=%llu incoming<=%llu capacity=%llu): "
+                    "sweep, compact or create a larger engine",
                     (unsigned long long)e->live, (unsigned long long)e->tombs,
                     (unsigned long long)incoming, (unsigned long long)e->cap);
     return RL_OK;
@@ -205,7 +219,8 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
         if (rc) return rc;
     }
     if (t) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream));
-    k_commit<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, d_hits, n, e->d_limits, now, e->d_hit_slot);
+    k_commit<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, d_hits, n, e->d_limits, now, e->d_hit_slot, 0,
+                                                  e->d_status);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[5], e->stream));
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -223,6 +238,91 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
     }
     e->stats.batches++;
     e->stats.hits += n;
+    return RL_OK;
+}
+
+// check_and_update in its general form (rl_general.hpp): multi-counter requests and/or
+// load_counters.  Exact for every input; slower than run_check_k1 (sorts every hit).
+int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_req_off, u32 n_req, u64 now,
+                      bool load, uint8_t* d_verdict, int32_t* d_first, u64* d_rem, u64* d_exp) {
+    int rc = check_room(e, n_hits);
+    if (rc) return rc;
+    const bool mark_fresh = !load && d_req_off != nullptr;
+    const u32* hit_req = nullptr;
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+    if (d_req_off) {
+        k_gen_hit_req<<<cdiv(n_req, 256), 256, 0, e->stream>>>(d_req_off, n_req, e->d_hit_req);
+        hit_req = e->d_hit_req;
+    }
+    if (n_hits == 0) {  // only empty requests: lib.rs:434-440, not limited
+        HIP_TRY(e, hipMemsetAsync(d_verdict, 0, n_req, e->stream));
+        if (d_first) HIP_TRY(e, hipMemsetAsync(d_first, 0xFF, (size_t)n_req * sizeof(int32_t), e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return RL_OK;
+    }
+    const u32 gh = cdiv(n_hits, 256), gr = cdiv(n_req, 256);
+    if (mark_fresh)
+        k_probe<PM_CHECK, true><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now,
+            e->d_hit_slot, e->d_status);
+    else
+        k_probe<PM_CHECK, false><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now,
+            e->d_hit_slot, e->d_status);
+    HIP_TRY(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    e->live += e->h_status->n_inserted;
+    if (e->h_status->err) {
+        // created cells stay (harmless (0, now+w) cells) but the scratch and fresh marks are cleared
+        k_abort<<<gh, 256, 0, e->stream>>>(e->table, n_hits, e->d_hit_slot);
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return status_to_error(e, e->h_status->err);
+    }
+    // sort every hit by (slot, idx)
+    k_gen_keys<<<gh, 256, 0, e->stream>>>(e->d_hit_slot, n_hits, e->d_keys_a);
+    size_t tmp = e->sort_tmp_bytes;
+    HIP_TRY(e, rocprim::radix_sort_keys(e->d_sort_tmp, tmp, e->d_keys_a, e->d_keys_b, (size_t)n_hits, 0u,
+                                        32u + e->log2cap, e->stream));
+    k_ord_heads<<<gh, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_hits);
+    k_gen_fill_u8<<<gr, 256, 0, e->stream>>>(e->d_admitted, n_req, 1);
+    int32_t* first = d_first ? d_first : e->d_first;
+    u32 rounds = 0;
+    for (;;) {
+        HIP_TRY(e, hipMemsetAsync(&e->d_status->n_rounds, 0, sizeof(u32), e->stream));
+        k_gen_contrib<<<gh, 256, 0, e->stream>>>(e->d_keys_b, n_hits, d_hits, hit_req, e->d_admitted, e->d_contrib);
+        size_t stmp = e->scan_tmp_bytes;
+        HIP_TRY(e, rocprim::exclusive_scan(e->d_scan_tmp, stmp, e->d_contrib, e->d_scan, Contrib{0, 0},
+                                           (size_t)n_hits, ContribPlus(), e->stream));
+        k_gen_eval<<<gh, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_hits, e->d_scan, d_hits, hit_req,
+                                              e->d_admitted, e->d_limits, now, e->d_pass, load ? d_rem : nullptr,
+                                              load ? d_exp : nullptr);
+        k_gen_requests<<<gr, 256, 0, e->stream>>>(d_req_off, n_req, e->d_pass, e->d_admitted, d_verdict, first,
+                                                  &e->d_status->n_rounds);
+        HIP_TRY(e, hipGetLastError());
+        rc = read_status(e);
+        if (rc) return rc;
+        ++rounds;
+        if (!e->h_status->n_rounds) break;
+        if (rounds > n_req + 2) return fail(e, RL_ERR_DEVICE, "general resolver did not converge (bug)");
+    }
+    k_gen_finish<<<gh, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_hits, e->d_scan, d_hits, hit_req,
+                                            e->d_admitted, e->d_limits, now);
+    if (mark_fresh)
+        k_gen_reach<<<gr, 256, 0, e->stream>>>(e->table, d_req_off, n_req, e->d_hit_slot, first);
+    k_commit<<<gh, 256, 0, e->stream>>>(e->table, d_hits, n_hits, e->d_limits, now, e->d_hit_slot,
+                                        mark_fresh ? 1 : 0, e->d_status);
+    HIP_TRY(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    const u32 removed = e->h_status->n_removed;
+    e->live -= removed;
+    e->tombs += removed;
+    e->stats.batches++;
+    e->stats.hits += n_hits;
+    e->stats.ordered_hits += n_hits;
+    e->stats.ordered_batches++;
+    e->stats.probe_steps += rounds;  // reused: fixpoint rounds of the general resolver
     return RL_OK;
 }
 
@@ -329,6 +429,11 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_ord_list, mb * sizeof(u32));
     ALLOC(e->d_keys_a, mb * sizeof(u64));
     ALLOC(e->d_keys_b, mb * sizeof(u64));
+    ALLOC(e->d_hit_req, mb * sizeof(u32));
+    ALLOC(e->d_contrib, mb * sizeof(Contrib));
+    ALLOC(e->d_scan, mb * sizeof(Contrib));
+    ALLOC(e->d_pass, mb);
+    ALLOC(e->d_admitted, mb);
     ALLOC(e->d_status, sizeof(Status));
     ALLOC(e->d_total, sizeof(unsigned long long));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
@@ -337,6 +442,12 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         return bail(RL_ERR_DEVICE);
     e->sort_tmp_bytes = tmp ? tmp : 16;
     ALLOC(e->d_sort_tmp, e->sort_tmp_bytes);
+    size_t stmp = 0;
+    if (rocprim::exclusive_scan(nullptr, stmp, e->d_contrib, e->d_scan, Contrib{0, 0}, mb, ContribPlus(),
+                                e->stream) != hipSuccess)
+        return bail(RL_ERR_DEVICE);
+    e->scan_tmp_bytes = stmp ? stmp : 16;
+    ALLOC(e->d_scan_tmp, e->scan_tmp_bytes);
 #undef ALLOC
     if (hipHostMalloc((void**)&e->h_status, sizeof(Status)) != hipSuccess) return bail(RL_ERR_NOMEM);
     if (hipHostMalloc((void**)&e->h_total, sizeof(unsigned long long)) != hipSuccess) return bail(RL_ERR_NOMEM);
@@ -354,7 +465,8 @@ void rl_engine_destroy(rl_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
                     e->d_remaining, e->d_expires, e->d_hit_slot, e->d_ord_list, e->d_keys_a,  e->d_keys_b,
-                    e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt};
+                    e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
+                    e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -424,11 +536,12 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
     std::lock_guard<std::mutex> g(e->mu);
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
-    if (d_req_off || load_counters) {
-        (void)d_remaining;
-        (void)d_expires_in_us;
-        return fail(e, RL_ERR_INVALID, "multi-counter requests / load_counters: not built yet in this round");
-    }
+    if (load_counters && (!d_remaining || !d_expires_in_us))
+        return fail(e, RL_ERR_INVALID, "load_counters needs remaining and expires_in_us buffers");
+    if (d_req_off || load_counters)
+        return run_check_general(e, reinterpret_cast<const Hit*>(d_hits), n_hits, d_req_off, n_req, now_us,
+                                 load_counters != 0, d_verdict, d_first_limited, reinterpret_cast<u64*>(d_remaining),
+                                 reinterpret_cast<u64*>(d_expires_in_us));
     return run_check_k1(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
 }
 
@@ -440,18 +553,35 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     std::lock_guard<std::mutex> g(e->mu);
     if (n_req == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
+    if (load_counters && (!remaining || !expires_in_us))
+        return fail(e, RL_ERR_INVALID, "load_counters needs remaining and expires_in_us buffers");
+    if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
+    if (n_hits)
+        HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
     if (req_off || load_counters) {
-        (void)remaining;
-        (void)expires_in_us;
-        return fail(e, RL_ERR_INVALID, "multi-counter requests / load_counters: not built yet in this round");
+        if (req_off) {
+            if (req_off[0] != 0 || req_off[n_req] != n_hits) return fail(e, RL_ERR_INVALID, "req_off must start at 0 and end at n_hits");
+            for (u32 r = 0; r < n_req; ++r)
+                if (req_off[r] > req_off[r + 1]) return fail(e, RL_ERR_INVALID, "req_off must be non-decreasing");
+            HIP_TRY(e, hipMemcpyAsync(e->d_req_off, req_off, ((size_t)n_req + 1) * sizeof(u32), hipMemcpyHostToDevice,
+                                      e->stream));
+        }
+        rc = run_check_general(e, e->d_hits, n_hits, req_off ? e->d_req_off : nullptr, n_req, now_us,
+                               load_counters != 0, e->d_verdict, e->d_first, e->d_remaining, e->d_expires);
+    } else {
+        rc = run_check_k1(e, e->d_hits, n_hits, now_us, e->d_verdict, first_limited ? e->d_first : nullptr);
     }
-    HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
-    rc = run_check_k1(e, e->d_hits, n_hits, now_us, e->d_verdict, first_limited ? e->d_first : nullptr);
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n_req, hipMemcpyDeviceToHost, e->stream));
     if (first_limited)
         HIP_TRY(e, hipMemcpyAsync(first_limited, e->d_first, (size_t)n_req * sizeof(int32_t), hipMemcpyDeviceToHost,
                                   e->stream));
+    if (load_counters && n_hits) {
+        HIP_TRY(e, hipMemcpyAsync(remaining, e->d_remaining, (size_t)n_hits * sizeof(u64), hipMemcpyDeviceToHost,
+                                  e->stream));
+        HIP_TRY(e, hipMemcpyAsync(expires_in_us, e->d_expires, (size_t)n_hits * sizeof(u64), hipMemcpyDeviceToHost,
+                                  e->stream));
+    }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
 }

@@ -54,7 +54,7 @@ constexpr int PM_UPDATE = 2;         // insert both (update_counter, in_memory.r
 
 // Linear probing over 64-byte cells.  Returns the slot or SLOT_INVALID.
 // `first_tag` is the tag already loaded from the start slot.
-template <int MODE>
+template <int MODE, bool FRESH = false>
 __device__ __forceinline__ u32 probe_from(Cell* __restrict__ table, u32 log2cap, u32 slot,
                                           u64 first_tag, u64 key, u32 limit,
                                           const LimitDev* __restrict__ limits, u64 now,
@@ -77,6 +77,7 @@ __device__ __forceinline__ u32 probe_from(Cell* __restrict__ table, u32 log2cap,
                 c->value = 0;
                 c->expiry = now + limits[limit & ~SIMPLE_FLAG].window_us;
                 c->limit = limit;
+                if (FRESH) c->pad = 1u;  // created by this batch, not yet confirmed (rl_general.hpp)
                 n_created++;
                 return slot;
             }
@@ -93,7 +94,7 @@ __device__ __forceinline__ u32 probe_from(Cell* __restrict__ table, u32 log2cap,
 // ---------------------------------------------------------------------------------------------
 // k_probe
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool FRESH = false>
 __global__ __launch_bounds__(PROBE_BLOCK) void k_probe(Cell* __restrict__ table, u32 log2cap,
                                                         u64 seed, const Hit* __restrict__ hits,
                                                         u32 n, const LimitDev* __restrict__ limits,
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(PROBE_BLOCK) void k_probe(Cell* __restrict__ table,
             slot[u] = SLOT_INVALID;
             continue;
         }
-        slot[u] = probe_from<MODE>(table, log2cap, slot[u], tag0[u], h[u].key, h[u].limit, limits,
-                                   now, st, created);
+        slot[u] = probe_from<MODE, FRESH>(table, log2cap, slot[u], tag0[u], h[u].key, h[u].limit,
+                                          limits, now, st, created);
         if (slot[u] == SLOT_INVALID) continue;
         // LDS aggregation keyed by the cell slot.
         u32 e = (slot[u] * 0x9E3779B1u) >> (32 - 11);  // AGG_N == 2^11
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(DECIDE_BLOCK) void k_decide(
 __global__ __launch_bounds__(256) void k_commit(Cell* __restrict__ table,
                                                 const Hit* __restrict__ hits, u32 n,
                                                 const LimitDev* __restrict__ limits, u64 now,
-                                                const u32* __restrict__ hit_slot) {
+                                                const u32* __restrict__ hit_slot,
+                                                int drop_unreached, Status* st) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const u32 hs = hit_slot[i];
@@ -284,6 +286,23 @@ __global__ __launch_bounds__(256) void k_commit(Cell* __restrict__ table,
     Cell* c = &table[hs & SLOT_MASK];
     const LimitDev L = limits[c->limit & ~SIMPLE_FLAG];
     const u64 expiry = c->expiry;
+    if (drop_unreached) {
+        // A cell created by k_probe that no request actually reached (its request stopped at an
+        // earlier limited counter, in_memory.rs:109-113,129-133) must not exist.
+        const u32 fresh = c->pad;
+        c->pad = 0;
+        if (fresh == 1u) {
+            c->tag = TAG_TOMB;
+            c->pend = 0;
+            c->cnt = 0;
+            c->amb = 0;
+            c->nonuni = 0;
+            c->aux = 0;
+            c->seg = 0;
+            atomicAdd(&st->n_removed, 1u);
+            return;
+        }
+    }
     const bool expired = expiry <= now;
     if (L.window_us == 0) {
         const u64 a = c->aux;
@@ -327,6 +346,7 @@ __global__ __launch_bounds__(256) void k_abort(Cell* __restrict__ table, u32 n,
     c->nonuni = 0;
     c->aux = 0;
     c->seg = 0;
+    c->pad = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

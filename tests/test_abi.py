@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/rl_engine.h declares (no GPU,
+no compute calls)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "rl_engine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_counter_storage_surface():
+    syms = _header_symbols()
+    for must in ("rl_check_and_update_batch", "rl_is_within_limits_batch", "rl_update_counter_batch",
+                 "rl_add_counter", "rl_get_counters", "rl_delete_counters", "rl_clear", "rl_sweep_expired"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(engine_lib):
+    from limitador_amd import _lib
+
+    for name in _header_symbols():
+        assert hasattr(engine_lib, name), f"{name} declared in rl_engine.h but not exported"
+        assert name in _lib.SYMBOLS, f"{name} has no ctypes signature in limitador_amd/_lib.py"
+
+
+def test_wire_structs_match_header_sizes():
+    import ctypes as C
+
+    from limitador_amd import _lib, wire
+
+    assert wire.HIT_DTYPE.itemsize == 16
+    assert wire.CELL_ROW_DTYPE.itemsize == 32
+    assert wire.LIMIT_ROW_DTYPE.itemsize == 16
+    assert C.sizeof(_lib.RlConfig) == 32
+    assert C.sizeof(_lib.RlStats) == 72
+
+
+def test_engine_refuses_to_run_without_a_gpu(engine_lib):
+    """No CPU fallback: on a box without a HIP device the engine fails loudly."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from limitador_amd.engine import Engine, EngineError
+
+    with pytest.raises(EngineError) as e:
+        Engine(capacity_cells=1024)
+    assert e.value.code == -3
+
+
+def test_owner_of_is_a_pure_function(engine_lib):
+    seen = {engine_lib.rl_owner_of(k * 0x9E3779B97F4A7C15 % (1 << 64), 7, 8) for k in range(1000)}
+    assert seen == set(range(8))
+    assert engine_lib.rl_owner_of(12345, 7, 1) == 0

@@ -1,0 +1,417 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle: bit-exact verdicts,
+first-limited indices and final table contents on the same seeded inputs.  Needs a MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+import scenarios
+from helpers.limiter import TestsLimiter
+from limitador_amd import workloads as W
+from limitador_amd.wire import CELL_ROW_DTYPE, HIT_DTYPE, RL_SIMPLE
+
+pytestmark = pytest.mark.gpu
+
+SEC = 1_000_000
+NOW = W.NOW0_US
+
+
+@pytest.fixture()
+def make_engine():
+    from limitador_amd.engine import Engine
+
+    made = []
+
+    def _make(capacity_cells=1 << 16, **kw):
+        e = Engine(capacity_cells=capacity_cells, **kw)
+        made.append(e)
+        return e
+
+    yield _make
+    for e in made:
+        e.close()
+
+
+def assert_same_state(eng, orc, n_simple_expected=None):
+    """Every live cell of the engine equals the oracle's cell, and the counts agree."""
+    rows = eng.dump_cells()
+    qual = rows[(rows["limit"] & RL_SIMPLE) == 0]
+    simp = rows[(rows["limit"] & RL_SIMPLE) != 0]
+    assert len(qual) == orc.num_qualified(), (len(qual), orc.num_qualified())
+    assert len(np.unique(rows["key"])) == len(rows), "duplicate key in the table"
+    for r in qual:
+        got = orc.peek(int(r["key"]))
+        assert got is not None, f"engine has key {int(r['key'])} the oracle lacks"
+        assert (int(r["value"]), int(r["expiry_us"]), int(r["limit"])) == got, (r, got)
+    for r in simp:
+        got = orc.peek_simple(int(r["limit"]))
+        assert got is not None
+        assert (int(r["value"]), int(r["expiry_us"])) == got, (r, got)
+    if n_simple_expected is not None:
+        assert len(simp) == n_simple_expected
+
+
+def pair(make_engine, rows, simple_keys=(), **kw):
+    eng = make_engine(**kw)
+    orc = oracle.OracleStorage()
+    eng.set_limits(rows)
+    orc.set_limits(rows)
+    for limit, key in simple_keys:
+        eng.add_counter(limit | RL_SIMPLE, key)
+        orc.add_counter(limit | RL_SIMPLE, key)
+    return eng, orc
+
+
+def run_both(eng, orc, hits, now, **kw):
+    v1, f1, r1, e1 = eng.check_and_update(hits, now, **kw)
+    v2, f2, r2, e2 = orc.check_and_update(hits, now, **kw)
+    assert np.array_equal(v1, v2), f"verdict mismatch at {np.nonzero(v1 != v2)[0][:10]}"
+    assert np.array_equal(f1, f2), f"first_limited mismatch at {np.nonzero(f1 != f2)[0][:10]}"
+    if kw.get("load_counters"):
+        assert np.array_equal(r1, r2), f"remaining mismatch at {np.nonzero(r1 != r2)[0][:10]}"
+        assert np.array_equal(e1, e2), f"expires_in mismatch at {np.nonzero(e1 != e2)[0][:10]}"
+    return v1
+
+
+# ---- the reference's own scenarios, through the engine ---------------------------------------
+@pytest.mark.parametrize("scenario", scenarios.ALL, ids=lambda f: f.__name__)
+def test_reference_scenarios_on_engine(make_engine, scenario):
+    scenario(TestsLimiter(make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)))
+
+
+# ---- seeded random traces, single-counter requests -------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_single_counter_batches(make_engine, seed):
+    rng = np.random.default_rng(seed)
+    rows = [(5, 1), (50, 10), (1000, 60), (0, 60), (2**64 - 1, 3600), (7, 0)]
+    simple = [(4, 9_000_001), (0, 9_000_002)]
+    eng, orc = pair(make_engine, rows, simple)
+    n_keys = 300
+    key_limit = rng.integers(0, 4, size=n_keys)  # each qualified key belongs to one limit
+    key_limit[:10] = 5  # some zero-window keys
+    now = NOW
+    for step in range(25):
+        n = int(rng.integers(1, 3000))
+        idx = (rng.zipf(1.3, size=n) - 1) % n_keys if step % 2 else rng.integers(0, n_keys, size=n)
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        hits["key"] = W.splitmix64(idx.astype(np.uint64))
+        hits["limit"] = key_limit[idx]
+        hits["delta"] = rng.integers(0, 4, size=n) if step % 3 else 1
+        # sprinkle the two simple counters in
+        sm = rng.random(n) < 0.05
+        which = rng.integers(0, 2, size=n)
+        hits["key"][sm] = np.where(which[sm] == 0, 9_000_001, 9_000_002)
+        hits["limit"][sm] = np.where(which[sm] == 0, 4, 0) | RL_SIMPLE
+        run_both(eng, orc, hits, now)
+        now += int(rng.integers(0, 3 * SEC))
+    assert_same_state(eng, orc, n_simple_expected=2)
+
+
+def test_one_hot_key_nonuniform_deltas(make_engine):
+    """Every hit on one cell, mixed deltas: the sequential walk of the ordered resolver."""
+    rng = np.random.default_rng(7)
+    eng, orc = pair(make_engine, [(5000, 60)])
+    for step in range(4):
+        n = 20000
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        hits["key"] = 77
+        hits["limit"] = 0
+        hits["delta"] = rng.integers(0, 6, size=n)
+        v = run_both(eng, orc, hits, NOW + step)
+        if step == 0:
+            assert 0 < v.sum() < n  # the window fills up inside the first batch
+    assert_same_state(eng, orc)
+
+
+def test_hot_keys_uniform_delta_saturate_mid_batch(make_engine):
+    rng = np.random.default_rng(8)
+    eng, orc = pair(make_engine, [(1000, 60)])
+    n = 200_000
+    hits = np.empty(n, dtype=HIT_DTYPE)
+    hits["key"] = W.splitmix64(rng.integers(0, 40, size=n).astype(np.uint64))
+    hits["limit"] = 0
+    hits["delta"] = 1
+    v = run_both(eng, orc, hits, NOW)
+    assert v.sum() == n - 40 * 1000
+    run_both(eng, orc, hits, NOW + 1)
+    run_both(eng, orc, hits, NOW + 61 * SEC)  # windows rolled over
+    assert_same_state(eng, orc)
+
+
+def test_wrapping_values_match_release_build_arithmetic(make_engine):
+    """value + delta wraps (in_memory.rs:88,261 in a release build)."""
+    big = 2**64 - 3
+    eng, orc = pair(make_engine, [(2**64 - 1, 60)])
+    one = np.zeros(1, dtype=HIT_DTYPE)
+    one[0] = (5, 0, 2)
+    cell = np.zeros(1, dtype=CELL_ROW_DTYPE)
+    cell[0] = (5, 0, 0, big, NOW + 30 * SEC)
+    eng.load_cells(cell)
+    orc.load_cells([5], [0], [big], [NOW + 30 * SEC])
+    hits = np.repeat(one, 8)
+    run_both(eng, orc, hits, NOW)
+    assert_same_state(eng, orc)
+
+
+def test_empty_batch_and_single_hit(make_engine):
+    eng, orc = pair(make_engine, [(1, 60)])
+    v, f, _, _ = eng.check_and_update(np.zeros(0, dtype=HIT_DTYPE), NOW)
+    assert v.shape == (0,)
+    one = np.zeros(1, dtype=HIT_DTYPE)
+    one[0] = (5, 0, 1)
+    assert run_both(eng, orc, one, NOW)[0] == 0
+    assert run_both(eng, orc, one, NOW)[0] == 1
+    assert_same_state(eng, orc)
+
+
+def test_maximum_batch_size(make_engine):
+    n = 1 << 18
+    eng, orc = pair(make_engine, [(3, 60)], capacity_cells=1 << 20, max_batch_hits=n)
+    rng = np.random.default_rng(5)
+    hits = W.uniform_batch(50_000, n, rng)
+    run_both(eng, orc, hits, NOW)
+    assert_same_state(eng, orc)
+    from limitador_amd.engine import EngineError
+
+    with pytest.raises(EngineError) as e:
+        eng.check_and_update(np.zeros(n + 1, dtype=HIT_DTYPE), NOW)
+    assert e.value.code == -7
+
+
+# ---- error behaviour ---------------------------------------------------------------------------
+def test_errors_are_loud_and_leave_the_table_usable(make_engine):
+    from limitador_amd.engine import EngineError
+
+    eng, orc = pair(make_engine, [(5, 60), (5, 60)])
+    bad = np.zeros(1, dtype=HIT_DTYPE)
+    bad[0] = (1, 9, 1)  # unknown limit id
+    with pytest.raises(EngineError) as e:
+        eng.check_and_update(bad, NOW)
+    assert e.value.code == -1 and not e.value.transient
+    bad[0] = (1, 0 | RL_SIMPLE, 1)  # simple counter never add_counter'ed
+    with pytest.raises(EngineError) as e:
+        eng.check_and_update(bad, NOW)
+    assert e.value.code == -5
+    ok = np.zeros(1, dtype=HIT_DTYPE)
+    ok[0] = (2, 0, 1)
+    run_both(eng, orc, ok, NOW)
+    bad[0] = (2, 1, 1)  # same key, different limit
+    with pytest.raises(EngineError) as e:
+        eng.check_and_update(bad, NOW)
+    assert e.value.code == -6
+    run_both(eng, orc, ok, NOW)
+    assert_same_state(eng, orc)
+
+
+# ---- the other CounterStorage methods ------------------------------------------------------------
+def test_is_within_limits_and_update_counter_parity(make_engine):
+    rng = np.random.default_rng(11)
+    rows = [(5, 1), (50, 10), (9, 0)]
+    eng, orc = pair(make_engine, rows, [(1, 7_000_001)])
+    now = NOW
+    for step in range(12):
+        n = int(rng.integers(1, 4000))
+        idx = rng.integers(0, 200, size=n)
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        hits["key"] = W.splitmix64(idx.astype(np.uint64))
+        hits["limit"] = idx % 3
+        hits["delta"] = rng.integers(0, 5, size=n)
+        sm = rng.random(n) < 0.05
+        hits["key"][sm] = 7_000_001
+        hits["limit"][sm] = 1 | RL_SIMPLE
+        assert np.array_equal(eng.is_within_limits(hits, now), orc.is_within_limits(hits, now))
+        eng.update_counters(hits, now)
+        orc.update_counters(hits, now)
+        assert np.array_equal(eng.is_within_limits(hits, now), orc.is_within_limits(hits, now))
+        now += int(rng.integers(0, 2 * SEC))
+    # update_counter on a vacant simple cell creates it (in_memory.rs:60-62)
+    h = np.zeros(1, dtype=HIT_DTYPE)
+    h[0] = (7_000_002, 0 | RL_SIMPLE, 3)
+    eng.update_counters(h, now)
+    orc.update_counters(h, now)
+    assert_same_state(eng, orc, n_simple_expected=2)
+
+
+def test_get_delete_clear_sweep_parity(make_engine):
+    rng = np.random.default_rng(12)
+    rows = [(100, 1), (100, 10), (100, 60)]
+    eng, orc = pair(make_engine, rows, [(2, 8_000_001)])
+    hits = np.empty(3000, dtype=HIT_DTYPE)
+    idx = rng.integers(0, 500, size=3000)
+    hits["key"] = W.splitmix64(idx.astype(np.uint64))
+    hits["limit"] = idx % 2
+    hits["delta"] = 1
+    run_both(eng, orc, hits, NOW)
+    s = np.zeros(1, dtype=HIT_DTYPE)
+    s[0] = (8_000_001, 2 | RL_SIMPLE, 1)
+    run_both(eng, orc, s, NOW)
+
+    def same_counters(limit, now):
+        a = eng.get_counters(limit, now)
+        b = orc.get_counters(limit, now)
+        if limit & RL_SIMPLE:
+            assert len(a) == len(b)
+            if len(a):
+                assert (int(a[0]["value"]), int(a[0]["expiry_us"])) == (int(b[0]["value"]), int(b[0]["expires_in_us"]))
+            return len(a)
+        ka = sorted((int(r["key"]), int(r["value"]), int(r["expiry_us"])) for r in a)
+        kb = sorted((int(r["key"]), int(r["value"]), int(r["expires_in_us"])) for r in b)
+        assert ka == kb
+        return len(ka)
+
+    t = NOW + SEC // 2
+    assert same_counters(0, t) > 0 and same_counters(1, t) > 0 and same_counters(2 | RL_SIMPLE, t) == 1
+    t = NOW + 2 * SEC  # limit 0's 1-second windows are over: hidden (in_memory.rs:168,180)
+    assert same_counters(0, t) == 0 and same_counters(1, t) > 0
+    assert eng.sweep_expired(t) == orc.sweep_expired(t)
+    assert_same_state(eng, orc, n_simple_expected=1)
+    eng.delete_counters(1)
+    orc.delete_counters(1)
+    assert same_counters(1, t) == 0
+    eng.clear()
+    orc.clear()
+    assert_same_state(eng, orc, n_simple_expected=0)
+    eng.compact()
+    assert_same_state(eng, orc, n_simple_expected=0)
+    st = eng.stats()
+    assert st["tombstones"] == 0 and st["live_cells"] == orc.num_qualified()
+    # the table keeps working after compaction
+    run_both(eng, orc, hits, t)
+    assert_same_state(eng, orc)
+
+
+def test_sweep_is_an_explicit_eviction_event(make_engine):
+    """SURVEY.md §7 hard part 3: dropping an expired cell is observable when the next touch is a
+    denied one; replaying the sweep into the oracle keeps parity."""
+    eng, orc = pair(make_engine, [(3, 1)])
+    h = np.zeros(1, dtype=HIT_DTYPE)
+    h[0] = (42, 0, 2)
+    run_both(eng, orc, h, NOW)
+    t = NOW + 5 * SEC
+    assert eng.sweep_expired(t) == orc.sweep_expired(t) == 1
+    h[0] = (42, 0, 9)  # denied (9 > 3) but re-creates the cell with a fresh window
+    run_both(eng, orc, h, t)
+    h[0] = (42, 0, 1)
+    run_both(eng, orc, h, t + SEC // 2)
+    assert_same_state(eng, orc)
+
+
+# ---- BASELINE.json configs at full size ----------------------------------------------------------
+def _full_size(make_engine, n_keys, n_hits, steps, zipf):
+    rows = [(W.MAX_VALUE, W.WINDOW_S)]
+    cap = 1 << int(np.ceil(np.log2(n_keys * 2)))
+    eng, orc = pair(make_engine, rows, capacity_cells=cap, max_batch_hits=n_hits)
+    chunk = 1 << 20
+    for lo in range(0, n_keys, chunk):
+        cells = W.universe_rows(n_keys, lo=lo, hi=min(n_keys, lo + chunk))
+        eng.load_cells(cells)
+        orc.load_cells(cells["key"], cells["limit"], cells["value"], cells["expiry_us"])
+    assert eng.stats()["live_cells"] == n_keys
+    rng = np.random.default_rng(W.SEED)
+    cdf = W.zipf_cdf(n_keys) if zipf else None
+    now = NOW
+    denied = 0
+    for _ in range(steps):
+        hits = W.zipf_batch(n_keys, n_hits, rng, cdf) if zipf else W.uniform_batch(n_keys, n_hits, rng)
+        denied += int(run_both(eng, orc, hits, now, want_first_limited=True).sum())
+        now += 1000
+    assert 0 < denied < steps * n_hits  # a real allow/deny mix
+    # final table: same multiset of (key, value, expiry) — compare via order-independent checksums
+    rows_ = eng.dump_cells()
+    assert len(rows_) == orc.num_qualified() == n_keys
+    sample = rows_[:: max(1, n_keys // 20000)]
+    for r in sample:
+        assert (int(r["value"]), int(r["expiry_us"]), int(r["limit"])) == orc.peek(int(r["key"]))
+    return eng
+
+
+def test_config2_uniform_64k_on_1m_keys(make_engine):
+    """BASELINE.json configs[1]: 1M keys, uniform 64k batches, fixed window, delta 1."""
+    _full_size(make_engine, 1 << 20, 1 << 16, steps=20, zipf=False)
+
+
+def test_config3_zipf_1m_on_10m_keys(make_engine):
+    """BASELINE.json configs[2] (fixed-window semantics): 10M keys, Zipf-0.99 1M batches."""
+    eng = _full_size(make_engine, 10_000_000, 1_000_000, steps=3, zipf=True)
+    assert eng.stats()["ordered_hits"] > 0  # the hot keys saturate inside a batch
+
+
+# ---- multi-counter requests and load_counters (the general resolver) ------------------------------
+def _multi_batch(rng, n_req, rows, simple_ids, n_users, max_k=6, dup_prob=0.05, zero_k_prob=0.03):
+    """Requests over a small universe: simple counters first, then qualified (in_memory.rs:105,121)."""
+    qual_ids = [i for i in range(len(rows)) if i not in simple_ids]
+    hits, off = [], [0]
+    for _ in range(n_req):
+        delta = int(rng.integers(0, 4)) if rng.random() < 0.3 else 1
+        req = []
+        if rng.random() >= zero_k_prob:
+            k = int(rng.integers(1, max_k + 1))
+            user = int(rng.zipf(1.5) - 1) % n_users if rng.random() < 0.7 else int(rng.integers(0, n_users))
+            chosen = rng.permutation(len(rows))[:k]
+            for lid in sorted(chosen, key=lambda x: (x not in simple_ids,)):
+                lid = int(lid)
+                if lid in simple_ids:
+                    req.append((10_000_000 + lid, lid | RL_SIMPLE, delta))
+                else:
+                    key = int(W.splitmix64(np.array([lid * 100_003 + user], dtype=np.uint64))[0])
+                    req.append((key, lid, delta))
+            if rng.random() < dup_prob and qual_ids:
+                q = [h for h in req if not (h[1] & RL_SIMPLE)]
+                if q:
+                    req.append(q[0])  # the same counter twice in one request
+        hits.extend(req)
+        off.append(len(hits))
+    arr = np.zeros(len(hits), dtype=HIT_DTYPE)
+    for i, h in enumerate(hits):
+        arr[i] = h
+    return arr, np.array(off, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("load", [False, True], ids=["noload", "load_counters"])
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_multi_counter_requests(make_engine, seed, load):
+    rng = np.random.default_rng(seed)
+    rows = [(40, 1), (5000, 10), (3, 1), (25, 10), (200, 60), (2, 60), (9, 0), (2**64 - 1, 3600)]
+    simple_ids = {0, 1}
+    eng, orc = pair(make_engine, rows, [(0, 10_000_000), (1, 10_000_001)])
+    now = NOW
+    for step in range(14):
+        hits, off = _multi_batch(rng, int(rng.integers(1, 1500)), rows, simple_ids, n_users=60)
+        run_both(eng, orc, hits, now, req_off=off, load_counters=load)
+        now += int(rng.integers(0, 2 * SEC))
+    assert_same_state(eng, orc, n_simple_expected=2)
+    st = eng.stats()
+    assert st["live_cells"] == orc.num_qualified() + 2
+
+
+def test_single_counter_requests_with_load_counters(make_engine):
+    rng = np.random.default_rng(31)
+    eng, orc = pair(make_engine, [(50, 2), (7, 1)])
+    now = NOW
+    for step in range(8):
+        n = 5000
+        idx = (rng.zipf(1.2, size=n) - 1) % 300
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        hits["key"] = W.splitmix64(idx.astype(np.uint64))
+        hits["limit"] = idx % 2
+        hits["delta"] = rng.integers(0, 3, size=n)
+        run_both(eng, orc, hits, now, load_counters=True)
+        now += SEC // 2
+    assert_same_state(eng, orc)
+
+
+def test_unreached_counters_are_not_created(make_engine):
+    """Appendix A (G): a request stops at its first limited counter when !load_counters."""
+    eng, orc = pair(make_engine, [(0, 60), (10, 60)])
+    hits = np.zeros(4, dtype=HIT_DTYPE)
+    hits[0] = (100, 0, 1)  # limited (max 0)
+    hits[1] = (200, 1, 1)  # never reached -> never created
+    hits[2] = (300, 1, 1)  # second request, reaches and creates 300 ...
+    hits[3] = (200, 1, 1)  # ... and 200
+    off = np.array([0, 2, 4], dtype=np.uint32)
+    v = run_both(eng, orc, hits[:2], NOW, req_off=off[:2])
+    assert v[0] == 1
+    assert_same_state(eng, orc)
+    assert {int(k) for k in eng.dump_cells()["key"]} == {100}
+    run_both(eng, orc, hits, NOW + 1, req_off=off)
+    assert_same_state(eng, orc)
+    assert {int(k) for k in eng.dump_cells()["key"]} == {100, 200, 300}
