@@ -29,8 +29,8 @@ struct alignas(64) Cell {
     u64 tag;     //  0  key, TAG_EMPTY or TAG_TOMB
     u64 value;   //  8  AtomicExpiringValue.value
     u64 expiry;  // 16  AtomicExpiringValue.expiry (us since epoch)
-    u64 pend;    // 24  scratch: sum of the deltas of this batch's hits (0 between batches)
-    u32 cnt;     // 32  scratch: number of hits in this batch (0 between batches)
+    u64 pend;    // 24  scratch: (hit count << 40) | sum of deltas of this batch (0 between batches)
+    u32 cnt;     // 32  reserved
     u32 limit;   // 36  limit id | SIMPLE_FLAG (attribute: delete/get by limit, sanity check)
     u32 amb;     // 40  scratch: AMB_*
     u32 nonuni;  // 44  scratch: ordered segment has non-uniform deltas / needs sequential walk
@@ -62,6 +62,15 @@ constexpr u32 ERRBIT_MISSING_SIMPLE = 2u;
 constexpr u32 ERRBIT_TABLE_FULL = 4u;
 constexpr u32 ERRBIT_KEY_LIMIT = 8u;
 constexpr u32 ERRBIT_RESERVED_KEY = 16u;
+constexpr u32 ERRBIT_BIG_DELTA = 32u;  // not an error: the batch must take the exact general path
+
+// One 64-bit atomic per (tile, cell) carries both the hit count (leader election) and the delta
+// sum: count in the top 24 bits, sum in the low 40.  Exact as long as the deltas of a whole batch
+// cannot carry out of 40 bits; k_probe flags any delta >= 2^40 / n_hits and the host then reruns
+// the batch through the general path, which does not use the sum.
+constexpr u32 PEND_SHIFT = 40;
+constexpr u64 PEND_SUM_MASK = (1ull << PEND_SHIFT) - 1ull;
+constexpr u32 MAX_BATCH_HITS = (1u << 24) - 1u;
 
 constexpr u32 SLOT_INVALID = 0x7FFFFFFFu;
 constexpr u32 SLOT_MASK = 0x7FFFFFFFu;

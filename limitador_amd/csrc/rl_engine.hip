@@ -170,6 +170,9 @@ int do_compact(rl_engine* e) {
     return RL_OK;
 }
 
+int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_req_off, u32 n_req, u64 now,
+                      bool load, uint8_t* d_verdict, int32_t* d_first, u64* d_rem, u64* d_exp);
+
 // The ordered resolver (rl_ordered.hpp).  n_ord is known on the host.
 int run_ordered(rl_engine* e, const Hit* d_hits, u32 n_ord, u64 now, uint8_t* d_verdict,
                 int32_t* d_first) {
@@ -197,8 +200,8 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
     if (t) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
     k_probe<PM_CHECK><<<cdiv(n, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
-        e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(), now, e->d_hit_slot,
-        e->d_status);
+        e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(), now,
+        (1ull << PEND_SHIFT) / n, e->d_hit_slot, e->d_status);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
     k_decide<<<cdiv(n, DECIDE_BLOCK), DECIDE_BLOCK, 0, e->stream>>>(
         e->table, d_hits, n, e->d_limits, now, e->d_hit_slot, d_verdict, d_first, e->d_ord_list, e->d_status);
@@ -210,7 +213,9 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
     if (e->h_status->err) {
         k_abort<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, n, e->d_hit_slot);
         HIP_TRY(e, hipStreamSynchronize(e->stream));
-        return status_to_error(e, e->h_status->err);
+        if (e->h_status->err == ERRBIT_BIG_DELTA)  // exact path for deltas the packed sum cannot hold
+            return run_check_general(e, d_hits, n, nullptr, n, now, false, d_verdict, d_first, nullptr, nullptr);
+        return status_to_error(e, e->h_status->err & ~ERRBIT_BIG_DELTA);
     }
     const u32 n_ord = e->h_status->n_ord;
     if (t) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream));
@@ -262,12 +267,12 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
     }
     const u32 gh = cdiv(n_hits, 256), gr = cdiv(n_req, 256);
     if (mark_fresh)
-        k_probe<PM_CHECK, true><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
-            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now,
+        k_probe<PM_CHECK, true, false><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now, 0ull,
             e->d_hit_slot, e->d_status);
     else
-        k_probe<PM_CHECK, false><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
-            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now,
+        k_probe<PM_CHECK, false, false><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now, 0ull,
             e->d_hit_slot, e->d_status);
     HIP_TRY(e, hipGetLastError());
     rc = read_status(e);
@@ -400,6 +405,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->device = cfg->device;
     e->seed = cfg->hash_seed;
     e->max_batch = cfg->max_batch_hits ? cfg->max_batch_hits : (1u << 20);
+    if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     e->log2cap = ceil_log2(cfg->capacity_cells < 1024 ? 1024 : cfg->capacity_cells);
     if (e->log2cap > 31) {
@@ -619,15 +625,21 @@ int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hit
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
     k_probe<PM_UPDATE><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
         e->table, e->log2cap, e->seed, e->d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now_us,
-        e->d_hit_slot, e->d_status);
+        (1ull << PEND_SHIFT) / n_hits, e->d_hit_slot, e->d_status);
     HIP_TRY(e, hipGetLastError());
     rc = read_status(e);
     if (rc) return rc;
     e->live += e->h_status->n_inserted;
+    if (e->h_status->err == ERRBIT_BIG_DELTA) {
+        k_update_serial<<<1, 64, 0, e->stream>>>(e->table, e->d_hits, n_hits, e->d_limits, now_us, e->d_hit_slot);
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return RL_OK;
+    }
     if (e->h_status->err) {
         k_abort<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, n_hits, e->d_hit_slot);
         HIP_TRY(e, hipStreamSynchronize(e->stream));
-        return status_to_error(e, e->h_status->err);
+        return status_to_error(e, e->h_status->err & ~ERRBIT_BIG_DELTA);
     }
     if (e->any_zero_window)
         k_update_aux<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, e->d_hits, n_hits, e->d_limits,

@@ -94,11 +94,11 @@ __device__ __forceinline__ u32 probe_from(Cell* __restrict__ table, u32 log2cap,
 // ---------------------------------------------------------------------------------------------
 // k_probe
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool FRESH = false>
+template <int MODE, bool FRESH = false, bool WITH_SUM = true>
 __global__ __launch_bounds__(PROBE_BLOCK) void k_probe(Cell* __restrict__ table, u32 log2cap,
                                                         u64 seed, const Hit* __restrict__ hits,
                                                         u32 n, const LimitDev* __restrict__ limits,
-                                                        u32 n_limits, u64 now,
+                                                        u32 n_limits, u64 now, u64 delta_limit,
                                                         u32* __restrict__ hit_slot, Status* st) {
     __shared__ u32 a_slot[AGG_N];
     __shared__ u32 a_cnt[AGG_N];
@@ -170,19 +170,21 @@ __global__ __launch_bounds__(PROBE_BLOCK) void k_probe(Cell* __restrict__ table,
             e = (e + 1) & (AGG_N - 1);
         }
         atomicAdd(&a_cnt[e], 1u);
-        atomicAdd(&a_sum[e], (u64)h[u].delta);
+        if (WITH_SUM) {
+            if ((u64)h[u].delta >= delta_limit) atomicOr(&st->err, ERRBIT_BIG_DELTA);
+            atomicAdd(&a_sum[e], (u64)h[u].delta);
+        }
         my_e[u] = e;
     }
     if (created) atomicAdd(&s_created, created);
     __syncthreads();
-    // One pair of global atomics per (tile, cell).
+    // One global atomic per (tile, cell): count (top 24 bits) and delta sum (low 40 bits).
     for (u32 e = tid; e < AGG_N; e += PROBE_BLOCK) {
         const u32 s = a_slot[e];
         if (s != AGG_EMPTY) {
-            Cell* c = &table[s];
-            const u32 old = atomicAdd(&c->cnt, a_cnt[e]);
-            atomicAdd(&c->pend, a_sum[e]);
-            a_lead[e] = (old == 0u);
+            const u64 add = ((u64)a_cnt[e] << PEND_SHIFT) | (WITH_SUM ? (a_sum[e] & PEND_SUM_MASK) : 0ull);
+            const u64 old = atomicAdd(&table[s].pend, add);
+            a_lead[e] = ((old >> PEND_SHIFT) == 0ull);
         }
     }
     if (tid == 0 && s_created) atomicAdd(&st->n_inserted, s_created);
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(DECIDE_BLOCK) void k_decide(
             Cell* c = &table[slot];
             const u64 value = c->value;
             const u64 expiry = c->expiry;
-            const u64 total = c->pend;
+            const u64 total = c->pend & PEND_SUM_MASK;
             const u32 climit = c->limit;
             if (climit != h.limit) atomicOr(&st->err, ERRBIT_KEY_LIMIT);
             const LimitDev L = limits[h.limit & ~SIMPLE_FLAG];
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void k_commit(Cell* __restrict__ table,
         if (amb == AMB_NONE) {
             const u64 s = expired ? 0ull : c->value;
             u64 sum;
-            if (!__builtin_add_overflow(s, c->pend, &sum) && sum <= L.max_value) {
+            if (!__builtin_add_overflow(s, c->pend & PEND_SUM_MASK, &sum) && sum <= L.max_value) {
                 c->value = sum;
                 if (expired) c->expiry = now + L.window_us;  // update_if_expired, :87-99
             }
@@ -378,14 +380,37 @@ __global__ __launch_bounds__(256) void k_update_commit(Cell* __restrict__ table,
         c->value = c->aux & 0xFFFFFFFFull;
         c->expiry = now;
     } else if (c->expiry <= now) {
-        c->value = c->pend;  // first update stores, the rest fetch_add (:36-42)
+        c->value = c->pend & PEND_SUM_MASK;  // first update stores, the rest fetch_add (:36-42)
         c->expiry = now + L.window_us;
     } else {
-        c->value += c->pend;  // wraps like fetch_add
+        c->value += c->pend & PEND_SUM_MASK;  // wraps like fetch_add
     }
     c->pend = 0;
     c->cnt = 0;
     c->aux = 0;
+}
+
+// Exact fallback for update_counter batches whose deltas could carry out of the packed 40-bit sum:
+// one lane replays AtomicExpiringValue::update hit by hit (slots already resolved by k_probe).
+__global__ void k_update_serial(Cell* __restrict__ table, const Hit* __restrict__ hits, u32 n,
+                                const LimitDev* __restrict__ limits, u64 now,
+                                const u32* __restrict__ hit_slot) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (u32 i = 0; i < n; ++i) {
+        const u32 slot = hit_slot[i] & SLOT_MASK;
+        if (slot == SLOT_INVALID) continue;
+        Cell* c = &table[slot];
+        const u64 w = limits[c->limit & ~SIMPLE_FLAG].window_us;
+        const u64 d = hits[i].delta;
+        if (c->expiry <= now) {
+            c->expiry = now + w;
+            c->value = d;
+        } else {
+            c->value += d;
+        }
+        c->pend = 0;
+        c->aux = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

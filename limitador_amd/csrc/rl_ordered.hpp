@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_ord_uniform(Cell* __restrict__ table,
         // wrapping arithmetic.
         const u64 s = (c->expiry <= now) ? 0ull : c->value;
         u64 tmp;
-        bad = bad || __builtin_add_overflow(s, c->pend, &tmp);
+        bad = bad || __builtin_add_overflow(s, c->pend & PEND_SUM_MASK, &tmp);
     }
     if (bad) c->nonuni = 1;
 }

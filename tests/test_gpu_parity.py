@@ -124,7 +124,7 @@ def test_one_hot_key_nonuniform_deltas(make_engine):
 
 def test_hot_keys_uniform_delta_saturate_mid_batch(make_engine):
     rng = np.random.default_rng(8)
-    eng, orc = pair(make_engine, [(1000, 60)])
+    eng, orc = pair(make_engine, [(1000, 60)], max_batch_hits=200_000)
     n = 200_000
     hits = np.empty(n, dtype=HIT_DTYPE)
     hits["key"] = W.splitmix64(rng.integers(0, 40, size=n).astype(np.uint64))
@@ -415,3 +415,20 @@ def test_unreached_counters_are_not_created(make_engine):
     run_both(eng, orc, hits, NOW + 1, req_off=off)
     assert_same_state(eng, orc)
     assert {int(k) for k in eng.dump_cells()["key"]} == {100, 200, 300}
+
+
+def test_huge_deltas_take_the_exact_path(make_engine):
+    """Deltas that could carry out of the packed 40-bit batch sum are rerouted, not truncated."""
+    rng = np.random.default_rng(41)
+    eng, orc = pair(make_engine, [(2**40, 60), (2**64 - 1, 60)])
+    n = 3000
+    idx = rng.integers(0, 20, size=n)
+    hits = np.empty(n, dtype=HIT_DTYPE)
+    hits["key"] = W.splitmix64(idx.astype(np.uint64))
+    hits["limit"] = idx % 2
+    hits["delta"] = rng.integers(2**31, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    run_both(eng, orc, hits, NOW)
+    eng.update_counters(hits, NOW + 1)
+    orc.update_counters(hits, NOW + 1)
+    run_both(eng, orc, hits, NOW + 2)
+    assert_same_state(eng, orc)
