@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1_000_000, help="hits per GPU per step")
     ap.add_argument("--zipf", type=float, default=0.99, help="0 => uniform keys")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the routed (all-to-all) data path even with one rank (exercises the N>1 code on one GPU)")
     return ap.parse_args()
 
 
@@ -93,13 +95,16 @@ def main():
         raise SystemExit("bench.py needs a MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_keys_total = args.keys * world
     cap = 1 << (int(n_keys_total / world * 2.2 - 1).bit_length())
-    max_batch = args.batch if world == 1 else int(args.batch * 2)
+    max_batch = int(args.batch * 2) if sharded else args.batch
     eng = Engine(capacity_cells=cap, max_batch_hits=max_batch, device=local_rank)
     eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
 
@@ -126,7 +131,7 @@ def main():
     verdict = torch.empty(args.batch, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    if world > 1:
+    if sharded:
         from limitador_amd.sharded import ShardedEngine
 
         sh = ShardedEngine(eng, dist.group.WORLD, dev, max_local_hits=args.batch)
@@ -145,7 +150,7 @@ def main():
     eng.kernel_timing_read(reset=True)
     denied = 0
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -153,14 +158,14 @@ def main():
         step(i, now)
         now += 1000
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kt = eng.kernel_timing_read(reset=True)
     eng.kernel_timing(False)
     denied = int(verdict.sum().item())
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -190,7 +195,7 @@ def main():
                        else f"{args.keys} keys/GPU, zipf {args.zipf}, {args.batch}-hit batch/GPU",
                        "keys_per_gpu": args.keys, "batch_per_gpu": args.batch, "zipf_s": args.zipf,
                        "table_capacity_cells": cap, "cell_bytes": 64,
-                       "parallelism": "single GPU" if world == 1 else f"hash-sharded x{world}, RCCL all-to-all",
+                       "parallelism": f"hash-sharded x{world}, RCCL all-to-all" if sharded else "single GPU",
                        "denied_in_last_batch": denied},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
@@ -206,7 +211,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

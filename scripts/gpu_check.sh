@@ -27,3 +27,8 @@ if [[ $what == all || $what == prof ]]; then
 fi
 tail -5 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.err 2>/dev/null
 cat gpurun_out/bench.json 2>/dev/null
+if [[ $what == sharded ]]; then
+  timeout 900 python -m pytest tests/test_gpu_sharded.py -m gpu -q 2>&1 | tail -30 > gpurun_out/pytest_sharded.log
+  timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --force-sharded > gpurun_out/bench_sharded1.json 2> gpurun_out/bench_sharded1.err
+  tail -5 gpurun_out/pytest_sharded.log; tail -3 gpurun_out/bench_sharded1.err; cat gpurun_out/bench_sharded1.json
+fi

@@ -1,0 +1,80 @@
+"""Device side of the sharded path on one MI355X: the stable owner partition / un-permute kernels
+against numpy, and the whole ShardedEngine over RCCL with world_size 1."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from limitador_amd import workloads as W
+from limitador_amd.sharded import HipLocal, ShardedEngine, owner_of_tensor
+from limitador_amd.wire import HIT_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("n", [1, 63, 2048, 100_003])
+def test_route_partition_is_a_stable_partition_by_owner(world, n):
+    from limitador_amd.engine import Engine
+
+    eng = Engine(capacity_cells=1 << 12, max_batch_hits=1 << 17)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(n * 31 + world)
+    hits = W.uniform_batch(1 << 20, n, rng)
+    hits["delta"] = np.arange(n) % 7
+    t = torch.from_numpy(hits.view(np.int64).reshape(-1, 2).copy()).to(dev)
+    loc = HipLocal(eng, dev, n, world)
+    out, perm, counts = loc.partition(t, world)
+    torch.cuda.synchronize()
+    owners = owner_of_tensor(t[:, 0].cpu(), eng.hash_seed, world).numpy()
+    want_perm = np.argsort(owners, kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), want_perm)
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(owners, minlength=world))
+    assert np.array_equal(out.cpu().numpy(), t.cpu().numpy()[want_perm])
+    # un-permute returns per-hit bytes to ingress order
+    src = torch.arange(n, dtype=torch.int64, device=dev).to(torch.uint8)
+    dst = torch.zeros(n, dtype=torch.uint8, device=dev)
+    loc.unpermute(src, perm, n, dst)
+    torch.cuda.synchronize()
+    want = np.zeros(n, dtype=np.uint8)
+    want[want_perm] = (np.arange(n) % 256).astype(np.uint8)
+    assert np.array_equal(dst.cpu().numpy(), want)
+    eng.close()
+
+
+def test_sharded_engine_over_rccl_world_1():
+    import torch.distributed as dist
+    from limitador_amd.engine import Engine
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 50_000
+        eng = Engine(capacity_cells=1 << 16, max_batch_hits=2 * n)
+        rows = [(20, 60)]
+        eng.set_limits(rows)
+        orc = oracle.OracleStorage()
+        orc.set_limits(rows)
+        sh = ShardedEngine(eng, dist.group.WORLD, dev, max_local_hits=n)
+        rng = np.random.default_rng(3)
+        now = W.NOW0_US
+        for _ in range(3):
+            hits = W.zipf_batch(5000, n, rng)
+            t = torch.from_numpy(hits.view(np.int64).reshape(-1, 2).copy()).to(dev)
+            out = torch.empty(n, dtype=torch.uint8, device=dev)
+            sh.check_and_update(t, now, out)
+            torch.cuda.synchronize()
+            v, _, _, _ = orc.check_and_update(hits, now)
+            assert np.array_equal(out.cpu().numpy(), v)
+            now += 1000
+        eng.close()
+    finally:
+        dist.destroy_process_group()
