@@ -22,9 +22,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # Algorithmic bytes per (request x counter), SURVEY.md §8(d): 16 B descriptor read + 24 B cell read
-# (key, value, expiry) + 8 B value write-back + 1 B verdict = 49 B, split over the three kernels
-# of the pipeline as stated in DESIGN.md §Measurement.
-ALGO_BYTES = {"probe": 16 + 8, "decide": 16 + 1, "commit": 8}
+# (key, value, expiry) + 8 B value write-back + 1 B verdict = 49 B.  k_bkt_apply is the kernel that
+# reads the descriptor and the cell, writes the value back and emits the verdict, so all 49 B are
+# its algorithmic bytes; the partition kernels (hist / scan / scatter) only reorder the batch —
+# ranking traffic is overhead, not algorithmic — and are charged 0.  The legacy
+# pipeline (RL_K1_PATH=legacy) splits the 49 B over probe / decide / commit.
+ALGO_BYTES = {"apply": 49, "hist": 0, "scan": 0, "scatter": 0,
+              "legacy_probe": 16 + 8, "legacy_decide": 16 + 1, "legacy_commit": 8, "legacy_ordered": 0}
 ALGO_BYTES_TOTAL = 49
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -174,10 +178,10 @@ def main():
         st = eng.stats()
         decisions = args.batch * world * args.steps
         launches = max(1, kt["launches"])
-        per = {k: kt["ms_" + k] / launches for k in ("probe", "decide", "commit", "ordered")}
+        per = {k: v / launches for k, v in kt["ms"].items() if v > 0}
         hits_per_launch = st["hits"] / max(1, st["batches"])
-        dom = max(("probe", "decide", "commit"), key=lambda k: per[k])
-        dom_gbps = ALGO_BYTES[dom] * hits_per_launch / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+        dom = max(per, key=lambda k: per[k]) if per else "apply"
+        dom_gbps = ALGO_BYTES[dom] * hits_per_launch / (per[dom] * 1e-3) / 1e9 if per.get(dom, 0) > 0 else 0.0
         pipe_ms = sum(per.values())
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -200,7 +204,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_hit": ALGO_BYTES[dom], "hits_per_launch": hits_per_launch,
-                         "avg_launch_ms": per[dom]},
+                         "avg_launch_ms": per.get(dom, 0.0)},
             "pipeline": {"kernel_ms_per_batch": per, "device_ms_per_batch": pipe_ms,
                          "achieved_GBps_49B": ALGO_BYTES_TOTAL * hits_per_launch / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
                          "ordered_hits_per_batch": st["ordered_hits"] / max(1, st["batches"])},

@@ -199,11 +199,23 @@ int32_t rl_unpermute_u8_device(rl_engine *e, const uint8_t *d_src, const uint32_
 /* The HIP stream (hipStream_t) the engine launches on, for callers that order their own work
  * against it, and a per-kernel timing hook used by bench.py (HIP events on that stream). */
 void *rl_engine_stream(rl_engine *e);
-/* Enable (1) / disable (0) HIP-event timing of the dominant kernel; read accumulated
- * milliseconds and launch count since the last reset. */
+/* Enable (1) / disable (0) HIP-event timing of the kernels of the single-counter hot path (events
+ * on the engine's stream, inside rl_check_and_update_batch[_device]).  rl_kernel_timing_read copies
+ * the milliseconds accumulated per slot since the last reset into ms[RL_TIMING_SLOTS] and the number
+ * of timed batches into *launches. */
+enum {
+    RL_T_HIST = 0,           /* k_bkt_hist: per-tile bucket histogram + batch validation */
+    RL_T_SCAN = 1,           /* k_bkt_scan + k_bkt_starts */
+    RL_T_SCATTER = 2,        /* k_bkt_scatter: stable partition into bucket order */
+    RL_T_APPLY = 3,          /* k_bkt_apply: probe, decide, commit — the dominant kernel */
+    RL_T_LEGACY_PROBE = 4,   /* first-generation pipeline (RL_K1_PATH=legacy) */
+    RL_T_LEGACY_DECIDE = 5,
+    RL_T_LEGACY_ORDERED = 6,
+    RL_T_LEGACY_COMMIT = 7,
+    RL_TIMING_SLOTS = 8
+};
 int32_t rl_kernel_timing(rl_engine *e, int32_t enable);
-int32_t rl_kernel_timing_read(rl_engine *e, double *ms_probe, double *ms_decide, double *ms_commit,
-                              double *ms_ordered, uint64_t *launches, int32_t reset);
+int32_t rl_kernel_timing_read(rl_engine *e, double *ms, uint64_t *launches, int32_t reset);
 
 #ifdef __cplusplus
 }

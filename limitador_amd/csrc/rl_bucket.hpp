@@ -1,0 +1,1032 @@
+// rl_bucket.hpp — the measured hot path: CounterStorage::check_and_update for a batch of
+// single-counter requests as ONE read and ONE write per touched counter cell, no global atomics
+// on the data path and no mid-batch host round trip.
+//
+// Sequential contract (reference limitador/src/storage/in_memory.rs:72-156, called once per
+// request): hit i is decided against the cell state left by hits < i.  Hits on DIFFERENT cells
+// never interact, so the batch is split by key hash into buckets; every hit of one key lands in
+// the same bucket, a bucket is owned by exactly one workgroup, and inside the bucket the hits
+// keep their trace order (the partition is stable).  The owner replays its bucket with the
+// reference's arithmetic, but wavefront-parallel: per round of APPLY_R hits it aggregates the
+// hits per key in an LDS hash (ds atomics), reads each NEW key's cell once from HBM, decides
+//     run + sum(round) <= max    -> every hit of the key admitted, whatever the order
+//     run + delta      >  max    -> this hit denied, whatever the order (run only grows)
+//     otherwise (uniform delta)  -> admitted iff trace-order rank < (max - run) / delta
+//     anything else              -> replayed hit by hit in trace order (wrapping u64, 0-s windows)
+// (`run` = value_at(now) + what this batch has admitted so far, atomic_expiring_value.rs:19-24,
+// 36-42), keeps the cell in LDS across rounds, and writes value (and expiry, when the window was
+// reset: update_if_expired, atomic_expiring_value.rs:87-99) back once.
+//
+//   k_bkt_hist     per tile of the batch: hits per bucket (LDS histogram); validates the hits
+//   k_bkt_scan     per bucket: exclusive scan of its tile counts (one wave per bucket)
+//   k_bkt_starts   bucket starts (exclusive scan of the bucket totals) + processing order
+//   k_bkt_scatter  stable partition: 16-B hit records + original indices into bucket order
+//   k_bkt_apply    one workgroup per bucket: the replay described above
+#pragma once
+#include "rl_kernels.hpp"
+
+namespace rl {
+
+constexpr int BK_LOG2_MAX = 11;
+constexpr int BK_MAX = 1 << BK_LOG2_MAX;
+constexpr int HOT_MAX = 64;                   // keys that get a bucket of their own
+constexpr int BKT_MAX = BK_MAX + HOT_MAX;     // hash buckets + hot-key buckets
+constexpr int PT_BLOCK = 1024;                // 16 waves per workgroup
+constexpr int PT_WAVES = PT_BLOCK / 64;
+constexpr int PT_STEPS = 4;                   // 64-hit steps per wave
+constexpr int PT_WAVE_TILE = 64 * PT_STEPS;   // contiguous hits owned by one wave
+constexpr int PT_TILE = PT_WAVES * PT_WAVE_TILE;  // hits per workgroup (4096)
+constexpr u32 BK_BIG = 1024;                  // hash buckets at least this large are processed first
+constexpr int HOT_SAMPLE = 2048;              // hits sampled per batch to find the next batch's hot keys
+constexpr int HOT_SLOTS = 4096;
+constexpr u32 HOT_MIN_COUNT = 4;              // sampled hits that make a key hot (>= ~0.2 % of the batch)
+constexpr int HOT_HASH = 128;                 // LDS lookup table of the current hot set
+
+// Keys that took a large share of the PREVIOUS batch ("hot": a Zipf head, a simple limit every
+// request of a namespace hits).  Each gets a bucket to itself, so the stable partition leaves the
+// key's hits contiguous and in trace order: position in the bucket == the hit's rank on the key.
+// Any stale or arbitrary set is valid — the set only has to be the same in every kernel of one
+// batch; it decides which code path a key takes, never a verdict.
+struct HotSet {
+    u32 n;
+    u32 pad;
+    u64 key[HOT_MAX];
+};
+constexpr u32 HS_FOUND = 1u;
+constexpr u32 HS_EXPIRED = 2u;
+struct HotState {  // the hot key's cell as it was before this batch (snapshot taken by k_bkt_hist)
+    u64 s;         // value_at(now)
+    u32 slot;      // SLOT_INVALID: no cell yet
+    u32 flags;
+    u32 climit;    // the cell's limit attribute
+    u32 pad;
+};
+// Zeroed before every batch (one memset): the status block, then per hot key the largest delta
+// and the largest ~delta (== ~smallest) seen in the batch.
+struct BatchScratch {
+    Status st;
+    u32 hot_dmax[HOT_MAX];
+    u32 hot_ndmin[HOT_MAX];
+};
+
+// Record of the partitioned batch: the hit's key and delta, its index in the caller's batch (where
+// the verdict goes) and an 8-bit fold of its limit id — one 16-byte store per hit.  The limit id
+// itself is not carried: it is an attribute of the counter cell (the caller interns key -> limit),
+// the fold only lets the engine notice a caller that sends one key with two limit ids (exact for
+// ids below 128, 255/256 otherwise); a new cell reads the id from the caller's batch.
+struct BHit {
+    u64 key;
+    u32 delta;
+    u32 idx_tag;  // idx (24 bits: MAX_BATCH_HITS) | limit fold << 24
+};
+static_assert(sizeof(BHit) == 16, "one dwordx4 per record");
+__host__ __device__ inline u32 limit_fold(u32 limit) {
+    return (limit ^ (limit >> 8) ^ (limit >> 16) ^ (limit >> 24)) & 0xFFu;
+}
+__device__ __forceinline__ BHit load_bhit(const BHit* p, u32 j) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p + j);
+    BHit h;
+    h.key = ((u64)v.y << 32) | v.x;
+    h.delta = v.z;
+    h.idx_tag = v.w;
+    return h;
+}
+
+__device__ __forceinline__ u32 bucket_of_hash(u64 hh, u32 bk_log2) {
+    return bk_log2 ? (u32)(hh >> (64 - bk_log2)) : 0u;
+}
+
+// LDS lookup table of the hot set: build (all threads call it; needs a barrier afterwards).
+__device__ __forceinline__ void hot_table_build(const HotSet* __restrict__ hot, u64 seed, u64* s_key,
+                                                u32* s_idx) {
+    for (u32 q = threadIdx.x; q < (u32)HOT_HASH; q += blockDim.x) s_key[q] = TAG_EMPTY;
+    __syncthreads();
+    const u32 n = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
+    if (threadIdx.x < n) {
+        const u64 k = hot->key[threadIdx.x];
+        u32 q = (u32)(fmix64(k ^ seed) >> 8) & (HOT_HASH - 1);
+        while (atomicCAS(&s_key[q], TAG_EMPTY, k) != TAG_EMPTY) q = (q + 1) & (HOT_HASH - 1);
+        s_idx[q] = threadIdx.x;
+    }
+}
+// -1, or the key's index in the hot set.  `hh` = fmix64(key ^ seed).
+__device__ __forceinline__ int hot_lookup(const u64* s_key, const u32* s_idx, u64 key, u64 hh) {
+    u32 q = (u32)(hh >> 8) & (HOT_HASH - 1);
+    for (;;) {
+        const u64 k = s_key[q];
+        if (k == key) return (int)s_idx[q];
+        if (k == TAG_EMPTY) return -1;
+        q = (q + 1) & (HOT_HASH - 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_hist: hist[tile * nbt + bucket] = hits of `tile` that belong to `bucket`
+// (nbt = 2^bk_log2 hash buckets + HOT_MAX hot-key buckets).
+// Also the only place the batch is validated, so that k_bkt_apply can refuse to touch the table
+// when the batch is malformed: limit id range, reserved keys, and (in_memory.rs:106-107) a
+// simple counter must already have its cell.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ table, u32 log2cap,
+                                                       u64 seed, const Hit* __restrict__ hits, u32 n,
+                                                       const LimitDev* __restrict__ limits,
+                                                       u32 n_limits, u32 bk_log2, u32 ntiles,
+                                                       u32* __restrict__ hist, BatchScratch* bs,
+                                                       const HotSet* __restrict__ hot) {
+    __shared__ u32 s_hist[BKT_MAX];
+    __shared__ u64 s_hot_key[HOT_HASH];
+    __shared__ u32 s_hot_idx[HOT_HASH];
+    __shared__ u32 s_dmax[HOT_MAX], s_ndmin[HOT_MAX];
+    const u32 tid = threadIdx.x;
+    Status* st = &bs->st;
+    const u32 nb = 1u << bk_log2;
+    const u32 nbt = nb + HOT_MAX;
+    for (u32 b = tid; b < nbt; b += PT_BLOCK) s_hist[b] = 0;
+    if (tid < HOT_MAX) {
+        s_dmax[tid] = 0;
+        s_ndmin[tid] = 0;
+    }
+    const u32 base = blockIdx.x * PT_TILE;
+    Hit h[PT_TILE / PT_BLOCK];
+#pragma unroll
+    for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
+        const u32 i = base + r * PT_BLOCK + tid;
+        if (i < n) h[r] = load_hit(hits, i);
+    }
+    hot_table_build(hot, seed, s_hot_key, s_hot_idx);
+    __syncthreads();
+    u32 err = 0;
+#pragma unroll
+    for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
+        const u32 i = base + r * PT_BLOCK + tid;
+        if (i < n) {
+            if ((h[r].limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
+            else if (h[r].key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
+            else if (h[r].limit & SIMPLE_FLAG) {
+                u32 dummy = 0;
+                u32 slot = slot_of(h[r].key, seed, log2cap);
+                slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, h[r].key,
+                                             h[r].limit, limits, 0ull, st, dummy);
+                if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
+            }
+            const u64 hh = fmix64(h[r].key ^ seed);
+            const int hi = hot_lookup(s_hot_key, s_hot_idx, h[r].key, hh);
+            if (hi >= 0) {
+                atomicAdd(&s_hist[nb + hi], 1u);
+                atomicMax(&s_dmax[hi], h[r].delta);
+                atomicMax(&s_ndmin[hi], ~h[r].delta);
+            } else {
+                atomicAdd(&s_hist[bucket_of_hash(hh, bk_log2)], 1u);
+            }
+        }
+    }
+    if (err) atomicOr(&st->err, err);
+    __syncthreads();
+    for (u32 b = tid; b < nbt; b += PT_BLOCK) hist[(size_t)blockIdx.x * nbt + b] = s_hist[b];
+    if (tid < HOT_MAX && s_hist[nb + tid]) {
+        atomicMax(&bs->hot_dmax[tid], s_dmax[tid]);
+        atomicMax(&bs->hot_ndmin[tid], s_ndmin[tid]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_scan: per bucket (column of hist), exclusive scan over the tiles in place;
+// total[bucket] = its hit count.  A workgroup owns 32 columns; its 32 thread groups split the
+// tiles, sum their part, exchange the part sums through LDS and rewrite their part.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_bkt_scan(u32* __restrict__ hist, u32 ntiles, u32 nbt,
+                                                   u32* __restrict__ total) {
+    __shared__ u32 s_part[32][32];
+    const u32 cl = threadIdx.x & 31u;
+    const u32 c = blockIdx.x * 32 + cl;
+    const u32 g = threadIdx.x >> 5;
+    const u32 per = (ntiles + 31) / 32;
+    const u32 t_lo = g * per < ntiles ? g * per : ntiles;
+    const u32 t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
+    u32 sum = 0;
+    if (c < nbt) {
+#pragma unroll 8
+        for (u32 t = t_lo; t < t_hi; ++t) sum += hist[(size_t)t * nbt + c];
+    }
+    s_part[g][cl] = sum;
+    __syncthreads();
+    if (c >= nbt) return;
+    u32 run = 0, all = 0;
+    for (u32 gg = 0; gg < 32; ++gg) {
+        const u32 x = s_part[gg][cl];
+        if (gg < g) run += x;
+        all += x;
+    }
+#pragma unroll 8
+    for (u32 t = t_lo; t < t_hi; ++t) {
+        const u32 v = hist[(size_t)t * nbt + c];
+        hist[(size_t)t * nbt + c] = run;
+        run += v;
+    }
+    if (g == 0) total[c] = all;
+}
+
+// Exclusive prefix of `v` over the 1024 threads of the workgroup (thread order); `total` = sum.
+__device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* s_w, u32& total) {
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 o = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += o;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+#pragma unroll
+    for (u32 ww = 0; ww < (u32)PT_WAVES; ++ww) {
+        const u32 x = s_w[ww];
+        if (ww < w) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + inc - v;
+}
+
+// Lanes of the wave whose `d` equals mine (among `valid` lanes): one ballot per bucket-id bit.
+__device__ __forceinline__ u64 match_digit(u32 d, u32 nbits, u64 valid) {
+    u64 m = valid;
+#pragma unroll
+    for (u32 b = 0; b < (u32)BK_LOG2_MAX + 1u; ++b) {
+        if (b < nbits) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bm = __ballot(bit);
+            m &= bit ? bm : ~bm;
+        }
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_scatter: stable partition.  Every workgroup first rebuilds the bucket starts (exclusive
+// scan of the bucket totals: cheaper than another launch); workgroup 0 also publishes the
+// hash-bucket ranges in processing order (large buckets first) and the hot-bucket ranges.
+// Wave w of a workgroup owns the contiguous hits [tile + w*256, tile + (w+1)*256) and walks them
+// in 64-hit steps in trace order; the rank of a hit inside (wave, bucket) comes from a
+// wave-private LDS counter plus its position among the lanes of the step that share the bucket.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict__ hits, u32 n, u64 seed,
+                                                          u32 bk_log2, const u32* __restrict__ hist,
+                                                          const u32* __restrict__ total,
+                                                          const HotSet* __restrict__ hot,
+                                                          BHit* __restrict__ b_hits,
+                                                          uint2* __restrict__ ranges,
+                                                          uint2* __restrict__ hot_ranges, Status* st,
+                                                          const Cell* __restrict__ table, u32 log2cap,
+                                                          const LimitDev* __restrict__ limits, u64 now,
+                                                          u32 ntiles, HotState* __restrict__ hot_state,
+                                                          HotSet* __restrict__ hot_next) {
+    __shared__ __align__(16) unsigned short s_cnt[PT_WAVES][BKT_MAX];
+    __shared__ u32 s_base[BKT_MAX];
+    __shared__ u32 s_w[PT_WAVES];
+    __shared__ u64 s_hot_key[HOT_HASH];
+    __shared__ u32 s_hot_idx[HOT_HASH];
+    const u32 tid = threadIdx.x;
+    // One extra workgroup snapshots the cells of the current hot keys (for k_bkt_apply) and picks the
+    // NEXT batch's hot keys from a strided sample of this batch.
+    if (blockIdx.x == ntiles) {
+        // ---- snapshot of the current hot keys' cells ---------------------------------------------
+        const u32 nh = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
+        if (tid < nh) {
+            const u64 k = hot->key[tid];
+            u32 dummy = 0;
+            u32 slot = slot_of(k, seed, log2cap);
+            slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, k, 0u, limits,
+                                         0ull, st, dummy);
+            HotState hs{0ull, slot, 0u, 0u, 0u};
+            if (slot != SLOT_INVALID) {
+                const Cell* c = &table[slot];
+                const u64 expiry = c->expiry;
+                hs.flags = HS_FOUND | (expiry <= now ? HS_EXPIRED : 0u);
+                hs.s = expiry <= now ? 0ull : c->value;
+                hs.climit = c->limit;
+            }
+            hot_state[tid] = hs;
+        }
+        // ---- next batch's hot set: keys with >= HOT_MIN_COUNT hits in a strided sample -----------
+        static_assert(sizeof(s_cnt) >= HOT_SLOTS * (sizeof(u64) + sizeof(u32)), "sampler tables alias s_cnt");
+        u64* s_big_key = reinterpret_cast<u64*>(&s_cnt[0][0]);
+        u32* s_big_cnt = reinterpret_cast<u32*>(s_big_key + HOT_SLOTS);
+        u32& s_n = s_w[0];
+        for (u32 q = tid; q < (u32)HOT_SLOTS; q += PT_BLOCK) {
+            s_big_key[q] = TAG_EMPTY;
+            s_big_cnt[q] = 0;
+        }
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const u32 ns = n < (u32)HOT_SAMPLE ? n : (u32)HOT_SAMPLE;
+        const u32 stride = n / (ns ? ns : 1u);
+        for (u32 k = tid; k < ns; k += PT_BLOCK) {
+            const u64 key = hits[(size_t)k * stride].key;
+            u32 q = (u32)(fmix64(key ^ seed) >> 16) & (HOT_SLOTS - 1);
+            for (;;) {
+                const u64 prev = atomicCAS(&s_big_key[q], TAG_EMPTY, key);
+                if (prev == TAG_EMPTY || prev == key) break;
+                q = (q + 1) & (HOT_SLOTS - 1);
+            }
+            atomicAdd(&s_big_cnt[q], 1u);
+        }
+        __syncthreads();
+        for (u32 q = tid; q < (u32)HOT_SLOTS; q += PT_BLOCK) {
+            if (s_big_cnt[q] >= HOT_MIN_COUNT && s_big_key[q] < TAG_TOMB) {
+                const u32 pos = atomicAdd(&s_n, 1u);
+                if (pos < (u32)HOT_MAX) hot_next->key[pos] = s_big_key[q];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) hot_next->n = s_n < (u32)HOT_MAX ? s_n : (u32)HOT_MAX;
+        return;
+    }
+    const u32 lane = tid & 63u, w = tid >> 6;
+    const u32 nb = 1u << bk_log2;
+    const u32 nbt = nb + HOT_MAX;
+    const u32 wbase = blockIdx.x * PT_TILE + w * PT_WAVE_TILE;
+    uint4 raw[PT_STEPS];
+#pragma unroll
+    for (int u = 0; u < PT_STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        if (i < n) raw[u] = *reinterpret_cast<const uint4*>(hits + i);
+    }
+    hot_table_build(hot, seed, s_hot_key, s_hot_idx);
+    {
+        // bucket order in the partitioned arrays: hash buckets 0..nb-1, then the hot buckets
+        const u32 b0 = 3 * tid;
+        u32 c[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c[q] = b0 + q < nbt ? total[b0 + q] : 0u;
+        u32 all;
+        const u32 ex = block_excl_scan_1024(c[0] + c[1] + c[2], s_w, all);
+        u32 lo[3] = {ex, ex + c[0], ex + c[0] + c[1]};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (b0 + q < nbt) s_base[b0 + q] = lo[q] + hist[(size_t)blockIdx.x * nbt + b0 + q];
+        if (blockIdx.x == 0) {
+            u32 g[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) g[q] = (b0 + q < nb && c[q] >= BK_BIG) ? 1u : 0u;
+            u32 nbig;
+            u32 gx = block_excl_scan_1024(g[0] + g[1] + g[2], s_w, nbig);
+            const bool refuse = st->err != 0;  // k_bkt_hist rejected the batch: empty ranges, nothing applied
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const u32 b = b0 + q;
+                const uint2 r = refuse ? make_uint2(0, 0) : make_uint2(lo[q], lo[q] + c[q]);
+                if (b < nb) ranges[g[q] ? gx : nbig + (b - gx)] = r;
+                else if (b < nbt) hot_ranges[b - nb] = r;
+                gx += g[q];
+            }
+        }
+    }
+    for (u32 b = tid; b < nbt; b += PT_BLOCK) {
+#pragma unroll
+        for (int ww = 0; ww < PT_WAVES; ++ww) s_cnt[ww][b] = 0;
+    }
+    __syncthreads();
+    unsigned short rank[PT_STEPS];
+    unsigned short dig[PT_STEPS];
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int u = 0; u < PT_STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        const bool ok = i < n;
+        const u64 valid = __ballot(ok);
+        const u64 key = ((u64)raw[u].y << 32) | raw[u].x;
+        u32 d = 0;
+        if (ok) {
+            const u64 hh = fmix64(key ^ seed);
+            const int hi = hot_lookup(s_hot_key, s_hot_idx, key, hh);
+            d = hi >= 0 ? nb + (u32)hi : bucket_of_hash(hh, bk_log2);
+        }
+        const u64 m = match_digit(d, (bk_log2 > 6u ? bk_log2 : 6u) + 1u, valid);
+        u32 r = 0;
+        if (ok) {
+            const u32 c = s_cnt[w][d];
+            r = c + (u32)__popcll(m & lt);
+            if ((m & lt) == 0ull) s_cnt[w][d] = (unsigned short)(c + (u32)__popcll(m));
+        }
+        rank[u] = (unsigned short)r;
+        dig[u] = (unsigned short)d;
+    }
+    __syncthreads();
+    // wave-private counts -> exclusive offsets of the waves inside (tile, bucket)
+    for (u32 b = tid; b < nbt; b += PT_BLOCK) {
+        u32 acc = 0;
+#pragma unroll
+        for (int ww = 0; ww < PT_WAVES; ++ww) {
+            const u32 c = s_cnt[ww][b];
+            s_cnt[ww][b] = (unsigned short)acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PT_STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        if (i < n) {
+            const u32 d = dig[u];
+            const u32 dst = s_base[d] + s_cnt[w][d] + rank[u];
+            *reinterpret_cast<uint4*>(b_hits + dst) =
+                make_uint4(raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_apply
+// ---------------------------------------------------------------------------------------------
+constexpr int AP_BLOCK = 256;
+constexpr int AP_HPT = 2;                     // consecutive batch items per thread
+constexpr int AP_R = AP_BLOCK * AP_HPT;       // hits per decide/commit round
+constexpr int AP_WS = 4;                      // strips of AP_BLOCK hits per quick-path window
+constexpr int AP_W = AP_BLOCK * AP_WS;        // hits per window
+constexpr int AP_Q = 2048;                    // ring of deferred hits (< AP_R left over + one window)
+constexpr int ENT_LOG2 = 10;
+constexpr int ENT_N = 1 << ENT_LOG2;          // LDS cells per workgroup
+constexpr int ENT_KEEP = ENT_N * 3 / 4 - AP_R;  // rebuild the LDS cells before a round if more are live
+constexpr u32 EF_EXPIRED = 1u;   // the cell was expired when first read: the first admitted hit resets the window
+constexpr u32 EF_DIRTY = 2u;     // at least one hit admitted: the cell must be written back
+constexpr u32 EF_SLOW = 4u;      // this round: replay the entry's hits one by one
+constexpr u32 EF_BAD = 8u;       // a hit carried a limit id that is not the cell's / no cell
+constexpr u32 EF_COUNT_SHIFT = 8;  // bits 8..31: hits this entry has absorbed (hot entries survive a rebuild)
+constexpr u32 EF_HOT_MIN = 16;
+constexpr u32 ENT_NONE = 0xFFFFu;
+
+struct ApplyLds {
+    u64 key[ENT_N];
+    u64 run[ENT_N];    // value the next hit reads; for 0-second windows: the last admitted delta
+    u64 rsum[ENT_N];   // this round: sum of deltas
+    u64 cnt4[ENT_N];   // this round: hits per wave (4 x u16)
+    u32 slot[ENT_N];
+    u32 limit[ENT_N];  // the CELL's limit attribute
+    u32 dmax[ENT_N];   // this round: largest delta
+    u32 flags[ENT_N];
+    u32 queue[AP_Q];   // deferred hits (positions in the bucketed arrays), trace order
+    u32 h_delta[AP_R];
+    unsigned short h_ent[AP_R];
+    uint8_t h_verdict[AP_R];
+    u32 wcnt[AP_WS][4];
+    // hot-bucket workers only
+    u32 hot_lo[HOT_MAX], hot_hi[HOT_MAX], hot_chunk0[HOT_MAX + 1], hot_fast[HOT_MAX], hot_limit[HOT_MAX];
+    u64 hot_s[HOT_MAX], hot_room[HOT_MAX], hot_d[HOT_MAX];
+    u32 n_ent;
+    u32 any_slow;
+    u32 n_created;
+    u32 n_keep;
+};
+
+struct ApplyArgs {
+    Cell* table;
+    u32 log2cap;
+    u64 seed;
+    const BHit* b_hits;
+    const Hit* hits;  // the caller's batch: only read for the limit id of a key that has no cell yet
+    const LimitDev* limits;
+    u64 now;
+    uint8_t* verdict;
+    int32_t* first_limited;
+    Status* st;
+    u32 vmask;   // debug (RL_DEBUG_VMASK): AND-mask on the verdict index, 0xFFFFFFFF normally
+    u64* trace;  // debug (RL_APPLY_TRACE=1): per-workgroup phase timestamps, 16 per workgroup; else null
+};
+#define RL_STAMP(k)                                                                       \
+    do {                                                                                  \
+        if (A.trace && threadIdx.x == 0) A.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+    } while (0)
+
+// Write the dirty LDS cells back; optionally rebuild the LDS hash keeping only the hot entries.
+__device__ __forceinline__ void apply_commit(ApplyLds& S, const ApplyArgs& A, bool rebuild) {
+    constexpr int PER = ENT_N / AP_BLOCK;
+    u64 k_key[PER], k_run[PER];
+    u32 k_slot[PER], k_limit[PER], k_flags[PER];
+    bool keep[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 e = threadIdx.x + q * AP_BLOCK;
+        keep[q] = false;
+        const u64 key = S.key[e];
+        if (key == TAG_EMPTY) continue;
+        u32 f = S.flags[e];
+        if (f & EF_DIRTY) {
+            Cell* c = &A.table[S.slot[e]];
+            c->value = S.run[e];
+            if (f & EF_EXPIRED) c->expiry = A.now + A.limits[S.limit[e] & ~SIMPLE_FLAG].window_us;
+            // the window is open again — except a 0-second one, which is expired at every read
+            if (A.limits[S.limit[e] & ~SIMPLE_FLAG].window_us != 0) f &= ~EF_EXPIRED;
+            f &= ~EF_DIRTY;
+        }
+        if (rebuild && (f >> EF_COUNT_SHIFT) >= EF_HOT_MIN && !(f & EF_BAD)) {
+            keep[q] = true;
+            k_key[q] = key;
+            k_run[q] = S.run[e];
+            k_slot[q] = S.slot[e];
+            k_limit[q] = S.limit[e];
+            k_flags[q] = f;
+        }
+    }
+    if (!rebuild) return;
+    if (threadIdx.x == 0) S.n_keep = 0;
+    __syncthreads();
+    u32 nk = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) nk += keep[q] ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) nk += __shfl_down(nk, off);
+    if ((threadIdx.x & 63u) == 0 && nk) atomicAdd(&S.n_keep, nk);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 e = threadIdx.x + q * AP_BLOCK;
+        S.key[e] = TAG_EMPTY;
+        S.flags[e] = 0;
+    }
+    __syncthreads();
+    const bool reinsert = S.n_keep <= (u32)ENT_KEEP;
+    if (reinsert) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (!keep[q]) continue;
+            u32 e = (u32)(fmix64(k_key[q] ^ A.seed) >> 20) & (ENT_N - 1);
+            while (atomicCAS(&S.key[e], TAG_EMPTY, k_key[q]) != TAG_EMPTY) e = (e + 1) & (ENT_N - 1);
+            S.run[e] = k_run[q];
+            S.slot[e] = k_slot[q];
+            S.limit[e] = k_limit[q];
+            S.flags[e] = k_flags[q];
+        }
+    }
+    if (threadIdx.x == 0) S.n_ent = reinsert ? S.n_keep : 0u;
+    __syncthreads();
+}
+
+// One decide/commit round over up to AP_R hits given by their positions in the bucketed arrays:
+// position of item p is first + p (from_queue == false) or S.queue[(first + p) % AP_Q].
+__device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, bool from_queue, u32 first,
+                                            u32 n_items) {
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63u, w = tid >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    if (S.n_ent > (u32)ENT_KEEP) {  // block-uniform (read after the previous round's barrier)
+        __syncthreads();
+        apply_commit(S, A, true);
+    }
+    BHit h[AP_HPT];
+    u32 idx[AP_HPT], ent[AP_HPT], hslot[AP_HPT], climit[AP_HPT];
+    u64 ctag[AP_HPT], cvalue[AP_HPT], cexpiry[AP_HPT];
+    bool ok[AP_HPT], creator[AP_HPT], leader[AP_HPT];
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        const u32 p = tid * AP_HPT + u;
+        ok[u] = p < n_items;
+        creator[u] = leader[u] = false;
+        ent[u] = 0;
+        if (ok[u]) {
+            const u32 j = from_queue ? S.queue[(first + p) & (AP_Q - 1)] : first + p;
+            h[u] = load_bhit(A.b_hits, j);
+            idx[u] = h[u].idx_tag & 0xFFFFFFu;
+        }
+    }
+    // The home cell of every hit is fetched right away (tag+value, expiry, limit: one 64-byte line),
+    // overlapping the HBM latency with the LDS work of phase A; only the claimer of a new LDS cell
+    // consumes it.
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        if (!ok[u]) continue;
+        hslot[u] = slot_of(h[u].key, A.seed, A.log2cap);
+        const Cell* c = &A.table[hslot[u]];
+        const uint4 a = *reinterpret_cast<const uint4*>(c);
+        ctag[u] = ((u64)a.y << 32) | a.x;
+        cvalue[u] = ((u64)a.w << 32) | a.z;
+        cexpiry[u] = c->expiry;
+        climit[u] = c->limit;
+    }
+    RL_STAMP(2);
+    // ---- A: find or claim the key's LDS cell, add this hit to the round's aggregates ------------
+    u32 n_new = 0;
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        const u32 p = tid * AP_HPT + u;
+        if (!ok[u]) {
+            S.h_ent[p] = (unsigned short)ENT_NONE;
+            continue;
+        }
+        u32 e = (u32)(fmix64(h[u].key ^ A.seed) >> 20) & (ENT_N - 1);
+        for (;;) {
+            const u64 prev = atomicCAS(&S.key[e], TAG_EMPTY, h[u].key);
+            if (prev == TAG_EMPTY) {
+                creator[u] = true;
+                ++n_new;
+                break;
+            }
+            if (prev == h[u].key) break;
+            e = (e + 1) & (ENT_N - 1);
+        }
+        ent[u] = e;
+        atomicAdd(&S.rsum[e], (u64)h[u].delta);
+        atomicMax(&S.dmax[e], h[u].delta);
+        leader[u] = atomicAdd(&S.cnt4[e], 1ull << (16 * w)) == 0ull;
+        S.h_ent[p] = (unsigned short)e;
+        S.h_delta[p] = h[u].delta;
+    }
+    for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off);
+    if (lane == 0 && n_new) atomicAdd(&S.n_ent, n_new);
+    RL_STAMP(3);
+    // ---- B: the claimer of a new LDS cell resolves the counter cell -------------------------------
+    u32 created = 0;
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        if (!creator[u]) continue;
+        const u32 e = ent[u];
+        u32 slot = hslot[u];
+        u64 value = cvalue[u], expiry = cexpiry[u];
+        u32 cl = climit[u];
+        if (ctag[u] != h[u].key) {  // not at home: probe on (or create: in_memory.rs:122-127)
+            const u32 hl = A.hits[idx[u]].limit;
+            slot = probe_from<PM_CHECK>(A.table, A.log2cap, slot, ctag[u], h[u].key, hl, A.limits, A.now, A.st,
+                                        created);
+            value = 0;
+            expiry = 0;
+            cl = hl;
+            if (slot != SLOT_INVALID) {
+                const Cell* c = &A.table[slot];
+                value = c->value;
+                expiry = c->expiry;
+                cl = c->limit;
+            }
+        }
+        const bool expired = expiry <= A.now;
+        S.run[e] = expired ? 0ull : value;  // value_at(now), atomic_expiring_value.rs:19-24
+        S.slot[e] = slot;
+        S.limit[e] = cl;
+        S.flags[e] = (expired ? EF_EXPIRED : 0u) | (slot == SLOT_INVALID ? EF_BAD : 0u);
+    }
+    if (created) atomicAdd(&S.n_created, created);
+    RL_STAMP(4);
+    __syncthreads();
+    RL_STAMP(5);
+    // ---- C: verdicts -------------------------------------------------------------------------------
+    uint8_t v[AP_HPT];
+    bool need_rank[AP_HPT], slow[AP_HPT];
+    u64 room[AP_HPT];
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        v[u] = 1;
+        need_rank[u] = slow[u] = false;
+        room[u] = 0;
+        if (!ok[u]) continue;
+        const u32 e = ent[u];
+        if (limit_fold(S.limit[e]) != (h[u].idx_tag >> 24)) {
+            atomicOr(&S.flags[e], EF_BAD);
+            atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
+            continue;
+        }
+        const LimitDev Lu = A.limits[S.limit[e] & ~SIMPLE_FLAG];
+        const u64 run = S.run[e], sum = S.rsum[e], c4 = S.cnt4[e];
+        const u64 d = h[u].delta;
+        const u64 cnt = (c4 & 0xFFFFull) + ((c4 >> 16) & 0xFFFFull) + ((c4 >> 32) & 0xFFFFull) + (c4 >> 48);
+        u64 tot;
+        const bool ovf = __builtin_add_overflow(run, sum, &tot);
+        if (Lu.window_us == 0 || ovf) {
+            slow[u] = true;  // every read sees an expired cell / the sum wraps: replay
+        } else if (tot <= Lu.max_value) {
+            v[u] = 0;
+        } else if (run + d > Lu.max_value) {
+            v[u] = 1;
+        } else if (sum == cnt * (u64)S.dmax[e]) {  // all deltas of the round equal (and > 0 here)
+            need_rank[u] = true;
+            room[u] = (Lu.max_value - run) / d;
+        } else {
+            slow[u] = true;
+        }
+        if (slow[u]) {
+            atomicOr(&S.flags[e], EF_SLOW);
+            S.any_slow = 1;
+        }
+    }
+    // trace-order rank among the round's hits on the same key: hits of earlier waves, then
+    // earlier lanes of this wave, then earlier hits of this lane.
+    for (;;) {
+        bool have = false;
+        u32 my_e = 0;
+#pragma unroll
+        for (int u = AP_HPT - 1; u >= 0; --u)
+            if (need_rank[u]) {
+                have = true;
+                my_e = ent[u];
+            }
+        const u64 pend = __ballot(have);
+        if (!pend) break;
+        const u32 e0 = __shfl(my_e, __ffsll((long long)pend) - 1);
+        u32 before_lane = 0;
+#pragma unroll
+        for (int u = 0; u < AP_HPT; ++u) before_lane += (u32)__popcll(__ballot(ok[u] && ent[u] == e0) & lt);
+        const u64 c4 = S.cnt4[e0];
+        u64 pre = 0;
+        for (u32 ww = 0; ww < w; ++ww) pre += (c4 >> (16 * ww)) & 0xFFFFull;
+        u32 mine = 0;
+#pragma unroll
+        for (int u = 0; u < AP_HPT; ++u) {
+            if (need_rank[u] && ent[u] == e0) {
+                v[u] = (pre + before_lane + mine) < room[u] ? 0 : 1;
+                need_rank[u] = false;
+            }
+            if (ok[u] && ent[u] == e0) ++mine;
+        }
+    }
+    __syncthreads();
+    RL_STAMP(6);
+    // ---- slow entries: one lane replays the round in trace order, reference arithmetic -----------
+    if (S.any_slow) {
+        if (tid == 0) {
+            for (u32 p = 0; p < n_items; ++p) {
+                const u32 e = S.h_ent[p];
+                const u32 f = S.flags[e];
+                if (!(f & EF_SLOW) || (f & EF_BAD)) continue;
+                const LimitDev Le = A.limits[S.limit[e] & ~SIMPLE_FLAG];
+                const u64 d = S.h_delta[p];
+                const u64 cur = Le.window_us == 0 ? 0ull : S.run[e];
+                const u64 sum = cur + d;  // wraps like the reference's release build (in_memory.rs:88)
+                const bool adm = sum <= Le.max_value;
+                if (adm) {
+                    S.run[e] = Le.window_us == 0 ? d : sum;
+                    S.flags[e] = f | EF_DIRTY | (Le.window_us == 0 ? EF_EXPIRED : 0u);
+                }
+                S.h_verdict[p] = adm ? 0 : 1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < AP_HPT; ++u)
+            if (slow[u]) v[u] = S.h_verdict[tid * AP_HPT + u];
+    }
+    // ---- D: the round's first arriver of each key folds the round into `run` --------------------
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        if (!ok[u]) continue;
+        const u32 i = idx[u];
+        A.verdict[i & A.vmask] = v[u];
+        if (A.first_limited) A.first_limited[i] = v[u] ? (int32_t)i : -1;
+        if (!leader[u]) continue;
+        const u32 e = ent[u];
+        u32 f = S.flags[e];
+        const u64 c4 = S.cnt4[e];
+        const u64 cnt = (c4 & 0xFFFFull) + ((c4 >> 16) & 0xFFFFull) + ((c4 >> 32) & 0xFFFFull) + (c4 >> 48);
+        if (!(f & (EF_SLOW | EF_BAD))) {
+            const LimitDev Le = A.limits[S.limit[e] & ~SIMPLE_FLAG];
+            const u64 run = S.run[e], sum = S.rsum[e];
+            const u64 dm = S.dmax[e];
+            if (run + sum <= Le.max_value) {  // no overflow here: overflowing rounds are slow
+                S.run[e] = run + sum;
+                f |= EF_DIRTY;
+            } else if (sum == cnt * dm && run + dm <= Le.max_value) {
+                const u64 rm = (Le.max_value - run) / dm;
+                const u64 n_adm = cnt < rm ? cnt : rm;
+                if (n_adm) {
+                    S.run[e] = run + n_adm * dm;
+                    f |= EF_DIRTY;
+                }
+            }
+        }
+        const u32 seen = (f >> EF_COUNT_SHIFT) + (u32)cnt;
+        f = (f & 0xFFu & ~EF_SLOW) | ((seen > 0xFFFFFFu ? 0xFFFFFFu : seen) << EF_COUNT_SHIFT);
+        S.flags[e] = f;
+        S.rsum[e] = 0;
+        S.cnt4[e] = 0;
+        S.dmax[e] = 0;
+    }
+    if (tid == 0) S.any_slow = 0;
+    __syncthreads();
+    RL_STAMP(7);
+}
+
+// A whole bucket [lo, hi) of the partitioned batch, in trace order, by one workgroup.
+__device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u32 lo, u32 hi) {
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63u, w = tid >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    for (u32 e = tid; e < ENT_N; e += AP_BLOCK) {
+        S.key[e] = TAG_EMPTY;
+        S.rsum[e] = 0;
+        S.cnt4[e] = 0;
+        S.dmax[e] = 0;
+        S.flags[e] = 0;
+    }
+    if (tid == 0) {
+        S.n_ent = 0;
+        S.any_slow = 0;
+    }
+    __syncthreads();
+    RL_STAMP(1);
+
+    // The first AP_R hits of the bucket go straight through a decide/commit round.  In a bucket made
+    // long by a frequent key this also brings that key's cell into LDS.
+    apply_round(S, A, false, lo, (hi - lo) < (u32)AP_R ? (hi - lo) : (u32)AP_R);
+
+    // The rest of a long bucket streams through in windows: a hit whose key is already in LDS and
+    // saturated (run + delta > max, and run can only grow) is denied on the spot — valid in any
+    // order; everything else is deferred, in trace order, to a ring of positions that is drained in
+    // decide/commit rounds.
+    u32 q_head = 0, q_tail = 0;
+    for (u32 wbase = lo + AP_R; wbase < hi; wbase += AP_W) {
+        bool unres[AP_WS];
+        u32 pos[AP_WS];
+#pragma unroll
+        for (int u = 0; u < AP_WS; ++u) {
+            const u32 j = wbase + u * AP_BLOCK + tid;
+            pos[u] = j;
+            unres[u] = false;
+            if (j >= hi) continue;
+            const BHit h = load_bhit(A.b_hits, j);
+            const u32 i = h.idx_tag & 0xFFFFFFu;
+            unres[u] = true;
+            u32 e = (u32)(fmix64(h.key ^ A.seed) >> 20) & (ENT_N - 1);
+            for (;;) {
+                const u64 k = S.key[e];
+                if (k == h.key) {
+                    const u64 run = S.run[e];
+                    const u32 f = S.flags[e];
+                    const u32 cl = S.limit[e];
+                    const LimitDev L = A.limits[cl & ~SIMPLE_FLAG];
+                    if (limit_fold(cl) == (h.idx_tag >> 24) && !(f & EF_BAD) && L.window_us != 0 && run < (1ull << 63) &&
+                        run + (u64)h.delta > L.max_value) {
+                        A.verdict[i & A.vmask] = 1;
+                        if (A.first_limited) A.first_limited[i] = (int32_t)i;
+                        unres[u] = false;
+                    }
+                    break;
+                }
+                if (k == TAG_EMPTY) break;
+                e = (e + 1) & (ENT_N - 1);
+            }
+        }
+        // stable compaction of the unresolved hits into the ring: order (strip, wave, lane)
+        u64 bal[AP_WS];
+#pragma unroll
+        for (int u = 0; u < AP_WS; ++u) {
+            bal[u] = __ballot(unres[u]);
+            if (lane == 0) S.wcnt[u][w] = (u32)__popcll(bal[u]);
+        }
+        __syncthreads();
+        u32 total = 0;
+#pragma unroll
+        for (int u = 0; u < AP_WS; ++u) {
+            u32 before = 0, strip_total = 0;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const u32 c = S.wcnt[u][ww];
+                if (ww < (int)w) before += c;
+                strip_total += c;
+            }
+            if (unres[u]) S.queue[(q_tail + total + before + (u32)__popcll(bal[u] & lt)) & (AP_Q - 1)] = pos[u];
+            total += strip_total;
+        }
+        q_tail += total;
+        __syncthreads();
+        while (q_tail - q_head >= (u32)AP_R) {
+            apply_round(S, A, true, q_head, AP_R);
+            q_head += AP_R;
+        }
+    }
+    if (q_tail != q_head) apply_round(S, A, true, q_head, q_tail - q_head);
+    RL_STAMP(8);
+    apply_commit(S, A, false);
+    RL_STAMP(9);
+    __syncthreads();  // the LDS cells may be reused for another bucket
+}
+
+// A hot key's bucket holds one key, in trace order: a hit's position in the bucket is its rank on
+// the key.  With one delta value d > 0 for the whole bucket the reference admits exactly the first
+// (max - s) / d hits (s = value_at(now): in_memory.rs:259-264 with atomic_expiring_value.rs:36-42
+// applied after each admission), so every hit is decided from its position alone, by any number
+// of workgroups.  Buckets that do not fit that form (mixed deltas, 0-second window, values near
+// 2^64, a stale hot set that made two keys share...) are replayed by one worker through
+// apply_bucket, which is exact for everything.
+constexpr int HOT_BLOCKS = 128;
+constexpr int HOT_CHUNK = AP_BLOCK * 4;
+
+__device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 worker,
+                                          const uint2* __restrict__ hot_ranges,
+                                          const HotState* __restrict__ hot_state,
+                                          const BatchScratch* __restrict__ bs) {
+    const u32 tid = threadIdx.x;
+    if (tid < HOT_MAX) {
+        const uint2 r = hot_ranges[tid];
+        const u32 cnt = r.y - r.x;
+        u32 fast = 0, limit = 0;
+        u64 s = 0, room = 0, d = 0;
+        if (cnt) {
+            const HotState hs = hot_state[tid];
+            const u32 dmax = bs->hot_dmax[tid], dmin = ~bs->hot_ndmin[tid];
+            limit = (hs.flags & HS_FOUND) ? hs.climit : A.hits[A.b_hits[r.x].idx_tag & 0xFFFFFFu].limit;
+            const LimitDev L = A.limits[limit & ~SIMPLE_FLAG];
+            s = hs.s;
+            d = dmax;
+            if (dmin == dmax && L.window_us != 0 && s < (1ull << 62) &&
+                ((hs.flags & HS_FOUND) || !(limit & SIMPLE_FLAG))) {
+                fast = 1;
+                room = s > L.max_value ? 0ull : (d ? (L.max_value - s) / d : ~0ull);
+            }
+        }
+        S.hot_lo[tid] = r.x;
+        S.hot_hi[tid] = r.y;
+        S.hot_fast[tid] = fast;
+        S.hot_limit[tid] = limit;
+        S.hot_s[tid] = s;
+        S.hot_room[tid] = room;
+        S.hot_d[tid] = d;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 acc = 0;
+        for (int hk = 0; hk < HOT_MAX; ++hk) {
+            S.hot_chunk0[hk] = acc;
+            if (S.hot_fast[hk]) acc += (S.hot_hi[hk] - S.hot_lo[hk] + HOT_CHUNK - 1) / HOT_CHUNK;
+        }
+        S.hot_chunk0[HOT_MAX] = acc;
+    }
+    __syncthreads();
+    // ---- fast buckets: chunks of HOT_CHUNK hits, grid-strided over the workers --------------------
+    const u32 n_chunks = S.hot_chunk0[HOT_MAX];
+    for (u32 c = worker; c < n_chunks; c += HOT_BLOCKS) {
+        int hk = 0;
+        while (hk + 1 < HOT_MAX && (S.hot_chunk0[hk + 1] <= c || !S.hot_fast[hk])) ++hk;
+        const u32 lo = S.hot_lo[hk], hi = S.hot_hi[hk];
+        const u32 first = lo + (c - S.hot_chunk0[hk]) * HOT_CHUNK;
+        const u64 room = S.hot_room[hk];
+        const u32 limit = S.hot_limit[hk];
+#pragma unroll
+        for (int u = 0; u < HOT_CHUNK / AP_BLOCK; ++u) {
+            const u32 j = first + u * AP_BLOCK + tid;
+            if (j >= hi) continue;
+            const BHit h = load_bhit(A.b_hits, j);
+            const u32 i = h.idx_tag & 0xFFFFFFu;
+            uint8_t v = (u64)(j - lo) < room ? 0 : 1;
+            if ((h.idx_tag >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
+                atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
+                v = 1;
+            }
+            A.verdict[i & A.vmask] = v;
+            if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
+        }
+        if (first == lo && tid == 0) {
+            // the bucket's first chunk also applies AtomicExpiringValue::update for the admitted hits
+            const HotState hs = *(&hot_state[hk]);
+            const LimitDev L = A.limits[limit & ~SIMPLE_FLAG];
+            const u64 cnt = hi - lo;
+            const u64 n_adm = cnt < room ? cnt : room;
+            u32 slot = hs.slot;
+            bool expired = (hs.flags & HS_EXPIRED) != 0;
+            if (slot == SLOT_INVALID) {  // first touch creates the cell (in_memory.rs:122-127), verdict or not
+                u32 created = 0;
+                const u64 key = A.b_hits[lo].key;
+                slot = slot_of(key, A.seed, A.log2cap);
+                slot = probe_from<PM_CHECK>(A.table, A.log2cap, slot, A.table[slot].tag, key, limit, A.limits,
+                                            A.now, A.st, created);
+                if (created) atomicAdd(&A.st->n_inserted, created);
+                expired = false;
+            }
+            if (n_adm && slot != SLOT_INVALID) {
+                Cell* cell = &A.table[slot];
+                cell->value = S.hot_s[hk] + n_adm * S.hot_d[hk];
+                if (expired) cell->expiry = A.now + L.window_us;
+            }
+        }
+    }
+    // ---- everything else: replayed by one worker per bucket ---------------------------------------
+    for (int hk = 0; hk < HOT_MAX; ++hk) {
+        if (S.hot_fast[hk] || S.hot_hi[hk] == S.hot_lo[hk] || (u32)hk % HOT_BLOCKS != worker) continue;
+        if (tid == 0) S.n_created = 0;
+        const u32 lo = S.hot_lo[hk], hi = S.hot_hi[hk];
+        apply_bucket(S, A, lo, hi);
+        if (tid == 0 && S.n_created) atomicAdd(&A.st->n_inserted, S.n_created);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
+    Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits,
+    const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
+    const uint2* __restrict__ hot_ranges, const HotState* __restrict__ hot_state,
+    const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
+    int32_t* __restrict__ first_limited, BatchScratch* bs, u32 vmask, u64* trace) {
+    __shared__ ApplyLds S;
+    if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
+    ApplyArgs A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st, vmask, trace};
+    if (blockIdx.x >= nb) {
+        // k_bkt_hist refused the batch: the hot ranges are empty too, nothing is applied
+        apply_hot(S, A, blockIdx.x - nb, hot_ranges, hot_state, bs);
+        return;
+    }
+    const uint2 range = ranges[blockIdx.x];
+    if (range.x == range.y) return;
+    if (threadIdx.x == 0) S.n_created = 0;
+    apply_bucket(S, A, range.x, range.y);
+    if (threadIdx.x == 0) {
+        if (S.n_created) atomicAdd(&bs->st.n_inserted, S.n_created);
+        if (trace) trace[(size_t)blockIdx.x * 16 + 10] = range.y - range.x;
+    }
+}
+
+}  // namespace rl

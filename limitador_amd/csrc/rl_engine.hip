@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -21,6 +22,7 @@
 #include "rl_cell.hpp"
 #include "rl_kernels.hpp"
 #include "rl_ordered.hpp"
+#include "rl_bucket.hpp"
 #include "rl_general.hpp"
 #include "rl_route.hpp"
 
@@ -74,12 +76,26 @@ struct rl_engine {
     unsigned long long* h_total = nullptr; // pinned
     // routing scratch
     u32* d_route_cnt = nullptr;
+    // bucketed hot path (rl_bucket.hpp)
+    bool legacy_k1 = false;   // RL_K1_PATH=legacy: the first-generation probe/decide/commit pipeline
+    u32 bk_log2_cfg = BK_LOG2_MAX;     // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX)
+    u32 bk_tiles_max = 0;
+    u32* d_bk_hist = nullptr;
+    u32* d_bk_total = nullptr;
+    uint2* d_bk_ranges = nullptr;
+    uint2* d_hot_ranges = nullptr;
+    HotSet* d_hot = nullptr;        // [2]: the set used by this batch, the set it picks for the next
+    u32 hot_cur = 0;
+    HotState* d_hot_state = nullptr;
+    u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
+    u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
+    BHit* d_bk_hits = nullptr;
 
     rl_stats_t stats{};
 
     bool timing = false;
     hipEvent_t ev[8]{};
-    double ms_probe = 0, ms_decide = 0, ms_commit = 0, ms_ordered = 0;
+    double ms_slot[RL_TIMING_SLOTS]{};
     u64 timed_launches = 0;
 };
 
@@ -192,8 +208,9 @@ int run_ordered(rl_engine* e, const Hit* d_hits, u32 n_ord, u64 now, uint8_t* d_
     return RL_OK;
 }
 
-// check_and_update for single-counter requests, all pointers on the device.
-int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
+// check_and_update for single-counter requests, all pointers on the device: first-generation
+// pipeline (kept for A/B measurement, RL_K1_PATH=legacy).
+int run_check_k1_legacy(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
     int rc = check_room(e, n);
     if (rc) return rc;
     const bool t = e->timing;
@@ -235,15 +252,108 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
         HIP_TRY(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
         HIP_TRY(e, hipEventElapsedTime(&c, e->ev[3], e->ev[4]));
         HIP_TRY(e, hipEventElapsedTime(&d, e->ev[4], e->ev[5]));
-        e->ms_probe += a;
-        e->ms_decide += b;
-        e->ms_ordered += c;
-        e->ms_commit += d;
+        e->ms_slot[RL_T_LEGACY_PROBE] += a;
+        e->ms_slot[RL_T_LEGACY_DECIDE] += b;
+        e->ms_slot[RL_T_LEGACY_ORDERED] += c;
+        e->ms_slot[RL_T_LEGACY_COMMIT] += d;
         e->timed_launches++;
     }
     e->stats.batches++;
     e->stats.hits += n;
     return RL_OK;
+}
+
+// check_and_update for single-counter requests, all pointers on the device: the bucketed
+// single-pass path (rl_bucket.hpp).  Five launches, one host synchronisation at the end.
+int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
+    int rc = check_room(e, n);
+    if (rc) return rc;
+    // k_bkt_apply commits as it goes, so a table that fills up mid-batch (RL_ERR_TABLE_FULL from the
+    // probe loop) leaves the batch partially applied; keep a margin so that only a batch bringing
+    // more than capacity/4 NEW keys into an almost full table can get there.
+    {
+        const u64 used = e->live + e->tombs, inc = n < e->cap / 4 ? n : e->cap / 4;
+        if (used + inc > e->cap - e->cap / 16)
+            return fail(e, RL_ERR_TABLE_FULL,
+                        "batch of %u hits could push the table past 15/16 occupancy (live=%llu tombstones=%llu "
+                        "capacity=%llu): sweep, compact or create a larger engine",
+                        n, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
+    }
+    const bool t = e->timing;
+    u32 bk_log2 = ceil_log2(cdiv(n, 384));
+    if (bk_log2 > e->bk_log2_cfg) bk_log2 = e->bk_log2_cfg;
+    const u32 nb = 1u << bk_log2;
+    const u32 ntiles = cdiv(n, PT_TILE);
+    const u32 nbt = nb + HOT_MAX;
+    BatchScratch* bs = reinterpret_cast<BatchScratch*>(e->d_status);
+    const HotSet* hot = e->d_hot + e->hot_cur;
+    HotSet* hot_next = e->d_hot + (e->hot_cur ^ 1u);
+    e->hot_cur ^= 1u;
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(BatchScratch), e->stream));
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+    k_bkt_hist<<<ntiles, PT_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits,
+                                                   (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot);
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
+    k_bkt_scan<<<cdiv(nbt, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
+    k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
+                                                          hot, e->d_bk_hits, e->d_bk_ranges, e->d_hot_ranges,
+                                                          &bs->st, e->table, e->log2cap, e->d_limits, now, ntiles,
+                                                          e->d_hot_state, hot_next);
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream));
+    k_bkt_apply<<<nb + HOT_BLOCKS, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
+                                                             e->d_bk_ranges, nb, e->d_hot_ranges, e->d_hot_state,
+                                                             e->d_limits, now, d_verdict, d_first, bs,
+                                                             e->dbg_vmask, e->d_bk_trace);
+    if (t) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream));
+    HIP_TRY(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    e->live += e->h_status->n_inserted;
+    if (e->h_status->err) return status_to_error(e, e->h_status->err);
+    if (e->d_bk_trace && getenv("RL_APPLY_TRACE_DUMP")) {
+        std::vector<u64> tr((size_t)nb * 16);
+        HIP_TRY(e, hipMemcpy(tr.data(), e->d_bk_trace, tr.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        u64 t_min = ~0ull, t_max = 0;
+        double acc[10] = {0};
+        u32 used = 0;
+        u64 longest = 0, longest_n = 0;
+        for (u32 b = 0; b < nb; ++b) {
+            const u64* r = &tr[(size_t)b * 16];
+            if (r[9] == 0 || r[10] == 0) continue;
+            ++used;
+            if (r[0] < t_min) t_min = r[0];
+            if (r[9] > t_max) t_max = r[9];
+            for (int q = 1; q <= 9; ++q) acc[q] += (double)(r[q] - r[q - 1]);
+            if (r[9] - r[0] > longest) {
+                longest = r[9] - r[0];
+                longest_n = r[10];
+            }
+        }
+        fprintf(stderr, "[apply trace] blocks=%u span=%.2fus longest=%.2fus(%llu hits) avg us:", used,
+                (double)(t_max - t_min) * 0.01, (double)longest * 0.01, (unsigned long long)longest_n);
+        const char* names[10] = {"", "init", "load", "A", "B", "syncB", "C", "D", "rest", "commit"};
+        for (int q = 1; q <= 9; ++q) fprintf(stderr, " %s=%.2f", names[q], used ? acc[q] / used * 0.01 : 0.0);
+        fprintf(stderr, "\n");
+        HIP_TRY(e, hipMemset(e->d_bk_trace, 0, tr.size() * sizeof(u64)));
+    }
+    if (t) {
+        float ms[4] = {0, 0, 0, 0};
+        for (int q = 0; q < 4; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], e->ev[q], e->ev[q + 1]));
+        e->ms_slot[RL_T_HIST] += ms[0];
+        e->ms_slot[RL_T_SCAN] += ms[1];
+        e->ms_slot[RL_T_SCATTER] += ms[2];
+        e->ms_slot[RL_T_APPLY] += ms[3];
+        e->timed_launches++;
+    }
+    e->stats.batches++;
+    e->stats.hits += n;
+    return RL_OK;
+}
+
+int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
+    return e->legacy_k1 ? run_check_k1_legacy(e, d_hits, n, now, d_verdict, d_first)
+                        : run_check_k1_bucketed(e, d_hits, n, now, d_verdict, d_first);
 }
 
 // check_and_update in its general form (rl_general.hpp): multi-counter requests and/or
@@ -407,6 +517,12 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->max_batch = cfg->max_batch_hits ? cfg->max_batch_hits : (1u << 20);
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
+    if (const char* v = getenv("RL_K1_PATH")) e->legacy_k1 = strcmp(v, "legacy") == 0;
+    if (const char* v = getenv("RL_DEBUG_VMASK")) e->dbg_vmask = (u32)strtoul(v, nullptr, 0);
+    if (const char* v = getenv("RL_BUCKET_LOG2")) {
+        const long b = strtol(v, nullptr, 10);
+        if (b >= 0 && b <= BK_LOG2_MAX) e->bk_log2_cfg = (u32)b;
+    }
     e->log2cap = ceil_log2(cfg->capacity_cells < 1024 ? 1024 : cfg->capacity_cells);
     if (e->log2cap > 31) {
         delete e;
@@ -440,8 +556,23 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_scan, mb * sizeof(Contrib));
     ALLOC(e->d_pass, mb);
     ALLOC(e->d_admitted, mb);
-    ALLOC(e->d_status, sizeof(Status));
+    ALLOC(e->d_status, sizeof(BatchScratch));
     ALLOC(e->d_total, sizeof(unsigned long long));
+    e->bk_tiles_max = cdiv(mb, PT_TILE) + 1;
+    ALLOC(e->d_bk_hist, (size_t)BKT_MAX * e->bk_tiles_max * sizeof(u32));
+    ALLOC(e->d_bk_total, (size_t)BKT_MAX * sizeof(u32));
+    ALLOC(e->d_bk_ranges, (size_t)BK_MAX * sizeof(uint2));
+    ALLOC(e->d_hot_ranges, (size_t)HOT_MAX * sizeof(uint2));
+    ALLOC(e->d_hot, 2 * sizeof(HotSet));
+    if (hipMemset(e->d_hot, 0, 2 * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_hot_state, (size_t)HOT_MAX * sizeof(HotState));
+    if (const char* v = getenv("RL_APPLY_TRACE"))
+        if (v[0] == '1') {
+            ALLOC(e->d_bk_trace, (size_t)(BK_MAX + HOT_BLOCKS) * 16 * sizeof(u64));
+            if (hipMemset(e->d_bk_trace, 0, (size_t)(BK_MAX + HOT_BLOCKS) * 16 * sizeof(u64)) != hipSuccess)
+                return bail(RL_ERR_DEVICE);
+        }
+    ALLOC(e->d_bk_hits, mb * sizeof(BHit));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
     size_t tmp = 0;
     if (rocprim::radix_sort_keys(nullptr, tmp, e->d_keys_a, e->d_keys_b, mb, 0u, 64u, e->stream) != hipSuccess)
@@ -472,7 +603,9 @@ void rl_engine_destroy(rl_engine* e) {
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
                     e->d_remaining, e->d_expires, e->d_hit_slot, e->d_ord_list, e->d_keys_a,  e->d_keys_b,
                     e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
-                    e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp};
+                    e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp,
+                    e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_trace,
+                    e->d_hot_ranges, e->d_hot,     e->d_hot_state};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -757,17 +890,14 @@ int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
     return RL_OK;
 }
 
-int32_t rl_kernel_timing_read(rl_engine* e, double* ms_probe, double* ms_decide, double* ms_commit,
-                              double* ms_ordered, uint64_t* launches, int32_t reset) {
+int32_t rl_kernel_timing_read(rl_engine* e, double* ms, uint64_t* launches, int32_t reset) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (ms_probe) *ms_probe = e->ms_probe;
-    if (ms_decide) *ms_decide = e->ms_decide;
-    if (ms_commit) *ms_commit = e->ms_commit;
-    if (ms_ordered) *ms_ordered = e->ms_ordered;
+    if (ms)
+        for (int q = 0; q < RL_TIMING_SLOTS; ++q) ms[q] = e->ms_slot[q];
     if (launches) *launches = e->timed_launches;
     if (reset) {
-        e->ms_probe = e->ms_decide = e->ms_commit = e->ms_ordered = 0;
+        for (auto& v : e->ms_slot) v = 0;
         e->timed_launches = 0;
     }
     return RL_OK;

@@ -183,10 +183,12 @@ class Engine:
     def kernel_timing(self, enable=True):
         self._check(self._lib.rl_kernel_timing(self._h, int(bool(enable))))
 
+    TIMING_SLOTS = ("hist", "scan", "scatter", "apply", "legacy_probe", "legacy_decide", "legacy_ordered",
+                    "legacy_commit")  # RL_T_* of include/rl_engine.h
+
     def kernel_timing_read(self, reset=True):
-        a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        """{"ms": {slot: accumulated milliseconds}, "launches": timed batches} since the last reset."""
+        ms = (C.c_double * len(self.TIMING_SLOTS))()
         n = C.c_uint64()
-        self._check(self._lib.rl_kernel_timing_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d),
-                                                     C.byref(n), int(bool(reset))))
-        return {"ms_probe": a.value, "ms_decide": b.value, "ms_commit": c.value, "ms_ordered": d.value,
-                "launches": n.value}
+        self._check(self._lib.rl_kernel_timing_read(self._h, ms, C.byref(n), int(bool(reset))))
+        return {"ms": dict(zip(self.TIMING_SLOTS, list(ms))), "launches": n.value}
