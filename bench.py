@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1_000_000, help="hits per GPU per step")
     ap.add_argument("--zipf", type=float, default=0.99, help="0 => uniform keys")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--cap-mult", type=float, default=1.0, help="scale the table capacity (experiments)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the routed (all-to-all) data path even with one rank (exercises the N>1 code on one GPU)")
     return ap.parse_args()
@@ -107,7 +108,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_keys_total = args.keys * world
-    cap = 1 << (int(n_keys_total / world * 2.2 - 1).bit_length())
+    cap = 1 << (int(n_keys_total / world * 2.2 * args.cap_mult - 1).bit_length())
     max_batch = int(args.batch * 2) if sharded else args.batch
     eng = Engine(capacity_cells=cap, max_batch_hits=max_batch, device=local_rank)
     eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])

@@ -29,7 +29,7 @@ namespace rl {
 
 constexpr int BK_LOG2_MAX = 11;
 constexpr int BK_MAX = 1 << BK_LOG2_MAX;
-constexpr int HOT_MAX = 64;                   // keys that get a bucket of their own
+constexpr int HOT_MAX = 128;                  // keys that get a bucket of their own
 constexpr int BKT_MAX = BK_MAX + HOT_MAX;     // hash buckets + hot-key buckets
 constexpr int PT_BLOCK = 1024;                // 16 waves per workgroup
 constexpr int PT_WAVES = PT_BLOCK / 64;
@@ -37,16 +37,18 @@ constexpr int PT_STEPS = 4;                   // 64-hit steps per wave
 constexpr int PT_WAVE_TILE = 64 * PT_STEPS;   // contiguous hits owned by one wave
 constexpr int PT_TILE = PT_WAVES * PT_WAVE_TILE;  // hits per workgroup (4096)
 constexpr u32 BK_BIG = 1024;                  // hash buckets at least this large are processed first
-constexpr int HOT_SAMPLE = 2048;              // hits sampled per batch to find the next batch's hot keys
-constexpr int HOT_SLOTS = 4096;
-constexpr u32 HOT_MIN_COUNT = 4;              // sampled hits that make a key hot (>= ~0.2 % of the batch)
-constexpr int HOT_HASH = 128;                 // LDS lookup table of the current hot set
+constexpr int HOT_CHUNK = 1024;              // hits per work item of a hot bucket
+constexpr u32 HOT_PROMOTE = 512;              // hits in one batch that make a key hot for the next batch
+constexpr u32 HOT_KEEP = 256;                 // hits in one batch that keep a hot key hot
+constexpr int HOT_HASH = 256;                 // LDS lookup table of the current hot set
 
 // Keys that took a large share of the PREVIOUS batch ("hot": a Zipf head, a simple limit every
 // request of a namespace hits).  Each gets a bucket to itself, so the stable partition leaves the
 // key's hits contiguous and in trace order: position in the bucket == the hit's rank on the key.
 // Any stale or arbitrary set is valid — the set only has to be the same in every kernel of one
-// batch; it decides which code path a key takes, never a verdict.
+// batch; it decides which code path a key takes, never a verdict.  k_bkt_apply builds the next
+// batch's set from exact counts: hot keys that still got HOT_KEEP hits, plus every key of a hash
+// bucket that absorbed HOT_PROMOTE hits (a traffic shift costs one batch of long buckets).
 struct HotSet {
     u32 n;
     u32 pad;
@@ -67,6 +69,20 @@ struct BatchScratch {
     Status st;
     u32 hot_dmax[HOT_MAX];
     u32 hot_ndmin[HOT_MAX];
+    u32 hot_limit[HOT_MAX];  // the limit id one of the key's hits carried
+};
+// What k_bkt_apply needs to decide a hot key's bucket, prepared once per batch by k_bkt_scatter.
+struct HotParam {
+    u32 lo, hi;   // the bucket's range in the partitioned batch
+    u32 fast;     // decided from positions (see apply_hot); else replayed by one workgroup
+    u32 limit;    // limit id | SIMPLE
+    u64 s;        // value_at(now) before the batch
+    u64 room;     // hits the reference admits: the first `room` of the bucket
+    u64 d;        // the bucket's delta (fast only)
+    u32 chunk0;   // HOT_CHUNK-sized chunks of the fast buckets before this one
+    u32 slot;     // the key's cell, SLOT_INVALID if it has none yet
+    u32 expired;  // the cell was expired: the first admitted hit resets the window
+    u32 pad;
 };
 
 // Record of the partitioned batch: the hit's key and delta, its index in the caller's batch (where
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     __shared__ u32 s_hist[BKT_MAX];
     __shared__ u64 s_hot_key[HOT_HASH];
     __shared__ u32 s_hot_idx[HOT_HASH];
-    __shared__ u32 s_dmax[HOT_MAX], s_ndmin[HOT_MAX];
+    __shared__ u32 s_dmax[HOT_MAX], s_ndmin[HOT_MAX], s_hlimit[HOT_MAX];
     const u32 tid = threadIdx.x;
     Status* st = &bs->st;
     const u32 nb = 1u << bk_log2;
@@ -173,8 +189,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
             const int hi = hot_lookup(s_hot_key, s_hot_idx, h[r].key, hh);
             if (hi >= 0) {
                 atomicAdd(&s_hist[nb + hi], 1u);
-                atomicMax(&s_dmax[hi], h[r].delta);
-                atomicMax(&s_ndmin[hi], ~h[r].delta);
+                // extrema of the key's deltas: read first, so that after the first few hits of a key
+                // nothing but the count is an atomic on its (contended) LDS words
+                const u32 d = h[r].delta;
+                if (d > s_dmax[hi]) atomicMax(&s_dmax[hi], d);
+                if (~d > s_ndmin[hi]) atomicMax(&s_ndmin[hi], ~d);
+                s_hlimit[hi] = h[r].limit;
             } else {
                 atomicAdd(&s_hist[bucket_of_hash(hh, bk_log2)], 1u);
             }
@@ -186,6 +206,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     if (tid < HOT_MAX && s_hist[nb + tid]) {
         atomicMax(&bs->hot_dmax[tid], s_dmax[tid]);
         atomicMax(&bs->hot_ndmin[tid], s_ndmin[tid]);
+        bs->hot_limit[tid] = s_hlimit[tid];
     }
 }
 
@@ -276,71 +297,86 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                                                           const u32* __restrict__ total,
                                                           const HotSet* __restrict__ hot,
                                                           BHit* __restrict__ b_hits,
-                                                          uint2* __restrict__ ranges,
-                                                          uint2* __restrict__ hot_ranges, Status* st,
+                                                          uint2* __restrict__ ranges, Status* st,
                                                           const Cell* __restrict__ table, u32 log2cap,
                                                           const LimitDev* __restrict__ limits, u64 now,
-                                                          u32 ntiles, HotState* __restrict__ hot_state,
-                                                          HotSet* __restrict__ hot_next) {
+                                                          u32 ntiles, HotParam* __restrict__ hot_param,
+                                                          HotSet* __restrict__ hot_next,
+                                                          const BatchScratch* __restrict__ bs) {
     __shared__ __align__(16) unsigned short s_cnt[PT_WAVES][BKT_MAX];
     __shared__ u32 s_base[BKT_MAX];
     __shared__ u32 s_w[PT_WAVES];
     __shared__ u64 s_hot_key[HOT_HASH];
     __shared__ u32 s_hot_idx[HOT_HASH];
     const u32 tid = threadIdx.x;
-    // One extra workgroup snapshots the cells of the current hot keys (for k_bkt_apply) and picks the
-    // NEXT batch's hot keys from a strided sample of this batch.
+    // One extra workgroup prepares the hot keys' buckets for k_bkt_apply.
     if (blockIdx.x == ntiles) {
-        // ---- snapshot of the current hot keys' cells ---------------------------------------------
+        // ---- the hot keys of this batch: where their buckets are, the state of their cells before
+        //      the batch, and how the bucket will be decided (apply_hot); next batch's hot set -------
+        const u32 nb_ = 1u << bk_log2, nbt_ = nb_ + HOT_MAX;
+        const u32 b0 = 3 * tid;
+        u32 c3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c3[q] = b0 + q < nbt_ ? total[b0 + q] : 0u;
+        u32 all;
+        const u32 ex = block_excl_scan_1024(c3[0] + c3[1] + c3[2], s_w, all);
+        u32* s_lo = s_base;  // s_lo[h] = start of hot bucket h
+        {
+            u32 lo3[3] = {ex, ex + c3[0], ex + c3[0] + c3[1]};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (b0 + q >= nb_ && b0 + q < nbt_) s_lo[b0 + q - nb_] = lo3[q];
+        }
+        if (tid == 0) hot_next->n = 0;  // k_bkt_apply appends the keys it promotes
+        __syncthreads();
+        const bool refuse = st->err != 0;  // k_bkt_hist rejected the batch: empty ranges, nothing applied
         const u32 nh = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
-        if (tid < nh) {
-            const u64 k = hot->key[tid];
-            u32 dummy = 0;
-            u32 slot = slot_of(k, seed, log2cap);
-            slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, k, 0u, limits,
-                                         0ull, st, dummy);
-            HotState hs{0ull, slot, 0u, 0u, 0u};
-            if (slot != SLOT_INVALID) {
-                const Cell* c = &table[slot];
-                const u64 expiry = c->expiry;
-                hs.flags = HS_FOUND | (expiry <= now ? HS_EXPIRED : 0u);
-                hs.s = expiry <= now ? 0ull : c->value;
-                hs.climit = c->limit;
+        u32* s_nchunk = s_base + HOT_MAX;
+        if (tid == HOT_MAX) hot_param[HOT_MAX] = HotParam{};
+        if (tid < HOT_MAX) {
+            HotParam hp{};
+            hp.slot = SLOT_INVALID;
+            const u32 cnt = refuse ? 0u : total[nb_ + tid];
+            hp.lo = s_lo[tid];
+            hp.hi = hp.lo + cnt;
+            if (tid < nh && cnt) {
+                const u64 k = hot->key[tid];
+                u32 dummy = 0;
+                u32 slot = slot_of(k, seed, log2cap);
+                slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, k, 0u, limits,
+                                             0ull, st, dummy);
+                hp.slot = slot;
+                hp.limit = bs->hot_limit[tid];
+                bool limit_ok = true;
+                if (slot != SLOT_INVALID) {
+                    const Cell* c = &table[slot];
+                    const u64 expiry = c->expiry;
+                    hp.expired = expiry <= now ? 1u : 0u;
+                    hp.s = expiry <= now ? 0ull : c->value;
+                    limit_ok = c->limit == hp.limit;
+                }
+                const u32 dmax = bs->hot_dmax[tid], dmin = ~bs->hot_ndmin[tid];
+                const LimitDev L = limits[hp.limit & ~SIMPLE_FLAG];
+                hp.d = dmax;
+                if (dmin == dmax && L.window_us != 0 && hp.s < (1ull << 62) && limit_ok &&
+                    (slot != SLOT_INVALID || !(hp.limit & SIMPLE_FLAG))) {
+                    hp.fast = 1;
+                    hp.room = hp.s > L.max_value ? 0ull : (hp.d ? (L.max_value - hp.s) / hp.d : ~0ull);
+                }
+                if (cnt >= HOT_KEEP) {
+                    const u32 pos = atomicAdd(&hot_next->n, 1u);
+                    if (pos < (u32)HOT_MAX) hot_next->key[pos] = k;
+                }
             }
-            hot_state[tid] = hs;
-        }
-        // ---- next batch's hot set: keys with >= HOT_MIN_COUNT hits in a strided sample -----------
-        static_assert(sizeof(s_cnt) >= HOT_SLOTS * (sizeof(u64) + sizeof(u32)), "sampler tables alias s_cnt");
-        u64* s_big_key = reinterpret_cast<u64*>(&s_cnt[0][0]);
-        u32* s_big_cnt = reinterpret_cast<u32*>(s_big_key + HOT_SLOTS);
-        u32& s_n = s_w[0];
-        for (u32 q = tid; q < (u32)HOT_SLOTS; q += PT_BLOCK) {
-            s_big_key[q] = TAG_EMPTY;
-            s_big_cnt[q] = 0;
-        }
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        const u32 ns = n < (u32)HOT_SAMPLE ? n : (u32)HOT_SAMPLE;
-        const u32 stride = n / (ns ? ns : 1u);
-        for (u32 k = tid; k < ns; k += PT_BLOCK) {
-            const u64 key = hits[(size_t)k * stride].key;
-            u32 q = (u32)(fmix64(key ^ seed) >> 16) & (HOT_SLOTS - 1);
-            for (;;) {
-                const u64 prev = atomicCAS(&s_big_key[q], TAG_EMPTY, key);
-                if (prev == TAG_EMPTY || prev == key) break;
-                q = (q + 1) & (HOT_SLOTS - 1);
-            }
-            atomicAdd(&s_big_cnt[q], 1u);
-        }
-        __syncthreads();
-        for (u32 q = tid; q < (u32)HOT_SLOTS; q += PT_BLOCK) {
-            if (s_big_cnt[q] >= HOT_MIN_COUNT && s_big_key[q] < TAG_TOMB) {
-                const u32 pos = atomicAdd(&s_n, 1u);
-                if (pos < (u32)HOT_MAX) hot_next->key[pos] = s_big_key[q];
-            }
+            s_nchunk[tid] = hp.fast ? (cnt + HOT_CHUNK - 1) / HOT_CHUNK : 0u;
+            hot_param[tid] = hp;
         }
         __syncthreads();
-        if (tid == 0) hot_next->n = s_n < (u32)HOT_MAX ? s_n : (u32)HOT_MAX;
+        if (tid <= HOT_MAX) {  // chunk0[h] = chunks of the fast buckets before h; entry HOT_MAX = all
+            u32 acc = 0;
+            for (u32 q = 0; q < tid; ++q) acc += s_nchunk[q];
+            hot_param[tid].chunk0 = acc;
+        }
         return;
     }
     const u32 lane = tid & 63u, w = tid >> 6;
@@ -378,7 +414,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                 const u32 b = b0 + q;
                 const uint2 r = refuse ? make_uint2(0, 0) : make_uint2(lo[q], lo[q] + c[q]);
                 if (b < nb) ranges[g[q] ? gx : nbig + (b - gx)] = r;
-                else if (b < nbt) hot_ranges[b - nb] = r;
                 gx += g[q];
             }
         }
@@ -403,7 +438,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
             const int hi = hot_lookup(s_hot_key, s_hot_idx, key, hh);
             d = hi >= 0 ? nb + (u32)hi : bucket_of_hash(hh, bk_log2);
         }
-        const u64 m = match_digit(d, (bk_log2 > 6u ? bk_log2 : 6u) + 1u, valid);
+        const u64 m = match_digit(d, (bk_log2 > 7u ? bk_log2 : 7u) + 1u, valid);
         u32 r = 0;
         if (ok) {
             const u32 c = s_cnt[w][d];
@@ -456,6 +491,7 @@ constexpr u32 EF_BAD = 8u;       // a hit carried a limit id that is not the cel
 constexpr u32 EF_COUNT_SHIFT = 8;  // bits 8..31: hits this entry has absorbed (hot entries survive a rebuild)
 constexpr u32 EF_HOT_MIN = 16;
 constexpr u32 ENT_NONE = 0xFFFFu;
+constexpr int LIM_LDS = 512;   // limit-table rows the bucketed path supports (all of them live in LDS)
 
 struct ApplyLds {
     u64 key[ENT_N];
@@ -471,10 +507,10 @@ struct ApplyLds {
     unsigned short h_ent[AP_R];
     uint8_t h_verdict[AP_R];
     u32 wcnt[AP_WS][4];
-    // hot-bucket workers only
-    u32 hot_lo[HOT_MAX], hot_hi[HOT_MAX], hot_chunk0[HOT_MAX + 1], hot_fast[HOT_MAX], hot_limit[HOT_MAX];
-    u64 hot_s[HOT_MAX], hot_room[HOT_MAX], hot_d[HOT_MAX];
+    LimitDev lim[LIM_LDS];  // the limit table
+    HotParam hot[HOT_MAX + 1];  // copy of the batch's hot-bucket table
     u32 n_ent;
+    u32 bucket_len;
     u32 any_slow;
     u32 n_created;
     u32 n_keep;
@@ -487,10 +523,12 @@ struct ApplyArgs {
     const BHit* b_hits;
     const Hit* hits;  // the caller's batch: only read for the limit id of a key that has no cell yet
     const LimitDev* limits;
+    u32 n_limits;
     u64 now;
     uint8_t* verdict;
     int32_t* first_limited;
     Status* st;
+    HotSet* hot_next;  // next batch's hot keys (appended to)
     u32 vmask;   // debug (RL_DEBUG_VMASK): AND-mask on the verdict index, 0xFFFFFFFF normally
     u64* trace;  // debug (RL_APPLY_TRACE=1): per-workgroup phase timestamps, 16 per workgroup; else null
 };
@@ -498,6 +536,13 @@ struct ApplyArgs {
     do {                                                                                  \
         if (A.trace && threadIdx.x == 0) A.trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
     } while (0)
+
+// Row of the limit table, always from LDS: a global load here would also wait for the prefetched
+// inputs of the next bucket (the memory counter retires in order).  The host only takes this path
+// when the whole table fits (n_limits <= LIM_LDS); ids were range-checked by k_bkt_hist.
+__device__ __forceinline__ LimitDev limit_row(const ApplyLds& S, const ApplyArgs& A, u32 limit) {
+    return S.lim[(limit & ~SIMPLE_FLAG) & (LIM_LDS - 1)];
+}
 
 // Write the dirty LDS cells back; optionally rebuild the LDS hash keeping only the hot entries.
 __device__ __forceinline__ void apply_commit(ApplyLds& S, const ApplyArgs& A, bool rebuild) {
@@ -512,12 +557,20 @@ __device__ __forceinline__ void apply_commit(ApplyLds& S, const ApplyArgs& A, bo
         const u64 key = S.key[e];
         if (key == TAG_EMPTY) continue;
         u32 f = S.flags[e];
+        // promote: the key absorbed HOT_PROMOTE hits, or it is what made this bucket long (hits denied
+        // on the spot by the window pass are not counted, so a saturated key shows fewer than it got)
+        if (!rebuild && !(f & EF_BAD) &&
+            ((f >> EF_COUNT_SHIFT) >= HOT_PROMOTE ||
+             ((f >> EF_COUNT_SHIFT) >= HOT_PROMOTE / 4 && S.bucket_len >= 2 * HOT_PROMOTE))) {
+            const u32 pos = atomicAdd(&A.hot_next->n, 1u);
+            if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = key;
+        }
         if (f & EF_DIRTY) {
             Cell* c = &A.table[S.slot[e]];
             c->value = S.run[e];
-            if (f & EF_EXPIRED) c->expiry = A.now + A.limits[S.limit[e] & ~SIMPLE_FLAG].window_us;
+            if (f & EF_EXPIRED) c->expiry = A.now + limit_row(S, A, S.limit[e]).window_us;
             // the window is open again — except a 0-second one, which is expired at every read
-            if (A.limits[S.limit[e] & ~SIMPLE_FLAG].window_us != 0) f &= ~EF_EXPIRED;
+            if (limit_row(S, A, S.limit[e]).window_us != 0) f &= ~EF_EXPIRED;
             f &= ~EF_DIRTY;
         }
         if (rebuild && (f >> EF_COUNT_SHIFT) >= EF_HOT_MIN && !(f & EF_BAD)) {
@@ -561,20 +614,57 @@ __device__ __forceinline__ void apply_commit(ApplyLds& S, const ApplyArgs& A, bo
     __syncthreads();
 }
 
-// One decide/commit round over up to AP_R hits given by their positions in the bucketed arrays:
-// position of item p is first + p (from_queue == false) or S.queue[(first + p) % AP_Q].
-__device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, bool from_queue, u32 first,
-                                            u32 n_items) {
+// Inputs of one decide/commit round, fetched ahead of the round itself: the hits, and for every hit
+// its home cell (tag + value, expiry, limit: one 64-byte line) — only the claimer of a new LDS cell
+// consumes the latter.
+struct RoundIn {
+    BHit h[AP_HPT];
+    u32 hslot[AP_HPT], climit[AP_HPT];
+    u64 ctag[AP_HPT], cvalue[AP_HPT], cexpiry[AP_HPT];
+};
+// position of item p is first + p (from_queue == false) or S.queue[(first + p) % AP_Q]
+__device__ __forceinline__ void round_load_hits(const ApplyLds& S, const ApplyArgs& A, bool from_queue,
+                                                u32 first, u32 n_items, RoundIn& in) {
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        const u32 p = threadIdx.x * AP_HPT + u;
+        if (p < n_items) {
+            const u32 j = from_queue ? S.queue[(first + p) & (AP_Q - 1)] : first + p;
+            in.h[u] = load_bhit(A.b_hits, j);
+        }
+    }
+}
+__device__ __forceinline__ void round_load_lines(const ApplyArgs& A, u32 n_items, RoundIn& in) {
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        const u32 p = threadIdx.x * AP_HPT + u;
+        if (p >= n_items) continue;
+        in.hslot[u] = slot_of(in.h[u].key, A.seed, A.log2cap);
+        const Cell* c = &A.table[in.hslot[u]];
+        const uint4 a = *reinterpret_cast<const uint4*>(c);
+        in.ctag[u] = ((u64)a.y << 32) | a.x;
+        in.cvalue[u] = ((u64)a.w << 32) | a.z;
+        in.cexpiry[u] = c->expiry;
+        in.climit[u] = c->limit;
+    }
+}
+
+// One decide/commit round over up to AP_R hits (inputs already requested).  `mid` runs once the
+// round's own table reads are done (after phase B): the place to request the NEXT bucket's inputs,
+// since the memory counter retires in order and a later wait would also wait for them.
+template <class Mid>
+__device__ __forceinline__ void apply_round_core(ApplyLds& S, const ApplyArgs& A, u32 n_items, RoundIn& in,
+                                                 Mid mid) {
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, w = tid >> 6;
     const u64 lt = (1ull << lane) - 1ull;
-    if (S.n_ent > (u32)ENT_KEEP) {  // block-uniform (read after the previous round's barrier)
-        __syncthreads();
-        apply_commit(S, A, true);
-    }
-    BHit h[AP_HPT];
-    u32 idx[AP_HPT], ent[AP_HPT], hslot[AP_HPT], climit[AP_HPT];
-    u64 ctag[AP_HPT], cvalue[AP_HPT], cexpiry[AP_HPT];
+    BHit(&h)[AP_HPT] = in.h;
+    u32(&hslot)[AP_HPT] = in.hslot;
+    u32(&climit)[AP_HPT] = in.climit;
+    u64(&ctag)[AP_HPT] = in.ctag;
+    u64(&cvalue)[AP_HPT] = in.cvalue;
+    u64(&cexpiry)[AP_HPT] = in.cexpiry;
+    u32 idx[AP_HPT], ent[AP_HPT];
     bool ok[AP_HPT], creator[AP_HPT], leader[AP_HPT];
 #pragma unroll
     for (int u = 0; u < AP_HPT; ++u) {
@@ -582,25 +672,7 @@ __device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, boo
         ok[u] = p < n_items;
         creator[u] = leader[u] = false;
         ent[u] = 0;
-        if (ok[u]) {
-            const u32 j = from_queue ? S.queue[(first + p) & (AP_Q - 1)] : first + p;
-            h[u] = load_bhit(A.b_hits, j);
-            idx[u] = h[u].idx_tag & 0xFFFFFFu;
-        }
-    }
-    // The home cell of every hit is fetched right away (tag+value, expiry, limit: one 64-byte line),
-    // overlapping the HBM latency with the LDS work of phase A; only the claimer of a new LDS cell
-    // consumes it.
-#pragma unroll
-    for (int u = 0; u < AP_HPT; ++u) {
-        if (!ok[u]) continue;
-        hslot[u] = slot_of(h[u].key, A.seed, A.log2cap);
-        const Cell* c = &A.table[hslot[u]];
-        const uint4 a = *reinterpret_cast<const uint4*>(c);
-        ctag[u] = ((u64)a.y << 32) | a.x;
-        cvalue[u] = ((u64)a.w << 32) | a.z;
-        cexpiry[u] = c->expiry;
-        climit[u] = c->limit;
+        idx[u] = ok[u] ? (h[u].idx_tag & 0xFFFFFFu) : 0u;
     }
     RL_STAMP(2);
     // ---- A: find or claim the key's LDS cell, add this hit to the round's aggregates ------------
@@ -642,18 +714,56 @@ __device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, boo
         u32 slot = hslot[u];
         u64 value = cvalue[u], expiry = cexpiry[u];
         u32 cl = climit[u];
-        if (ctag[u] != h[u].key) {  // not at home: probe on (or create: in_memory.rs:122-127)
-            const u32 hl = A.hits[idx[u]].limit;
-            slot = probe_from<PM_CHECK>(A.table, A.log2cap, slot, ctag[u], h[u].key, hl, A.limits, A.now, A.st,
-                                        created);
-            value = 0;
-            expiry = 0;
-            cl = hl;
-            if (slot != SLOT_INVALID) {
+        if (ctag[u] != h[u].key) {
+            // Not at home: probe on, fetching whole cells so that a match needs no further read; the
+            // limit id (caller's batch) is only read when the cell has to be created
+            // (in_memory.rs:122-127).
+            const u32 mask = (1u << A.log2cap) - 1u;
+            u64 tag = ctag[u];  // the tag at `slot`; not ours
+            bool done = false, missing_simple = false;
+            for (u32 step = 0; step <= mask; ++step) {
+                if (tag == TAG_EMPTY) {
+                    const u32 hl = A.hits[idx[u]].limit;
+                    if (hl & SIMPLE_FLAG) {  // in_memory.rs:106-107: a simple counter must pre-exist
+                        missing_simple = true;
+                        break;
+                    }
+                    const u64 old = atomicCAS(&A.table[slot].tag, TAG_EMPTY, h[u].key);
+                    if (old == TAG_EMPTY || old == h[u].key) {
+                        Cell* c = &A.table[slot];
+                        if (old == TAG_EMPTY) {  // AtomicExpiringValue::new(0, now + window), in_memory.rs:123-125
+                            c->value = 0;
+                            c->expiry = A.now + A.limits[hl & ~SIMPLE_FLAG].window_us;
+                            c->limit = hl;
+                            ++created;
+                        }
+                        value = c->value;
+                        expiry = c->expiry;
+                        cl = c->limit;
+                        done = true;
+                        break;
+                    }
+                    // somebody else's key landed here first: keep probing
+                }
+                slot = (slot + 1) & mask;
                 const Cell* c = &A.table[slot];
-                value = c->value;
-                expiry = c->expiry;
-                cl = c->limit;
+                const uint4 a = *reinterpret_cast<const uint4*>(c);
+                const u64 ex = c->expiry;
+                const u32 li = c->limit;
+                tag = ((u64)a.y << 32) | a.x;
+                if (tag == h[u].key) {
+                    value = ((u64)a.w << 32) | a.z;
+                    expiry = ex;
+                    cl = li;
+                    done = true;
+                    break;
+                }
+            }
+            if (!done) {
+                atomicOr(&A.st->err, missing_simple ? ERRBIT_MISSING_SIMPLE : ERRBIT_TABLE_FULL);
+                slot = SLOT_INVALID;
+                value = 0;
+                expiry = 0;
             }
         }
         const bool expired = expiry <= A.now;
@@ -663,6 +773,7 @@ __device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, boo
         S.flags[e] = (expired ? EF_EXPIRED : 0u) | (slot == SLOT_INVALID ? EF_BAD : 0u);
     }
     if (created) atomicAdd(&S.n_created, created);
+    mid();
     RL_STAMP(4);
     __syncthreads();
     RL_STAMP(5);
@@ -682,7 +793,7 @@ __device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, boo
             atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
             continue;
         }
-        const LimitDev Lu = A.limits[S.limit[e] & ~SIMPLE_FLAG];
+        const LimitDev Lu = limit_row(S, A, S.limit[e]);
         const u64 run = S.run[e], sum = S.rsum[e], c4 = S.cnt4[e];
         const u64 d = h[u].delta;
         const u64 cnt = (c4 & 0xFFFFull) + ((c4 >> 16) & 0xFFFFull) + ((c4 >> 32) & 0xFFFFull) + (c4 >> 48);
@@ -744,7 +855,7 @@ __device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, boo
                 const u32 e = S.h_ent[p];
                 const u32 f = S.flags[e];
                 if (!(f & EF_SLOW) || (f & EF_BAD)) continue;
-                const LimitDev Le = A.limits[S.limit[e] & ~SIMPLE_FLAG];
+                const LimitDev Le = limit_row(S, A, S.limit[e]);
                 const u64 d = S.h_delta[p];
                 const u64 cur = Le.window_us == 0 ? 0ull : S.run[e];
                 const u64 sum = cur + d;  // wraps like the reference's release build (in_memory.rs:88)
@@ -774,7 +885,7 @@ __device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, boo
         const u64 c4 = S.cnt4[e];
         const u64 cnt = (c4 & 0xFFFFull) + ((c4 >> 16) & 0xFFFFull) + ((c4 >> 32) & 0xFFFFull) + (c4 >> 48);
         if (!(f & (EF_SLOW | EF_BAD))) {
-            const LimitDev Le = A.limits[S.limit[e] & ~SIMPLE_FLAG];
+            const LimitDev Le = limit_row(S, A, S.limit[e]);
             const u64 run = S.run[e], sum = S.rsum[e];
             const u64 dm = S.dmax[e];
             if (run + sum <= Le.max_value) {  // no overflow here: overflowing rounds are slow
@@ -801,8 +912,24 @@ __device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, boo
     RL_STAMP(7);
 }
 
+// A round that fetches its own inputs (everything but the first round of a bucket).
+__device__ __forceinline__ void apply_round(ApplyLds& S, const ApplyArgs& A, bool from_queue, u32 first,
+                                            u32 n_items) {
+    if (S.n_ent > (u32)ENT_KEEP) {  // block-uniform (read after the previous round's barrier)
+        __syncthreads();
+        apply_commit(S, A, true);
+    }
+    RoundIn in;
+    round_load_hits(S, A, from_queue, first, n_items, in);
+    round_load_lines(A, n_items, in);
+    apply_round_core(S, A, n_items, in, [] {});
+}
+
 // A whole bucket [lo, hi) of the partitioned batch, in trace order, by one workgroup.
-__device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u32 lo, u32 hi) {
+// `in0` holds the (already requested) inputs of its first min(AP_R, hi - lo) hits.
+template <class Mid>
+__device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u32 lo, u32 hi, RoundIn& in0,
+                                             Mid mid) {
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, w = tid >> 6;
     const u64 lt = (1ull << lane) - 1ull;
@@ -816,20 +943,31 @@ __device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u3
     if (tid == 0) {
         S.n_ent = 0;
         S.any_slow = 0;
+        S.bucket_len = hi - lo;
     }
     __syncthreads();
     RL_STAMP(1);
 
     // The first AP_R hits of the bucket go straight through a decide/commit round.  In a bucket made
     // long by a frequent key this also brings that key's cell into LDS.
-    apply_round(S, A, false, lo, (hi - lo) < (u32)AP_R ? (hi - lo) : (u32)AP_R);
+    apply_round_core(S, A, (hi - lo) < (u32)AP_R ? (hi - lo) : (u32)AP_R, in0, mid);
 
     // The rest of a long bucket streams through in windows: a hit whose key is already in LDS and
     // saturated (run + delta > max, and run can only grow) is denied on the spot — valid in any
     // order; everything else is deferred, in trace order, to a ring of positions that is drained in
     // decide/commit rounds.
     u32 q_head = 0, q_tail = 0;
-    for (u32 wbase = lo + AP_R; wbase < hi; wbase += AP_W) {
+    // two window buffers, used alternately: the next window's hits are requested before the current
+    // one is examined (no copies of registers with a load in flight)
+    auto window_load = [&](u32 wbase, BHit(&wh)[AP_WS]) {
+#pragma unroll
+        for (int u = 0; u < AP_WS; ++u) {
+            const u32 j = wbase + u * AP_BLOCK + tid;
+            if (j < hi) wh[u] = load_bhit(A.b_hits, j);
+        }
+    };
+    auto window = [&](u32 wbase, BHit(&wh)[AP_WS], BHit(&wnext)[AP_WS]) {
+        if (wbase + AP_W < hi) window_load(wbase + AP_W, wnext);
         bool unres[AP_WS];
         u32 pos[AP_WS];
 #pragma unroll
@@ -838,7 +976,7 @@ __device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u3
             pos[u] = j;
             unres[u] = false;
             if (j >= hi) continue;
-            const BHit h = load_bhit(A.b_hits, j);
+            const BHit h = wh[u];
             const u32 i = h.idx_tag & 0xFFFFFFu;
             unres[u] = true;
             u32 e = (u32)(fmix64(h.key ^ A.seed) >> 20) & (ENT_N - 1);
@@ -848,7 +986,7 @@ __device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u3
                     const u64 run = S.run[e];
                     const u32 f = S.flags[e];
                     const u32 cl = S.limit[e];
-                    const LimitDev L = A.limits[cl & ~SIMPLE_FLAG];
+                    const LimitDev L = limit_row(S, A, cl);
                     if (limit_fold(cl) == (h.idx_tag >> 24) && !(f & EF_BAD) && L.window_us != 0 && run < (1ull << 63) &&
                         run + (u64)h.delta > L.max_value) {
                         A.verdict[i & A.vmask] = 1;
@@ -888,6 +1026,18 @@ __device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u3
             apply_round(S, A, true, q_head, AP_R);
             q_head += AP_R;
         }
+    };
+    if (lo + AP_R < hi) {
+        BHit wa[AP_WS], wb[AP_WS];
+        window_load(lo + AP_R, wa);
+        for (u32 wbase = lo + AP_R;;) {
+            window(wbase, wa, wb);
+            wbase += AP_W;
+            if (wbase >= hi) break;
+            window(wbase, wb, wa);
+            wbase += AP_W;
+            if (wbase >= hi) break;
+        }
     }
     if (q_tail != q_head) apply_round(S, A, true, q_head, q_tail - q_head);
     RL_STAMP(8);
@@ -903,59 +1053,29 @@ __device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u3
 // of workgroups.  Buckets that do not fit that form (mixed deltas, 0-second window, values near
 // 2^64, a stale hot set that made two keys share...) are replayed by one worker through
 // apply_bucket, which is exact for everything.
-constexpr int HOT_BLOCKS = 128;
-constexpr int HOT_CHUNK = AP_BLOCK * 4;
 
-__device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 worker,
-                                          const uint2* __restrict__ hot_ranges,
-                                          const HotState* __restrict__ hot_state,
-                                          const BatchScratch* __restrict__ bs) {
+__device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 worker, u32 n_workers) {
     const u32 tid = threadIdx.x;
-    if (tid < HOT_MAX) {
-        const uint2 r = hot_ranges[tid];
-        const u32 cnt = r.y - r.x;
-        u32 fast = 0, limit = 0;
-        u64 s = 0, room = 0, d = 0;
-        if (cnt) {
-            const HotState hs = hot_state[tid];
-            const u32 dmax = bs->hot_dmax[tid], dmin = ~bs->hot_ndmin[tid];
-            limit = (hs.flags & HS_FOUND) ? hs.climit : A.hits[A.b_hits[r.x].idx_tag & 0xFFFFFFu].limit;
-            const LimitDev L = A.limits[limit & ~SIMPLE_FLAG];
-            s = hs.s;
-            d = dmax;
-            if (dmin == dmax && L.window_us != 0 && s < (1ull << 62) &&
-                ((hs.flags & HS_FOUND) || !(limit & SIMPLE_FLAG))) {
-                fast = 1;
-                room = s > L.max_value ? 0ull : (d ? (L.max_value - s) / d : ~0ull);
-            }
-        }
-        S.hot_lo[tid] = r.x;
-        S.hot_hi[tid] = r.y;
-        S.hot_fast[tid] = fast;
-        S.hot_limit[tid] = limit;
-        S.hot_s[tid] = s;
-        S.hot_room[tid] = room;
-        S.hot_d[tid] = d;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        u32 acc = 0;
-        for (int hk = 0; hk < HOT_MAX; ++hk) {
-            S.hot_chunk0[hk] = acc;
-            if (S.hot_fast[hk]) acc += (S.hot_hi[hk] - S.hot_lo[hk] + HOT_CHUNK - 1) / HOT_CHUNK;
-        }
-        S.hot_chunk0[HOT_MAX] = acc;
-    }
-    __syncthreads();
+    RL_STAMP(11);
+    RL_STAMP(12);
+    if (A.trace && worker == 0 && tid < HOT_MAX && S.hot[tid].hi != S.hot[tid].lo)
+        atomicAdd(&A.st->pad[S.hot[tid].fast ? 0 : 1], S.hot[tid].hi - S.hot[tid].lo);
     // ---- fast buckets: chunks of HOT_CHUNK hits, grid-strided over the workers --------------------
-    const u32 n_chunks = S.hot_chunk0[HOT_MAX];
-    for (u32 c = worker; c < n_chunks; c += HOT_BLOCKS) {
-        int hk = 0;
-        while (hk + 1 < HOT_MAX && (S.hot_chunk0[hk + 1] <= c || !S.hot_fast[hk])) ++hk;
-        const u32 lo = S.hot_lo[hk], hi = S.hot_hi[hk];
-        const u32 first = lo + (c - S.hot_chunk0[hk]) * HOT_CHUNK;
-        const u64 room = S.hot_room[hk];
-        const u32 limit = S.hot_limit[hk];
+    const u32 n_chunks = S.hot[HOT_MAX].chunk0;
+    for (u32 c = worker; c < n_chunks; c += n_workers) {
+        // the bucket that owns chunk c: the LAST h with chunk0[h] <= c (a bucket without chunks shares
+        // its successor's chunk0, so it is never the last one)
+        u32 a = 0, b = HOT_MAX;  // invariant: chunk0[a] <= c < chunk0[b]
+        while (b - a > 1) {
+            const u32 m = (a + b) >> 1;
+            if (S.hot[m].chunk0 <= c) a = m;
+            else b = m;
+        }
+        const HotParam hp = S.hot[a];
+        const u32 lo = hp.lo, hi = hp.hi;
+        const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
+        const u64 room = hp.room;
+        const u32 limit = hp.limit;
 #pragma unroll
         for (int u = 0; u < HOT_CHUNK / AP_BLOCK; ++u) {
             const u32 j = first + u * AP_BLOCK + tid;
@@ -972,12 +1092,11 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
         }
         if (first == lo && tid == 0) {
             // the bucket's first chunk also applies AtomicExpiringValue::update for the admitted hits
-            const HotState hs = *(&hot_state[hk]);
-            const LimitDev L = A.limits[limit & ~SIMPLE_FLAG];
+            const LimitDev L = limit_row(S, A, limit);
             const u64 cnt = hi - lo;
             const u64 n_adm = cnt < room ? cnt : room;
-            u32 slot = hs.slot;
-            bool expired = (hs.flags & HS_EXPIRED) != 0;
+            u32 slot = hp.slot;
+            bool expired = hp.expired != 0;
             if (slot == SLOT_INVALID) {  // first touch creates the cell (in_memory.rs:122-127), verdict or not
                 u32 created = 0;
                 const u64 key = A.b_hits[lo].key;
@@ -989,44 +1108,84 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
             }
             if (n_adm && slot != SLOT_INVALID) {
                 Cell* cell = &A.table[slot];
-                cell->value = S.hot_s[hk] + n_adm * S.hot_d[hk];
+                cell->value = hp.s + n_adm * hp.d;
                 if (expired) cell->expiry = A.now + L.window_us;
             }
         }
     }
+    RL_STAMP(13);
     // ---- everything else: replayed by one worker per bucket ---------------------------------------
-    for (int hk = 0; hk < HOT_MAX; ++hk) {
-        if (S.hot_fast[hk] || S.hot_hi[hk] == S.hot_lo[hk] || (u32)hk % HOT_BLOCKS != worker) continue;
-        if (tid == 0) S.n_created = 0;
-        const u32 lo = S.hot_lo[hk], hi = S.hot_hi[hk];
-        apply_bucket(S, A, lo, hi);
-        if (tid == 0 && S.n_created) atomicAdd(&A.st->n_inserted, S.n_created);
-        __syncthreads();
+    for (u32 hk = worker; hk < (u32)HOT_MAX; hk += n_workers) {
+        const HotParam hp = S.hot[hk];
+        if (hp.fast || hp.hi == hp.lo) continue;
+        RoundIn in0;
+        const u32 n0 = (hp.hi - hp.lo) < (u32)AP_R ? (hp.hi - hp.lo) : (u32)AP_R;
+        round_load_hits(S, A, false, hp.lo, n0, in0);
+        round_load_lines(A, n0, in0);
+        apply_bucket(S, A, hp.lo, hp.hi, in0, [] {});
     }
 }
+
+// Persistent workgroups: workgroup g replays hash buckets g, g + G, g + 2G, ... (ranges[] is in
+// processing order, large buckets first) and then takes its share of the hot-bucket chunks.  The
+// inputs of the next bucket (its first AP_R hits, then their home cells) are requested while the
+// current bucket is being decided, so the HBM latency of one bucket hides behind the LDS work of
+// the previous one.
+constexpr int AP_MAX_PER_WG = 16;  // buckets per workgroup: the host launches G >= nb / 16 workgroups
 
 __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits,
     const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
-    const uint2* __restrict__ hot_ranges, const HotState* __restrict__ hot_state,
-    const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
-    int32_t* __restrict__ first_limited, BatchScratch* bs, u32 vmask, u64* trace) {
+    const HotParam* __restrict__ hot_param,
+    const LimitDev* __restrict__ limits, u32 n_limits, u64 now, uint8_t* __restrict__ verdict,
+    int32_t* __restrict__ first_limited, BatchScratch* bs, HotSet* hot_next, u32 vmask, u64* trace) {
     __shared__ ApplyLds S;
-    if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
-    ApplyArgs A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st, vmask, trace};
-    if (blockIdx.x >= nb) {
-        // k_bkt_hist refused the batch: the hot ranges are empty too, nothing is applied
-        apply_hot(S, A, blockIdx.x - nb, hot_ranges, hot_state, bs);
-        return;
+    __shared__ uint2 s_ranges[AP_MAX_PER_WG + 4];
+    const u32 tid = threadIdx.x, G = gridDim.x;
+    if (trace && tid == 0) trace[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
+    ApplyArgs A{table, log2cap, seed, b_hits, hits,  limits, n_limits, now,
+                verdict, first_limited, &bs->st, hot_next, vmask, trace};
+    if (tid < AP_MAX_PER_WG + 4) {
+        const u32 k = blockIdx.x + tid * G;
+        s_ranges[tid] = (tid < AP_MAX_PER_WG && k < nb) ? ranges[k] : make_uint2(0, 0);
     }
-    const uint2 range = ranges[blockIdx.x];
-    if (range.x == range.y) return;
-    if (threadIdx.x == 0) S.n_created = 0;
-    apply_bucket(S, A, range.x, range.y);
-    if (threadIdx.x == 0) {
-        if (S.n_created) atomicAdd(&bs->st.n_inserted, S.n_created);
-        if (trace) trace[(size_t)blockIdx.x * 16 + 10] = range.y - range.x;
+    for (u32 q = tid; q < (u32)LIM_LDS && q < n_limits; q += AP_BLOCK) S.lim[q] = limits[q];
+    if (tid <= HOT_MAX) S.hot[tid] = hot_param[tid];
+    if (tid == 0) S.n_created = 0;
+    __syncthreads();
+    auto first_n = [](uint2 r) { return (r.y - r.x) < (u32)AP_R ? (r.y - r.x) : (u32)AP_R; };
+    // Three input buffers used round-robin (bucket t decides from b[t % 3] while the lines of bucket
+    // t+1 land in b[(t+1) % 3] and the hits of bucket t+2 in b[(t+2) % 3]); the loop is unrolled by
+    // three so that no register that is the target of a load in flight ever has to be copied.
+    RoundIn b0, b1, b2;
+    round_load_hits(S, A, false, s_ranges[0].x, first_n(s_ranges[0]), b0);
+    round_load_hits(S, A, false, s_ranges[1].x, first_n(s_ranges[1]), b1);
+    round_load_lines(A, first_n(s_ranges[0]), b0);
+    auto step = [&](u32 t, RoundIn& cur, RoundIn& nxt, RoundIn& nn) -> bool {
+        if (t >= (u32)AP_MAX_PER_WG || blockIdx.x + t * G >= nb) return false;
+        const uint2 r_cur = s_ranges[t], r_nxt = s_ranges[t + 1], r_nn = s_ranges[t + 2];
+        auto mid = [&] {
+            round_load_lines(A, first_n(r_nxt), nxt);
+            round_load_hits(S, A, false, r_nn.x, first_n(r_nn), nn);
+        };
+        if (r_cur.x != r_cur.y) apply_bucket(S, A, r_cur.x, r_cur.y, cur, mid);
+        else mid();
+        if (trace && tid == 0) {
+            trace[(size_t)blockIdx.x * 16 + 10] = r_cur.y - r_cur.x;
+            trace[(size_t)blockIdx.x * 16 + 15] += ((u64)1 << 32) + (r_cur.y - r_cur.x);
+        }
+        return true;
+    };
+    for (u32 t = 0;; t += 3) {
+        if (!step(t, b0, b1, b2)) break;
+        if (!step(t + 1, b1, b2, b0)) break;
+        if (!step(t + 2, b2, b0, b1)) break;
     }
+    // k_bkt_hist refused the batch: the hot ranges are empty too, nothing is applied
+    apply_hot(S, A, blockIdx.x, G);
+    RL_STAMP(14);
+    __syncthreads();
+    if (tid == 0 && S.n_created) atomicAdd(&bs->st.n_inserted, S.n_created);
 }
 
 }  // namespace rl

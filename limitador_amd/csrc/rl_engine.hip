@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
@@ -83,10 +84,10 @@ struct rl_engine {
     u32* d_bk_hist = nullptr;
     u32* d_bk_total = nullptr;
     uint2* d_bk_ranges = nullptr;
-    uint2* d_hot_ranges = nullptr;
     HotSet* d_hot = nullptr;        // [2]: the set used by this batch, the set it picks for the next
     u32 hot_cur = 0;
-    HotState* d_hot_state = nullptr;
+    HotParam* d_hot_param = nullptr;
+    u32 n_cus = 256;
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
     BHit* d_bk_hits = nullptr;
@@ -297,14 +298,17 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
     k_bkt_scan<<<cdiv(nbt, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
     k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
-                                                          hot, e->d_bk_hits, e->d_bk_ranges, e->d_hot_ranges,
-                                                          &bs->st, e->table, e->log2cap, e->d_limits, now, ntiles,
-                                                          e->d_hot_state, hot_next);
+                                                          hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
+                                                          e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
+                                                          hot_next, bs);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream));
-    k_bkt_apply<<<nb + HOT_BLOCKS, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
-                                                             e->d_bk_ranges, nb, e->d_hot_ranges, e->d_hot_state,
-                                                             e->d_limits, now, d_verdict, d_first, bs,
-                                                             e->dbg_vmask, e->d_bk_trace);
+    u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
+    if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
+    if (n_wg > nb && nb >= 64) n_wg = nb;
+    k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
+                                                  e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
+                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, bs, hot_next,
+                                                  e->dbg_vmask, e->d_bk_trace);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream));
     HIP_TRY(e, hipGetLastError());
     rc = read_status(e);
@@ -312,13 +316,13 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
     e->live += e->h_status->n_inserted;
     if (e->h_status->err) return status_to_error(e, e->h_status->err);
     if (e->d_bk_trace && getenv("RL_APPLY_TRACE_DUMP")) {
-        std::vector<u64> tr((size_t)nb * 16);
+        std::vector<u64> tr((size_t)(n_wg < BK_MAX ? n_wg : BK_MAX) * 16);
         HIP_TRY(e, hipMemcpy(tr.data(), e->d_bk_trace, tr.size() * sizeof(u64), hipMemcpyDeviceToHost));
         u64 t_min = ~0ull, t_max = 0;
         double acc[10] = {0};
         u32 used = 0;
         u64 longest = 0, longest_n = 0;
-        for (u32 b = 0; b < nb; ++b) {
+        for (u32 b = 0; b < tr.size() / 16; ++b) {
             const u64* r = &tr[(size_t)b * 16];
             if (r[9] == 0 || r[10] == 0) continue;
             ++used;
@@ -334,7 +338,45 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
                 (double)(t_max - t_min) * 0.01, (double)longest * 0.01, (unsigned long long)longest_n);
         const char* names[10] = {"", "init", "load", "A", "B", "syncB", "C", "D", "rest", "commit"};
         for (int q = 1; q <= 9; ++q) fprintf(stderr, " %s=%.2f", names[q], used ? acc[q] / used * 0.01 : 0.0);
-        fprintf(stderr, "\n");
+        double h_acc[3] = {0, 0, 0};
+        u64 h_last = 0;
+        for (u32 b = 0; b < tr.size() / 16; ++b) {
+            const u64* r = &tr[(size_t)b * 16];
+            if (!r[14]) continue;
+            h_acc[0] += (double)(r[12] - r[11]);
+            h_acc[1] += (double)(r[13] - r[12]);
+            h_acc[2] += (double)(r[14] - r[13]);
+            if (r[14] > h_last) h_last = r[14];
+        }
+        u32 late = 0;
+        double start_max = 0;
+        for (u32 b = 0; b < tr.size() / 16; ++b) {
+            const u64* r = &tr[(size_t)b * 16];
+            if (!r[0]) continue;
+            const double st_us = (double)(r[0] - t_min) * 0.01;
+            if (st_us > 5.0) ++late;
+            if (st_us > start_max) start_max = st_us;
+        }
+        fprintf(stderr, " | late_starts=%u max_start=%.1fus", late, start_max);
+        {
+            std::vector<std::pair<u64, u32>> ends;
+            for (u32 b = 0; b < tr.size() / 16; ++b)
+                if (tr[(size_t)b * 16 + 9]) ends.push_back({tr[(size_t)b * 16 + 9] - t_min, b});
+            std::sort(ends.begin(), ends.end());
+            fprintf(stderr, " | end pct: p10=%.1f p50=%.1f p90=%.1f p99=%.1f max=%.1f | slowest:",
+                    ends[ends.size() / 10].first * 0.01, ends[ends.size() / 2].first * 0.01,
+                    ends[ends.size() * 9 / 10].first * 0.01, ends[ends.size() * 99 / 100].first * 0.01,
+                    ends.back().first * 0.01);
+            for (size_t q = ends.size() >= 4 ? ends.size() - 4 : 0; q < ends.size(); ++q) {
+                const u64* r = &tr[(size_t)ends[q].second * 16];
+                fprintf(stderr, " [wg%u end=%.1f buckets=%llu hits=%llu]", ends[q].second, ends[q].first * 0.01,
+                        (unsigned long long)(r[15] >> 32), (unsigned long long)(r[15] & 0xFFFFFFFFull));
+            }
+        }
+        const double nbk = (double)(tr.size() / 16);
+        fprintf(stderr, " | hot: setup=%.2f fast=%.2f slow=%.2f end=%.2fus fast_hits=%u slow_hits=%u\n",
+                h_acc[0] / nbk * 0.01, h_acc[1] / nbk * 0.01, h_acc[2] / nbk * 0.01, (double)(h_last - t_min) * 0.01,
+                e->h_status->pad[0], e->h_status->pad[1]);
         HIP_TRY(e, hipMemset(e->d_bk_trace, 0, tr.size() * sizeof(u64)));
     }
     if (t) {
@@ -352,7 +394,7 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
 }
 
 int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
-    return e->legacy_k1 ? run_check_k1_legacy(e, d_hits, n, now, d_verdict, d_first)
+    return (e->legacy_k1 || e->h_limits.size() > (size_t)LIM_LDS) ? run_check_k1_legacy(e, d_hits, n, now, d_verdict, d_first)
                         : run_check_k1_bucketed(e, d_hits, n, now, d_verdict, d_first);
 }
 
@@ -535,6 +577,15 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     };
     if (hipSetDevice(e->device) != hipSuccess) return bail(RL_ERR_NO_DEVICE);
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0)
+            e->n_cus = (u32)cus;
+        if (const char* v = getenv("RL_APPLY_WG_PER_CU")) {  // tuning knob
+            const long m = strtol(v, nullptr, 10);
+            if (m >= 1 && m <= 8) e->n_cus = e->n_cus * (u32)m / 2;
+        }
+    }
     int rc = alloc_table(e, e->cap, &e->table);
     if (rc) return bail(rc);
     const size_t mb = e->max_batch;
@@ -562,14 +613,13 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_bk_hist, (size_t)BKT_MAX * e->bk_tiles_max * sizeof(u32));
     ALLOC(e->d_bk_total, (size_t)BKT_MAX * sizeof(u32));
     ALLOC(e->d_bk_ranges, (size_t)BK_MAX * sizeof(uint2));
-    ALLOC(e->d_hot_ranges, (size_t)HOT_MAX * sizeof(uint2));
     ALLOC(e->d_hot, 2 * sizeof(HotSet));
     if (hipMemset(e->d_hot, 0, 2 * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);
-    ALLOC(e->d_hot_state, (size_t)HOT_MAX * sizeof(HotState));
+    ALLOC(e->d_hot_param, (size_t)(HOT_MAX + 1) * sizeof(HotParam));
     if (const char* v = getenv("RL_APPLY_TRACE"))
         if (v[0] == '1') {
-            ALLOC(e->d_bk_trace, (size_t)(BK_MAX + HOT_BLOCKS) * 16 * sizeof(u64));
-            if (hipMemset(e->d_bk_trace, 0, (size_t)(BK_MAX + HOT_BLOCKS) * 16 * sizeof(u64)) != hipSuccess)
+            ALLOC(e->d_bk_trace, (size_t)(BK_MAX + 64) * 16 * sizeof(u64));
+            if (hipMemset(e->d_bk_trace, 0, (size_t)(BK_MAX + 64) * 16 * sizeof(u64)) != hipSuccess)
                 return bail(RL_ERR_DEVICE);
         }
     ALLOC(e->d_bk_hits, mb * sizeof(BHit));
@@ -605,7 +655,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_trace,
-                    e->d_hot_ranges, e->d_hot,     e->d_hot_state};
+                    e->d_hot,     e->d_hot_param};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);

@@ -25,5 +25,7 @@ short gpurun_out/bench_uniform.json
 timeout 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --zipf 0 --keys 1048576 --batch 65536 > gpurun_out/bench_cfg1.json 2> gpurun_out/bench_cfg1.err
 short gpurun_out/bench_cfg1.json
 RL_APPLY_TRACE=1 RL_APPLY_TRACE_DUMP=1 timeout 300 python bench.py --steps 3 --warmup 2 --cpu-seconds 0 2>&1 | grep -E "apply trace" | tail -2
-RL_DEBUG_VMASK=0xFFF timeout 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > gpurun_out/bench_vmask.json 2> gpurun_out/bench_vmask.err
-short gpurun_out/bench_vmask.json
+for m in 1 4; do
+RL_APPLY_WG_PER_CU=$m timeout 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > gpurun_out/bench_wg$m.json 2> gpurun_out/bench_wg$m.err
+short gpurun_out/bench_wg$m.json
+done
