@@ -184,11 +184,17 @@ def main():
         dom = max(per, key=lambda k: per[k]) if per else "apply"
         dom_gbps = ALGO_BYTES[dom] * hits_per_launch / (per[dom] * 1e-3) / 1e9 if per.get(dom, 0) > 0 else 0.0
         pipe_ms = sum(per.values())
+        kname = {"apply": "k_bkt_apply", "hist": "k_bkt_hist", "scan": "k_bkt_scan", "scatter": "k_bkt_scatter"}.get(
+            dom, "k_" + dom.replace("legacy_", ""))
+        # HBM bytes per launch of that kernel from the PMC passes of the last profiling visit
+        # (scripts/gpu_profile.sh -> scripts/summarize_prof.py -> profiles/traffic.json): counters cannot
+        # be collected inside this run, so the figure is the committed one for this workload or null.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        default_workload = (args.keys, args.batch, args.zipf) == (10_000_000, 1_000_000, 0.99)
+        if os.path.exists(tpath) and default_workload and world == 1:
             try:
-                traffic = json.load(open(tpath)).get("k_" + dom, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath))["kernels"].get(kname, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -202,7 +208,7 @@ def main():
                        "table_capacity_cells": cap, "cell_bytes": 64,
                        "parallelism": f"hash-sharded x{world}, RCCL all-to-all" if sharded else "single GPU",
                        "denied_in_last_batch": denied},
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_hit": ALGO_BYTES[dom], "hits_per_launch": hits_per_launch,
                          "avg_launch_ms": per.get(dom, 0.0)},

@@ -31,6 +31,8 @@ constexpr int BK_LOG2_MAX = 11;
 constexpr int BK_MAX = 1 << BK_LOG2_MAX;
 constexpr int HOT_MAX = 128;                  // keys that get a bucket of their own
 constexpr int BKT_MAX = BK_MAX + HOT_MAX;     // hash buckets + hot-key buckets
+constexpr int HOT_COLS = 3 * HOT_MAX;         // per tile and hot key: largest delta, largest ~delta, a limit id
+constexpr int ROW_MAX = BKT_MAX + HOT_COLS;   // columns of one tile's row of the histogram matrix
 constexpr int PT_BLOCK = 1024;                // 16 waves per workgroup
 constexpr int PT_WAVES = PT_BLOCK / 64;
 constexpr int PT_STEPS = 4;                   // 64-hit steps per wave
@@ -63,13 +65,9 @@ struct HotState {  // the hot key's cell as it was before this batch (snapshot t
     u32 climit;    // the cell's limit attribute
     u32 pad;
 };
-// Zeroed before every batch (one memset): the status block, then per hot key the largest delta
-// and the largest ~delta (== ~smallest) seen in the batch.
+// Zeroed before every batch (one memset).
 struct BatchScratch {
     Status st;
-    u32 hot_dmax[HOT_MAX];
-    u32 hot_ndmin[HOT_MAX];
-    u32 hot_limit[HOT_MAX];  // the limit id one of the key's hits carried
 };
 // What k_bkt_apply needs to decide a hot key's bucket, prepared once per batch by k_bkt_scatter.
 struct HotParam {
@@ -115,14 +113,25 @@ __device__ __forceinline__ u32 bucket_of_hash(u64 hh, u32 bk_log2) {
 // LDS lookup table of the hot set: build (all threads call it; needs a barrier afterwards).
 __device__ __forceinline__ void hot_table_build(const HotSet* __restrict__ hot, u64 seed, u64* s_key,
                                                 u32* s_idx) {
-    for (u32 q = threadIdx.x; q < (u32)HOT_HASH; q += blockDim.x) s_key[q] = TAG_EMPTY;
+    // the count and the keys are fetched together (one HBM latency, not two)
+    const u32 n_raw = hot->n;
+    const u64 k = threadIdx.x < (u32)HOT_MAX ? hot->key[threadIdx.x] : TAG_EMPTY;
+    for (u32 q = threadIdx.x; q < (u32)HOT_HASH; q += blockDim.x) {
+        s_key[q] = TAG_EMPTY;
+        s_idx[q] = 0xFFFFFFFFu;
+    }
     __syncthreads();
-    const u32 n = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
+    const u32 n = n_raw < (u32)HOT_MAX ? n_raw : (u32)HOT_MAX;
     if (threadIdx.x < n) {
-        const u64 k = hot->key[threadIdx.x];
+        // A key listed twice still gets ONE slot, and the smaller of its indices: every workgroup
+        // of every kernel of the batch must map a key to the same bucket.
         u32 q = (u32)(fmix64(k ^ seed) >> 8) & (HOT_HASH - 1);
-        while (atomicCAS(&s_key[q], TAG_EMPTY, k) != TAG_EMPTY) q = (q + 1) & (HOT_HASH - 1);
-        s_idx[q] = threadIdx.x;
+        for (;;) {
+            const u64 prev = atomicCAS(&s_key[q], TAG_EMPTY, k);
+            if (prev == TAG_EMPTY || prev == k) break;
+            q = (q + 1) & (HOT_HASH - 1);
+        }
+        atomicMin(&s_idx[q], threadIdx.x);
     }
 }
 // -1, or the key's index in the hot set.  `hh` = fmix64(key ^ seed).
@@ -136,9 +145,25 @@ __device__ __forceinline__ int hot_lookup(const u64* s_key, const u32* s_idx, u6
     }
 }
 
+// Lanes of the wave whose `d` equals mine (among `valid` lanes): one ballot per bucket-id bit.
+__device__ __forceinline__ u64 match_digit(u32 d, u32 nbits, u64 valid) {
+    u64 m = valid;
+#pragma unroll
+    for (u32 b = 0; b < (u32)BK_LOG2_MAX + 1u; ++b) {
+        if (b < nbits) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bm = __ballot(bit);
+            m &= bit ? bm : ~bm;
+        }
+    }
+    return m;
+}
+
 // ---------------------------------------------------------------------------------------------
-// k_bkt_hist: hist[tile * nbt + bucket] = hits of `tile` that belong to `bucket`
-// (nbt = 2^bk_log2 hash buckets + HOT_MAX hot-key buckets).
+// k_bkt_hist: hist[tile * nrow + bucket] = hits of `tile` that belong to `bucket`
+// (nbt = 2^bk_log2 hash buckets + HOT_MAX hot-key buckets; a row has nrow = nbt + HOT_COLS columns:
+// behind the counts, per hot key, the largest delta, the largest ~delta and a limit id the tile saw —
+// k_bkt_scan reduces those columns with max, so no global atomic is needed for them).
 // Also the only place the batch is validated, so that k_bkt_apply can refuse to touch the table
 // when the batch is malformed: limit id range, reserved keys, and (in_memory.rs:106-107) a
 // simple counter must already have its cell.
@@ -172,9 +197,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     hot_table_build(hot, seed, s_hot_key, s_hot_idx);
     __syncthreads();
     u32 err = 0;
+    int hidx[PT_TILE / PT_BLOCK];
 #pragma unroll
     for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
         const u32 i = base + r * PT_BLOCK + tid;
+        hidx[r] = -1;
         if (i < n) {
             if ((h[r].limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
             else if (h[r].key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
@@ -186,27 +213,40 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
                 if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
             }
             const u64 hh = fmix64(h[r].key ^ seed);
-            const int hi = hot_lookup(s_hot_key, s_hot_idx, h[r].key, hh);
-            if (hi >= 0) {
-                atomicAdd(&s_hist[nb + hi], 1u);
-                // extrema of the key's deltas: read first, so that after the first few hits of a key
-                // nothing but the count is an atomic on its (contended) LDS words
-                const u32 d = h[r].delta;
-                if (d > s_dmax[hi]) atomicMax(&s_dmax[hi], d);
-                if (~d > s_ndmin[hi]) atomicMax(&s_ndmin[hi], ~d);
-                s_hlimit[hi] = h[r].limit;
-            } else {
-                atomicAdd(&s_hist[bucket_of_hash(hh, bk_log2)], 1u);
-            }
+            hidx[r] = hot_lookup(s_hot_key, s_hot_idx, h[r].key, hh);
+            if (hidx[r] < 0) atomicAdd(&s_hist[bucket_of_hash(hh, bk_log2)], 1u);
         }
+    }
+    // Hot keys: many lanes of a wave carry the same key.  The lanes that share a key find each other
+    // with one ballot per index bit and their lowest lane adds the whole group to the count: one LDS
+    // atomic per distinct key per wave-step instead of one per hit.
+    const u64 lt = (1ull << (tid & 63u)) - 1ull;
+#pragma unroll
+    for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
+        const bool is_hot = hidx[r] >= 0;
+        const u64 valid = __ballot(is_hot);
+        if (!valid) continue;
+        const u64 m = match_digit(is_hot ? (u32)hidx[r] : 0u, 7u, valid);
+        if (!is_hot) continue;
+        const u32 d = h[r].delta;
+        const bool leader = (m & lt) == 0ull;
+        if (leader) {
+            atomicAdd(&s_hist[nb + hidx[r]], (u32)__popcll(m));
+            s_hlimit[hidx[r]] = h[r].limit;
+        }
+        // extrema of the key's deltas: read first, so that only a new extreme is an atomic
+        if (d > s_dmax[hidx[r]]) atomicMax(&s_dmax[hidx[r]], d);
+        if (~d > s_ndmin[hidx[r]]) atomicMax(&s_ndmin[hidx[r]], ~d);
     }
     if (err) atomicOr(&st->err, err);
     __syncthreads();
-    for (u32 b = tid; b < nbt; b += PT_BLOCK) hist[(size_t)blockIdx.x * nbt + b] = s_hist[b];
-    if (tid < HOT_MAX && s_hist[nb + tid]) {
-        atomicMax(&bs->hot_dmax[tid], s_dmax[tid]);
-        atomicMax(&bs->hot_ndmin[tid], s_ndmin[tid]);
-        bs->hot_limit[tid] = s_hlimit[tid];
+    u32* row = hist + (size_t)blockIdx.x * (nbt + HOT_COLS);
+    for (u32 b = tid; b < nbt; b += PT_BLOCK) row[b] = s_hist[b];
+    if (tid < HOT_MAX) {
+        const bool any = s_hist[nb + tid] != 0;
+        row[nbt + tid] = any ? s_dmax[tid] : 0u;
+        row[nbt + HOT_MAX + tid] = any ? s_ndmin[tid] : 0u;
+        row[nbt + 2 * HOT_MAX + tid] = any ? s_hlimit[tid] : 0u;
     }
 }
 
@@ -218,31 +258,38 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
 __global__ __launch_bounds__(1024) void k_bkt_scan(u32* __restrict__ hist, u32 ntiles, u32 nbt,
                                                    u32* __restrict__ total) {
     __shared__ u32 s_part[32][32];
+    const u32 nrow = nbt + HOT_COLS;
     const u32 cl = threadIdx.x & 31u;
     const u32 c = blockIdx.x * 32 + cl;
+    const bool is_max = c >= nbt;  // the hot-key attribute columns: total[c] = max over the tiles
     const u32 g = threadIdx.x >> 5;
     const u32 per = (ntiles + 31) / 32;
     const u32 t_lo = g * per < ntiles ? g * per : ntiles;
     const u32 t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
     u32 sum = 0;
-    if (c < nbt) {
+    if (c < nrow) {
 #pragma unroll 8
-        for (u32 t = t_lo; t < t_hi; ++t) sum += hist[(size_t)t * nbt + c];
+        for (u32 t = t_lo; t < t_hi; ++t) {
+            const u32 v = hist[(size_t)t * nrow + c];
+            sum = is_max ? (v > sum ? v : sum) : sum + v;
+        }
     }
     s_part[g][cl] = sum;
     __syncthreads();
-    if (c >= nbt) return;
+    if (c >= nrow) return;
     u32 run = 0, all = 0;
     for (u32 gg = 0; gg < 32; ++gg) {
         const u32 x = s_part[gg][cl];
         if (gg < g) run += x;
-        all += x;
+        all = is_max ? (x > all ? x : all) : all + x;
     }
+    if (!is_max) {
 #pragma unroll 8
-    for (u32 t = t_lo; t < t_hi; ++t) {
-        const u32 v = hist[(size_t)t * nbt + c];
-        hist[(size_t)t * nbt + c] = run;
-        run += v;
+        for (u32 t = t_lo; t < t_hi; ++t) {
+            const u32 v = hist[(size_t)t * nrow + c];
+            hist[(size_t)t * nrow + c] = run;
+            run += v;
+        }
     }
     if (g == 0) total[c] = all;
 }
@@ -268,20 +315,6 @@ __device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* s_w, u32& total)
     __syncthreads();
     total = tot;
     return woff + inc - v;
-}
-
-// Lanes of the wave whose `d` equals mine (among `valid` lanes): one ballot per bucket-id bit.
-__device__ __forceinline__ u64 match_digit(u32 d, u32 nbits, u64 valid) {
-    u64 m = valid;
-#pragma unroll
-    for (u32 b = 0; b < (u32)BK_LOG2_MAX + 1u; ++b) {
-        if (b < nbits) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bm = __ballot(bit);
-            m &= bit ? bm : ~bm;
-        }
-    }
-    return m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -346,7 +379,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                 slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, k, 0u, limits,
                                              0ull, st, dummy);
                 hp.slot = slot;
-                hp.limit = bs->hot_limit[tid];
+                hp.limit = total[nbt_ + 2 * HOT_MAX + tid];
                 bool limit_ok = true;
                 if (slot != SLOT_INVALID) {
                     const Cell* c = &table[slot];
@@ -355,7 +388,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                     hp.s = expiry <= now ? 0ull : c->value;
                     limit_ok = c->limit == hp.limit;
                 }
-                const u32 dmax = bs->hot_dmax[tid], dmin = ~bs->hot_ndmin[tid];
+                const u32 dmax = total[nbt_ + tid], dmin = ~total[nbt_ + HOT_MAX + tid];
                 const LimitDev L = limits[hp.limit & ~SIMPLE_FLAG];
                 hp.d = dmax;
                 if (dmin == dmax && L.window_us != 0 && hp.s < (1ull << 62) && limit_ok &&
@@ -401,7 +434,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         u32 lo[3] = {ex, ex + c[0], ex + c[0] + c[1]};
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            if (b0 + q < nbt) s_base[b0 + q] = lo[q] + hist[(size_t)blockIdx.x * nbt + b0 + q];
+            if (b0 + q < nbt) s_base[b0 + q] = lo[q] + hist[(size_t)blockIdx.x * (nbt + HOT_COLS) + b0 + q];
         if (blockIdx.x == 0) {
             u32 g[3];
 #pragma unroll
@@ -511,6 +544,7 @@ struct ApplyLds {
     HotParam hot[HOT_MAX + 1];  // copy of the batch's hot-bucket table
     u32 n_ent;
     u32 bucket_len;
+    u32 promote_ok;  // 0 while a hot bucket is replayed: its key is kept or dropped by count, not promoted
     u32 any_slow;
     u32 n_created;
     u32 n_keep;
@@ -559,7 +593,7 @@ __device__ __forceinline__ void apply_commit(ApplyLds& S, const ApplyArgs& A, bo
         u32 f = S.flags[e];
         // promote: the key absorbed HOT_PROMOTE hits, or it is what made this bucket long (hits denied
         // on the spot by the window pass are not counted, so a saturated key shows fewer than it got)
-        if (!rebuild && !(f & EF_BAD) &&
+        if (!rebuild && !(f & EF_BAD) && S.promote_ok &&
             ((f >> EF_COUNT_SHIFT) >= HOT_PROMOTE ||
              ((f >> EF_COUNT_SHIFT) >= HOT_PROMOTE / 4 && S.bucket_len >= 2 * HOT_PROMOTE))) {
             const u32 pos = atomicAdd(&A.hot_next->n, 1u);
@@ -1115,6 +1149,7 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
     }
     RL_STAMP(13);
     // ---- everything else: replayed by one worker per bucket ---------------------------------------
+    if (tid == 0) S.promote_ok = 0;  // (apply_bucket starts with a barrier)
     for (u32 hk = worker; hk < (u32)HOT_MAX; hk += n_workers) {
         const HotParam hp = S.hot[hk];
         if (hp.fast || hp.hi == hp.lo) continue;
@@ -1151,7 +1186,10 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     }
     for (u32 q = tid; q < (u32)LIM_LDS && q < n_limits; q += AP_BLOCK) S.lim[q] = limits[q];
     if (tid <= HOT_MAX) S.hot[tid] = hot_param[tid];
-    if (tid == 0) S.n_created = 0;
+    if (tid == 0) {
+        S.n_created = 0;
+        S.promote_ok = 1;
+    }
     __syncthreads();
     auto first_n = [](uint2 r) { return (r.y - r.x) < (u32)AP_R ? (r.y - r.x) : (u32)AP_R; };
     // Three input buffers used round-robin (bucket t decides from b[t % 3] while the lines of bucket

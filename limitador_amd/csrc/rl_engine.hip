@@ -295,7 +295,7 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
     k_bkt_hist<<<ntiles, PT_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits,
                                                    (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
-    k_bkt_scan<<<cdiv(nbt, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
+    k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
     k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
                                                           hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
@@ -610,8 +610,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_status, sizeof(BatchScratch));
     ALLOC(e->d_total, sizeof(unsigned long long));
     e->bk_tiles_max = cdiv(mb, PT_TILE) + 1;
-    ALLOC(e->d_bk_hist, (size_t)BKT_MAX * e->bk_tiles_max * sizeof(u32));
-    ALLOC(e->d_bk_total, (size_t)BKT_MAX * sizeof(u32));
+    ALLOC(e->d_bk_hist, (size_t)ROW_MAX * e->bk_tiles_max * sizeof(u32));
+    ALLOC(e->d_bk_total, (size_t)ROW_MAX * sizeof(u32));
     ALLOC(e->d_bk_ranges, (size_t)BK_MAX * sizeof(uint2));
     ALLOC(e->d_hot, 2 * sizeof(HotSet));
     if (hipMemset(e->d_hot, 0, 2 * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);

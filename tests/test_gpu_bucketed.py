@@ -1,0 +1,192 @@
+"""Parity cases aimed at the code paths of the bucketed hot path (limitador_amd/csrc/rl_bucket.hpp):
+long hash buckets (window pass, deferred ring, LDS rebuilds), hot-key buckets (decided from their
+position; replayed when they do not fit that form), hot-set promotion / demotion, and the fallbacks.
+Every case is bit-exact against the CPU oracle.  Needs a MI355X."""
+import numpy as np
+import pytest
+
+from limitador_amd import workloads as W
+from limitador_amd.wire import CELL_ROW_DTYPE, HIT_DTYPE, RL_SIMPLE
+from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_both  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x9E3779B97F4A7C15  # Engine's default hash_seed
+M64 = (1 << 64) - 1
+
+
+def fmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint64(33))
+        x = x * np.uint64(0xFF51AFD7ED558CCD)
+        x = x ^ (x >> np.uint64(33))
+        x = x * np.uint64(0xC4CEB9FE1A85EC53)
+        x = x ^ (x >> np.uint64(33))
+    return x
+
+
+def bucket_log2(n_hits):
+    """rl_engine.hip run_check_k1_bucketed: buckets for a batch of n_hits."""
+    per = -(-n_hits // 384)
+    return min(11, max(0, int(np.ceil(np.log2(per))) if per > 1 else 0))
+
+
+def keys_in_bucket(n_keys, n_hits, bucket=0, start=1):
+    """n_keys distinct keys that all fall into hash bucket `bucket` for a batch of n_hits."""
+    b = bucket_log2(n_hits)
+    out = []
+    x = start
+    while len(out) < n_keys:
+        cand = np.arange(x, x + 200_000, dtype=np.uint64)
+        k = W.splitmix64(cand)
+        if b:
+            k = k[(fmix64(k ^ np.uint64(SEED)) >> np.uint64(64 - b)) == bucket]
+        out.extend(int(v) for v in k[: n_keys - len(out)])
+        x += 200_000
+    return np.array(out, dtype=np.uint64)
+
+
+def make_hits(keys, limits, deltas):
+    h = np.empty(len(keys), dtype=HIT_DTYPE)
+    h["key"] = keys
+    h["limit"] = limits
+    h["delta"] = deltas
+    return h
+
+
+@pytest.mark.parametrize("seed,n_keys", [(1, 40), (2, 900), (3, 6000)])
+def test_one_long_bucket_windows_ring_and_rebuilds(make_engine, seed, n_keys):
+    """Every hit of the batch lands in ONE hash bucket: 40 keys (all in LDS, window pass denies the
+    saturated ones), 900 keys (LDS rebuilds) and 6000 keys (rebuilds every round)."""
+    rng = np.random.default_rng(seed)
+    n = 30_000
+    rows = [(7, 60), (300, 60), (2**64 - 1, 60), (3, 0), (40, 1)]
+    eng, orc = pair(make_engine, rows, max_batch_hits=n)
+    keys = keys_in_bucket(n_keys, n)
+    key_limit = rng.integers(0, 5, size=n_keys)
+    now = NOW
+    for step in range(5):
+        idx = (rng.zipf(1.2, size=n) - 1) % n_keys if step % 2 == 0 else rng.integers(0, n_keys, size=n)
+        deltas = 1 if step < 2 else rng.integers(0, 5, size=n)
+        run_both(eng, orc, make_hits(keys[idx], key_limit[idx], deltas), now)
+        now += int(rng.integers(0, 2 * SEC))
+    assert_same_state(eng, orc)
+
+
+def test_hot_keys_are_promoted_decided_by_position_and_demoted(make_engine):
+    rng = np.random.default_rng(11)
+    n = 120_000
+    rows = [(5000, 60), (100, 60), (10**9, 60), (50, 0)]
+    eng, orc = pair(make_engine, rows, max_batch_hits=n, capacity_cells=1 << 18)
+    n_bg = 50_000
+    bg = W.splitmix64(np.arange(1000, 1000 + n_bg, dtype=np.uint64))
+    hot = W.splitmix64(np.arange(10, 18, dtype=np.uint64))  # 8 keys, ~7500 hits each
+    hot_limit = np.array([0, 0, 1, 1, 2, 2, 3, 0])
+
+    def batch(hot_share, deltas_fn):
+        is_hot = rng.random(n) < hot_share
+        hi = rng.integers(0, len(hot), size=n)
+        bi = rng.integers(0, n_bg, size=n)
+        keys = np.where(is_hot, hot[hi], bg[bi])
+        limits = np.where(is_hot, hot_limit[hi], bi % 3)
+        return make_hits(keys, limits, deltas_fn(n, is_hot))
+
+    ones = lambda n_, h_: np.ones(n_, dtype=np.uint32)  # noqa: E731
+    now = NOW
+    run_both(eng, orc, batch(0.5, ones), now)  # the hot keys sit in hash buckets: long buckets, promotion
+    for step in range(3):  # now in hot buckets, uniform delta: decided by position
+        now += 1000
+        run_both(eng, orc, batch(0.5, ones), now)
+    # mixed deltas on the hot keys: the hot buckets are replayed
+    now += 1000
+    run_both(eng, orc, batch(0.5, lambda n_, h_: rng.integers(0, 4, size=n_).astype(np.uint32)), now)
+    # uniform but larger delta, after the windows rolled over (contested inside the batch)
+    now += 61 * SEC
+    run_both(eng, orc, batch(0.5, lambda n_, h_: np.full(n_, 3, dtype=np.uint32)), now)
+    # delta 0 everywhere (admitted iff value <= max, and still refreshes an expired window)
+    now += 61 * SEC
+    run_both(eng, orc, batch(0.5, lambda n_, h_: np.zeros(n_, dtype=np.uint32)), now)
+    # the hot keys' cells are evicted: the hot path has to create them (in_memory.rs:122-127)
+    now += 61 * SEC
+    assert eng.sweep_expired(now) == orc.sweep_expired(now)
+    run_both(eng, orc, batch(0.5, ones), now)
+    # traffic moves away: the hot set empties again
+    for step in range(2):
+        now += 1000
+        run_both(eng, orc, batch(0.0, ones), now)
+    now += 1000
+    run_both(eng, orc, batch(0.5, ones), now)
+    assert_same_state(eng, orc)
+
+
+def test_more_hot_keys_than_hot_buckets(make_engine):
+    rng = np.random.default_rng(12)
+    n = 400_000
+    eng, orc = pair(make_engine, [(900, 60)], max_batch_hits=n, capacity_cells=1 << 16)
+    keys = W.splitmix64(np.arange(1, 301, dtype=np.uint64))  # 300 keys x ~1333 hits: all above the bar
+    now = NOW
+    for step in range(3):
+        run_both(eng, orc, make_hits(keys[rng.integers(0, 300, size=n)], 0, 1), now)
+        now += 1000
+    assert_same_state(eng, orc)
+
+
+def test_hot_simple_counter_and_wrapping_hot_value(make_engine):
+    """A simple limit every request hits is the canonical hot key; and a hot key whose value sits
+    next to 2^64 has to be replayed with the reference's wrapping add."""
+    rng = np.random.default_rng(13)
+    n = 50_000
+    rows = [(10_000, 60), (2**64 - 1, 60), (5, 60)]
+    eng, orc = pair(make_engine, rows, simple_keys=[(0, 7_000_001)], max_batch_hits=n)
+    cell = np.zeros(1, dtype=CELL_ROW_DTYPE)
+    cell[0] = (4242, 1, 0, 2**64 - 40, NOW + 30 * SEC)
+    eng.load_cells(cell)
+    orc.load_cells([4242], [1], [2**64 - 40], [NOW + 30 * SEC])
+    bg = W.splitmix64(np.arange(500, 900, dtype=np.uint64))
+    now = NOW
+    for step in range(4):
+        which = rng.random(n)
+        keys = np.where(which < 0.4, 7_000_001, np.where(which < 0.7, 4242, bg[rng.integers(0, 400, size=n)]))
+        limits = np.where(which < 0.4, 0 | RL_SIMPLE, np.where(which < 0.7, 1, 2)).astype(np.uint32)
+        run_both(eng, orc, make_hits(keys, limits, 1), now)
+        now += 1000
+    assert_same_state(eng, orc, n_simple_expected=1)
+
+
+def test_hot_key_with_two_limit_ids_is_reported(make_engine):
+    from limitador_amd.engine import EngineError
+
+    n = 20_000
+    eng, orc = pair(make_engine, [(10**6, 60), (10**6, 60)], max_batch_hits=n)
+    good = make_hits(np.full(n, 99, dtype=np.uint64), 0, 1)
+    run_both(eng, orc, good, NOW)       # promoted
+    run_both(eng, orc, good, NOW + 1)   # decided by position
+    bad = good.copy()
+    bad["limit"][n // 2] = 1
+    with pytest.raises(EngineError) as e:
+        eng.check_and_update(bad, NOW + 2)
+    assert e.value.code == -6
+
+
+def test_limit_tables_larger_than_the_lds_copy_take_the_first_generation_path(make_engine):
+    rng = np.random.default_rng(14)
+    rows = [(int(rng.integers(1, 50)), 60) for _ in range(700)]
+    eng, orc = pair(make_engine, rows, max_limits=1024)
+    idx = rng.integers(0, 5000, size=20_000)
+    hits = make_hits(W.splitmix64(idx.astype(np.uint64)), idx % 700, 1)
+    run_both(eng, orc, hits, NOW)
+    run_both(eng, orc, hits, NOW + 1)
+    assert_same_state(eng, orc)
+    assert eng.stats()["ordered_batches"] > 0  # the legacy pipeline ran
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 383, 385, 511, 513, 1025, 4097, 8191])
+def test_batch_sizes_around_the_tile_and_round_boundaries(make_engine, n):
+    rng = np.random.default_rng(n)
+    eng, orc = pair(make_engine, [(3, 60), (1, 0)])
+    keys = W.splitmix64(rng.integers(0, max(2, n // 3), size=n).astype(np.uint64))
+    hits = make_hits(keys, (keys % np.uint64(2)).astype(np.uint32), rng.integers(0, 3, size=n))
+    run_both(eng, orc, hits, NOW)
+    run_both(eng, orc, hits, NOW + 5)
+    assert_same_state(eng, orc)
