@@ -18,10 +18,17 @@
 // reset: update_if_expired, atomic_expiring_value.rs:87-99) back once.
 //
 //   k_bkt_hist     per tile of the batch: hits per bucket (LDS histogram); validates the hits
-//   k_bkt_scan     per bucket: exclusive scan of its tile counts (one wave per bucket)
-//   k_bkt_starts   bucket starts (exclusive scan of the bucket totals) + processing order
-//   k_bkt_scatter  stable partition: 16-B hit records + original indices into bucket order
-//   k_bkt_apply    one workgroup per bucket: the replay described above
+//   k_bkt_scan     per bucket: exclusive scan of its tile counts; bucket totals
+//   k_bkt_scatter  stable partition into bucket order (16-B records); one extra workgroup prepares
+//                  the hot keys' buckets (HotParam)
+//   k_bkt_apply    persistent workgroups, one hash bucket at a time: the replay described above,
+//                  with the next bucket's inputs in flight; then the hot buckets, from positions
+//
+// Hot keys (a Zipf head, a simple limit every request of a namespace hits) would make one bucket
+// — one workgroup — the critical path.  A key that absorbed HOT_PROMOTE hits in one batch gets a
+// bucket of its own in the next: stable partition + one key per bucket means a hit's position in
+// the bucket IS its trace-order rank on the key, so with a single delta value the verdict is
+// rank < (max - value) / delta for any number of workgroups in parallel (apply_hot).
 #pragma once
 #include "rl_kernels.hpp"
 
@@ -55,15 +62,6 @@ struct HotSet {
     u32 n;
     u32 pad;
     u64 key[HOT_MAX];
-};
-constexpr u32 HS_FOUND = 1u;
-constexpr u32 HS_EXPIRED = 2u;
-struct HotState {  // the hot key's cell as it was before this batch (snapshot taken by k_bkt_hist)
-    u64 s;         // value_at(now)
-    u32 slot;      // SLOT_INVALID: no cell yet
-    u32 flags;
-    u32 climit;    // the cell's limit attribute
-    u32 pad;
 };
 // Zeroed before every batch (one memset).
 struct BatchScratch {
