@@ -58,3 +58,21 @@ def test_owner_of_is_a_pure_function(engine_lib):
     seen = {engine_lib.rl_owner_of(k * 0x9E3779B97F4A7C15 % (1 << 64), 7, 8) for k in range(1000)}
     assert seen == set(range(8))
     assert engine_lib.rl_owner_of(12345, 7, 1) == 0
+
+
+def _storage_header_symbols():
+    src = open(os.path.join(ROOT, "include", "rl_storage.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rls_[a-z0-9_]+)\s*\(", src)) - {"rls_emit_fn"})
+
+
+def test_host_mirror_library_exports_every_declared_symbol(engine_lib):
+    """include/rl_storage.h (C view of the C++ CounterStorage mirror) against librl_storage.so."""
+    from limitador_amd import host_storage
+
+    so = host_storage.load()
+    syms = _storage_header_symbols()
+    assert "rls_check_and_update" in syms and "rls_batcher_check_and_update" in syms
+    for name in syms:
+        assert hasattr(so, name), f"{name} declared in rl_storage.h but not exported"
+        assert name in host_storage.SYMBOLS, f"{name} has no ctypes signature in limitador_amd/host_storage.py"
