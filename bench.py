@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--zipf", type=float, default=0.99, help="0 => uniform keys")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--cap-mult", type=float, default=1.0, help="scale the table capacity (experiments)")
+    ap.add_argument("--depth", type=int, default=2, choices=(1, 2),
+                    help="batches in flight on one GPU: 2 = submit batch k+1 before collecting batch k "
+                         "(rl_check_and_update_submit_device / _collect), 1 = one blocking call per batch")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the routed (all-to-all) data path even with one rank (exercises the N>1 code on one GPU)")
     return ap.parse_args()
@@ -134,6 +137,7 @@ def main():
     batches = [W.torch_batch(n_keys_total, args.batch, dev, gen, cdf) for _ in range(total_steps)]
     del cdf
     verdict = torch.empty(args.batch, dtype=torch.uint8, device=dev)
+    verdicts = [verdict, torch.empty(args.batch, dtype=torch.uint8, device=dev)]
     torch.cuda.synchronize()
 
     if sharded:
@@ -143,14 +147,32 @@ def main():
 
         def step(i, now):
             sh.check_and_update(batches[i], now, verdict)
-    else:
+    elif args.depth == 1:
         def step(i, now):
             eng.check_and_update_device(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
+    else:
+        # Two batches in flight: batch i is enqueued behind batch i-1 on the engine's stream before the
+        # host waits for batch i-1, so the device never idles between batches.  Batches are applied in
+        # submission order; every step's batch has completed when the timed region ends (drain()).
+        pending = [0]
+
+        def step(i, now):
+            eng.submit_device(batches[i].data_ptr(), args.batch, now, verdicts[i & 1].data_ptr())
+            if pending[0]:
+                eng.collect()
+            else:
+                pending[0] = 1
+
+    def drain():
+        if not sharded and args.depth == 2 and pending[0]:
+            eng.collect()
+            pending[0] = 0
 
     now = W.NOW0_US
     for i in range(args.warmup):
         step(i, now)
         now += 1000
+    drain()
     eng.kernel_timing(True)
     eng.kernel_timing_read(reset=True)
     denied = 0
@@ -162,6 +184,7 @@ def main():
     for i in range(args.warmup, total_steps):
         step(i, now)
         now += 1000
+    drain()
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
@@ -169,7 +192,7 @@ def main():
     dt = time.perf_counter() - t0
     kt = eng.kernel_timing_read(reset=True)
     eng.kernel_timing(False)
-    denied = int(verdict.sum().item())
+    denied = int((verdicts[(total_steps - 1) & 1] if (not sharded and args.depth == 2) else verdict).sum().item())
     if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,6 +230,7 @@ def main():
                        "keys_per_gpu": args.keys, "batch_per_gpu": args.batch, "zipf_s": args.zipf,
                        "table_capacity_cells": cap, "cell_bytes": 64,
                        "parallelism": f"hash-sharded x{world}, RCCL all-to-all" if sharded else "single GPU",
+                       "batches_in_flight": 1 if sharded else args.depth,
                        "denied_in_last_batch": denied},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,

@@ -48,7 +48,8 @@ typedef enum {
                                    here (in_memory.rs:107 `.unwrap()`) */
     RL_ERR_KEY_LIMIT = -6,      /* a hit's limit id differs from the one stored with its key */
     RL_ERR_BATCH_TOO_LARGE = -7,
-    RL_ERR_NOMEM = -8
+    RL_ERR_NOMEM = -8,
+    RL_ERR_BUSY = -9            /* batches are in flight (rl_check_and_update_submit_device): collect them first */
 } rl_status;
 
 /* bit 31 of a limit id marks a counter of a limit WITHOUT variables ("simple", the
@@ -150,6 +151,16 @@ int32_t rl_check_and_update_batch_device(rl_engine *e, const rl_hit *d_hits, uin
                                          uint64_t now_us, int32_t load_counters,
                                          uint8_t *d_verdict, int32_t *d_first_limited,
                                          uint64_t *d_remaining, uint64_t *d_expires_in_us);
+
+/* The same for single-counter requests (every hit its own request, no load_counters), split in two so
+ * that a feeder (a micro-batcher) can keep the device busy: _submit enqueues the batch on the engine's
+ * stream and returns; _collect waits for the OLDEST submitted batch and returns ITS status (verdicts
+ * and first_limited of that batch are then complete).  At most two batches may be in flight; they are
+ * applied in submission order, so the sequential contract holds across them.  While batches are in
+ * flight every other entry point returns RL_ERR_BUSY. */
+int32_t rl_check_and_update_submit_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
+                                          uint8_t *d_verdict, int32_t *d_first_limited);
+int32_t rl_check_and_update_collect(rl_engine *e);
 
 /* CounterStorage::is_within_limits (in_memory.rs:20-35), one verdict per hit, read-only:
  * within[i] = max_value >= value_at(now) + delta; a missing cell reads as 0. */

@@ -63,9 +63,13 @@ struct HotSet {
     u32 pad;
     u64 key[HOT_MAX];
 };
-// Zeroed before every batch (one memset).
+// Per-batch scratch of the bucketed path.  Two of them alternate: the last workgroup of a batch's
+// k_bkt_apply mirrors the status block to host-mapped memory (no copy command behind the batch) and
+// zeroes the OTHER one for the next batch (no memset command in front of it).
 struct BatchScratch {
     Status st;
+    u32 ticket;  // workgroups of k_bkt_apply that have finished
+    u32 pad[15];
 };
 // What k_bkt_apply needs to decide a hot key's bucket, prepared once per batch by k_bkt_scatter.
 struct HotParam {
@@ -171,13 +175,18 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
                                                        const LimitDev* __restrict__ limits,
                                                        u32 n_limits, u32 bk_log2, u32 ntiles,
                                                        u32* __restrict__ hist, BatchScratch* bs,
-                                                       const HotSet* __restrict__ hot) {
+                                                       const HotSet* __restrict__ hot, u64* htrace) {
     __shared__ u32 s_hist[BKT_MAX];
     __shared__ u64 s_hot_key[HOT_HASH];
     __shared__ u32 s_hot_idx[HOT_HASH];
     __shared__ u32 s_dmax[HOT_MAX], s_ndmin[HOT_MAX], s_hlimit[HOT_MAX];
     const u32 tid = threadIdx.x;
     Status* st = &bs->st;
+#define RL_HSTAMP(k)                                                                           \
+    do {                                                                                       \
+        if (htrace && threadIdx.x == 0) htrace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+    RL_HSTAMP(0);
     const u32 nb = 1u << bk_log2;
     const u32 nbt = nb + HOT_MAX;
     for (u32 b = tid; b < nbt; b += PT_BLOCK) s_hist[b] = 0;
@@ -192,8 +201,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
         const u32 i = base + r * PT_BLOCK + tid;
         if (i < n) h[r] = load_hit(hits, i);
     }
+    RL_HSTAMP(1);
     hot_table_build(hot, seed, s_hot_key, s_hot_idx);
     __syncthreads();
+    RL_HSTAMP(2);
     u32 err = 0;
     int hidx[PT_TILE / PT_BLOCK];
 #pragma unroll
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
             if (hidx[r] < 0) atomicAdd(&s_hist[bucket_of_hash(hh, bk_log2)], 1u);
         }
     }
+    RL_HSTAMP(3);
     // Hot keys: many lanes of a wave carry the same key.  The lanes that share a key find each other
     // with one ballot per index bit and their lowest lane adds the whole group to the count: one LDS
     // atomic per distinct key per wave-step instead of one per hit.
@@ -237,7 +249,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
         if (~d > s_ndmin[hidx[r]]) atomicMax(&s_ndmin[hidx[r]], ~d);
     }
     if (err) atomicOr(&st->err, err);
+    RL_HSTAMP(4);
     __syncthreads();
+    RL_HSTAMP(5);
     u32* row = hist + (size_t)blockIdx.x * (nbt + HOT_COLS);
     for (u32 b = tid; b < nbt; b += PT_BLOCK) row[b] = s_hist[b];
     if (tid < HOT_MAX) {
@@ -246,6 +260,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
         row[nbt + HOT_MAX + tid] = any ? s_ndmin[tid] : 0u;
         row[nbt + 2 * HOT_MAX + tid] = any ? s_hlimit[tid] : 0u;
     }
+    RL_HSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1171,7 +1186,8 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
     const HotParam* __restrict__ hot_param,
     const LimitDev* __restrict__ limits, u32 n_limits, u64 now, uint8_t* __restrict__ verdict,
-    int32_t* __restrict__ first_limited, BatchScratch* bs, HotSet* hot_next, u32 vmask, u64* trace) {
+    int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_next, Status* host_status,
+    HotSet* hot_next, u32 vmask, u64* trace) {
     __shared__ ApplyLds S;
     __shared__ uint2 s_ranges[AP_MAX_PER_WG + 4];
     const u32 tid = threadIdx.x, G = gridDim.x;
@@ -1221,7 +1237,24 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     apply_hot(S, A, blockIdx.x, G);
     RL_STAMP(14);
     __syncthreads();
-    if (tid == 0 && S.n_created) atomicAdd(&bs->st.n_inserted, S.n_created);
+    if (tid == 0) {
+        // Last workgroup out: hand the status block to the host and reset the other scratch.  No
+        // agent-scope fence (a release would write the XCD's whole L2 back, once per workgroup):
+        // everything the last workgroup reads was written with device-scope atomics, and this
+        // workgroup's own contribution has RETURNED before its ticket is taken.
+        u32 dep = 0;
+        if (S.n_created) dep = atomicAdd(&bs->st.n_inserted, S.n_created);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(dep) : "memory");
+        if (atomicAdd(&bs->ticket, 1u) == G - 1) {
+            Status out{};
+            out.err = __hip_atomic_load(&bs->st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.n_inserted = __hip_atomic_load(&bs->st.n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.pad[0] = __hip_atomic_load(&bs->st.pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.pad[1] = __hip_atomic_load(&bs->st.pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *host_status = out;
+            *bs_next = BatchScratch{};
+        }
+    }
 }
 
 }  // namespace rl

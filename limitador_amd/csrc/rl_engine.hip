@@ -73,6 +73,17 @@ struct rl_engine {
     size_t scan_tmp_bytes = 0;
     Status* d_status = nullptr;
     Status* h_status = nullptr; // pinned
+    BatchScratch* d_bs = nullptr;   // [2], alternating (rl_bucket.hpp)
+    u32 bs_cur = 0;
+    // batches of the bucketed path submitted but not yet collected (at most two)
+    struct Inflight {
+        hipEvent_t tev[5]{};   // before hist / scan / scatter / apply, after apply (= done)
+        Status* h_st = nullptr;  // host-mapped: written by the batch's last workgroup
+        u32 n = 0, n_wg = 0, ntiles = 0;
+        bool timed = false;
+    } inflight[2];
+    u64 sub_seq = 0, col_seq = 0;
+    u64 inflight_hits = 0;
     unsigned long long* d_total = nullptr;
     unsigned long long* h_total = nullptr; // pinned
     // routing scratch
@@ -264,57 +275,9 @@ int run_check_k1_legacy(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t
     return RL_OK;
 }
 
-// check_and_update for single-counter requests, all pointers on the device: the bucketed
-// single-pass path (rl_bucket.hpp).  Five launches, one host synchronisation at the end.
-int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
-    int rc = check_room(e, n);
-    if (rc) return rc;
-    // k_bkt_apply commits as it goes, so a table that fills up mid-batch (RL_ERR_TABLE_FULL from the
-    // probe loop) leaves the batch partially applied; keep a margin so that only a batch bringing
-    // more than capacity/4 NEW keys into an almost full table can get there.
-    {
-        const u64 used = e->live + e->tombs, inc = n < e->cap / 4 ? n : e->cap / 4;
-        if (used + inc > e->cap - e->cap / 16)
-            return fail(e, RL_ERR_TABLE_FULL,
-                        "batch of %u hits could push the table past 15/16 occupancy (live=%llu tombstones=%llu "
-                        "capacity=%llu): sweep, compact or create a larger engine",
-                        n, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
-    }
-    const bool t = e->timing;
-    u32 bk_log2 = ceil_log2(cdiv(n, 384));
-    if (bk_log2 > e->bk_log2_cfg) bk_log2 = e->bk_log2_cfg;
-    const u32 nb = 1u << bk_log2;
-    const u32 ntiles = cdiv(n, PT_TILE);
-    const u32 nbt = nb + HOT_MAX;
-    BatchScratch* bs = reinterpret_cast<BatchScratch*>(e->d_status);
-    const HotSet* hot = e->d_hot + e->hot_cur;
-    HotSet* hot_next = e->d_hot + (e->hot_cur ^ 1u);
-    e->hot_cur ^= 1u;
-    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(BatchScratch), e->stream));
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
-    k_bkt_hist<<<ntiles, PT_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits,
-                                                   (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot);
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
-    k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
-    k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
-                                                          hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
-                                                          e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
-                                                          hot_next, bs);
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream));
-    u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
-    if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
-    if (n_wg > nb && nb >= 64) n_wg = nb;
-    k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
-                                                  e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
-                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, bs, hot_next,
-                                                  e->dbg_vmask, e->d_bk_trace);
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream));
-    HIP_TRY(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    e->live += e->h_status->n_inserted;
-    if (e->h_status->err) return status_to_error(e, e->h_status->err);
+// Debug (RL_APPLY_TRACE=1 RL_APPLY_TRACE_DUMP=1): phase timestamps the kernels left behind.
+int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
+    (void)h_st;
     if (e->d_bk_trace && getenv("RL_APPLY_TRACE_DUMP")) {
         std::vector<u64> tr((size_t)(n_wg < BK_MAX ? n_wg : BK_MAX) * 16);
         HIP_TRY(e, hipMemcpy(tr.data(), e->d_bk_trace, tr.size() * sizeof(u64), hipMemcpyDeviceToHost));
@@ -338,6 +301,22 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
                 (double)(t_max - t_min) * 0.01, (double)longest * 0.01, (unsigned long long)longest_n);
         const char* names[10] = {"", "init", "load", "A", "B", "syncB", "C", "D", "rest", "commit"};
         for (int q = 1; q <= 9; ++q) fprintf(stderr, " %s=%.2f", names[q], used ? acc[q] / used * 0.01 : 0.0);
+        {
+            std::vector<u64> ht((size_t)ntiles * 8);
+            HIP_TRY(e, hipMemcpy(ht.data(), e->d_bk_trace + (size_t)(BK_MAX + 64) * 16, ht.size() * sizeof(u64),
+                                 hipMemcpyDeviceToHost));
+            double a[7] = {0};
+            u64 h0 = ~0ull, h1 = 0;
+            for (u32 b = 0; b < ntiles; ++b) {
+                const u64* r = &ht[(size_t)b * 8];
+                for (int q = 1; q <= 6; ++q) a[q] += (double)(r[q] - r[q - 1]);
+                if (r[0] < h0) h0 = r[0];
+                if (r[6] > h1) h1 = r[6];
+            }
+            fprintf(stderr, " | hist: span=%.2f loads_issue=%.2f hot_table=%.2f loop=%.2f hotloop=%.2f sync=%.2f rowwrite=%.2f",
+                    (double)(h1 - h0) * 0.01, a[1] / ntiles * 0.01, a[2] / ntiles * 0.01, a[3] / ntiles * 0.01,
+                    a[4] / ntiles * 0.01, a[5] / ntiles * 0.01, a[6] / ntiles * 0.01);
+        }
         double h_acc[3] = {0, 0, 0};
         u64 h_last = 0;
         for (u32 b = 0; b < tr.size() / 16; ++b) {
@@ -376,21 +355,106 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
         const double nbk = (double)(tr.size() / 16);
         fprintf(stderr, " | hot: setup=%.2f fast=%.2f slow=%.2f end=%.2fus fast_hits=%u slow_hits=%u\n",
                 h_acc[0] / nbk * 0.01, h_acc[1] / nbk * 0.01, h_acc[2] / nbk * 0.01, (double)(h_last - t_min) * 0.01,
-                e->h_status->pad[0], e->h_status->pad[1]);
+                h_st->pad[0], h_st->pad[1]);
         HIP_TRY(e, hipMemset(e->d_bk_trace, 0, tr.size() * sizeof(u64)));
     }
-    if (t) {
+    return RL_OK;
+}
+
+// Enqueue one batch of the bucketed path on the engine's stream (no host synchronisation).
+int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
+    if (e->sub_seq - e->col_seq >= 2) return fail(e, RL_ERR_BUSY, "two batches are already in flight: collect one first");
+    int rc = check_room(e, n + e->inflight_hits);
+    if (rc) return rc;
+    // k_bkt_apply commits as it goes, so a table that fills up mid-batch (RL_ERR_TABLE_FULL from the
+    // probe loop) leaves the batch partially applied; keep a margin so that only a batch bringing
+    // more than capacity/4 NEW keys into an almost full table can get there.
+    {
+        const u64 inc0 = (u64)n + e->inflight_hits;
+        const u64 used = e->live + e->tombs, inc = inc0 < e->cap / 4 ? inc0 : e->cap / 4;
+        if (used + inc > e->cap - e->cap / 16)
+            return fail(e, RL_ERR_TABLE_FULL,
+                        "batch of %u hits could push the table past 15/16 occupancy (live=%llu tombstones=%llu "
+                        "capacity=%llu): sweep, compact or create a larger engine",
+                        n, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
+    }
+    rl_engine::Inflight& f = e->inflight[e->sub_seq & 1u];
+    const bool t = e->timing;
+    u32 bk_log2 = ceil_log2(cdiv(n, 384));
+    if (bk_log2 > e->bk_log2_cfg) bk_log2 = e->bk_log2_cfg;
+    const u32 nb = 1u << bk_log2;
+    const u32 ntiles = cdiv(n, PT_TILE);
+    const u32 nbt = nb + HOT_MAX;
+    BatchScratch* bs = e->d_bs + e->bs_cur;
+    BatchScratch* bs_next = e->d_bs + (e->bs_cur ^ 1u);
+    e->bs_cur ^= 1u;
+    const HotSet* hot = e->d_hot + e->hot_cur;
+    HotSet* hot_next = e->d_hot + (e->hot_cur ^ 1u);
+    e->hot_cur ^= 1u;
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[0], e->stream));
+    k_bkt_hist<<<ntiles, PT_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits,
+                                                   (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot,
+                                                   e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 : nullptr);
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[1], e->stream));
+    k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[2], e->stream));
+    k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
+                                                          hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
+                                                          e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
+                                                          hot_next, bs);
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
+    u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
+    if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
+    if (n_wg > nb && nb >= 64) n_wg = nb;
+    // the last workgroup of k_bkt_apply writes the status block straight into f.h_st (host-mapped)
+    k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
+                                                  e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
+                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, bs, bs_next,
+                                                  f.h_st, hot_next, e->dbg_vmask, e->d_bk_trace);
+    HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+    HIP_TRY(e, hipGetLastError());
+    f.n = n;
+    f.n_wg = n_wg;
+    f.ntiles = ntiles;
+    f.timed = t;
+    e->inflight_hits += n;
+    e->sub_seq++;
+    return RL_OK;
+}
+
+// Wait for the oldest batch in flight and account for it.
+int collect_k1_bucketed(rl_engine* e) {
+    if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
+    rl_engine::Inflight& f = e->inflight[e->col_seq & 1u];
+    HIP_TRY(e, hipEventSynchronize(f.tev[4]));
+    e->col_seq++;
+    e->inflight_hits -= f.n;
+    e->live += f.h_st->n_inserted;
+    e->stats.batches++;
+    e->stats.hits += f.n;
+    if (f.h_st->err) return status_to_error(e, f.h_st->err);
+    if (e->d_bk_trace && getenv("RL_APPLY_TRACE_DUMP")) {
+        const int rc = dump_apply_trace(e, f.n_wg, f.ntiles, f.h_st);
+        if (rc) return rc;
+    }
+    if (f.timed) {
         float ms[4] = {0, 0, 0, 0};
-        for (int q = 0; q < 4; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], e->ev[q], e->ev[q + 1]));
+        for (int q = 0; q < 4; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], f.tev[q], f.tev[q + 1]));
         e->ms_slot[RL_T_HIST] += ms[0];
         e->ms_slot[RL_T_SCAN] += ms[1];
         e->ms_slot[RL_T_SCATTER] += ms[2];
         e->ms_slot[RL_T_APPLY] += ms[3];
         e->timed_launches++;
     }
-    e->stats.batches++;
-    e->stats.hits += n;
     return RL_OK;
+}
+
+// check_and_update for single-counter requests, all pointers on the device: the bucketed
+// single-pass path (rl_bucket.hpp).  Four launches, one host synchronisation at the end.
+int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
+    int rc = submit_k1_bucketed(e, d_hits, n, now, d_verdict, d_first);
+    if (rc) return rc;
+    return collect_k1_bucketed(e);
 }
 
 int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
@@ -607,7 +671,9 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_scan, mb * sizeof(Contrib));
     ALLOC(e->d_pass, mb);
     ALLOC(e->d_admitted, mb);
-    ALLOC(e->d_status, sizeof(BatchScratch));
+    ALLOC(e->d_status, sizeof(Status));
+    ALLOC(e->d_bs, 2 * sizeof(BatchScratch));
+    if (hipMemset(e->d_bs, 0, 2 * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_total, sizeof(unsigned long long));
     e->bk_tiles_max = cdiv(mb, PT_TILE) + 1;
     ALLOC(e->d_bk_hist, (size_t)ROW_MAX * e->bk_tiles_max * sizeof(u32));
@@ -618,8 +684,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_hot_param, (size_t)(HOT_MAX + 1) * sizeof(HotParam));
     if (const char* v = getenv("RL_APPLY_TRACE"))
         if (v[0] == '1') {
-            ALLOC(e->d_bk_trace, (size_t)(BK_MAX + 64) * 16 * sizeof(u64));
-            if (hipMemset(e->d_bk_trace, 0, (size_t)(BK_MAX + 64) * 16 * sizeof(u64)) != hipSuccess)
+            ALLOC(e->d_bk_trace, ((size_t)(BK_MAX + 64) * 16 + 4096 * 8) * sizeof(u64));
+            if (hipMemset(e->d_bk_trace, 0, ((size_t)(BK_MAX + 64) * 16 + 4096 * 8) * sizeof(u64)) != hipSuccess)
                 return bail(RL_ERR_DEVICE);
         }
     ALLOC(e->d_bk_hits, mb * sizeof(BHit));
@@ -636,10 +702,16 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->scan_tmp_bytes = stmp ? stmp : 16;
     ALLOC(e->d_scan_tmp, e->scan_tmp_bytes);
 #undef ALLOC
-    if (hipHostMalloc((void**)&e->h_status, sizeof(Status)) != hipSuccess) return bail(RL_ERR_NOMEM);
+    if (hipHostMalloc((void**)&e->h_status, sizeof(Status), hipHostMallocMapped) != hipSuccess) return bail(RL_ERR_NOMEM);
     if (hipHostMalloc((void**)&e->h_total, sizeof(unsigned long long)) != hipSuccess) return bail(RL_ERR_NOMEM);
     for (auto& ev : e->ev)
         if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
+    for (auto& f : e->inflight) {
+        for (auto& ev : f.tev)
+            if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
+        if (hipHostMalloc((void**)&f.h_st, sizeof(Status), hipHostMallocMapped) != hipSuccess) return bail(RL_ERR_NOMEM);
+        memset(f.h_st, 0, sizeof(Status));
+    }
     if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(RL_ERR_DEVICE);
     e->stats.capacity_cells = e->cap;
     *out = e;
@@ -655,20 +727,25 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_trace,
-                    e->d_hot,     e->d_hot_param};
+                    e->d_hot,     e->d_hot_param, e->d_bs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_total) (void)hipHostFree(e->h_total);
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& f : e->inflight) {
+        for (auto& ev : f.tev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (f.h_st) (void)hipHostFree(f.h_st);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
 const char* rl_last_error(const rl_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
-int32_t rl_status_is_transient(int32_t status) { return status == RL_ERR_DEVICE ? 1 : 0; }
+int32_t rl_status_is_transient(int32_t status) { return (status == RL_ERR_DEVICE || status == RL_ERR_BUSY) ? 1 : 0; }
 
 int32_t rl_stats(rl_engine* e, rl_stats_t* out) {
     if (!e || !out) return RL_ERR_INVALID;
@@ -685,6 +762,7 @@ void* rl_engine_stream(rl_engine* e) { return e ? (void*)e->stream : nullptr; }
 int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (n && !rows) return fail(e, RL_ERR_INVALID, "rows is null");
     if ((u64)first + n > e->max_limits) return fail(e, RL_ERR_INVALID, "limit rows [%u,%u) exceed max_limits %u", first, first + n, e->max_limits);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -706,6 +784,7 @@ int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, ui
 int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (!(limit & RL_SIMPLE)) return RL_OK;  // in_memory.rs:39: only limits without variables
     if (RL_LIMIT_ID(limit) >= e->h_limits.size()) return fail(e, RL_ERR_INVALID, "unknown limit id %u", RL_LIMIT_ID(limit));
     HIP_TRY(e, hipSetDevice(e->device));
@@ -723,6 +802,7 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
     int rc = validate_batch(e, d_hits, n_hits, d_req_off, n_req, d_verdict);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     if (load_counters && (!d_remaining || !d_expires_in_us))
@@ -740,6 +820,7 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     int rc = validate_batch(e, hits, n_hits, req_off, n_req, verdict);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (n_req == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     if (load_counters && (!remaining || !expires_in_us))
@@ -775,11 +856,31 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     return RL_OK;
 }
 
+int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
+                                          uint8_t* d_verdict, int32_t* d_first_limited) {
+    int rc = validate_batch(e, d_hits, n_hits, nullptr, n_hits, d_verdict);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n_hits == 0) return fail(e, RL_ERR_INVALID, "empty batch");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (e->legacy_k1 || e->h_limits.size() > (size_t)LIM_LDS)
+        return fail(e, RL_ERR_INVALID, "submit/collect needs the bucketed path (<= %d limit rows, RL_K1_PATH unset)", LIM_LDS);
+    return submit_k1_bucketed(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
+}
+
+int32_t rl_check_and_update_collect(rl_engine* e) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    return collect_k1_bucketed(e);
+}
+
 int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us,
                                   uint8_t* within) {
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, within);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
@@ -800,6 +901,7 @@ int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hit
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, &dummy);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     rc = check_room(e, n_hits);
@@ -838,30 +940,35 @@ int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_r
                         uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     return scan_locked<SCAN_GET>(e, limit, now_us, out, cap, n_out);
 }
 
 int32_t rl_dump_cells(rl_engine* e, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     return scan_locked<SCAN_DUMP>(e, 0, 0, out, cap, n_out);
 }
 
 int32_t rl_delete_counters(rl_engine* e, uint32_t limit) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     return scan_locked<SCAN_DELETE_LIMIT>(e, limit, 0, nullptr, 0, nullptr);
 }
 
 int32_t rl_clear(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     return scan_locked<SCAN_CLEAR_SIMPLE>(e, 0, 0, nullptr, 0, nullptr);
 }
 
 int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     const u64 before = e->live;
     int rc = scan_locked<SCAN_SWEEP>(e, 0, now_us, nullptr, 0, nullptr);
     if (rc) return rc;
@@ -873,6 +980,7 @@ int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
 int32_t rl_compact(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     HIP_TRY(e, hipSetDevice(e->device));
     return do_compact(e);
 }
@@ -880,6 +988,7 @@ int32_t rl_compact(rl_engine* e) {
 int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n) {
     if (!e || (n && !d_rows)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     HIP_TRY(e, hipSetDevice(e->device));
     if (n == 0) return RL_OK;
     return insert_rows_locked(e, reinterpret_cast<const CellRow*>(d_rows), n, 1);
@@ -888,6 +997,7 @@ int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n
 int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
     if (!e || (n && !rows)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     HIP_TRY(e, hipSetDevice(e->device));
     if (n == 0) return RL_OK;
     CellRow* d_rows = nullptr;

@@ -14,6 +14,7 @@ RL_OK = 0
 ERR_NAMES = {
     -1: "RL_ERR_INVALID", -2: "RL_ERR_DEVICE", -3: "RL_ERR_NO_DEVICE", -4: "RL_ERR_TABLE_FULL",
     -5: "RL_ERR_MISSING_SIMPLE", -6: "RL_ERR_KEY_LIMIT", -7: "RL_ERR_BATCH_TOO_LARGE", -8: "RL_ERR_NOMEM",
+    -9: "RL_ERR_BUSY",
 }
 
 
@@ -120,6 +121,15 @@ class Engine:
         self._check(self._lib.rl_check_and_update_batch_device(
             self._h, d_hits, n_hits, d_req_off, n_hits if n_req is None else n_req, int(now_us),
             int(bool(load_counters)), d_verdict, d_first_limited, d_remaining, d_expires))
+
+    def submit_device(self, d_hits, n_hits, now_us, d_verdict, d_first_limited=None):
+        """Enqueue a single-counter batch (raw device pointers) without waiting; at most two in flight."""
+        self._check(self._lib.rl_check_and_update_submit_device(self._h, d_hits, n_hits, int(now_us), d_verdict,
+                                                                d_first_limited))
+
+    def collect(self):
+        """Wait for the oldest submitted batch; raises its error, if any."""
+        self._check(self._lib.rl_check_and_update_collect(self._h))
 
     def is_within_limits(self, hits, now_us):
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)

@@ -190,3 +190,44 @@ def test_batch_sizes_around_the_tile_and_round_boundaries(make_engine, n):
     run_both(eng, orc, hits, NOW)
     run_both(eng, orc, hits, NOW + 5)
     assert_same_state(eng, orc)
+
+
+def test_submit_collect_keeps_the_sequential_contract(make_engine):
+    """Two batches in flight (rl_check_and_update_submit_device / _collect) on overlapping keys: the
+    result is the reference applied to batch 0, then batch 1, ...; other entry points answer BUSY."""
+    import torch
+
+    from limitador_amd.engine import EngineError
+
+    rng = np.random.default_rng(21)
+    n = 60_000
+    eng, orc = pair(make_engine, [(40, 60), (900, 60)], max_batch_hits=n, capacity_cells=1 << 17)
+    dev = torch.device("cuda", 0)
+    batches, expect = [], []
+    now = NOW
+    for step in range(6):
+        idx = (rng.zipf(1.2, size=n) - 1) % 20_000
+        h = make_hits(W.splitmix64(idx.astype(np.uint64)), (idx % 2).astype(np.uint32), 1)
+        v, _f, _r, _e = orc.check_and_update(h, now + step)
+        expect.append(v)
+        batches.append(torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev))
+    out = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(6)]
+    torch.cuda.synchronize()
+    eng.submit_device(batches[0].data_ptr(), n, now, out[0].data_ptr())
+    for step in range(1, 6):
+        eng.submit_device(batches[step].data_ptr(), n, now + step, out[step].data_ptr())
+        if step == 3:
+            with pytest.raises(EngineError) as e:  # two in flight: a third submit, or any other call, is refused
+                eng.submit_device(batches[0].data_ptr(), n, now, out[0].data_ptr())
+            assert e.value.code == -9 and e.value.transient
+            with pytest.raises(EngineError) as e:
+                eng.dump_cells()
+            assert e.value.code == -9
+        eng.collect()
+    eng.collect()
+    with pytest.raises(EngineError):
+        eng.collect()  # nothing left
+    torch.cuda.synchronize()
+    for step in range(6):
+        assert np.array_equal(out[step].cpu().numpy(), expect[step]), f"batch {step}"
+    assert_same_state(eng, orc)
