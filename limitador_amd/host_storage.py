@@ -4,6 +4,7 @@ leaves all interning, ordering and result mapping to the C++ side; used by the t
 reference's scenarios through the same code a Rust `GpuStorage` would replace."""
 import ctypes as C
 import os
+import threading
 
 from . import _lib
 from .build import STORAGE_SO
@@ -105,6 +106,7 @@ class HostStorage:
             raise StorageError(rc, "rls_storage_create failed (no MI355X visible?)" if rc == -3 else "create failed")
         self._h = h
         self._batcher = None
+        self._batcher_lock = threading.Lock()
 
     def close(self):
         if self._batcher:
@@ -144,10 +146,11 @@ class HostStorage:
             keep.append(k)
         limited, idx = C.c_int32(), C.c_int32(-1)
         if batched:
-            if self._batcher is None:
-                b = C.c_void_p()
-                self._check(self._so.rls_batcher_create(self._h, 64, 200, C.byref(b)))
-                self._batcher = b
+            with self._batcher_lock:
+                if self._batcher is None:
+                    b = C.c_void_p()
+                    self._check(self._so.rls_batcher_create(self._h, 64, 200, C.byref(b)))
+                    self._batcher = b
             fn, h = self._so.rls_batcher_check_and_update, self._batcher
         else:
             fn, h = self._so.rls_check_and_update, self._h
