@@ -348,7 +348,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                                                           const LimitDev* __restrict__ limits, u64 now,
                                                           u32 ntiles, HotParam* __restrict__ hot_param,
                                                           HotSet* __restrict__ hot_next,
-                                                          const BatchScratch* __restrict__ bs) {
+                                                          const BatchScratch* __restrict__ bs, u64* htrace) {
     __shared__ __align__(16) unsigned short s_cnt[PT_WAVES][BKT_MAX];
     __shared__ u32 s_base[BKT_MAX];
     __shared__ u32 s_w[PT_WAVES];
@@ -425,6 +425,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         }
         return;
     }
+    RL_HSTAMP(0);
     const u32 lane = tid & 63u, w = tid >> 6;
     const u32 nb = 1u << bk_log2;
     const u32 nbt = nb + HOT_MAX;
@@ -464,11 +465,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
             }
         }
     }
+    RL_HSTAMP(1);
     for (u32 b = tid; b < nbt; b += PT_BLOCK) {
 #pragma unroll
         for (int ww = 0; ww < PT_WAVES; ++ww) s_cnt[ww][b] = 0;
     }
     __syncthreads();
+    RL_HSTAMP(2);
     unsigned short rank[PT_STEPS];
     unsigned short dig[PT_STEPS];
     const u64 lt = (1ull << lane) - 1ull;
@@ -494,7 +497,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         rank[u] = (unsigned short)r;
         dig[u] = (unsigned short)d;
     }
+    RL_HSTAMP(3);
     __syncthreads();
+    RL_HSTAMP(4);
     // wave-private counts -> exclusive offsets of the waves inside (tile, bucket)
     for (u32 b = tid; b < nbt; b += PT_BLOCK) {
         u32 acc = 0;
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         }
     }
     __syncthreads();
+    RL_HSTAMP(5);
 #pragma unroll
     for (int u = 0; u < PT_STEPS; ++u) {
         const u32 i = wbase + u * 64 + lane;
@@ -516,6 +522,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                 make_uint4(raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24));
         }
     }
+    RL_HSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------

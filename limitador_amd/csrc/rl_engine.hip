@@ -313,6 +313,22 @@ int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
                 if (r[0] < h0) h0 = r[0];
                 if (r[6] > h1) h1 = r[6];
             }
+            {
+                std::vector<u64> st2((size_t)ntiles * 8);
+                HIP_TRY(e, hipMemcpy(st2.data(), e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8,
+                                     st2.size() * sizeof(u64), hipMemcpyDeviceToHost));
+                double c[7] = {0};
+                u64 s0 = ~0ull, s1 = 0;
+                for (u32 b = 0; b < ntiles; ++b) {
+                    const u64* r = &st2[(size_t)b * 8];
+                    for (int q = 1; q <= 6; ++q) c[q] += (double)(r[q] - r[q - 1]);
+                    if (r[0] < s0) s0 = r[0];
+                    if (r[6] > s1) s1 = r[6];
+                }
+                fprintf(stderr, " | scatter: span=%.2f prologue=%.2f zero=%.2f steps=%.2f sync=%.2f prefix=%.2f write=%.2f",
+                        (double)(s1 - s0) * 0.01, c[1] / ntiles * 0.01, c[2] / ntiles * 0.01, c[3] / ntiles * 0.01,
+                        c[4] / ntiles * 0.01, c[5] / ntiles * 0.01, c[6] / ntiles * 0.01);
+            }
             fprintf(stderr, " | hist: span=%.2f loads_issue=%.2f hot_table=%.2f loop=%.2f hotloop=%.2f sync=%.2f rowwrite=%.2f",
                     (double)(h1 - h0) * 0.01, a[1] / ntiles * 0.01, a[2] / ntiles * 0.01, a[3] / ntiles * 0.01,
                     a[4] / ntiles * 0.01, a[5] / ntiles * 0.01, a[6] / ntiles * 0.01);
@@ -401,7 +417,8 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
                                                           hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
                                                           e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
-                                                          hot_next, bs);
+                                                          hot_next, bs,
+                                                          e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 : nullptr);
     if (t) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
     u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
     if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
