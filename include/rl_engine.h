@@ -199,7 +199,8 @@ int32_t rl_dump_cells(rl_engine *e, rl_cell_row *out, uint64_t cap, uint64_t *n_
 uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world);
 /* Stable partition of d_hits by owner shard: d_out holds the hits grouped by owner
  * (owner 0 first), each group in original order; d_perm[j] = original index of d_out[j];
- * d_counts[world] = group sizes.  Blocks until done. */
+ * d_counts[world] = group sizes.  Blocks until done (unless rl_engine_set_stream gave the engine the
+ * caller's stream). */
 int32_t rl_route_partition_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits,
                                   uint32_t world, rl_hit *d_out, uint32_t *d_perm,
                                   uint32_t *d_counts);
@@ -210,6 +211,12 @@ int32_t rl_unpermute_u8_device(rl_engine *e, const uint8_t *d_src, const uint32_
 /* The HIP stream (hipStream_t) the engine launches on, for callers that order their own work
  * against it, and a per-kernel timing hook used by bench.py (HIP events on that stream). */
 void *rl_engine_stream(rl_engine *e);
+/* Launch on the caller's stream instead (external = 1; `stream` may be NULL, the default stream), or go
+ * back to the engine's own (external = 0).  For callers that chain
+ * their own device work (collectives, copies) around the engine's: with an external stream the
+ * routing helpers below enqueue and return without blocking (the caller's stream order is the
+ * synchronisation), and submit / collect give the same for the hot path. */
+int32_t rl_engine_set_stream(rl_engine *e, void *stream, int32_t external);
 /* Enable (1) / disable (0) HIP-event timing of the kernels of the single-counter hot path (events
  * on the engine's stream, inside rl_check_and_update_batch[_device]).  rl_kernel_timing_read copies
  * the milliseconds accumulated per slot since the last reset into ms[RL_TIMING_SLOTS] and the number

@@ -36,7 +36,8 @@ struct rl_engine {
     std::mutex mu;
     std::string err;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every kernel is launched on
+    hipStream_t own_stream = nullptr;  // created by the engine; `stream` may be replaced (rl_engine_set_stream)
     u64 seed = 0;
 
     Cell* table = nullptr;
@@ -98,6 +99,7 @@ struct rl_engine {
     HotSet* d_hot = nullptr;        // [2]: the set used by this batch, the set it picks for the next
     u32 hot_cur = 0;
     HotParam* d_hot_param = nullptr;
+    bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
@@ -657,7 +659,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         return rc;
     };
     if (hipSetDevice(e->device) != hipSuccess) return bail(RL_ERR_NO_DEVICE);
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
+    if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
+    e->stream = e->own_stream;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0)
@@ -756,7 +759,7 @@ void rl_engine_destroy(rl_engine* e) {
             if (ev) (void)hipEventDestroy(ev);
         if (f.h_st) (void)hipHostFree(f.h_st);
     }
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
 
@@ -775,6 +778,17 @@ int32_t rl_stats(rl_engine* e, rl_stats_t* out) {
 }
 
 void* rl_engine_stream(rl_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->stream = external ? (hipStream_t)stream : e->own_stream;  // NULL is a stream too: the default one
+    e->external_stream = external != 0;
+    return RL_OK;
+}
 
 int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) {
     if (!e) return RL_ERR_INVALID;
@@ -1045,7 +1059,7 @@ int32_t rl_route_partition_device(rl_engine* e, const rl_hit* d_hits, uint32_t n
                                                               world, e->d_route_cnt,
                                                               reinterpret_cast<Hit*>(d_out), d_perm);
     HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (!e->external_stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
 }
 
@@ -1056,7 +1070,7 @@ int32_t rl_unpermute_u8_device(rl_engine* e, const uint8_t* d_src, const uint32_
     HIP_TRY(e, hipSetDevice(e->device));
     if (n) k_unpermute_u8<<<cdiv(n, 256), 256, 0, e->stream>>>(d_src, d_perm, n, d_dst);
     HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (!e->external_stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
 }
 

@@ -80,6 +80,14 @@ class Engine:
         """The engine's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
         return self._lib.rl_engine_stream(self._h) or 0
 
+    def set_stream(self, stream):
+        """Launch on the caller's hipStream_t (an int, e.g. torch.cuda.current_stream().cuda_stream — 0 is
+        the default stream); None returns to the engine's own stream."""
+        if stream is None:
+            self._check(self._lib.rl_engine_set_stream(self._h, None, 0))
+        else:
+            self._check(self._lib.rl_engine_set_stream(self._h, C.c_void_p(int(stream)), 1))
+
     def stats(self):
         s = _lib.RlStats()
         self._check(self._lib.rl_stats(self._h, C.byref(s)))

@@ -47,7 +47,9 @@ def owner_mask(keys, hash_seed, world, rank):
 
 
 class HipLocal:
-    """The three device-side operations of a shard, on the HIP engine (raw pointers)."""
+    """The three device-side operations of a shard, on the HIP engine (raw pointers).  The engine is
+    put on torch's current stream, so its kernels, the RCCL collectives and torch's own ops are ordered
+    by the stream and none of the three operations blocks the host."""
 
     def __init__(self, engine, device, max_local_hits, world):
         self.engine = engine
@@ -55,22 +57,28 @@ class HipLocal:
         self.sorted_hits = torch.empty((max_local_hits, 2), dtype=torch.int64, device=device)
         self.perm = torch.empty(max_local_hits, dtype=torch.int32, device=device)
         self.counts = torch.empty(world, dtype=torch.int32, device=device)
+        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self._pending = False
 
     def partition(self, hits, world):
         n = hits.shape[0]
-        torch.cuda.current_stream().synchronize()
         self.engine.route_partition_device(hits.data_ptr(), n, world, self.sorted_hits.data_ptr(),
                                            self.perm.data_ptr(), self.counts.data_ptr())
         return self.sorted_hits[:n], self.perm[:n], self.counts
 
     def check(self, hits, n, now_us, verdict):
-        torch.cuda.current_stream().synchronize()
         if n:
-            self.engine.check_and_update_device(hits.data_ptr(), n, now_us, verdict.data_ptr())
+            self.engine.submit_device(hits.data_ptr(), n, now_us, verdict.data_ptr())
+            self._pending = True
 
     def unpermute(self, src, perm, n, dst):
-        torch.cuda.current_stream().synchronize()
         self.engine.unpermute_u8_device(src.data_ptr(), perm.data_ptr(), n, dst.data_ptr())
+
+    def finish(self):
+        """Status of the batch submitted by check() (raises the engine's error, if any)."""
+        if self._pending:
+            self._pending = False
+            self.engine.collect()
 
 
 class ShardedEngine:
@@ -105,5 +113,8 @@ class ShardedEngine:
         self.local.check(rh, n_recv, now_us, rv)
         sv = self._sorted_verdict[:n]
         dist.all_to_all_single(sv, rv, output_split_sizes=send, input_split_sizes=recv, group=self.group)
+        # the batch's status is read while the verdicts travel back; routing helpers do not block
+        if hasattr(self.local, "finish"):
+            self.local.finish()
         self.local.unpermute(sv, perm, n, verdict_out)
         return n_recv
