@@ -432,3 +432,50 @@ def test_huge_deltas_take_the_exact_path(make_engine):
     orc.update_counters(hits, NOW + 1)
     run_both(eng, orc, hits, NOW + 2)
     assert_same_state(eng, orc)
+
+
+def test_config5_shape_multi_namespace_trace_replay(make_engine):
+    """BASELINE.json configs[4] at test size: 4 namespaces x 8 limits (2 simple
+    + 6 qualified on 1-2 variables), windows {1, 10, 60, 3600} s, conditions as per-request
+    applicability, k in [1, 8] counters per request, >= 16 batches with an advancing clock (crossing the
+    1 s and 10 s windows) and an rl_sweep_expired between batches, replayed into the oracle."""
+    rng = np.random.default_rng(55)
+    windows = [1, 10, 60, 3600]
+    rows, simple, limit_of = [], [], {}
+    for ns in range(4):
+        for j in range(8):
+            lid = len(rows)
+            is_simple = j < 2
+            rows.append((int(rng.integers(20, 4000)) if j == 0 else int(rng.integers(2, 60)), windows[(ns + j) % 4]))
+            limit_of[(ns, j)] = lid
+            if is_simple:
+                simple.append((lid, 20_000_000 + lid))
+    eng, orc = pair(make_engine, rows, simple, capacity_cells=1 << 17, max_batch_hits=1 << 16)
+    now = NOW
+    for step in range(18):
+        n_req = int(rng.integers(500, 4000))
+        hits, off = [], [0]
+        for _ in range(n_req):
+            ns = int(rng.integers(0, 4))
+            user = int(rng.zipf(1.4) - 1) % 500
+            path = int(rng.integers(0, 6))
+            delta = 1 if rng.random() < 0.8 else int(rng.integers(0, 5))
+            applies = [j for j in range(8) if rng.random() < (0.9 if j < 2 else 0.45)][:8] or [0]
+            req = []
+            for j in sorted(applies, key=lambda x: (x >= 2,)):  # simple first (in_memory.rs:105,121)
+                lid = limit_of[(ns, j)]
+                if j < 2:
+                    req.append((20_000_000 + lid, lid | RL_SIMPLE, delta))
+                else:  # qualified on user (odd j: user and path)
+                    material = lid * 1_000_003 + user * 7 + (path if j % 2 else 0)
+                    req.append((int(W.splitmix64(np.array([material], dtype=np.uint64))[0]), lid, delta))
+            hits.extend(req)
+            off.append(len(hits))
+        arr = np.zeros(len(hits), dtype=HIT_DTYPE)
+        for i, h in enumerate(hits):
+            arr[i] = h
+        run_both(eng, orc, arr, now, req_off=np.array(off, dtype=np.uint32), load_counters=bool(step % 3 == 2))
+        now += int(rng.integers(SEC // 4, 3 * SEC))
+        if step % 2:
+            assert eng.sweep_expired(now) == orc.sweep_expired(now)
+    assert_same_state(eng, orc, n_simple_expected=8)
