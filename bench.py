@@ -51,8 +51,20 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, budget_s):
-    """The CPU oracle on the same workload shape (same universe, same Zipf batches), one thread."""
+def _cpu_batches(args):
+    import numpy as np
+
+    from limitador_amd import workloads as W
+
+    rng = np.random.default_rng(W.SEED)
+    cdf = W.zipf_cdf(args.keys, args.zipf) if args.zipf > 0 else None
+    n = min(args.batch, 1_000_000)
+    return n, [W.zipf_batch(args.keys, n, rng, cdf) if cdf is not None else W.uniform_batch(args.keys, n, rng)
+               for _ in range(3)]
+
+
+def _cpu_shard(args, n_shards, shard):
+    """One oracle table holding shard `shard` of the universe (keys are assigned by a hash of the key)."""
     import numpy as np
 
     import oracle
@@ -63,15 +75,32 @@ def cpu_baseline(args, budget_s):
     chunk = 1 << 21
     for lo in range(0, args.keys, chunk):
         c = W.universe_rows(args.keys, lo=lo, hi=min(args.keys, lo + chunk))
+        if n_shards > 1:
+            c = c[(W.splitmix64(c["key"]) % np.uint64(n_shards)) == shard]
         orc.load_cells(c["key"], c["limit"], c["value"], c["expiry_us"])
-    rng = np.random.default_rng(W.SEED)
-    cdf = W.zipf_cdf(args.keys, args.zipf) if args.zipf > 0 else None
-    n = min(args.batch, 1_000_000)
-    batches = []
-    for _ in range(3):
-        batches.append(W.zipf_batch(args.keys, n, rng, cdf) if cdf is not None else W.uniform_batch(args.keys, n, rng))
+    return orc
+
+
+def cpu_baseline(args, budget_s):
+    """The CPU oracle (C restatement of the reference path) on the same workload shape.
+
+    `value`: every host core, keys hash-sharded over one single-threaded table per thread (valid for
+    single-counter requests: cells are independent) — each thread replays, in trace order,
+    the hits of its shard; the partition of the batch by shard is NOT timed.  This is an upper bound for a
+    CPU implementation of these semantics: the reference itself is one shared concurrent map and pays CEL
+    evaluation, allocation and cache bookkeeping per request on top.  `single_thread`: the same oracle,
+    one thread, whole batch (the parity reference)."""
+    import threading
+
+    import numpy as np
+
+    from limitador_amd import workloads as W
+
+    n, batches = _cpu_batches(args)
+    # ---- one thread -----------------------------------------------------------------------------
+    orc = _cpu_shard(args, 1, 0)
     done, spent, now, i = 0, 0.0, W.NOW0_US, 0
-    while spent < budget_s and i < 64:
+    while spent < budget_s / 2 and i < 64:
         h = batches[i % len(batches)]
         t0 = time.perf_counter()
         orc.check_and_update(h, now, want_first_limited=False)
@@ -80,8 +109,58 @@ def cpu_baseline(args, budget_s):
         now += 1000
         i += 1
     orc.close()
-    return {"value": done / spent, "unit": "decisions/s", "cores": 1, "kind": "port",
-            "sample": f"{i} batches x {n} hits, {args.keys} keys, zipf {args.zipf}, single thread, "
+    single = done / spent
+    # ---- all cores -------------------------------------------------------------------------------
+    cores = min(os.cpu_count() or 1, 64)
+    if cores < 2:
+        return {"value": single, "unit": "decisions/s", "cores": 1, "kind": "port",
+                "sample": f"{i} batches x {n} hits, single thread, oracle/limitador_oracle.c"}
+    shards = [None] * cores
+
+    def build(t):
+        shards[t] = _cpu_shard(args, cores, t)
+
+    ths = [threading.Thread(target=build, args=(t,)) for t in range(cores)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    parts = []
+    for h in batches:
+        owner = W.splitmix64(h["key"]) % np.uint64(cores)
+        parts.append([np.ascontiguousarray(h[owner == t]) for t in range(cores)])
+    # persistent worker threads, one per shard, released batch by batch (ctypes drops the GIL inside the
+    # oracle call); the timed span of a batch is barrier to barrier
+    start, stop = threading.Barrier(cores + 1), threading.Barrier(cores + 1)
+    state = {"part": None, "now": W.NOW0_US, "run": True}
+
+    def worker(t):
+        while True:
+            start.wait()
+            if not state["run"]:
+                return
+            shards[t].check_and_update(state["part"][t], state["now"], want_first_limited=False)
+            stop.wait()
+
+    ths = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(cores)]
+    [t.start() for t in ths]
+    done_mt, spent_mt, j = 0, 0.0, 0
+    while spent_mt < budget_s / 2 and j < 256:
+        state["part"] = parts[j % len(parts)]
+        t0 = time.perf_counter()
+        start.wait()
+        stop.wait()
+        spent_mt += time.perf_counter() - t0
+        done_mt += n
+        state["now"] += 1000
+        j += 1
+    state["run"] = False
+    start.wait()
+    [t.join() for t in ths]
+    for o in shards:
+        o.close()
+    return {"value": done_mt / spent_mt, "unit": "decisions/s", "cores": cores, "kind": "port",
+            "single_thread": single,
+            "sample": f"{j} batches x {n} hits over {cores} threads (keys hash-sharded, one table per thread, "
+                      f"partition not timed) + {i} batches on one thread; {args.keys} keys, zipf {args.zipf}; "
                       f"oracle/limitador_oracle.c (hash-map table, no CEL/moka/tracing)"}
 
 
