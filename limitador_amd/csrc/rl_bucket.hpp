@@ -36,7 +36,7 @@ namespace rl {
 
 constexpr int BK_LOG2_MAX = 11;
 constexpr int BK_MAX = 1 << BK_LOG2_MAX;
-constexpr int HOT_MAX = 128;                  // keys that get a bucket of their own
+constexpr int HOT_MAX = 512;                  // keys that get a bucket of their own
 constexpr int BKT_MAX = BK_MAX + HOT_MAX;     // hash buckets + hot-key buckets
 constexpr int HOT_COLS = 3 * HOT_MAX;         // per tile and hot key: largest delta, largest ~delta, a limit id
 constexpr int ROW_MAX = BKT_MAX + HOT_COLS;   // columns of one tile's row of the histogram matrix
@@ -47,17 +47,20 @@ constexpr int PT_WAVE_TILE = 64 * PT_STEPS;   // contiguous hits owned by one wa
 constexpr int PT_TILE = PT_WAVES * PT_WAVE_TILE;  // hits per workgroup (4096)
 constexpr u32 BK_BIG = 1024;                  // hash buckets at least this large are processed first
 constexpr int HOT_CHUNK = 1024;              // hits per work item of a hot bucket
-constexpr u32 HOT_PROMOTE = 512;              // hits in one batch that make a key hot for the next batch
-constexpr u32 HOT_KEEP = 256;                 // hits in one batch that keep a hot key hot
-constexpr int HOT_HASH = 256;                 // LDS lookup table of the current hot set
+constexpr u32 HOT_PROMOTE = 160;              // hits in one batch that make (or keep) a key hot: the floor of the
+                                              // threshold, which the host doubles while more keys qualify than fit
+constexpr u32 HOT_LONG_BUCKET = 1024;         // a bucket this long is long BECAUSE of a key: promote it earlier
+constexpr int HOT_HASH = 1024;                // LDS lookup table of the current hot set
 
 // Keys that took a large share of the PREVIOUS batch ("hot": a Zipf head, a simple limit every
 // request of a namespace hits).  Each gets a bucket to itself, so the stable partition leaves the
 // key's hits contiguous and in trace order: position in the bucket == the hit's rank on the key.
 // Any stale or arbitrary set is valid — the set only has to be the same in every kernel of one
 // batch; it decides which code path a key takes, never a verdict.  k_bkt_apply builds the next
-// batch's set from exact counts: hot keys that still got HOT_KEEP hits, plus every key of a hash
-// bucket that absorbed HOT_PROMOTE hits (a traffic shift costs one batch of long buckets).
+// batch's set from exact counts: hot keys that still got `hot_threshold` hits, plus every key of a hash
+// bucket that absorbed as many (a traffic shift costs one batch of long buckets).  The host keeps
+// the threshold at HOT_PROMOTE and doubles it while more keys qualify than there are hot buckets, so
+// that under pressure the hottest keys are the ones that stay.
 struct HotSet {
     u32 n;
     u32 pad;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
         const bool is_hot = hidx[r] >= 0;
         const u64 valid = __ballot(is_hot);
         if (!valid) continue;
-        const u64 m = match_digit(is_hot ? (u32)hidx[r] : 0u, 7u, valid);
+        const u64 m = match_digit(is_hot ? (u32)hidx[r] : 0u, 9u, valid);
         if (!is_hot) continue;
         const u32 d = h[r].delta;
         const bool leader = (m & lt) == 0ull;
@@ -348,7 +351,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                                                           const LimitDev* __restrict__ limits, u64 now,
                                                           u32 ntiles, HotParam* __restrict__ hot_param,
                                                           HotSet* __restrict__ hot_next,
-                                                          const BatchScratch* __restrict__ bs, u64* htrace) {
+                                                          const BatchScratch* __restrict__ bs, u32 hot_threshold,
+                                                          u64* htrace) {
     __shared__ __align__(16) unsigned short s_cnt[PT_WAVES][BKT_MAX];
     __shared__ u32 s_base[BKT_MAX];
     __shared__ u32 s_w[PT_WAVES];
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                     hp.fast = 1;
                     hp.room = hp.s > L.max_value ? 0ull : (hp.d ? (L.max_value - hp.s) / hp.d : ~0ull);
                 }
-                if (cnt >= HOT_KEEP) {
+                if (cnt >= hot_threshold) {
                     const u32 pos = atomicAdd(&hot_next->n, 1u);
                     if (pos < (u32)HOT_MAX) hot_next->key[pos] = k;
                 }
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
             const int hi = hot_lookup(s_hot_key, s_hot_idx, key, hh);
             d = hi >= 0 ? nb + (u32)hi : bucket_of_hash(hh, bk_log2);
         }
-        const u64 m = match_digit(d, (bk_log2 > 7u ? bk_log2 : 7u) + 1u, valid);
+        const u64 m = match_digit(d, (bk_log2 > 9u ? bk_log2 : 9u) + 1u, valid);
         u32 r = 0;
         if (ok) {
             const u32 c = s_cnt[w][d];
@@ -561,7 +565,9 @@ struct ApplyLds {
     uint8_t h_verdict[AP_R];
     u32 wcnt[AP_WS][4];
     LimitDev lim[LIM_LDS];  // the limit table
-    HotParam hot[HOT_MAX + 1];  // copy of the batch's hot-bucket table
+    struct HotRange {
+        u32 lo, hi, chunk0, fast;
+    } hot[HOT_MAX + 1];  // where the hot buckets are (the full HotParam rows stay in global memory)
     u32 n_ent;
     u32 bucket_len;
     u32 promote_ok;  // 0 while a hot bucket is replayed: its key is kept or dropped by count, not promoted
@@ -583,6 +589,8 @@ struct ApplyArgs {
     int32_t* first_limited;
     Status* st;
     HotSet* hot_next;  // next batch's hot keys (appended to)
+    const HotParam* hot_param;  // this batch's hot-bucket table
+    u32 hot_threshold;          // hits in this batch that make a key hot for the next one
     u32 vmask;   // debug (RL_DEBUG_VMASK): AND-mask on the verdict index, 0xFFFFFFFF normally
     u64* trace;  // debug (RL_APPLY_TRACE=1): per-workgroup phase timestamps, 16 per workgroup; else null
 };
@@ -614,8 +622,8 @@ __device__ __forceinline__ void apply_commit(ApplyLds& S, const ApplyArgs& A, bo
         // promote: the key absorbed HOT_PROMOTE hits, or it is what made this bucket long (hits denied
         // on the spot by the window pass are not counted, so a saturated key shows fewer than it got)
         if (!rebuild && !(f & EF_BAD) && S.promote_ok &&
-            ((f >> EF_COUNT_SHIFT) >= HOT_PROMOTE ||
-             ((f >> EF_COUNT_SHIFT) >= HOT_PROMOTE / 4 && S.bucket_len >= 2 * HOT_PROMOTE))) {
+            ((f >> EF_COUNT_SHIFT) >= A.hot_threshold ||
+             ((f >> EF_COUNT_SHIFT) >= A.hot_threshold / 4 && S.bucket_len >= HOT_LONG_BUCKET))) {
             const u32 pos = atomicAdd(&A.hot_next->n, 1u);
             if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = key;
         }
@@ -1112,8 +1120,9 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
     const u32 tid = threadIdx.x;
     RL_STAMP(11);
     RL_STAMP(12);
-    if (A.trace && worker == 0 && tid < HOT_MAX && S.hot[tid].hi != S.hot[tid].lo)
-        atomicAdd(&A.st->pad[S.hot[tid].fast ? 0 : 1], S.hot[tid].hi - S.hot[tid].lo);
+    if (A.trace && worker == 0)
+        for (u32 q = tid; q < (u32)HOT_MAX; q += AP_BLOCK)
+            if (S.hot[q].hi != S.hot[q].lo) atomicAdd(&A.st->pad[S.hot[q].fast ? 0 : 1], S.hot[q].hi - S.hot[q].lo);
     // ---- fast buckets: chunks of HOT_CHUNK hits, grid-strided over the workers --------------------
     const u32 n_chunks = S.hot[HOT_MAX].chunk0;
     for (u32 c = worker; c < n_chunks; c += n_workers) {
@@ -1125,7 +1134,7 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
             if (S.hot[m].chunk0 <= c) a = m;
             else b = m;
         }
-        const HotParam hp = S.hot[a];
+        const HotParam hp = A.hot_param[a];  // one dependent read per chunk of HOT_CHUNK hits
         const u32 lo = hp.lo, hi = hp.hi;
         const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
         const u64 room = hp.room;
@@ -1171,7 +1180,7 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
     // ---- everything else: replayed by one worker per bucket ---------------------------------------
     if (tid == 0) S.promote_ok = 0;  // (apply_bucket starts with a barrier)
     for (u32 hk = worker; hk < (u32)HOT_MAX; hk += n_workers) {
-        const HotParam hp = S.hot[hk];
+        const ApplyLds::HotRange hp = S.hot[hk];
         if (hp.fast || hp.hi == hp.lo) continue;
         RoundIn in0;
         const u32 n0 = (hp.hi - hp.lo) < (u32)AP_R ? (hp.hi - hp.lo) : (u32)AP_R;
@@ -1194,19 +1203,22 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     const HotParam* __restrict__ hot_param,
     const LimitDev* __restrict__ limits, u32 n_limits, u64 now, uint8_t* __restrict__ verdict,
     int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_next, Status* host_status,
-    HotSet* hot_next, u32 vmask, u64* trace) {
+    HotSet* hot_next, u32 hot_threshold, u32 vmask, u64* trace) {
     __shared__ ApplyLds S;
     __shared__ uint2 s_ranges[AP_MAX_PER_WG + 4];
     const u32 tid = threadIdx.x, G = gridDim.x;
     if (trace && tid == 0) trace[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
     ApplyArgs A{table, log2cap, seed, b_hits, hits,  limits, n_limits, now,
-                verdict, first_limited, &bs->st, hot_next, vmask, trace};
+                verdict, first_limited, &bs->st, hot_next, hot_param, hot_threshold, vmask, trace};
     if (tid < AP_MAX_PER_WG + 4) {
         const u32 k = blockIdx.x + tid * G;
         s_ranges[tid] = (tid < AP_MAX_PER_WG && k < nb) ? ranges[k] : make_uint2(0, 0);
     }
     for (u32 q = tid; q < (u32)LIM_LDS && q < n_limits; q += AP_BLOCK) S.lim[q] = limits[q];
-    if (tid <= HOT_MAX) S.hot[tid] = hot_param[tid];
+    for (u32 q = tid; q <= (u32)HOT_MAX; q += AP_BLOCK) {
+        const HotParam hp = hot_param[q];
+        S.hot[q] = ApplyLds::HotRange{hp.lo, hp.hi, hp.chunk0, hp.fast};
+    }
     if (tid == 0) {
         S.n_created = 0;
         S.promote_ok = 1;
@@ -1258,6 +1270,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
             out.n_inserted = __hip_atomic_load(&bs->st.n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.pad[0] = __hip_atomic_load(&bs->st.pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.pad[1] = __hip_atomic_load(&bs->st.pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.pad[2] = __hip_atomic_load(&hot_next->n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // keys that qualified
             *host_status = out;
             *bs_next = BatchScratch{};
         }

@@ -98,6 +98,7 @@ struct rl_engine {
     uint2* d_bk_ranges = nullptr;
     HotSet* d_hot = nullptr;        // [2]: the set used by this batch, the set it picks for the next
     u32 hot_cur = 0;
+    u32 hot_threshold = HOT_PROMOTE;  // doubled while more keys qualify than there are hot buckets
     HotParam* d_hot_param = nullptr;
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
@@ -419,7 +420,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
                                                           hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
                                                           e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
-                                                          hot_next, bs,
+                                                          hot_next, bs, e->hot_threshold,
                                                           e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 : nullptr);
     if (t) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
     u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
@@ -429,7 +430,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
                                                   e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
                                                   (u32)e->h_limits.size(), now, d_verdict, d_first, bs, bs_next,
-                                                  f.h_st, hot_next, e->dbg_vmask, e->d_bk_trace);
+                                                  f.h_st, hot_next, e->hot_threshold, e->dbg_vmask, e->d_bk_trace);
     HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
     HIP_TRY(e, hipGetLastError());
     f.n = n;
@@ -449,6 +450,9 @@ int collect_k1_bucketed(rl_engine* e) {
     e->col_seq++;
     e->inflight_hits -= f.n;
     e->live += f.h_st->n_inserted;
+    // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
+    if (f.h_st->pad[2] > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
+    else if (f.h_st->pad[2] < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
     e->stats.batches++;
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);

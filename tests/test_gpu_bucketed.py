@@ -124,10 +124,10 @@ def test_more_hot_keys_than_hot_buckets(make_engine):
     rng = np.random.default_rng(12)
     n = 400_000
     eng, orc = pair(make_engine, [(900, 60)], max_batch_hits=n, capacity_cells=1 << 16)
-    keys = W.splitmix64(np.arange(1, 301, dtype=np.uint64))  # 300 keys x ~1333 hits: all above the bar
+    keys = W.splitmix64(np.arange(1, 701, dtype=np.uint64))  # 700 keys x ~570 hits: all above the bar, 512 slots
     now = NOW
     for step in range(3):
-        run_both(eng, orc, make_hits(keys[rng.integers(0, 300, size=n)], 0, 1), now)
+        run_both(eng, orc, make_hits(keys[rng.integers(0, 700, size=n)], 0, 1), now)
         now += 1000
     assert_same_state(eng, orc)
 
