@@ -644,7 +644,15 @@ __device__ __forceinline__ void apply_commit(ApplyLds& S, const ApplyArgs& A, bo
             k_flags[q] = f;
         }
     }
-    if (!rebuild) return;
+    if (!rebuild) {  // end of the bucket: leave the table empty
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const u32 e = threadIdx.x + q * AP_BLOCK;
+            S.key[e] = TAG_EMPTY;
+            S.flags[e] = 0;
+        }
+        return;
+    }
     if (threadIdx.x == 0) S.n_keep = 0;
     __syncthreads();
     u32 nk = 0;
@@ -748,7 +756,9 @@ __device__ __forceinline__ void apply_round_core(ApplyLds& S, const ApplyArgs& A
         }
         u32 e = (u32)(fmix64(h[u].key ^ A.seed) >> 20) & (ENT_N - 1);
         for (;;) {
-            const u64 prev = atomicCAS(&S.key[e], TAG_EMPTY, h[u].key);
+            // a plain read first: the lanes that repeat a key already in LDS do not queue up on a CAS
+            u64 prev = S.key[e];
+            if (prev == TAG_EMPTY) prev = atomicCAS(&S.key[e], TAG_EMPTY, h[u].key);
             if (prev == TAG_EMPTY) {
                 creator[u] = true;
                 ++n_new;
@@ -759,7 +769,7 @@ __device__ __forceinline__ void apply_round_core(ApplyLds& S, const ApplyArgs& A
         }
         ent[u] = e;
         atomicAdd(&S.rsum[e], (u64)h[u].delta);
-        atomicMax(&S.dmax[e], h[u].delta);
+        if (h[u].delta > S.dmax[e]) atomicMax(&S.dmax[e], h[u].delta);  // only a new maximum is an atomic
         leader[u] = atomicAdd(&S.cnt4[e], 1ull << (16 * w)) == 0ull;
         S.h_ent[p] = (unsigned short)e;
         S.h_delta[p] = h[u].delta;
@@ -995,13 +1005,7 @@ __device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u3
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, w = tid >> 6;
     const u64 lt = (1ull << lane) - 1ull;
-    for (u32 e = tid; e < ENT_N; e += AP_BLOCK) {
-        S.key[e] = TAG_EMPTY;
-        S.rsum[e] = 0;
-        S.cnt4[e] = 0;
-        S.dmax[e] = 0;
-        S.flags[e] = 0;
-    }
+    // (the LDS cells are empty here: cleared once per launch and again by every bucket's final commit)
     if (tid == 0) {
         S.n_ent = 0;
         S.any_slow = 0;
@@ -1103,9 +1107,9 @@ __device__ __forceinline__ void apply_bucket(ApplyLds& S, const ApplyArgs& A, u3
     }
     if (q_tail != q_head) apply_round(S, A, true, q_head, q_tail - q_head);
     RL_STAMP(8);
-    apply_commit(S, A, false);
+    apply_commit(S, A, false);  // also leaves every LDS cell empty for the next bucket
     RL_STAMP(9);
-    __syncthreads();  // the LDS cells may be reused for another bucket
+    __syncthreads();
 }
 
 // A hot key's bucket holds one key, in trace order: a hit's position in the bucket is its rank on
@@ -1215,6 +1219,13 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
         s_ranges[tid] = (tid < AP_MAX_PER_WG && k < nb) ? ranges[k] : make_uint2(0, 0);
     }
     for (u32 q = tid; q < (u32)LIM_LDS && q < n_limits; q += AP_BLOCK) S.lim[q] = limits[q];
+    for (u32 e = tid; e < ENT_N; e += AP_BLOCK) {
+        S.key[e] = TAG_EMPTY;
+        S.rsum[e] = 0;
+        S.cnt4[e] = 0;
+        S.dmax[e] = 0;
+        S.flags[e] = 0;
+    }
     for (u32 q = tid; q <= (u32)HOT_MAX; q += AP_BLOCK) {
         const HotParam hp = hot_param[q];
         S.hot[q] = ApplyLds::HotRange{hp.lo, hp.hi, hp.chunk0, hp.fast};
