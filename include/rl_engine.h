@@ -194,6 +194,53 @@ int32_t rl_load_cells(rl_engine *e, const rl_cell_row *rows, uint64_t n);
 int32_t rl_load_cells_device(rl_engine *e, const rl_cell_row *d_rows, uint64_t n);
 int32_t rl_dump_cells(rl_engine *e, rl_cell_row *out, uint64_t cap, uint64_t *n_out);
 
+/* ---- upstream of the trait: limit matching and key derivation on the device --------------------- */
+/* RateLimiter::counters_that_apply (lib.rs:507-522) = Limit::applies (limit.rs:157-174) +
+ * Counter::new / resolve_variables (counter.rs:19-31, limit.rs:133-148) for limits whose conditions are
+ * `descriptors[0]['k'] == 'v'` / `!= 'v'` and whose variables are `descriptors[0]['k']` (at most two).
+ * Strings are dictionary-encoded by the caller (exact ids < 2^26); a request is its namespace id and the
+ * (key id, value id) entries of descriptors[0].  A condition on an absent key is false for both
+ * operators (limit/cel.rs:321-338); a limit with an absent variable yields no counter
+ * (limit/cel.rs:176-191).  The counters of a request come out in match-table order, simple counters
+ * first (in_memory.rs:105,121), keyed by rl_match_key — packed ids, injective, hence exact. */
+typedef struct {
+    uint32_t key;   /* descriptor key id */
+    uint32_t op;    /* 0: ==   1: != */
+    uint32_t value; /* value id */
+} rl_match_cond;
+typedef struct {
+    uint32_t limit;      /* limit id (< 4095, a row of rl_limits_set) | RL_SIMPLE iff n_vars == 0 */
+    uint32_t ns;         /* namespace id; the table must be sorted by it */
+    uint32_t cond_off;   /* first condition of this limit in conds[] */
+    uint32_t n_cond;
+    uint32_t n_vars;     /* 0..2 */
+    uint32_t var_key[2]; /* descriptor key ids of the variables, in variable-name order */
+    uint32_t pad;
+} rl_match_limit;
+int32_t rl_match_table_set(rl_engine *e, const rl_match_limit *limits, uint32_t n_limits,
+                           const rl_match_cond *conds, uint32_t n_conds, uint32_t n_namespaces);
+/* The key the device derives for (limit, variable values): what rl_add_counter must be given for a
+ * limit without variables, and what identifies a counter in rl_get_counters / rl_dump_cells rows. */
+uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t v1);
+/* counters_that_apply + check_and_update for a batch of requests, applied in index order with one
+ * clock value.  Requests: req_ns[n_req], req_delta[n_req], CSR ent_off[n_req+1] into ent_key / ent_val.
+ * Out: verdict[n_req]; limited_limit[n_req] (may be NULL): limit id of the first limited counter, -1 when
+ * Ok or when no limit applies (lib.rs:434-440); optionally the derived counters themselves
+ * (req_off_out[n_req+1], hits_out[<= hits_cap], *n_hits_out) and, with load_counters, remaining /
+ * expires_in_us per derived counter.  Host pointers. */
+int32_t rl_match_and_check_batch(rl_engine *e, const uint32_t *req_ns, const uint32_t *ent_off,
+                                 const uint32_t *ent_key, const uint32_t *ent_val, const uint32_t *req_delta,
+                                 uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t *verdict,
+                                 int32_t *limited_limit, uint32_t *req_off_out, rl_hit *hits_out,
+                                 uint32_t hits_cap, uint32_t *n_hits_out, uint64_t *remaining,
+                                 uint64_t *expires_in_us);
+/* Same with device pointers for the request arrays, verdict and limited_limit. */
+int32_t rl_match_and_check_batch_device(rl_engine *e, const uint32_t *d_req_ns, const uint32_t *d_ent_off,
+                                        const uint32_t *d_ent_key, const uint32_t *d_ent_val,
+                                        const uint32_t *d_req_delta, uint32_t n_req, uint64_t now_us,
+                                        int32_t load_counters, uint8_t *d_verdict, int32_t *d_limited_limit,
+                                        uint32_t *n_hits_out);
+
 /* ---- multi-GPU routing helpers (device pointers, engine's stream) ----------------------- */
 /* Owner shard of a key for a world of `world` shards (any world >= 1). */
 uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world);

@@ -26,11 +26,14 @@
 #include "rl_bucket.hpp"
 #include "rl_general.hpp"
 #include "rl_route.hpp"
+#include "rl_match.hpp"
 
 using namespace rl;
 
 static_assert(sizeof(rl_hit) == sizeof(Hit), "rl_hit layout");
 static_assert(sizeof(rl_cell_row) == sizeof(CellRow), "rl_cell_row layout");
+static_assert(sizeof(rl_match_limit) == sizeof(MatchLimit), "rl_match_limit layout");
+static_assert(sizeof(rl_match_cond) == sizeof(MatchCond), "rl_match_cond layout");
 
 struct rl_engine {
     std::mutex mu;
@@ -105,6 +108,23 @@ struct rl_engine {
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
     BHit* d_bk_hits = nullptr;
+
+    // on-device limit matching (rl_match.hpp)
+    MatchLimit* d_match_limits = nullptr;
+    MatchCond* d_match_conds = nullptr;
+    u32* d_match_ns_off = nullptr;
+    u32 n_match_limits = 0, n_match_ns = 0;
+    u32* d_m_ns = nullptr;      // staging for host-pointer calls: per request namespace, delta
+    u32* d_m_delta = nullptr;
+    u32* d_m_ent_off = nullptr;
+    u32* d_m_ent_key = nullptr;
+    u32* d_m_ent_val = nullptr;
+    u32* d_m_count = nullptr;
+    int32_t* d_m_limited = nullptr;
+    u32* h_m_total = nullptr;   // pinned: {n_hits, not_all_single}
+    u32* d_m_flags = nullptr;
+    void* d_m_scan_tmp = nullptr;
+    size_t m_scan_tmp_bytes = 0;
 
     rl_stats_t stats{};
 
@@ -714,6 +734,23 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         }
     ALLOC(e->d_bk_hits, mb * sizeof(BHit));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
+    ALLOC(e->d_m_ns, mb * sizeof(u32));
+    ALLOC(e->d_m_delta, mb * sizeof(u32));
+    ALLOC(e->d_m_ent_off, (mb + 1) * sizeof(u32));
+    ALLOC(e->d_m_ent_key, mb * sizeof(u32));
+    ALLOC(e->d_m_ent_val, mb * sizeof(u32));
+    ALLOC(e->d_m_count, (mb + 1) * sizeof(u32));
+    ALLOC(e->d_m_limited, mb * sizeof(int32_t));
+    ALLOC(e->d_m_flags, 16);
+    {
+        size_t mtmp = 0;
+        if (rocprim::exclusive_scan(nullptr, mtmp, e->d_m_count, e->d_req_off, 0u, mb + 1, rocprim::plus<u32>(),
+                                    e->stream) != hipSuccess)
+            return bail(RL_ERR_DEVICE);
+        e->m_scan_tmp_bytes = mtmp ? mtmp : 16;
+        ALLOC(e->d_m_scan_tmp, e->m_scan_tmp_bytes);
+    }
+    if (hipHostMalloc((void**)&e->h_m_total, 16) != hipSuccess) return bail(RL_ERR_NOMEM);
     size_t tmp = 0;
     if (rocprim::radix_sort_keys(nullptr, tmp, e->d_keys_a, e->d_keys_b, mb, 0u, 64u, e->stream) != hipSuccess)
         return bail(RL_ERR_DEVICE);
@@ -751,11 +788,14 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_trace,
-                    e->d_hot,     e->d_hot_param, e->d_bs};
+                    e->d_hot,     e->d_hot_param, e->d_bs,
+                    e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
+                    e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_total) (void)hipHostFree(e->h_total);
+    if (e->h_m_total) (void)hipHostFree(e->h_m_total);
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& f : e->inflight) {
@@ -1042,6 +1082,148 @@ int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
                              : fail(e, RL_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(r));
     (void)hipFree(d_rows);
     return rc;
+}
+
+// ---- on-device limit matching (rl_match.hpp) -------------------------------------------------------
+uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t v1) {
+    return match_key(limit_id, n_vars, v0, v1);
+}
+
+int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t n_limits, const rl_match_cond* conds,
+                           uint32_t n_conds, uint32_t n_namespaces) {
+    if (!e || (n_limits && !limits) || (n_conds && !conds)) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    HIP_TRY(e, hipSetDevice(e->device));
+    std::vector<u32> ns_off(n_namespaces + 1, 0);
+    for (u32 i = 0; i < n_limits; ++i) {
+        const rl_match_limit& L = limits[i];
+        if (L.ns >= n_namespaces) return fail(e, RL_ERR_INVALID, "match limit %u: namespace id %u out of range", i, L.ns);
+        if (i && limits[i - 1].ns > L.ns) return fail(e, RL_ERR_INVALID, "match limits must be sorted by namespace id");
+        if (L.n_vars > MATCH_MAX_VARS) return fail(e, RL_ERR_INVALID, "match limit %u: more than %u variables stay on the host path", i, MATCH_MAX_VARS);
+        if (((L.limit & RL_SIMPLE) != 0) != (L.n_vars == 0)) return fail(e, RL_ERR_INVALID, "match limit %u: RL_SIMPLE must be set iff the limit has no variables", i);
+        if (RL_LIMIT_ID(L.limit) >= e->h_limits.size() || RL_LIMIT_ID(L.limit) >= 4095u) return fail(e, RL_ERR_INVALID, "match limit %u: unknown limit id", i);
+        if ((u64)L.cond_off + L.n_cond > n_conds) return fail(e, RL_ERR_INVALID, "match limit %u: conditions out of range", i);
+        ns_off[L.ns + 1]++;
+    }
+    for (u32 n = 0; n < n_namespaces; ++n) ns_off[n + 1] += ns_off[n];
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->d_match_limits) (void)hipFree(e->d_match_limits);
+    if (e->d_match_conds) (void)hipFree(e->d_match_conds);
+    if (e->d_match_ns_off) (void)hipFree(e->d_match_ns_off);
+    e->d_match_limits = nullptr;
+    e->d_match_conds = nullptr;
+    e->d_match_ns_off = nullptr;
+    if (hipMalloc((void**)&e->d_match_limits, (n_limits ? n_limits : 1) * sizeof(MatchLimit)) != hipSuccess ||
+        hipMalloc((void**)&e->d_match_conds, (n_conds ? n_conds : 1) * sizeof(MatchCond)) != hipSuccess ||
+        hipMalloc((void**)&e->d_match_ns_off, ns_off.size() * sizeof(u32)) != hipSuccess)
+        return fail(e, RL_ERR_NOMEM, "hipMalloc of the match table failed");
+    if (n_limits) HIP_TRY(e, hipMemcpy(e->d_match_limits, limits, n_limits * sizeof(MatchLimit), hipMemcpyHostToDevice));
+    if (n_conds) HIP_TRY(e, hipMemcpy(e->d_match_conds, conds, n_conds * sizeof(MatchCond), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->d_match_ns_off, ns_off.data(), ns_off.size() * sizeof(u32), hipMemcpyHostToDevice));
+    e->n_match_limits = n_limits;
+    e->n_match_ns = n_namespaces;
+    return RL_OK;
+}
+
+// device pointers for the request arrays and for verdict / limited_limit; derived hits stay in the
+// engine's staging buffers (e->d_hits, e->d_req_off)
+static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* d_ent_off, const u32* d_ent_key,
+                                      const u32* d_ent_val, const u32* d_delta, u32 n_req, u64 now, bool load,
+                                      uint8_t* d_verdict, int32_t* d_limited, u32* n_hits_out) {
+    if (!e->d_match_limits) return fail(e, RL_ERR_INVALID, "rl_match_table_set was not called");
+    const u32 g = cdiv(n_req, 256);
+    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_m_count + n_req, 0, sizeof(u32), e->stream));
+    k_match<false><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
+                                             e->d_match_ns_off, e->n_match_ns, e->d_match_conds, e->d_m_count, nullptr,
+                                             nullptr, e->d_status);
+    size_t stmp = e->m_scan_tmp_bytes;
+    HIP_TRY(e, rocprim::exclusive_scan(e->d_m_scan_tmp, stmp, e->d_m_count, e->d_req_off, 0u, (size_t)n_req + 1,
+                                       rocprim::plus<u32>(), e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_req_off + n_req, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    int rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status->err) return status_to_error(e, e->h_status->err);
+    const u32 n_hits = e->h_m_total[0];
+    if (n_hits_out) *n_hits_out = n_hits;
+    if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the requests expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
+    if (n_hits) {
+        HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+        k_match<true><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
+                                                e->d_match_ns_off, e->n_match_ns, e->d_match_conds, nullptr, e->d_req_off,
+                                                e->d_hits, e->d_status);
+        rc = read_status(e);
+        if (rc) return rc;
+        if (e->h_status->err & ERRBIT_RESERVED_KEY)
+            return fail(e, RL_ERR_INVALID, "a value id does not fit %u bits: such dictionaries keep the host path", MATCH_VAL_BITS);
+        if (e->h_status->err) return status_to_error(e, e->h_status->err);
+    }
+    rc = run_check_general(e, e->d_hits, n_hits, e->d_req_off, n_req, now, load, d_verdict, e->d_first, e->d_remaining,
+                           e->d_expires);
+    if (rc) return rc;
+    if (d_limited) {
+        k_match_limited_limit<<<g, 256, 0, e->stream>>>(e->d_first, e->d_hits, n_req, d_limited);
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    return RL_OK;
+}
+
+int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, const uint32_t* d_ent_off,
+                                        const uint32_t* d_ent_key, const uint32_t* d_ent_val,
+                                        const uint32_t* d_req_delta, uint32_t n_req, uint64_t now_us,
+                                        int32_t load_counters, uint8_t* d_verdict, int32_t* d_limited_limit,
+                                        uint32_t* n_hits_out) {
+    if (!e || !n_req || !d_req_ns || !d_ent_off || !d_req_delta || !d_verdict) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
+    HIP_TRY(e, hipSetDevice(e->device));
+    return match_and_check_locked(e, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, n_req, now_us,
+                                  load_counters != 0, d_verdict, d_limited_limit, n_hits_out);
+}
+
+int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
+                                 const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
+                                 int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, uint32_t* req_off_out,
+                                 rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out, uint64_t* remaining,
+                                 uint64_t* expires_in_us) {
+    if (!e || !n_req || !req_ns || !ent_off || !req_delta || !verdict) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
+    const u32 n_ent = ent_off[n_req];
+    if (n_ent > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "descriptor entries %u > max_batch_hits %u", n_ent, e->max_batch);
+    if (n_ent && (!ent_key || !ent_val)) return fail(e, RL_ERR_INVALID, "ent_key / ent_val are null");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(e->d_m_ns, req_ns, (size_t)n_req * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_m_delta, req_delta, (size_t)n_req * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_m_ent_off, ent_off, ((size_t)n_req + 1) * 4, hipMemcpyHostToDevice, e->stream));
+    if (n_ent) {
+        HIP_TRY(e, hipMemcpyAsync(e->d_m_ent_key, ent_key, (size_t)n_ent * 4, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->d_m_ent_val, ent_val, (size_t)n_ent * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    u32 n_hits = 0;
+    int rc = match_and_check_locked(e, e->d_m_ns, e->d_m_ent_off, e->d_m_ent_key, e->d_m_ent_val, e->d_m_delta, n_req,
+                                    now_us, load_counters != 0, e->d_verdict, limited_limit ? e->d_m_limited : nullptr,
+                                    &n_hits);
+    if (n_hits_out) *n_hits_out = n_hits;
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n_req, hipMemcpyDeviceToHost, e->stream));
+    if (limited_limit)
+        HIP_TRY(e, hipMemcpyAsync(limited_limit, e->d_m_limited, (size_t)n_req * 4, hipMemcpyDeviceToHost, e->stream));
+    if (req_off_out)
+        HIP_TRY(e, hipMemcpyAsync(req_off_out, e->d_req_off, ((size_t)n_req + 1) * 4, hipMemcpyDeviceToHost, e->stream));
+    const u32 n_copy = n_hits < hits_cap ? n_hits : hits_cap;
+    if (hits_out && n_copy)
+        HIP_TRY(e, hipMemcpyAsync(hits_out, e->d_hits, (size_t)n_copy * sizeof(Hit), hipMemcpyDeviceToHost, e->stream));
+    if (load_counters && n_copy && remaining && expires_in_us) {
+        HIP_TRY(e, hipMemcpyAsync(remaining, e->d_remaining, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(expires_in_us, e->d_expires, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
 }
 
 uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world) { return owner_of(key, hash_seed, world); }

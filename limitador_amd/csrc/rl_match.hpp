@@ -1,0 +1,146 @@
+// rl_match.hpp — limit matching and counter-key derivation on the device: the step UPSTREAM of
+// CounterStorage::check_and_update in the reference,
+//     RateLimiter::counters_that_apply   limitador/src/lib.rs:507-522
+//     Limit::applies                      limitador/src/limit.rs:157-174
+//     Limit::resolve_variables            limitador/src/limit.rs:133-148
+//     Counter::new                        limitador/src/counter.rs:19-31
+// for the predicate shapes rate-limit configurations are made of
+//     descriptors[0]['key'] == 'value'     descriptors[0]['key'] != 'value'      (conditions)
+//     descriptors[0]['key']                                                     (variables)
+// (limitador-server/sandbox/limits.yaml, examples/limits.yaml, doc/how-it-works.md).  Anything
+// else is CEL and stays on the host: the caller simply does not put such a limit in the match table.
+//
+// Strings never reach the device: the ingest side dictionary-encodes descriptor keys and values to
+// dense ids (exact — two different strings never share an id), so a request is
+//     namespace id, [(key id, value id)] entries of descriptors[0], delta
+// and a compiled limit is a list of (key id, ==|!=, value id) conditions plus the key ids of its
+// variables.  Semantics restated from the reference:
+//   * a condition on a key the request does not carry is FALSE, for == and for != alike
+//     (limit/cel.rs:321-338: NoSuchKey -> Ok(false));
+//   * a limit whose variable is not in the request does not produce a counter
+//     (limit/cel.rs:176-191: NoSuchKey -> Ok(None); counter.rs:22-24);
+//   * every limit of the namespace that applies yields one counter (lib.rs:512-521) — here in
+//     match-table order, simple counters (no variables) first, as the storage walks them
+//     (in_memory.rs:105,121);
+//   * the counter's identity is (limit, resolved variable values) (counter.rs:123-138): the key is
+//     the PACKED ids — limit id + 1 in bits 52.., value ids in bits 0..25 and 26..51 — injective, so
+//     exact; dictionaries beyond 2^26 values or limits with more than two variables keep the host
+//     path.
+//
+//   k_match_count   requests x limits of their namespace -> counters per request
+//   (exclusive scan of the counts: rocPRIM)
+//   k_match_fill    the same evaluation again, writing the rl_hit records at the scanned offsets
+#pragma once
+#include "rl_kernels.hpp"
+
+namespace rl {
+
+constexpr u32 MATCH_MAX_VARS = 2;
+constexpr u32 MATCH_VAL_BITS = 26;
+constexpr u32 MATCH_NO_VALUE = 0xFFFFFFFFu;
+
+struct MatchCond {  // == rl_match_cond
+    u32 key;
+    u32 op;  // 0: ==   1: !=
+    u32 value;
+};
+struct MatchLimit {  // == rl_match_limit
+    u32 limit;     // limit id | SIMPLE_FLAG (set iff n_vars == 0)
+    u32 ns;        // namespace id; the table is sorted by ns
+    u32 cond_off;  // first condition in the condition array
+    u32 n_cond;
+    u32 n_vars;
+    u32 var_key[MATCH_MAX_VARS];  // descriptor keys of the variables, in variable-name order
+    u32 pad;
+};
+static_assert(sizeof(MatchLimit) == 32, "rl_match_limit is 32 bytes");
+static_assert(sizeof(MatchCond) == 12, "rl_match_cond is 12 bytes");
+
+__host__ __device__ inline u64 match_key(u32 limit_id, u32 n_vars, u32 v0, u32 v1) {
+    return ((u64)(limit_id + 1u) << (2 * MATCH_VAL_BITS)) | ((u64)(n_vars > 1 ? v1 : 0u) << MATCH_VAL_BITS) |
+           (u64)(n_vars > 0 ? v0 : 0u);
+}
+
+// value id of descriptor key `key` in the request's entries, MATCH_NO_VALUE if absent.  The first
+// entry wins, like the first insertion into the reference's context map.
+__device__ __forceinline__ u32 entry_value(const u32* __restrict__ ent_key, const u32* __restrict__ ent_val, u32 b,
+                                           u32 e, u32 key) {
+    for (u32 q = b; q < e; ++q)
+        if (ent_key[q] == key) return ent_val[q];
+    return MATCH_NO_VALUE;
+}
+
+// Does limit L apply to the request, and with which variable values?  (limit.rs:157-174, 133-148)
+__device__ __forceinline__ bool limit_applies(const MatchLimit& L, const MatchCond* __restrict__ conds,
+                                              const u32* __restrict__ ent_key, const u32* __restrict__ ent_val, u32 b,
+                                              u32 e, u32 (&vars)[MATCH_MAX_VARS]) {
+    for (u32 c = 0; c < L.n_cond; ++c) {
+        const MatchCond cd = conds[L.cond_off + c];
+        const u32 v = entry_value(ent_key, ent_val, b, e, cd.key);
+        if (v == MATCH_NO_VALUE) return false;  // NoSuchKey -> false, whatever the operator
+        if ((v == cd.value) != (cd.op == 0u)) return false;
+    }
+    vars[0] = vars[1] = 0;
+    for (u32 q = 0; q < L.n_vars; ++q) {
+        const u32 v = entry_value(ent_key, ent_val, b, e, L.var_key[q]);
+        if (v == MATCH_NO_VALUE) return false;
+        vars[q] = v;
+    }
+    return true;
+}
+
+// One thread per request.  FILL == false: count[r] = counters of request r.  FILL == true: write
+// them at hit_off[r].., simple counters first (two passes over the namespace's limits).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_match(const u32* __restrict__ req_ns, const u32* __restrict__ ent_off,
+                                               const u32* __restrict__ ent_key, const u32* __restrict__ ent_val,
+                                               const u32* __restrict__ req_delta, u32 n_req,
+                                               const MatchLimit* __restrict__ limits,
+                                               const u32* __restrict__ ns_off, u32 n_ns,
+                                               const MatchCond* __restrict__ conds, u32* __restrict__ count,
+                                               const u32* __restrict__ hit_off, Hit* __restrict__ hits,
+                                               Status* st) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_req) return;
+    const u32 ns = req_ns[r];
+    const u32 b = ent_off[r], e = ent_off[r + 1];
+    u32 k = 0;
+    if (ns < n_ns) {
+        const u32 l0 = ns_off[ns], l1 = ns_off[ns + 1];
+        const u32 delta = FILL ? req_delta[r] : 0u;
+        const u32 out = FILL ? hit_off[r] : 0u;
+        for (int pass = 0; pass < 2; ++pass) {  // pass 0: limits without variables, pass 1: with
+            for (u32 li = l0; li < l1; ++li) {
+                const MatchLimit L = limits[li];
+                if ((L.n_vars != 0u) != (pass == 1)) continue;
+                u32 vars[MATCH_MAX_VARS];
+                if (!limit_applies(L, conds, ent_key, ent_val, b, e, vars)) continue;
+                if (FILL) {
+                    if (vars[0] >> MATCH_VAL_BITS || vars[1] >> MATCH_VAL_BITS) atomicOr(&st->err, ERRBIT_RESERVED_KEY);
+                    Hit h;
+                    h.key = match_key(L.limit & ~SIMPLE_FLAG, L.n_vars, vars[0], vars[1]);
+                    h.limit = L.limit;
+                    h.delta = delta;
+                    hits[out + k] = h;
+                }
+                ++k;
+            }
+        }
+    } else {
+        atomicOr(&st->err, ERRBIT_BAD_LIMIT);  // unknown namespace id
+    }
+    if (!FILL) count[r] = k;
+}
+
+// first_limited (index into hits) -> the limit id whose name the reference reports
+// (Authorization::Limited(name), in_memory.rs:91-93,97-99), -1 when the request is not limited.
+__global__ __launch_bounds__(256) void k_match_limited_limit(const int32_t* __restrict__ first_limited,
+                                                             const Hit* __restrict__ hits, u32 n_req,
+                                                             int32_t* __restrict__ out) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_req) return;
+    const int32_t f = first_limited[r];
+    out[r] = f < 0 ? -1 : (int32_t)(hits[f].limit & ~SIMPLE_FLAG);
+}
+
+}  // namespace rl

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .wire import CELL_ROW_DTYPE, HIT_DTYPE, LIMIT_ROW_DTYPE
+from .wire import CELL_ROW_DTYPE, HIT_DTYPE, LIMIT_ROW_DTYPE, MATCH_COND_DTYPE, MATCH_LIMIT_DTYPE
 
 RL_OK = 0
 ERR_NAMES = {
@@ -186,6 +186,43 @@ class Engine:
         out = np.empty(n.value, dtype=CELL_ROW_DTYPE)
         self._check(self._lib.rl_dump_cells(self._h, _ptr(out), out.shape[0], C.byref(n)))
         return out[: min(out.shape[0], n.value)]
+
+    # -- upstream of the trait: limit matching + key derivation on the device ---------------------
+    def set_match_table(self, limits, conds, n_namespaces):
+        """limits: MATCH_LIMIT_DTYPE array sorted by ns; conds: MATCH_COND_DTYPE array."""
+        limits = np.ascontiguousarray(limits, dtype=MATCH_LIMIT_DTYPE)
+        conds = np.ascontiguousarray(conds, dtype=MATCH_COND_DTYPE)
+        self._check(self._lib.rl_match_table_set(self._h, _ptr(limits), limits.shape[0], _ptr(conds), conds.shape[0],
+                                                 int(n_namespaces)))
+
+    def match_key(self, limit_id, values=()):
+        v = list(values) + [0, 0]
+        return int(self._lib.rl_match_key(int(limit_id), len(values), int(v[0]), int(v[1])))
+
+    def match_and_check(self, req_ns, ent_off, ent_key, ent_val, req_delta, now_us, load_counters=False, hits_cap=None):
+        """counters_that_apply + check_and_update for a batch of dictionary-encoded requests.
+        -> dict(verdict, limited_limit, req_off, hits, remaining, expires_in_us)"""
+        req_ns = np.ascontiguousarray(req_ns, dtype=np.uint32)
+        ent_off = np.ascontiguousarray(ent_off, dtype=np.uint32)
+        ent_key = np.ascontiguousarray(ent_key, dtype=np.uint32)
+        ent_val = np.ascontiguousarray(ent_val, dtype=np.uint32)
+        req_delta = np.ascontiguousarray(req_delta, dtype=np.uint32)
+        n_req = req_ns.shape[0]
+        cap = self.max_batch_hits if hits_cap is None else hits_cap
+        verdict = np.empty(n_req, dtype=np.uint8)
+        limited = np.empty(n_req, dtype=np.int32)
+        req_off = np.empty(n_req + 1, dtype=np.uint32)
+        hits = np.empty(cap, dtype=HIT_DTYPE)
+        rem = np.zeros(cap, dtype=np.uint64)
+        exp = np.zeros(cap, dtype=np.uint64)
+        n_hits = C.c_uint32(0)
+        self._check(self._lib.rl_match_and_check_batch(
+            self._h, _ptr(req_ns), _ptr(ent_off), _ptr(ent_key), _ptr(ent_val), _ptr(req_delta), n_req, int(now_us),
+            int(bool(load_counters)), _ptr(verdict), _ptr(limited), _ptr(req_off), _ptr(hits), cap, C.byref(n_hits),
+            _ptr(rem), _ptr(exp)))
+        n = n_hits.value
+        return {"verdict": verdict, "limited_limit": limited, "req_off": req_off, "hits": hits[:n],
+                "remaining": rem[:n] if load_counters else None, "expires_in_us": exp[:n] if load_counters else None}
 
     # -- routing helpers (multi-GPU) -------------------------------------------------------------
     def owner_of(self, key, world):

@@ -1,0 +1,178 @@
+"""On-device limit matching + key derivation (limitador_amd/csrc/rl_match.hpp) against the test-side
+restatement of RateLimiter::counters_that_apply (tests/helpers/limiter.py: Limit.applies,
+_counters_that_apply — the code the reference's scenarios pin), then the verdicts of the derived
+counters against the CPU oracle.  Needs a MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers.limiter import Counter, Limit
+from limitador_amd.wire import HIT_DTYPE, MATCH_COND_DTYPE, MATCH_LIMIT_DTYPE, RL_SIMPLE
+from test_gpu_parity import NOW, SEC, assert_same_state, make_engine  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+class Dictionary:
+    """Exact string -> dense id (what the ingest side keeps)."""
+
+    def __init__(self):
+        self.ids = {}
+
+    def __call__(self, s):
+        return self.ids.setdefault(s, len(self.ids))
+
+
+def compile_table(eng, limits, key_id, val_id):
+    """limits: list of helpers.limiter.Limit in table order (sorted by namespace)."""
+    from helpers.limiter import _COND
+
+    ns_id = Dictionary()
+    rows = np.zeros(len(limits), dtype=MATCH_LIMIT_DTYPE)
+    conds = []
+    for i, l in enumerate(limits):
+        rows[i]["limit"] = i | (0 if l.variables else RL_SIMPLE)
+        rows[i]["ns"] = ns_id(l.namespace)
+        rows[i]["cond_off"] = len(conds)
+        rows[i]["n_cond"] = len(l.conditions)
+        for c in l.conditions:
+            var, op, lit = _COND.match(c).groups()
+            conds.append((key_id(var), 0 if op == "==" else 1, val_id(lit)))
+        rows[i]["n_vars"] = len(l.variables)
+        for q, v in enumerate(l.variables):  # sorted by name already (BTreeSet)
+            rows[i]["var_key"][q] = key_id(v)
+    eng.set_limits([(l.max_value, l.seconds) for l in limits])
+    eng.set_match_table(rows, np.array(conds, dtype=MATCH_COND_DTYPE).reshape(-1), len(ns_id.ids))
+    return ns_id
+
+
+def expected_counters(limits, ns, ctx):
+    """lib.rs:507-522 in table order, then simple first (in_memory.rs:105,121)."""
+    out = []
+    for i, l in enumerate(limits):
+        if l.namespace == ns and l.applies(ctx):
+            out.append((i, Counter(l, tuple(sorted((v, ctx[v]) for v in l.variables)))))
+    return [c for c in out if not c[1].is_qualified()] + [c for c in out if c[1].is_qualified()]
+
+
+@pytest.mark.parametrize("seed,load", [(1, False), (2, True), (3, False)])
+def test_match_table_against_counters_that_apply(make_engine, seed, load):
+    rng = np.random.default_rng(seed)
+    methods, paths = ["GET", "POST", "PUT"], ["/a", "/b", "/json"]
+    limits = []
+    for ns in ("ns0", "ns1", "ns2"):
+        for j in range(6):
+            conds = []
+            if rng.random() < 0.7:
+                conds.append(f"m {'==' if rng.random() < 0.7 else '!='} '{methods[rng.integers(0, 3)]}'")
+            if rng.random() < 0.5:
+                conds.append(f"p {'==' if rng.random() < 0.5 else '!='} '{paths[rng.integers(0, 3)]}'")
+            variables = [(), ("u",), ("a", "u"), ("a",)][int(rng.integers(0, 4))] if j else ()
+            lim = Limit(ns, int(rng.integers(1, 40)), [1, 10, 60][int(rng.integers(0, 3))], conds, variables, name=f"{ns}-{j}")
+            if lim not in limits:  # identity = (ns, seconds, conditions, variables)
+                limits.append(lim)
+    limits.sort(key=lambda l: l.namespace)
+    eng = make_engine(capacity_cells=1 << 16, max_batch_hits=1 << 15)
+    key_id, val_id = Dictionary(), Dictionary()
+    ns_id = compile_table(eng, limits, key_id, val_id)
+    orc = oracle.OracleStorage()
+    orc.set_limits([(l.max_value, l.seconds) for l in limits])
+    n_simple = 0
+    for i, l in enumerate(limits):
+        if not l.variables:
+            eng.add_counter(i | RL_SIMPLE, eng.match_key(i))
+            orc.add_counter(i | RL_SIMPLE, eng.match_key(i))
+            n_simple += 1
+    now = NOW
+    for step in range(6):
+        n_req = int(rng.integers(1, 3000))
+        req_ns, ent_off, ent_key, ent_val, delta = [], [0], [], [], []
+        want_hits, want_off = [], [0]
+        for _ in range(n_req):
+            ns = f"ns{int(rng.integers(0, 3))}" if rng.random() < 0.95 else "ns0"
+            ctx = {}
+            if rng.random() < 0.9:
+                ctx["m"] = methods[rng.integers(0, 3)]
+            if rng.random() < 0.8:
+                ctx["p"] = paths[rng.integers(0, 3)]
+            if rng.random() < 0.8:
+                ctx["u"] = f"user{int(rng.zipf(1.5)) % 50}"
+            if rng.random() < 0.6:
+                ctx["a"] = f"app{int(rng.integers(0, 5))}"
+            d = int(rng.integers(0, 4)) if rng.random() < 0.3 else 1
+            req_ns.append(ns_id(ns))
+            items = list(ctx.items())
+            rng.shuffle(items)
+            for k, v in items:
+                ent_key.append(key_id(k))
+                ent_val.append(val_id(v))
+            ent_off.append(len(ent_key))
+            delta.append(d)
+            for i, c in expected_counters(limits, ns, ctx):
+                vals = [val_id(v) for _k, v in c.set_variables]
+                want_hits.append((eng.match_key(i, vals), i | (0 if c.is_qualified() else RL_SIMPLE), d))
+            want_off.append(len(want_hits))
+        got = eng.match_and_check(req_ns, ent_off, ent_key, ent_val, delta, now, load_counters=load)
+        want = np.zeros(len(want_hits), dtype=HIT_DTYPE)
+        for i, h in enumerate(want_hits):
+            want[i] = h
+        assert np.array_equal(got["req_off"], np.array(want_off, dtype=np.uint32)), "counters per request"
+        assert np.array_equal(got["hits"], want), "derived counters (key, limit, delta)"
+        v, f, r, e = orc.check_and_update(want, now, req_off=np.array(want_off, dtype=np.uint32), load_counters=load)
+        assert np.array_equal(got["verdict"], v)
+        lim_of = np.where(f >= 0, want["limit"][np.maximum(f, 0)] & ~np.uint32(RL_SIMPLE), -1) if len(want) else f
+        assert np.array_equal(got["limited_limit"], lim_of.astype(np.int32))
+        if load:
+            assert np.array_equal(got["remaining"], r) and np.array_equal(got["expires_in_us"], e)
+        now += int(rng.integers(0, 2 * SEC))
+    assert_same_state(eng, orc, n_simple_expected=n_simple)
+
+
+def test_match_table_rejects_what_must_stay_on_the_host(make_engine):
+    from limitador_amd.engine import EngineError
+
+    eng = make_engine()
+    eng.set_limits([(5, 60)])
+    rows = np.zeros(1, dtype=MATCH_LIMIT_DTYPE)
+    rows[0]["limit"] = 0  # no variables but RL_SIMPLE missing
+    with pytest.raises(EngineError) as e:
+        eng.set_match_table(rows, np.zeros(0, dtype=MATCH_COND_DTYPE), 1)
+    assert e.value.code == -1
+    rows[0]["limit"], rows[0]["n_vars"] = 0, 3  # three variables
+    with pytest.raises(EngineError):
+        eng.set_match_table(rows, np.zeros(0, dtype=MATCH_COND_DTYPE), 1)
+    rows[0]["n_vars"], rows[0]["var_key"] = 1, (0, 0)
+    eng.set_match_table(rows, np.zeros(0, dtype=MATCH_COND_DTYPE), 1)
+    # a value id beyond 26 bits cannot be packed into an exact key
+    with pytest.raises(EngineError) as e:
+        eng.match_and_check([0], [0, 1], [0], [1 << 26], [1], NOW)
+    assert e.value.code == -1
+
+
+# The reference's own vectors for Limit::applies (limitador/src/limit.rs:239-348), through the device.
+APPLIES_VECTORS = [
+    # (conditions, variables, context, applies)                                      limit.rs
+    (["x == '5'"], ["y"], {"x": "5", "y": "1"}, True),                              # :239-254 limit_applies
+    (["x == '5'"], ["y"], {"x": "1", "y": "1"}, False),                             # :256-271 cond is false
+    (["x == '5'"], ["y"], {"a": "1", "y": "1"}, False),                             # :273-289 cond var not set
+    (["x == '5'"], ["y"], {"x": "5"}, False),                                       # :291-306 var not set
+    (["x == '5'", "y == '2'"], ["z"], {"x": "5", "y": "2", "z": "1"}, True),        # :308-327 all conditions
+    (["x == '5'", "y == '2'"], ["z"], {"x": "3", "y": "2", "z": "1"}, False),       # :329-348 one does not
+]
+
+
+@pytest.mark.parametrize("conds,variables,ctx,applies", APPLIES_VECTORS)
+def test_reference_applies_vectors_on_device(make_engine, conds, variables, ctx, applies):
+    limit = Limit("test_namespace", 10, 60, conds, variables)
+    assert limit.applies(ctx) == applies  # the restatement the random test compares against
+    eng = make_engine()
+    key_id, val_id = Dictionary(), Dictionary()
+    ns_id = compile_table(eng, [limit], key_id, val_id)
+    items = list(ctx.items())
+    got = eng.match_and_check([ns_id("test_namespace")], [0, len(items)], [key_id(k) for k, _ in items],
+                              [val_id(v) for _, v in items], [1], NOW)
+    assert len(got["hits"]) == (1 if applies else 0)
+    assert got["verdict"][0] == 0 and got["limited_limit"][0] == -1
+    if applies:
+        vals = [val_id(ctx[v]) for v in sorted(variables)]
+        assert int(got["hits"][0]["key"]) == eng.match_key(0, vals)
