@@ -113,7 +113,7 @@ struct rl_engine {
     MatchLimit* d_match_limits = nullptr;
     MatchCond* d_match_conds = nullptr;
     u32* d_match_ns_off = nullptr;
-    u32 n_match_limits = 0, n_match_ns = 0;
+    u32 n_match_limits = 0, n_match_ns = 0, n_match_conds = 0;
     u32* d_m_ns = nullptr;      // staging for host-pointer calls: per request namespace, delta
     u32* d_m_delta = nullptr;
     u32* d_m_ent_off = nullptr;
@@ -1123,6 +1123,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
     HIP_TRY(e, hipMemcpy(e->d_match_ns_off, ns_off.data(), ns_off.size() * sizeof(u32), hipMemcpyHostToDevice));
     e->n_match_limits = n_limits;
     e->n_match_ns = n_namespaces;
+    e->n_match_conds = n_conds;
     return RL_OK;
 }
 
@@ -1135,9 +1136,13 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
     const u32 g = cdiv(n_req, 256);
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_m_count + n_req, 0, sizeof(u32), e->stream));
-    k_match<false><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
-                                             e->d_match_ns_off, e->n_match_ns, e->d_match_conds, e->d_m_count, nullptr,
-                                             nullptr, e->d_status);
+    const bool in_lds = e->n_match_limits <= MATCH_LDS_LIMITS && e->n_match_conds <= MATCH_LDS_CONDS &&
+                        e->n_match_ns <= MATCH_LDS_NS;
+    auto k_count = in_lds ? k_match<false, true> : k_match<false, false>;
+    auto k_fill = in_lds ? k_match<true, true> : k_match<true, false>;
+    k_count<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
+                                             e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
+                                             e->n_match_conds, e->d_m_count, nullptr, nullptr, e->d_status);
     size_t stmp = e->m_scan_tmp_bytes;
     HIP_TRY(e, rocprim::exclusive_scan(e->d_m_scan_tmp, stmp, e->d_m_count, e->d_req_off, 0u, (size_t)n_req + 1,
                                        rocprim::plus<u32>(), e->stream));
@@ -1150,9 +1155,9 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
     if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the requests expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
     if (n_hits) {
         HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-        k_match<true><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
-                                                e->d_match_ns_off, e->n_match_ns, e->d_match_conds, nullptr, e->d_req_off,
-                                                e->d_hits, e->d_status);
+        k_fill<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
+                                                e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
+                                                e->n_match_conds, nullptr, e->d_req_off, e->d_hits, e->d_status);
         rc = read_status(e);
         if (rc) return rc;
         if (e->h_status->err & ERRBIT_RESERVED_KEY)

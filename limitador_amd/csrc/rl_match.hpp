@@ -61,28 +61,41 @@ __host__ __device__ inline u64 match_key(u32 limit_id, u32 n_vars, u32 v0, u32 v
            (u64)(n_vars > 0 ? v0 : 0u);
 }
 
-// value id of descriptor key `key` in the request's entries, MATCH_NO_VALUE if absent.  The first
-// entry wins, like the first insertion into the reference's context map.
-__device__ __forceinline__ u32 entry_value(const u32* __restrict__ ent_key, const u32* __restrict__ ent_val, u32 b,
-                                           u32 e, u32 key) {
-    for (u32 q = b; q < e; ++q)
-        if (ent_key[q] == key) return ent_val[q];
-    return MATCH_NO_VALUE;
-}
+constexpr u32 MATCH_REG_ENTRIES = 8;   // descriptor entries of a request kept in registers
+constexpr u32 MATCH_LDS_LIMITS = 256;  // the match table is staged in LDS when it is this small ...
+constexpr u32 MATCH_LDS_CONDS = 512;   // ... (a few KB: every request walks all limits of its namespace)
+constexpr u32 MATCH_LDS_NS = 64;
+
+// The request's descriptor entries: the first MATCH_REG_ENTRIES in registers, the rest re-read.
+struct ReqEntries {
+    u32 k[MATCH_REG_ENTRIES], v[MATCH_REG_ENTRIES];
+    u32 n, b;
+    const u32* ent_key;
+    const u32* ent_val;
+    // value id of descriptor key `key`, MATCH_NO_VALUE if absent.  The first entry wins, like the
+    // first insertion into the reference's context map.
+    __device__ __forceinline__ u32 value_of(u32 key) const {
+#pragma unroll
+        for (u32 q = 0; q < MATCH_REG_ENTRIES; ++q)
+            if (q < n && k[q] == key) return v[q];
+        for (u32 q = MATCH_REG_ENTRIES; q < n; ++q)
+            if (ent_key[b + q] == key) return ent_val[b + q];
+        return MATCH_NO_VALUE;
+    }
+};
 
 // Does limit L apply to the request, and with which variable values?  (limit.rs:157-174, 133-148)
-__device__ __forceinline__ bool limit_applies(const MatchLimit& L, const MatchCond* __restrict__ conds,
-                                              const u32* __restrict__ ent_key, const u32* __restrict__ ent_val, u32 b,
-                                              u32 e, u32 (&vars)[MATCH_MAX_VARS]) {
+__device__ __forceinline__ bool limit_applies(const MatchLimit& L, const MatchCond* conds, const ReqEntries& R,
+                                              u32 (&vars)[MATCH_MAX_VARS]) {
     for (u32 c = 0; c < L.n_cond; ++c) {
         const MatchCond cd = conds[L.cond_off + c];
-        const u32 v = entry_value(ent_key, ent_val, b, e, cd.key);
+        const u32 v = R.value_of(cd.key);
         if (v == MATCH_NO_VALUE) return false;  // NoSuchKey -> false, whatever the operator
         if ((v == cd.value) != (cd.op == 0u)) return false;
     }
     vars[0] = vars[1] = 0;
     for (u32 q = 0; q < L.n_vars; ++q) {
-        const u32 v = entry_value(ent_key, ent_val, b, e, L.var_key[q]);
+        const u32 v = R.value_of(L.var_key[q]);
         if (v == MATCH_NO_VALUE) return false;
         vars[q] = v;
     }
@@ -91,30 +104,53 @@ __device__ __forceinline__ bool limit_applies(const MatchLimit& L, const MatchCo
 
 // One thread per request.  FILL == false: count[r] = counters of request r.  FILL == true: write
 // them at hit_off[r].., simple counters first (two passes over the namespace's limits).
-template <bool FILL>
+template <bool FILL, bool IN_LDS>
 __global__ __launch_bounds__(256) void k_match(const u32* __restrict__ req_ns, const u32* __restrict__ ent_off,
                                                const u32* __restrict__ ent_key, const u32* __restrict__ ent_val,
                                                const u32* __restrict__ req_delta, u32 n_req,
-                                               const MatchLimit* __restrict__ limits,
+                                               const MatchLimit* __restrict__ limits, u32 n_limits,
                                                const u32* __restrict__ ns_off, u32 n_ns,
-                                               const MatchCond* __restrict__ conds, u32* __restrict__ count,
-                                               const u32* __restrict__ hit_off, Hit* __restrict__ hits,
-                                               Status* st) {
+                                               const MatchCond* __restrict__ conds, u32 n_conds,
+                                               u32* __restrict__ count, const u32* __restrict__ hit_off,
+                                               Hit* __restrict__ hits, Status* st) {
+    __shared__ MatchLimit s_limits[MATCH_LDS_LIMITS];
+    __shared__ MatchCond s_conds[MATCH_LDS_CONDS];
+    __shared__ u32 s_ns_off[MATCH_LDS_NS + 1];
+    // IN_LDS (chosen by the host when the table is small): no pointer that could be either LDS or global
+    // survives, so the loads stay ds_read / global_load instead of flat_load
+    if (IN_LDS) {
+        for (u32 q = threadIdx.x; q < n_limits; q += 256) s_limits[q] = limits[q];
+        for (u32 q = threadIdx.x; q < n_conds; q += 256) s_conds[q] = conds[q];
+        for (u32 q = threadIdx.x; q <= n_ns; q += 256) s_ns_off[q] = ns_off[q];
+        __syncthreads();
+    }
+    const MatchLimit* T = IN_LDS ? (const MatchLimit*)s_limits : limits;
+    const MatchCond* Cd = IN_LDS ? (const MatchCond*)s_conds : conds;
+    const u32* NO = IN_LDS ? (const u32*)s_ns_off : ns_off;
     const u32 r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n_req) return;
     const u32 ns = req_ns[r];
-    const u32 b = ent_off[r], e = ent_off[r + 1];
+    ReqEntries R;
+    R.b = ent_off[r];
+    R.n = ent_off[r + 1] - R.b;
+    R.ent_key = ent_key;
+    R.ent_val = ent_val;
+#pragma unroll
+    for (u32 q = 0; q < MATCH_REG_ENTRIES; ++q) {
+        R.k[q] = q < R.n ? ent_key[R.b + q] : MATCH_NO_VALUE;
+        R.v[q] = q < R.n ? ent_val[R.b + q] : 0u;
+    }
     u32 k = 0;
     if (ns < n_ns) {
-        const u32 l0 = ns_off[ns], l1 = ns_off[ns + 1];
+        const u32 l0 = NO[ns], l1 = NO[ns + 1];
         const u32 delta = FILL ? req_delta[r] : 0u;
         const u32 out = FILL ? hit_off[r] : 0u;
         for (int pass = 0; pass < 2; ++pass) {  // pass 0: limits without variables, pass 1: with
             for (u32 li = l0; li < l1; ++li) {
-                const MatchLimit L = limits[li];
+                const MatchLimit L = T[li];
                 if ((L.n_vars != 0u) != (pass == 1)) continue;
                 u32 vars[MATCH_MAX_VARS];
-                if (!limit_applies(L, conds, ent_key, ent_val, b, e, vars)) continue;
+                if (!limit_applies(L, Cd, R, vars)) continue;
                 if (FILL) {
                     if (vars[0] >> MATCH_VAL_BITS || vars[1] >> MATCH_VAL_BITS) atomicOr(&st->err, ERRBIT_RESERVED_KEY);
                     Hit h;
