@@ -712,10 +712,11 @@ __device__ __forceinline__ void round_load_lines(const ApplyArgs& A, u32 n_items
         in.hslot[u] = slot_of(in.h[u].key, A.seed, A.log2cap);
         const Cell* c = &A.table[in.hslot[u]];
         const uint4 a = *reinterpret_cast<const uint4*>(c);
+        const uint4 b = reinterpret_cast<const uint4*>(c)[1];  // expiry, limit
         in.ctag[u] = ((u64)a.y << 32) | a.x;
         in.cvalue[u] = ((u64)a.w << 32) | a.z;
-        in.cexpiry[u] = c->expiry;
-        in.climit[u] = c->limit;
+        in.cexpiry[u] = ((u64)b.y << 32) | b.x;
+        in.climit[u] = b.z;
     }
 }
 
@@ -820,8 +821,9 @@ __device__ __forceinline__ void apply_round_core(ApplyLds& S, const ApplyArgs& A
                 slot = (slot + 1) & mask;
                 const Cell* c = &A.table[slot];
                 const uint4 a = *reinterpret_cast<const uint4*>(c);
-                const u64 ex = c->expiry;
-                const u32 li = c->limit;
+                const uint4 b = reinterpret_cast<const uint4*>(c)[1];
+                const u64 ex = ((u64)b.y << 32) | b.x;
+                const u32 li = b.z;
                 tag = ((u64)a.y << 32) | a.x;
                 if (tag == h[u].key) {
                     value = ((u64)a.w << 32) | a.z;

@@ -26,17 +26,19 @@ constexpr u32 AMB_ADMIT = 2;    // resolved: at least one hit admitted, aux = fi
 constexpr u32 AMB_DENY = 3;     // resolved: nothing admitted, cell unchanged
 
 struct alignas(64) Cell {
-    u64 tag;     //  0  key, TAG_EMPTY or TAG_TOMB
-    u64 value;   //  8  AtomicExpiringValue.value
-    u64 expiry;  // 16  AtomicExpiringValue.expiry (us since epoch)
-    u64 pend;    // 24  scratch: (hit count << 40) | sum of deltas of this batch (0 between batches)
-    u32 cnt;     // 32  reserved
-    u32 limit;   // 36  limit id | SIMPLE_FLAG (attribute: delete/get by limit, sanity check)
-    u32 amb;     // 40  scratch: AMB_*
-    u32 nonuni;  // 44  scratch: ordered segment has non-uniform deltas / needs sequential walk
-    u64 aux;     // 48  scratch: resolver's final value, or (idx+1)<<32|delta for 0-second windows
-    u32 seg;     // 56  scratch: start of this cell's segment in the sorted ordered list
-    u32 pad;     // 60
+    u64 tag;     //  0  key, TAG_EMPTY or TAG_TOMB                       } one dwordx4
+    u64 value;   //  8  AtomicExpiringValue.value                        }
+    u64 expiry;  // 16  AtomicExpiringValue.expiry (us since epoch)      } one dwordx4: what the hot path
+    u32 limit;   // 24  limit id | SIMPLE_FLAG (attribute of the cell)   } reads besides tag + value
+    u32 cnt;     // 28  reserved                                         }
+    // ---- per-batch scratch of the general resolver / first-generation pipeline: 32 contiguous bytes,
+    //      zero between batches, cleared with two 16-byte stores ------------------------------------
+    u64 pend;    // 32  (hit count << 40) | sum of deltas of this batch
+    u64 aux;     // 40  resolver's final value, or (idx+1)<<32|delta for 0-second windows
+    u32 amb;     // 48  AMB_*
+    u32 nonuni;  // 52  ordered segment has non-uniform deltas / needs sequential walk
+    u32 seg;     // 56  start of this cell's segment in the sorted ordered list
+    u32 pad;     // 60  general resolver: 1 = created by this batch, not yet reached; 2 = reached
 };
 static_assert(sizeof(Cell) == 64, "one cell = one 64-byte line");
 
@@ -75,6 +77,13 @@ constexpr u32 MAX_BATCH_HITS = (1u << 24) - 1u;
 constexpr u32 SLOT_INVALID = 0x7FFFFFFFu;
 constexpr u32 SLOT_MASK = 0x7FFFFFFFu;
 constexpr u32 LEADER_BIT = 0x80000000u;
+
+// Zero the scratch half of a cell (bytes 32..63).
+__device__ __forceinline__ void cell_clear_scratch(Cell* c) {
+    uint4* p = reinterpret_cast<uint4*>(&c->pend);
+    p[0] = make_uint4(0, 0, 0, 0);
+    p[1] = make_uint4(0, 0, 0, 0);
+}
 
 __host__ __device__ inline u64 fmix64(u64 x) {
     x ^= x >> 33;

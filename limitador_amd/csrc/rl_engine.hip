@@ -251,7 +251,7 @@ int run_check_k1_legacy(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t
     const bool t = e->timing;
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
     if (t) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
-    k_probe<PM_CHECK><<<cdiv(n, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+    k_probe<PM_CHECK><<<std::min(cdiv(n, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
         e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(), now,
         (1ull << PEND_SHIFT) / n, e->d_hit_slot, e->d_status);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
@@ -276,7 +276,7 @@ int run_check_k1_legacy(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t
         if (rc) return rc;
     }
     if (t) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream));
-    k_commit<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, d_hits, n, e->d_limits, now, e->d_hit_slot, 0,
+    k_commit<<<std::min(cdiv(n, 256), COMMIT_MAX_BLOCKS), 256, 0, e->stream>>>(e->table, d_hits, n, e->d_limits, now, e->d_hit_slot, 0,
                                                   e->d_status);
     if (t) HIP_TRY(e, hipEventRecord(e->ev[5], e->stream));
     HIP_TRY(e, hipGetLastError());
@@ -509,6 +509,12 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
 // load_counters.  Exact for every input; slower than run_check_k1 (sorts every hit).
 int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_req_off, u32 n_req, u64 now,
                       bool load, uint8_t* d_verdict, int32_t* d_first, u64* d_rem, u64* d_exp) {
+    // The resolver creates the cells of every counter it sees and drops the ones no request reached
+    // (tombstones): compact when they pile up, before they stretch the probe chains.
+    if (e->tombs > e->cap / 8) {
+        const int crc = do_compact(e);
+        if (crc) return crc;
+    }
     int rc = check_room(e, n_hits);
     if (rc) return rc;
     const bool mark_fresh = !load && d_req_off != nullptr;
@@ -526,11 +532,11 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
     }
     const u32 gh = cdiv(n_hits, 256), gr = cdiv(n_req, 256);
     if (mark_fresh)
-        k_probe<PM_CHECK, true, false><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+        k_probe<PM_CHECK, true, false><<<std::min(cdiv(n_hits, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
             e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now, 0ull,
             e->d_hit_slot, e->d_status);
     else
-        k_probe<PM_CHECK, false, false><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+        k_probe<PM_CHECK, false, false><<<std::min(cdiv(n_hits, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
             e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now, 0ull,
             e->d_hit_slot, e->d_status);
     HIP_TRY(e, hipGetLastError());
@@ -574,7 +580,7 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
                                             e->d_admitted, e->d_limits, now);
     if (mark_fresh)
         k_gen_reach<<<gr, 256, 0, e->stream>>>(e->table, d_req_off, n_req, e->d_hit_slot, first);
-    k_commit<<<gh, 256, 0, e->stream>>>(e->table, d_hits, n_hits, e->d_limits, now, e->d_hit_slot,
+    k_commit<<<std::min(gh, COMMIT_MAX_BLOCKS), 256, 0, e->stream>>>(e->table, d_hits, n_hits, e->d_limits, now, e->d_hit_slot,
                                         mark_fresh ? 1 : 0, e->d_status);
     HIP_TRY(e, hipGetLastError());
     rc = read_status(e);
@@ -983,7 +989,7 @@ int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hit
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-    k_probe<PM_UPDATE><<<cdiv(n_hits, PROBE_TILE), PROBE_BLOCK, 0, e->stream>>>(
+    k_probe<PM_UPDATE><<<std::min(cdiv(n_hits, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
         e->table, e->log2cap, e->seed, e->d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now_us,
         (1ull << PEND_SHIFT) / n_hits, e->d_hit_slot, e->d_status);
     HIP_TRY(e, hipGetLastError());

@@ -37,6 +37,7 @@ constexpr int PROBE_HPT = 4;  // hits per thread
 constexpr int PROBE_TILE = PROBE_BLOCK * PROBE_HPT;
 constexpr int AGG_N = 2048;  // LDS aggregation table entries (2x tile)
 constexpr u32 AGG_EMPTY = 0xFFFFFFFFu;
+constexpr u32 PROBE_MAX_BLOCKS = 1024;  // workgroups of k_probe (tiles are grid-strided over them)
 
 __device__ __forceinline__ Hit load_hit(const Hit* hits, u32 i) {
     const uint4 v = *reinterpret_cast<const uint4*>(hits + i);
@@ -107,16 +108,20 @@ __global__ __launch_bounds__(PROBE_BLOCK) void k_probe(Cell* __restrict__ table,
     __shared__ u32 s_created;
 
     const u32 tid = threadIdx.x;
+    if (tid == 0) s_created = 0;
+    // Tiles are grid-strided over a bounded number of workgroups: the count of created cells goes
+    // through one same-address global atomic per workgroup (they serialise at ~30 ns each).
+    const u32 n_tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     for (u32 e = tid; e < AGG_N; e += PROBE_BLOCK) {
         a_slot[e] = AGG_EMPTY;
         a_cnt[e] = 0;
         a_sum[e] = 0;
         a_lead[e] = 0;
     }
-    if (tid == 0) s_created = 0;
     __syncthreads();
 
-    const u32 base = blockIdx.x * PROBE_TILE;
+    const u32 base = tile * PROBE_TILE;
     Hit h[PROBE_HPT];
     u32 slot[PROBE_HPT];
     u64 tag0[PROBE_HPT];
@@ -187,7 +192,6 @@ __global__ __launch_bounds__(PROBE_BLOCK) void k_probe(Cell* __restrict__ table,
             a_lead[e] = ((old >> PEND_SHIFT) == 0ull);
         }
     }
-    if (tid == 0 && s_created) atomicAdd(&st->n_inserted, s_created);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PROBE_HPT; ++u) {
@@ -198,6 +202,9 @@ __global__ __launch_bounds__(PROBE_BLOCK) void k_probe(Cell* __restrict__ table,
             hit_slot[i] = v;
         }
     }
+    __syncthreads();  // the LDS aggregation table is re-initialised for the next tile
+    }
+    if (tid == 0 && s_created) atomicAdd(&st->n_inserted, s_created);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,62 +283,61 @@ __global__ __launch_bounds__(DECIDE_BLOCK) void k_decide(
 // ---------------------------------------------------------------------------------------------
 // k_commit
 // ---------------------------------------------------------------------------------------------
+// Grid-stride over the hits with a bounded grid: the count of dropped cells goes through one
+// same-address global atomic per WORKGROUP, and those serialise at ~30 ns each on one address —
+// a workgroup per 256 hits would be 12 k of them for a 3 M-hit batch (0.5 ms, measured).
+constexpr u32 COMMIT_MAX_BLOCKS = 1024;
+
 __global__ __launch_bounds__(256) void k_commit(Cell* __restrict__ table,
                                                 const Hit* __restrict__ hits, u32 n,
                                                 const LimitDev* __restrict__ limits, u64 now,
                                                 const u32* __restrict__ hit_slot,
                                                 int drop_unreached, Status* st) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u32 hs = hit_slot[i];
-    if (!(hs & LEADER_BIT)) return;
-    Cell* c = &table[hs & SLOT_MASK];
-    const LimitDev L = limits[c->limit & ~SIMPLE_FLAG];
-    const u64 expiry = c->expiry;
-    if (drop_unreached) {
+    __shared__ u32 s_dropped;
+    if (threadIdx.x == 0) s_dropped = 0;
+    __syncthreads();
+    u32 my_dropped = 0;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const u32 hs = hit_slot[i];
+        if (!(hs & LEADER_BIT)) continue;
+        Cell* c = &table[hs & SLOT_MASK];
+        const LimitDev L = limits[c->limit & ~SIMPLE_FLAG];
+        const u64 expiry = c->expiry;
         // A cell created by k_probe that no request actually reached (its request stopped at an
         // earlier limited counter, in_memory.rs:109-113,129-133) must not exist.
-        const u32 fresh = c->pad;
-        c->pad = 0;
-        if (fresh == 1u) {
+        const bool dropped = drop_unreached && c->pad == 1u;
+        if (dropped) {
             c->tag = TAG_TOMB;
-            c->pend = 0;
-            c->cnt = 0;
-            c->amb = 0;
-            c->nonuni = 0;
-            c->aux = 0;
-            c->seg = 0;
-            atomicAdd(&st->n_removed, 1u);
-            return;
-        }
-    }
-    const bool expired = expiry <= now;
-    if (L.window_us == 0) {
-        const u64 a = c->aux;
-        if (a) {  // update(): expired -> (delta, now + 0)
-            c->value = a & 0xFFFFFFFFull;
-            c->expiry = now;
-        }
-    } else {
-        const u32 amb = c->amb;
-        if (amb == AMB_NONE) {
-            const u64 s = expired ? 0ull : c->value;
-            u64 sum;
-            if (!__builtin_add_overflow(s, c->pend & PEND_SUM_MASK, &sum) && sum <= L.max_value) {
-                c->value = sum;
-                if (expired) c->expiry = now + L.window_us;  // update_if_expired, :87-99
+            ++my_dropped;
+        } else {
+            const bool expired = expiry <= now;
+            if (L.window_us == 0) {
+                const u64 a = c->aux;
+                if (a) {  // update(): expired -> (delta, now + 0)
+                    c->value = a & 0xFFFFFFFFull;
+                    c->expiry = now;
+                }
+            } else {
+                const u32 amb = c->amb;
+                if (amb == AMB_NONE) {
+                    const u64 s = expired ? 0ull : c->value;
+                    u64 sum;
+                    if (!__builtin_add_overflow(s, c->pend & PEND_SUM_MASK, &sum) && sum <= L.max_value) {
+                        c->value = sum;
+                        if (expired) c->expiry = now + L.window_us;  // update_if_expired, :87-99
+                    }
+                } else if (amb == AMB_ADMIT) {
+                    c->value = c->aux;
+                    if (expired) c->expiry = now + L.window_us;
+                }
             }
-        } else if (amb == AMB_ADMIT) {
-            c->value = c->aux;
-            if (expired) c->expiry = now + L.window_us;
         }
+        cell_clear_scratch(c);  // (also resets `pad`)
     }
-    c->pend = 0;
-    c->cnt = 0;
-    c->amb = 0;
-    c->nonuni = 0;
-    c->aux = 0;
-    c->seg = 0;
+    for (int off = 32; off > 0; off >>= 1) my_dropped += __shfl_down(my_dropped, off);
+    if (__lane_id() == 0 && my_dropped) atomicAdd(&s_dropped, my_dropped);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_dropped) atomicAdd(&st->n_removed, s_dropped);
 }
 
 // Leaves the table's scratch clean after a failed batch (nothing is applied).
@@ -341,14 +347,7 @@ __global__ __launch_bounds__(256) void k_abort(Cell* __restrict__ table, u32 n,
     if (i >= n) return;
     const u32 slot = hit_slot[i] & SLOT_MASK;
     if (slot == SLOT_INVALID) return;
-    Cell* c = &table[slot];
-    c->pend = 0;
-    c->cnt = 0;
-    c->amb = 0;
-    c->nonuni = 0;
-    c->aux = 0;
-    c->seg = 0;
-    c->pad = 0;
+    cell_clear_scratch(&table[slot]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,9 +384,7 @@ __global__ __launch_bounds__(256) void k_update_commit(Cell* __restrict__ table,
     } else {
         c->value += c->pend & PEND_SUM_MASK;  // wraps like fetch_add
     }
-    c->pend = 0;
-    c->cnt = 0;
-    c->aux = 0;
+    cell_clear_scratch(c);
 }
 
 // Exact fallback for update_counter batches whose deltas could carry out of the packed 40-bit sum:
@@ -507,7 +504,7 @@ __global__ __launch_bounds__(256) void k_insert_rows(Cell* __restrict__ table, u
     atomicOr(&st->err, ERRBIT_TABLE_FULL);
 }
 
-// Streaming scan over the whole table.  Each lane reads the first 48 bytes of one cell as three
+// Streaming scan over the whole table.  Each lane reads the first 32 bytes of one cell as two
 // 16-byte loads (the whole 64-byte line is fetched once per cell: 64 B/slot of HBM traffic).
 constexpr int SCAN_GET = 0;          // append cells of `arg_limit` with ttl(now) > 0   (get_counters)
 constexpr int SCAN_DELETE_LIMIT = 1; // tombstone cells of `arg_limit`                 (delete_counters)
@@ -527,11 +524,10 @@ __global__ __launch_bounds__(256) void k_scan(Cell* __restrict__ table, u64 cap,
         const uint4 a = p[0];  // tag, value
         const u64 tag = ((u64)a.y << 32) | a.x;
         if (tag >= TAG_TOMB) continue;
-        const uint4 b = p[1];  // expiry, pend
-        const uint4 c = p[2];  // cnt, limit, amb, nonuni
+        const uint4 b = p[1];  // expiry, limit, cnt
         const u64 value = ((u64)a.w << 32) | a.z;
         const u64 expiry = ((u64)b.y << 32) | b.x;
-        const u32 limit = c.y;
+        const u32 limit = b.z;
         bool emit = false, kill = false;
         if (MODE == SCAN_GET) emit = (limit == arg_limit) && (expiry > now);
         if (MODE == SCAN_DUMP) emit = true;
@@ -579,15 +575,14 @@ __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u6
         const uint4 a = p[0];
         const u64 tag = ((u64)a.y << 32) | a.x;
         if (tag >= TAG_TOMB) continue;
-        const uint4 b = p[1];
-        const uint4 c = p[2];
+        const uint4 b = p[1];  // expiry, limit, cnt
         u32 slot = slot_of(tag, seed, dst_log2cap);
         for (u32 step = 0; step <= mask; ++step) {
             const u64 old = atomicCAS(&dst[slot].tag, TAG_EMPTY, tag);
             if (old == TAG_EMPTY) {
                 dst[slot].value = ((u64)a.w << 32) | a.z;
                 dst[slot].expiry = ((u64)b.y << 32) | b.x;
-                dst[slot].limit = c.y;
+                dst[slot].limit = b.z;
                 atomicAdd(&st->n_inserted, 1u);
                 break;
             }

@@ -3,8 +3,8 @@
 // reads, MI355X_MICROARCH.md §HBM) can be turned into bytes for k_bkt_apply and friends.
 //   k_calib_stream_read    1 GiB, 16 B per lane, coalesced          -> 1 GiB fetched
 //   k_calib_stream_write   1 GiB, 16 B per lane, coalesced          -> 1 GiB written
-//   k_calib_random_read48  2^20 random 64-byte cells of a 4 GiB table, 48 B read of each
-//                          (tag+value, expiry, limit: what k_bkt_apply reads) -> 64 MiB fetched
+//   k_calib_random_read32  2^20 random 64-byte cells of a 4 GiB table, 32 B read of each
+//                          (tag+value, expiry+limit: what k_bkt_apply reads)  -> 64 MiB fetched
 //   k_calib_random_store8  2^20 random 8-byte stores into the same table    -> 8 MiB useful,
 //                          64 MiB if the memory side writes whole 64-byte lines
 // build: hipcc -O3 --offload-arch=gfx950 pmc_calib.hip -o bin/pmc_calib ; run under rocprofv3 --pmc
@@ -29,14 +29,13 @@ __global__ __launch_bounds__(256) void k_calib_stream_write(uint4* p, size_t n16
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
         p[i] = make_uint4(salt, (u32)i, salt, (u32)i);
 }
-__global__ __launch_bounds__(256) void k_calib_random_read48(const char* table, u32 log2cells, u64 salt, u32 n, u64* sink) {
+__global__ __launch_bounds__(256) void k_calib_random_read32(const char* table, u32 log2cells, u64 salt, u32 n, u64* sink) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const char* c = table + (fmix64(i + salt) >> (64 - log2cells)) * 64;
     const uint4 a = *(const uint4*)c;
-    const u64 e = *(const u64*)(c + 16);
-    const u32 l = *(const u32*)(c + 36);
-    if ((a.x ^ e ^ l) == 0x1234567) *sink = e;
+    const uint4 b = *(const uint4*)(c + 16);
+    if ((a.x ^ b.x ^ b.z) == 0x1234567) *sink = b.x;
 }
 __global__ __launch_bounds__(256) void k_calib_random_store8(char* table, u32 log2cells, u64 salt, u32 n) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
@@ -53,10 +52,10 @@ int main() {
     for (int r = 0; r < 5; ++r) {
         k_calib_stream_read<<<4096, 256>>>((const uint4*)table + (size_t)r * n16 % (bytes / 16 - n16), n16, sink);
         k_calib_stream_write<<<4096, 256>>>((uint4*)table + (size_t)(r + 1) * n16 % (bytes / 16 - n16), n16, r);
-        k_calib_random_read48<<<n / 256, 256>>>(table, log2cells, 7777ull * (r + 1), n, sink);
+        k_calib_random_read32<<<n / 256, 256>>>(table, log2cells, 7777ull * (r + 1), n, sink);
         k_calib_random_store8<<<n / 256, 256>>>(table, log2cells, 9999ull * (r + 1), n);
         CK(hipDeviceSynchronize());
     }
-    printf("pmc_calib done: stream 1 GiB r/w, 2^20 random 64-B-cell reads (48 B each) and 8-B stores, 5 rounds\n");
+    printf("pmc_calib done: stream 1 GiB r/w, 2^20 random 64-B-cell reads (32 B each) and 8-B stores, 5 rounds\n");
     return 0;
 }

@@ -95,7 +95,7 @@ for p in PASSES:
 KNOWN = {  # bytes per launch of the calibration kernels
     "k_calib_stream_read": (1 << 30, 0),
     "k_calib_stream_write": (0, 1 << 30),
-    "k_calib_random_read48": (64 << 20, 0),
+    "k_calib_random_read32": (64 << 20, 0),
     "k_calib_random_store8": (0, 8 << 20),
 }
 fac = {}
@@ -114,7 +114,7 @@ for k, (rd, wr) in KNOWN.items():
     fac[k] = (fr, fw)
     lines.append(f"| `{k}` | {rd / 2**20:.0f} | {wr / 2**20:.0f} | {fs:.0f} | {ws:.0f} | "
                  f"{c.get('TCC_EA0_RDREQ_sum', NAN):.0f} | {c.get('TCC_EA0_WRREQ_sum', NAN):.0f} | {fr:.0f} | {fw:.0f} |")
-f_stream, f_random = fac["k_calib_stream_read"][0], fac["k_calib_random_read48"][0]
+f_stream, f_random = fac["k_calib_stream_read"][0], fac["k_calib_random_read32"][0]
 w_stream, w_random = fac["k_calib_stream_write"][1], fac["k_calib_random_store8"][1]
 lines.append("")
 lines.append(f"Factors used below: streaming read {f_stream:.0f} B per FETCH_SIZE KiB, random 64-B-cell read {f_random:.0f}; "
