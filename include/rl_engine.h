@@ -264,8 +264,10 @@ void *rl_engine_stream(rl_engine *e);
  * routing helpers below enqueue and return without blocking (the caller's stream order is the
  * synchronisation), and submit / collect give the same for the hot path. */
 int32_t rl_engine_set_stream(rl_engine *e, void *stream, int32_t external);
-/* Enable (1) / disable (0) HIP-event timing of the kernels of the single-counter hot path (events
- * on the engine's stream, inside rl_check_and_update_batch[_device]).  rl_kernel_timing_read copies
+/* HIP-event timing of the kernels of the single-counter hot path (events on the engine's stream):
+ * enable = 0 off (no event is recorded at all: completion is a sequence word the last workgroup
+ * stores into host-mapped memory), 1 every kernel (an event between any two kernels; each marker
+ * leaves the device idle for ~5 us), 2 only the dominant kernel, k_bkt_apply.  rl_kernel_timing_read copies
  * the milliseconds accumulated per slot since the last reset into ms[RL_TIMING_SLOTS] and the number
  * of timed batches into *launches. */
 enum {

@@ -15,6 +15,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <mutex>
 #include <new>
 #include <string>
@@ -84,7 +86,8 @@ struct rl_engine {
         hipEvent_t tev[5]{};   // before hist / scan / scatter / apply, after apply (= done)
         Status* h_st = nullptr;  // host-mapped: written by the batch's last workgroup
         u32 n = 0, n_wg = 0, ntiles = 0;
-        bool timed = false;
+        int timed = 0;
+        u32 seq = 0;  // value the batch's last workgroup stores into h_st->n_removed
     } inflight[2];
     u64 sub_seq = 0, col_seq = 0;
     u64 inflight_hits = 0;
@@ -128,7 +131,7 @@ struct rl_engine {
 
     rl_stats_t stats{};
 
-    bool timing = false;
+    int timing = 0;  // 0 off, 1 every kernel of the hot path, 2 k_bkt_apply only
     hipEvent_t ev[8]{};
     double ms_slot[RL_TIMING_SLOTS]{};
     u64 timed_launches = 0;
@@ -418,7 +421,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                         n, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
     }
     rl_engine::Inflight& f = e->inflight[e->sub_seq & 1u];
-    const bool t = e->timing;
+    const bool t = e->timing == 1;  // events between all four kernels
     u32 bk_log2 = ceil_log2(cdiv(n, 384));
     if (bk_log2 > e->bk_log2_cfg) bk_log2 = e->bk_log2_cfg;
     const u32 nb = 1u << bk_log2;
@@ -442,7 +445,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                                                           e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
                                                           hot_next, bs, e->hot_threshold,
                                                           e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 : nullptr);
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
+    if (e->timing) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
     u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
     if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
     if (n_wg > nb && nb >= 64) n_wg = nb;
@@ -450,13 +453,15 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
                                                   e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
                                                   (u32)e->h_limits.size(), now, d_verdict, d_first, bs, bs_next,
-                                                  f.h_st, hot_next, e->hot_threshold, e->dbg_vmask, e->d_bk_trace);
-    HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+                                                  f.h_st, (u32)(e->sub_seq + 1), hot_next, e->hot_threshold,
+                                                  e->dbg_vmask, e->d_bk_trace);
+    if (e->timing) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
     HIP_TRY(e, hipGetLastError());
     f.n = n;
     f.n_wg = n_wg;
     f.ntiles = ntiles;
-    f.timed = t;
+    f.timed = e->timing;
+    f.seq = (u32)(e->sub_seq + 1);
     e->inflight_hits += n;
     e->sub_seq++;
     return RL_OK;
@@ -466,7 +471,19 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 int collect_k1_bucketed(rl_engine* e) {
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
     rl_engine::Inflight& f = e->inflight[e->col_seq & 1u];
-    HIP_TRY(e, hipEventSynchronize(f.tev[4]));
+    {
+        // the batch's last workgroup stores its sequence number with the first 16 bytes of the status block
+        const volatile u32* done = &f.h_st->n_removed;
+        const auto t_start = std::chrono::steady_clock::now();
+        for (u64 spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != f.seq; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFFu) == 0xFFFFu) {
+                if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                    return fail(e, RL_ERR_DEVICE, "batch %u did not complete within 60 s", f.seq);
+                std::this_thread::yield();
+            }
+        }
+    }
     e->col_seq++;
     e->inflight_hits -= f.n;
     e->live += f.h_st->n_inserted;
@@ -482,7 +499,8 @@ int collect_k1_bucketed(rl_engine* e) {
     }
     if (f.timed) {
         float ms[4] = {0, 0, 0, 0};
-        for (int q = 0; q < 4; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], f.tev[q], f.tev[q + 1]));
+        HIP_TRY(e, hipEventSynchronize(f.tev[4]));
+        for (int q = f.timed == 1 ? 0 : 3; q < 4; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], f.tev[q], f.tev[q + 1]));
         e->ms_slot[RL_T_HIST] += ms[0];
         e->ms_slot[RL_T_SCAN] += ms[1];
         e->ms_slot[RL_T_SCATTER] += ms[2];
@@ -1274,7 +1292,8 @@ int32_t rl_unpermute_u8_device(rl_engine* e, const uint8_t* d_src, const uint32_
 int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    e->timing = enable != 0;
+    if (enable < 0 || enable > 2) return fail(e, RL_ERR_INVALID, "timing mode %d", enable);
+    e->timing = enable;
     return RL_OK;
 }
 

@@ -235,8 +235,9 @@ class Engine:
         self._check(self._lib.rl_unpermute_u8_device(self._h, d_src, d_perm, n, d_dst))
 
     # -- measurement -----------------------------------------------------------------------------
-    def kernel_timing(self, enable=True):
-        self._check(self._lib.rl_kernel_timing(self._h, int(bool(enable))))
+    def kernel_timing(self, mode=1):
+        """0 off, 1 events between all kernels of the hot path, 2 around k_bkt_apply only (rl_engine.h)."""
+        self._check(self._lib.rl_kernel_timing(self._h, int(mode)))
 
     TIMING_SLOTS = ("hist", "scan", "scatter", "apply", "legacy_probe", "legacy_decide", "legacy_ordered",
                     "legacy_commit")  # RL_T_* of include/rl_engine.h

@@ -46,75 +46,157 @@ def owner_mask(keys, hash_seed, world, rank):
     return owner_of_tensor(keys, hash_seed, world) == rank
 
 
+SLOTS = 3  # ingress slices in flight per rank (buffer sets)
+
+
 class HipLocal:
     """The three device-side operations of a shard, on the HIP engine (raw pointers).  The engine is
     put on torch's current stream, so its kernels, the RCCL collectives and torch's own ops are ordered
-    by the stream and none of the three operations blocks the host."""
+    by the stream and none of the three operations blocks the host.  One set of routing buffers per
+    slice in flight (ShardedEngine.submit / collect)."""
 
     def __init__(self, engine, device, max_local_hits, world):
         self.engine = engine
         self.device = device
-        self.sorted_hits = torch.empty((max_local_hits, 2), dtype=torch.int64, device=device)
-        self.perm = torch.empty(max_local_hits, dtype=torch.int32, device=device)
-        self.counts = torch.empty(world, dtype=torch.int32, device=device)
+        self.sorted_hits = [torch.empty((max_local_hits, 2), dtype=torch.int64, device=device) for _ in range(SLOTS)]
+        self.perm = [torch.empty(max_local_hits, dtype=torch.int32, device=device) for _ in range(SLOTS)]
         engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        self._pending = False
 
-    def partition(self, hits, world):
+    def partition(self, hits, world, slot, counts_out):
+        """Stable partition of `hits` by owner -> (sorted hits, permutation); hits per owner into counts_out."""
         n = hits.shape[0]
-        self.engine.route_partition_device(hits.data_ptr(), n, world, self.sorted_hits.data_ptr(),
-                                           self.perm.data_ptr(), self.counts.data_ptr())
-        return self.sorted_hits[:n], self.perm[:n], self.counts
+        self.engine.route_partition_device(hits.data_ptr(), n, world, self.sorted_hits[slot].data_ptr(),
+                                           self.perm[slot].data_ptr(), counts_out.data_ptr())
+        return self.sorted_hits[slot][:n], self.perm[slot][:n]
 
     def check(self, hits, n, now_us, verdict):
+        """Enqueue the local batch; -> True if finish() has something to wait for."""
         if n:
             self.engine.submit_device(hits.data_ptr(), n, now_us, verdict.data_ptr())
-            self._pending = True
+        return bool(n)
 
     def unpermute(self, src, perm, n, dst):
         self.engine.unpermute_u8_device(src.data_ptr(), perm.data_ptr(), n, dst.data_ptr())
 
     def finish(self):
-        """Status of the batch submitted by check() (raises the engine's error, if any)."""
-        if self._pending:
-            self._pending = False
-            self.engine.collect()
+        """Status of the OLDEST batch enqueued by check() (raises the engine's error, if any)."""
+        self.engine.collect()
+
+
+ROUTED, APPLIED, RETURNED = 1, 2, 3
 
 
 class ShardedEngine:
+    """submit() takes one ingress slice; collect() finishes the oldest one: its verdicts are then in
+    ingress order in its verdict_out.  A slice goes through three stages, each only ENQUEUED on the
+    stream (nothing here waits for the device except the size read, see below):
+
+        ROUTED    stable partition by owner, size exchange, sizes copied to pinned host memory
+        APPLIED   descriptor all-to-all (needs the sizes on the host), local check_and_update
+        RETURNED  verdict all-to-all back to the ingress ranks, un-permute to ingress order
+
+    Up to three slices are in flight, and submit() of slice i enqueues, in this order,
+        route(i),  return(i-2),  exchange+apply(i-1)
+    so the sizes of slice i-1 were copied long before the host needs them (their copy sits in front of
+    the local batch of slice i-2 in the stream): the host does not drain the device to read 2 x world
+    integers, and collect(i-2) leaves the local batch of slice i-1 queued behind it.  A blocking
+    check_and_update() is submit + collect on an empty pipeline.  Slices are applied in submission
+    order and every rank issues the same sequence of collectives."""
+
     def __init__(self, engine, group, device, max_local_hits, local=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.device = device
+        self.device = torch.device(device)
         self.local = local if local is not None else HipLocal(engine, device, max_local_hits, self.world)
         self.max_recv = getattr(engine, "max_batch_hits", None)
         cap = self.max_recv or 2 * max_local_hits
-        self._recv_hits = torch.empty((cap, 2), dtype=torch.int64, device=device)
-        self._recv_verdict = torch.empty(cap, dtype=torch.uint8, device=device)
-        self._sorted_verdict = torch.empty(max_local_hits, dtype=torch.uint8, device=device)
-        self._recv_counts = torch.empty(self.world, dtype=torch.int32, device=device)
+        dev = self.device
+        self._recv_hits = [torch.empty((cap, 2), dtype=torch.int64, device=dev) for _ in range(SLOTS)]
+        self._recv_verdict = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(SLOTS)]
+        self._sorted_verdict = [torch.empty(max_local_hits, dtype=torch.uint8, device=dev) for _ in range(SLOTS)]
+        # row 0: hits this rank sends to each owner, row 1: hits it receives from each rank
+        self._counts = [torch.empty((2, self.world), dtype=torch.int32, device=dev) for _ in range(SLOTS)]
+        self._on_gpu = dev.type == "cuda"
+        if self._on_gpu:
+            self._counts_host = [torch.empty((2, self.world), dtype=torch.int32, pin_memory=True) for _ in range(SLOTS)]
+            self._counts_ready = [torch.cuda.Event() for _ in range(SLOTS)]
+        self._pending = []  # oldest first: one dict per slice in flight
+        self._seq = 0
+
+    # -- the three stages of a slice ---------------------------------------------------------------
+    def _route(self, hits, now_us, verdict_out):
+        slot = self._seq % SLOTS
+        self._seq += 1
+        cnt = self._counts[slot]
+        sorted_hits, perm = self.local.partition(hits, self.world, slot, cnt[0])
+        dist.all_to_all_single(cnt[1], cnt[0], group=self.group)
+        if self._on_gpu:
+            self._counts_host[slot].copy_(cnt, non_blocking=True)
+            self._counts_ready[slot].record()
+        return {"slot": slot, "n": hits.shape[0], "now": now_us, "sorted": sorted_hits, "perm": perm,
+                "out": verdict_out, "stage": ROUTED, "n_recv": 0, "waits": False}
+
+    def _apply(self, p):
+        slot = p["slot"]
+        if self._on_gpu:
+            self._counts_ready[slot].synchronize()
+            send, recv = self._counts_host[slot].tolist()
+        else:
+            send, recv = self._counts[slot].tolist()
+        n_recv = sum(recv)
+        if n_recv > self._recv_hits[slot].shape[0]:
+            raise RuntimeError(f"rank {self.rank}: {n_recv} routed hits exceed the receive buffer "
+                               f"({self._recv_hits[slot].shape[0]}); raise max_batch_hits")
+        rh = self._recv_hits[slot][:n_recv]
+        dist.all_to_all_single(rh, p["sorted"], output_split_sizes=recv, input_split_sizes=send, group=self.group)
+        rv = self._recv_verdict[slot][:n_recv]
+        p["waits"] = bool(self.local.check(rh, n_recv, p["now"], rv))
+        p.update(send=send, recv=recv, n_recv=n_recv, rv=rv, stage=APPLIED)
+
+    def _return(self, p):
+        sv = self._sorted_verdict[p["slot"]][:p["n"]]
+        dist.all_to_all_single(sv, p["rv"], output_split_sizes=p["send"], input_split_sizes=p["recv"], group=self.group)
+        self.local.unpermute(sv, p["perm"], p["n"], p["out"])
+        p["stage"] = RETURNED
+
+    # -- the pipeline ---------------------------------------------------------------------------------
+    def submit(self, hits, now_us, verdict_out):
+        """hits: [n,2] int64 tensor laid out as rl_hit; verdict_out: uint8[n] (ingress order), valid after
+        the matching collect().  Both must stay alive and untouched until then."""
+        if len(self._pending) >= SLOTS:
+            raise RuntimeError(f"{SLOTS} slices are already in flight: collect() first")
+        older = list(self._pending)
+        self._pending.append(self._route(hits, now_us, verdict_out))
+        for p in older:
+            if p["stage"] == APPLIED:
+                self._return(p)
+        for p in older:
+            if p["stage"] == ROUTED:
+                self._apply(p)
+
+    def collect(self):
+        """Finish the oldest slice in flight: its verdicts are in its verdict_out (device-ordered on the
+        current stream).  -> hits this rank applied for it."""
+        if not self._pending:
+            raise RuntimeError("nothing in flight")
+        p = self._pending[0]
+        if p["stage"] == ROUTED:
+            self._apply(p)
+        if p["stage"] == APPLIED:
+            self._return(p)
+        self._pending.pop(0)
+        if p["waits"] and hasattr(self.local, "finish"):
+            self.local.finish()
+        return p["n_recv"]
+
+    @property
+    def in_flight(self):
+        return len(self._pending)
 
     def check_and_update(self, hits, now_us, verdict_out):
-        """hits: [n,2] int64 tensor laid out as rl_hit; verdict_out: uint8[n] (ingress order)."""
-        n = hits.shape[0]
-        sorted_hits, perm, counts = self.local.partition(hits, self.world)
-        # who sends how much to whom
-        dist.all_to_all_single(self._recv_counts, counts, group=self.group)
-        send = counts.tolist()
-        recv = self._recv_counts.tolist()
-        n_recv = sum(recv)
-        if n_recv > self._recv_hits.shape[0]:
-            raise RuntimeError(f"rank {self.rank}: {n_recv} routed hits exceed the receive buffer "
-                               f"({self._recv_hits.shape[0]}); raise max_batch_hits")
-        rh = self._recv_hits[:n_recv]
-        dist.all_to_all_single(rh, sorted_hits, output_split_sizes=recv, input_split_sizes=send, group=self.group)
-        rv = self._recv_verdict[:n_recv]
-        self.local.check(rh, n_recv, now_us, rv)
-        sv = self._sorted_verdict[:n]
-        dist.all_to_all_single(sv, rv, output_split_sizes=send, input_split_sizes=recv, group=self.group)
-        # the batch's status is read while the verdicts travel back; routing helpers do not block
-        if hasattr(self.local, "finish"):
-            self.local.finish()
-        self.local.unpermute(sv, perm, n, verdict_out)
-        return n_recv
+        """One slice, blocking until it is applied (submit + collect on an empty pipeline)."""
+        if self._pending:
+            raise RuntimeError("slices in flight: collect() them first")
+        self.submit(hits, now_us, verdict_out)
+        return self.collect()

@@ -27,7 +27,8 @@ def test_route_partition_is_a_stable_partition_by_owner(world, n):
     hits["delta"] = np.arange(n) % 7
     t = torch.from_numpy(hits.view(np.int64).reshape(-1, 2).copy()).to(dev)
     loc = HipLocal(eng, dev, n, world)
-    out, perm, counts = loc.partition(t, world)
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    out, perm = loc.partition(t, world, 0, counts)
     torch.cuda.synchronize()
     owners = owner_of_tensor(t[:, 0].cpu(), eng.hash_seed, world).numpy()
     want_perm = np.argsort(owners, kind="stable")
@@ -75,6 +76,24 @@ def test_sharded_engine_over_rccl_world_1():
             v, _, _, _ = orc.check_and_update(hits, now)
             assert np.array_equal(out.cpu().numpy(), v)
             now += 1000
+        # three slices in flight (routed / applied / returned): same sequential result
+        outs, want = [], []
+        for step in range(7):
+            hits = W.zipf_batch(5000, n - 17 * step, rng)
+            t = torch.from_numpy(hits.view(np.int64).reshape(-1, 2).copy()).to(dev)
+            outs.append((t, torch.empty(len(hits), dtype=torch.uint8, device=dev)))
+            sh.submit(t, now, outs[-1][1])
+            want.append(orc.check_and_update(hits, now)[0])
+            if sh.in_flight == 3:
+                assert sh.collect() == n - 17 * (step - 2)
+            now += 1000
+        with pytest.raises(RuntimeError):
+            sh.check_and_update(t, now, outs[-1][1])  # not on a busy pipeline
+        while sh.in_flight:
+            sh.collect()
+        torch.cuda.synchronize()
+        for step in range(7):
+            assert np.array_equal(outs[step][1].cpu().numpy(), want[step]), f"slice {step}"
         eng.close()
     finally:
         dist.destroy_process_group()

@@ -31,11 +31,11 @@ class OracleLocal:
         self.orc.set_limits(ROWS)
         self.world = world
 
-    def partition(self, hits, world):
+    def partition(self, hits, world, slot, counts_out):
         owners = owner_of_tensor(hits[:, 0], SEED, world).numpy()
         perm = np.argsort(owners, kind="stable")
-        counts = np.bincount(owners, minlength=world).astype(np.int32)
-        return hits[torch.from_numpy(perm)].contiguous(), torch.from_numpy(perm.astype(np.int32)), torch.from_numpy(counts)
+        counts_out.copy_(torch.from_numpy(np.bincount(owners, minlength=world).astype(np.int32)))
+        return hits[torch.from_numpy(perm)].contiguous(), torch.from_numpy(perm.astype(np.int32))
 
     def check(self, hits, n, now_us, verdict):
         if n == 0:
@@ -64,7 +64,7 @@ def _slices(world, steps, n):
     return out
 
 
-def _worker(rank, world, port, steps, n, q):
+def _worker(rank, world, port, steps, n, q, depth=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,12 +74,21 @@ def _worker(rank, world, port, steps, n, q):
         data = _slices(world, steps, n)
         verdicts = []
         now = W.NOW0_US
+        outs = []
         for s in range(steps):
             hits = torch.from_numpy(data[s][rank].view(np.int64).reshape(-1, 2).copy())
             out = torch.empty(n, dtype=torch.uint8)
-            sh.check_and_update(hits, now, out)
-            verdicts.append(out.numpy().copy())
+            outs.append(out)
+            if depth == 1:
+                sh.check_and_update(hits, now, out)
+            else:  # `depth` slices in flight
+                sh.submit(hits, now, out)
+                if sh.in_flight == depth:
+                    sh.collect()
             now += 400_000
+        while sh.in_flight:
+            sh.collect()
+        verdicts = [o.numpy().copy() for o in outs]
         # every key must live on exactly its owner
         for key in W.splitmix64(np.arange(97, dtype=np.uint64)):
             own = int(owner_of_tensor(torch.tensor([int(key)], dtype=torch.uint64).view(torch.int64), SEED, world)[0])
@@ -95,12 +104,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_sharded_path_matches_the_sequential_reference():
+@pytest.mark.parametrize("depth", [1, 2, 3], ids=["blocking", "two_in_flight", "three_in_flight"])
+def test_two_rank_sharded_path_matches_the_sequential_reference(depth):
     world, steps, n = 2, 6, 700
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, n, q, depth)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
