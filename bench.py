@@ -191,9 +191,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_keys_total = args.keys * world
-    # table sized for short probe chains, not for footprint: load <= 0.15 (10 M keys -> 2^26 cells = 4.3 GB
-    # of the 288 GB): a displaced key costs its workgroup a dependent HBM round trip
-    cap = 1 << (int(n_keys_total / world * 4.4 * args.cap_mult - 1).bit_length())
+    # table sized for short probe chains, not for footprint: load <= 0.075 (10 M keys -> 2^27 cells = 8.6 GB
+    # of the 288 GB): a displaced key costs its workgroup a dependent HBM round trip (DESIGN.md §3.1;
+    # measured: load 0.30 / 0.15 / 0.075 -> k_bkt_apply 66.9 / 62.0 / 58.3 us)
+    cap = 1 << (int(n_keys_total / world * 8.8 * args.cap_mult - 1).bit_length())
     max_batch = int(args.batch * 2) if sharded else args.batch
     eng = Engine(capacity_cells=cap, max_batch_hits=max_batch, device=local_rank)
     eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])

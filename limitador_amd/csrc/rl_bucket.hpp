@@ -209,11 +209,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     __syncthreads();
     RL_HSTAMP(2);
     u32 err = 0;
-    int hidx[PT_TILE / PT_BLOCK];
 #pragma unroll
     for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
         const u32 i = base + r * PT_BLOCK + tid;
-        hidx[r] = -1;
         if (i < n) {
             if ((h[r].limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
             else if (h[r].key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
@@ -225,32 +223,23 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
                 if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
             }
             const u64 hh = fmix64(h[r].key ^ seed);
-            hidx[r] = hot_lookup(s_hot_key, s_hot_idx, h[r].key, hh);
-            if (hidx[r] < 0) atomicAdd(&s_hist[bucket_of_hash(hh, bk_log2)], 1u);
+            const int hidx = hot_lookup(s_hot_key, s_hot_idx, h[r].key, hh);
+            if (hidx < 0) {
+                atomicAdd(&s_hist[bucket_of_hash(hh, bk_log2)], 1u);
+            } else {
+                // Only a count is needed here (the stable ranks are k_bkt_scatter's job), so the lanes of
+                // a wave that carry the same hot key simply queue up on its LDS counter — a few cycles
+                // per lane, far cheaper than finding each other with ballots.
+                atomicAdd(&s_hist[nb + hidx], 1u);
+                s_hlimit[hidx] = h[r].limit;  // any of the key's hits: k_bkt_scatter checks them against the cell
+                // extrema of the key's deltas: read first, so that only a new extreme is an atomic
+                const u32 d = h[r].delta;
+                if (d > s_dmax[hidx]) atomicMax(&s_dmax[hidx], d);
+                if (~d > s_ndmin[hidx]) atomicMax(&s_ndmin[hidx], ~d);
+            }
         }
     }
     RL_HSTAMP(3);
-    // Hot keys: many lanes of a wave carry the same key.  The lanes that share a key find each other
-    // with one ballot per index bit and their lowest lane adds the whole group to the count: one LDS
-    // atomic per distinct key per wave-step instead of one per hit.
-    const u64 lt = (1ull << (tid & 63u)) - 1ull;
-#pragma unroll
-    for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
-        const bool is_hot = hidx[r] >= 0;
-        const u64 valid = __ballot(is_hot);
-        if (!valid) continue;
-        const u64 m = match_digit(is_hot ? (u32)hidx[r] : 0u, 9u, valid);
-        if (!is_hot) continue;
-        const u32 d = h[r].delta;
-        const bool leader = (m & lt) == 0ull;
-        if (leader) {
-            atomicAdd(&s_hist[nb + hidx[r]], (u32)__popcll(m));
-            s_hlimit[hidx[r]] = h[r].limit;
-        }
-        // extrema of the key's deltas: read first, so that only a new extreme is an atomic
-        if (d > s_dmax[hidx[r]]) atomicMax(&s_dmax[hidx[r]], d);
-        if (~d > s_ndmin[hidx[r]]) atomicMax(&s_ndmin[hidx[r]], ~d);
-    }
     if (err) atomicOr(&st->err, err);
     RL_HSTAMP(4);
     __syncthreads();

@@ -384,7 +384,7 @@ int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
             for (u32 b = 0; b < tr.size() / 16; ++b)
                 if (tr[(size_t)b * 16 + 9]) ends.push_back({tr[(size_t)b * 16 + 9] - t_min, b});
             std::sort(ends.begin(), ends.end());
-            fprintf(stderr, " | end pct: p10=%.1f p50=%.1f p90=%.1f p99=%.1f max=%.1f | slowest:",
+            if (!ends.empty()) fprintf(stderr, " | end pct: p10=%.1f p50=%.1f p90=%.1f p99=%.1f max=%.1f | slowest:",
                     ends[ends.size() / 10].first * 0.01, ends[ends.size() / 2].first * 0.01,
                     ends[ends.size() * 9 / 10].first * 0.01, ends[ends.size() * 99 / 100].first * 0.01,
                     ends.back().first * 0.01);
