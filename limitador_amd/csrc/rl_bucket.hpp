@@ -45,7 +45,6 @@ constexpr int PT_WAVES = PT_BLOCK / 64;
 constexpr int PT_STEPS = 4;                   // 64-hit steps per wave
 constexpr int PT_WAVE_TILE = 64 * PT_STEPS;   // contiguous hits owned by one wave
 constexpr int PT_TILE = PT_WAVES * PT_WAVE_TILE;  // hits per workgroup (4096)
-constexpr u32 BK_BIG = 1024;                  // hash buckets at least this large are processed first
 constexpr int HOT_CHUNK = 1024;              // hits per work item of a hot bucket
 constexpr u32 HOT_PROMOTE = 160;              // hits in one batch that make (or keep) a key hot: the floor of the
                                               // threshold, which the host doubles while more keys qualify than fit
@@ -350,6 +349,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
     const u32 tid = threadIdx.x;
     // One extra workgroup prepares the hot keys' buckets for k_bkt_apply.
     if (blockIdx.x == ntiles) {
+        if (htrace && tid == 0) htrace[(size_t)2040 * 8] = wall_clock64();
         // ---- the hot keys of this batch: where their buckets are, the state of their cells before
         //      the batch, and how the bucket will be decided (apply_hot); next batch's hot set -------
         const u32 nb_ = 1u << bk_log2, nbt_ = nb_ + HOT_MAX;
@@ -371,6 +371,38 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         const bool refuse = st->err != 0;  // k_bkt_hist rejected the batch: empty ranges, nothing applied
         const u32 nh = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
         u32* s_nchunk = s_base + HOT_MAX;
+        {
+            // ranges[]: the hash buckets in the order k_bkt_apply's workgroups take them (workgroup w:
+            // entries w, w + G, ...), longest first in 64 size classes, so that every workgroup draws the
+            // same mix of long and short buckets (a bucket's time is its number of 512-hit rounds).
+            u32* s_cls = s_base + 2 * HOT_MAX;
+            u32* s_cls_lo = s_cls + 64;
+            if (tid < 64) s_cls[tid] = 0;
+            __syncthreads();
+            u32 cls[3], r[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                cls[q] = 63u - (c3[q] / 32u < 63u ? c3[q] / 32u : 63u);
+                r[q] = b0 + q < nb_ ? atomicAdd(&s_cls[cls[q]], 1u) : 0u;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                u32 inc = s_cls[tid];
+                const u32 own = inc;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const u32 o = __shfl_up(inc, off);
+                    if ((int)tid >= off) inc += o;
+                }
+                s_cls_lo[tid] = inc - own;
+            }
+            __syncthreads();
+            const u32 lo3[3] = {ex, ex + c3[0], ex + c3[0] + c3[1]};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (b0 + q < nb_)
+                    ranges[s_cls_lo[cls[q]] + r[q]] = refuse ? make_uint2(0, 0) : make_uint2(lo3[q], lo3[q] + c3[q]);
+        }
         if (tid == HOT_MAX) hot_param[HOT_MAX] = HotParam{};
         if (tid < HOT_MAX) {
             HotParam hp{};
@@ -416,6 +448,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
             for (u32 q = 0; q < tid; ++q) acc += s_nchunk[q];
             hot_param[tid].chunk0 = acc;
         }
+        if (htrace && tid == 0) htrace[(size_t)2040 * 8 + 1] = wall_clock64();
         return;
     }
     RL_HSTAMP(0);
@@ -442,21 +475,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (b0 + q < nbt) s_base[b0 + q] = lo[q] + hist[(size_t)blockIdx.x * (nbt + HOT_COLS) + b0 + q];
-        if (blockIdx.x == 0) {
-            u32 g[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) g[q] = (b0 + q < nb && c[q] >= BK_BIG) ? 1u : 0u;
-            u32 nbig;
-            u32 gx = block_excl_scan_1024(g[0] + g[1] + g[2], s_w, nbig);
-            const bool refuse = st->err != 0;  // k_bkt_hist rejected the batch: empty ranges, nothing applied
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const u32 b = b0 + q;
-                const uint2 r = refuse ? make_uint2(0, 0) : make_uint2(lo[q], lo[q] + c[q]);
-                if (b < nb) ranges[g[q] ? gx : nbig + (b - gx)] = r;
-                gx += g[q];
-            }
-        }
     }
     RL_HSTAMP(1);
     for (u32 b = tid; b < nbt; b += PT_BLOCK) {
@@ -1205,8 +1223,22 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     if (trace && tid == 0) trace[(size_t)blockIdx.x * 16 + 0] = wall_clock64();
     ApplyArgs A{table, log2cap, seed, b_hits, hits,  limits, n_limits, now,
                 verdict, first_limited, &bs->st, hot_next, hot_param, hot_threshold, vmask, trace};
+    auto first_n = [](uint2 r) { return (r.y - r.x) < (u32)AP_R ? (r.y - r.x) : (u32)AP_R; };
+    // Three input buffers used round-robin (bucket t decides from b[t % 3] while the lines of bucket
+    // t+1 land in b[(t+1) % 3] and the hits of bucket t+2 in b[(t+2) % 3]); the loop is unrolled by
+    // three so that no register that is the target of a load in flight ever has to be copied.
+    RoundIn b0, b1, b2;
+    {
+        // the first two buckets' hits are requested before anything else: they fly during the LDS set-up
+        const uint2 r0 = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
+        const uint2 r1 = 2 * G - 1 - blockIdx.x < nb ? ranges[2 * G - 1 - blockIdx.x] : make_uint2(0, 0);
+        round_load_hits(S, A, false, r0.x, first_n(r0), b0);
+        round_load_hits(S, A, false, r1.x, first_n(r1), b1);
+    }
     if (tid < AP_MAX_PER_WG + 4) {
-        const u32 k = blockIdx.x + tid * G;
+        // row `tid` of ranges[] (longest buckets first), rows taken alternately left-to-right and
+        // right-to-left: the workgroup that drew the longest bucket of one row draws the shortest of the next
+        const u32 k = tid * G + ((tid & 1u) ? G - 1 - blockIdx.x : blockIdx.x);
         s_ranges[tid] = (tid < AP_MAX_PER_WG && k < nb) ? ranges[k] : make_uint2(0, 0);
     }
     for (u32 q = tid; q < (u32)LIM_LDS && q < n_limits; q += AP_BLOCK) S.lim[q] = limits[q];
@@ -1226,16 +1258,9 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
         S.promote_ok = 1;
     }
     __syncthreads();
-    auto first_n = [](uint2 r) { return (r.y - r.x) < (u32)AP_R ? (r.y - r.x) : (u32)AP_R; };
-    // Three input buffers used round-robin (bucket t decides from b[t % 3] while the lines of bucket
-    // t+1 land in b[(t+1) % 3] and the hits of bucket t+2 in b[(t+2) % 3]); the loop is unrolled by
-    // three so that no register that is the target of a load in flight ever has to be copied.
-    RoundIn b0, b1, b2;
-    round_load_hits(S, A, false, s_ranges[0].x, first_n(s_ranges[0]), b0);
-    round_load_hits(S, A, false, s_ranges[1].x, first_n(s_ranges[1]), b1);
     round_load_lines(A, first_n(s_ranges[0]), b0);
     auto step = [&](u32 t, RoundIn& cur, RoundIn& nxt, RoundIn& nn) -> bool {
-        if (t >= (u32)AP_MAX_PER_WG || blockIdx.x + t * G >= nb) return false;
+        if (t >= (u32)AP_MAX_PER_WG || t * G >= nb) return false;
         const uint2 r_cur = s_ranges[t], r_nxt = s_ranges[t + 1], r_nn = s_ranges[t + 2];
         auto mid = [&] {
             round_load_lines(A, first_n(r_nxt), nxt);

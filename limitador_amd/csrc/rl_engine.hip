@@ -351,7 +351,12 @@ int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
                     if (r[0] < s0) s0 = r[0];
                     if (r[6] > s1) s1 = r[6];
                 }
-                fprintf(stderr, " | scatter: span=%.2f prologue=%.2f zero=%.2f steps=%.2f sync=%.2f prefix=%.2f write=%.2f",
+                u64 xb[2] = {0, 0};
+                HIP_TRY(e, hipMemcpy(xb, e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 + 2040 * 8, sizeof(xb),
+                                     hipMemcpyDeviceToHost));
+                fprintf(stderr, " | scatter: hot-param block %.2f..%.2f", (double)((int64_t)(xb[0] - s0)) * 0.01,
+                        (double)((int64_t)(xb[1] - s0)) * 0.01);
+                fprintf(stderr, " span=%.2f prologue=%.2f zero=%.2f steps=%.2f sync=%.2f prefix=%.2f write=%.2f",
                         (double)(s1 - s0) * 0.01, c[1] / ntiles * 0.01, c[2] / ntiles * 0.01, c[3] / ntiles * 0.01,
                         c[4] / ntiles * 0.01, c[5] / ntiles * 0.01, c[6] / ntiles * 0.01);
             }
