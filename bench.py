@@ -47,6 +47,9 @@ def parse():
                     help="batches in flight on one GPU: 2 = submit batch k+1 before collecting batch k "
                          "(rl_check_and_update_submit_device / _collect), 1 = one blocking call per batch; "
                          "the routed path keeps 3 ingress slices in flight at depth 2 (ShardedEngine)")
+    ap.add_argument("--timing-mode", type=int, default=3, choices=(0, 2, 3),
+                    help="HIP events in the timed region: 2 = around k_bkt_apply on every launch, 3 = on every "
+                         "fourth launch, 0 = none (roofline then comes from the breakdown pass)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the routed (all-to-all) data path even with one rank (exercises the N>1 code on one GPU)")
     return ap.parse_args()
@@ -278,7 +281,7 @@ def main():
     drain()
     kt_all = eng.kernel_timing_read(reset=True)
     # Timed region: events around the dominant kernel only (k_bkt_apply), for the roofline.
-    eng.kernel_timing(2)
+    eng.kernel_timing(args.timing_mode)
     denied = 0
     torch.cuda.synchronize()
     if sharded:
@@ -346,8 +349,9 @@ def main():
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_hit": ALGO_BYTES[dom], "hits_per_launch": hits_per_launch,
                          "avg_launch_ms": per.get(dom, 0.0),
-                         "timed_with": "HIP events around this kernel on every launch of the timed region"
-                         if dom in timed else "HIP events in the breakdown pass before the timed region"},
+                         "timed_with": (f"HIP events around this kernel on {kt['launches']} of the {args.steps} "
+                                        "launches of the timed region") if dom in timed
+                         else "HIP events in the breakdown pass before the timed region"},
             "pipeline": {"kernel_ms_per_batch": per, "device_ms_per_batch": pipe_ms,
                          "achieved_GBps_49B": ALGO_BYTES_TOTAL * hits_per_launch / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
                          "ordered_hits_per_batch": st["ordered_hits"] / max(1, st["batches"])},

@@ -267,7 +267,8 @@ int32_t rl_engine_set_stream(rl_engine *e, void *stream, int32_t external);
 /* HIP-event timing of the kernels of the single-counter hot path (events on the engine's stream):
  * enable = 0 off (no event is recorded at all: completion is a sequence word the last workgroup
  * stores into host-mapped memory), 1 every kernel (an event between any two kernels; each marker
- * leaves the device idle for ~5 us), 2 only the dominant kernel, k_bkt_apply.  rl_kernel_timing_read copies
+ * leaves the device idle for ~5 us), 2 only the dominant kernel, k_bkt_apply, 3 the same on every
+ * fourth batch (a sampled average that barely perturbs the pipeline).  rl_kernel_timing_read copies
  * the milliseconds accumulated per slot since the last reset into ms[RL_TIMING_SLOTS] and the number
  * of timed batches into *launches. */
 enum {

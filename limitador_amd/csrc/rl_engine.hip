@@ -131,7 +131,7 @@ struct rl_engine {
 
     rl_stats_t stats{};
 
-    int timing = 0;  // 0 off, 1 every kernel of the hot path, 2 k_bkt_apply only
+    int timing = 0;  // 0 off, 1 every kernel of the hot path, 2 k_bkt_apply only, 3 k_bkt_apply of every 4th batch
     hipEvent_t ev[8]{};
     double ms_slot[RL_TIMING_SLOTS]{};
     u64 timed_launches = 0;
@@ -450,7 +450,8 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                                                           e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
                                                           hot_next, bs, e->hot_threshold,
                                                           e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 : nullptr);
-    if (e->timing) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
+    const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
+    if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
     u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
     if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
     if (n_wg > nb && nb >= 64) n_wg = nb;
@@ -460,12 +461,12 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                                                   (u32)e->h_limits.size(), now, d_verdict, d_first, bs, bs_next,
                                                   f.h_st, (u32)(e->sub_seq + 1), hot_next, e->hot_threshold,
                                                   e->dbg_vmask, e->d_bk_trace);
-    if (e->timing) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+    if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
     HIP_TRY(e, hipGetLastError());
     f.n = n;
     f.n_wg = n_wg;
     f.ntiles = ntiles;
-    f.timed = e->timing;
+    f.timed = t_apply ? (e->timing == 1 ? 1 : 2) : 0;
     f.seq = (u32)(e->sub_seq + 1);
     e->inflight_hits += n;
     e->sub_seq++;
@@ -1297,7 +1298,7 @@ int32_t rl_unpermute_u8_device(rl_engine* e, const uint8_t* d_src, const uint32_
 int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (enable < 0 || enable > 2) return fail(e, RL_ERR_INVALID, "timing mode %d", enable);
+    if (enable < 0 || enable > 3) return fail(e, RL_ERR_INVALID, "timing mode %d", enable);
     e->timing = enable;
     return RL_OK;
 }

@@ -236,7 +236,8 @@ class Engine:
 
     # -- measurement -----------------------------------------------------------------------------
     def kernel_timing(self, mode=1):
-        """0 off, 1 events between all kernels of the hot path, 2 around k_bkt_apply only (rl_engine.h)."""
+        """0 off, 1 events between all kernels of the hot path, 2 around k_bkt_apply only, 3 around
+        k_bkt_apply of every fourth batch (rl_engine.h)."""
         self._check(self._lib.rl_kernel_timing(self._h, int(mode)))
 
     TIMING_SLOTS = ("hist", "scan", "scatter", "apply", "legacy_probe", "legacy_decide", "legacy_ordered",
