@@ -224,6 +224,16 @@ class Engine:
         return {"verdict": verdict, "limited_limit": limited, "req_off": req_off, "hits": hits[:n],
                 "remaining": rem[:n] if load_counters else None, "expires_in_us": exp[:n] if load_counters else None}
 
+    def match_and_check_device(self, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, n_req, now_us,
+                               d_verdict, d_limited_limit, load_counters=False):
+        """rl_match_and_check_batch_device: request arrays, verdict and limited_limit are device pointers.
+        -> number of counters derived."""
+        n_hits = C.c_uint32(0)
+        self._check(self._lib.rl_match_and_check_batch_device(
+            self._h, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, int(n_req), int(now_us),
+            int(bool(load_counters)), d_verdict, d_limited_limit, C.byref(n_hits)))
+        return n_hits.value
+
     # -- routing helpers (multi-GPU) -------------------------------------------------------------
     def owner_of(self, key, world):
         return self._lib.rl_owner_of(int(key), self.hash_seed, int(world))

@@ -16,6 +16,12 @@ that order restricted to its keys, so the sharded result is bit-identical to the
 reference applied to the concatenated slices (tests/test_sharded_gloo.py checks this with two
 gloo processes; the driver runs the RCCL path on 2/4/8 GPUs).
 
+Requests that touch several counters (multi-limit namespaces: all-or-nothing across the request's
+counters, in_memory.rs:141-153) are routed by NAMESPACE instead (ShardedRequestEngine below): every
+limit and counter of a namespace lives on one GPU, so a request's counters are never split and the
+owner runs the on-device matcher + the general resolver on "the global trace restricted to its
+namespaces".
+
 This is a different job from the reference's only multi-node mechanism (CRDT replication over
 gRPC, limitador/src/storage/distributed/): that one replicates counters, this one routes requests.
 """
@@ -200,3 +206,94 @@ class ShardedEngine:
             raise RuntimeError("slices in flight: collect() them first")
         self.submit(hits, now_us, verdict_out)
         return self.collect()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Requests with several counters: sharded by namespace
+# ---------------------------------------------------------------------------------------------------
+def namespace_owner(ns, world):
+    """Owner shard of a namespace id (int tensor) — a 32-bit mix, the same on every rank."""
+    x = (ns.to(torch.int64) * 0x9E3779B1) & 0xFFFFFFFF
+    x = x ^ (x >> 15)
+    x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+    x = x ^ (x >> 13)
+    return (x * world) >> 32
+
+
+class HipMatchLocal:
+    """Owner-side work on the HIP engine: counters_that_apply + check_and_update for the received
+    requests (rl_match_and_check_batch_device).  The engine's match table holds ALL limits; a rank
+    only ever receives requests of the namespaces it owns."""
+
+    def __init__(self, engine, device):
+        self.engine = engine
+        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def match_and_check(self, ns, ent_off, ent_key, ent_val, delta, now_us, verdict, limited):
+        n = ns.shape[0]
+        if n:
+            self.engine.match_and_check_device(ns.data_ptr(), ent_off.data_ptr(), ent_key.data_ptr(),
+                                               ent_val.data_ptr(), delta.data_ptr(), n, now_us,
+                                               verdict.data_ptr(), limited.data_ptr())
+
+
+class ShardedRequestEngine:
+    """check(): one ingress slice of dictionary-encoded requests (namespace id, delta, CSR descriptor
+    entries — the input of rl_match_and_check_batch) -> verdict and limited-limit id per request, in
+    ingress order.  Requests travel to the owner of their namespace (stable partition, so the owner
+    sees "rank 0's slice, then rank 1's, ..." restricted to its namespaces = the sequential reference on
+    the concatenated slices), are matched and decided there, and the two result words travel back.
+    Blocking: the general resolver behind the matcher has host round trips of its own."""
+
+    def __init__(self, group, device, local):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device)
+        self.local = local
+
+    def check(self, req_ns, ent_off, ent_key, ent_val, req_delta, now_us):
+        """int32 tensors on self.device: req_ns[n], req_delta[n], ent_off[n+1], ent_key[m], ent_val[m]."""
+        dev, world = self.device, self.world
+        n = req_ns.shape[0]
+        i64 = torch.int64
+        owner = namespace_owner(req_ns, world)
+        perm = torch.sort(owner, stable=True).indices
+        ne = (ent_off[1:] - ent_off[:-1]).to(i64)
+        send_cnt = torch.zeros((world, 2), dtype=i64, device=dev)
+        send_cnt[:, 0] = torch.bincount(owner, minlength=world)
+        send_cnt[:, 1].index_add_(0, owner, ne)
+        recv_cnt = torch.empty_like(send_cnt)
+        dist.all_to_all_single(recv_cnt, send_cnt, group=self.group)
+        # the slice in owner order: request words, then every request's entries, contiguous again
+        ne_s = ne[perm]
+        reqs = torch.stack([req_ns.to(torch.int32), req_delta.to(torch.int32), ne.to(torch.int32)], dim=1)[perm].contiguous()
+        m = int(ent_key.shape[0])
+        first_s = ent_off[:-1].to(i64)[perm] - (torch.cumsum(ne_s, 0) - ne_s)
+        src = torch.repeat_interleave(first_s, ne_s, output_size=m) + torch.arange(m, dtype=i64, device=dev)
+        ents = torch.stack([ent_key.to(torch.int32), ent_val.to(torch.int32)], dim=1)[src].contiguous()
+        sc, rc = send_cnt.tolist(), recv_cnt.tolist()
+        send_req, send_ent = [c[0] for c in sc], [c[1] for c in sc]
+        recv_req, recv_ent = [c[0] for c in rc], [c[1] for c in rc]
+        n_recv, m_recv = sum(recv_req), sum(recv_ent)
+        r_reqs = torch.empty((n_recv, 3), dtype=torch.int32, device=dev)
+        r_ents = torch.empty((m_recv, 2), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(r_reqs, reqs, output_split_sizes=recv_req, input_split_sizes=send_req, group=self.group)
+        dist.all_to_all_single(r_ents, ents, output_split_sizes=recv_ent, input_split_sizes=send_ent, group=self.group)
+        # owner side
+        r_off = torch.zeros(n_recv + 1, dtype=torch.int32, device=dev)
+        r_off[1:] = torch.cumsum(r_reqs[:, 2], 0)
+        r_verdict = torch.zeros(n_recv, dtype=torch.uint8, device=dev)
+        r_limited = torch.full((n_recv,), -1, dtype=torch.int32, device=dev)
+        self.local.match_and_check(r_reqs[:, 0].contiguous(), r_off, r_ents[:, 0].contiguous(),
+                                   r_ents[:, 1].contiguous(), r_reqs[:, 1].contiguous(), now_us, r_verdict, r_limited)
+        # back to the ingress ranks, then to ingress order
+        s_verdict = torch.empty(n, dtype=torch.uint8, device=dev)
+        s_limited = torch.empty(n, dtype=torch.int32, device=dev)
+        dist.all_to_all_single(s_verdict, r_verdict, output_split_sizes=send_req, input_split_sizes=recv_req, group=self.group)
+        dist.all_to_all_single(s_limited, r_limited, output_split_sizes=send_req, input_split_sizes=recv_req, group=self.group)
+        verdict = torch.empty_like(s_verdict)
+        limited = torch.empty_like(s_limited)
+        verdict[perm] = s_verdict
+        limited[perm] = s_limited
+        return verdict, limited

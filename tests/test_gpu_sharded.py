@@ -97,3 +97,52 @@ def test_sharded_engine_over_rccl_world_1():
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_namespace_sharded_requests_over_rccl_world_1():
+    """ShardedRequestEngine on the HIP engine (device matcher + general resolver behind RCCL with one
+    rank) against the id-level CPU matcher + the oracle, multi-counter requests included."""
+    import torch.distributed as dist
+    from helpers.match_cpu import (Dictionary, compile_rows, limited_limit, match_key, match_requests,
+                                   random_limits, random_requests)
+    from limitador_amd.engine import Engine
+    from limitador_amd.sharded import HipMatchLocal, ShardedRequestEngine
+    from limitador_amd.wire import RL_SIMPLE
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(17)
+        namespaces = [f"ns{i}" for i in range(5)]
+        limits = random_limits(rng, namespaces)
+        key_id, val_id = Dictionary(), Dictionary()
+        rows, conds, ns_id = compile_rows(limits, key_id, val_id)
+        eng = Engine(capacity_cells=1 << 16, max_batch_hits=1 << 16)
+        eng.set_limits([(l.max_value, l.seconds) for l in limits])
+        eng.set_match_table(rows, conds, len(ns_id.ids))
+        orc = oracle.OracleStorage()
+        orc.set_limits([(l.max_value, l.seconds) for l in limits])
+        for i, l in enumerate(limits):
+            if not l.variables:
+                eng.add_counter(i | RL_SIMPLE, match_key(i, []))
+                orc.add_counter(i | RL_SIMPLE, match_key(i, []))
+        sh = ShardedRequestEngine(dist.group.WORLD, dev, HipMatchLocal(eng, dev))
+        now = W.NOW0_US
+        for step in range(4):
+            _c, req_ns, ent_off, ent_key, ent_val, delta = random_requests(rng, 3000 + step, namespaces, ns_id, key_id, val_id)
+            t = [torch.from_numpy(a.astype(np.int32)).to(dev) for a in (req_ns, ent_off, ent_key, ent_val, delta)]
+            v, lim = sh.check(*t, now)
+            torch.cuda.synchronize()
+            hits, off = match_requests(rows, conds, req_ns, ent_off, ent_key, ent_val, delta)
+            wv, wf, _r, _e = orc.check_and_update(hits, now, req_off=off)
+            assert np.array_equal(v.cpu().numpy(), wv), f"step {step}"
+            assert np.array_equal(lim.cpu().numpy(), limited_limit(wf, hits)), f"step {step}"
+            now += 400_000
+        eng.close()
+    finally:
+        dist.destroy_process_group()
