@@ -189,6 +189,11 @@ int32_t rl_clear(rl_engine *e);
 int32_t rl_sweep_expired(rl_engine *e, uint64_t now_us, uint64_t *n_removed);
 /* Force a compaction (rehash of live cells into a fresh table). */
 int32_t rl_compact(rl_engine *e);
+/* Rehash the live cells into a table of capacity_cells (rounded up to a power of two, >= 1024): how a
+ * caller answers RL_ERR_TABLE_FULL — or shrinks after a sweep — without losing a counter.  Refused
+ * (RL_ERR_INVALID) if the live cells would fill the new table beyond one half.  Old and new table are
+ * both resident while it runs. */
+int32_t rl_resize(rl_engine *e, uint64_t capacity_cells);
 /* Snapshot: bulk insert / overwrite cells, and dump every live cell (raw value/expiry). */
 int32_t rl_load_cells(rl_engine *e, const rl_cell_row *rows, uint64_t n);
 int32_t rl_load_cells_device(rl_engine *e, const rl_cell_row *d_rows, uint64_t n);

@@ -207,17 +207,25 @@ int check_room(rl_engine* e, u64 incoming) {
     return RL_OK;
 }
 
-int do_compact(rl_engine* e) {
+// Rehash the live cells into a fresh table of 2^new_log2cap cells (0: same size — a compaction).
+int do_compact(rl_engine* e, u32 new_log2cap = 0) {
+    if (!new_log2cap) new_log2cap = e->log2cap;
     Cell* fresh = nullptr;
-    int rc = alloc_table(e, e->cap, &fresh);
+    int rc = alloc_table(e, 1ull << new_log2cap, &fresh);
     if (rc) return rc;
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-    k_rehash<<<2048, 256, 0, e->stream>>>(e->table, e->cap, fresh, e->log2cap, e->seed, e->d_status);
+    k_rehash<<<2048, 256, 0, e->stream>>>(e->table, e->cap, fresh, new_log2cap, e->seed, e->d_status);
     HIP_TRY(e, hipGetLastError());
     rc = read_status(e);
-    if (rc) return rc;
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
     HIP_TRY(e, hipFree(e->table));
     e->table = fresh;
+    e->log2cap = new_log2cap;
+    e->cap = 1ull << new_log2cap;
+    e->stats.capacity_cells = e->cap;
     e->live = e->h_status->n_inserted;
     e->tombs = 0;
     e->stats.rebuilds++;
@@ -1088,6 +1096,19 @@ int32_t rl_compact(rl_engine* e) {
     if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     HIP_TRY(e, hipSetDevice(e->device));
     return do_compact(e);
+}
+
+int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const u32 lg = ceil_log2(capacity_cells < 1024 ? 1024 : capacity_cells);
+    if (lg > 31) return fail(e, RL_ERR_INVALID, "capacity %llu beyond 2^31 cells", (unsigned long long)capacity_cells);
+    if (e->live > (1ull << lg) / 2)
+        return fail(e, RL_ERR_INVALID, "%llu live cells would fill a %llu-cell table beyond one half",
+                    (unsigned long long)e->live, (unsigned long long)(1ull << lg));
+    return do_compact(e, lg);
 }
 
 int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n) {

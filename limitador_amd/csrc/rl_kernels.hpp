@@ -570,6 +570,7 @@ __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u6
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u32 mask = (1u << dst_log2cap) - 1u;
+    u32 moved = 0;
     for (u64 s = gid; s < src_cap; s += stride) {
         const uint4* p = reinterpret_cast<const uint4*>(&src[s]);
         const uint4 a = p[0];
@@ -583,12 +584,20 @@ __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u6
                 dst[slot].value = ((u64)a.w << 32) | a.z;
                 dst[slot].expiry = ((u64)b.y << 32) | b.x;
                 dst[slot].limit = b.z;
-                atomicAdd(&st->n_inserted, 1u);
+                ++moved;
                 break;
             }
             slot = (slot + 1) & mask;
         }
     }
+    // one atomic per workgroup (same-address atomics serialise at ~30 ns each)
+    __shared__ u32 s_moved;
+    if (threadIdx.x == 0) s_moved = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) moved += __shfl_down(moved, off);
+    if ((threadIdx.x & 63u) == 0 && moved) atomicAdd(&s_moved, moved);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_moved) atomicAdd(&st->n_inserted, s_moved);
 }
 
 }  // namespace rl

@@ -173,6 +173,10 @@ class Engine:
     def compact(self):
         self._check(self._lib.rl_compact(self._h))
 
+    def resize(self, capacity_cells):
+        """Rehash into a table of capacity_cells (rounded up to a power of two)."""
+        self._check(self._lib.rl_resize(self._h, int(capacity_cells)))
+
     def load_cells(self, rows):
         rows = np.ascontiguousarray(rows, dtype=CELL_ROW_DTYPE)
         self._check(self._lib.rl_load_cells(self._h, _ptr(rows), rows.shape[0]))

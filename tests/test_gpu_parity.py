@@ -479,3 +479,42 @@ def test_config5_shape_multi_namespace_trace_replay(make_engine):
         if step % 2:
             assert eng.sweep_expired(now) == orc.sweep_expired(now)
     assert_same_state(eng, orc, n_simple_expected=8)
+
+
+def test_resize_answers_table_full_without_losing_a_counter(make_engine):
+    """rl_resize: a table past its occupancy bound is grown in place (rehash into a larger one), every
+    counter keeps its value and window; shrinking below twice the live cells is refused."""
+    from limitador_amd.engine import EngineError
+
+    rng = np.random.default_rng(23)
+    eng, orc = pair(make_engine, [(7, 60), (3, 10)], simple_keys=[(1, 9_000_001)], capacity_cells=4096,
+                    max_batch_hits=4096)
+    keys = W.splitmix64(np.arange(1, 3301, dtype=np.uint64))
+
+    def batch(lo, hi):
+        h = np.empty(hi - lo, dtype=HIT_DTYPE)
+        h["key"], h["limit"], h["delta"] = keys[lo:hi], 0, rng.integers(1, 4, size=hi - lo)
+        return h
+
+    run_both(eng, orc, batch(0, 1400), NOW)
+    run_both(eng, orc, batch(700, 2800), NOW + 1)
+    run_both(eng, orc, batch(2600, 3200), NOW + 2)  # 3201 live cells of 4096: past 3/4
+    with pytest.raises(EngineError) as e:
+        eng.check_and_update(batch(3200, 3300), NOW + 3)  # refused up front, nothing applied
+    assert e.value.code == -4
+    before = np.sort(eng.dump_cells(), order="key")
+    eng.resize(1 << 14)
+    assert eng.stats()["capacity_cells"] == 1 << 14
+    assert np.array_equal(before, np.sort(eng.dump_cells(), order="key"))
+    run_both(eng, orc, batch(3200, 3300), NOW + 3)
+    run_both(eng, orc, batch(0, 3300), NOW + 4)
+    h = np.zeros(1, dtype=HIT_DTYPE)
+    h[0] = (9_000_001, 1 | RL_SIMPLE, 1)
+    run_both(eng, orc, h, NOW + 5)
+    with pytest.raises(EngineError) as e:
+        eng.resize(4096)  # 3301 live cells > 4096 / 2
+    assert e.value.code == -1
+    eng.resize(8192)  # shrinking is fine while the table stays at most half full
+    assert eng.stats()["capacity_cells"] == 8192
+    run_both(eng, orc, batch(100, 2700), NOW + 61 * SEC)  # every window has rolled over
+    assert_same_state(eng, orc, n_simple_expected=1)
