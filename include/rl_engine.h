@@ -58,6 +58,10 @@ typedef enum {
 #define RL_SIMPLE 0x80000000u
 #define RL_LIMIT_ID(x) ((x) & 0x7FFFFFFFu)
 
+/* rl_config.flags: double the table (rl_resize) instead of answering RL_ERR_TABLE_FULL when a call
+ * finds it past its occupancy bound — only possible while no batch is in flight. */
+#define RL_CFG_AUTO_GROW 1u
+
 typedef struct {
     int32_t device;          /* HIP device ordinal */
     uint32_t max_batch_hits; /* largest n_hits one call may carry */
@@ -65,7 +69,7 @@ typedef struct {
                                 by capacity/2 (RL_ERR_TABLE_FULL beyond).  Replaces moka's
                                 `cache_size` (in_memory.rs:205-212) but never evicts silently. */
     uint32_t max_limits;     /* rows of the limit table */
-    uint32_t reserved;
+    uint32_t flags;          /* RL_CFG_* */
     uint64_t hash_seed;
 } rl_config;
 

@@ -46,7 +46,7 @@ def _sig(lib, name, restype, argtypes):
 
 class RlConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch_hits", C.c_uint32), ("capacity_cells", C.c_uint64),
-                ("max_limits", C.c_uint32), ("reserved", C.c_uint32), ("hash_seed", C.c_uint64)]
+                ("max_limits", C.c_uint32), ("flags", C.c_uint32), ("hash_seed", C.c_uint64)]
 
 
 class RlStats(C.Structure):

@@ -41,6 +41,7 @@ int GpuCounterStorage::create(uint64_t capacity_cells, uint32_t max_batch_hits, 
     cfg.max_batch_hits = max_batch_hits;
     cfg.capacity_cells = capacity_cells;
     cfg.max_limits = 4096;
+    cfg.flags = RL_CFG_AUTO_GROW;  // the reference's storage never refuses a counter: grow, do not fail
     cfg.hash_seed = 0x9E3779B97F4A7C15ull;
     rl_engine* e = nullptr;
     const int rc = rl_engine_create(&cfg, &e);

@@ -108,6 +108,7 @@ struct rl_engine {
     HotParam* d_hot_param = nullptr;
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
+    bool auto_grow = false;  // RL_CFG_AUTO_GROW
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
     BHit* d_bk_hits = nullptr;
@@ -193,22 +194,46 @@ int alloc_table(rl_engine* e, u64 cap, Cell** out) {
     return RL_OK;
 }
 
+int do_compact(rl_engine* e, u32 new_log2cap);
+
+// With RL_CFG_AUTO_GROW: double the table (rehash) instead of refusing — possible only while no batch
+// is in flight.  -> true if the table was grown and the caller should look again.
+bool grow_instead(rl_engine* e, int* rc) {
+    if (!e->auto_grow || e->sub_seq != e->col_seq || e->log2cap >= 31) return false;
+    *rc = do_compact(e, e->log2cap + 1);
+    return *rc == RL_OK;
+}
+
 int check_room(rl_engine* e, u64 incoming) {
     // Linear probing stays short while (live + tombstones) <= 3/4 capacity.  Refuse new work once
     // the table is past that, and refuse a batch that could not fit even if every hit were a new
     // key; in between, the probe loop's own bound reports RL_ERR_TABLE_FULL if it ever runs out.
+    for (int rc = RL_OK;;) {
+        const u64 used = e->live + e->tombs;
+        // (auto-grow: room for every incoming hit to be a new key, so that no batch can fill the table
+        // half-way through — the one failure that leaves a batch partially applied)
+        const bool grow_now = e->auto_grow && used + incoming > e->cap - e->cap / 4;
+        if (!grow_now &&
+            !(used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap))
+            return RL_OK;
+        if (grow_instead(e, &rc)) continue;
+        if (grow_now && !rc && !(used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap))
+            return RL_OK;  // could not grow right now (a batch is in flight): the plain bound still holds
+        if (rc) return rc;
+        break;
+    }
     const u64 used = e->live + e->tombs;
-    if (used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap)
+    {
         return fail(e, RL_ERR_TABLE_FULL,
                     "table past 75%% occupancy (live=%llu tombstones=%llu incoming<=%llu capacity=%llu): "
                     "sweep, compact or create a larger engine",
                     (unsigned long long)e->live, (unsigned long long)e->tombs,
                     (unsigned long long)incoming, (unsigned long long)e->cap);
-    return RL_OK;
+    }
 }
 
 // Rehash the live cells into a fresh table of 2^new_log2cap cells (0: same size — a compaction).
-int do_compact(rl_engine* e, u32 new_log2cap = 0) {
+int do_compact(rl_engine* e, u32 new_log2cap) {
     if (!new_log2cap) new_log2cap = e->log2cap;
     Cell* fresh = nullptr;
     int rc = alloc_table(e, 1ull << new_log2cap, &fresh);
@@ -424,11 +449,13 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     // k_bkt_apply commits as it goes, so a table that fills up mid-batch (RL_ERR_TABLE_FULL from the
     // probe loop) leaves the batch partially applied; keep a margin so that only a batch bringing
     // more than capacity/4 NEW keys into an almost full table can get there.
-    {
+    for (;;) {
         const u64 inc0 = (u64)n + e->inflight_hits;
         const u64 used = e->live + e->tombs, inc = inc0 < e->cap / 4 ? inc0 : e->cap / 4;
-        if (used + inc > e->cap - e->cap / 16)
-            return fail(e, RL_ERR_TABLE_FULL,
+        if (used + inc <= e->cap - e->cap / 16) break;
+        if (grow_instead(e, &rc)) continue;
+        if (rc) return rc;
+        return fail(e, RL_ERR_TABLE_FULL,
                         "batch of %u hits could push the table past 15/16 occupancy (live=%llu tombstones=%llu "
                         "capacity=%llu): sweep, compact or create a larger engine",
                         n, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
@@ -544,7 +571,7 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
     // The resolver creates the cells of every counter it sees and drops the ones no request reached
     // (tombstones): compact when they pile up, before they stretch the probe chains.
     if (e->tombs > e->cap / 8) {
-        const int crc = do_compact(e);
+        const int crc = do_compact(e, 0);
         if (crc) return crc;
     }
     int rc = check_room(e, n_hits);
@@ -701,6 +728,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (!e) return RL_ERR_NOMEM;
     e->device = cfg->device;
     e->seed = cfg->hash_seed;
+    e->auto_grow = (cfg->flags & RL_CFG_AUTO_GROW) != 0;
     e->max_batch = cfg->max_batch_hits ? cfg->max_batch_hits : (1u << 20);
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
@@ -1086,7 +1114,7 @@ int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
     int rc = scan_locked<SCAN_SWEEP>(e, 0, now_us, nullptr, 0, nullptr);
     if (rc) return rc;
     if (n_removed) *n_removed = before - e->live;
-    if (e->tombs > e->cap / 8) return do_compact(e);
+    if (e->tombs > e->cap / 8) return do_compact(e, 0);
     return RL_OK;
 }
 
@@ -1095,7 +1123,7 @@ int32_t rl_compact(rl_engine* e) {
     std::lock_guard<std::mutex> g(e->mu);
     if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     HIP_TRY(e, hipSetDevice(e->device));
-    return do_compact(e);
+    return do_compact(e, 0);
 }
 
 int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {

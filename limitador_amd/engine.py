@@ -36,10 +36,10 @@ class Engine:
     """One counter table on one MI355X (InMemoryStorage::new, in_memory.rs:205-212)."""
 
     def __init__(self, capacity_cells, max_batch_hits=1 << 20, max_limits=1024, device=0,
-                 hash_seed=0x9E3779B97F4A7C15):
+                 hash_seed=0x9E3779B97F4A7C15, auto_grow=False):
         self._lib = _lib.load()
         cfg = _lib.RlConfig(device=device, max_batch_hits=max_batch_hits, capacity_cells=capacity_cells,
-                            max_limits=max_limits, reserved=0, hash_seed=hash_seed)
+                            max_limits=max_limits, flags=1 if auto_grow else 0, hash_seed=hash_seed)
         h = C.c_void_p()
         rc = self._lib.rl_engine_create(C.byref(cfg), C.byref(h))
         if rc != RL_OK:

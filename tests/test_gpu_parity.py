@@ -518,3 +518,19 @@ def test_resize_answers_table_full_without_losing_a_counter(make_engine):
     assert eng.stats()["capacity_cells"] == 8192
     run_both(eng, orc, batch(100, 2700), NOW + 61 * SEC)  # every window has rolled over
     assert_same_state(eng, orc, n_simple_expected=1)
+
+
+def test_auto_grow_doubles_the_table_instead_of_refusing(make_engine):
+    rng = np.random.default_rng(29)
+    eng, orc = pair(make_engine, [(5, 60), (2, 1)], capacity_cells=1024, max_batch_hits=4096, auto_grow=True)
+    keys = W.splitmix64(np.arange(1, 20_001, dtype=np.uint64))
+    now = NOW
+    for step in range(12):
+        idx = rng.integers(0, min(20_000, 2000 * (step + 1)), size=3000)
+        h = np.empty(3000, dtype=HIT_DTYPE)
+        h["key"], h["limit"], h["delta"] = keys[idx], (idx % 2).astype(np.uint32), rng.integers(0, 3, size=3000)
+        run_both(eng, orc, h, now)
+        now += int(rng.integers(0, SEC))
+    st = eng.stats()
+    assert st["capacity_cells"] >= 32768 and st["rebuilds"] >= 5
+    assert_same_state(eng, orc)
