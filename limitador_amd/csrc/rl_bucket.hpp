@@ -1268,7 +1268,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
         };
         if (r_cur.x != r_cur.y) apply_bucket(S, A, r_cur.x, r_cur.y, cur, mid);
         else mid();
-        if (trace && tid == 0) {
+        if (trace && tid == 0 && r_cur.x != r_cur.y) {
             trace[(size_t)blockIdx.x * 16 + 10] = r_cur.y - r_cur.x;
             trace[(size_t)blockIdx.x * 16 + 15] += ((u64)1 << 32) + (r_cur.y - r_cur.x);
         }
@@ -1280,7 +1280,10 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
         if (!step(t + 2, b2, b0, b1)) break;
     }
     // k_bkt_hist refused the batch: the hot ranges are empty too, nothing is applied
-    apply_hot(S, A, blockIdx.x, G);
+    // (workers in reverse: the low workgroups drew the longest hash buckets — some of them a bucket
+    // beyond one round — and the hot chunks are dealt from worker 0 up, so the extra chunk of an uneven
+    // deal goes to the workgroups that finish their buckets first)
+    apply_hot(S, A, G - 1 - blockIdx.x, G);
     RL_STAMP(14);
     __syncthreads();
     if (tid == 0) {

@@ -346,7 +346,7 @@ int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
         u64 longest = 0, longest_n = 0;
         for (u32 b = 0; b < tr.size() / 16; ++b) {
             const u64* r = &tr[(size_t)b * 16];
-            if (r[9] == 0 || r[10] == 0) continue;
+            if (r[9] == 0) continue;
             ++used;
             if (r[0] < t_min) t_min = r[0];
             if (r[9] > t_max) t_max = r[9];
@@ -426,6 +426,21 @@ int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
                     ends[ends.size() / 10].first * 0.01, ends[ends.size() / 2].first * 0.01,
                     ends[ends.size() * 9 / 10].first * 0.01, ends[ends.size() * 99 / 100].first * 0.01,
                     ends.back().first * 0.01);
+            {  // mean end per 32 consecutive workgroups (the order buckets were dealt in)
+                fprintf(stderr, " | end by wg/32:");
+                const size_t nwg = tr.size() / 16;
+                for (size_t g0 = 0; g0 < nwg; g0 += 32) {
+                    double a = 0;
+                    u32 c = 0;
+                    for (size_t b = g0; b < g0 + 32 && b < nwg; ++b)
+                        if (tr[b * 16 + 9]) {
+                            a += (double)(tr[b * 16 + 9] - t_min) * 0.01;
+                            ++c;
+                        }
+                    fprintf(stderr, " %.1f", c ? a / c : 0.0);
+                }
+                fprintf(stderr, " |");
+            }
             for (size_t q = ends.size() >= 4 ? ends.size() - 4 : 0; q < ends.size(); ++q) {
                 const u64* r = &tr[(size_t)ends[q].second * 16];
                 fprintf(stderr, " [wg%u end=%.1f buckets=%llu hits=%llu]", ends[q].second, ends[q].first * 0.01,
