@@ -188,6 +188,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     do {                                                                                       \
         if (htrace && threadIdx.x == 0) htrace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
     } while (0)
+    // the same tile -> XCD assignment as k_bkt_scatter (see there): the tile this workgroup streams now
+    // is re-read from the same XCD's L2 by the scatter pass
+    u32 tile;
+    {
+        const u32 x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = ntiles >> 3, rem = ntiles & 7u;
+        tile = x * per + (x < rem ? x : rem) + j;
+    }
     RL_HSTAMP(0);
     const u32 nb = 1u << bk_log2;
     const u32 nbt = nb + HOT_MAX;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
         s_dmax[tid] = 0;
         s_ndmin[tid] = 0;
     }
-    const u32 base = blockIdx.x * PT_TILE;
+    const u32 base = tile * PT_TILE;
     Hit h[PT_TILE / PT_BLOCK];
 #pragma unroll
     for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     RL_HSTAMP(4);
     __syncthreads();
     RL_HSTAMP(5);
-    u32* row = hist + (size_t)blockIdx.x * (nbt + HOT_COLS);
+    u32* row = hist + (size_t)tile * (nbt + HOT_COLS);
     for (u32 b = tid; b < nbt; b += PT_BLOCK) row[b] = s_hist[b];
     if (tid < HOT_MAX) {
         const bool any = s_hist[nb + tid] != 0;
