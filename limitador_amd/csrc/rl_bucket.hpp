@@ -42,9 +42,10 @@ constexpr int HOT_COLS = 3 * HOT_MAX;         // per tile and hot key: largest d
 constexpr int ROW_MAX = BKT_MAX + HOT_COLS;   // columns of one tile's row of the histogram matrix
 constexpr int PT_BLOCK = 1024;                // 16 waves per workgroup
 constexpr int PT_WAVES = PT_BLOCK / 64;
-constexpr int PT_STEPS = 4;                   // 64-hit steps per wave
-constexpr int PT_WAVE_TILE = 64 * PT_STEPS;   // contiguous hits owned by one wave
-constexpr int PT_TILE = PT_WAVES * PT_WAVE_TILE;  // hits per workgroup (4096)
+constexpr int PT_STEPS = 4;                   // 64-hit steps per wave (large batches)
+constexpr int PT_TILE = PT_BLOCK * PT_STEPS;  // hits per workgroup (4096)
+constexpr int PT_TILE_SMALL = PT_BLOCK;       // small batches: one step per wave, four times the workgroups
+constexpr u32 PT_SMALL_MAX_TILES = 256;       // ... as long as that is at most one workgroup per CU
 constexpr int HOT_CHUNK = 1024;              // hits per work item of a hot bucket
 constexpr u32 HOT_PROMOTE = 160;              // hits in one batch that make (or keep) a key hot: the floor of the
                                               // threshold, which the host doubles while more keys qualify than fit
@@ -172,6 +173,7 @@ __device__ __forceinline__ u64 match_digit(u32 d, u32 nbits, u64 valid) {
 // when the batch is malformed: limit id range, reserved keys, and (in_memory.rs:106-107) a
 // simple counter must already have its cell.
 // ---------------------------------------------------------------------------------------------
+template <int STEPS>
 __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ table, u32 log2cap,
                                                        u64 seed, const Hit* __restrict__ hits, u32 n,
                                                        const LimitDev* __restrict__ limits,
@@ -203,10 +205,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
         s_dmax[tid] = 0;
         s_ndmin[tid] = 0;
     }
-    const u32 base = tile * PT_TILE;
-    Hit h[PT_TILE / PT_BLOCK];
+    const u32 base = tile * (PT_BLOCK * STEPS);
+    Hit h[STEPS];
 #pragma unroll
-    for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
+    for (int r = 0; r < STEPS; ++r) {
         const u32 i = base + r * PT_BLOCK + tid;
         if (i < n) h[r] = load_hit(hits, i);
     }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     RL_HSTAMP(2);
     u32 err = 0;
 #pragma unroll
-    for (int r = 0; r < PT_TILE / PT_BLOCK; ++r) {
+    for (int r = 0; r < STEPS; ++r) {
         const u32 i = base + r * PT_BLOCK + tid;
         if (i < n) {
             if ((h[r].limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
@@ -336,6 +338,7 @@ __device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* s_w, u32& total)
 // in 64-hit steps in trace order; the rank of a hit inside (wave, bucket) comes from a
 // wave-private LDS counter plus its position among the lanes of the step that share the bucket.
 // ---------------------------------------------------------------------------------------------
+template <int STEPS>
 __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict__ hits, u32 n, u64 seed,
                                                           u32 bk_log2, const u32* __restrict__ hist,
                                                           const u32* __restrict__ total,
@@ -471,10 +474,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
     const u32 lane = tid & 63u, w = tid >> 6;
     const u32 nb = 1u << bk_log2;
     const u32 nbt = nb + HOT_MAX;
-    const u32 wbase = tile * PT_TILE + w * PT_WAVE_TILE;
-    uint4 raw[PT_STEPS];
+    const u32 wbase = tile * (PT_BLOCK * STEPS) + w * (64 * STEPS);
+    uint4 raw[STEPS];
 #pragma unroll
-    for (int u = 0; u < PT_STEPS; ++u) {
+    for (int u = 0; u < STEPS; ++u) {
         const u32 i = wbase + u * 64 + lane;
         if (i < n) raw[u] = *reinterpret_cast<const uint4*>(hits + i);
     }
@@ -499,11 +502,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
     }
     __syncthreads();
     RL_HSTAMP(2);
-    unsigned short rank[PT_STEPS];
-    unsigned short dig[PT_STEPS];
+    unsigned short rank[STEPS];
+    unsigned short dig[STEPS];
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int u = 0; u < PT_STEPS; ++u) {
+    for (int u = 0; u < STEPS; ++u) {
         const u32 i = wbase + u * 64 + lane;
         const bool ok = i < n;
         const u64 valid = __ballot(ok);
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
     __syncthreads();
     RL_HSTAMP(5);
 #pragma unroll
-    for (int u = 0; u < PT_STEPS; ++u) {
+    for (int u = 0; u < STEPS; ++u) {
         const u32 i = wbase + u * 64 + lane;
         if (i < n) {
             const u32 d = dig[u];

@@ -480,7 +480,9 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     u32 bk_log2 = ceil_log2(cdiv(n, 384));
     if (bk_log2 > e->bk_log2_cfg) bk_log2 = e->bk_log2_cfg;
     const u32 nb = 1u << bk_log2;
-    const u32 ntiles = cdiv(n, PT_TILE);
+    // small batches: quarter-size tiles, so that the two partition passes still spread over the CUs
+    const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
+    const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
     const u32 nbt = nb + HOT_MAX;
     BatchScratch* bs = e->d_bs + e->bs_cur;
     BatchScratch* bs_next = e->d_bs + (e->bs_cur ^ 1u);
@@ -489,13 +491,15 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     HotSet* hot_next = e->d_hot + (e->hot_cur ^ 1u);
     e->hot_cur ^= 1u;
     if (t) HIP_TRY(e, hipEventRecord(f.tev[0], e->stream));
-    k_bkt_hist<<<ntiles, PT_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits,
+    auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
+    hist_k<<<ntiles, PT_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits,
                                                    (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot,
                                                    e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 : nullptr);
     if (t) HIP_TRY(e, hipEventRecord(f.tev[1], e->stream));
     k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     if (t) HIP_TRY(e, hipEventRecord(f.tev[2], e->stream));
-    k_bkt_scatter<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
+    auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
+    scatter_k<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
                                                           hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
                                                           e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
                                                           hot_next, bs, e->hot_threshold,
@@ -800,7 +804,10 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_bs, 2 * sizeof(BatchScratch));
     if (hipMemset(e->d_bs, 0, 2 * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_total, sizeof(unsigned long long));
-    e->bk_tiles_max = cdiv(mb, PT_TILE) + 1;
+    {
+        const u32 big = cdiv(mb, PT_TILE), sm = cdiv(mb, PT_TILE_SMALL) < PT_SMALL_MAX_TILES ? cdiv(mb, PT_TILE_SMALL) : PT_SMALL_MAX_TILES;
+        e->bk_tiles_max = (big > sm ? big : sm) + 1;
+    }
     ALLOC(e->d_bk_hist, (size_t)ROW_MAX * e->bk_tiles_max * sizeof(u32));
     ALLOC(e->d_bk_total, (size_t)ROW_MAX * sizeof(u32));
     ALLOC(e->d_bk_ranges, (size_t)BK_MAX * sizeof(uint2));

@@ -181,10 +181,12 @@ def test_limit_tables_larger_than_the_lds_copy_take_the_first_generation_path(ma
     assert eng.stats()["ordered_batches"] > 0  # the legacy pipeline ran
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 383, 385, 511, 513, 1025, 4097, 8191])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 383, 385, 511, 513, 1023, 1024, 1025, 2049, 4097, 8191,
+                               262_144, 262_145, 266_241])  # 1024-hit tiles up to 256 of them, then 4096-hit tiles
 def test_batch_sizes_around_the_tile_and_round_boundaries(make_engine, n):
     rng = np.random.default_rng(n)
-    eng, orc = pair(make_engine, [(3, 60), (1, 0)])
+    eng, orc = pair(make_engine, [(3, 60), (1, 0)], capacity_cells=1 << 16 if n < 100_000 else 1 << 19,
+                    max_batch_hits=max(n, 8192))
     keys = W.splitmix64(rng.integers(0, max(2, n // 3), size=n).astype(np.uint64))
     hits = make_hits(keys, (keys % np.uint64(2)).astype(np.uint32), rng.integers(0, 3, size=n))
     run_both(eng, orc, hits, NOW)
