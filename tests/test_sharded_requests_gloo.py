@@ -127,3 +127,35 @@ def test_two_rank_namespace_sharded_requests_match_the_sequential_reference():
         limited_total += int(v.sum())
         now += 300_000
     assert limited_total > 0 and multi > 100
+
+
+def test_empty_and_entryless_slices_single_rank():
+    """Edge cases of the request router in one process (gloo, world 1): an empty slice, requests
+    without descriptor entries, and a slice whose requests all miss every limit."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        limits, rows, conds, ns_id, key_id, val_id = _setup()
+        local = OracleMatchLocal(limits, rows, conds)
+        sh = ShardedRequestEngine(dist.group.WORLD, torch.device("cpu"), local)
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32)  # noqa: E731
+        v, lim = sh.check(i32([]), i32([0]), i32([]), i32([]), i32([]), W.NOW0_US)
+        assert v.numel() == 0 and lim.numel() == 0
+        # three requests, none carries an entry: only condition-less simple limits can apply
+        ns = [ns_id(NAMESPACES[0]), ns_id(NAMESPACES[1]), ns_id(NAMESPACES[0])]
+        v, lim = sh.check(i32(ns), i32([0, 0, 0, 0]), i32([]), i32([]), i32([1, 1, 1]), W.NOW0_US)
+        hits, off = match_requests(rows, conds, np.array(ns), np.array([0, 0, 0, 0]), np.array([]), np.array([]),
+                                   np.array([1, 1, 1]))
+        ref = _storage(limits, rows)
+        wv, wf, _r, _e = ref.check_and_update(hits, W.NOW0_US, req_off=off)
+        assert np.array_equal(v.numpy(), wv) and np.array_equal(lim.numpy(), limited_limit(wf, hits))
+        # a namespace id no limit knows: nothing applies, every request passes
+        v, lim = sh.check(i32([len(ns_id.ids)] * 4), i32([0, 1, 2, 3, 4]), i32([0, 0, 0, 0]), i32([1, 1, 1, 1]),
+                          i32([1, 1, 1, 1]), W.NOW0_US)
+        assert not v.any() and (lim == -1).all()
+    finally:
+        dist.destroy_process_group()
