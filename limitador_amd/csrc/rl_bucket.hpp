@@ -773,18 +773,22 @@ __device__ __forceinline__ void apply_round_core(ApplyLds& S, const ApplyArgs& A
     }
     RL_STAMP(2);
     // ---- A: find or claim the key's LDS cell, add this hit to the round's aggregates ------------
+    // Staged over the thread's hits: the same LDS operation is issued for every hit before any result
+    // is consumed, so the round trips of independent hits overlap instead of queueing behind each other.
     u32 n_new = 0;
+    u64 first_key[AP_HPT];
 #pragma unroll
     for (int u = 0; u < AP_HPT; ++u) {
-        const u32 p = tid * AP_HPT + u;
-        if (!ok[u]) {
-            S.h_ent[p] = (unsigned short)ENT_NONE;
-            continue;
-        }
-        u32 e = (u32)(fmix64(h[u].key ^ A.seed) >> 20) & (ENT_N - 1);
+        ent[u] = ok[u] ? (u32)(fmix64(h[u].key ^ A.seed) >> 20) & (ENT_N - 1) : 0u;
+        first_key[u] = ok[u] ? S.key[ent[u]] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        if (!ok[u]) continue;
+        u32 e = ent[u];
+        u64 prev = first_key[u];
         for (;;) {
             // a plain read first: the lanes that repeat a key already in LDS do not queue up on a CAS
-            u64 prev = S.key[e];
             if (prev == TAG_EMPTY) prev = atomicCAS(&S.key[e], TAG_EMPTY, h[u].key);
             if (prev == TAG_EMPTY) {
                 creator[u] = true;
@@ -793,14 +797,34 @@ __device__ __forceinline__ void apply_round_core(ApplyLds& S, const ApplyArgs& A
             }
             if (prev == h[u].key) break;
             e = (e + 1) & (ENT_N - 1);
+            prev = S.key[e];
         }
         ent[u] = e;
-        atomicAdd(&S.rsum[e], (u64)h[u].delta);
-        if (h[u].delta > S.dmax[e]) atomicMax(&S.dmax[e], h[u].delta);  // only a new maximum is an atomic
-        leader[u] = atomicAdd(&S.cnt4[e], 1ull << (16 * w)) == 0ull;
-        S.h_ent[p] = (unsigned short)e;
+    }
+    u32 seen_dmax[AP_HPT];
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        const u32 p = tid * AP_HPT + u;
+        if (!ok[u]) {
+            S.h_ent[p] = (unsigned short)ENT_NONE;
+            seen_dmax[u] = 0;
+            continue;
+        }
+        atomicAdd(&S.rsum[ent[u]], (u64)h[u].delta);
+        seen_dmax[u] = S.dmax[ent[u]];
+        S.h_ent[p] = (unsigned short)ent[u];
         S.h_delta[p] = h[u].delta;
     }
+    u64 before[AP_HPT];
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) {
+        before[u] = 1;
+        if (!ok[u]) continue;
+        if (h[u].delta > seen_dmax[u]) atomicMax(&S.dmax[ent[u]], h[u].delta);  // only a new maximum is an atomic
+        before[u] = atomicAdd(&S.cnt4[ent[u]], 1ull << (16 * w));
+    }
+#pragma unroll
+    for (int u = 0; u < AP_HPT; ++u) leader[u] = ok[u] && before[u] == 0ull;
     for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off);
     if (lane == 0 && n_new) atomicAdd(&S.n_ent, n_new);
     RL_STAMP(3);
