@@ -1246,6 +1246,37 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
     }
 }
 
+// End of a batch's last kernel, one thread per workgroup: the last workgroup out hands the status
+// block to the host and resets the other scratch.  No agent-scope fence (a release would write the
+// XCD's whole L2 back, once per workgroup): everything the last workgroup reads was written with
+// device-scope atomics, and this workgroup's own contribution has RETURNED before its ticket is taken.
+__device__ __forceinline__ void apply_finish(ApplyLds& S, BatchScratch* bs, BatchScratch* bs_next, Status* host_status,
+                                             u32 done_seq, u32 G, const u32* hot_n_ptr, u32 hot_n) {
+    u32 dep = 0;
+    if (S.n_created) dep = atomicAdd(&bs->st.n_inserted, S.n_created);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(dep) : "memory");
+    if (atomicAdd(&bs->ticket, 1u) == G - 1) {
+        Status out{};
+        out.err = __hip_atomic_load(&bs->st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out.n_inserted = __hip_atomic_load(&bs->st.n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out.pad[0] = __hip_atomic_load(&bs->st.pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out.pad[1] = __hip_atomic_load(&bs->st.pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // keys that qualified for the next hot set (read here: every other workgroup's promotions are done)
+        out.pad[2] = hot_n_ptr ? __hip_atomic_load(hot_n_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hot_n;
+        // The host does not wait on an event (a marker in the queue costs ~5 us of idle device per
+        // batch): it polls the first 16 bytes of the status block, written LAST and as ONE store, so
+        // `n_removed == done_seq` means the whole block of this batch is there.
+        out.n_removed = done_seq;
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* hp = reinterpret_cast<u32x4*>(host_status);
+        const u32* o = reinterpret_cast<const u32*>(&out);
+        for (int q = 1; q < 4; ++q) hp[q] = u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, hp);
+        *bs_next = BatchScratch{};
+    }
+}
+
 // Persistent workgroups: workgroup g replays hash buckets g, g + G, g + 2G, ... (ranges[] is in
 // processing order, large buckets first) and then takes its share of the hot-bucket chunks.  The
 // inputs of the next bucket (its first AP_R hits, then their home cells) are requested while the
@@ -1329,34 +1360,69 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     apply_hot(S, A, G - 1 - blockIdx.x, G);
     RL_STAMP(14);
     __syncthreads();
-    if (tid == 0) {
-        // Last workgroup out: hand the status block to the host and reset the other scratch.  No
-        // agent-scope fence (a release would write the XCD's whole L2 back, once per workgroup):
-        // everything the last workgroup reads was written with device-scope atomics, and this
-        // workgroup's own contribution has RETURNED before its ticket is taken.
-        u32 dep = 0;
-        if (S.n_created) dep = atomicAdd(&bs->st.n_inserted, S.n_created);
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(dep) : "memory");
-        if (atomicAdd(&bs->ticket, 1u) == G - 1) {
-            Status out{};
-            out.err = __hip_atomic_load(&bs->st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.n_inserted = __hip_atomic_load(&bs->st.n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.pad[0] = __hip_atomic_load(&bs->st.pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.pad[1] = __hip_atomic_load(&bs->st.pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.pad[2] = __hip_atomic_load(&hot_next->n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // keys that qualified
-            // The host does not wait on an event (a marker in the queue costs ~5 us of idle device per
-            // batch): it polls the first 16 bytes of the status block, written LAST and as ONE store, so
-            // `n_removed == done_seq` means the whole block of this batch is there.
-            out.n_removed = done_seq;
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            u32x4* hp = reinterpret_cast<u32x4*>(host_status);
-            const u32* o = reinterpret_cast<const u32*>(&out);
-            for (int q = 1; q < 4; ++q) hp[q] = u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, hp);
-            *bs_next = BatchScratch{};
-        }
+    if (tid == 0) apply_finish(S, bs, bs_next, host_status, done_seq, G, &hot_next->n, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_tiny: a batch of at most TINY_MAX hits IS one bucket — it is in trace order already — so one
+// workgroup validates it, rewrites it as BHit records and replays it with the bucket code: one
+// launch instead of four (a 1..1024-hit call: ~30 us -> ~15 us).  The hot set is left as it is.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 TINY_MAX = 1024;
+
+__global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
+    Cell* __restrict__ table, u32 log2cap, u64 seed, const Hit* __restrict__ hits, u32 n, BHit* __restrict__ b_hits,
+    const LimitDev* __restrict__ limits, u32 n_limits, u64 now, uint8_t* __restrict__ verdict,
+    int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_next, Status* host_status, u32 done_seq,
+    u32 hot_n_report, u32 vmask) {
+    __shared__ ApplyLds S;
+    __shared__ u32 s_err;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) s_err = 0;
+    for (u32 q = tid; q < (u32)LIM_LDS && q < n_limits; q += AP_BLOCK) S.lim[q] = limits[q];
+    for (u32 e = tid; e < ENT_N; e += AP_BLOCK) {
+        S.key[e] = TAG_EMPTY;
+        S.rsum[e] = 0;
+        S.cnt4[e] = 0;
+        S.dmax[e] = 0;
+        S.flags[e] = 0;
     }
+    if (tid == 0) {
+        S.n_created = 0;
+        S.promote_ok = 0;  // no promotion from here: the hot set belongs to the partitioned path
+    }
+    __syncthreads();
+    // the checks of k_bkt_hist (nothing is applied to a malformed batch) + the record format of k_bkt_scatter
+    u32 err = 0;
+    for (u32 i = tid; i < n; i += AP_BLOCK) {
+        const Hit h = load_hit(hits, i);
+        if ((h.limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
+        else if (h.key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
+        else if (h.limit & SIMPLE_FLAG) {  // in_memory.rs:106-107: a simple counter must pre-exist
+            u32 dummy = 0;
+            u32 slot = slot_of(h.key, seed, log2cap);
+            slot = probe_from<PM_LOOKUP>(table, log2cap, slot, table[slot].tag, h.key, h.limit, limits, 0ull, &bs->st,
+                                         dummy);
+            if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
+        }
+        *reinterpret_cast<uint4*>(b_hits + i) =
+            make_uint4((u32)h.key, (u32)(h.key >> 32), h.delta, i | (limit_fold(h.limit) << 24));
+    }
+    if (err) atomicOr(&s_err, err);
+    __syncthreads();  // (also orders the b_hits stores before this workgroup's loads of them)
+    if (s_err) {
+        if (tid == 0) atomicOr(&bs->st.err, s_err);
+    } else if (n) {
+        ApplyArgs A{table, log2cap, seed, b_hits, hits, limits, n_limits, now, verdict, first_limited, &bs->st,
+                    nullptr, nullptr, 0xFFFFFFFFu, vmask, nullptr};
+        RoundIn in0;
+        const u32 n0 = n < (u32)AP_R ? n : (u32)AP_R;
+        round_load_hits(S, A, false, 0, n0, in0);
+        round_load_lines(A, n0, in0);
+        apply_bucket(S, A, 0, n, in0, [] {});
+    }
+    __syncthreads();
+    if (tid == 0) apply_finish(S, bs, bs_next, host_status, done_seq, 1u, nullptr, hot_n_report);
 }
 
 }  // namespace rl

@@ -109,6 +109,7 @@ struct rl_engine {
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
+    u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
     BHit* d_bk_hits = nullptr;
@@ -477,6 +478,31 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     }
     rl_engine::Inflight& f = e->inflight[e->sub_seq & 1u];
     const bool t = e->timing == 1;  // events between all four kernels
+    if (n <= e->tiny_max) {
+        // one launch: the batch is one bucket (k_bkt_tiny); the hot set is left untouched
+        BatchScratch* tbs = e->d_bs + e->bs_cur;
+        BatchScratch* tbs_next = e->d_bs + (e->bs_cur ^ 1u);
+        e->bs_cur ^= 1u;
+        const bool t_tiny = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
+        if (t_tiny) {
+            if (e->timing == 1)
+                for (int q = 0; q < 3; ++q) HIP_TRY(e, hipEventRecord(f.tev[q], e->stream));
+            HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
+        }
+        k_bkt_tiny<<<1, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_bk_hits, e->d_limits,
+                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, tbs, tbs_next, f.h_st,
+                                                  (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2, e->dbg_vmask);
+        if (t_tiny) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+        HIP_TRY(e, hipGetLastError());
+        f.n = n;
+        f.n_wg = 1;
+        f.ntiles = 0;
+        f.timed = t_tiny ? (e->timing == 1 ? 1 : 2) : 0;
+        f.seq = (u32)(e->sub_seq + 1);
+        e->inflight_hits += n;
+        e->sub_seq++;
+        return RL_OK;
+    }
     u32 bk_log2 = ceil_log2(cdiv(n, 384));
     if (bk_log2 > e->bk_log2_cfg) bk_log2 = e->bk_log2_cfg;
     const u32 nb = 1u << bk_log2;
@@ -553,7 +579,7 @@ int collect_k1_bucketed(rl_engine* e) {
     e->stats.batches++;
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
-    if (e->d_bk_trace && getenv("RL_APPLY_TRACE_DUMP")) {
+    if (e->d_bk_trace && f.ntiles && getenv("RL_APPLY_TRACE_DUMP")) {
         const int rc = dump_apply_trace(e, f.n_wg, f.ntiles, f.h_st);
         if (rc) return rc;
     }
@@ -753,6 +779,10 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     if (const char* v = getenv("RL_K1_PATH")) e->legacy_k1 = strcmp(v, "legacy") == 0;
     if (const char* v = getenv("RL_DEBUG_VMASK")) e->dbg_vmask = (u32)strtoul(v, nullptr, 0);
+    if (const char* v = getenv("RL_TINY_MAX")) {
+        const long b = strtol(v, nullptr, 10);
+        if (b >= 0 && b <= (long)TINY_MAX) e->tiny_max = (u32)b;
+    }
     if (const char* v = getenv("RL_BUCKET_LOG2")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= BK_LOG2_MAX) e->bk_log2_cfg = (u32)b;

@@ -1,0 +1,42 @@
+"""Latency of ONE blocking rl_check_and_update_batch_device call as a function of the batch size (device
+buffers, table of 1 M keys): what a micro-batching transport pays per batch.  Needs a MI355X."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from limitador_amd import workloads as W  # noqa: E402
+from limitador_amd.engine import Engine  # noqa: E402
+
+dev = torch.device("cuda", 0)
+n_keys = 1_000_000
+eng = Engine(capacity_cells=1 << 24, max_batch_hits=1 << 20)
+eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+eng.load_cells(W.universe_rows(n_keys))
+rng = np.random.default_rng(W.SEED)
+out = {}
+now = W.NOW0_US
+for n in (1, 256, 4096, 16384, 65536, 262144, 1 << 20):
+    reps = 200 if n <= 65536 else 50
+    batches = [torch.from_numpy(W.uniform_batch(n_keys, n, rng).view(np.int64).reshape(-1, 2).copy()).to(dev)
+               for _ in range(8)]
+    verdict = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for i in range(10):
+        eng.check_and_update_device(batches[i & 7].data_ptr(), n, now, verdict.data_ptr())
+        now += 1000
+    t = []
+    for i in range(reps):
+        t0 = time.perf_counter()
+        eng.check_and_update_device(batches[i & 7].data_ptr(), n, now, verdict.data_ptr())
+        t.append(time.perf_counter() - t0)
+        now += 1000
+    t = np.sort(np.array(t)) * 1e6
+    out[n] = {"p50_us": round(float(t[len(t) // 2]), 1), "p99_us": round(float(t[int(len(t) * 0.99)]), 1),
+              "decisions_per_s_at_p50": round(n / (t[len(t) // 2] * 1e-6))}
+print(json.dumps(out))
+eng.close()

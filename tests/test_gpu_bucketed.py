@@ -183,7 +183,14 @@ def test_limit_tables_larger_than_the_lds_copy_take_the_first_generation_path(ma
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 383, 385, 511, 513, 1023, 1024, 1025, 2049, 4097, 8191,
                                262_144, 262_145, 266_241])  # 1024-hit tiles up to 256 of them, then 4096-hit tiles
-def test_batch_sizes_around_the_tile_and_round_boundaries(make_engine, n):
+@pytest.mark.parametrize("one_launch", [True, False], ids=["tiny_path_on", "partitioned_only"])
+def test_batch_sizes_around_the_tile_and_round_boundaries(make_engine, monkeypatch, n, one_launch):
+    """Batches of at most 1024 hits take the one-launch path (k_bkt_tiny); RL_TINY_MAX=0 sends them
+    through the four partitioned kernels like every larger batch."""
+    if not one_launch:
+        if n > 1025:
+            pytest.skip("the one-launch path only concerns batches of up to 1024 hits")
+        monkeypatch.setenv("RL_TINY_MAX", "0")
     rng = np.random.default_rng(n)
     eng, orc = pair(make_engine, [(3, 60), (1, 0)], capacity_cells=1 << 16 if n < 100_000 else 1 << 19,
                     max_batch_hits=max(n, 8192))

@@ -73,8 +73,13 @@ def run_both(eng, orc, hits, now, **kw):
 
 
 # ---- the reference's own scenarios, through the engine ---------------------------------------
+@pytest.mark.parametrize("one_launch", [True, False], ids=["tiny_path_on", "partitioned_only"])
 @pytest.mark.parametrize("scenario", scenarios.ALL, ids=lambda f: f.__name__)
-def test_reference_scenarios_on_engine(make_engine, scenario):
+def test_reference_scenarios_on_engine(make_engine, monkeypatch, scenario, one_launch):
+    """Per-request calls (1..k hits) take the one-launch path (k_bkt_tiny) by default; RL_TINY_MAX=0
+    runs the same scenarios through the four partitioned kernels."""
+    if not one_launch:
+        monkeypatch.setenv("RL_TINY_MAX", "0")
     scenario(TestsLimiter(make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)))
 
 
