@@ -109,6 +109,8 @@ struct rl_engine {
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
+    u32 gen_tiny_max = 64;   // general form: requests of up to this many hits in all take k_gen_tiny (same switch)
+    u32 gen_seq = 0;
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
@@ -621,6 +623,36 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
     }
     int rc = check_room(e, n_hits);
     if (rc) return rc;
+    if (n_hits && n_hits <= e->gen_tiny_max && n_req <= 4096) {
+        // A few requests (the per-request calls of the trait): one workgroup, one launch (k_gen_tiny),
+        // completion through a sequence word in the host-mapped status block.
+        const u32 seq = ++e->gen_seq ? e->gen_seq : ++e->gen_seq;
+        __atomic_store_n(&e->h_status->n_removed, 0u, __ATOMIC_RELEASE);
+        k_gen_tiny<<<1, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n_hits, d_req_off, n_req, e->d_limits,
+                                             (u32)e->h_limits.size(), now, load ? 1 : 0, d_verdict, d_first,
+                                             load ? d_rem : nullptr, load ? d_exp : nullptr, e->h_status, seq);
+        HIP_TRY(e, hipGetLastError());
+        const volatile u32* done = &e->h_status->n_removed;
+        const auto t_start = std::chrono::steady_clock::now();
+        for (u64 spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != seq; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFFu) == 0xFFFFu) {
+                if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                    return fail(e, RL_ERR_DEVICE, "k_gen_tiny did not complete within 60 s");
+                std::this_thread::yield();
+            }
+        }
+        const u32 err = e->h_status->err, dropped = e->h_status->n_ord, created = e->h_status->n_inserted;
+        e->live += created;
+        if (err) return status_to_error(e, err);
+        e->live -= dropped;
+        e->tombs += dropped;
+        e->stats.batches++;
+        e->stats.hits += n_hits;
+        e->stats.ordered_hits += n_hits;
+        e->stats.ordered_batches++;
+        return RL_OK;
+    }
     const bool mark_fresh = !load && d_req_off != nullptr;
     const u32* hit_req = nullptr;
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
@@ -782,6 +814,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= (long)TINY_MAX) e->tiny_max = (u32)b;
+        if (b == 0) e->gen_tiny_max = 0;
     }
     if (const char* v = getenv("RL_BUCKET_LOG2")) {
         const long b = strtol(v, nullptr, 10);

@@ -190,4 +190,165 @@ __global__ __launch_bounds__(256) void k_gen_reach(Cell* __restrict__ table,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gen_tiny: the general form for a FEW requests (at most GT_MAX hits — the per-request calls of
+// the trait, a request's 1..k counters, small micro-batches): one workgroup, one launch, no sort,
+// no fixpoint, no host round trip.  The hits' cells are resolved in parallel (created like
+// in_memory.rs:122-127), their state is copied to LDS, then ONE lane replays the requests in index
+// order with the reference's own control flow (in_memory.rs:72-156: simple counters first, early
+// return at the first limited counter unless load_counters, check everything before updating
+// anything), and the touched cells are written back in parallel.  A cell this batch created that no
+// request reached before stopping is dropped again (the reference would not have created it).
+// ---------------------------------------------------------------------------------------------
+constexpr u32 GT_MAX = 256;  // hits (one per thread)
+constexpr u32 GT_ENT = 512;  // LDS cells
+constexpr u32 GT_DIRTY = 1u, GT_CREATED = 2u, GT_REACHED = 4u;
+
+__global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 log2cap, u64 seed,
+                                                  const Hit* __restrict__ hits, u32 n_hits,
+                                                  const u32* __restrict__ req_off, u32 n_req,
+                                                  const LimitDev* __restrict__ limits, u32 n_limits, u64 now, int load,
+                                                  uint8_t* __restrict__ verdict, int32_t* __restrict__ first_limited,
+                                                  u64* __restrict__ remaining, u64* __restrict__ expires_in,
+                                                  Status* host_status, u32 done_seq) {
+    __shared__ u64 s_key[GT_ENT], s_value[GT_ENT], s_expiry[GT_ENT];
+    __shared__ u32 s_slot[GT_ENT], s_limit[GT_ENT], s_flags[GT_ENT];
+    __shared__ u64 h_max[GT_MAX], h_win[GT_MAX];
+    __shared__ u32 h_delta[GT_MAX], h_lim[GT_MAX];
+    __shared__ unsigned short h_ent[GT_MAX];
+    __shared__ u32 s_err, s_created, s_dropped;
+    __shared__ Status s_st;  // probe_from reports into a Status block
+    Status* st = &s_st;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) s_st.err = 0;
+    for (u32 e = tid; e < GT_ENT; e += 256) {
+        s_key[e] = TAG_EMPTY;
+        s_flags[e] = 0;
+    }
+    if (tid == 0) s_err = s_created = s_dropped = 0;
+    __syncthreads();
+    // ---- 1a: validate, find or create the cell, claim the key's LDS cell ---------------------------
+    bool claimer = false;
+    u32 my_slot = SLOT_INVALID, my_ent = 0;
+    Hit h{};
+    if (tid < n_hits) {
+        h = load_hit(hits, tid);
+        u32 err = 0;
+        if ((h.limit & ~SIMPLE_FLAG) >= n_limits) err = ERRBIT_BAD_LIMIT;
+        else if (h.key >= TAG_TOMB) err = ERRBIT_RESERVED_KEY;
+        else {
+            const LimitDev L = limits[h.limit & ~SIMPLE_FLAG];
+            h_max[tid] = L.max_value;
+            h_win[tid] = L.window_us;
+            h_delta[tid] = h.delta;
+            h_lim[tid] = h.limit;
+            u32 created = 0;
+            const u32 s0 = slot_of(h.key, seed, log2cap);
+            my_slot = probe_from<PM_CHECK>(table, log2cap, s0, table[s0].tag, h.key, h.limit, limits, now, st, created);
+            if (my_slot == SLOT_INVALID) {
+                err = (h.limit & SIMPLE_FLAG) ? ERRBIT_MISSING_SIMPLE : ERRBIT_TABLE_FULL;
+            } else {
+                u32 e = (u32)(fmix64(h.key ^ seed) >> 20) & (GT_ENT - 1);
+                for (;;) {
+                    const u64 prev = atomicCAS(&s_key[e], TAG_EMPTY, h.key);
+                    if (prev == TAG_EMPTY) {
+                        claimer = true;
+                        break;
+                    }
+                    if (prev == h.key) break;
+                    e = (e + 1) & (GT_ENT - 1);
+                }
+                my_ent = e;
+                h_ent[tid] = (unsigned short)e;
+                if (created) {
+                    atomicOr(&s_flags[e], GT_CREATED);
+                    atomicAdd(&s_created, 1u);
+                }
+            }
+        }
+        if (err) atomicOr(&s_err, err);
+    }
+    __syncthreads();  // every created cell is complete (workgroup-scope fence) before anyone copies it
+    // ---- 1b: the claimer copies the cell to LDS -----------------------------------------------------
+    if (claimer) {
+        const Cell* c = &table[my_slot];
+        s_value[my_ent] = c->value;
+        s_expiry[my_ent] = c->expiry;
+        s_limit[my_ent] = c->limit;
+        s_slot[my_ent] = my_slot;
+    }
+    __syncthreads();
+    if (tid < n_hits && my_slot != SLOT_INVALID && s_limit[my_ent] != h.limit) atomicOr(&s_err, ERRBIT_KEY_LIMIT);
+    __syncthreads();
+    const u32 err_all = s_err;
+    // ---- 2: one lane replays the requests, in_memory.rs:72-156 ----------------------------------------
+    if (tid == 0 && !err_all) {
+        for (u32 r = 0; r < n_req; ++r) {
+            const u32 b = req_off ? req_off[r] : r, e_ = req_off ? req_off[r + 1] : r + 1;
+            int32_t first = -1;
+            bool stopped = false;
+            for (int pass = 0; pass < 2 && !stopped; ++pass) {  // simple counters (:105-118), then qualified (:121-139)
+                for (u32 j = b; j < e_; ++j) {
+                    if (((h_lim[j] & SIMPLE_FLAG) == 0u) != (pass == 1)) continue;
+                    const u32 e = h_ent[j];
+                    s_flags[e] |= GT_REACHED;
+                    const u64 value = s_expiry[e] <= now ? 0ull : s_value[e];  // value_at(now)
+                    const u64 sum = value + (u64)h_delta[j];                     // wraps like the release build
+                    const bool within = sum <= h_max[j];
+                    if (load) {
+                        remaining[j] = within ? h_max[j] - sum : 0ull;  // checked_sub().unwrap_or_default(), :88-89
+                        if (first < 0 && !within) first = (int32_t)j;   // :90-94
+                        expires_in[j] = s_expiry[e] > now ? s_expiry[e] - now : 0ull;  // ttl, :114-116,134-136
+                    } else if (!within) {  // :109-113, :129-133: return at once, nothing is updated
+                        first = (int32_t)j;
+                        stopped = true;
+                        break;
+                    }
+                }
+            }
+            if (first < 0) {  // :146-153: update every counter, simple ones first
+                for (int pass = 0; pass < 2; ++pass)
+                    for (u32 j = b; j < e_; ++j) {
+                        if (((h_lim[j] & SIMPLE_FLAG) == 0u) != (pass == 1)) continue;
+                        const u32 e = h_ent[j];
+                        if (s_expiry[e] <= now) {  // atomic_expiring_value.rs:36-42,87-99
+                            s_expiry[e] = now + h_win[j];
+                            s_value[e] = (u64)h_delta[j];
+                        } else {
+                            s_value[e] += (u64)h_delta[j];
+                        }
+                        s_flags[e] |= GT_DIRTY;
+                    }
+            }
+            verdict[r] = first < 0 ? 0 : 1;
+            if (first_limited) first_limited[r] = first;
+        }
+    }
+    __syncthreads();
+    // ---- 3: write back, drop what no request reached --------------------------------------------------
+    if (!err_all) {
+        for (u32 e = tid; e < GT_ENT; e += 256) {
+            if (s_key[e] == TAG_EMPTY) continue;
+            const u32 f = s_flags[e];
+            Cell* c = &table[s_slot[e]];
+            if (f & GT_DIRTY) {
+                c->value = s_value[e];
+                c->expiry = s_expiry[e];
+            }
+            if (!load && (f & GT_CREATED) && !(f & GT_REACHED)) {
+                c->tag = TAG_TOMB;
+                atomicAdd(&s_dropped, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // completion word written last, with the counts, as ONE 16-byte store (see apply_finish)
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{s_err, s_dropped, s_created, done_seq},
+                                    reinterpret_cast<u32x4*>(host_status));
+    }
+}
+
 }  // namespace rl
