@@ -1421,6 +1421,9 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
         round_load_lines(A, n0, in0);
         apply_bucket(S, A, 0, n, in0, [] {});
     }
+    // the verdicts may go straight to host-mapped memory (rl_check_and_update_batch): every wave's stores
+    // have been acknowledged before the completion word is written
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) apply_finish(S, bs, bs_next, host_status, done_seq, 1u, nullptr, hot_n_report);
 }

@@ -111,6 +111,7 @@ struct rl_engine {
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
     u32 gen_tiny_max = 64;   // general form: requests of up to this many hits in all take k_gen_tiny (same switch)
     u32 gen_seq = 0;
+    uint8_t* h_tiny = nullptr;  // host-mapped staging of a tiny host-buffer call: the kernel reads and writes it directly
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
@@ -142,6 +143,11 @@ struct rl_engine {
 };
 
 namespace {
+
+// layout of rl_engine::h_tiny (host-mapped staging of a one-launch host-buffer call)
+constexpr size_t TIO_HITS = 1024;
+constexpr size_t TIO_OFF_HITS = 0, TIO_OFF_REQ = 16384, TIO_OFF_VERDICT = 24576, TIO_OFF_FIRST = 25600,
+                 TIO_OFF_REM = 29696, TIO_OFF_EXP = 37888, TIO_BYTES = 46080;
 
 int fail(rl_engine* e, int code, const char* fmt, ...) {
     char buf[512];
@@ -623,7 +629,7 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
     }
     int rc = check_room(e, n_hits);
     if (rc) return rc;
-    if (n_hits && n_hits <= e->gen_tiny_max && n_req <= 4096) {
+    if (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ) {
         // A few requests (the per-request calls of the trait): one workgroup, one launch (k_gen_tiny),
         // completion through a sequence word in the host-mapped status block.
         const u32 seq = ++e->gen_seq ? e->gen_seq : ++e->gen_seq;
@@ -915,6 +921,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_scan_tmp, e->scan_tmp_bytes);
 #undef ALLOC
     if (hipHostMalloc((void**)&e->h_status, sizeof(Status), hipHostMallocMapped) != hipSuccess) return bail(RL_ERR_NOMEM);
+    if (hipHostMalloc((void**)&e->h_tiny, TIO_BYTES, hipHostMallocMapped) != hipSuccess) return bail(RL_ERR_NOMEM);
     if (hipHostMalloc((void**)&e->h_total, sizeof(unsigned long long)) != hipSuccess) return bail(RL_ERR_NOMEM);
     for (auto& ev : e->ev)
         if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
@@ -945,6 +952,7 @@ void rl_engine_destroy(rl_engine* e) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
+    if (e->h_tiny) (void)hipHostFree(e->h_tiny);
     if (e->h_total) (void)hipHostFree(e->h_total);
     if (e->h_m_total) (void)hipHostFree(e->h_m_total);
     for (auto& ev : e->ev)
@@ -1052,13 +1060,45 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     if (load_counters && (!remaining || !expires_in_us))
         return fail(e, RL_ERR_INVALID, "load_counters needs remaining and expires_in_us buffers");
     if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
+    if (req_off) {
+        if (req_off[0] != 0 || req_off[n_req] != n_hits) return fail(e, RL_ERR_INVALID, "req_off must start at 0 and end at n_hits");
+        for (u32 r = 0; r < n_req; ++r)
+            if (req_off[r] > req_off[r + 1]) return fail(e, RL_ERR_INVALID, "req_off must be non-decreasing");
+    }
+    {
+        // A call the one-launch kernels take (k_bkt_tiny / k_gen_tiny): no copy commands at all.  The
+        // request is staged in host-mapped memory the kernel reads directly, the results land there too
+        // and are complete when the kernel's completion word is (both kernels are waited for by polling).
+        const bool general = req_off || load_counters;
+        const bool one_launch = general ? (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ)
+                                        : (n_hits && n_hits <= e->tiny_max && !e->legacy_k1 &&
+                                           e->h_limits.size() <= (size_t)LIM_LDS);
+        if (one_launch && n_hits <= TIO_HITS && n_req <= TIO_HITS) {
+            Hit* t_hits = reinterpret_cast<Hit*>(e->h_tiny + TIO_OFF_HITS);
+            u32* t_off = reinterpret_cast<u32*>(e->h_tiny + TIO_OFF_REQ);
+            uint8_t* t_verdict = e->h_tiny + TIO_OFF_VERDICT;
+            int32_t* t_first = reinterpret_cast<int32_t*>(e->h_tiny + TIO_OFF_FIRST);
+            u64* t_rem = reinterpret_cast<u64*>(e->h_tiny + TIO_OFF_REM);
+            u64* t_exp = reinterpret_cast<u64*>(e->h_tiny + TIO_OFF_EXP);
+            memcpy(t_hits, hits, (size_t)n_hits * sizeof(Hit));
+            if (req_off) memcpy(t_off, req_off, ((size_t)n_req + 1) * sizeof(u32));
+            rc = general ? run_check_general(e, t_hits, n_hits, req_off ? t_off : nullptr, n_req, now_us, load_counters != 0,
+                                             t_verdict, t_first, t_rem, t_exp)
+                         : run_check_k1(e, t_hits, n_hits, now_us, t_verdict, first_limited ? t_first : nullptr);
+            if (rc) return rc;
+            memcpy(verdict, t_verdict, n_req);
+            if (first_limited) memcpy(first_limited, t_first, (size_t)n_req * sizeof(int32_t));
+            if (load_counters) {
+                memcpy(remaining, t_rem, (size_t)n_hits * sizeof(u64));
+                memcpy(expires_in_us, t_exp, (size_t)n_hits * sizeof(u64));
+            }
+            return RL_OK;
+        }
+    }
     if (n_hits)
         HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
     if (req_off || load_counters) {
         if (req_off) {
-            if (req_off[0] != 0 || req_off[n_req] != n_hits) return fail(e, RL_ERR_INVALID, "req_off must start at 0 and end at n_hits");
-            for (u32 r = 0; r < n_req; ++r)
-                if (req_off[r] > req_off[r + 1]) return fail(e, RL_ERR_INVALID, "req_off must be non-decreasing");
             HIP_TRY(e, hipMemcpyAsync(e->d_req_off, req_off, ((size_t)n_req + 1) * sizeof(u32), hipMemcpyHostToDevice,
                                       e->stream));
         }

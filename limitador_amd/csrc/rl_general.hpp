@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void k_gen_reach(Cell* __restrict__ table,
 // request reached before stopping is dropped again (the reference would not have created it).
 // ---------------------------------------------------------------------------------------------
 constexpr u32 GT_MAX = 256;  // hits (one per thread)
+constexpr u32 GT_MAX_REQ = 256;
 constexpr u32 GT_ENT = 512;  // LDS cells
 constexpr u32 GT_DIRTY = 1u, GT_CREATED = 2u, GT_REACHED = 4u;
 
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
     __shared__ u64 h_max[GT_MAX], h_win[GT_MAX];
     __shared__ u32 h_delta[GT_MAX], h_lim[GT_MAX];
     __shared__ unsigned short h_ent[GT_MAX];
+    __shared__ u32 s_req_off[GT_MAX_REQ + 1];  // (req_off may live in host-mapped memory: read it once, in parallel)
     __shared__ u32 s_err, s_created, s_dropped;
     __shared__ Status s_st;  // probe_from reports into a Status block
     Status* st = &s_st;
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
         s_flags[e] = 0;
     }
     if (tid == 0) s_err = s_created = s_dropped = 0;
+    for (u32 r = tid; r <= n_req; r += 256) s_req_off[r] = req_off ? req_off[r] : r;
     __syncthreads();
     // ---- 1a: validate, find or create the cell, claim the key's LDS cell ---------------------------
     bool claimer = false;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
     // ---- 2: one lane replays the requests, in_memory.rs:72-156 ----------------------------------------
     if (tid == 0 && !err_all) {
         for (u32 r = 0; r < n_req; ++r) {
-            const u32 b = req_off ? req_off[r] : r, e_ = req_off ? req_off[r + 1] : r + 1;
+            const u32 b = s_req_off[r], e_ = s_req_off[r + 1];
             int32_t first = -1;
             bool stopped = false;
             for (int pass = 0; pass < 2 && !stopped; ++pass) {  // simple counters (:105-118), then qualified (:121-139)

@@ -40,3 +40,35 @@ for n in (1, 256, 4096, 16384, 65536, 262144, 1 << 20):
               "decisions_per_s_at_p50": round(n / (t[len(t) // 2] * 1e-6))}
 print(json.dumps(out))
 eng.close()
+
+
+def per_request(tiny):
+    """One request with 3 counters (1 simple + 2 qualified), the trait's per-request call."""
+    os.environ["RL_TINY_MAX"] = "1024" if tiny else "0"
+    from limitador_amd.wire import HIT_DTYPE, RL_SIMPLE
+
+    eng = Engine(capacity_cells=1 << 16, max_batch_hits=1 << 12)
+    eng.set_limits([(10**9, 60), (10**9, 60), (10**9, 60)])
+    eng.add_counter(0 | RL_SIMPLE, 7_000_001)
+    res = {}
+    for load in (False, True):
+        t = []
+        now_ = W.NOW0_US
+        for i in range(300):
+            h = np.zeros(3, dtype=HIT_DTYPE)
+            h[0] = (7_000_001, 0 | RL_SIMPLE, 1)
+            h[1] = (W.splitmix64(np.uint64(i % 50 + 1)), 1, 1)
+            h[2] = (W.splitmix64(np.uint64(i % 7 + 100)), 2, 1)
+            t0 = time.perf_counter()
+            eng.check_and_update(h, now_, req_off=np.array([0, 3], dtype=np.uint32), load_counters=load)
+            t.append(time.perf_counter() - t0)
+            now_ += 1000
+        t = np.sort(np.array(t[50:])) * 1e6
+        res["load_counters" if load else "plain"] = {"p50_us": round(float(t[len(t) // 2]), 1),
+                                                     "p99_us": round(float(t[int(len(t) * 0.99)]), 1)}
+    eng.close()
+    return res
+
+
+print(json.dumps({"one request x 3 counters, host buffers": {"one_launch": per_request(True),
+                                                              "general_pipeline": per_request(False)}}))
