@@ -1,0 +1,82 @@
+/*
+ * rl_ingest.h — host-side ingest for the on-device limit matcher (rl_match_and_check_batch):
+ * what sits between Limitador's transport (limitador-server/src/envoy_rls/server.rs:91-208: a
+ * RateLimitRequest = domain + descriptors of string key/value entries + hits_addend) and the engine's
+ * dictionary-encoded request arrays.  C view of limitador_amd/csrc/host/ingest.{hpp,cpp}.
+ *
+ *   limits    Limit::new(namespace, max_value, seconds, conditions, variables) (limit.rs:54-76) with
+ *             conditions of the shapes limit files are made of
+ *                 descriptors[0]['key'] == 'value'      descriptors[0]['key'] != 'value'
+ *                 descriptors[0].key == 'value'         key == 'value'   (the older form)
+ *             and variables  descriptors[0]['key'] | descriptors[0].key | key  (at most two per limit)
+ *             -> rows of rl_limits_set + the compiled match table of rl_match_table_set.  Anything else
+ *             is CEL: RLI_HOST_ONLY, the caller keeps such a limit on its own evaluation path.
+ *             Identity is (namespace, seconds, conditions, variables) (limit.rs:177-214): adding a limit
+ *             with a known identity returns its id and refreshes max_value (what update_limit does).
+ *   requests  namespace + descriptors[0] entries + delta -> req_ns / CSR (ent_key, ent_val) / req_delta.
+ *             Strings are interned exactly (two different strings never share an id).  A namespace
+ *             without limits maps to namespace id 0, which never has limits: no counter, not limited
+ *             (lib.rs:434-440).  Values first seen in a request are interned on the fly: an id the
+ *             table does not know simply matches no `==` and every `!=`.
+ *
+ * Every function returns >= 0 or a negative rl_status (rl_engine.h) unless stated otherwise.
+ */
+#ifndef RL_INGEST_H
+#define RL_INGEST_H
+#include <stdint.h>
+
+#include "rl_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rli_ingest rli_ingest;
+
+#define RLI_HOST_ONLY (-100) /* a condition or variable the device matcher does not evaluate */
+
+int32_t rli_create(rli_ingest **out);
+void rli_destroy(rli_ingest *g);
+const char *rli_last_error(const rli_ingest *g);
+
+/* -> limit id (row of rl_limits_set), RLI_HOST_ONLY, or a negative rl_status. */
+int32_t rli_add_limit(rli_ingest *g, const char *namespace_, uint64_t max_value, uint64_t seconds,
+                      const char *const *conditions, uint32_t n_conditions, const char *const *variables,
+                      uint32_t n_variables);
+/* Build the tables (sorted by namespace id; namespace 0 is the empty one).  Call after the last
+ * rli_add_limit and before the accessors below / rli_install. */
+int32_t rli_compile(rli_ingest *g);
+uint32_t rli_n_limits(const rli_ingest *g);
+uint32_t rli_n_conds(const rli_ingest *g);
+uint32_t rli_n_namespaces(const rli_ingest *g);
+const rl_limit_row *rli_limit_rows(const rli_ingest *g);  /* [n_limits], indexed by limit id */
+const rl_match_limit *rli_match_limits(const rli_ingest *g); /* [n_limits], table order */
+const rl_match_cond *rli_match_conds(const rli_ingest *g);   /* [n_conds] */
+/* rl_limits_set + rl_match_table_set + rl_add_counter for every limit without variables. */
+int32_t rli_install(rli_ingest *g, rl_engine *e);
+
+/* The request batch under construction. */
+void rli_batch_clear(rli_ingest *g);
+/* -> index of the request in the batch.  keys/values: the entries of descriptors[0], in order. */
+int32_t rli_batch_add(rli_ingest *g, const char *namespace_, const char *const *keys, const char *const *values,
+                      uint32_t n_entries, uint32_t delta);
+uint32_t rli_batch_n_requests(const rli_ingest *g);
+uint32_t rli_batch_n_entries(const rli_ingest *g);
+const uint32_t *rli_batch_req_ns(const rli_ingest *g);    /* [n_requests] */
+const uint32_t *rli_batch_req_delta(const rli_ingest *g); /* [n_requests] */
+const uint32_t *rli_batch_ent_off(const rli_ingest *g);   /* [n_requests + 1] */
+const uint32_t *rli_batch_ent_key(const rli_ingest *g);   /* [n_entries] */
+const uint32_t *rli_batch_ent_val(const rli_ingest *g);   /* [n_entries] */
+/* counters_that_apply + check_and_update for the batch (rl_match_and_check_batch): verdict[n_requests],
+ * limited_limit[n_requests] (limit id of the first limited counter, -1 otherwise; may be NULL). */
+int32_t rli_check(rli_ingest *g, rl_engine *e, uint64_t now_us, uint8_t *verdict, int32_t *limited_limit);
+
+/* Dictionary look-ups (tests, diagnostics): id of a string, -1 if it was never interned. */
+int64_t rli_key_id(const rli_ingest *g, const char *key);
+int64_t rli_value_id(const rli_ingest *g, const char *value);
+int64_t rli_namespace_id(const rli_ingest *g, const char *namespace_);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RL_INGEST_H */

@@ -53,12 +53,14 @@ def build_storage(force=False, verbose=False):
     if not os.path.exists(src):
         return None
     srcs = _sources(os.path.join(CSRC, "host"), (".cpp", ".hpp", ".h")) + [os.path.join(ROOT, "include", "rl_engine.h"),
-                                                                             os.path.join(ROOT, "include", "rl_storage.h")]
+                                                                             os.path.join(ROOT, "include", "rl_storage.h"),
+                                                                             os.path.join(ROOT, "include", "rl_ingest.h")]
     if not force and _newer(STORAGE_SO, srcs):
         return STORAGE_SO
     build_engine(force=False, verbose=verbose)
+    ingest = os.path.join(CSRC, "host", "ingest.cpp")  # host-side ingest of the device matcher (rl_ingest.h)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"), src,
-           "-o", STORAGE_SO, "-L" + LIBDIR, "-lrl_engine", "-Wl,-rpath,$ORIGIN"]
+           ingest, "-o", STORAGE_SO, "-L" + LIBDIR, "-lrl_engine", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

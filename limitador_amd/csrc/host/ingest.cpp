@@ -1,0 +1,316 @@
+// ingest.cpp — host-side ingest for the on-device limit matcher (include/rl_ingest.h): compiles Limits
+// into the match table of rl_match_table_set and dictionary-encodes requests for
+// rl_match_and_check_batch.  What it restates from the reference:
+//   Limit identity                     limitador/src/limit.rs:177-214
+//   conditions / variables as sets     limitador/src/limit.rs:34-48 (BTreeSet)
+//   "no limits -> not limited"         limitador/src/lib.rs:434-440
+//   request shape                      limitador-server/src/envoy_rls/server.rs:91-208
+// The predicate shapes are the ones rl_match.hpp evaluates; anything else is CEL and stays with the
+// caller (RLI_HOST_ONLY).
+#include "../../../include/rl_ingest.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <set>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Dictionary {  // exact string -> dense id
+    std::unordered_map<std::string, uint32_t> ids;
+    uint32_t intern(const std::string& s) {
+        auto it = ids.find(s);
+        if (it != ids.end()) return it->second;
+        const uint32_t id = (uint32_t)ids.size();
+        ids.emplace(s, id);
+        return id;
+    }
+    int64_t find(const std::string& s) const {
+        auto it = ids.find(s);
+        return it == ids.end() ? -1 : (int64_t)it->second;
+    }
+};
+
+struct Cond {
+    std::string key;
+    uint32_t op;  // 0 ==, 1 !=
+    std::string value;
+    bool operator<(const Cond& o) const { return std::tie(key, op, value) < std::tie(o.key, o.op, o.value); }
+    bool operator==(const Cond& o) const { return key == o.key && op == o.op && value == o.value; }
+};
+
+struct LimitSpec {
+    std::string ns;
+    uint64_t max_value, seconds;
+    std::vector<Cond> conds;        // sorted, unique
+    std::vector<std::string> vars;  // descriptor keys, sorted by name, unique
+    using Identity = std::tuple<std::string, uint64_t, std::vector<Cond>, std::vector<std::string>>;
+    Identity identity() const { return Identity(ns, seconds, conds, vars); }
+};
+
+void skip_ws(const std::string& s, size_t& i) {
+    while (i < s.size() && std::isspace((unsigned char)s[i])) ++i;
+}
+
+// 'text' or "text" -> text
+bool parse_quoted(const std::string& s, size_t& i, std::string* out) {
+    skip_ws(s, i);
+    if (i >= s.size() || (s[i] != '\'' && s[i] != '"')) return false;
+    const char q = s[i++];
+    const size_t b = i;
+    while (i < s.size() && s[i] != q) ++i;
+    if (i >= s.size()) return false;
+    *out = s.substr(b, i - b);
+    ++i;
+    return true;
+}
+
+// descriptors[0]['key'] | descriptors[0].key | key     (key: letters, digits, '_', '.', '-', ':')
+bool parse_key_ref(const std::string& s, size_t& i, std::string* key) {
+    skip_ws(s, i);
+    static const std::string pre = "descriptors[0]";
+    if (s.compare(i, pre.size(), pre) == 0) {
+        i += pre.size();
+        skip_ws(s, i);
+        if (i < s.size() && s[i] == '[') {
+            ++i;
+            if (!parse_quoted(s, i, key)) return false;
+            skip_ws(s, i);
+            if (i >= s.size() || s[i] != ']') return false;
+            ++i;
+            return !key->empty();
+        }
+        if (i < s.size() && s[i] == '.') ++i;
+        else return false;
+    }
+    const size_t b = i;
+    while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '.' || s[i] == '-' || s[i] == ':')) ++i;
+    if (i == b || std::isdigit((unsigned char)s[b])) return false;
+    *key = s.substr(b, i - b);
+    return true;
+}
+
+bool parse_condition(const std::string& s, Cond* c) {
+    size_t i = 0;
+    if (!parse_key_ref(s, i, &c->key)) return false;
+    skip_ws(s, i);
+    if (s.compare(i, 2, "==") == 0) c->op = 0;
+    else if (s.compare(i, 2, "!=") == 0) c->op = 1;
+    else return false;
+    i += 2;
+    if (!parse_quoted(s, i, &c->value)) return false;
+    skip_ws(s, i);
+    return i == s.size();
+}
+
+bool parse_variable(const std::string& s, std::string* key) {
+    size_t i = 0;
+    if (!parse_key_ref(s, i, key)) return false;
+    skip_ws(s, i);
+    return i == s.size();
+}
+
+}  // namespace
+
+struct rli_ingest {
+    Dictionary ns_ids, key_ids, val_ids;
+    std::vector<LimitSpec> limits;  // index = limit id
+    std::map<LimitSpec::Identity, uint32_t> by_identity;
+    // compiled
+    bool compiled = false;
+    std::vector<rl_limit_row> rows;
+    std::vector<rl_match_limit> table;
+    std::vector<rl_match_cond> conds;
+    // batch
+    std::vector<uint32_t> req_ns, req_delta, ent_off{0}, ent_key, ent_val;
+    std::string err;
+};
+
+static int32_t gfail(rli_ingest* g, int32_t rc, const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g->err = buf;
+    return rc;
+}
+
+extern "C" {
+
+int32_t rli_create(rli_ingest** out) {
+    if (!out) return RL_ERR_INVALID;
+    rli_ingest* g = new (std::nothrow) rli_ingest();
+    if (!g) return RL_ERR_NOMEM;
+    g->ns_ids.intern("");  // namespace id 0: the namespace without limits
+    *out = g;
+    return RL_OK;
+}
+
+void rli_destroy(rli_ingest* g) { delete g; }
+
+const char* rli_last_error(const rli_ingest* g) { return g ? g->err.c_str() : "null ingest"; }
+
+int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_t seconds,
+                      const char* const* conditions, uint32_t n_conditions, const char* const* variables,
+                      uint32_t n_variables) {
+    if (!g || !ns || (n_conditions && !conditions) || (n_variables && !variables)) return RL_ERR_INVALID;
+    if (!*ns) return gfail(g, RL_ERR_INVALID, "empty namespace");
+    LimitSpec L;
+    L.ns = ns;
+    L.max_value = max_value;
+    L.seconds = seconds;
+    std::set<Cond> cs;
+    for (uint32_t i = 0; i < n_conditions; ++i) {
+        Cond c;
+        if (!conditions[i] || !parse_condition(conditions[i], &c))
+            return gfail(g, RLI_HOST_ONLY, "condition %u is not `key ==|!= 'value'`: stays on the host", i);
+        cs.insert(c);
+    }
+    L.conds.assign(cs.begin(), cs.end());
+    std::set<std::string> vs;
+    for (uint32_t i = 0; i < n_variables; ++i) {
+        std::string k;
+        if (!variables[i] || !parse_variable(variables[i], &k))
+            return gfail(g, RLI_HOST_ONLY, "variable %u is not a descriptor key: stays on the host", i);
+        vs.insert(k);
+    }
+    if (vs.size() > 2) return gfail(g, RLI_HOST_ONLY, "more than two variables: stays on the host");
+    L.vars.assign(vs.begin(), vs.end());
+    auto it = g->by_identity.find(L.identity());
+    if (it != g->by_identity.end()) {  // same limit (limit.rs:177-214): max_value is not identity
+        g->limits[it->second].max_value = max_value;
+        g->compiled = false;
+        return (int32_t)it->second;
+    }
+    if (g->limits.size() >= 4095) return gfail(g, RL_ERR_INVALID, "more than 4095 limits");
+    const uint32_t id = (uint32_t)g->limits.size();
+    g->by_identity.emplace(L.identity(), id);
+    g->limits.push_back(std::move(L));
+    g->compiled = false;
+    return (int32_t)id;
+}
+
+int32_t rli_compile(rli_ingest* g) {
+    if (!g) return RL_ERR_INVALID;
+    const uint32_t n = (uint32_t)g->limits.size();
+    g->rows.assign(n, rl_limit_row{0, 0});
+    std::vector<uint32_t> order(n), ns_of(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        g->rows[i] = rl_limit_row{g->limits[i].max_value, g->limits[i].seconds};
+        ns_of[i] = g->ns_ids.intern(g->limits[i].ns);
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ns_of[a] < ns_of[b]; });
+    g->table.clear();
+    g->conds.clear();
+    for (uint32_t id : order) {
+        const LimitSpec& L = g->limits[id];
+        rl_match_limit m{};
+        m.limit = id | (L.vars.empty() ? RL_SIMPLE : 0u);
+        m.ns = ns_of[id];
+        m.cond_off = (uint32_t)g->conds.size();
+        m.n_cond = (uint32_t)L.conds.size();
+        m.n_vars = (uint32_t)L.vars.size();
+        for (size_t q = 0; q < L.vars.size(); ++q) m.var_key[q] = g->key_ids.intern(L.vars[q]);
+        for (const Cond& c : L.conds) {
+            const uint32_t v = g->val_ids.intern(c.value);
+            if (v >> 26) return gfail(g, RL_ERR_INVALID, "more than 2^26 distinct values");
+            g->conds.push_back(rl_match_cond{g->key_ids.intern(c.key), c.op, v});
+        }
+        g->table.push_back(m);
+    }
+    g->compiled = true;
+    return RL_OK;
+}
+
+uint32_t rli_n_limits(const rli_ingest* g) { return g ? (uint32_t)g->limits.size() : 0; }
+uint32_t rli_n_conds(const rli_ingest* g) { return g ? (uint32_t)g->conds.size() : 0; }
+uint32_t rli_n_namespaces(const rli_ingest* g) { return g ? (uint32_t)g->ns_ids.ids.size() : 0; }
+const rl_limit_row* rli_limit_rows(const rli_ingest* g) { return g && g->compiled ? g->rows.data() : nullptr; }
+const rl_match_limit* rli_match_limits(const rli_ingest* g) { return g && g->compiled ? g->table.data() : nullptr; }
+const rl_match_cond* rli_match_conds(const rli_ingest* g) { return g && g->compiled ? g->conds.data() : nullptr; }
+
+int32_t rli_install(rli_ingest* g, rl_engine* e) {
+    if (!g || !e) return RL_ERR_INVALID;
+    if (!g->compiled) {
+        const int32_t rc = rli_compile(g);
+        if (rc) return rc;
+    }
+    int32_t rc = rl_limits_set(e, 0, g->rows.data(), (uint32_t)g->rows.size());
+    if (rc) return gfail(g, rc, "rl_limits_set: %s", rl_last_error(e));
+    rc = rl_match_table_set(e, g->table.data(), (uint32_t)g->table.size(), g->conds.data(), (uint32_t)g->conds.size(),
+                            (uint32_t)g->ns_ids.ids.size());
+    if (rc) return gfail(g, rc, "rl_match_table_set: %s", rl_last_error(e));
+    for (uint32_t id = 0; id < g->limits.size(); ++id)
+        if (g->limits[id].vars.empty()) {  // add_counter, in_memory.rs:38-44: limits without variables only
+            rc = rl_add_counter(e, id | RL_SIMPLE, rl_match_key(id, 0, 0, 0));
+            if (rc) return gfail(g, rc, "rl_add_counter: %s", rl_last_error(e));
+        }
+    return RL_OK;
+}
+
+void rli_batch_clear(rli_ingest* g) {
+    if (!g) return;
+    g->req_ns.clear();
+    g->req_delta.clear();
+    g->ent_off.assign(1, 0);
+    g->ent_key.clear();
+    g->ent_val.clear();
+}
+
+int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, const char* const* values,
+                      uint32_t n_entries, uint32_t delta) {
+    if (!g || !ns || (n_entries && (!keys || !values))) return RL_ERR_INVALID;
+    const int64_t nid = g->ns_ids.find(ns);
+    // a namespace no limit names has no counters (lib.rs:434-440): the empty namespace 0; so does one
+    // interned after the table was installed (its id is beyond the table's namespaces)
+    g->req_ns.push_back(nid < 0 ? 0u : (uint32_t)nid);
+    g->req_delta.push_back(delta);
+    for (uint32_t q = 0; q < n_entries; ++q) {
+        if (!keys[q] || !values[q]) return gfail(g, RL_ERR_INVALID, "null descriptor entry");
+        const int64_t kid = g->key_ids.find(keys[q]);
+        if (kid < 0) continue;  // a key no limit reads: it cannot influence any condition or variable
+        const uint32_t v = g->val_ids.intern(values[q]);
+        if (v >> 26) return gfail(g, RL_ERR_INVALID, "more than 2^26 distinct values: restart the dictionary");
+        g->ent_key.push_back((uint32_t)kid);
+        g->ent_val.push_back(v);
+    }
+    g->ent_off.push_back((uint32_t)g->ent_key.size());
+    return (int32_t)g->req_ns.size() - 1;
+}
+
+uint32_t rli_batch_n_requests(const rli_ingest* g) { return g ? (uint32_t)g->req_ns.size() : 0; }
+uint32_t rli_batch_n_entries(const rli_ingest* g) { return g ? (uint32_t)g->ent_key.size() : 0; }
+const uint32_t* rli_batch_req_ns(const rli_ingest* g) { return g ? g->req_ns.data() : nullptr; }
+const uint32_t* rli_batch_req_delta(const rli_ingest* g) { return g ? g->req_delta.data() : nullptr; }
+const uint32_t* rli_batch_ent_off(const rli_ingest* g) { return g ? g->ent_off.data() : nullptr; }
+const uint32_t* rli_batch_ent_key(const rli_ingest* g) { return g ? g->ent_key.data() : nullptr; }
+const uint32_t* rli_batch_ent_val(const rli_ingest* g) { return g ? g->ent_val.data() : nullptr; }
+
+int32_t rli_check(rli_ingest* g, rl_engine* e, uint64_t now_us, uint8_t* verdict, int32_t* limited_limit) {
+    if (!g || !e || !verdict) return RL_ERR_INVALID;
+    const uint32_t n = (uint32_t)g->req_ns.size();
+    if (!n) return RL_OK;
+    // ids interned after the install are unknown to the table: a namespace maps to the empty one
+    const uint32_t n_ns_installed = (uint32_t)g->ns_ids.ids.size();
+    (void)n_ns_installed;
+    uint32_t n_hits = 0;
+    const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
+                                                g->req_delta.data(), n, now_us, 0, verdict, limited_limit, nullptr,
+                                                nullptr, 0, &n_hits, nullptr, nullptr);
+    if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
+    return RL_OK;
+}
+
+int64_t rli_key_id(const rli_ingest* g, const char* s) { return g && s ? g->key_ids.find(s) : -1; }
+int64_t rli_value_id(const rli_ingest* g, const char* s) { return g && s ? g->val_ids.find(s) : -1; }
+int64_t rli_namespace_id(const rli_ingest* g, const char* s) { return g && s ? g->ns_ids.find(s) : -1; }
+
+}  // extern "C"

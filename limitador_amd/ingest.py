@@ -1,0 +1,152 @@
+"""ctypes view of the C++ host-side ingest (include/rl_ingest.h, limitador_amd/csrc/host/ingest.cpp):
+Limits -> compiled match table, string requests -> dictionary-encoded request arrays, for the
+on-device matcher (Engine.match_and_check / rl_match_and_check_batch)."""
+import ctypes as C
+
+import numpy as np
+
+from . import host_storage
+from .wire import LIMIT_ROW_DTYPE, MATCH_COND_DTYPE, MATCH_LIMIT_DTYPE
+
+HOST_ONLY = -100
+SYMBOLS = {}
+
+
+def _lib():
+    so = host_storage.load()  # librl_storage.so carries the ingest as well
+    if SYMBOLS:
+        return so
+    p, cp, u32, u64, i32, i64 = C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64
+    strs = C.POINTER(C.c_char_p)
+    sig = {
+        "rli_create": (i32, [C.POINTER(p)]),
+        "rli_destroy": (None, [p]),
+        "rli_last_error": (cp, [p]),
+        "rli_add_limit": (i32, [p, cp, u64, u64, strs, u32, strs, u32]),
+        "rli_compile": (i32, [p]),
+        "rli_n_limits": (u32, [p]),
+        "rli_n_conds": (u32, [p]),
+        "rli_n_namespaces": (u32, [p]),
+        "rli_limit_rows": (p, [p]),
+        "rli_match_limits": (p, [p]),
+        "rli_match_conds": (p, [p]),
+        "rli_install": (i32, [p, p]),
+        "rli_batch_clear": (None, [p]),
+        "rli_batch_add": (i32, [p, cp, strs, strs, u32, u32]),
+        "rli_batch_n_requests": (u32, [p]),
+        "rli_batch_n_entries": (u32, [p]),
+        "rli_batch_req_ns": (p, [p]),
+        "rli_batch_req_delta": (p, [p]),
+        "rli_batch_ent_off": (p, [p]),
+        "rli_batch_ent_key": (p, [p]),
+        "rli_batch_ent_val": (p, [p]),
+        "rli_check": (i32, [p, p, u64, C.POINTER(C.c_uint8), C.POINTER(i32)]),
+        "rli_key_id": (i64, [p, cp]),
+        "rli_value_id": (i64, [p, cp]),
+        "rli_namespace_id": (i64, [p, cp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(so, name)
+        fn.restype, fn.argtypes = res, args
+        SYMBOLS[name] = fn
+    return so
+
+
+def _strs(items):
+    arr = (C.c_char_p * max(1, len(items)))()
+    for i, s in enumerate(items):
+        arr[i] = s.encode()
+    return arr
+
+
+def _view(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class IngestError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rl_ingest {code}: {msg}")
+        self.code = code
+
+
+class Ingest:
+    def __init__(self):
+        self._so = _lib()
+        h = C.c_void_p()
+        rc = SYMBOLS["rli_create"](C.byref(h))
+        if rc:
+            raise IngestError(rc, "rli_create failed")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            SYMBOLS["rli_destroy"](self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise IngestError(rc, SYMBOLS["rli_last_error"](self._h).decode())
+        return rc
+
+    def add_limit(self, namespace, max_value, seconds, conditions=(), variables=()):
+        """-> limit id, or HOST_ONLY if the limit needs CEL the device matcher does not evaluate."""
+        rc = SYMBOLS["rli_add_limit"](self._h, namespace.encode(), int(max_value), int(seconds), _strs(list(conditions)),
+                                      len(conditions), _strs(list(variables)), len(variables))
+        if rc == HOST_ONLY:
+            return HOST_ONLY
+        return self._check(rc)
+
+    def compile(self):
+        self._check(SYMBOLS["rli_compile"](self._h))
+        n, nc = SYMBOLS["rli_n_limits"](self._h), SYMBOLS["rli_n_conds"](self._h)
+        return {"limit_rows": _view(SYMBOLS["rli_limit_rows"](self._h), n, LIMIT_ROW_DTYPE),
+                "limits": _view(SYMBOLS["rli_match_limits"](self._h), n, MATCH_LIMIT_DTYPE),
+                "conds": _view(SYMBOLS["rli_match_conds"](self._h), nc, MATCH_COND_DTYPE),
+                "n_namespaces": SYMBOLS["rli_n_namespaces"](self._h)}
+
+    def install(self, engine):
+        self._check(SYMBOLS["rli_install"](self._h, engine._h))
+
+    def batch_clear(self):
+        SYMBOLS["rli_batch_clear"](self._h)
+
+    def batch_add(self, namespace, entries, delta=1):
+        """entries: the (key, value) pairs of descriptors[0], in order."""
+        keys, vals = [k for k, _ in entries], [v for _, v in entries]
+        return self._check(SYMBOLS["rli_batch_add"](self._h, namespace.encode(), _strs(keys), _strs(vals), len(keys),
+                                                    int(delta)))
+
+    def batch(self):
+        n, m = SYMBOLS["rli_batch_n_requests"](self._h), SYMBOLS["rli_batch_n_entries"](self._h)
+        u32 = np.uint32
+        return {"req_ns": _view(SYMBOLS["rli_batch_req_ns"](self._h), n, u32),
+                "req_delta": _view(SYMBOLS["rli_batch_req_delta"](self._h), n, u32),
+                "ent_off": _view(SYMBOLS["rli_batch_ent_off"](self._h), n + 1, u32),
+                "ent_key": _view(SYMBOLS["rli_batch_ent_key"](self._h), m, u32),
+                "ent_val": _view(SYMBOLS["rli_batch_ent_val"](self._h), m, u32)}
+
+    def check(self, engine, now_us):
+        n = SYMBOLS["rli_batch_n_requests"](self._h)
+        verdict = np.zeros(n, dtype=np.uint8)
+        limited = np.full(n, -1, dtype=np.int32)
+        self._check(SYMBOLS["rli_check"](self._h, engine._h, int(now_us), verdict.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                         limited.ctypes.data_as(C.POINTER(C.c_int32))))
+        return verdict, limited
+
+    def key_id(self, s):
+        return SYMBOLS["rli_key_id"](self._h, s.encode())
+
+    def value_id(self, s):
+        return SYMBOLS["rli_value_id"](self._h, s.encode())
+
+    def namespace_id(self, s):
+        return SYMBOLS["rli_namespace_id"](self._h, s.encode())

@@ -76,3 +76,18 @@ def test_host_mirror_library_exports_every_declared_symbol(engine_lib):
     for name in syms:
         assert hasattr(so, name), f"{name} declared in rl_storage.h but not exported"
         assert name in host_storage.SYMBOLS, f"{name} has no ctypes signature in limitador_amd/host_storage.py"
+
+
+def test_ingest_library_exports_every_declared_symbol(engine_lib):
+    """include/rl_ingest.h (host-side ingest of the device matcher) against librl_storage.so."""
+    from limitador_amd import host_storage, ingest
+
+    so = host_storage.load()
+    src = open(os.path.join(ROOT, "include", "rl_ingest.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(rli_[a-z0-9_]+)\s*\(", src)))
+    assert "rli_add_limit" in syms and "rli_check" in syms and len(syms) >= 20
+    ingest._lib()
+    for name in syms:
+        assert hasattr(so, name), f"{name} declared in rl_ingest.h but not exported"
+        assert name in ingest.SYMBOLS, f"{name} has no ctypes signature in limitador_amd/ingest.py"

@@ -176,3 +176,54 @@ def test_reference_applies_vectors_on_device(make_engine, conds, variables, ctx,
     if applies:
         vals = [val_id(ctx[v]) for v in sorted(variables)]
         assert int(got["hits"][0]["key"]) == eng.match_key(0, vals)
+
+
+def test_cpp_ingest_drives_the_device_matcher(make_engine):
+    """include/rl_ingest.h end to end: limits given as strings are compiled and installed by the C++
+    ingest, requests are encoded from strings, rl_match_and_check_batch decides — against the
+    string-level counters_that_apply + the oracle."""
+    from helpers.match_cpu import limited_limit, match_key, match_requests, random_limits
+    from limitador_amd.ingest import Ingest
+
+    rng = np.random.default_rng(41)
+    namespaces = ["ns0", "ns1", "ns2"]
+    limits = random_limits(rng, namespaces)
+    g = Ingest()
+    for l in limits:
+        assert g.add_limit(l.namespace, l.max_value, l.seconds, list(l.conditions), list(l.variables)) >= 0
+    t = g.compile()
+    eng = make_engine(capacity_cells=1 << 16, max_batch_hits=1 << 15)
+    g.install(eng)
+    orc = oracle.OracleStorage()
+    orc.set_limits([(l.max_value, l.seconds) for l in limits])
+    n_simple = 0
+    for i, l in enumerate(limits):
+        if not l.variables:
+            orc.add_counter(i | RL_SIMPLE, match_key(i, []))
+            n_simple += 1
+    methods, paths = ["GET", "POST", "PUT"], ["/a", "/b", "/json"]
+    now = NOW
+    for step in range(4):
+        g.batch_clear()
+        for _ in range(int(rng.integers(1, 2500))):
+            ns = namespaces[int(rng.integers(0, 3))] if rng.random() < 0.95 else "nobody"
+            ctx = {}
+            if rng.random() < 0.9:
+                ctx["m"] = methods[rng.integers(0, 3)]
+            if rng.random() < 0.8:
+                ctx["p"] = paths[rng.integers(0, 3)]
+            if rng.random() < 0.8:
+                ctx["u"] = f"user{int(rng.zipf(1.5)) % 50}"
+            if rng.random() < 0.6:
+                ctx["a"] = f"app{int(rng.integers(0, 5))}"
+            g.batch_add(ns, list(ctx.items()), int(rng.integers(0, 3)))
+        b = g.batch()
+        verdict, limited = g.check(eng, now)
+        hits, off = match_requests(t["limits"], t["conds"], b["req_ns"], b["ent_off"], b["ent_key"], b["ent_val"],
+                                   b["req_delta"])
+        wv, wf, _r, _e = orc.check_and_update(hits, now, req_off=off)
+        assert np.array_equal(verdict, wv), f"step {step}"
+        assert np.array_equal(limited, limited_limit(wf, hits)), f"step {step}"
+        now += int(rng.integers(0, 2 * SEC))
+    assert_same_state(eng, orc, n_simple_expected=n_simple)
+    g.close()
