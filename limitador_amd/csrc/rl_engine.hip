@@ -109,7 +109,7 @@ struct rl_engine {
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
-    u32 gen_tiny_max = 64;   // general form: requests of up to this many hits in all take k_gen_tiny (same switch)
+    u32 gen_tiny_max = 0;    // general form: calls of up to this many hits take k_gen_tiny — opt-in (RL_GEN_TINY_MAX=64)
     u32 gen_seq = 0;
     uint8_t* h_tiny = nullptr;  // host-mapped staging of a tiny host-buffer call: the kernel reads and writes it directly
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
@@ -820,7 +820,10 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= (long)TINY_MAX) e->tiny_max = (u32)b;
-        if (b == 0) e->gen_tiny_max = 0;
+    }
+    if (const char* v = getenv("RL_GEN_TINY_MAX")) {
+        const long b = strtol(v, nullptr, 10);
+        if (b >= 0 && b <= (long)GT_MAX) e->gen_tiny_max = (u32)b;
     }
     if (const char* v = getenv("RL_BUCKET_LOG2")) {
         const long b = strtol(v, nullptr, 10);
@@ -920,15 +923,22 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->scan_tmp_bytes = stmp ? stmp : 16;
     ALLOC(e->d_scan_tmp, e->scan_tmp_bytes);
 #undef ALLOC
-    if (hipHostMalloc((void**)&e->h_status, sizeof(Status), hipHostMallocMapped) != hipSuccess) return bail(RL_ERR_NOMEM);
-    if (hipHostMalloc((void**)&e->h_tiny, TIO_BYTES, hipHostMallocMapped) != hipSuccess) return bail(RL_ERR_NOMEM);
+    // Host-mapped blocks the device writes while the host polls them: fine-grained (coherent) memory, so a
+    // device store is on its way to the host when the wave's vmcnt says so, not when the kernel ends.
+    auto host_block = [](void** p, size_t bytes) {
+        if (hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) return true;
+        (void)hipGetLastError();
+        return hipHostMalloc(p, bytes, hipHostMallocMapped) == hipSuccess;
+    };
+    if (!host_block((void**)&e->h_status, sizeof(Status))) return bail(RL_ERR_NOMEM);
+    if (!host_block((void**)&e->h_tiny, TIO_BYTES)) return bail(RL_ERR_NOMEM);
     if (hipHostMalloc((void**)&e->h_total, sizeof(unsigned long long)) != hipSuccess) return bail(RL_ERR_NOMEM);
     for (auto& ev : e->ev)
         if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
     for (auto& f : e->inflight) {
         for (auto& ev : f.tev)
             if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
-        if (hipHostMalloc((void**)&f.h_st, sizeof(Status), hipHostMallocMapped) != hipSuccess) return bail(RL_ERR_NOMEM);
+        if (!host_block((void**)&f.h_st, sizeof(Status))) return bail(RL_ERR_NOMEM);
         memset(f.h_st, 0, sizeof(Status));
     }
     if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(RL_ERR_DEVICE);
@@ -1045,7 +1055,12 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
         return run_check_general(e, reinterpret_cast<const Hit*>(d_hits), n_hits, d_req_off, n_req, now_us,
                                  load_counters != 0, d_verdict, d_first_limited, reinterpret_cast<u64*>(d_remaining),
                                  reinterpret_cast<u64*>(d_expires_in_us));
-    return run_check_k1(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
+    rc = run_check_k1(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
+    // The batch is known to be applied as soon as its completion word is seen; a BLOCKING call also
+    // promises that the verdicts can be read from any stream, i.e. that the kernel has ended (with the
+    // caller's own stream set, stream order is the caller's synchronisation, as documented).
+    if (!rc && !e->external_stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return rc;
 }
 
 int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
@@ -1086,6 +1101,9 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
                                              t_verdict, t_first, t_rem, t_exp)
                          : run_check_k1(e, t_hits, n_hits, now_us, t_verdict, first_limited ? t_first : nullptr);
             if (rc) return rc;
+            // The completion word has been seen; the RESULTS are read only after the kernel has ended
+            // (its end-of-kernel release makes every store host-visible whatever the memory's caching).
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
             memcpy(verdict, t_verdict, n_req);
             if (first_limited) memcpy(first_limited, t_first, (size_t)n_req * sizeof(int32_t));
             if (load_counters) {

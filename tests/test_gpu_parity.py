@@ -388,6 +388,38 @@ def test_random_multi_counter_requests(make_engine, seed, load):
     assert st["live_cells"] == orc.num_qualified() + 2
 
 
+@pytest.mark.parametrize("one_launch", [False, pytest.param(True, marks=pytest.mark.xfail(
+    strict=False, reason="k_gen_tiny is opt-in (RL_GEN_TINY_MAX) until this stress test has run green on a MI355X: "
+    "its first run read results from host-mapped memory before the kernel had ended (fixed, not re-verified)"))],
+    ids=["general_pipeline", "k_gen_tiny_opt_in"])
+@pytest.mark.parametrize("load", [False, True], ids=["noload", "load_counters"])
+@pytest.mark.parametrize("seed", [23, 24, 25])
+def test_random_small_multi_counter_batches(make_engine, monkeypatch, seed, load, one_launch):
+    """A few requests per call (up to 64 hits) — the per-request calls of the trait: the same random
+    shapes as above (simple and qualified counters, duplicates inside a request, 0-second windows, a
+    limit that never limits), many calls so that windows expire and counters are created, reached,
+    dropped and recreated.  Through the general pipeline (default) and through the one-launch kernel."""
+    if one_launch:
+        monkeypatch.setenv("RL_GEN_TINY_MAX", "64")
+    rng = np.random.default_rng(seed)
+    rows = [(40, 1), (5000, 10), (3, 1), (25, 10), (200, 60), (2, 60), (9, 0), (2**64 - 1, 3600)]
+    simple_ids = {0, 1}
+    eng, orc = pair(make_engine, rows, [(0, 10_000_000), (1, 10_000_001)])
+    now = NOW
+    calls = 0
+    for step in range(250):
+        hits, off = _multi_batch(rng, int(rng.integers(1, 14)), rows, simple_ids, n_users=12)
+        if len(hits) > 64:
+            continue
+        run_both(eng, orc, hits, now, req_off=off, load_counters=load)
+        calls += 1
+        now += int(rng.integers(0, SEC // 2))
+    assert calls > 150
+    assert_same_state(eng, orc, n_simple_expected=2)
+    st = eng.stats()
+    assert st["live_cells"] == orc.num_qualified() + 2
+
+
 def test_single_counter_requests_with_load_counters(make_engine):
     rng = np.random.default_rng(31)
     eng, orc = pair(make_engine, [(50, 2), (7, 1)])
