@@ -109,7 +109,7 @@ struct rl_engine {
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
-    u32 gen_tiny_max = 0;    // general form: calls of up to this many hits take k_gen_tiny — opt-in (RL_GEN_TINY_MAX=64)
+    u32 gen_tiny_max = 64;   // general form: calls of up to this many hits take k_gen_tiny (RL_GEN_TINY_MAX=0 disables)
     u32 gen_seq = 0;
     uint8_t* h_tiny = nullptr;  // host-mapped staging of a tiny host-buffer call: the kernel reads and writes it directly
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
@@ -820,6 +820,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= (long)TINY_MAX) e->tiny_max = (u32)b;
+        if (b == 0) e->gen_tiny_max = 0;  // RL_TINY_MAX=0 switches both one-launch kernels off
     }
     if (const char* v = getenv("RL_GEN_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);

@@ -45,7 +45,7 @@ eng.close()
 def per_request(tiny):
     """One request with 3 counters (1 simple + 2 qualified), the trait's per-request call."""
     os.environ["RL_TINY_MAX"] = "1024" if tiny else "0"
-    os.environ["RL_GEN_TINY_MAX"] = "64" if tiny else "0"  # k_gen_tiny is opt-in
+    os.environ["RL_GEN_TINY_MAX"] = "64" if tiny else "0"
     from limitador_amd.wire import HIT_DTYPE, RL_SIMPLE
 
     eng = Engine(capacity_cells=1 << 16, max_batch_hits=1 << 12)

@@ -388,10 +388,7 @@ def test_random_multi_counter_requests(make_engine, seed, load):
     assert st["live_cells"] == orc.num_qualified() + 2
 
 
-@pytest.mark.parametrize("one_launch", [False, pytest.param(True, marks=pytest.mark.xfail(
-    strict=False, reason="k_gen_tiny is opt-in (RL_GEN_TINY_MAX) until this stress test has run green on a MI355X: "
-    "its first run read results from host-mapped memory before the kernel had ended (fixed, not re-verified)"))],
-    ids=["general_pipeline", "k_gen_tiny_opt_in"])
+@pytest.mark.parametrize("one_launch", [False, True], ids=["general_pipeline", "k_gen_tiny"])
 @pytest.mark.parametrize("load", [False, True], ids=["noload", "load_counters"])
 @pytest.mark.parametrize("seed", [23, 24, 25])
 def test_random_small_multi_counter_batches(make_engine, monkeypatch, seed, load, one_launch):
@@ -399,8 +396,7 @@ def test_random_small_multi_counter_batches(make_engine, monkeypatch, seed, load
     shapes as above (simple and qualified counters, duplicates inside a request, 0-second windows, a
     limit that never limits), many calls so that windows expire and counters are created, reached,
     dropped and recreated.  Through the general pipeline (default) and through the one-launch kernel."""
-    if one_launch:
-        monkeypatch.setenv("RL_GEN_TINY_MAX", "64")
+    monkeypatch.setenv("RL_GEN_TINY_MAX", "64" if one_launch else "0")
     rng = np.random.default_rng(seed)
     rows = [(40, 1), (5000, 10), (3, 1), (25, 10), (200, 60), (2, 60), (9, 0), (2**64 - 1, 3600)]
     simple_ids = {0, 1}
