@@ -2,7 +2,7 @@
  * rl_ingest.h — host-side ingest for the on-device limit matcher (rl_match_and_check_batch):
  * what sits between Limitador's transport (limitador-server/src/envoy_rls/server.rs:91-208: a
  * RateLimitRequest = domain + descriptors of string key/value entries + hits_addend) and the engine's
- * dictionary-encoded request arrays.  C view of limitador_amd/csrc/host/ingest.{hpp,cpp}.
+ * dictionary-encoded request arrays.  C view of limitador_amd/csrc/host/ingest.cpp.
  *
  *   limits    Limit::new(namespace, max_value, seconds, conditions, variables) (limit.rs:54-76) with
  *             conditions of the shapes limit files are made of
@@ -33,7 +33,9 @@ extern "C" {
 
 typedef struct rli_ingest rli_ingest;
 
-#define RLI_HOST_ONLY (-100) /* a condition or variable the device matcher does not evaluate */
+#define RLI_HOST_ONLY (-100)      /* a condition or variable the device matcher does not evaluate */
+#define RLI_UNKNOWN_DOMAIN (-101) /* RateLimitRequest without a domain: the reference answers Code::Unknown
+                                     without consulting the storage (envoy_rls/server.rs:105-115) */
 
 int32_t rli_create(rli_ingest **out);
 void rli_destroy(rli_ingest *g);
@@ -60,6 +62,14 @@ void rli_batch_clear(rli_ingest *g);
 /* -> index of the request in the batch.  keys/values: the entries of descriptors[0], in order. */
 int32_t rli_batch_add(rli_ingest *g, const char *namespace_, const char *const *keys, const char *const *values,
                       uint32_t n_entries, uint32_t delta);
+/* The same from the wire: one serialized envoy.service.ratelimit.v3.RateLimitRequest
+ * (rls.proto:38-53: domain = 1, descriptors = 2, hits_addend = 3; ratelimit.proto:65-95: entries = 1 of
+ * (key = 1, value = 2)), interpreted like ShouldRateLimit does (envoy_rls/server.rs:97-137): namespace =
+ * domain, the context of descriptors[0] is its entries with the LAST value of a repeated key
+ * (HashMap::insert), hits_addend 0 means 1.  Further descriptors are not looked at (limits that read
+ * them are RLI_HOST_ONLY).  -> request index, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID for a malformed
+ * message (nothing is added). */
+int32_t rli_batch_add_rls(rli_ingest *g, const uint8_t *msg, uint32_t len);
 uint32_t rli_batch_n_requests(const rli_ingest *g);
 uint32_t rli_batch_n_entries(const rli_ingest *g);
 const uint32_t *rli_batch_req_ns(const rli_ingest *g);    /* [n_requests] */

@@ -116,6 +116,86 @@ bool parse_variable(const std::string& s, std::string* key) {
     return i == s.size();
 }
 
+// ---- protobuf wire format, just enough for RateLimitRequest ------------------------------------------
+struct Wire {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool varint(uint64_t* v) {
+        uint64_t r = 0;
+        for (int shift = 0; shift < 64 && p < end; shift += 7) {
+            const uint8_t b = *p++;
+            r |= (uint64_t)(b & 0x7F) << shift;
+            if (!(b & 0x80)) {
+                *v = r;
+                return true;
+            }
+        }
+        return false;
+    }
+    bool bytes(Wire* sub) {  // length-delimited payload
+        uint64_t n;
+        if (!varint(&n) || n > (uint64_t)(end - p)) return false;
+        sub->p = p;
+        sub->end = p + n;
+        p += n;
+        return true;
+    }
+    bool skip(uint32_t wire_type) {
+        uint64_t v;
+        Wire w;
+        switch (wire_type) {
+            case 0: return varint(&v);
+            case 1: if (end - p < 8) return false; p += 8; return true;
+            case 2: return bytes(&w);
+            case 5: if (end - p < 4) return false; p += 4; return true;
+            default: return false;  // groups are not used by these messages
+        }
+    }
+    bool done() const { return p >= end; }
+};
+
+// RateLimitDescriptor.Entry { key = 1; value = 2 }
+bool parse_entry(Wire w, std::string* key, std::string* value) {
+    while (!w.done()) {
+        uint64_t tag;
+        if (!w.varint(&tag)) return false;
+        const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+        Wire sub;
+        if ((field == 1 || field == 2) && wt == 2) {
+            if (!w.bytes(&sub)) return false;
+            (field == 1 ? key : value)->assign(reinterpret_cast<const char*>(sub.p), (size_t)(sub.end - sub.p));
+        } else if (!w.skip(wt)) {
+            return false;
+        }
+    }
+    return true;
+}
+
+// RateLimitDescriptor { repeated Entry entries = 1; RateLimitOverride limit = 2 }
+bool parse_descriptor(Wire w, std::vector<std::pair<std::string, std::string>>* entries) {
+    while (!w.done()) {
+        uint64_t tag;
+        if (!w.varint(&tag)) return false;
+        const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+        Wire sub;
+        if (field == 1 && wt == 2) {
+            if (!w.bytes(&sub)) return false;
+            std::string k, v;
+            if (!parse_entry(sub, &k, &v)) return false;
+            bool replaced = false;  // HashMap::insert: a repeated key keeps its LAST value
+            for (auto& kv : *entries)
+                if (kv.first == k) {
+                    kv.second = v;
+                    replaced = true;
+                }
+            if (!replaced) entries->emplace_back(std::move(k), std::move(v));
+        } else if (!w.skip(wt)) {
+            return false;
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 struct rli_ingest {
@@ -284,6 +364,41 @@ int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, co
     }
     g->ent_off.push_back((uint32_t)g->ent_key.size());
     return (int32_t)g->req_ns.size() - 1;
+}
+
+int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) {
+    if (!g || (len && !msg)) return RL_ERR_INVALID;
+    Wire w{msg, msg + len};
+    std::string domain;
+    std::vector<std::pair<std::string, std::string>> entries;
+    uint64_t hits_addend = 0;
+    uint32_t n_descriptors = 0;
+    while (!w.done()) {
+        uint64_t tag;
+        if (!w.varint(&tag)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (tag)");
+        const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+        Wire sub;
+        if (field == 1 && wt == 2) {
+            if (!w.bytes(&sub)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (domain)");
+            domain.assign(reinterpret_cast<const char*>(sub.p), (size_t)(sub.end - sub.p));
+        } else if (field == 2 && wt == 2) {
+            if (!w.bytes(&sub)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (descriptor)");
+            if (n_descriptors++ == 0 && !parse_descriptor(sub, &entries))
+                return gfail(g, RL_ERR_INVALID, "malformed RateLimitDescriptor");
+        } else if (field == 3 && wt == 0) {
+            if (!w.varint(&hits_addend)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (hits_addend)");
+        } else if (!w.skip(wt)) {
+            return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (field %u)", field);
+        }
+    }
+    if (domain.empty()) return RLI_UNKNOWN_DOMAIN;
+    std::vector<const char*> keys, values;
+    for (const auto& kv : entries) {
+        keys.push_back(kv.first.c_str());
+        values.push_back(kv.second.c_str());
+    }
+    const uint32_t delta = hits_addend == 0 ? 1u : (uint32_t)hits_addend;  // server.rs:131-137
+    return rli_batch_add(g, domain.c_str(), keys.data(), values.data(), (uint32_t)keys.size(), delta);
 }
 
 uint32_t rli_batch_n_requests(const rli_ingest* g) { return g ? (uint32_t)g->req_ns.size() : 0; }

@@ -9,6 +9,7 @@ from . import host_storage
 from .wire import LIMIT_ROW_DTYPE, MATCH_COND_DTYPE, MATCH_LIMIT_DTYPE
 
 HOST_ONLY = -100
+UNKNOWN_DOMAIN = -101
 SYMBOLS = {}
 
 
@@ -33,6 +34,7 @@ def _lib():
         "rli_install": (i32, [p, p]),
         "rli_batch_clear": (None, [p]),
         "rli_batch_add": (i32, [p, cp, strs, strs, u32, u32]),
+        "rli_batch_add_rls": (i32, [p, C.c_char_p, u32]),
         "rli_batch_n_requests": (u32, [p]),
         "rli_batch_n_entries": (u32, [p]),
         "rli_batch_req_ns": (p, [p]),
@@ -124,6 +126,14 @@ class Ingest:
         keys, vals = [k for k, _ in entries], [v for _, v in entries]
         return self._check(SYMBOLS["rli_batch_add"](self._h, namespace.encode(), _strs(keys), _strs(vals), len(keys),
                                                     int(delta)))
+
+    def batch_add_rls(self, message):
+        """message: one serialized envoy.service.ratelimit.v3.RateLimitRequest.
+        -> request index, or UNKNOWN_DOMAIN (the reference answers Code::Unknown)."""
+        rc = SYMBOLS["rli_batch_add_rls"](self._h, bytes(message), len(message))
+        if rc == UNKNOWN_DOMAIN:
+            return UNKNOWN_DOMAIN
+        return self._check(rc)
 
     def batch(self):
         n, m = SYMBOLS["rli_batch_n_requests"](self._h), SYMBOLS["rli_batch_n_entries"](self._h)

@@ -106,3 +106,91 @@ def test_compiled_table_and_encoded_requests_give_counters_that_apply(ingest, se
         assert simple_flags == sorted(simple_flags, reverse=True)
         total += len(got)
     assert total > 600
+
+
+# ---- the wire: envoy.service.ratelimit.v3.RateLimitRequest ------------------------------------------
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(field, payload):  # length-delimited field
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def rls_request(domain, descriptors, hits_addend=None, junk=False):
+    """Hand-encoded RateLimitRequest (rls.proto:38-53, ratelimit.proto:65-95)."""
+    msg = b""
+    if domain is not None:
+        msg += _ld(1, domain.encode())
+    for entries in descriptors:
+        d = b"".join(_ld(1, _ld(1, k.encode()) + _ld(2, v.encode())) for k, v in entries)
+        if junk:  # a RateLimitOverride (field 2) and an unknown fixed32 field the decoder has to skip
+            d += _ld(2, _varint((1 << 3) | 0) + _varint(7)) + _varint((9 << 3) | 5) + bytes([1, 2, 3, 4])
+        msg += _ld(2, d)
+    if hits_addend is not None:
+        msg += _varint((3 << 3) | 0) + _varint(hits_addend)
+    return msg
+
+
+def _protobuf_classes():
+    """The two messages built at run time with the protobuf runtime (no generated stubs in the image)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+    f = descriptor_pb2.FileDescriptorProto(name="rls_test.proto", package="t", syntax="proto3")
+    entry = descriptor_pb2.DescriptorProto(name="Entry")
+    entry.field.add(name="key", number=1, type=9, label=1)
+    entry.field.add(name="value", number=2, type=9, label=1)
+    desc = descriptor_pb2.DescriptorProto(name="RateLimitDescriptor")
+    desc.nested_type.append(entry)
+    desc.field.add(name="entries", number=1, type=11, label=3, type_name=".t.RateLimitDescriptor.Entry")
+    req = descriptor_pb2.DescriptorProto(name="RateLimitRequest")
+    req.field.add(name="domain", number=1, type=9, label=1)
+    req.field.add(name="descriptors", number=2, type=11, label=3, type_name=".t.RateLimitDescriptor")
+    req.field.add(name="hits_addend", number=3, type=13, label=1)
+    f.message_type.extend([desc, req])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("t.RateLimitRequest"))
+
+
+def test_rate_limit_requests_from_the_wire(ingest):
+    from limitador_amd.ingest import UNKNOWN_DOMAIN, IngestError
+
+    g = ingest
+    g.add_limit("ns", 10, 60, ["descriptors[0]['req.method'] == 'GET'"], ["descriptors[0]['user_id']"])
+    g.compile()
+    # descriptors[0] only; a repeated key keeps its LAST value (HashMap::insert, server.rs:122-128);
+    # hits_addend absent or 0 -> 1 (server.rs:131-137); unknown fields are skipped
+    assert g.batch_add_rls(rls_request("ns", [[("req.method", "POST"), ("user_id", "bob"), ("req.method", "GET")],
+                                              [("user_id", "ignored")]], junk=True)) == 0
+    assert g.batch_add_rls(rls_request("ns", [[("user_id", "eve")]], hits_addend=0)) == 1
+    assert g.batch_add_rls(rls_request("elsewhere", [[("req.method", "GET")]], hits_addend=5)) == 2
+    assert g.batch_add_rls(rls_request("", [[("req.method", "GET")]])) == UNKNOWN_DOMAIN  # Code::Unknown, server.rs:105-115
+    assert g.batch_add_rls(rls_request(None, [])) == UNKNOWN_DOMAIN
+    with pytest.raises(IngestError):
+        g.batch_add_rls(rls_request("ns", [[("a", "b")]])[:-2])  # truncated
+    b = g.batch()
+    assert b["req_ns"].tolist() == [g.namespace_id("ns"), g.namespace_id("ns"), 0]
+    assert b["req_delta"].tolist() == [1, 1, 5]
+    assert b["ent_off"].tolist() == [0, 2, 3, 4]
+    assert b["ent_key"].tolist() == [g.key_id("req.method"), g.key_id("user_id"), g.key_id("user_id"), g.key_id("req.method")]
+    assert b["ent_val"].tolist() == [g.value_id("GET"), g.value_id("bob"), g.value_id("eve"), g.value_id("GET")]
+    # the same request serialized by the protobuf runtime decodes identically
+    Req = _protobuf_classes()
+    m = Req(domain="ns", hits_addend=3)
+    d = m.descriptors.add()
+    for k, v in [("req.method", "GET"), ("user_id", "zoe")]:
+        e = d.entries.add()
+        e.key, e.value = k, v
+    g.batch_clear()
+    assert g.batch_add_rls(m.SerializeToString()) == 0
+    assert g.batch_add_rls(rls_request("ns", [[("req.method", "GET"), ("user_id", "zoe")]], hits_addend=3)) == 1
+    b = g.batch()
+    assert b["req_delta"].tolist() == [3, 3] and b["ent_off"].tolist() == [0, 2, 4]
+    assert b["ent_val"][:2].tolist() == b["ent_val"][2:].tolist() == [g.value_id("GET"), g.value_id("zoe")]
