@@ -81,6 +81,11 @@ const uint32_t *rli_batch_ent_val(const rli_ingest *g);   /* [n_entries] */
  * limited_limit[n_requests] (limit id of the first limited counter, -1 otherwise; may be NULL). */
 int32_t rli_check(rli_ingest *g, rl_engine *e, uint64_t now_us, uint8_t *verdict, int32_t *limited_limit);
 
+/* The answer on the wire: a serialized RateLimitResponse carrying overall_code (rls.proto:62-71,182) the way
+ * ShouldRateLimit builds it without rate-limit headers (envoy_rls/server.rs:176-206): verdict 0 -> OK,
+ * 1 -> OVER_LIMIT, RLI_UNKNOWN_DOMAIN -> UNKNOWN.  Writes at most 2 bytes into out, returns the length. */
+uint32_t rli_rls_response(int32_t verdict, uint8_t out[2]);
+
 /* Dictionary look-ups (tests, diagnostics): id of a string, -1 if it was never interned. */
 int64_t rli_key_id(const rli_ingest *g, const char *key);
 int64_t rli_value_id(const rli_ingest *g, const char *value);

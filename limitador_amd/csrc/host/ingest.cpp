@@ -424,6 +424,14 @@ int32_t rli_check(rli_ingest* g, rl_engine* e, uint64_t now_us, uint8_t* verdict
     return RL_OK;
 }
 
+uint32_t rli_rls_response(int32_t verdict, uint8_t out[2]) {
+    // RateLimitResponse { Code overall_code = 1 }: UNKNOWN = 0 is the default and is not put on the wire
+    if (verdict == RLI_UNKNOWN_DOMAIN || verdict < 0 || !out) return 0;
+    out[0] = (1u << 3) | 0u;
+    out[1] = verdict ? 2u : 1u;  // OVER_LIMIT : OK
+    return 2;
+}
+
 int64_t rli_key_id(const rli_ingest* g, const char* s) { return g && s ? g->key_ids.find(s) : -1; }
 int64_t rli_value_id(const rli_ingest* g, const char* s) { return g && s ? g->val_ids.find(s) : -1; }
 int64_t rli_namespace_id(const rli_ingest* g, const char* s) { return g && s ? g->ns_ids.find(s) : -1; }

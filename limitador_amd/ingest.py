@@ -43,6 +43,7 @@ def _lib():
         "rli_batch_ent_key": (p, [p]),
         "rli_batch_ent_val": (p, [p]),
         "rli_check": (i32, [p, p, u64, C.POINTER(C.c_uint8), C.POINTER(i32)]),
+        "rli_rls_response": (u32, [i32, C.POINTER(C.c_uint8)]),
         "rli_key_id": (i64, [p, cp]),
         "rli_value_id": (i64, [p, cp]),
         "rli_namespace_id": (i64, [p, cp]),
@@ -151,6 +152,14 @@ class Ingest:
         self._check(SYMBOLS["rli_check"](self._h, engine._h, int(now_us), verdict.ctypes.data_as(C.POINTER(C.c_uint8)),
                                          limited.ctypes.data_as(C.POINTER(C.c_int32))))
         return verdict, limited
+
+    @staticmethod
+    def rls_response(verdict):
+        """Serialized RateLimitResponse for a verdict (0 OK, 1 OVER_LIMIT, UNKNOWN_DOMAIN -> UNKNOWN)."""
+        _lib()
+        out = (C.c_uint8 * 2)()
+        n = SYMBOLS["rli_rls_response"](int(verdict), out)
+        return bytes(out[:n])
 
     def key_id(self, s):
         return SYMBOLS["rli_key_id"](self._h, s.encode())

@@ -194,3 +194,20 @@ def test_rate_limit_requests_from_the_wire(ingest):
     b = g.batch()
     assert b["req_delta"].tolist() == [3, 3] and b["ent_off"].tolist() == [0, 2, 4]
     assert b["ent_val"][:2].tolist() == b["ent_val"][2:].tolist() == [g.value_id("GET"), g.value_id("zoe")]
+
+
+def test_rate_limit_response_on_the_wire(engine_lib):
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    from limitador_amd.ingest import UNKNOWN_DOMAIN, Ingest
+
+    f = descriptor_pb2.FileDescriptorProto(name="rls_resp_test.proto", package="t2", syntax="proto3")
+    resp = descriptor_pb2.DescriptorProto(name="RateLimitResponse")
+    resp.field.add(name="overall_code", number=1, type=13, label=1)  # the enum's numbers: UNKNOWN 0, OK 1, OVER_LIMIT 2
+    f.message_type.append(resp)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    Resp = message_factory.GetMessageClass(pool.FindMessageTypeByName("t2.RateLimitResponse"))
+    for verdict, code in ((0, 1), (1, 2), (UNKNOWN_DOMAIN, 0)):
+        m = Resp()
+        m.ParseFromString(Ingest.rls_response(verdict))
+        assert m.overall_code == code
