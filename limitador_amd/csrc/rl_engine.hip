@@ -648,6 +648,9 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
                 std::this_thread::yield();
             }
         }
+        // like the pipeline below, return only once the kernel has ended: the results (device or
+        // host-mapped memory) are then visible to any reader, not just to this stream
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
         const u32 err = e->h_status->err, dropped = e->h_status->n_ord, created = e->h_status->n_inserted;
         e->live += created;
         if (err) return status_to_error(e, err);
