@@ -1,0 +1,660 @@
+// rl_apply2.hpp — k_bkt_apply2: the bucket replay of rl_bucket.hpp re-cut for occupancy.
+//
+// Same contract and the same exact algorithm as k_bkt_apply (see the header of rl_bucket.hpp:
+// reference limitador/src/storage/in_memory.rs:72-156 applied hit by hit in trace order, one read
+// and one write per touched counter cell), different machine mapping:
+//
+//   * ONE workgroup per hash bucket, not persistent.  k_bkt_apply hides the dependent chain of a
+//     bucket (hits -> home cells -> LDS aggregation -> probes -> verdicts -> write-back, ~6 us)
+//     behind a software pipeline of three register buffers, which costs 251 VGPRs and, with 77 KB
+//     of LDS, leaves 2 workgroups = 2 waves per SIMD on a CU.  Here the chain is hidden by OTHER
+//     workgroups: 22-44 KB of LDS and <= 96 VGPRs keep 3-6 of them resident per CU.
+//   * the limit table and the hot-bucket table are read from global memory (L2-resident, a few
+//     hundred bytes) instead of LDS copies: 16 KB of LDS less, and no row limit on the limit table.
+//   * one 64-bit LDS atomic per hit carries the round's delta sum AND the per-wave hit counts
+//     (k_bkt_apply: two 64-bit atomics); deltas >= 2^23 cannot share the 32-bit sum field and send
+//     their key through the sequential replay, which is exact for everything.
+//   * hot-key chunks are found through a chunk table prepared by k_bkt_scatter (no binary search).
+#pragma once
+#include "rl_bucket.hpp"
+
+namespace rl {
+
+constexpr u32 AP2_BIG_DELTA = 1u << 23;  // 512 hits x (2^23 - 1) < 2^32: the round's sum fits 32 bits
+
+template <int HPT, int ENT_LOG2>
+struct Apply2Lds {
+    static constexpr int E = 1 << ENT_LOG2;
+    static constexpr int R = AP_BLOCK * HPT;          // hits per decide/commit round
+    static constexpr int KEEP = E * 3 / 4 - R;        // rebuild the LDS cells before a round if more are live
+    static_assert(KEEP > 0, "the LDS hash must hold one round at load <= 3/4");
+    u64 key[E];
+    u64 run[E];    // value the next hit reads; for 0-second windows: the last admitted delta
+    u64 agg[E];    // this round: hits per wave (4 x 8 bits, bits 32..63) | sum of deltas < 2^23 (bits 0..31)
+    u32 slot[E];
+    u32 limit[E];  // the CELL's limit attribute
+    u32 dmax[E];   // this round: largest delta
+    u32 flags[E];  // EF_* | hits absorbed << EF_COUNT_SHIFT
+    u32 h_delta[R];
+    unsigned short h_ent[R];
+    uint8_t h_verdict[R];
+    u32 n_ent;
+    u32 bucket_len;
+    u32 promote_ok;
+    u32 any_slow;
+    u32 n_created;
+    u32 n_keep;
+};
+
+struct Apply2Args {
+    Cell* table;
+    u32 log2cap;
+    u64 seed;
+    const BHit* b_hits;
+    const Hit* hits;  // the caller's batch: only read for the limit id of a key that has no cell yet
+    const LimitDev* limits;
+    u64 now;
+    uint8_t* verdict;
+    int32_t* first_limited;
+    Status* st;
+    HotSet* hot_next;
+    const HotParam* hot_param;
+    const unsigned short* chunk_tab;  // hot chunk -> index of its hot bucket
+    u32 hot_threshold;
+    u32 dbg;  // RL_DEBUG_APPLY2 (timing experiments only): 1 no ticket, 2 no verdict stores, 4 no write-back, 8 no cell reads
+};
+
+__device__ __forceinline__ LimitDev limit_row2(const Apply2Args& A, u32 limit) {
+    // 16 bytes, L1/L2-resident; ids were range-checked by k_bkt_hist
+    const uint4 v = *reinterpret_cast<const uint4*>(&A.limits[limit & ~SIMPLE_FLAG]);
+    LimitDev L;
+    L.max_value = ((u64)v.y << 32) | v.x;
+    L.window_us = ((u64)v.w << 32) | v.z;
+    return L;
+}
+
+__device__ __forceinline__ u32 agg_count(u64 agg) {
+    const u32 c4 = (u32)(agg >> 32);
+    return (c4 & 0xFFu) + ((c4 >> 8) & 0xFFu) + ((c4 >> 16) & 0xFFu) + (c4 >> 24);
+}
+
+// Write the dirty LDS cells back; optionally rebuild the LDS hash keeping only the hot entries.
+// Ends with every thread past a barrier when `rebuild`.
+template <int HPT, int ENT_LOG2>
+__device__ __forceinline__ void apply2_commit(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, bool rebuild) {
+    constexpr int E = 1 << ENT_LOG2;
+    constexpr int PER = E / AP_BLOCK;
+    constexpr int KEEP = Apply2Lds<HPT, ENT_LOG2>::KEEP;
+    u64 k_key[PER], k_run[PER];
+    u32 k_slot[PER], k_limit[PER], k_flags[PER];
+    bool keep[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 e = threadIdx.x + q * AP_BLOCK;
+        keep[q] = false;
+        const u64 key = S.key[e];
+        if (key == TAG_EMPTY) continue;
+        u32 f = S.flags[e];
+        // promote: the key absorbed hot_threshold hits, or it is what made this bucket long
+        if (!rebuild && !(f & EF_BAD) && S.promote_ok &&
+            ((f >> EF_COUNT_SHIFT) >= A.hot_threshold ||
+             ((f >> EF_COUNT_SHIFT) >= A.hot_threshold / 4 && S.bucket_len >= HOT_LONG_BUCKET))) {
+            const u32 pos = atomicAdd(&A.hot_next->n, 1u);
+            if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = key;
+        }
+        if ((f & EF_DIRTY) && !(A.dbg & 4u)) {
+            Cell* c = &A.table[S.slot[e]];
+            const LimitDev L = limit_row2(A, S.limit[e]);
+            c->value = S.run[e];
+            if (f & EF_EXPIRED) c->expiry = A.now + L.window_us;  // update_if_expired, atomic_expiring_value.rs:87-99
+            // the window is open again — except a 0-second one, which is expired at every read
+            if (L.window_us != 0) f &= ~EF_EXPIRED;
+            f &= ~EF_DIRTY;
+        }
+        if (rebuild && (f >> EF_COUNT_SHIFT) >= EF_HOT_MIN && !(f & EF_BAD)) {
+            keep[q] = true;
+            k_key[q] = key;
+            k_run[q] = S.run[e];
+            k_slot[q] = S.slot[e];
+            k_limit[q] = S.limit[e];
+            k_flags[q] = f;
+        }
+    }
+    if (!rebuild) return;  // end of the bucket: the workgroup is done with its LDS cells
+    if (threadIdx.x == 0) S.n_keep = 0;
+    __syncthreads();
+    u32 nk = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) nk += keep[q] ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) nk += __shfl_down(nk, off);
+    if ((threadIdx.x & 63u) == 0 && nk) atomicAdd(&S.n_keep, nk);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 e = threadIdx.x + q * AP_BLOCK;
+        S.key[e] = TAG_EMPTY;
+        S.flags[e] = 0;
+    }
+    __syncthreads();
+    const bool reinsert = S.n_keep <= (u32)KEEP;
+    if (reinsert) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (!keep[q]) continue;
+            u32 e = (u32)(fmix64(k_key[q] ^ A.seed) >> 20) & (E - 1);
+            while (atomicCAS(&S.key[e], TAG_EMPTY, k_key[q]) != TAG_EMPTY) e = (e + 1) & (E - 1);
+            S.run[e] = k_run[q];
+            S.slot[e] = k_slot[q];
+            S.limit[e] = k_limit[q];
+            S.flags[e] = k_flags[q];
+        }
+    }
+    if (threadIdx.x == 0) S.n_ent = reinsert ? S.n_keep : 0u;
+    __syncthreads();
+}
+
+// One decide/commit round over the hits [first, first + n_items) of the partitioned batch
+// (n_items <= R), in trace order.  Ends with every thread past a barrier.
+template <int HPT, int ENT_LOG2>
+__device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, u32 first,
+                                             u32 n_items) {
+    constexpr int E = 1 << ENT_LOG2;
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63u, w = tid >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    BHit h[HPT];
+    u32 hslot[HPT], climit[HPT];
+    u64 ctag[HPT], cvalue[HPT], cexpiry[HPT];
+    u32 idx[HPT], ent[HPT];
+    bool ok[HPT], creator[HPT], leader[HPT];
+    // ---- the round's inputs: the hits (coalesced), then every hit's home cell (one 32-byte read) --
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        const u32 p = tid * HPT + u;
+        ok[u] = p < n_items;
+        creator[u] = leader[u] = false;
+        ent[u] = 0;
+        if (ok[u]) h[u] = load_bhit(A.b_hits, first + p);
+    }
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        idx[u] = ok[u] ? (h[u].idx_tag & 0xFFFFFFu) : 0u;
+        if (!ok[u]) continue;
+        hslot[u] = slot_of(h[u].key, A.seed, A.log2cap);
+        const Cell* c = &A.table[(A.dbg & 8u) ? (hslot[u] & 0xFFFu) : hslot[u]];
+        const uint4 a = *reinterpret_cast<const uint4*>(c);
+        const uint4 b = reinterpret_cast<const uint4*>(c)[1];  // expiry, limit
+        ctag[u] = ((u64)a.y << 32) | a.x;
+        cvalue[u] = ((u64)a.w << 32) | a.z;
+        cexpiry[u] = ((u64)b.y << 32) | b.x;
+        climit[u] = b.z;
+    }
+    // ---- A: find or claim the key's LDS cell, add this hit to the round's aggregates ------------
+    u32 n_new = 0;
+    u64 first_key[HPT];
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        ent[u] = ok[u] ? (u32)(fmix64(h[u].key ^ A.seed) >> 20) & (E - 1) : 0u;
+        first_key[u] = ok[u] ? S.key[ent[u]] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        if (!ok[u]) continue;
+        u32 e = ent[u];
+        u64 prev = first_key[u];
+        for (;;) {
+            // a plain read first: the lanes that repeat a key already in LDS do not queue up on a CAS
+            if (prev == TAG_EMPTY) prev = atomicCAS(&S.key[e], TAG_EMPTY, h[u].key);
+            if (prev == TAG_EMPTY) {
+                creator[u] = true;
+                ++n_new;
+                break;
+            }
+            if (prev == h[u].key) break;
+            e = (e + 1) & (E - 1);
+            prev = S.key[e];
+        }
+        ent[u] = e;
+    }
+    u64 before[HPT];
+    u32 seen_dmax[HPT];
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        const u32 p = tid * HPT + u;
+        before[u] = ~0ull;
+        seen_dmax[u] = 0;
+        if (!ok[u]) {
+            S.h_ent[p] = (unsigned short)ENT_NONE;
+            continue;
+        }
+        const u32 d = h[u].delta;
+        // ONE atomic: this wave's hit count (8 bits per wave) and the delta (32-bit sum field)
+        before[u] = atomicAdd(&S.agg[ent[u]], (1ull << (32 + 8 * w)) | (u64)(d < AP2_BIG_DELTA ? d : 0u));
+        seen_dmax[u] = S.dmax[ent[u]];
+        S.h_ent[p] = (unsigned short)ent[u];
+        S.h_delta[p] = d;
+    }
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        if (!ok[u]) continue;
+        if (h[u].delta > seen_dmax[u]) atomicMax(&S.dmax[ent[u]], h[u].delta);  // only a new maximum is an atomic
+        leader[u] = (before[u] >> 32) == 0ull;  // the round's first arriver on this key
+    }
+    for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off);
+    if (lane == 0 && n_new) atomicAdd(&S.n_ent, n_new);
+    // ---- B: the claimer of a new LDS cell resolves the counter cell -------------------------------
+    u32 created = 0;
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        if (!creator[u]) continue;
+        const u32 e = ent[u];
+        u32 slot = hslot[u];
+        u64 value = cvalue[u], expiry = cexpiry[u];
+        u32 cl = climit[u];
+        if (ctag[u] != h[u].key) {
+            // Not at home: probe on, fetching whole cells so that a match needs no further read; the
+            // limit id (caller's batch) is only read when the cell has to be created (in_memory.rs:122-127).
+            const u32 mask = (1u << A.log2cap) - 1u;
+            u64 tag = ctag[u];
+            bool done = false, missing_simple = false;
+            for (u32 step = 0; step <= mask; ++step) {
+                if (tag == TAG_EMPTY) {
+                    const u32 hl = A.hits[idx[u]].limit;
+                    if (hl & SIMPLE_FLAG) {  // in_memory.rs:106-107: a simple counter must pre-exist
+                        missing_simple = true;
+                        break;
+                    }
+                    const u64 old = atomicCAS(&A.table[slot].tag, TAG_EMPTY, h[u].key);
+                    if (old == TAG_EMPTY || old == h[u].key) {
+                        Cell* c = &A.table[slot];
+                        if (old == TAG_EMPTY) {  // AtomicExpiringValue::new(0, now + window), in_memory.rs:123-125
+                            c->value = 0;
+                            c->expiry = A.now + limit_row2(A, hl).window_us;
+                            c->limit = hl;
+                            ++created;
+                        }
+                        value = c->value;
+                        expiry = c->expiry;
+                        cl = c->limit;
+                        done = true;
+                        break;
+                    }
+                    // somebody else's key landed here first: keep probing
+                }
+                slot = (slot + 1) & mask;
+                const Cell* c = &A.table[slot];
+                const uint4 a = *reinterpret_cast<const uint4*>(c);
+                const uint4 b = reinterpret_cast<const uint4*>(c)[1];
+                tag = ((u64)a.y << 32) | a.x;
+                if (tag == h[u].key) {
+                    value = ((u64)a.w << 32) | a.z;
+                    expiry = ((u64)b.y << 32) | b.x;
+                    cl = b.z;
+                    done = true;
+                    break;
+                }
+            }
+            if (!done) {
+                atomicOr(&A.st->err, missing_simple ? ERRBIT_MISSING_SIMPLE : ERRBIT_TABLE_FULL);
+                slot = SLOT_INVALID;
+                value = 0;
+                expiry = 0;
+            }
+        }
+        const bool expired = expiry <= A.now;
+        S.run[e] = expired ? 0ull : value;  // value_at(now), atomic_expiring_value.rs:19-24
+        S.slot[e] = slot;
+        S.limit[e] = cl;
+        S.flags[e] = (expired ? EF_EXPIRED : 0u) | (slot == SLOT_INVALID ? EF_BAD : 0u);
+    }
+    if (created) atomicAdd(&S.n_created, created);
+    __syncthreads();
+    // ---- C: verdicts -------------------------------------------------------------------------------
+    uint8_t v[HPT];
+    bool need_rank[HPT], slow[HPT];
+    u64 room[HPT];
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        v[u] = 1;
+        need_rank[u] = slow[u] = false;
+        room[u] = 0;
+        if (!ok[u]) continue;
+        const u32 e = ent[u];
+        const u32 el = S.limit[e];
+        if (limit_fold(el) != (h[u].idx_tag >> 24)) {
+            atomicOr(&S.flags[e], EF_BAD);
+            atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
+            continue;
+        }
+        const LimitDev Lu = limit_row2(A, el);
+        const u64 run = S.run[e], agg = S.agg[e];
+        const u64 sum = agg & 0xFFFFFFFFull;
+        const u64 cnt = agg_count(agg);
+        const u32 dm = S.dmax[e];
+        const u64 d = h[u].delta;
+        u64 tot;
+        const bool ovf = __builtin_add_overflow(run, sum, &tot);
+        if (Lu.window_us == 0 || ovf || dm >= AP2_BIG_DELTA) {
+            slow[u] = true;  // every read sees an expired cell / the sum wraps or left the sum field: replay
+        } else if (tot <= Lu.max_value) {
+            v[u] = 0;
+        } else if (run + d > Lu.max_value) {
+            v[u] = 1;
+        } else if (sum == cnt * (u64)dm) {  // all deltas of the round equal (and > 0 here)
+            need_rank[u] = true;
+            room[u] = (Lu.max_value - run) / d;
+        } else {
+            slow[u] = true;
+        }
+        if (slow[u]) {
+            atomicOr(&S.flags[e], EF_SLOW);
+            S.any_slow = 1;
+        }
+    }
+    // trace-order rank among the round's hits on the same key: hits of earlier waves, then
+    // earlier lanes of this wave, then earlier hits of this lane.
+    for (;;) {
+        bool have = false;
+        u32 my_e = 0;
+#pragma unroll
+        for (int u = HPT - 1; u >= 0; --u)
+            if (need_rank[u]) {
+                have = true;
+                my_e = ent[u];
+            }
+        const u64 pend = __ballot(have);
+        if (!pend) break;
+        const u32 e0 = __shfl(my_e, __ffsll((long long)pend) - 1);
+        u32 before_lane = 0;
+#pragma unroll
+        for (int u = 0; u < HPT; ++u) before_lane += (u32)__popcll(__ballot(ok[u] && ent[u] == e0) & lt);
+        const u32 c4 = (u32)(S.agg[e0] >> 32);
+        u32 pre = 0;
+        for (u32 ww = 0; ww < w; ++ww) pre += (c4 >> (8 * ww)) & 0xFFu;
+        u32 mine = 0;
+#pragma unroll
+        for (int u = 0; u < HPT; ++u) {
+            if (need_rank[u] && ent[u] == e0) {
+                v[u] = (u64)(pre + before_lane + mine) < room[u] ? 0 : 1;
+                need_rank[u] = false;
+            }
+            if (ok[u] && ent[u] == e0) ++mine;
+        }
+    }
+    __syncthreads();
+    // ---- slow entries: one lane replays the round in trace order, reference arithmetic -----------
+    if (S.any_slow) {
+        if (tid == 0) {
+            for (u32 p = 0; p < n_items; ++p) {
+                const u32 e = S.h_ent[p];
+                const u32 f = S.flags[e];
+                if (!(f & EF_SLOW) || (f & EF_BAD)) continue;
+                const LimitDev Le = limit_row2(A, S.limit[e]);
+                const u64 d = S.h_delta[p];
+                const u64 cur = Le.window_us == 0 ? 0ull : S.run[e];
+                const u64 sum = cur + d;  // wraps like the reference's release build (in_memory.rs:88)
+                const bool adm = sum <= Le.max_value;
+                if (adm) {
+                    S.run[e] = Le.window_us == 0 ? d : sum;
+                    S.flags[e] = f | EF_DIRTY | (Le.window_us == 0 ? EF_EXPIRED : 0u);
+                }
+                S.h_verdict[p] = adm ? 0 : 1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < HPT; ++u)
+            if (slow[u]) v[u] = S.h_verdict[tid * HPT + u];
+    }
+    // ---- D: the round's first arriver of each key folds the round into `run` --------------------
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        if (!ok[u]) continue;
+        const u32 i = idx[u];
+        if (!(A.dbg & 2u)) A.verdict[i] = v[u];
+        if (A.first_limited) A.first_limited[i] = v[u] ? (int32_t)i : -1;
+        if (!leader[u]) continue;
+        const u32 e = ent[u];
+        u32 f = S.flags[e];
+        const u64 agg = S.agg[e];
+        const u64 cnt = agg_count(agg);
+        if (!(f & (EF_SLOW | EF_BAD))) {
+            const LimitDev Le = limit_row2(A, S.limit[e]);
+            const u64 run = S.run[e], sum = agg & 0xFFFFFFFFull;
+            const u64 dm = S.dmax[e];
+            if (run + sum <= Le.max_value) {  // no overflow here: overflowing rounds are slow
+                S.run[e] = run + sum;
+                f |= EF_DIRTY;
+            } else if (sum == cnt * dm && run + dm <= Le.max_value) {
+                const u64 rm = (Le.max_value - run) / dm;
+                const u64 n_adm = cnt < rm ? cnt : rm;
+                if (n_adm) {
+                    S.run[e] = run + n_adm * dm;
+                    f |= EF_DIRTY;
+                }
+            }
+        }
+        const u32 seen = (f >> EF_COUNT_SHIFT) + (u32)cnt;
+        f = (f & 0xFFu & ~EF_SLOW) | ((seen > 0xFFFFFFu ? 0xFFFFFFu : seen) << EF_COUNT_SHIFT);
+        S.flags[e] = f;
+        S.agg[e] = 0;
+        S.dmax[e] = 0;
+    }
+    if (tid == 0) S.any_slow = 0;
+    __syncthreads();
+}
+
+// Empty LDS cells (all threads; the caller places the barrier).
+template <int HPT, int ENT_LOG2>
+__device__ __forceinline__ void apply2_clear(Apply2Lds<HPT, ENT_LOG2>& S) {
+    constexpr int E = 1 << ENT_LOG2;
+    for (u32 e = threadIdx.x; e < (u32)E; e += AP_BLOCK) {
+        S.key[e] = TAG_EMPTY;
+        S.agg[e] = 0;
+        S.dmax[e] = 0;
+        S.flags[e] = 0;
+    }
+}
+
+// A whole bucket [lo, hi) of the partitioned batch, in trace order, by one workgroup.  The LDS
+// cells must be empty on entry; they are NOT cleared on exit (callers that replay a second bucket
+// clear them again).
+template <int HPT, int ENT_LOG2>
+__device__ __forceinline__ void apply2_bucket(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, u32 lo, u32 hi) {
+    constexpr int R = AP_BLOCK * HPT;
+    constexpr int KEEP = Apply2Lds<HPT, ENT_LOG2>::KEEP;
+    if (threadIdx.x == 0) {
+        S.n_ent = 0;
+        S.any_slow = 0;
+        S.bucket_len = hi - lo;
+    }
+    __syncthreads();
+    for (u32 first = lo; first < hi; first += R) {
+        if (first != lo && S.n_ent > (u32)KEEP) {  // block-uniform (read after the previous round's barrier)
+            __syncthreads();
+            apply2_commit(S, A, true);
+        }
+        apply2_round(S, A, first, (hi - first) < (u32)R ? (hi - first) : (u32)R);
+    }
+    apply2_commit(S, A, false);
+}
+
+// Hot buckets (one key each, see apply_hot in rl_bucket.hpp): chunk c of the fast buckets is decided
+// from positions alone; chunk_tab[c] names its bucket.
+__device__ __forceinline__ void apply2_hot_chunk(const Apply2Args& A, u32 c) {
+    const u32 tid = threadIdx.x;
+    const u32 hb = A.chunk_tab[c];
+    const HotParam hp = A.hot_param[hb];
+    const u32 lo = hp.lo, hi = hp.hi;
+    const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
+    const u64 room = hp.room;
+    const u32 limit = hp.limit;
+#pragma unroll
+    for (int u = 0; u < HOT_CHUNK / AP_BLOCK; ++u) {
+        const u32 j = first + u * AP_BLOCK + tid;
+        if (j >= hi) continue;
+        const BHit h = load_bhit(A.b_hits, j);
+        const u32 i = h.idx_tag & 0xFFFFFFu;
+        uint8_t v = (u64)(j - lo) < room ? 0 : 1;
+        if ((h.idx_tag >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
+            atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
+            v = 1;
+        }
+        if (!(A.dbg & 2u)) A.verdict[i] = v;
+        if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
+    }
+    if (first == lo && tid == 0) {
+        // the bucket's first chunk also applies AtomicExpiringValue::update for the admitted hits
+        const LimitDev L = limit_row2(A, limit);
+        const u64 cnt = hi - lo;
+        const u64 n_adm = cnt < room ? cnt : room;
+        u32 slot = hp.slot;
+        bool expired = hp.expired != 0;
+        if (slot == SLOT_INVALID) {  // first touch creates the cell (in_memory.rs:122-127), verdict or not
+            u32 created = 0;
+            const u64 key = A.b_hits[lo].key;
+            slot = slot_of(key, A.seed, A.log2cap);
+            slot = probe_from<PM_CHECK>(A.table, A.log2cap, slot, A.table[slot].tag, key, limit, A.limits, A.now,
+                                        A.st, created);
+            if (created) atomicAdd(&A.st->n_inserted, created);
+            expired = false;
+        }
+        if (n_adm && slot != SLOT_INVALID) {
+            Cell* cell = &A.table[slot];
+            cell->value = hp.s + n_adm * hp.d;
+            if (expired) cell->expiry = A.now + L.window_us;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_count_new: how many cells would this (already partitioned) batch create?  Same walk as
+// k_bkt_apply2 up to the point where a new key's probe chain ends at an empty slot — counted, not
+// claimed; nothing is written to the table, no verdict is produced.  The host runs it only when the
+// cheap bound "every hit could be a new key" does not fit the table, to decide BEFORE anything is
+// applied whether the batch fits (all-or-nothing under RL_ERR_TABLE_FULL).  Exact per bucket; a key
+// that is dropped by a rebuild of the LDS cells of a long bucket and met again is counted twice
+// (an over-estimate, never an under-estimate).
+// ---------------------------------------------------------------------------------------------
+template <int ENT_LOG2>
+__global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restrict__ table, u32 log2cap, u64 seed,
+                                                            const BHit* __restrict__ b_hits,
+                                                            const uint2* __restrict__ ranges, u32 nb,
+                                                            const HotParam* __restrict__ hot_param,
+                                                            u32* __restrict__ n_new_out) {
+    constexpr int E = 1 << ENT_LOG2;
+    constexpr u32 KEEP = E * 3 / 4 - AP_BLOCK;
+    __shared__ u64 s_key[E];
+    __shared__ u32 s_n_ent, s_new;
+    const u32 tid = threadIdx.x, G = gridDim.x;
+    if (tid == 0) s_new = 0;
+    u32 my_new = 0;
+    auto count_bucket = [&](u32 lo, u32 hi) {
+        __syncthreads();
+        for (u32 e = tid; e < (u32)E; e += AP_BLOCK) s_key[e] = TAG_EMPTY;
+        if (tid == 0) s_n_ent = 0;
+        __syncthreads();
+        for (u32 first = lo; first < hi; first += AP_BLOCK) {
+            if (s_n_ent > KEEP) {  // block-uniform (read after a barrier)
+                __syncthreads();
+                for (u32 e = tid; e < (u32)E; e += AP_BLOCK) s_key[e] = TAG_EMPTY;
+                if (tid == 0) s_n_ent = 0;
+                __syncthreads();
+            }
+            const u32 j = first + tid;
+            bool creator = false;
+            u64 key = 0;
+            if (j < hi) {
+                key = load_bhit(b_hits, j).key;
+                u32 e = (u32)(fmix64(key ^ seed) >> 20) & (E - 1);
+                for (;;) {
+                    u64 prev = s_key[e];
+                    if (prev == TAG_EMPTY) prev = atomicCAS(&s_key[e], TAG_EMPTY, key);
+                    if (prev == TAG_EMPTY) {
+                        creator = true;
+                        break;
+                    }
+                    if (prev == key) break;
+                    e = (e + 1) & (E - 1);
+                }
+            }
+            if (creator) {
+                atomicAdd(&s_n_ent, 1u);
+                const u32 mask = (1u << log2cap) - 1u;
+                u32 slot = slot_of(key, seed, log2cap);
+                for (u32 step = 0; step <= mask; ++step) {
+                    const u64 tag = table[slot].tag;
+                    if (tag == key) break;
+                    if (tag == TAG_EMPTY) {
+                        ++my_new;
+                        break;
+                    }
+                    slot = (slot + 1) & mask;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    const uint2 r = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
+    if (r.x != r.y) count_bucket(r.x, r.y);
+    for (u32 hk = blockIdx.x; hk < (u32)HOT_MAX; hk += G) {
+        const HotParam hp = hot_param[hk];  // (block-uniform)
+        if (hp.hi == hp.lo) continue;
+        if (hp.fast) {  // one key per bucket; k_bkt_scatter looked its cell up
+            if (tid == 0 && hp.slot == SLOT_INVALID) ++my_new;
+        } else {
+            count_bucket(hp.lo, hp.hi);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) my_new += __shfl_down(my_new, off);
+    if ((tid & 63u) == 0 && my_new) atomicAdd(&s_new, my_new);
+    __syncthreads();
+    if (tid == 0 && s_new) atomicAdd(n_new_out, s_new);
+}
+
+template <int HPT, int ENT_LOG2, int MIN_WAVES>
+__global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply2(
+    Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits,
+    const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
+    const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab,
+    const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
+    int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_next, Status* host_status, u32 done_seq,
+    HotSet* hot_next, u32 hot_threshold, u32 dbg) {
+    __shared__ Apply2Lds<HPT, ENT_LOG2> S;
+    const u32 tid = threadIdx.x, G = gridDim.x;
+    Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
+                 hot_next, hot_param, chunk_tab, hot_threshold, dbg};
+    // ranges[] is in processing order (longest buckets first): the hardware hands workgroups out in
+    // index order, so the long buckets start first and the short ones fill the tail
+    const uint2 r = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
+    const u32 n_chunks = hot_param[HOT_MAX].chunk0;
+    apply2_clear(S);
+    if (tid == 0) {
+        S.n_created = 0;
+        S.promote_ok = 1;
+    }
+    __syncthreads();
+    if (r.x != r.y) apply2_bucket(S, A, r.x, r.y);
+    // ---- the hot buckets: fast chunks from positions, the rest replayed by one workgroup each ------
+    for (u32 c = G - 1 - blockIdx.x; c < n_chunks; c += G) apply2_hot_chunk(A, c);
+    for (u32 hk = G - 1 - blockIdx.x; hk < (u32)HOT_MAX; hk += G) {
+        const HotParam hp = hot_param[hk];  // (block-uniform)
+        if (hp.fast || hp.hi == hp.lo) continue;
+        __syncthreads();
+        apply2_clear(S);
+        if (tid == 0) S.promote_ok = 0;  // its key is kept or dropped by count (k_bkt_scatter), not promoted
+        __syncthreads();
+        apply2_bucket(S, A, hp.lo, hp.hi);
+    }
+    // every wave's stores have been acknowledged before the workgroup's ticket is taken
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (dbg & 1u) {  // timing experiment: workgroup 0 reports completion, nobody takes a ticket
+            if (blockIdx.x == 0) apply_finish(0u, bs, bs_next, host_status, done_seq, 1u, &hot_next->n, 0u);
+        } else {
+            apply_finish(S.n_created, bs, bs_next, host_status, done_seq, G, &hot_next->n, 0u, (dbg >> 4) & 3u);
+        }
+    }
+}
+
+}  // namespace rl

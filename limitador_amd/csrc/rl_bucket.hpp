@@ -69,10 +69,17 @@ struct HotSet {
 // Per-batch scratch of the bucketed path.  Two of them alternate: the last workgroup of a batch's
 // k_bkt_apply mirrors the status block to host-mapped memory (no copy command behind the batch) and
 // zeroes the OTHER one for the next batch (no memset command in front of it).
-struct BatchScratch {
+struct alignas(16) BatchScratch {
     Status st;
-    u32 ticket;  // workgroups of k_bkt_apply that have finished
+    u32 ticket;  // ticket shards that are complete
     u32 pad[15];
+    // Workgroups that have finished, counted in 8 shards (blockIdx & 7: one per XCD), each on a line
+    // of its own: same-address device-scope atomics serialise at ~10-30 ns apiece, and one ticket word
+    // taken by 2048 workgroups was 9 us of a 46 us kernel.
+    struct Shard {
+        u32 t;
+        u32 pad[31];
+    } shard[8];
 };
 // What k_bkt_apply needs to decide a hot key's bucket, prepared once per batch by k_bkt_scatter.
 struct HotParam {
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                                                           u32 ntiles, HotParam* __restrict__ hot_param,
                                                           HotSet* __restrict__ hot_next,
                                                           const BatchScratch* __restrict__ bs, u32 hot_threshold,
-                                                          u64* htrace) {
+                                                          unsigned short* __restrict__ chunk_tab, u64* htrace) {
     __shared__ __align__(16) unsigned short s_cnt[PT_WAVES][BKT_MAX];
     __shared__ u32 s_base[BKT_MAX];
     __shared__ u32 s_w[PT_WAVES];
@@ -453,10 +460,24 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
             hot_param[tid] = hp;
         }
         __syncthreads();
+        u32* s_c0 = s_base + 2 * HOT_MAX + 256;  // chunk0[] again, for the chunk table below
         if (tid <= HOT_MAX) {  // chunk0[h] = chunks of the fast buckets before h; entry HOT_MAX = all
             u32 acc = 0;
             for (u32 q = 0; q < tid; ++q) acc += s_nchunk[q];
             hot_param[tid].chunk0 = acc;
+            s_c0[tid] = acc;
+        }
+        __syncthreads();
+        // chunk_tab[c] = the fast bucket that owns chunk c: the LAST h with chunk0[h] <= c (a bucket
+        // without chunks shares its successor's chunk0, so it is never the last one) — k_bkt_apply2
+        for (u32 c = tid; c < s_c0[HOT_MAX]; c += PT_BLOCK) {
+            u32 a = 0, b = HOT_MAX;  // invariant: chunk0[a] <= c < chunk0[b]
+            while (b - a > 1) {
+                const u32 m = (a + b) >> 1;
+                if (s_c0[m] <= c) a = m;
+                else b = m;
+            }
+            chunk_tab[c] = (unsigned short)a;
         }
         if (htrace && tid == 0) htrace[(size_t)2040 * 8 + 1] = wall_clock64();
         return;
@@ -1250,12 +1271,26 @@ __device__ __forceinline__ void apply_hot(ApplyLds& S, const ApplyArgs& A, u32 w
 // block to the host and resets the other scratch.  No agent-scope fence (a release would write the
 // XCD's whole L2 back, once per workgroup): everything the last workgroup reads was written with
 // device-scope atomics, and this workgroup's own contribution has RETURNED before its ticket is taken.
-__device__ __forceinline__ void apply_finish(ApplyLds& S, BatchScratch* bs, BatchScratch* bs_next, Status* host_status,
-                                             u32 done_seq, u32 G, const u32* hot_n_ptr, u32 hot_n) {
+__device__ __forceinline__ void apply_finish(u32 n_created, BatchScratch* bs, BatchScratch* bs_next, Status* host_status,
+                                             u32 done_seq, u32 G, const u32* hot_n_ptr, u32 hot_n, u32 tmode = 0) {
     u32 dep = 0;
-    if (S.n_created) dep = atomicAdd(&bs->st.n_inserted, S.n_created);
+    if (n_created) dep = atomicAdd(&bs->st.n_inserted, n_created);
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(dep) : "memory");
-    if (atomicAdd(&bs->ticket, 1u) == G - 1) {
+    bool last;
+    if (tmode == 1) {  // (experiment) one ticket word
+        last = atomicAdd(&bs->ticket, 1u) == G - 1;
+    } else if (tmode == 2) {  // (experiment) shards by consecutive runs of workgroups
+        const u32 per = (G + 7u) >> 3, shard = blockIdx.x / per;
+        const u32 n_in_shard = (shard + 1) * per <= G ? per : G - shard * per;
+        const u32 n_shards = (G + per - 1) / per;
+        last = atomicAdd(&bs->shard[shard].t, 1u) == n_in_shard - 1 && atomicAdd(&bs->ticket, 1u) == n_shards - 1;
+    } else {
+        const u32 shard = blockIdx.x & 7u;
+        const u32 n_in_shard = (G + 7u - shard) >> 3;  // workgroups b < G with (b & 7) == shard
+        last = atomicAdd(&bs->shard[shard].t, 1u) == n_in_shard - 1 &&
+               atomicAdd(&bs->ticket, 1u) == (G < 8u ? G : 8u) - 1;
+    }
+    if (last) {
         Status out{};
         out.err = __hip_atomic_load(&bs->st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         out.n_inserted = __hip_atomic_load(&bs->st.n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1273,7 +1308,11 @@ __device__ __forceinline__ void apply_finish(ApplyLds& S, BatchScratch* bs, Batc
         for (int q = 1; q < 4; ++q) hp[q] = u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, hp);
-        *bs_next = BatchScratch{};
+        // the other scratch, zeroed for the next batch: explicit 16-byte stores (the plain assignment of
+        // a 1 KB struct compiles to a byte loop: 15 us on one lane)
+        u32x4* z = reinterpret_cast<u32x4*>(bs_next);
+#pragma unroll 8
+        for (u32 q = 0; q < (u32)(sizeof(BatchScratch) / 16); ++q) z[q] = u32x4{0, 0, 0, 0};
     }
 }
 
@@ -1360,7 +1399,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_apply(
     apply_hot(S, A, G - 1 - blockIdx.x, G);
     RL_STAMP(14);
     __syncthreads();
-    if (tid == 0) apply_finish(S, bs, bs_next, host_status, done_seq, G, &hot_next->n, 0u);
+    if (tid == 0) apply_finish(S.n_created, bs, bs_next, host_status, done_seq, G, &hot_next->n, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1425,7 +1464,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
     // have been acknowledged before the completion word is written
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) apply_finish(S, bs, bs_next, host_status, done_seq, 1u, nullptr, hot_n_report);
+    if (tid == 0) apply_finish(S.n_created, bs, bs_next, host_status, done_seq, 1u, nullptr, hot_n_report);
 }
 
 }  // namespace rl

@@ -26,6 +26,7 @@
 #include "rl_kernels.hpp"
 #include "rl_ordered.hpp"
 #include "rl_bucket.hpp"
+#include "rl_apply2.hpp"
 #include "rl_general.hpp"
 #include "rl_route.hpp"
 #include "rl_match.hpp"
@@ -88,6 +89,7 @@ struct rl_engine {
         u32 n = 0, n_wg = 0, ntiles = 0;
         int timed = 0;
         u32 seq = 0;  // value the batch's last workgroup stores into h_st->n_removed
+        bool settled = false;  // completion seen and its new cells already added to `live` (settle_inflight)
     } inflight[2];
     u64 sub_seq = 0, col_seq = 0;
     u64 inflight_hits = 0;
@@ -116,6 +118,10 @@ struct rl_engine {
     u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
     u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
     BHit* d_bk_hits = nullptr;
+    unsigned short* d_chunk_tab = nullptr;  // hot chunk -> hot bucket (k_bkt_scatter -> k_bkt_apply2)
+    int apply_gen = 2;      // RL_APPLY=1: the persistent first cut (k_bkt_apply); 2 (default): k_bkt_apply2
+    u32 dbg_apply2 = 0;     // RL_DEBUG_APPLY2 (timing experiments only)
+    int apply2_cfg = 0;     // RL_APPLY2_CFG: which instantiation of k_bkt_apply2 (see launch_apply2)
 
     // on-device limit matching (rl_match.hpp)
     MatchLimit* d_match_limits = nullptr;
@@ -213,31 +219,53 @@ bool grow_instead(rl_engine* e, int* rc) {
     return *rc == RL_OK;
 }
 
-int check_room(rl_engine* e, u64 incoming) {
-    // Linear probing stays short while (live + tombstones) <= 3/4 capacity.  Refuse new work once
-    // the table is past that, and refuse a batch that could not fit even if every hit were a new
-    // key; in between, the probe loop's own bound reports RL_ERR_TABLE_FULL if it ever runs out.
+int check_room(rl_engine* e, u64 incoming, bool* need_count = nullptr) {
+    // All-or-nothing for every mutating call: the kernels commit as they go, so a call must never run out
+    // of table half-way.  A call is accepted only if
+    //   (live + tombstones) <= 3/4 capacity                  (linear probing stays short), and
+    //   (live + tombstones) + new keys <= 15/16 capacity     (every probe ends at an empty slot),
+    // so RL_ERR_TABLE_FULL is only ever answered HERE or by the caller's exact count, before anything is
+    // applied.  "new keys" is first bounded by `incoming` (every hit / row could bring a new key); when that
+    // bound does not fit, a caller that can count exactly passes `need_count` and runs k_bkt_count_new on the
+    // partitioned batch (the single-counter path), everything else is refused on the bound.  With
+    // RL_CFG_AUTO_GROW the table is doubled as soon as used + incoming would pass 3/4 (only possible while
+    // no batch is in flight).
+    if (need_count) *need_count = false;
     for (int rc = RL_OK;;) {
         const u64 used = e->live + e->tombs;
-        // (auto-grow: room for every incoming hit to be a new key, so that no batch can fill the table
-        // half-way through — the one failure that leaves a batch partially applied)
+        const bool low = used <= e->cap - e->cap / 4;
+        const bool fits = low && used + incoming <= e->cap - e->cap / 16;
         const bool grow_now = e->auto_grow && used + incoming > e->cap - e->cap / 4;
-        if (!grow_now &&
-            !(used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap))
-            return RL_OK;
+        if (fits && !grow_now) return RL_OK;
         if (grow_instead(e, &rc)) continue;
-        if (grow_now && !rc && !(used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap))
-            return RL_OK;  // could not grow right now (a batch is in flight): the plain bound still holds
         if (rc) return rc;
-        break;
-    }
-    const u64 used = e->live + e->tombs;
-    {
+        if (fits) return RL_OK;  // could not grow right now (a batch is in flight): the plain bound still holds
+        if (low && need_count) {
+            *need_count = true;
+            return RL_OK;
+        }
         return fail(e, RL_ERR_TABLE_FULL,
-                    "table past 75%% occupancy (live=%llu tombstones=%llu incoming<=%llu capacity=%llu): "
-                    "sweep, compact or create a larger engine",
-                    (unsigned long long)e->live, (unsigned long long)e->tombs,
-                    (unsigned long long)incoming, (unsigned long long)e->cap);
+                    "refused, nothing applied: %llu incoming hits could push the table past its occupancy bound "
+                    "(live=%llu tombstones=%llu capacity=%llu): rl_resize, sweep, compact or create a larger engine",
+                    (unsigned long long)incoming, (unsigned long long)e->live, (unsigned long long)e->tombs,
+                    (unsigned long long)e->cap);
+    }
+}
+
+// The first-generation pipelines (general resolver, update_counter, RL_K1_PATH=legacy) create cells while
+// they probe and keep the round-1 occupancy heuristic until they are replaced by bucketed forms.
+int check_room_lenient(rl_engine* e, u64 incoming) {
+    for (int rc = RL_OK;;) {
+        const u64 used = e->live + e->tombs;
+        const bool grow_now = e->auto_grow && used + incoming > e->cap - e->cap / 4;
+        const bool ok = !(used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap);
+        if (ok && !grow_now) return RL_OK;
+        if (grow_instead(e, &rc)) continue;
+        if (rc) return rc;
+        if (ok) return RL_OK;
+        return fail(e, RL_ERR_TABLE_FULL, "table past 75%% occupancy (live=%llu tombstones=%llu incoming<=%llu capacity=%llu)",
+                    (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)incoming,
+                    (unsigned long long)e->cap);
     }
 }
 
@@ -291,7 +319,7 @@ int run_ordered(rl_engine* e, const Hit* d_hits, u32 n_ord, u64 now, uint8_t* d_
 // check_and_update for single-counter requests, all pointers on the device: first-generation
 // pipeline (kept for A/B measurement, RL_K1_PATH=legacy).
 int run_check_k1_legacy(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
-    int rc = check_room(e, n);
+    int rc = check_room_lenient(e, n);
     if (rc) return rc;
     const bool t = e->timing;
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
@@ -465,28 +493,71 @@ int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
     return RL_OK;
 }
 
+// Spin until the batch's last workgroup has stored its sequence number (see apply_finish).
+int wait_done(rl_engine* e, rl_engine::Inflight& f) {
+    const volatile u32* done = &f.h_st->n_removed;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (u64 spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != f.seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0xFFFFu) {
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                return fail(e, RL_ERR_DEVICE, "batch %u did not complete within 60 s", f.seq);
+            std::this_thread::yield();
+        }
+    }
+    return RL_OK;
+}
+
+// Wait for every batch in flight and add the cells they created to `live` now (their status is still
+// handed out by rl_check_and_update_collect): used when a new batch needs the exact occupancy.
+int settle_inflight(rl_engine* e) {
+    for (u64 q = e->col_seq; q < e->sub_seq; ++q) {
+        rl_engine::Inflight& f = e->inflight[q & 1u];
+        if (f.settled) continue;
+        const int rc = wait_done(e, f);
+        if (rc) return rc;
+        e->live += f.h_st->n_inserted;
+        e->inflight_hits -= f.n;
+        f.settled = true;
+    }
+    return RL_OK;
+}
+
+// k_bkt_apply2 in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD>.
+void launch_apply2(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u64 now, uint8_t* d_verdict, int32_t* d_first,
+                   BatchScratch* bs, BatchScratch* bs_next, Status* h_st, u32 seq, HotSet* hot_next) {
+#define RL_AP2(HPT, EL, MW)                                                                                        \
+    k_bkt_apply2<HPT, EL, MW><<<n_wg, AP_BLOCK, 0, e->stream>>>(                                                   \
+        e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits, e->d_bk_ranges, nb, e->d_hot_param, e->d_chunk_tab,   \
+        e->d_limits, now, d_verdict, d_first, bs, bs_next, h_st, seq, hot_next, e->hot_threshold, e->dbg_apply2)
+    switch (e->apply2_cfg) {
+        default:
+        case 0: RL_AP2(1, 9, 6); break;
+        case 1: RL_AP2(1, 9, 4); break;
+        case 2: RL_AP2(1, 10, 3); break;
+        case 3: RL_AP2(2, 10, 3); break;
+        case 4: RL_AP2(2, 10, 2); break;
+        case 5: RL_AP2(1, 9, 5); break;
+        case 6: RL_AP2(1, 9, 7); break;
+    }
+#undef RL_AP2
+}
+
 // Enqueue one batch of the bucketed path on the engine's stream (no host synchronisation).
 int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
     if (e->sub_seq - e->col_seq >= 2) return fail(e, RL_ERR_BUSY, "two batches are already in flight: collect one first");
-    int rc = check_room(e, n + e->inflight_hits);
+    bool need_count = false;
+    int rc = check_room(e, n + e->inflight_hits, &need_count);
     if (rc) return rc;
-    // k_bkt_apply commits as it goes, so a table that fills up mid-batch (RL_ERR_TABLE_FULL from the
-    // probe loop) leaves the batch partially applied; keep a margin so that only a batch bringing
-    // more than capacity/4 NEW keys into an almost full table can get there.
-    for (;;) {
-        const u64 inc0 = (u64)n + e->inflight_hits;
-        const u64 used = e->live + e->tombs, inc = inc0 < e->cap / 4 ? inc0 : e->cap / 4;
-        if (used + inc <= e->cap - e->cap / 16) break;
-        if (grow_instead(e, &rc)) continue;
+    if (need_count && e->sub_seq != e->col_seq) {
+        // the exact count needs the exact occupancy: let the batches in flight finish first
+        rc = settle_inflight(e);
+        if (!rc) rc = check_room(e, n + e->inflight_hits, &need_count);
         if (rc) return rc;
-        return fail(e, RL_ERR_TABLE_FULL,
-                        "batch of %u hits could push the table past 15/16 occupancy (live=%llu tombstones=%llu "
-                        "capacity=%llu): sweep, compact or create a larger engine",
-                        n, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
     }
     rl_engine::Inflight& f = e->inflight[e->sub_seq & 1u];
     const bool t = e->timing == 1;  // events between all four kernels
-    if (n <= e->tiny_max) {
+    if (n <= e->tiny_max && !need_count) {
         // one launch: the batch is one bucket (k_bkt_tiny); the hot set is left untouched
         BatchScratch* tbs = e->d_bs + e->bs_cur;
         BatchScratch* tbs_next = e->d_bs + (e->bs_cur ^ 1u);
@@ -507,6 +578,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         f.ntiles = 0;
         f.timed = t_tiny ? (e->timing == 1 ? 1 : 2) : 0;
         f.seq = (u32)(e->sub_seq + 1);
+        f.settled = false;
         e->inflight_hits += n;
         e->sub_seq++;
         return RL_OK;
@@ -536,19 +608,48 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     scatter_k<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
                                                           hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
                                                           e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
-                                                          hot_next, bs, e->hot_threshold,
+                                                          hot_next, bs, e->hot_threshold, e->d_chunk_tab,
                                                           e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 : nullptr);
+    if (need_count) {
+        // the cheap bound (every hit a new key) does not fit: count the batch's new keys exactly, before
+        // anything is applied, and refuse the whole batch if they do not fit
+        u32 n_new = 0;
+        HIP_TRY(e, hipMemsetAsync(e->d_m_flags, 0, sizeof(u32), e->stream));
+        k_bkt_count_new<10><<<nb < 64u ? 64u : nb, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits,
+                                                                         e->d_bk_ranges, nb, e->d_hot_param, e->d_m_flags);
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_m_flags, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        n_new = e->h_m_total[0];
+        if (e->live + e->tombs + n_new > e->cap - e->cap / 16) {
+            // leave the engine as it was: this batch's scratch goes back (clean) to the next batch
+            e->bs_cur ^= 1u;
+            HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            return fail(e, RL_ERR_TABLE_FULL,
+                        "refused, nothing applied: the batch brings %u new keys into a table with live=%llu "
+                        "tombstones=%llu capacity=%llu (bound 15/16): rl_resize, sweep, compact or create a larger engine",
+                        n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
+        }
+    }
     const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
     if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
-    u32 n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
-    if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
-    if (n_wg > nb && nb >= 64) n_wg = nb;
-    // the last workgroup of k_bkt_apply writes the status block straight into f.h_st (host-mapped)
-    k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
-                                                  e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
-                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, bs, bs_next,
-                                                  f.h_st, (u32)(e->sub_seq + 1), hot_next, e->hot_threshold,
-                                                  e->dbg_vmask, e->d_bk_trace);
+    u32 n_wg;
+    if (e->apply_gen == 2) {
+        // one workgroup per hash bucket (at least 64, so that the hot chunks of a small batch still spread)
+        n_wg = nb < 64u ? 64u : nb;
+        launch_apply2(e, n_wg, d_hits, nb, now, d_verdict, d_first, bs, bs_next, f.h_st, (u32)(e->sub_seq + 1), hot_next);
+    } else {
+        n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
+        if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
+        if (n_wg > nb && nb >= 64) n_wg = nb;
+        // the last workgroup of k_bkt_apply writes the status block straight into f.h_st (host-mapped)
+        k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
+                                                      e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
+                                                      (u32)e->h_limits.size(), now, d_verdict, d_first, bs, bs_next,
+                                                      f.h_st, (u32)(e->sub_seq + 1), hot_next, e->hot_threshold,
+                                                      e->dbg_vmask, e->d_bk_trace);
+    }
     if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
     HIP_TRY(e, hipGetLastError());
     f.n = n;
@@ -556,6 +657,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     f.ntiles = ntiles;
     f.timed = t_apply ? (e->timing == 1 ? 1 : 2) : 0;
     f.seq = (u32)(e->sub_seq + 1);
+    f.settled = false;
     e->inflight_hits += n;
     e->sub_seq++;
     return RL_OK;
@@ -565,22 +667,19 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 int collect_k1_bucketed(rl_engine* e) {
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
     rl_engine::Inflight& f = e->inflight[e->col_seq & 1u];
-    {
-        // the batch's last workgroup stores its sequence number with the first 16 bytes of the status block
-        const volatile u32* done = &f.h_st->n_removed;
-        const auto t_start = std::chrono::steady_clock::now();
-        for (u64 spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != f.seq; ++spins) {
-            __builtin_ia32_pause();
-            if ((spins & 0xFFFFu) == 0xFFFFu) {
-                if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
-                    return fail(e, RL_ERR_DEVICE, "batch %u did not complete within 60 s", f.seq);
-                std::this_thread::yield();
-            }
+    if (!f.settled) {
+        const int wrc = wait_done(e, f);
+        if (wrc) {
+            // give the slot up (a stuck batch must not leave the engine RL_ERR_BUSY for ever); the table's
+            // state is unknown from here on, which is what the device error tells the caller
+            e->col_seq++;
+            e->inflight_hits -= f.n;
+            return wrc;
         }
+        e->inflight_hits -= f.n;
+        e->live += f.h_st->n_inserted;
     }
     e->col_seq++;
-    e->inflight_hits -= f.n;
-    e->live += f.h_st->n_inserted;
     // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
     if (f.h_st->pad[2] > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
     else if (f.h_st->pad[2] < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
@@ -627,7 +726,7 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
         const int crc = do_compact(e, 0);
         if (crc) return crc;
     }
-    int rc = check_room(e, n_hits);
+    int rc = check_room_lenient(e, n_hits);
     if (rc) return rc;
     if (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ) {
         // A few requests (the per-request calls of the trait): one workgroup, one launch (k_gen_tiny),
@@ -819,6 +918,9 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     if (const char* v = getenv("RL_K1_PATH")) e->legacy_k1 = strcmp(v, "legacy") == 0;
+    if (const char* v = getenv("RL_APPLY")) e->apply_gen = atoi(v) == 1 ? 1 : 2;
+    if (const char* v = getenv("RL_APPLY2_CFG")) e->apply2_cfg = atoi(v);
+    if (const char* v = getenv("RL_DEBUG_APPLY2")) e->dbg_apply2 = (u32)strtoul(v, nullptr, 0);
     if (const char* v = getenv("RL_DEBUG_VMASK")) e->dbg_vmask = (u32)strtoul(v, nullptr, 0);
     if (const char* v = getenv("RL_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
@@ -897,6 +999,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
                 return bail(RL_ERR_DEVICE);
         }
     ALLOC(e->d_bk_hits, mb * sizeof(BHit));
+    ALLOC(e->d_chunk_tab, ((size_t)mb / HOT_CHUNK + HOT_MAX + 8) * sizeof(unsigned short));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
     ALLOC(e->d_m_ns, mb * sizeof(u32));
     ALLOC(e->d_m_delta, mb * sizeof(u32));
@@ -959,7 +1062,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_remaining, e->d_expires, e->d_hit_slot, e->d_ord_list, e->d_keys_a,  e->d_keys_b,
                     e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp,
-                    e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_trace,
+                    e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_trace, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp};
@@ -1192,7 +1295,7 @@ int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hit
     if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
-    rc = check_room(e, n_hits);
+    rc = check_room_lenient(e, n_hits);
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));

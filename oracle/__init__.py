@@ -76,6 +76,8 @@ def lib():
         L.lo_peek_simple.argtypes = [p, u32, C.POINTER(Cell)]
         L.lo_load_qualified.argtypes = [p, p, p, p, p, C.c_size_t]
         L.lo_check_and_update_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, p, C.c_size_t, u64, i32, p, p, p, p]
+        L.lo_check_and_update_batch_ex.argtypes = [p, p, C.c_size_t, p, C.c_size_t, p, C.c_size_t, p, p, u64, i32, p, p,
+                                                   p, p]
         L.lo_is_within_limits_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, u64, p]
         L.lo_update_counter_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, u64]
         _lib = L
@@ -127,7 +129,10 @@ class OracleStorage:
         if rc < 0:
             raise OracleError(rc)
 
-    def check_and_update(self, hits, now_us, req_off=None, load_counters=False, want_first_limited=True):
+    def check_and_update(self, hits, now_us, req_off=None, load_counters=False, want_first_limited=True,
+                         req_delta=None, req_now_us=None):
+        """req_delta: per-request u64 deltas (in_memory.rs:75) replacing the 32-bit wire field;
+        req_now_us: per-request clock values replacing now_us."""
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
         n_hits = hits.shape[0]
         if req_off is not None:
@@ -135,13 +140,20 @@ class OracleStorage:
             n_req = req_off.shape[0] - 1
         else:
             n_req = n_hits
+        if req_delta is not None:
+            req_delta = np.ascontiguousarray(req_delta, dtype=np.uint64)
+            assert req_delta.shape[0] == n_req
+        if req_now_us is not None:
+            req_now_us = np.ascontiguousarray(req_now_us, dtype=np.uint64)
+            assert req_now_us.shape[0] == n_req
         verdict = np.empty(n_req, dtype=np.uint8)
         first = np.empty(n_req, dtype=np.int32)
         remaining = np.zeros(n_hits, dtype=np.uint64) if load_counters else None
         expires = np.zeros(n_hits, dtype=np.uint64) if load_counters else None
-        rc = self.L.lo_check_and_update_batch(self.h, _ptr(self.limits), self.limits.shape[0], _ptr(hits), n_hits,
-                                              _ptr(req_off), n_req, int(now_us), int(bool(load_counters)),
-                                              _ptr(verdict), _ptr(first), _ptr(remaining), _ptr(expires))
+        rc = self.L.lo_check_and_update_batch_ex(self.h, _ptr(self.limits), self.limits.shape[0], _ptr(hits), n_hits,
+                                                 _ptr(req_off), n_req, _ptr(req_delta), _ptr(req_now_us), int(now_us),
+                                                 int(bool(load_counters)), _ptr(verdict), _ptr(first),
+                                                 _ptr(remaining), _ptr(expires))
         if rc < 0:
             raise OracleError(rc)
         return verdict, (first if want_first_limited else None), remaining, expires

@@ -444,6 +444,19 @@ int lo_check_and_update_batch(lo_storage *s, const lo_limit_row *limits, size_t 
                               size_t n_req, uint64_t now_us, int load_counters, uint8_t *verdict,
                               int32_t *first_limited, uint64_t *remaining,
                               uint64_t *expires_in_us) {
+    return lo_check_and_update_batch_ex(s, limits, n_limits, hits, n_hits, req_off, n_req, NULL, NULL, now_us,
+                                        load_counters, verdict, first_limited, remaining, expires_in_us);
+}
+
+/* The same with the reference's full-width arguments: req_delta[r] (may be NULL) is the request's
+ * u64 delta (in_memory.rs:75 `delta: u64`) instead of the 32-bit wire field; req_now_us[r] (may be
+ * NULL) is the clock value request r reads (in_memory.rs:83 reads it once per call). */
+int lo_check_and_update_batch_ex(lo_storage *s, const lo_limit_row *limits, size_t n_limits,
+                                 const lo_hit *hits, size_t n_hits, const uint32_t *req_off,
+                                 size_t n_req, const uint64_t *req_delta, const uint64_t *req_now_us,
+                                 uint64_t now_us, int load_counters, uint8_t *verdict,
+                                 int32_t *first_limited, uint64_t *remaining,
+                                 uint64_t *expires_in_us) {
     enum { STACK_N = 64 };
     lo_counter stack_ctrs[STACK_N];
     for (size_t r = 0; r < n_req; r++) {
@@ -464,7 +477,8 @@ int lo_check_and_update_batch(lo_storage *s, const lo_limit_row *limits, size_t 
                 return -1;
             }
         int64_t lim = -1;
-        int rc = lo_check_and_update(s, ctrs, k, hits[b].delta, load_counters, now_us, &lim);
+        int rc = lo_check_and_update(s, ctrs, k, req_delta ? req_delta[r] : (uint64_t)hits[b].delta, load_counters,
+                                     req_now_us ? req_now_us[r] : now_us, &lim);
         if (rc < 0) {
             if (ctrs != stack_ctrs) free(ctrs);
             return rc;

@@ -25,6 +25,14 @@
  *     u64 `key`.  The oracle never hashes strings.
  *   - u64 `value + delta` wraps (Rust release-build behaviour of in_memory.rs:88,261;
  *     fetch_add always wraps).
+ *   - get_counters (in_memory.rs:159-187) is restated PER LIMIT: the reference walks the limit set,
+ *     and for every limit returns the simple cell of that limit plus — through one shared pass over
+ *     the qualified cache filtered by `limits.contains(counter.limit())` — the qualified cells of
+ *     every limit in the set; lo_get_counters(limit) returns the cells of ONE limit and the caller
+ *     unions them over the set, which yields the same HashSet<Counter>.  The reference also computes
+ *     `remaining = max_value - value` unchecked (:166,178: wraps in release, panics in debug when a
+ *     limit's max_value was lowered below the stored value); the oracle reports value_at(now) and
+ *     leaves that subtraction to the caller (tests/helpers/limiter.py, the host mirror), which wraps.
  *   - moka's capacity eviction (in_memory.rs:208-210) is not modelled: parity is
  *     unpinned above cache_size (no reference test exceeds it).  Eviction exists
  *     only as the explicit events lo_evict / lo_sweep_expired.
@@ -140,6 +148,15 @@ int lo_check_and_update_batch(lo_storage *s, const lo_limit_row *limits, size_t 
                               size_t n_req, uint64_t now_us, int load_counters, uint8_t *verdict,
                               int32_t *first_limited, uint64_t *remaining,
                               uint64_t *expires_in_us);
+/* Same; req_delta[n_req] (may be NULL): the request's u64 delta (in_memory.rs:75) instead of the
+ * 32-bit wire field; req_now_us[n_req] (may be NULL): the clock value each request reads
+ * (in_memory.rs:83), instead of one now_us for the whole batch. */
+int lo_check_and_update_batch_ex(lo_storage *s, const lo_limit_row *limits, size_t n_limits,
+                                 const lo_hit *hits, size_t n_hits, const uint32_t *req_off,
+                                 size_t n_req, const uint64_t *req_delta, const uint64_t *req_now_us,
+                                 uint64_t now_us, int load_counters, uint8_t *verdict,
+                                 int32_t *first_limited, uint64_t *remaining,
+                                 uint64_t *expires_in_us);
 int lo_is_within_limits_batch(lo_storage *s, const lo_limit_row *limits, size_t n_limits,
                               const lo_hit *hits, size_t n_hits, uint64_t now_us,
                               uint8_t *within);

@@ -123,7 +123,7 @@ def test_hot_keys_are_promoted_decided_by_position_and_demoted(make_engine):
 def test_more_hot_keys_than_hot_buckets(make_engine):
     rng = np.random.default_rng(12)
     n = 400_000
-    eng, orc = pair(make_engine, [(900, 60)], max_batch_hits=n, capacity_cells=1 << 16)
+    eng, orc = pair(make_engine, [(900, 60)], max_batch_hits=n, capacity_cells=1 << 19)
     keys = W.splitmix64(np.arange(1, 701, dtype=np.uint64))  # 700 keys x ~570 hits: all above the bar, 512 slots
     now = NOW
     for step in range(3):
@@ -239,4 +239,33 @@ def test_submit_collect_keeps_the_sequential_contract(make_engine):
     torch.cuda.synchronize()
     for step in range(6):
         assert np.array_equal(out[step].cpu().numpy(), expect[step]), f"batch {step}"
+    assert_same_state(eng, orc)
+
+
+def test_a_batch_that_does_not_fit_is_refused_before_anything_is_applied(make_engine):
+    """All-or-nothing under RL_ERR_TABLE_FULL: the batch's NEW keys are counted exactly (k_bkt_count_new) when
+    the cheap bound (every hit a new key) does not fit; a batch that would fill the table is refused with
+    the table untouched, one that fits — however many hits it carries — is applied in full."""
+    from limitador_amd.engine import EngineError
+
+    rng = np.random.default_rng(31)
+    eng, orc = pair(make_engine, [(50, 60)], capacity_cells=4096, max_batch_hits=1 << 16)
+    keys = W.splitmix64(np.arange(1, 5001, dtype=np.uint64))
+    # 40 000 hits on 2 000 keys into an empty 4 096-cell table: the cheap bound fails, the exact count fits
+    run_both(eng, orc, make_hits(keys[rng.integers(0, 2000, size=40_000)], 0, 1), NOW)
+    assert eng.stats()["live_cells"] == 2000
+    before = np.sort(eng.dump_cells(), order="key")
+    # 30 000 hits that would bring 2 000 more keys: 4 000 > 15/16 x 4 096 -> refused, nothing applied
+    big = make_hits(keys[rng.integers(0, 4000, size=30_000)], 0, 1)
+    assert len(np.unique(big["key"])) == 4000
+    with pytest.raises(EngineError) as e:
+        eng.check_and_update(big, NOW + 1)
+    assert e.value.code == -4
+    assert np.array_equal(before, np.sort(eng.dump_cells(), order="key"))
+    assert eng.stats()["live_cells"] == 2000
+    # the engine is still usable, and a batch that fits goes through: 1 000 new keys -> 3 000 live (<= 3/4)
+    run_both(eng, orc, make_hits(keys[rng.integers(0, 3000, size=30_000)], 0, 1), NOW + 2)
+    run_both(eng, orc, make_hits(keys[rng.integers(0, 3000, size=3000)], 0, 1), NOW + 3)
+    eng.resize(1 << 14)
+    run_both(eng, orc, big, NOW + 4)
     assert_same_state(eng, orc)

@@ -129,7 +129,7 @@ def test_one_hot_key_nonuniform_deltas(make_engine):
 
 def test_hot_keys_uniform_delta_saturate_mid_batch(make_engine):
     rng = np.random.default_rng(8)
-    eng, orc = pair(make_engine, [(1000, 60)], max_batch_hits=200_000)
+    eng, orc = pair(make_engine, [(1000, 60)], capacity_cells=1 << 18, max_batch_hits=200_000)
     n = 200_000
     hits = np.empty(n, dtype=HIT_DTYPE)
     hits["key"] = W.splitmix64(rng.integers(0, 40, size=n).astype(np.uint64))
