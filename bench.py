@@ -25,10 +25,8 @@ if ROOT not in sys.path:
 # (key, value, expiry) + 8 B value write-back + 1 B verdict = 49 B.  k_bkt_apply is the kernel that
 # reads the descriptor and the cell, writes the value back and emits the verdict, so all 49 B are
 # its algorithmic bytes; the partition kernels (hist / scan / scatter) only reorder the batch —
-# ranking traffic is overhead, not algorithmic — and are charged 0.  The legacy
-# pipeline (RL_K1_PATH=legacy) splits the 49 B over probe / decide / commit.
-ALGO_BYTES = {"apply": 49, "hist": 0, "scan": 0, "scatter": 0,
-              "legacy_probe": 16 + 8, "legacy_decide": 16 + 1, "legacy_commit": 8, "legacy_ordered": 0}
+# ranking traffic is overhead, not algorithmic — and are charged 0.
+ALGO_BYTES = {"apply": 49, "hist": 0, "scan": 0, "scatter": 0, "hot_state": 0}
 ALGO_BYTES_TOTAL = 49
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -43,10 +41,11 @@ def parse():
     ap.add_argument("--zipf", type=float, default=0.99, help="0 => uniform keys")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--cap-mult", type=float, default=1.0, help="scale the table capacity (experiments)")
-    ap.add_argument("--depth", type=int, default=2, choices=(1, 2),
-                    help="batches in flight on one GPU: 2 = submit batch k+1 before collecting batch k "
-                         "(rl_check_and_update_submit_device / _collect), 1 = one blocking call per batch; "
-                         "the routed path keeps 3 ingress slices in flight at depth 2 (ShardedEngine)")
+    ap.add_argument("--depth", type=int, default=3, choices=(1, 2, 3),
+                    help="batches in flight on one GPU: N = submit batch k+N-1 before collecting batch k "
+                         "(rl_check_and_update_submit_device / _collect; with 2+ the partition of the next batch "
+                         "overlaps k_bkt_apply of this one), 1 = one blocking call per batch; "
+                         "the routed path keeps 3 ingress slices in flight at depth >= 2 (ShardedEngine)")
     ap.add_argument("--timing-mode", type=int, default=3, choices=(0, 2, 3),
                     help="HIP events in the timed region: 2 = around k_bkt_apply on every launch, 3 = on every "
                          "fourth launch, 0 = none (roofline then comes from the breakdown pass)")
@@ -223,7 +222,7 @@ def main():
     batches = [W.torch_batch(n_keys_total, args.batch, dev, gen, cdf) for _ in range(total_steps)]
     del cdf
     verdict = torch.empty(args.batch, dtype=torch.uint8, device=dev)
-    verdicts = [verdict] + [torch.empty(args.batch, dtype=torch.uint8, device=dev) for _ in range(2)]
+    verdicts = [verdict] + [torch.empty(args.batch, dtype=torch.uint8, device=dev) for _ in range(3)]
     torch.cuda.synchronize()
 
     if sharded:
@@ -245,25 +244,27 @@ def main():
         def step(i, now):
             eng.check_and_update_device(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
     else:
-        # Two batches in flight: batch i is enqueued behind batch i-1 on the engine's stream before the
-        # host waits for batch i-1, so the device never idles between batches.  Batches are applied in
-        # submission order; every step's batch has completed when the timed region ends (drain()).
+        # `depth` batches in flight: batch i is enqueued before the host waits for batch i-depth+1, so the
+        # device never idles between batches and the partition of batch i+1 (own stream) overlaps k_bkt_apply
+        # of batch i.  Batches are applied in submission order; every step's batch has completed when the
+        # timed region ends (drain()).
         pending = [0]
 
         def step(i, now):
-            eng.submit_device(batches[i].data_ptr(), args.batch, now, verdicts[i & 1].data_ptr())
-            if pending[0]:
+            eng.submit_device(batches[i].data_ptr(), args.batch, now, verdicts[i & 3].data_ptr())
+            if pending[0] == args.depth - 1:
                 eng.collect()
             else:
-                pending[0] = 1
+                pending[0] += 1
 
     def drain():
         if sharded:
             while sh.in_flight:
                 sh.collect()
-        elif args.depth == 2 and pending[0]:
-            eng.collect()
-            pending[0] = 0
+        elif args.depth >= 2:
+            while pending[0]:
+                eng.collect()
+                pending[0] -= 1
 
     now = W.NOW0_US
     for i in range(args.warmup):
@@ -272,11 +273,14 @@ def main():
     drain()
     # Per-kernel breakdown, OUTSIDE the timed region: events between all four kernels (each event marker
     # idles the device ~5 us, so this mode is not the one the throughput is quoted in).  The warm-up
-    # batches are replayed; the legacy pipeline, if forced, reports its own slots.
+    # batches are replayed.
     eng.kernel_timing(1)
     eng.kernel_timing_read(reset=True)
     for i in range(min(args.warmup, 5)):
-        step(i, now)
+        if sharded:
+            step(i, now)
+        else:  # one blocking call per batch: every kernel runs alone (no overlap with the next batch's partition)
+            eng.check_and_update_device(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
         now += 1000
     drain()
     kt_all = eng.kernel_timing_read(reset=True)
@@ -302,7 +306,7 @@ def main():
     if args.depth == 1:
         last = verdict
     else:
-        last = verdicts[(total_steps - 1) % 3] if sharded else verdicts[(total_steps - 1) & 1]
+        last = verdicts[(total_steps - 1) % 3] if sharded else verdicts[(total_steps - 1) & 3]
     denied = int(last.sum().item())
     if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -321,7 +325,7 @@ def main():
         dom_gbps = ALGO_BYTES[dom] * hits_per_launch / (per[dom] * 1e-3) / 1e9 if per.get(dom, 0) > 0 else 0.0
         pipe_ms = sum(per.values())
         kname = {"apply": "k_bkt_apply", "hist": "k_bkt_hist", "scan": "k_bkt_scan", "scatter": "k_bkt_scatter"}.get(
-            dom, "k_" + dom.replace("legacy_", ""))
+            dom, "k_" + dom)
         # HBM bytes per launch of that kernel from the PMC passes of the last profiling visit
         # (scripts/gpu_profile.sh -> scripts/summarize_prof.py -> profiles/traffic.json): counters cannot
         # be collected inside this run, so the figure is the committed one for this workload or null.
@@ -344,6 +348,7 @@ def main():
                        "table_capacity_cells": cap, "cell_bytes": 64,
                        "parallelism": f"hash-sharded x{world}, RCCL all-to-all" if sharded else "single GPU",
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
+                       "overlap": "partition of batch k+1 (own stream) beside k_hot_state + k_bkt_apply of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
                        "denied_in_last_batch": denied},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,

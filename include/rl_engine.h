@@ -282,13 +282,10 @@ int32_t rl_engine_set_stream(rl_engine *e, void *stream, int32_t external);
  * of timed batches into *launches. */
 enum {
     RL_T_HIST = 0,           /* k_bkt_hist: per-tile bucket histogram + batch validation */
-    RL_T_SCAN = 1,           /* k_bkt_scan + k_bkt_starts */
+    RL_T_SCAN = 1,           /* k_bkt_scan */
     RL_T_SCATTER = 2,        /* k_bkt_scatter: stable partition into bucket order */
     RL_T_APPLY = 3,          /* k_bkt_apply: probe, decide, commit — the dominant kernel */
-    RL_T_LEGACY_PROBE = 4,   /* first-generation pipeline (RL_K1_PATH=legacy) */
-    RL_T_LEGACY_DECIDE = 5,
-    RL_T_LEGACY_ORDERED = 6,
-    RL_T_LEGACY_COMMIT = 7,
+    RL_T_HOT_STATE = 4,      /* k_hot_state: the hot keys' cells before the batch */
     RL_TIMING_SLOTS = 8
 };
 int32_t rl_kernel_timing(rl_engine *e, int32_t enable);

@@ -1,20 +1,26 @@
-// rl_apply2.hpp — k_bkt_apply2: the bucket replay of rl_bucket.hpp re-cut for occupancy.
+// rl_apply.hpp — k_bkt_apply: the bucket replay of the single-counter hot path (see rl_bucket.hpp for
+// the partition that feeds it and for the algorithm: reference limitador/src/storage/in_memory.rs:72-156
+// applied hit by hit in trace order, one read and one write per touched counter cell).
 //
-// Same contract and the same exact algorithm as k_bkt_apply (see the header of rl_bucket.hpp:
-// reference limitador/src/storage/in_memory.rs:72-156 applied hit by hit in trace order, one read
-// and one write per touched counter cell), different machine mapping:
-//
-//   * ONE workgroup per hash bucket, not persistent.  k_bkt_apply hides the dependent chain of a
-//     bucket (hits -> home cells -> LDS aggregation -> probes -> verdicts -> write-back, ~6 us)
-//     behind a software pipeline of three register buffers, which costs 251 VGPRs and, with 77 KB
-//     of LDS, leaves 2 workgroups = 2 waves per SIMD on a CU.  Here the chain is hidden by OTHER
-//     workgroups: 22-44 KB of LDS and <= 96 VGPRs keep 3-6 of them resident per CU.
+// Machine mapping:
+//   * ONE workgroup per hash bucket, not persistent: the dependent chain of a bucket (hits -> home
+//     cells -> LDS aggregation -> probes -> verdicts -> write-back, ~6 us) is hidden by OTHER
+//     workgroups — 22 KB of LDS and 58 VGPRs keep 6 of them resident per CU.  (The first cut was
+//     persistent with a software pipeline of three register buffers: 251 VGPRs + 77 KB of LDS = two
+//     workgroups per CU, 48 us; this one 36-38 us on the same batch.)
 //   * the limit table and the hot-bucket table are read from global memory (L2-resident, a few
-//     hundred bytes) instead of LDS copies: 16 KB of LDS less, and no row limit on the limit table.
-//   * one 64-bit LDS atomic per hit carries the round's delta sum AND the per-wave hit counts
-//     (k_bkt_apply: two 64-bit atomics); deltas >= 2^23 cannot share the 32-bit sum field and send
-//     their key through the sequential replay, which is exact for everything.
-//   * hot-key chunks are found through a chunk table prepared by k_bkt_scatter (no binary search).
+//     hundred bytes): no LDS copies, no row limit on the limit table.
+//   * one 64-bit LDS atomic per hit carries the round's delta sum AND the per-wave hit counts;
+//     deltas >= 2^23 cannot share the 32-bit sum field and send their key through the sequential
+//     replay, which is exact for everything.
+//   * hot-key chunks are found through a chunk table prepared by k_bkt_scatter.
+//   * completion: the last workgroup out (ticket, sharded per XCD: one ticket word taken by 2048
+//     workgroups was 9 us of serialised atomics) stores the batch's sequence number into host-mapped
+//     memory (apply_finish, rl_bucket.hpp).
+//
+//   k_bkt_apply      the batch's hash buckets + hot buckets
+//   k_bkt_tiny       a batch of <= TINY_MAX hits is one bucket: validate + replay in ONE launch
+//   k_bkt_count_new  dry run: how many cells would the batch create (all-or-nothing under TABLE_FULL)
 #pragma once
 #include "rl_bucket.hpp"
 
@@ -484,6 +490,7 @@ __device__ __forceinline__ void apply2_hot_chunk(const Apply2Args& A, u32 c) {
     const u32 tid = threadIdx.x;
     const u32 hb = A.chunk_tab[c];
     const HotParam hp = A.hot_param[hb];
+    if (!hp.fast) return;  // (block-uniform) uniform deltas, but the cell's state asks for the replay below
     const u32 lo = hp.lo, hi = hp.hi;
     const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
     const u64 room = hp.room;
@@ -528,7 +535,7 @@ __device__ __forceinline__ void apply2_hot_chunk(const Apply2Args& A, u32 c) {
 
 // ---------------------------------------------------------------------------------------------
 // k_bkt_count_new: how many cells would this (already partitioned) batch create?  Same walk as
-// k_bkt_apply2 up to the point where a new key's probe chain ends at an empty slot — counted, not
+// k_bkt_apply up to the point where a new key's probe chain ends at an empty slot — counted, not
 // claimed; nothing is written to the table, no verdict is produced.  The host runs it only when the
 // cheap bound "every hit could be a new key" does not fit the table, to decide BEFORE anything is
 // applied whether the batch fits (all-or-nothing under RL_ERR_TABLE_FULL).  Exact per bucket; a key
@@ -599,11 +606,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restri
     for (u32 hk = blockIdx.x; hk < (u32)HOT_MAX; hk += G) {
         const HotParam hp = hot_param[hk];  // (block-uniform)
         if (hp.hi == hp.lo) continue;
-        if (hp.fast) {  // one key per bucket; k_bkt_scatter looked its cell up
-            if (tid == 0 && hp.slot == SLOT_INVALID) ++my_new;
-        } else {
-            count_bucket(hp.lo, hp.hi);
-        }
+        count_bucket(hp.lo, hp.hi);  // (a bucket of a single key: one LDS cell, one probe per round of a rebuild)
     }
     for (int off = 32; off > 0; off >>= 1) my_new += __shfl_down(my_new, off);
     if ((tid & 63u) == 0 && my_new) atomicAdd(&s_new, my_new);
@@ -612,12 +615,12 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restri
 }
 
 template <int HPT, int ENT_LOG2, int MIN_WAVES>
-__global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply2(
+__global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
     Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits,
     const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
     const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab,
     const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
-    int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_next, Status* host_status, u32 done_seq,
+    int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
     HotSet* hot_next, u32 hot_threshold, u32 dbg) {
     __shared__ Apply2Lds<HPT, ENT_LOG2> S;
     const u32 tid = threadIdx.x, G = gridDim.x;
@@ -650,11 +653,62 @@ __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply2(
     __syncthreads();
     if (tid == 0) {
         if (dbg & 1u) {  // timing experiment: workgroup 0 reports completion, nobody takes a ticket
-            if (blockIdx.x == 0) apply_finish(0u, bs, bs_next, host_status, done_seq, 1u, &hot_next->n, 0u);
+            if (blockIdx.x == 0) apply_finish(0u, bs, bs_zero, host_status, done_seq, 1u, &hot_next->n, 0u);
         } else {
-            apply_finish(S.n_created, bs, bs_next, host_status, done_seq, G, &hot_next->n, 0u, (dbg >> 4) & 3u);
+            apply_finish(S.n_created, bs, bs_zero, host_status, done_seq, G, &hot_next->n, 0u);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_tiny: a batch of at most TINY_MAX hits IS one bucket — it is in trace order already — so one
+// workgroup validates it (the checks of k_bkt_hist), rewrites it as BHit records and replays it with
+// the bucket code: one launch instead of five.  The hot set is left as it is.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
+    Cell* __restrict__ table, u32 log2cap, u64 seed, const Hit* __restrict__ hits, u32 n, BHit* __restrict__ b_hits,
+    const LimitDev* __restrict__ limits, u32 n_limits, u64 now, uint8_t* __restrict__ verdict,
+    int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
+    u32 hot_n_report) {
+    __shared__ Apply2Lds<1, 9> S;
+    __shared__ u32 s_err;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) {
+        s_err = 0;
+        S.n_created = 0;
+        S.promote_ok = 0;  // no promotion from here: the hot set belongs to the partitioned path
+    }
+    apply2_clear(S);
+    __syncthreads();
+    u32 err = 0;
+    for (u32 i = tid; i < n; i += AP_BLOCK) {
+        const Hit h = load_hit(hits, i);
+        if ((h.limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
+        else if (h.key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
+        else if (h.limit & SIMPLE_FLAG) {  // in_memory.rs:106-107: a simple counter must pre-exist
+            u32 dummy = 0;
+            u32 slot = slot_of(h.key, seed, log2cap);
+            slot = probe_from<PM_LOOKUP>(table, log2cap, slot, table[slot].tag, h.key, h.limit, limits, 0ull, &bs->st,
+                                         dummy);
+            if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
+        }
+        *reinterpret_cast<uint4*>(b_hits + i) =
+            make_uint4((u32)h.key, (u32)(h.key >> 32), h.delta, i | (limit_fold(h.limit) << 24));
+    }
+    if (err) atomicOr(&s_err, err);
+    __syncthreads();  // (also orders the b_hits stores before this workgroup's loads of them)
+    if (s_err) {
+        if (tid == 0) atomicOr(&bs->st.err, s_err);
+    } else if (n) {
+        Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
+                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, 0u};
+        apply2_bucket(S, A, 0, n);
+    }
+    // the verdicts may go straight to host-mapped memory (rl_check_and_update_batch): every wave's stores
+    // have been acknowledged before the completion word is written
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) apply_finish(S.n_created, bs, bs_zero, host_status, done_seq, 1u, nullptr, hot_n_report);
 }
 
 }  // namespace rl

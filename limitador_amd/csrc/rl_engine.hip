@@ -26,7 +26,7 @@
 #include "rl_kernels.hpp"
 #include "rl_ordered.hpp"
 #include "rl_bucket.hpp"
-#include "rl_apply2.hpp"
+#include "rl_apply.hpp"
 #include "rl_general.hpp"
 #include "rl_route.hpp"
 #include "rl_match.hpp"
@@ -80,17 +80,17 @@ struct rl_engine {
     size_t scan_tmp_bytes = 0;
     Status* d_status = nullptr;
     Status* h_status = nullptr; // pinned
-    BatchScratch* d_bs = nullptr;   // [2], alternating (rl_bucket.hpp)
-    u32 bs_cur = 0;
+    BatchScratch* d_bs = nullptr;   // [3], rotating: batch k uses [k % 3] and zeroes [(k + 2) % 3] (rl_bucket.hpp)
+    u64 bs_seq = 0;                 // batches of the bucketed path (partitioned or tiny) submitted so far
     // batches of the bucketed path submitted but not yet collected (at most two)
     struct Inflight {
-        hipEvent_t tev[5]{};   // before hist / scan / scatter / apply, after apply (= done)
+        hipEvent_t tev[7]{};   // see collect_k1_bucketed
         Status* h_st = nullptr;  // host-mapped: written by the batch's last workgroup
         u32 n = 0, n_wg = 0, ntiles = 0;
         int timed = 0;
         u32 seq = 0;  // value the batch's last workgroup stores into h_st->n_removed
         bool settled = false;  // completion seen and its new cells already added to `live` (settle_inflight)
-    } inflight[2];
+    } inflight[4];  // at most three in flight
     u64 sub_seq = 0, col_seq = 0;
     u64 inflight_hits = 0;
     unsigned long long* d_total = nullptr;
@@ -98,16 +98,25 @@ struct rl_engine {
     // routing scratch
     u32* d_route_cnt = nullptr;
     // bucketed hot path (rl_bucket.hpp)
-    bool legacy_k1 = false;   // RL_K1_PATH=legacy: the first-generation probe/decide/commit pipeline
-    u32 bk_log2_cfg = BK_LOG2_MAX;     // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX)
+    u32 bk_log2_cfg = 10;              // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX): 1024 measured
+                                       // best at 1 M hits (cheaper partition, three rounds per bucket in k_bkt_apply)
     u32 bk_tiles_max = 0;
     u32* d_bk_hist = nullptr;
     u32* d_bk_total = nullptr;
-    uint2* d_bk_ranges = nullptr;
-    HotSet* d_hot = nullptr;        // [2]: the set used by this batch, the set it picks for the next
-    u32 hot_cur = 0;
+    uint2* d_bk_ranges = nullptr;   // [2][BK_MAX], by partitioned batch parity
+    // Hot sets, [3], rotating: partitioned batch p is partitioned with the set batch p-2 picked ([(p+1) % 3])
+    // and picks the set of batch p+2 ([p % 3]) — two interleaved lineages, so that the partition of batch
+    // p+1 never waits for k_bkt_apply of batch p (any stale set is valid, see HotSet).
+    HotSet* d_hot = nullptr;
+    u64 part_seq = 0;               // partitioned batches submitted so far
+    // Two streams: the partition of batch k+1 (k_bkt_hist / scan / scatter, on `pstream`) overlaps
+    // k_hot_state + k_bkt_apply of batch k (on `stream`).  With a caller's stream (rl_engine_set_stream)
+    // or RL_OVERLAP=0 both are the same stream.
+    hipStream_t pstream = nullptr, own_pstream = nullptr;
+    bool overlap = true;
+    hipEvent_t ev_parted[4]{}, ev_applied[4]{};
     u32 hot_threshold = HOT_PROMOTE;  // doubled while more keys qualify than there are hot buckets
-    HotParam* d_hot_param = nullptr;
+    HotParam* d_hot_param = nullptr;  // [2][HOT_MAX + 1], by partitioned batch parity
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
@@ -115,13 +124,12 @@ struct rl_engine {
     u32 gen_seq = 0;
     uint8_t* h_tiny = nullptr;  // host-mapped staging of a tiny host-buffer call: the kernel reads and writes it directly
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
-    u32 dbg_vmask = 0xFFFFFFFFu;  // RL_DEBUG_VMASK (timing experiments only: verdicts land in a few lines)
-    u64* d_bk_trace = nullptr;  // RL_APPLY_TRACE=1: phase timestamps of k_bkt_apply (debug)
-    BHit* d_bk_hits = nullptr;
-    unsigned short* d_chunk_tab = nullptr;  // hot chunk -> hot bucket (k_bkt_scatter -> k_bkt_apply2)
-    int apply_gen = 2;      // RL_APPLY=1: the persistent first cut (k_bkt_apply); 2 (default): k_bkt_apply2
+    BHit* d_bk_hits = nullptr;              // [2][max_batch], by partitioned batch parity
+    BHit* d_tiny_hits = nullptr;            // k_bkt_tiny's record buffer
+    unsigned short* d_chunk_tab = nullptr;  // [2][...] hot chunk -> hot bucket (k_bkt_scatter -> k_bkt_apply)
+    size_t chunk_tab_len = 0;
     u32 dbg_apply2 = 0;     // RL_DEBUG_APPLY2 (timing experiments only)
-    int apply2_cfg = 0;     // RL_APPLY2_CFG: which instantiation of k_bkt_apply2 (see launch_apply2)
+    int apply2_cfg = 0;     // RL_APPLY2_CFG: which instantiation of k_bkt_apply (see launch_apply)
 
     // on-device limit matching (rl_match.hpp)
     MatchLimit* d_match_limits = nullptr;
@@ -297,202 +305,6 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
 int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_req_off, u32 n_req, u64 now,
                       bool load, uint8_t* d_verdict, int32_t* d_first, u64* d_rem, u64* d_exp);
 
-// The ordered resolver (rl_ordered.hpp).  n_ord is known on the host.
-int run_ordered(rl_engine* e, const Hit* d_hits, u32 n_ord, u64 now, uint8_t* d_verdict,
-                int32_t* d_first) {
-    const u32 g = cdiv(n_ord, 256);
-    k_ord_keys<<<g, 256, 0, e->stream>>>(e->d_ord_list, n_ord, e->d_hit_slot, e->d_keys_a);
-    size_t tmp = e->sort_tmp_bytes;
-    // Sort by (slot, idx): idx occupies the low 32 bits, slot the next log2cap bits.
-    HIP_TRY(e, rocprim::radix_sort_keys(e->d_sort_tmp, tmp, e->d_keys_a, e->d_keys_b, (size_t)n_ord, 0u,
-                                        32u + e->log2cap, e->stream));
-    k_ord_heads<<<g, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_ord);
-    k_ord_uniform<<<g, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_ord, d_hits, now);
-    k_ord_resolve<<<g, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_ord, d_hits, e->d_limits, now,
-                                            d_verdict, d_first);
-    HIP_TRY(e, hipGetLastError());
-    e->stats.ordered_hits += n_ord;
-    e->stats.ordered_batches++;
-    return RL_OK;
-}
-
-// check_and_update for single-counter requests, all pointers on the device: first-generation
-// pipeline (kept for A/B measurement, RL_K1_PATH=legacy).
-int run_check_k1_legacy(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
-    int rc = check_room_lenient(e, n);
-    if (rc) return rc;
-    const bool t = e->timing;
-    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
-    k_probe<PM_CHECK><<<std::min(cdiv(n, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
-        e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(), now,
-        (1ull << PEND_SHIFT) / n, e->d_hit_slot, e->d_status);
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
-    k_decide<<<cdiv(n, DECIDE_BLOCK), DECIDE_BLOCK, 0, e->stream>>>(
-        e->table, d_hits, n, e->d_limits, now, e->d_hit_slot, d_verdict, d_first, e->d_ord_list, e->d_status);
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
-    HIP_TRY(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    e->live += e->h_status->n_inserted;
-    if (e->h_status->err) {
-        k_abort<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, n, e->d_hit_slot);
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        if (e->h_status->err == ERRBIT_BIG_DELTA)  // exact path for deltas the packed sum cannot hold
-            return run_check_general(e, d_hits, n, nullptr, n, now, false, d_verdict, d_first, nullptr, nullptr);
-        return status_to_error(e, e->h_status->err & ~ERRBIT_BIG_DELTA);
-    }
-    const u32 n_ord = e->h_status->n_ord;
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream));
-    if (n_ord) {
-        rc = run_ordered(e, d_hits, n_ord, now, d_verdict, d_first);
-        if (rc) return rc;
-    }
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream));
-    k_commit<<<std::min(cdiv(n, 256), COMMIT_MAX_BLOCKS), 256, 0, e->stream>>>(e->table, d_hits, n, e->d_limits, now, e->d_hit_slot, 0,
-                                                  e->d_status);
-    if (t) HIP_TRY(e, hipEventRecord(e->ev[5], e->stream));
-    HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (t) {
-        float a = 0, b = 0, c = 0, d = 0;
-        HIP_TRY(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
-        HIP_TRY(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
-        HIP_TRY(e, hipEventElapsedTime(&c, e->ev[3], e->ev[4]));
-        HIP_TRY(e, hipEventElapsedTime(&d, e->ev[4], e->ev[5]));
-        e->ms_slot[RL_T_LEGACY_PROBE] += a;
-        e->ms_slot[RL_T_LEGACY_DECIDE] += b;
-        e->ms_slot[RL_T_LEGACY_ORDERED] += c;
-        e->ms_slot[RL_T_LEGACY_COMMIT] += d;
-        e->timed_launches++;
-    }
-    e->stats.batches++;
-    e->stats.hits += n;
-    return RL_OK;
-}
-
-// Debug (RL_APPLY_TRACE=1 RL_APPLY_TRACE_DUMP=1): phase timestamps the kernels left behind.
-int dump_apply_trace(rl_engine* e, u32 n_wg, u32 ntiles, const Status* h_st) {
-    (void)h_st;
-    if (e->d_bk_trace && getenv("RL_APPLY_TRACE_DUMP")) {
-        std::vector<u64> tr((size_t)(n_wg < BK_MAX ? n_wg : BK_MAX) * 16);
-        HIP_TRY(e, hipMemcpy(tr.data(), e->d_bk_trace, tr.size() * sizeof(u64), hipMemcpyDeviceToHost));
-        u64 t_min = ~0ull, t_max = 0;
-        double acc[10] = {0};
-        u32 used = 0;
-        u64 longest = 0, longest_n = 0;
-        for (u32 b = 0; b < tr.size() / 16; ++b) {
-            const u64* r = &tr[(size_t)b * 16];
-            if (r[9] == 0) continue;
-            ++used;
-            if (r[0] < t_min) t_min = r[0];
-            if (r[9] > t_max) t_max = r[9];
-            for (int q = 1; q <= 9; ++q) acc[q] += (double)(r[q] - r[q - 1]);
-            if (r[9] - r[0] > longest) {
-                longest = r[9] - r[0];
-                longest_n = r[10];
-            }
-        }
-        fprintf(stderr, "[apply trace] blocks=%u span=%.2fus longest=%.2fus(%llu hits) avg us:", used,
-                (double)(t_max - t_min) * 0.01, (double)longest * 0.01, (unsigned long long)longest_n);
-        const char* names[10] = {"", "init", "load", "A", "B", "syncB", "C", "D", "rest", "commit"};
-        for (int q = 1; q <= 9; ++q) fprintf(stderr, " %s=%.2f", names[q], used ? acc[q] / used * 0.01 : 0.0);
-        {
-            std::vector<u64> ht((size_t)ntiles * 8);
-            HIP_TRY(e, hipMemcpy(ht.data(), e->d_bk_trace + (size_t)(BK_MAX + 64) * 16, ht.size() * sizeof(u64),
-                                 hipMemcpyDeviceToHost));
-            double a[7] = {0};
-            u64 h0 = ~0ull, h1 = 0;
-            for (u32 b = 0; b < ntiles; ++b) {
-                const u64* r = &ht[(size_t)b * 8];
-                for (int q = 1; q <= 6; ++q) a[q] += (double)(r[q] - r[q - 1]);
-                if (r[0] < h0) h0 = r[0];
-                if (r[6] > h1) h1 = r[6];
-            }
-            {
-                std::vector<u64> st2((size_t)ntiles * 8);
-                HIP_TRY(e, hipMemcpy(st2.data(), e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8,
-                                     st2.size() * sizeof(u64), hipMemcpyDeviceToHost));
-                double c[7] = {0};
-                u64 s0 = ~0ull, s1 = 0;
-                for (u32 b = 0; b < ntiles; ++b) {
-                    const u64* r = &st2[(size_t)b * 8];
-                    for (int q = 1; q <= 6; ++q) c[q] += (double)(r[q] - r[q - 1]);
-                    if (r[0] < s0) s0 = r[0];
-                    if (r[6] > s1) s1 = r[6];
-                }
-                u64 xb[2] = {0, 0};
-                HIP_TRY(e, hipMemcpy(xb, e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 + 2040 * 8, sizeof(xb),
-                                     hipMemcpyDeviceToHost));
-                fprintf(stderr, " | scatter: hot-param block %.2f..%.2f", (double)((int64_t)(xb[0] - s0)) * 0.01,
-                        (double)((int64_t)(xb[1] - s0)) * 0.01);
-                fprintf(stderr, " span=%.2f prologue=%.2f zero=%.2f steps=%.2f sync=%.2f prefix=%.2f write=%.2f",
-                        (double)(s1 - s0) * 0.01, c[1] / ntiles * 0.01, c[2] / ntiles * 0.01, c[3] / ntiles * 0.01,
-                        c[4] / ntiles * 0.01, c[5] / ntiles * 0.01, c[6] / ntiles * 0.01);
-            }
-            fprintf(stderr, " | hist: span=%.2f loads_issue=%.2f hot_table=%.2f loop=%.2f hotloop=%.2f sync=%.2f rowwrite=%.2f",
-                    (double)(h1 - h0) * 0.01, a[1] / ntiles * 0.01, a[2] / ntiles * 0.01, a[3] / ntiles * 0.01,
-                    a[4] / ntiles * 0.01, a[5] / ntiles * 0.01, a[6] / ntiles * 0.01);
-        }
-        double h_acc[3] = {0, 0, 0};
-        u64 h_last = 0;
-        for (u32 b = 0; b < tr.size() / 16; ++b) {
-            const u64* r = &tr[(size_t)b * 16];
-            if (!r[14]) continue;
-            h_acc[0] += (double)(r[12] - r[11]);
-            h_acc[1] += (double)(r[13] - r[12]);
-            h_acc[2] += (double)(r[14] - r[13]);
-            if (r[14] > h_last) h_last = r[14];
-        }
-        u32 late = 0;
-        double start_max = 0;
-        for (u32 b = 0; b < tr.size() / 16; ++b) {
-            const u64* r = &tr[(size_t)b * 16];
-            if (!r[0]) continue;
-            const double st_us = (double)(r[0] - t_min) * 0.01;
-            if (st_us > 5.0) ++late;
-            if (st_us > start_max) start_max = st_us;
-        }
-        fprintf(stderr, " | late_starts=%u max_start=%.1fus", late, start_max);
-        {
-            std::vector<std::pair<u64, u32>> ends;
-            for (u32 b = 0; b < tr.size() / 16; ++b)
-                if (tr[(size_t)b * 16 + 9]) ends.push_back({tr[(size_t)b * 16 + 9] - t_min, b});
-            std::sort(ends.begin(), ends.end());
-            if (!ends.empty()) fprintf(stderr, " | end pct: p10=%.1f p50=%.1f p90=%.1f p99=%.1f max=%.1f | slowest:",
-                    ends[ends.size() / 10].first * 0.01, ends[ends.size() / 2].first * 0.01,
-                    ends[ends.size() * 9 / 10].first * 0.01, ends[ends.size() * 99 / 100].first * 0.01,
-                    ends.back().first * 0.01);
-            {  // mean end per 32 consecutive workgroups (the order buckets were dealt in)
-                fprintf(stderr, " | end by wg/32:");
-                const size_t nwg = tr.size() / 16;
-                for (size_t g0 = 0; g0 < nwg; g0 += 32) {
-                    double a = 0;
-                    u32 c = 0;
-                    for (size_t b = g0; b < g0 + 32 && b < nwg; ++b)
-                        if (tr[b * 16 + 9]) {
-                            a += (double)(tr[b * 16 + 9] - t_min) * 0.01;
-                            ++c;
-                        }
-                    fprintf(stderr, " %.1f", c ? a / c : 0.0);
-                }
-                fprintf(stderr, " |");
-            }
-            for (size_t q = ends.size() >= 4 ? ends.size() - 4 : 0; q < ends.size(); ++q) {
-                const u64* r = &tr[(size_t)ends[q].second * 16];
-                fprintf(stderr, " [wg%u end=%.1f buckets=%llu hits=%llu]", ends[q].second, ends[q].first * 0.01,
-                        (unsigned long long)(r[15] >> 32), (unsigned long long)(r[15] & 0xFFFFFFFFull));
-            }
-        }
-        const double nbk = (double)(tr.size() / 16);
-        fprintf(stderr, " | hot: setup=%.2f fast=%.2f slow=%.2f end=%.2fus fast_hits=%u slow_hits=%u\n",
-                h_acc[0] / nbk * 0.01, h_acc[1] / nbk * 0.01, h_acc[2] / nbk * 0.01, (double)(h_last - t_min) * 0.01,
-                h_st->pad[0], h_st->pad[1]);
-        HIP_TRY(e, hipMemset(e->d_bk_trace, 0, tr.size() * sizeof(u64)));
-    }
-    return RL_OK;
-}
-
 // Spin until the batch's last workgroup has stored its sequence number (see apply_finish).
 int wait_done(rl_engine* e, rl_engine::Inflight& f) {
     const volatile u32* done = &f.h_st->n_removed;
@@ -512,7 +324,7 @@ int wait_done(rl_engine* e, rl_engine::Inflight& f) {
 // handed out by rl_check_and_update_collect): used when a new batch needs the exact occupancy.
 int settle_inflight(rl_engine* e) {
     for (u64 q = e->col_seq; q < e->sub_seq; ++q) {
-        rl_engine::Inflight& f = e->inflight[q & 1u];
+        rl_engine::Inflight& f = e->inflight[q & 3u];
         if (f.settled) continue;
         const int rc = wait_done(e, f);
         if (rc) return rc;
@@ -523,29 +335,35 @@ int settle_inflight(rl_engine* e) {
     return RL_OK;
 }
 
-// k_bkt_apply2 in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD>.
-void launch_apply2(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u64 now, uint8_t* d_verdict, int32_t* d_first,
-                   BatchScratch* bs, BatchScratch* bs_next, Status* h_st, u32 seq, HotSet* hot_next) {
-#define RL_AP2(HPT, EL, MW)                                                                                        \
-    k_bkt_apply2<HPT, EL, MW><<<n_wg, AP_BLOCK, 0, e->stream>>>(                                                   \
-        e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits, e->d_bk_ranges, nb, e->d_hot_param, e->d_chunk_tab,   \
-        e->d_limits, now, d_verdict, d_first, bs, bs_next, h_st, seq, hot_next, e->hot_threshold, e->dbg_apply2)
+// k_bkt_apply in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD>.
+void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u64 now, uint8_t* d_verdict,
+                  int32_t* d_first, BatchScratch* bs, BatchScratch* bs_zero, Status* h_st, u32 seq, HotSet* hot_prod) {
+    const BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
+    const uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
+    const HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
+    const unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
+#define RL_AP2(HPT, EL, MW)                                                                                     \
+    k_bkt_apply<HPT, EL, MW><<<n_wg, AP_BLOCK, 0, e->stream>>>(                                                 \
+        e->table, e->log2cap, e->seed, b_hits, d_hits, ranges, nb, hot_param, chunk_tab, e->d_limits, now,      \
+        d_verdict, d_first, bs, bs_zero, h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2)
     switch (e->apply2_cfg) {
         default:
         case 0: RL_AP2(1, 9, 6); break;
-        case 1: RL_AP2(1, 9, 4); break;
         case 2: RL_AP2(1, 10, 3); break;
         case 3: RL_AP2(2, 10, 3); break;
-        case 4: RL_AP2(2, 10, 2); break;
-        case 5: RL_AP2(1, 9, 5); break;
-        case 6: RL_AP2(1, 9, 7); break;
     }
 #undef RL_AP2
 }
 
-// Enqueue one batch of the bucketed path on the engine's stream (no host synchronisation).
+// Enqueue one batch of the bucketed path (no host synchronisation): the partition on `pstream`, then
+// k_hot_state + k_bkt_apply on `stream`, which therefore overlap the partition of the NEXT batch.
+//   partitioned batch p:  buffers [p % 2] (records, ranges, hot-bucket table, chunk table); scratch [p % 3],
+//   zeroes scratch [(p + 2) % 3]; partitioned with hot set [(p + 1) % 3], picks hot set [p % 3].
+//   stream order:  pstream: wait applied(p-2) | hist scan scatter | record parted(p)
+//                  stream:  wait parted(p) | k_hot_state k_bkt_apply | record applied(p)
+// (the partition of batch p+2 rewrites the buffers k_bkt_apply of batch p reads: hence the first wait.)
 int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
-    if (e->sub_seq - e->col_seq >= 2) return fail(e, RL_ERR_BUSY, "two batches are already in flight: collect one first");
+    if (e->sub_seq - e->col_seq >= 3) return fail(e, RL_ERR_BUSY, "three batches are already in flight: collect one first");
     bool need_count = false;
     int rc = check_room(e, n + e->inflight_hits, &need_count);
     if (rc) return rc;
@@ -555,28 +373,24 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         if (!rc) rc = check_room(e, n + e->inflight_hits, &need_count);
         if (rc) return rc;
     }
-    rl_engine::Inflight& f = e->inflight[e->sub_seq & 1u];
-    const bool t = e->timing == 1;  // events between all four kernels
+    rl_engine::Inflight& f = e->inflight[e->sub_seq & 3u];
+    const bool t = e->timing == 1;  // events between all kernels
+    const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
+    const bool two_streams = e->pstream != e->stream;
     if (n <= e->tiny_max && !need_count) {
-        // one launch: the batch is one bucket (k_bkt_tiny); the hot set is left untouched
-        BatchScratch* tbs = e->d_bs + e->bs_cur;
-        BatchScratch* tbs_next = e->d_bs + (e->bs_cur ^ 1u);
-        e->bs_cur ^= 1u;
-        const bool t_tiny = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
-        if (t_tiny) {
-            if (e->timing == 1)
-                for (int q = 0; q < 3; ++q) HIP_TRY(e, hipEventRecord(f.tev[q], e->stream));
-            HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
-        }
-        k_bkt_tiny<<<1, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_bk_hits, e->d_limits,
-                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, tbs, tbs_next, f.h_st,
-                                                  (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2, e->dbg_vmask);
-        if (t_tiny) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+        // one launch: the batch is one bucket (k_bkt_tiny), on the apply stream, with a scratch and a record
+        // buffer of its own (a partitioned batch's partition may be running beside it); the hot sets are left
+        // untouched
+        if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+        k_bkt_tiny<<<1, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_tiny_hits, e->d_limits,
+                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, e->d_bs + 3, e->d_bs + 3,
+                                                  f.h_st, (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2);
+        if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[5], e->stream));
         HIP_TRY(e, hipGetLastError());
         f.n = n;
         f.n_wg = 1;
         f.ntiles = 0;
-        f.timed = t_tiny ? (e->timing == 1 ? 1 : 2) : 0;
+        f.timed = t_apply ? 2 : 0;
         f.seq = (u32)(e->sub_seq + 1);
         f.settled = false;
         e->inflight_hits += n;
@@ -590,68 +404,69 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
     const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
     const u32 nbt = nb + HOT_MAX;
-    BatchScratch* bs = e->d_bs + e->bs_cur;
-    BatchScratch* bs_next = e->d_bs + (e->bs_cur ^ 1u);
-    e->bs_cur ^= 1u;
-    const HotSet* hot = e->d_hot + e->hot_cur;
-    HotSet* hot_next = e->d_hot + (e->hot_cur ^ 1u);
-    e->hot_cur ^= 1u;
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[0], e->stream));
+    const u64 p = e->part_seq;
+    const u32 par = (u32)(p & 1u);
+    BatchScratch* bs = e->d_bs + p % 3;
+    BatchScratch* bs_zero = e->d_bs + (p + 2) % 3;
+    const HotSet* hot_use = e->d_hot + (p + 1) % 3;
+    HotSet* hot_prod = e->d_hot + p % 3;
+    BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
+    uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
+    HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
+    unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
+    hipStream_t ps = e->pstream;
+    // ---- partition ----------------------------------------------------------------------------------
+    if (two_streams && p >= 2) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - 2) & 3u], 0));
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[0], ps));
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
-    hist_k<<<ntiles, PT_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits,
-                                                   (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot,
-                                                   e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 : nullptr);
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[1], e->stream));
-    k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, e->stream>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[2], e->stream));
+    hist_k<<<ntiles, PT_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(),
+                                        bk_log2, ntiles, e->d_bk_hist, bs, hot_use,
+                                        nullptr);
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[1], ps));
+    k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, ps>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[2], ps));
     auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
-    scatter_k<<<ntiles + 1, PT_BLOCK, 0, e->stream>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total,
-                                                          hot, e->d_bk_hits, e->d_bk_ranges, &bs->st, e->table,
-                                                          e->log2cap, e->d_limits, now, ntiles, e->d_hot_param,
-                                                          hot_next, bs, e->hot_threshold, e->d_chunk_tab,
-                                                          e->d_bk_trace ? e->d_bk_trace + (size_t)(BK_MAX + 64) * 16 + 2048 * 8 : nullptr);
+    scatter_k<<<ntiles + 1, PT_BLOCK, 0, ps>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits,
+                                               ranges, &bs->st, ntiles, hot_param, hot_prod, e->hot_threshold, chunk_tab,
+                                               nullptr);
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[3], ps));
+    HIP_TRY(e, hipGetLastError());
     if (need_count) {
         // the cheap bound (every hit a new key) does not fit: count the batch's new keys exactly, before
-        // anything is applied, and refuse the whole batch if they do not fit
-        u32 n_new = 0;
-        HIP_TRY(e, hipMemsetAsync(e->d_m_flags, 0, sizeof(u32), e->stream));
-        k_bkt_count_new<10><<<nb < 64u ? 64u : nb, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits,
-                                                                         e->d_bk_ranges, nb, e->d_hot_param, e->d_m_flags);
+        // anything is applied, and refuse the whole batch if they do not fit (nothing is in flight here)
+        HIP_TRY(e, hipMemsetAsync(e->d_m_flags, 0, sizeof(u32), ps));
+        k_bkt_count_new<10><<<nb < 64u ? 64u : nb, AP_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, b_hits, ranges, nb,
+                                                                      hot_param, e->d_m_flags);
         HIP_TRY(e, hipGetLastError());
-        HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_m_flags, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        n_new = e->h_m_total[0];
+        HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_m_flags, sizeof(u32), hipMemcpyDeviceToHost, ps));
+        HIP_TRY(e, hipStreamSynchronize(ps));
+        const u32 n_new = e->h_m_total[0];
         if (e->live + e->tombs + n_new > e->cap - e->cap / 16) {
-            // leave the engine as it was: this batch's scratch goes back (clean) to the next batch
-            e->bs_cur ^= 1u;
-            HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), e->stream));
-            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            // leave the engine as it was: this batch's scratch goes back, clean, to the next batch
+            HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), ps));
+            HIP_TRY(e, hipStreamSynchronize(ps));
             return fail(e, RL_ERR_TABLE_FULL,
                         "refused, nothing applied: the batch brings %u new keys into a table with live=%llu "
                         "tombstones=%llu capacity=%llu (bound 15/16): rl_resize, sweep, compact or create a larger engine",
                         n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
         }
     }
-    const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
-    if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[3], e->stream));
-    u32 n_wg;
-    if (e->apply_gen == 2) {
-        // one workgroup per hash bucket (at least 64, so that the hot chunks of a small batch still spread)
-        n_wg = nb < 64u ? 64u : nb;
-        launch_apply2(e, n_wg, d_hits, nb, now, d_verdict, d_first, bs, bs_next, f.h_st, (u32)(e->sub_seq + 1), hot_next);
-    } else {
-        n_wg = 2 * e->n_cus;  // persistent workgroups: two are resident per CU (LDS)
-        if (n_wg < cdiv(nb, AP_MAX_PER_WG)) n_wg = cdiv(nb, AP_MAX_PER_WG);
-        if (n_wg > nb && nb >= 64) n_wg = nb;
-        // the last workgroup of k_bkt_apply writes the status block straight into f.h_st (host-mapped)
-        k_bkt_apply<<<n_wg, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_bk_hits, d_hits,
-                                                      e->d_bk_ranges, nb, e->d_hot_param, e->d_limits,
-                                                      (u32)e->h_limits.size(), now, d_verdict, d_first, bs, bs_next,
-                                                      f.h_st, (u32)(e->sub_seq + 1), hot_next, e->hot_threshold,
-                                                      e->dbg_vmask, e->d_bk_trace);
+    if (two_streams) {
+        HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
     }
+    // ---- apply --------------------------------------------------------------------------------------
+    if (t) HIP_TRY(e, hipEventRecord(f.tev[6], e->stream));
+    k_hot_state<<<1, HOT_MAX, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_limits, now, hot_use, hot_param, &bs->st);
     if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+    // one workgroup per hash bucket (at least 64, so that the hot chunks of a small batch still spread); the
+    // last one out writes the status block straight into f.h_st (host-mapped)
+    const u32 n_wg = nb < 64u ? 64u : nb;
+    launch_apply(e, n_wg, d_hits, nb, par, now, d_verdict, d_first, bs, bs_zero, f.h_st, (u32)(e->sub_seq + 1), hot_prod);
+    if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[5], e->stream));
     HIP_TRY(e, hipGetLastError());
+    if (two_streams) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
+    e->part_seq++;
     f.n = n;
     f.n_wg = n_wg;
     f.ntiles = ntiles;
@@ -666,7 +481,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 // Wait for the oldest batch in flight and account for it.
 int collect_k1_bucketed(rl_engine* e) {
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
-    rl_engine::Inflight& f = e->inflight[e->col_seq & 1u];
+    rl_engine::Inflight& f = e->inflight[e->col_seq & 3u];
     if (!f.settled) {
         const int wrc = wait_done(e, f);
         if (wrc) {
@@ -686,18 +501,21 @@ int collect_k1_bucketed(rl_engine* e) {
     e->stats.batches++;
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
-    if (e->d_bk_trace && f.ntiles && getenv("RL_APPLY_TRACE_DUMP")) {
-        const int rc = dump_apply_trace(e, f.n_wg, f.ntiles, f.h_st);
-        if (rc) return rc;
-    }
     if (f.timed) {
-        float ms[4] = {0, 0, 0, 0};
-        HIP_TRY(e, hipEventSynchronize(f.tev[4]));
-        for (int q = f.timed == 1 ? 0 : 3; q < 4; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], f.tev[q], f.tev[q + 1]));
+        // tev: [0..3] on the partition stream (before hist / scan / scatter, after scatter), [6] [4] [5] on the
+        // apply stream (before k_hot_state, before and after k_bkt_apply)
+        float ms[5] = {0, 0, 0, 0, 0};
+        HIP_TRY(e, hipEventSynchronize(f.tev[5]));
+        if (f.timed == 1) {
+            for (int q = 0; q < 3; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], f.tev[q], f.tev[q + 1]));
+            HIP_TRY(e, hipEventElapsedTime(&ms[4], f.tev[6], f.tev[4]));
+        }
+        HIP_TRY(e, hipEventElapsedTime(&ms[3], f.tev[4], f.tev[5]));
         e->ms_slot[RL_T_HIST] += ms[0];
         e->ms_slot[RL_T_SCAN] += ms[1];
         e->ms_slot[RL_T_SCATTER] += ms[2];
         e->ms_slot[RL_T_APPLY] += ms[3];
+        e->ms_slot[RL_T_HOT_STATE] += ms[4];
         e->timed_launches++;
     }
     return RL_OK;
@@ -712,8 +530,7 @@ int run_check_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8
 }
 
 int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
-    return (e->legacy_k1 || e->h_limits.size() > (size_t)LIM_LDS) ? run_check_k1_legacy(e, d_hits, n, now, d_verdict, d_first)
-                        : run_check_k1_bucketed(e, d_hits, n, now, d_verdict, d_first);
+    return run_check_k1_bucketed(e, d_hits, n, now, d_verdict, d_first);
 }
 
 // check_and_update in its general form (rl_general.hpp): multi-counter requests and/or
@@ -917,11 +734,9 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->max_batch = cfg->max_batch_hits ? cfg->max_batch_hits : (1u << 20);
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
-    if (const char* v = getenv("RL_K1_PATH")) e->legacy_k1 = strcmp(v, "legacy") == 0;
-    if (const char* v = getenv("RL_APPLY")) e->apply_gen = atoi(v) == 1 ? 1 : 2;
+    if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
     if (const char* v = getenv("RL_APPLY2_CFG")) e->apply2_cfg = atoi(v);
     if (const char* v = getenv("RL_DEBUG_APPLY2")) e->dbg_apply2 = (u32)strtoul(v, nullptr, 0);
-    if (const char* v = getenv("RL_DEBUG_VMASK")) e->dbg_vmask = (u32)strtoul(v, nullptr, 0);
     if (const char* v = getenv("RL_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= (long)TINY_MAX) e->tiny_max = (u32)b;
@@ -948,6 +763,16 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (hipSetDevice(e->device) != hipSuccess) return bail(RL_ERR_NO_DEVICE);
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
     e->stream = e->own_stream;
+    if (e->overlap) {
+        if (hipStreamCreateWithFlags(&e->own_pstream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
+        e->pstream = e->own_pstream;
+    } else {
+        e->pstream = e->stream;
+    }
+    for (auto& ev : e->ev_parted)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
+    for (auto& ev : e->ev_applied)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0)
@@ -979,8 +804,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_pass, mb);
     ALLOC(e->d_admitted, mb);
     ALLOC(e->d_status, sizeof(Status));
-    ALLOC(e->d_bs, 2 * sizeof(BatchScratch));
-    if (hipMemset(e->d_bs, 0, 2 * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_bs, 4 * sizeof(BatchScratch));  // three rotating + k_bkt_tiny's own
+    if (hipMemset(e->d_bs, 0, 4 * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_total, sizeof(unsigned long long));
     {
         const u32 big = cdiv(mb, PT_TILE), sm = cdiv(mb, PT_TILE_SMALL) < PT_SMALL_MAX_TILES ? cdiv(mb, PT_TILE_SMALL) : PT_SMALL_MAX_TILES;
@@ -988,18 +813,15 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     }
     ALLOC(e->d_bk_hist, (size_t)ROW_MAX * e->bk_tiles_max * sizeof(u32));
     ALLOC(e->d_bk_total, (size_t)ROW_MAX * sizeof(u32));
-    ALLOC(e->d_bk_ranges, (size_t)BK_MAX * sizeof(uint2));
-    ALLOC(e->d_hot, 2 * sizeof(HotSet));
-    if (hipMemset(e->d_hot, 0, 2 * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);
-    ALLOC(e->d_hot_param, (size_t)(HOT_MAX + 1) * sizeof(HotParam));
-    if (const char* v = getenv("RL_APPLY_TRACE"))
-        if (v[0] == '1') {
-            ALLOC(e->d_bk_trace, ((size_t)(BK_MAX + 64) * 16 + 4096 * 8) * sizeof(u64));
-            if (hipMemset(e->d_bk_trace, 0, ((size_t)(BK_MAX + 64) * 16 + 4096 * 8) * sizeof(u64)) != hipSuccess)
-                return bail(RL_ERR_DEVICE);
-        }
-    ALLOC(e->d_bk_hits, mb * sizeof(BHit));
-    ALLOC(e->d_chunk_tab, ((size_t)mb / HOT_CHUNK + HOT_MAX + 8) * sizeof(unsigned short));
+    ALLOC(e->d_bk_ranges, 2 * (size_t)BK_MAX * sizeof(uint2));
+    ALLOC(e->d_hot, 3 * sizeof(HotSet));
+    if (hipMemset(e->d_hot, 0, 3 * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_hot_param, 2 * (size_t)(HOT_MAX + 1) * sizeof(HotParam));
+    if (hipMemset(e->d_hot_param, 0, 2 * (size_t)(HOT_MAX + 1) * sizeof(HotParam)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_bk_hits, 2 * mb * sizeof(BHit));
+    ALLOC(e->d_tiny_hits, (size_t)TINY_MAX * sizeof(BHit));
+    e->chunk_tab_len = (size_t)mb / HOT_CHUNK + HOT_MAX + 8;
+    ALLOC(e->d_chunk_tab, 2 * e->chunk_tab_len * sizeof(unsigned short));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
     ALLOC(e->d_m_ns, mb * sizeof(u32));
     ALLOC(e->d_m_delta, mb * sizeof(u32));
@@ -1058,11 +880,12 @@ void rl_engine_destroy(rl_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->own_pstream) (void)hipStreamSynchronize(e->own_pstream);
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
                     e->d_remaining, e->d_expires, e->d_hit_slot, e->d_ord_list, e->d_keys_a,  e->d_keys_b,
                     e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp,
-                    e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_trace, e->d_chunk_tab,
+                    e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp};
@@ -1079,6 +902,11 @@ void rl_engine_destroy(rl_engine* e) {
             if (ev) (void)hipEventDestroy(ev);
         if (f.h_st) (void)hipHostFree(f.h_st);
     }
+    for (auto& ev : e->ev_parted)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_applied)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->own_pstream) (void)hipStreamDestroy(e->own_pstream);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1105,8 +933,11 @@ int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
     if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->own_pstream) HIP_TRY(e, hipStreamSynchronize(e->own_pstream));
     e->stream = external ? (hipStream_t)stream : e->own_stream;  // NULL is a stream too: the default one
     e->external_stream = external != 0;
+    // with a caller's stream everything is enqueued there, in order (no overlap of consecutive batches)
+    e->pstream = (external || !e->own_pstream) ? e->stream : e->own_pstream;
     return RL_OK;
 }
 
@@ -1193,8 +1024,7 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
         // and are complete when the kernel's completion word is (both kernels are waited for by polling).
         const bool general = req_off || load_counters;
         const bool one_launch = general ? (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ)
-                                        : (n_hits && n_hits <= e->tiny_max && !e->legacy_k1 &&
-                                           e->h_limits.size() <= (size_t)LIM_LDS);
+                                        : (n_hits && n_hits <= e->tiny_max);
         if (one_launch && n_hits <= TIO_HITS && n_req <= TIO_HITS) {
             Hit* t_hits = reinterpret_cast<Hit*>(e->h_tiny + TIO_OFF_HITS);
             u32* t_off = reinterpret_cast<u32*>(e->h_tiny + TIO_OFF_REQ);
@@ -1220,8 +1050,9 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
             return RL_OK;
         }
     }
-    if (n_hits)
-        HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
+    if (n_hits)  // (the single-counter path reads the batch on the partition stream first)
+        HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice,
+                                  (req_off || load_counters) ? e->stream : e->pstream));
     if (req_off || load_counters) {
         if (req_off) {
             HIP_TRY(e, hipMemcpyAsync(e->d_req_off, req_off, ((size_t)n_req + 1) * sizeof(u32), hipMemcpyHostToDevice,
@@ -1254,8 +1085,6 @@ int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, ui
     std::lock_guard<std::mutex> g(e->mu);
     if (n_hits == 0) return fail(e, RL_ERR_INVALID, "empty batch");
     HIP_TRY(e, hipSetDevice(e->device));
-    if (e->legacy_k1 || e->h_limits.size() > (size_t)LIM_LDS)
-        return fail(e, RL_ERR_INVALID, "submit/collect needs the bucketed path (<= %d limit rows, RL_K1_PATH unset)", LIM_LDS);
     return submit_k1_bucketed(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
 }
 

@@ -254,8 +254,8 @@ class Engine:
         k_bkt_apply of every fourth batch (rl_engine.h)."""
         self._check(self._lib.rl_kernel_timing(self._h, int(mode)))
 
-    TIMING_SLOTS = ("hist", "scan", "scatter", "apply", "legacy_probe", "legacy_decide", "legacy_ordered",
-                    "legacy_commit")  # RL_T_* of include/rl_engine.h
+    TIMING_SLOTS = ("hist", "scan", "scatter", "apply", "hot_state", "reserved5", "reserved6",
+                    "reserved7")  # RL_T_* of include/rl_engine.h
 
     def kernel_timing_read(self, reset=True):
         """{"ms": {slot: accumulated milliseconds}, "launches": timed batches} since the last reset."""

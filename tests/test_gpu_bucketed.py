@@ -29,7 +29,7 @@ def fmix64(x):
 def bucket_log2(n_hits):
     """rl_engine.hip run_check_k1_bucketed: buckets for a batch of n_hits."""
     per = -(-n_hits // 384)
-    return min(11, max(0, int(np.ceil(np.log2(per))) if per > 1 else 0))
+    return min(10, max(0, int(np.ceil(np.log2(per))) if per > 1 else 0))
 
 
 def keys_in_bucket(n_keys, n_hits, bucket=0, start=1):
@@ -169,7 +169,9 @@ def test_hot_key_with_two_limit_ids_is_reported(make_engine):
     assert e.value.code == -6
 
 
-def test_limit_tables_larger_than_the_lds_copy_take_the_first_generation_path(make_engine):
+def test_large_limit_tables_take_the_same_path(make_engine):
+    """k_bkt_apply reads limit rows from global memory: no row limit (the first cut kept the table in LDS
+    and sent tables of more than 512 rows through the first-generation pipeline)."""
     rng = np.random.default_rng(14)
     rows = [(int(rng.integers(1, 50)), 60) for _ in range(700)]
     eng, orc = pair(make_engine, rows, max_limits=1024)
@@ -178,7 +180,7 @@ def test_limit_tables_larger_than_the_lds_copy_take_the_first_generation_path(ma
     run_both(eng, orc, hits, NOW)
     run_both(eng, orc, hits, NOW + 1)
     assert_same_state(eng, orc)
-    assert eng.stats()["ordered_batches"] > 0  # the legacy pipeline ran
+    assert eng.stats()["ordered_batches"] == 0
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 383, 385, 511, 513, 1023, 1024, 1025, 2049, 4097, 8191,
@@ -202,8 +204,9 @@ def test_batch_sizes_around_the_tile_and_round_boundaries(make_engine, monkeypat
 
 
 def test_submit_collect_keeps_the_sequential_contract(make_engine):
-    """Two batches in flight (rl_check_and_update_submit_device / _collect) on overlapping keys: the
-    result is the reference applied to batch 0, then batch 1, ...; other entry points answer BUSY."""
+    """Three batches in flight (rl_check_and_update_submit_device / _collect; the partition of one overlaps
+    k_bkt_apply of the one before) on overlapping keys: the result is the reference applied to batch 0, then
+    batch 1, ...; other entry points answer BUSY."""
     import torch
 
     from limitador_amd.engine import EngineError
@@ -223,16 +226,18 @@ def test_submit_collect_keeps_the_sequential_contract(make_engine):
     out = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(6)]
     torch.cuda.synchronize()
     eng.submit_device(batches[0].data_ptr(), n, now, out[0].data_ptr())
-    for step in range(1, 6):
+    eng.submit_device(batches[1].data_ptr(), n, now + 1, out[1].data_ptr())
+    for step in range(2, 6):
         eng.submit_device(batches[step].data_ptr(), n, now + step, out[step].data_ptr())
         if step == 3:
-            with pytest.raises(EngineError) as e:  # two in flight: a third submit, or any other call, is refused
+            with pytest.raises(EngineError) as e:  # three in flight: a fourth submit, or any other call, is refused
                 eng.submit_device(batches[0].data_ptr(), n, now, out[0].data_ptr())
             assert e.value.code == -9 and e.value.transient
             with pytest.raises(EngineError) as e:
                 eng.dump_cells()
             assert e.value.code == -9
         eng.collect()
+    eng.collect()
     eng.collect()
     with pytest.raises(EngineError):
         eng.collect()  # nothing left
