@@ -147,6 +147,19 @@ int32_t rl_check_and_update_batch(rl_engine *e, const rl_hit *hits, uint32_t n_h
                                   const uint32_t *req_off, uint32_t n_req, uint64_t now_us,
                                   int32_t load_counters, uint8_t *verdict, int32_t *first_limited,
                                   uint64_t *remaining, uint64_t *expires_in_us);
+/* The same with the reference's full-width arguments:
+ *   req_delta[n_req]   (may be NULL) the request's delta as the trait's u64 (`delta: u64`, in_memory.rs:75;
+ *                      storage/mod.rs:283-288) — it replaces the 32-bit wire field of the request's hits, so a
+ *                      delta beyond 2^32 is answered like the reference answers it (Limited / wrapping add,
+ *                      in_memory.rs:259-264), never with an error;
+ *   req_now_us[n_req]  (may be NULL) the clock value each request reads (in_memory.rs:83 reads it once per
+ *                      call) instead of one now_us for the whole batch: the requests are applied as
+ *                      consecutive runs that share a clock value. */
+int32_t rl_check_and_update_batch_ex(rl_engine *e, const rl_hit *hits, uint32_t n_hits,
+                                     const uint32_t *req_off, uint32_t n_req, const uint64_t *req_delta,
+                                     const uint64_t *req_now_us, uint64_t now_us, int32_t load_counters,
+                                     uint8_t *verdict, int32_t *first_limited, uint64_t *remaining,
+                                     uint64_t *expires_in_us);
 /* Same, every pointer a DEVICE pointer on the engine's device (the rate quoted by bench.py).
  * Work is enqueued on the engine's stream and the call returns after the batch has completed
  * (it must read the batch status word to decide whether the ordered resolver is needed). */
@@ -159,9 +172,11 @@ int32_t rl_check_and_update_batch_device(rl_engine *e, const rl_hit *d_hits, uin
 /* The same for single-counter requests (every hit its own request, no load_counters), split in two so
  * that a feeder (a micro-batcher) can keep the device busy: _submit enqueues the batch on the engine's
  * stream and returns; _collect waits for the OLDEST submitted batch and returns ITS status (verdicts
- * and first_limited of that batch are then complete).  At most two batches may be in flight; they are
- * applied in submission order, so the sequential contract holds across them.  While batches are in
- * flight every other entry point returns RL_ERR_BUSY. */
+ * and first_limited of that batch are then complete for work ordered after the batch on the engine's stream;
+ * a reader on another stream, or the host, synchronises with that stream first).  At most three batches may
+ * be in flight; they are applied in submission order, so the sequential contract holds across them, and the
+ * partition of one overlaps the replay of the one before (two streams inside the engine).  While batches
+ * are in flight every other entry point returns RL_ERR_BUSY. */
 int32_t rl_check_and_update_submit_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
                                           uint8_t *d_verdict, int32_t *d_first_limited);
 int32_t rl_check_and_update_collect(rl_engine *e);
@@ -174,6 +189,11 @@ int32_t rl_is_within_limits_batch(rl_engine *e, const rl_hit *hits, uint32_t n_h
  * find-or-create then AtomicExpiringValue::update; never checks the limit. */
 int32_t rl_update_counter_batch(rl_engine *e, const rl_hit *hits, uint32_t n_hits,
                                 uint64_t now_us);
+/* Both with the trait's `delta: u64` per hit (delta[n_hits], may be NULL: the 32-bit wire field). */
+int32_t rl_is_within_limits_batch_ex(rl_engine *e, const rl_hit *hits, uint32_t n_hits,
+                                     const uint64_t *delta, uint64_t now_us, uint8_t *within);
+int32_t rl_update_counter_batch_ex(rl_engine *e, const rl_hit *hits, uint32_t n_hits,
+                                   const uint64_t *delta, uint64_t now_us);
 
 /* ---- the rest of the CounterStorage surface -------------------------------------------- */
 /* CounterStorage::get_counters (in_memory.rs:159-187) for one limit: every cell of that limit

@@ -67,12 +67,16 @@ def _declare(lib):
     _sig(lib, "rl_add_counter", C.c_int32, [p, C.c_uint32, C.c_uint64])
     _sig(lib, "rl_check_and_update_batch", C.c_int32,
          [p, p, C.c_uint32, p, C.c_uint32, C.c_uint64, C.c_int32, p, p, p, p])
+    _sig(lib, "rl_check_and_update_batch_ex", C.c_int32,
+         [p, p, C.c_uint32, p, C.c_uint32, p, p, C.c_uint64, C.c_int32, p, p, p, p])
     _sig(lib, "rl_check_and_update_batch_device", C.c_int32,
          [p, p, C.c_uint32, p, C.c_uint32, C.c_uint64, C.c_int32, p, p, p, p])
     _sig(lib, "rl_check_and_update_submit_device", C.c_int32, [p, p, C.c_uint32, C.c_uint64, p, p])
     _sig(lib, "rl_check_and_update_collect", C.c_int32, [p])
     _sig(lib, "rl_is_within_limits_batch", C.c_int32, [p, p, C.c_uint32, C.c_uint64, p])
     _sig(lib, "rl_update_counter_batch", C.c_int32, [p, p, C.c_uint32, C.c_uint64])
+    _sig(lib, "rl_is_within_limits_batch_ex", C.c_int32, [p, p, C.c_uint32, p, C.c_uint64, p])
+    _sig(lib, "rl_update_counter_batch_ex", C.c_int32, [p, p, C.c_uint32, p, C.c_uint64])
     _sig(lib, "rl_get_counters", C.c_int32, [p, C.c_uint32, C.c_uint64, p, C.c_uint64, u64p])
     _sig(lib, "rl_delete_counters", C.c_int32, [p, C.c_uint32])
     _sig(lib, "rl_clear", C.c_int32, [p])

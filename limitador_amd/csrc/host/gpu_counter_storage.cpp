@@ -128,11 +128,11 @@ uint64_t GpuCounterStorage::key_of(uint32_t id, const Counter& c) {
 }
 
 int GpuCounterStorage::to_hit(const Counter& c, uint64_t delta, rl_hit* out) {
-    if (delta > 0xFFFFFFFFull) return fail_invalid("delta does not fit the 32-bit wire field (Envoy's hits_addend is uint32)");
     const uint32_t id = limit_id(c.limit);
     out->limit = id | (c.is_qualified() ? 0u : RL_SIMPLE);
     out->key = key_of(id, c);
-    out->delta = (uint32_t)delta;
+    // the 32-bit wire field; a delta beyond it travels in the call's u64 delta array (the trait's `delta: u64`)
+    out->delta = delta > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)delta;
     return RL_OK;
 }
 
@@ -141,7 +141,7 @@ int GpuCounterStorage::is_within_limits(const Counter& counter, uint64_t delta, 
     rl_hit h;
     if (int rc = to_hit(counter, delta, &h)) return rc;
     uint8_t w = 0;
-    if (int rc = rl_is_within_limits_batch(eng_, &h, 1, now_us(), &w)) return fail(rc);
+    if (int rc = rl_is_within_limits_batch_ex(eng_, &h, 1, delta > 0xFFFFFFFFull ? &delta : nullptr, now_us(), &w)) return fail(rc);
     *within = w != 0;
     return RL_OK;
 }
@@ -160,7 +160,7 @@ int GpuCounterStorage::update_counter(const Counter& counter, uint64_t delta) {
     std::lock_guard<std::mutex> g(mu_);
     rl_hit h;
     if (int rc = to_hit(counter, delta, &h)) return rc;
-    if (int rc = rl_update_counter_batch(eng_, &h, 1, now_us())) return fail(rc);
+    if (int rc = rl_update_counter_batch_ex(eng_, &h, 1, delta > 0xFFFFFFFFull ? &delta : nullptr, now_us())) return fail(rc);
     return RL_OK;
 }
 
@@ -183,6 +183,8 @@ int GpuCounterStorage::check_and_update_many(std::vector<Request*>& reqs) {
         // the reference applied to the requests one at a time
         const bool load = reqs[begin]->load_counters;
         std::vector<rl_hit> hits;
+        std::vector<uint64_t> deltas;  // per request, as the trait's u64
+        bool big_delta = false;
         std::vector<uint32_t> off{0};
         std::vector<std::vector<size_t>> order;  // per request: caller index of each hit
         size_t end = begin;
@@ -202,6 +204,8 @@ int GpuCounterStorage::check_and_update_many(std::vector<Request*>& reqs) {
                 hits.push_back(h);
             }
             off.push_back((uint32_t)hits.size());
+            deltas.push_back(r->delta);
+            big_delta = big_delta || r->delta > 0xFFFFFFFFull;
             all_single = all_single && cs.size() == 1;
             order.push_back(std::move(ord));
             ++end;
@@ -210,10 +214,11 @@ int GpuCounterStorage::check_and_update_many(std::vector<Request*>& reqs) {
         std::vector<uint8_t> verdict(n_req);
         std::vector<int32_t> first(n_req);
         std::vector<uint64_t> rem(load ? hits.size() : 0), exp(load ? hits.size() : 0);
-        const int rc = rl_check_and_update_batch(eng_, hits.data(), (uint32_t)hits.size(),
-                                                 (all_single && !load) ? nullptr : off.data(), n_req, now,
-                                                 load ? 1 : 0, verdict.data(), first.data(),
-                                                 load ? rem.data() : nullptr, load ? exp.data() : nullptr);
+        const int rc = rl_check_and_update_batch_ex(eng_, hits.data(), (uint32_t)hits.size(),
+                                                    (all_single && !load) ? nullptr : off.data(), n_req,
+                                                    big_delta ? deltas.data() : nullptr, nullptr, now, load ? 1 : 0,
+                                                    verdict.data(), first.data(), load ? rem.data() : nullptr,
+                                                    load ? exp.data() : nullptr);
         if (rc) return fail(rc);
         for (uint32_t q = 0; q < n_req; ++q) {
             Request* r = reqs[begin + q];

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
                                                        const LimitDev* __restrict__ limits,
                                                        u32 n_limits, u32 bk_log2, u32 ntiles,
                                                        u32* __restrict__ hist, BatchScratch* bs,
-                                                       const HotSet* __restrict__ hot, u64* htrace) {
+                                                       const HotSet* __restrict__ hot, u32 check_simple,
+                                                       u64* htrace) {
     __shared__ u32 s_hist[BKT_MAX];
     __shared__ u64 s_hot_key[HOT_HASH];
     __shared__ u32 s_hot_idx[HOT_HASH];
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
         if (i < n) {
             if ((h[r].limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
             else if (h[r].key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
-            else if (h[r].limit & SIMPLE_FLAG) {
+            else if ((h[r].limit & SIMPLE_FLAG) && check_simple) {  // (update_counter creates simple cells: in_memory.rs:60-62)
                 u32 dummy = 0;
                 u32 slot = slot_of(h[r].key, seed, log2cap);
                 slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, h[r].key,
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                                                           uint2* __restrict__ ranges, const Status* st,
                                                           u32 ntiles, HotParam* __restrict__ hot_param,
                                                           HotSet* __restrict__ hot_next, u32 hot_threshold,
-                                                          unsigned short* __restrict__ chunk_tab, u64* htrace) {
+                                                          unsigned short* __restrict__ chunk_tab, u32 all_chunks,
+                                                          u64* htrace) {
     __shared__ __align__(16) unsigned short s_cnt[PT_WAVES][BKT_MAX];
     __shared__ u32 s_base[BKT_MAX];
     __shared__ u32 s_w[PT_WAVES];
@@ -437,7 +439,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                     if (pos < (u32)HOT_MAX) hot_next->key[pos] = hot->key[tid];
                 }
             }
-            s_nchunk[tid] = hp.uni ? (cnt + HOT_CHUNK - 1) / HOT_CHUNK : 0u;
+            // (the general resolver walks EVERY hot bucket in chunks: all_chunks)
+            s_nchunk[tid] = (hp.uni || all_chunks) ? (cnt + HOT_CHUNK - 1) / HOT_CHUNK : 0u;
             hot_param[tid] = hp;
         }
         __syncthreads();

@@ -1,11 +1,11 @@
 // rl_cell.hpp — HBM data layout of the counter table and the device-side helpers every
 // kernel shares.  gfx950 only.
 //
-// One counter cell is ONE 64-byte line.  Every access on the hot path is a random access to
-// a single cell, so the cell's persistent state (what the reference keeps in the 16-byte
-// AtomicExpiringValue, limitador/src/storage/atomic_expiring_value.rs:5-9, plus its key) and
-// the per-batch scratch the kernels need (pending sum, hit count, flags) share the line: a hit
-// costs one line from HBM, and the later phases of the same batch find it in L2 / MALL.
+// One counter cell is 32 bytes, two per 64-byte line: the key, the 16-byte AtomicExpiringValue of the
+// reference (limitador/src/storage/atomic_expiring_value.rs:5-9) and the limit id.  Every access on the hot
+// path is a random access to a single cell, read as two 16-byte loads of one 32-byte sector; the streaming
+// operations (sweep, get_counters, delete, dump, rehash) move 32 B per slot.  No per-batch scratch lives in
+// the table: the batch pipelines keep theirs in LDS (rl_apply.hpp) or in per-pass arrays (rl_general.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,28 +19,14 @@ constexpr u64 TAG_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 constexpr u64 TAG_TOMB = 0xFFFFFFFFFFFFFFFEull;
 constexpr u32 SIMPLE_FLAG = 0x80000000u;
 
-// amb states (per-batch scratch)
-constexpr u32 AMB_NONE = 0;     // cell decided without looking at trace order
-constexpr u32 AMB_PENDING = 1;  // some hit of this batch needs trace-order resolution
-constexpr u32 AMB_ADMIT = 2;    // resolved: at least one hit admitted, aux = final value
-constexpr u32 AMB_DENY = 3;     // resolved: nothing admitted, cell unchanged
-
-struct alignas(64) Cell {
+struct alignas(32) Cell {
     u64 tag;     //  0  key, TAG_EMPTY or TAG_TOMB                       } one dwordx4
     u64 value;   //  8  AtomicExpiringValue.value                        }
-    u64 expiry;  // 16  AtomicExpiringValue.expiry (us since epoch)      } one dwordx4: what the hot path
-    u32 limit;   // 24  limit id | SIMPLE_FLAG (attribute of the cell)   } reads besides tag + value
-    u32 cnt;     // 28  reserved                                         }
-    // ---- per-batch scratch of the general resolver / first-generation pipeline: 32 contiguous bytes,
-    //      zero between batches, cleared with two 16-byte stores ------------------------------------
-    u64 pend;    // 32  (hit count << 40) | sum of deltas of this batch
-    u64 aux;     // 40  resolver's final value, or (idx+1)<<32|delta for 0-second windows
-    u32 amb;     // 48  AMB_*
-    u32 nonuni;  // 52  ordered segment has non-uniform deltas / needs sequential walk
-    u32 seg;     // 56  start of this cell's segment in the sorted ordered list
-    u32 pad;     // 60  general resolver: 1 = created by this batch, not yet reached; 2 = reached
+    u64 expiry;  // 16  AtomicExpiringValue.expiry (us since epoch)      } one dwordx4
+    u32 limit;   // 24  limit id | SIMPLE_FLAG (attribute of the cell)   }
+    u32 pad;     // 28  reserved (0)                                     }
 };
-static_assert(sizeof(Cell) == 64, "one cell = one 64-byte line");
+static_assert(sizeof(Cell) == 32, "one cell = one 32-byte sector");
 
 // Device copy of one rl_limit_row, window pre-multiplied to microseconds
 // (counter.rs:76-78 Duration::from_secs; atomic_expiring_value.rs:88 as_micros).
@@ -64,26 +50,10 @@ constexpr u32 ERRBIT_MISSING_SIMPLE = 2u;
 constexpr u32 ERRBIT_TABLE_FULL = 4u;
 constexpr u32 ERRBIT_KEY_LIMIT = 8u;
 constexpr u32 ERRBIT_RESERVED_KEY = 16u;
-constexpr u32 ERRBIT_BIG_DELTA = 32u;  // not an error: the batch must take the exact general path
 
-// One 64-bit atomic per (tile, cell) carries both the hit count (leader election) and the delta
-// sum: count in the top 24 bits, sum in the low 40.  Exact as long as the deltas of a whole batch
-// cannot carry out of 40 bits; k_probe flags any delta >= 2^40 / n_hits and the host then reruns
-// the batch through the general path, which does not use the sum.
-constexpr u32 PEND_SHIFT = 40;
-constexpr u64 PEND_SUM_MASK = (1ull << PEND_SHIFT) - 1ull;
-constexpr u32 MAX_BATCH_HITS = (1u << 24) - 1u;
+constexpr u32 MAX_BATCH_HITS = (1u << 24) - 1u;  // hit indices travel in 24 bits (BHit.idx_tag)
 
 constexpr u32 SLOT_INVALID = 0x7FFFFFFFu;
-constexpr u32 SLOT_MASK = 0x7FFFFFFFu;
-constexpr u32 LEADER_BIT = 0x80000000u;
-
-// Zero the scratch half of a cell (bytes 32..63).
-__device__ __forceinline__ void cell_clear_scratch(Cell* c) {
-    uint4* p = reinterpret_cast<uint4*>(&c->pend);
-    p[0] = make_uint4(0, 0, 0, 0);
-    p[1] = make_uint4(0, 0, 0, 0);
-}
 
 __host__ __device__ inline u64 fmix64(u64 x) {
     x ^= x >> 33;

@@ -12,7 +12,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <algorithm>
 #include <chrono>
@@ -24,7 +23,6 @@
 
 #include "rl_cell.hpp"
 #include "rl_kernels.hpp"
-#include "rl_ordered.hpp"
 #include "rl_bucket.hpp"
 #include "rl_apply.hpp"
 #include "rl_general.hpp"
@@ -37,6 +35,8 @@ static_assert(sizeof(rl_hit) == sizeof(Hit), "rl_hit layout");
 static_assert(sizeof(rl_cell_row) == sizeof(CellRow), "rl_cell_row layout");
 static_assert(sizeof(rl_match_limit) == sizeof(MatchLimit), "rl_match_limit layout");
 static_assert(sizeof(rl_match_cond) == sizeof(MatchCond), "rl_match_cond layout");
+
+constexpr u32 GEN_SUB_MAX = 4u << 20;  // most hits of one pass of the general resolver (its scratch is ~80 B per hit)
 
 struct rl_engine {
     std::mutex mu;
@@ -64,20 +64,21 @@ struct rl_engine {
     int32_t* d_first = nullptr;   // staging
     u64* d_remaining = nullptr;   // staging
     u64* d_expires = nullptr;     // staging
-    u32* d_hit_slot = nullptr;
-    u32* d_ord_list = nullptr;
-    u64* d_keys_a = nullptr;
-    u64* d_keys_b = nullptr;
-    void* d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
-    // general resolver (rl_general.hpp)
-    u32* d_hit_req = nullptr;
-    Contrib* d_contrib = nullptr;
-    Contrib* d_scan = nullptr;
-    uint8_t* d_pass = nullptr;
-    uint8_t* d_admitted = nullptr;
-    void* d_scan_tmp = nullptr;
-    size_t scan_tmp_bytes = 0;
+    // general resolver (rl_general.hpp): scratch of one pass (gen_cap hits)
+    u32 gen_cap = 0;
+    u32 gen_sub_max = GEN_SUB_MAX;  // RL_GEN_SUB_MAX: hits per pass
+    u32* d_hit_req = nullptr;       // [max_batch] hit -> request of the whole call
+    u64* d_req_delta = nullptr;     // [max_batch] staging of per-request u64 deltas
+    SHit* d_g_shits = nullptr;
+    SegInfo* d_g_seginfo = nullptr;
+    SegTot* d_g_segtot = nullptr;
+    SegTot* d_g_piece = nullptr;
+    u32* d_g_hitseg = nullptr;
+    uint8_t* d_g_reached = nullptr;
+    uint8_t* d_g_pass = nullptr;    // [2][gen_cap]
+    uint8_t* d_g_admitted = nullptr;
+    GenStatus* d_gst = nullptr;
+    CellRow* d_row1 = nullptr;      // one staged row (rl_add_counter)
     Status* d_status = nullptr;
     Status* h_status = nullptr; // pinned
     BatchScratch* d_bs = nullptr;   // [3], rotating: batch k uses [k % 3] and zeroes [(k + 2) % 3] (rl_bucket.hpp)
@@ -161,7 +162,7 @@ namespace {
 // layout of rl_engine::h_tiny (host-mapped staging of a one-launch host-buffer call)
 constexpr size_t TIO_HITS = 1024;
 constexpr size_t TIO_OFF_HITS = 0, TIO_OFF_REQ = 16384, TIO_OFF_VERDICT = 24576, TIO_OFF_FIRST = 25600,
-                 TIO_OFF_REM = 29696, TIO_OFF_EXP = 37888, TIO_BYTES = 46080;
+                 TIO_OFF_REM = 29696, TIO_OFF_EXP = 37888, TIO_OFF_DELTA = 46080, TIO_BYTES = 54272;
 
 int fail(rl_engine* e, int code, const char* fmt, ...) {
     char buf[512];
@@ -260,23 +261,6 @@ int check_room(rl_engine* e, u64 incoming, bool* need_count = nullptr) {
     }
 }
 
-// The first-generation pipelines (general resolver, update_counter, RL_K1_PATH=legacy) create cells while
-// they probe and keep the round-1 occupancy heuristic until they are replaced by bucketed forms.
-int check_room_lenient(rl_engine* e, u64 incoming) {
-    for (int rc = RL_OK;;) {
-        const u64 used = e->live + e->tombs;
-        const bool grow_now = e->auto_grow && used + incoming > e->cap - e->cap / 4;
-        const bool ok = !(used > e->cap - e->cap / 4 || used + (incoming < e->cap / 8 ? incoming : e->cap / 8) > e->cap);
-        if (ok && !grow_now) return RL_OK;
-        if (grow_instead(e, &rc)) continue;
-        if (rc) return rc;
-        if (ok) return RL_OK;
-        return fail(e, RL_ERR_TABLE_FULL, "table past 75%% occupancy (live=%llu tombstones=%llu incoming<=%llu capacity=%llu)",
-                    (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)incoming,
-                    (unsigned long long)e->cap);
-    }
-}
-
 // Rehash the live cells into a fresh table of 2^new_log2cap cells (0: same size — a compaction).
 int do_compact(rl_engine* e, u32 new_log2cap) {
     if (!new_log2cap) new_log2cap = e->log2cap;
@@ -302,8 +286,6 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
     return RL_OK;
 }
 
-int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_req_off, u32 n_req, u64 now,
-                      bool load, uint8_t* d_verdict, int32_t* d_first, u64* d_rem, u64* d_exp);
 
 // Spin until the batch's last workgroup has stored its sequence number (see apply_finish).
 int wait_done(rl_engine* e, rl_engine::Inflight& f) {
@@ -420,15 +402,14 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     if (t) HIP_TRY(e, hipEventRecord(f.tev[0], ps));
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
     hist_k<<<ntiles, PT_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(),
-                                        bk_log2, ntiles, e->d_bk_hist, bs, hot_use,
-                                        nullptr);
+                                        bk_log2, ntiles, e->d_bk_hist, bs, hot_use, 1u, nullptr);
     if (t) HIP_TRY(e, hipEventRecord(f.tev[1], ps));
     k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, ps>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     if (t) HIP_TRY(e, hipEventRecord(f.tev[2], ps));
     auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
     scatter_k<<<ntiles + 1, PT_BLOCK, 0, ps>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits,
                                                ranges, &bs->st, ntiles, hot_param, hot_prod, e->hot_threshold, chunk_tab,
-                                               nullptr);
+                                               0u, nullptr);
     if (t) HIP_TRY(e, hipEventRecord(f.tev[3], ps));
     HIP_TRY(e, hipGetLastError());
     if (need_count) {
@@ -533,26 +514,194 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
     return run_check_k1_bucketed(e, d_hits, n, now, d_verdict, d_first);
 }
 
-// check_and_update in its general form (rl_general.hpp): multi-counter requests and/or
-// load_counters.  Exact for every input; slower than run_check_k1 (sorts every hit).
-int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_req_off, u32 n_req, u64 now,
-                      bool load, uint8_t* d_verdict, int32_t* d_first, u64* d_rem, u64* d_exp) {
-    // The resolver creates the cells of every counter it sees and drops the ones no request reached
-    // (tombstones): compact when they pile up, before they stretch the probe chains.
-    if (e->tombs > e->cap / 8) {
-        const int crc = do_compact(e, 0);
-        if (crc) return crc;
+// ---- the general form (rl_general.hpp): multi-counter requests, load_counters, u64 deltas, update_counter ----
+constexpr u32 GEN_ROUNDS_ENQ = 4;           // fixpoint rounds enqueued blind between two looks at the status block
+
+struct GenCall {
+    const Hit* d_hits;
+    u32 n_hits;
+    const u32* d_req_off;  // null: every hit its own request
+    u32 n_req;
+    const u64* d_req_delta;  // null: the wire field
+    u64 now;
+    bool load, update_mode;
+    uint8_t* d_verdict;
+    int32_t* d_first;
+    u64* d_rem;
+    u64* d_exp;
+};
+
+// One pass: requests [req0, req0 + n_req) = hits [hit0, hit0 + n) of the call.  *overflow: a hash bucket was
+// too long for k_gen_sort, nothing was applied, the caller retries with smaller passes.
+int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hit0, u32 n, bool* overflow) {
+    *overflow = false;
+    hipStream_t st = e->stream;
+    if (n == 0) {  // only empty requests: lib.rs:434-440, not limited
+        HIP_TRY(e, hipMemsetAsync(c.d_verdict + req0, 0, n_req, st));
+        if (c.d_first) HIP_TRY(e, hipMemsetAsync(c.d_first + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
+        return RL_OK;
     }
-    int rc = check_room_lenient(e, n_hits);
+    int rc = check_room(e, 0);  // (the cells the pass creates are counted exactly below, before the commit)
     if (rc) return rc;
-    if (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ) {
+    const u64 p = e->part_seq;
+    const u32 par = (u32)(p & 1u);
+    BatchScratch* bs = e->d_bs + p % 3;
+    const HotSet* hot_use = e->d_hot + (p + 1) % 3;
+    HotSet* hot_prod = e->d_hot + p % 3;
+    BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
+    uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
+    HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
+    unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
+    const Hit* hits = c.d_hits + hit0;
+    // ---- partition ----------------------------------------------------------------------------------
+    u32 bk_log2 = ceil_log2(cdiv(n, 512));
+    if (bk_log2 > (u32)BK_LOG2_MAX) bk_log2 = BK_LOG2_MAX;
+    const u32 nb = 1u << bk_log2, nbt = nb + HOT_MAX;
+    const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
+    const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
+    HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), st));
+    HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
+    const bool mark = !c.load && !c.update_mode && c.d_req_off != nullptr;
+    if (mark) HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, st));
+    auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
+    hist_k<<<ntiles, PT_BLOCK, 0, st>>>(e->table, e->log2cap, e->seed, hits, n, e->d_limits, (u32)e->h_limits.size(), bk_log2,
+                                        ntiles, e->d_bk_hist, bs, hot_use, c.update_mode ? 0u : 1u, nullptr);
+    k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, st>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
+    auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
+    scatter_k<<<ntiles + 1, PT_BLOCK, 0, st>>>(hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits, ranges,
+                                               &bs->st, ntiles, hot_param, hot_prod, e->hot_threshold, chunk_tab, 1u, nullptr);
+    // ---- sort by cell, resolve the cells ---------------------------------------------------------------
+    GenArgs A{};
+    A.table = e->table;
+    A.log2cap = e->log2cap;
+    A.seed = e->seed;
+    A.limits = e->d_limits;
+    A.now = c.now;
+    A.hits = hits;
+    A.hit_req = c.d_req_off ? e->d_hit_req : nullptr;
+    A.req_off = c.d_req_off;
+    A.req_delta = c.d_req_delta;
+    A.hit0 = hit0;
+    A.req0 = req0;
+    A.n_hits = n;
+    A.n_req = n_req;
+    A.b_hits = b_hits;
+    A.ranges = ranges;
+    A.nb = nb;
+    A.hot_param = hot_param;
+    A.chunk_tab = chunk_tab;
+    A.hot_next = hot_prod;
+    A.hot_threshold = e->hot_threshold;
+    A.s_hits = e->d_g_shits;
+    A.seg_info = e->d_g_seginfo;
+    A.seg_tot = e->d_g_segtot;
+    A.piece_sum = e->d_g_piece;
+    A.hit_seg = mark ? e->d_g_hitseg : nullptr;
+    A.reached = e->d_g_reached;
+    A.pass[0] = e->d_g_pass;
+    A.pass[1] = e->d_g_pass + e->gen_cap;
+    A.admitted = e->d_g_admitted;
+    A.verdict = c.d_verdict + req0;
+    A.first_limited = c.d_first ? c.d_first + req0 : nullptr;
+    A.remaining = c.load ? c.d_rem + hit0 : nullptr;
+    A.expires_in = c.load ? c.d_exp + hit0 : nullptr;
+    A.gst = e->d_gst;
+    A.pst = &bs->st;
+    A.load = c.load ? 1u : 0u;
+    A.update_mode = c.update_mode ? 1u : 0u;
+    A.mark_reached = mark ? 1u : 0u;
+    k_gen_sort<<<nb + GS_HOT_BLOCKS, GS_BLOCK, 0, st>>>(A);
+    HIP_TRY(e, hipGetLastError());
+    // ---- fixpoint rounds: a few at a time, each returning at once if the one before changed nothing; then
+    //      k_gen_commit, which applies the pass only if the status block says it is final and fits -------------
+    u32 round = 0;
+    Status h_bst;
+    GenStatus h_gst;
+    auto cleanup = [&]() -> int {  // leave the rotating scratches clean for whatever batch comes next
+        HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), st));
+        return RL_OK;
+    };
+    for (;;) {
+        const u32 n_enq = c.update_mode ? 1u : GEN_ROUNDS_ENQ;
+        for (u32 q = 0; q < n_enq; ++q, ++round) {
+            // slot of changed[]: rounds of one group use slots 1.., the group's first round runs unconditionally
+            const u32 check = q == 0 ? 0u : q;
+            if (round > 0) k_gen_admit<<<cdiv(n_req, 256), 256, 0, st>>>(A, round, check);
+            k_gen_hot_sum<<<GS_HOT_BLOCKS, GS_BLOCK, 0, st>>>(A, round, check, q + 1);
+            k_gen_round<<<nb + GS_HOT_BLOCKS, GS_BLOCK, 0, st>>>(A, round, check, q + 1);
+        }
+        k_gen_final<<<cdiv(n_req, 256), 256, 0, st>>>(A);
+        k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A);
+        const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
+        k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipMemcpyAsync(&h_bst, &bs->st, sizeof(Status), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        e->stats.probe_steps += h_gst.rounds_run;
+        // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
+        if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
+        else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
+        const u32 err = h_bst.err | h_gst.err;
+        if (err || h_gst.overflow || h_gst.committed) break;
+        if (c.update_mode || !h_gst.changed[h_gst.last_slot]) break;  // converged, yet not committed: no room
+        if (round > n_req + 2 + GEN_ROUNDS_ENQ) return fail(e, RL_ERR_DEVICE, "general resolver did not converge (bug)");
+        // not yet: forget this group's flags, counts and reached marks, go on from the last round's pass flags
+        HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
+        if (mark) HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, st));
+    }
+    if (h_bst.err | h_gst.err) {
+        rc = cleanup();
+        return rc ? rc : status_to_error(e, h_bst.err | h_gst.err);  // nothing was applied
+    }
+    if (h_gst.overflow) {
+        // nothing was applied.  k_gen_sort promoted the heavy keys of the long buckets into this attempt's hot
+        // set: skipping one step of the rotation makes the retry partition with exactly that set.
+        *overflow = true;
+        e->part_seq += 2;
+        return cleanup();
+    }
+    if (!h_gst.committed) {
+        // ---- converged, but the cells the pass creates do not fit: grow (and redo the pass against the new
+        //      table: the cells' slots are stale) or refuse; nothing was applied ---------------------------------
+        rc = RL_OK;
+        const u64 cap_before = e->cap;
+        if (grow_instead(e, &rc) && e->cap > cap_before) {
+            rc = cleanup();
+            if (rc) return rc;
+            return run_general_pass(e, c, req0, n_req, hit0, n, overflow);
+        }
+        const int crc = cleanup();
+        if (rc) return rc;
+        if (crc) return crc;
+        return fail(e, RL_ERR_TABLE_FULL,
+                    "refused, nothing applied: the batch creates %u cells in a table with live=%llu tombstones=%llu "
+                    "capacity=%llu (bound 15/16): rl_resize, sweep, compact or create a larger engine",
+                    h_gst.n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
+    }
+    e->live += h_gst.n_new;
+    e->part_seq++;
+    rc = cleanup();
+    if (rc) return rc;
+    e->stats.batches++;
+    e->stats.hits += n;
+    e->stats.ordered_hits += n;
+    e->stats.ordered_batches++;
+    return RL_OK;
+}
+
+int run_check_general(rl_engine* e, const GenCall& c) {
+    if (c.n_hits && c.n_hits <= e->gen_tiny_max && c.n_req <= GT_MAX_REQ && !c.update_mode) {
         // A few requests (the per-request calls of the trait): one workgroup, one launch (k_gen_tiny),
         // completion through a sequence word in the host-mapped status block.
+        int rc = check_room(e, c.n_hits);
+        if (rc) return rc;
         const u32 seq = ++e->gen_seq ? e->gen_seq : ++e->gen_seq;
         __atomic_store_n(&e->h_status->n_removed, 0u, __ATOMIC_RELEASE);
-        k_gen_tiny<<<1, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n_hits, d_req_off, n_req, e->d_limits,
-                                             (u32)e->h_limits.size(), now, load ? 1 : 0, d_verdict, d_first,
-                                             load ? d_rem : nullptr, load ? d_exp : nullptr, e->h_status, seq);
+        k_gen_tiny<<<1, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, c.d_hits, c.n_hits, c.d_req_off, c.n_req,
+                                             e->d_limits, (u32)e->h_limits.size(), c.now, c.load ? 1 : 0, c.d_verdict, c.d_first,
+                                             c.load ? c.d_rem : nullptr, c.load ? c.d_exp : nullptr, c.d_req_delta,
+                                             e->h_status, seq);
         HIP_TRY(e, hipGetLastError());
         const volatile u32* done = &e->h_status->n_removed;
         const auto t_start = std::chrono::steady_clock::now();
@@ -564,8 +713,8 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
                 std::this_thread::yield();
             }
         }
-        // like the pipeline below, return only once the kernel has ended: the results (device or
-        // host-mapped memory) are then visible to any reader, not just to this stream
+        // return only once the kernel has ended: the results (device or host-mapped memory) are then
+        // visible to any reader, not just to this stream
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         const u32 err = e->h_status->err, dropped = e->h_status->n_ord, created = e->h_status->n_inserted;
         e->live += created;
@@ -573,87 +722,61 @@ int run_check_general(rl_engine* e, const Hit* d_hits, u32 n_hits, const u32* d_
         e->live -= dropped;
         e->tombs += dropped;
         e->stats.batches++;
-        e->stats.hits += n_hits;
-        e->stats.ordered_hits += n_hits;
+        e->stats.hits += c.n_hits;
+        e->stats.ordered_hits += c.n_hits;
         e->stats.ordered_batches++;
         return RL_OK;
     }
-    const bool mark_fresh = !load && d_req_off != nullptr;
-    const u32* hit_req = nullptr;
-    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-    if (d_req_off) {
-        k_gen_hit_req<<<cdiv(n_req, 256), 256, 0, e->stream>>>(d_req_off, n_req, e->d_hit_req);
-        hit_req = e->d_hit_req;
+    if (e->tombs > e->cap / 8) {
+        const int crc = do_compact(e, 0);
+        if (crc) return crc;
     }
-    if (n_hits == 0) {  // only empty requests: lib.rs:434-440, not limited
-        HIP_TRY(e, hipMemsetAsync(d_verdict, 0, n_req, e->stream));
-        if (d_first) HIP_TRY(e, hipMemsetAsync(d_first, 0xFF, (size_t)n_req * sizeof(int32_t), e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        return RL_OK;
-    }
-    const u32 gh = cdiv(n_hits, 256), gr = cdiv(n_req, 256);
-    if (mark_fresh)
-        k_probe<PM_CHECK, true, false><<<std::min(cdiv(n_hits, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
-            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now, 0ull,
-            e->d_hit_slot, e->d_status);
-    else
-        k_probe<PM_CHECK, false, false><<<std::min(cdiv(n_hits, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
-            e->table, e->log2cap, e->seed, d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now, 0ull,
-            e->d_hit_slot, e->d_status);
-    HIP_TRY(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    e->live += e->h_status->n_inserted;
-    if (e->h_status->err) {
-        // created cells stay (harmless (0, now+w) cells) but the scratch and fresh marks are cleared
-        k_abort<<<gh, 256, 0, e->stream>>>(e->table, n_hits, e->d_hit_slot);
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        return status_to_error(e, e->h_status->err);
-    }
-    // sort every hit by (slot, idx)
-    k_gen_keys<<<gh, 256, 0, e->stream>>>(e->d_hit_slot, n_hits, e->d_keys_a);
-    size_t tmp = e->sort_tmp_bytes;
-    HIP_TRY(e, rocprim::radix_sort_keys(e->d_sort_tmp, tmp, e->d_keys_a, e->d_keys_b, (size_t)n_hits, 0u,
-                                        32u + e->log2cap, e->stream));
-    k_ord_heads<<<gh, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_hits);
-    k_gen_fill_u8<<<gr, 256, 0, e->stream>>>(e->d_admitted, n_req, 1);
-    int32_t* first = d_first ? d_first : e->d_first;
-    u32 rounds = 0;
-    for (;;) {
-        HIP_TRY(e, hipMemsetAsync(&e->d_status->n_rounds, 0, sizeof(u32), e->stream));
-        k_gen_contrib<<<gh, 256, 0, e->stream>>>(e->d_keys_b, n_hits, d_hits, hit_req, e->d_admitted, e->d_contrib);
-        size_t stmp = e->scan_tmp_bytes;
-        HIP_TRY(e, rocprim::exclusive_scan(e->d_scan_tmp, stmp, e->d_contrib, e->d_scan, Contrib{0, 0},
-                                           (size_t)n_hits, ContribPlus(), e->stream));
-        k_gen_eval<<<gh, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_hits, e->d_scan, d_hits, hit_req,
-                                              e->d_admitted, e->d_limits, now, e->d_pass, load ? d_rem : nullptr,
-                                              load ? d_exp : nullptr);
-        k_gen_requests<<<gr, 256, 0, e->stream>>>(d_req_off, n_req, e->d_pass, e->d_admitted, d_verdict, first,
-                                                  &e->d_status->n_rounds);
-        HIP_TRY(e, hipGetLastError());
-        rc = read_status(e);
+    if (c.d_req_off) k_gen_hit_req<<<cdiv(c.n_req, 256), 256, 0, e->stream>>>(c.d_req_off, c.n_req, e->d_hit_req);
+    // ---- passes of at most sub_max hits (consecutive requests: the semantics are sequential anyway) -----
+    u32 sub_max = std::min(e->gen_sub_max, e->gen_cap);
+    u32 req_cur = 0, hit_cur = 0, attempts = 0;
+    while (req_cur < c.n_req) {
+        u32 req_end = c.n_req, hit_end = c.n_hits;
+        if (c.n_hits - hit_cur > sub_max) {
+            if (!c.d_req_off) {
+                req_end = req_cur + sub_max;
+                hit_end = hit_cur + sub_max;
+            } else {
+                // the last request boundary at or below hit_cur + sub_max
+                k_gen_cuts<<<1, 64, 0, e->stream>>>(c.d_req_off, c.n_req, hit_cur, sub_max, 1u, e->d_m_flags);
+                HIP_TRY(e, hipGetLastError());
+                HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_m_flags, 2 * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(e, hipStreamSynchronize(e->stream));
+                req_end = e->h_m_total[0];
+                hit_end = e->h_m_total[1];
+                if (req_end <= req_cur) {  // one request alone is larger than a pass
+                    req_end = req_cur + 1;
+                    HIP_TRY(e, hipMemcpy(&hit_end, c.d_req_off + req_end, sizeof(u32), hipMemcpyDeviceToHost));
+                    if (hit_end - hit_cur > e->gen_cap)
+                        return fail(e, RL_ERR_BATCH_TOO_LARGE, "one request carries %u counters (> %u)", hit_end - hit_cur, e->gen_cap);
+                }
+            }
+        }
+        bool overflow = false;
+        const int rc = run_general_pass(e, c, req_cur, req_end - req_cur, hit_cur, hit_end - hit_cur, &overflow);
         if (rc) return rc;
-        ++rounds;
-        if (!e->h_status->n_rounds) break;
-        if (rounds > n_req + 2) return fail(e, RL_ERR_DEVICE, "general resolver did not converge (bug)");
+        if (overflow) {
+            // nothing was applied.  First retry: the same pass with the heavy keys promoted (see run_general_pass);
+            // after that: the same requests in smaller passes.
+            if (++attempts > 1) {
+                const u32 had = hit_end - hit_cur;
+                if (req_end - req_cur <= 1 || had <= 1)
+                    return fail(e, RL_ERR_BATCH_TOO_LARGE, "one request puts more than %d counters into one hash bucket", GS_MAX);
+                sub_max = had / 2;
+            }
+            continue;
+        }
+        attempts = 0;
+        sub_max = std::min(e->gen_sub_max, e->gen_cap);
+        req_cur = req_end;
+        hit_cur = hit_end;
     }
-    k_gen_finish<<<gh, 256, 0, e->stream>>>(e->table, e->d_keys_b, n_hits, e->d_scan, d_hits, hit_req,
-                                            e->d_admitted, e->d_limits, now);
-    if (mark_fresh)
-        k_gen_reach<<<gr, 256, 0, e->stream>>>(e->table, d_req_off, n_req, e->d_hit_slot, first);
-    k_commit<<<std::min(gh, COMMIT_MAX_BLOCKS), 256, 0, e->stream>>>(e->table, d_hits, n_hits, e->d_limits, now, e->d_hit_slot,
-                                        mark_fresh ? 1 : 0, e->d_status);
-    HIP_TRY(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    const u32 removed = e->h_status->n_removed;
-    e->live -= removed;
-    e->tombs += removed;
-    e->stats.batches++;
-    e->stats.hits += n_hits;
-    e->stats.ordered_hits += n_hits;
-    e->stats.ordered_batches++;
-    e->stats.probe_steps += rounds;  // reused: fixpoint rounds of the general resolver
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
 }
 
@@ -735,6 +858,10 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
+    if (const char* v = getenv("RL_GEN_SUB_MAX")) {
+        const long b = strtol(v, nullptr, 10);
+        if (b >= 1024) e->gen_sub_max = (u32)std::min<long>(b, GEN_SUB_MAX);
+    }
     if (const char* v = getenv("RL_APPLY2_CFG")) e->apply2_cfg = atoi(v);
     if (const char* v = getenv("RL_DEBUG_APPLY2")) e->dbg_apply2 = (u32)strtoul(v, nullptr, 0);
     if (const char* v = getenv("RL_TINY_MAX")) {
@@ -794,15 +921,19 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_first, mb * sizeof(int32_t));
     ALLOC(e->d_remaining, mb * sizeof(u64));
     ALLOC(e->d_expires, mb * sizeof(u64));
-    ALLOC(e->d_hit_slot, mb * sizeof(u32));
-    ALLOC(e->d_ord_list, mb * sizeof(u32));
-    ALLOC(e->d_keys_a, mb * sizeof(u64));
-    ALLOC(e->d_keys_b, mb * sizeof(u64));
+    e->gen_cap = (u32)std::min<size_t>(mb, GEN_SUB_MAX);
     ALLOC(e->d_hit_req, mb * sizeof(u32));
-    ALLOC(e->d_contrib, mb * sizeof(Contrib));
-    ALLOC(e->d_scan, mb * sizeof(Contrib));
-    ALLOC(e->d_pass, mb);
-    ALLOC(e->d_admitted, mb);
+    ALLOC(e->d_req_delta, mb * sizeof(u64));
+    ALLOC(e->d_g_shits, (size_t)e->gen_cap * sizeof(SHit));
+    ALLOC(e->d_g_seginfo, (size_t)e->gen_cap * sizeof(SegInfo));
+    ALLOC(e->d_g_segtot, (size_t)e->gen_cap * sizeof(SegTot));
+    ALLOC(e->d_g_piece, ((size_t)e->gen_cap / HOT_CHUNK + HOT_MAX + 8) * sizeof(SegTot));
+    ALLOC(e->d_g_hitseg, (size_t)e->gen_cap * sizeof(u32));
+    ALLOC(e->d_g_reached, (size_t)e->gen_cap);
+    ALLOC(e->d_g_pass, 2 * (size_t)e->gen_cap);
+    ALLOC(e->d_g_admitted, mb);
+    ALLOC(e->d_gst, sizeof(GenStatus));
+    ALLOC(e->d_row1, sizeof(CellRow));
     ALLOC(e->d_status, sizeof(Status));
     ALLOC(e->d_bs, 4 * sizeof(BatchScratch));  // three rotating + k_bkt_tiny's own
     if (hipMemset(e->d_bs, 0, 4 * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
@@ -840,17 +971,6 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         ALLOC(e->d_m_scan_tmp, e->m_scan_tmp_bytes);
     }
     if (hipHostMalloc((void**)&e->h_m_total, 16) != hipSuccess) return bail(RL_ERR_NOMEM);
-    size_t tmp = 0;
-    if (rocprim::radix_sort_keys(nullptr, tmp, e->d_keys_a, e->d_keys_b, mb, 0u, 64u, e->stream) != hipSuccess)
-        return bail(RL_ERR_DEVICE);
-    e->sort_tmp_bytes = tmp ? tmp : 16;
-    ALLOC(e->d_sort_tmp, e->sort_tmp_bytes);
-    size_t stmp = 0;
-    if (rocprim::exclusive_scan(nullptr, stmp, e->d_contrib, e->d_scan, Contrib{0, 0}, mb, ContribPlus(),
-                                e->stream) != hipSuccess)
-        return bail(RL_ERR_DEVICE);
-    e->scan_tmp_bytes = stmp ? stmp : 16;
-    ALLOC(e->d_scan_tmp, e->scan_tmp_bytes);
 #undef ALLOC
     // Host-mapped blocks the device writes while the host polls them: fine-grained (coherent) memory, so a
     // device store is on its way to the host when the wave's vmcnt says so, not when the kernel ends.
@@ -882,9 +1002,9 @@ void rl_engine_destroy(rl_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->own_pstream) (void)hipStreamSynchronize(e->own_pstream);
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
-                    e->d_remaining, e->d_expires, e->d_hit_slot, e->d_ord_list, e->d_keys_a,  e->d_keys_b,
-                    e->d_sort_tmp, e->d_status,   e->d_total,    e->d_route_cnt,
-                    e->d_hit_req,  e->d_contrib,  e->d_scan,     e->d_pass,     e->d_admitted, e->d_scan_tmp,
+                    e->d_remaining, e->d_expires, e->d_status,   e->d_total,    e->d_route_cnt,
+                    e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_hitseg,
+                    e->d_g_reached, e->d_g_pass,  e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
@@ -971,7 +1091,7 @@ int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) {
     if (RL_LIMIT_ID(limit) >= e->h_limits.size()) return fail(e, RL_ERR_INVALID, "unknown limit id %u", RL_LIMIT_ID(limit));
     HIP_TRY(e, hipSetDevice(e->device));
     CellRow row{key, limit, 0, 0, 0};  // Default: (0, UNIX_EPOCH)
-    CellRow* d_row = reinterpret_cast<CellRow*>(e->d_keys_a);
+    CellRow* d_row = e->d_row1;
     HIP_TRY(e, hipMemcpyAsync(d_row, &row, sizeof(row), hipMemcpyHostToDevice, e->stream));
     return insert_rows_locked(e, d_row, 1, 0);
 }
@@ -990,9 +1110,9 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
     if (load_counters && (!d_remaining || !d_expires_in_us))
         return fail(e, RL_ERR_INVALID, "load_counters needs remaining and expires_in_us buffers");
     if (d_req_off || load_counters)
-        return run_check_general(e, reinterpret_cast<const Hit*>(d_hits), n_hits, d_req_off, n_req, now_us,
-                                 load_counters != 0, d_verdict, d_first_limited, reinterpret_cast<u64*>(d_remaining),
-                                 reinterpret_cast<u64*>(d_expires_in_us));
+        return run_check_general(e, GenCall{reinterpret_cast<const Hit*>(d_hits), n_hits, d_req_off, n_req, nullptr, now_us,
+                                            load_counters != 0, false, d_verdict, d_first_limited,
+                                            reinterpret_cast<u64*>(d_remaining), reinterpret_cast<u64*>(d_expires_in_us)});
     rc = run_check_k1(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
     // The batch is known to be applied as soon as its completion word is seen; a BLOCKING call also
     // promises that the verdicts can be read from any stream, i.e. that the kernel has ended (with the
@@ -1001,28 +1121,17 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
     return rc;
 }
 
-int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
-                                  uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t* verdict,
-                                  int32_t* first_limited, uint64_t* remaining, uint64_t* expires_in_us) {
-    int rc = validate_batch(e, hits, n_hits, req_off, n_req, verdict);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+// Host-buffer form of check_and_update for one clock value (the caller holds the engine's mutex).
+static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
+                                  uint32_t n_req, const uint64_t* req_delta, uint64_t now_us, int32_t load_counters,
+                                  uint8_t* verdict, int32_t* first_limited, uint64_t* remaining, uint64_t* expires_in_us) {
+    int rc = RL_OK;
     if (n_req == 0) return RL_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    if (load_counters && (!remaining || !expires_in_us))
-        return fail(e, RL_ERR_INVALID, "load_counters needs remaining and expires_in_us buffers");
-    if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
-    if (req_off) {
-        if (req_off[0] != 0 || req_off[n_req] != n_hits) return fail(e, RL_ERR_INVALID, "req_off must start at 0 and end at n_hits");
-        for (u32 r = 0; r < n_req; ++r)
-            if (req_off[r] > req_off[r + 1]) return fail(e, RL_ERR_INVALID, "req_off must be non-decreasing");
-    }
     {
         // A call the one-launch kernels take (k_bkt_tiny / k_gen_tiny): no copy commands at all.  The
         // request is staged in host-mapped memory the kernel reads directly, the results land there too
         // and are complete when the kernel's completion word is (both kernels are waited for by polling).
-        const bool general = req_off || load_counters;
+        const bool general = req_off || load_counters || req_delta;
         const bool one_launch = general ? (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ)
                                         : (n_hits && n_hits <= e->tiny_max);
         if (one_launch && n_hits <= TIO_HITS && n_req <= TIO_HITS) {
@@ -1034,8 +1143,11 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
             u64* t_exp = reinterpret_cast<u64*>(e->h_tiny + TIO_OFF_EXP);
             memcpy(t_hits, hits, (size_t)n_hits * sizeof(Hit));
             if (req_off) memcpy(t_off, req_off, ((size_t)n_req + 1) * sizeof(u32));
-            rc = general ? run_check_general(e, t_hits, n_hits, req_off ? t_off : nullptr, n_req, now_us, load_counters != 0,
-                                             t_verdict, t_first, t_rem, t_exp)
+            u64* t_delta = reinterpret_cast<u64*>(e->h_tiny + TIO_OFF_DELTA);
+            if (req_delta) memcpy(t_delta, req_delta, (size_t)n_req * sizeof(u64));
+            rc = general ? run_check_general(e, GenCall{t_hits, n_hits, req_off ? t_off : nullptr, n_req,
+                                                        req_delta ? t_delta : nullptr, now_us, load_counters != 0, false,
+                                                        t_verdict, t_first, t_rem, t_exp})
                          : run_check_k1(e, t_hits, n_hits, now_us, t_verdict, first_limited ? t_first : nullptr);
             if (rc) return rc;
             // The completion word has been seen; the RESULTS are read only after the kernel has ended
@@ -1052,14 +1164,17 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     }
     if (n_hits)  // (the single-counter path reads the batch on the partition stream first)
         HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice,
-                                  (req_off || load_counters) ? e->stream : e->pstream));
-    if (req_off || load_counters) {
+                                  (req_off || load_counters || req_delta) ? e->stream : e->pstream));
+    if (req_off || load_counters || req_delta) {
+        if (req_delta)
+            HIP_TRY(e, hipMemcpyAsync(e->d_req_delta, req_delta, (size_t)n_req * sizeof(u64), hipMemcpyHostToDevice, e->stream));
         if (req_off) {
             HIP_TRY(e, hipMemcpyAsync(e->d_req_off, req_off, ((size_t)n_req + 1) * sizeof(u32), hipMemcpyHostToDevice,
                                       e->stream));
         }
-        rc = run_check_general(e, e->d_hits, n_hits, req_off ? e->d_req_off : nullptr, n_req, now_us,
-                               load_counters != 0, e->d_verdict, e->d_first, e->d_remaining, e->d_expires);
+        rc = run_check_general(e, GenCall{e->d_hits, n_hits, req_off ? e->d_req_off : nullptr, n_req,
+                                          req_delta ? e->d_req_delta : nullptr, now_us, load_counters != 0, false, e->d_verdict,
+                                          e->d_first, e->d_remaining, e->d_expires});
     } else {
         rc = run_check_k1(e, e->d_hits, n_hits, now_us, e->d_verdict, first_limited ? e->d_first : nullptr);
     }
@@ -1076,6 +1191,60 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
+}
+
+int32_t rl_check_and_update_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
+                                     uint32_t n_req, const uint64_t* req_delta, const uint64_t* req_now_us, uint64_t now_us,
+                                     int32_t load_counters, uint8_t* verdict, int32_t* first_limited, uint64_t* remaining,
+                                     uint64_t* expires_in_us) {
+    int rc = validate_batch(e, hits, n_hits, req_off, n_req, verdict);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (n_req == 0) return RL_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (load_counters && (!remaining || !expires_in_us))
+        return fail(e, RL_ERR_INVALID, "load_counters needs remaining and expires_in_us buffers");
+    if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
+    if (req_off) {
+        if (req_off[0] != 0 || req_off[n_req] != n_hits) return fail(e, RL_ERR_INVALID, "req_off must start at 0 and end at n_hits");
+        for (u32 r = 0; r < n_req; ++r)
+            if (req_off[r] > req_off[r + 1]) return fail(e, RL_ERR_INVALID, "req_off must be non-decreasing");
+    }
+    if (!req_now_us)
+        return check_batch_locked(e, hits, n_hits, req_off, n_req, req_delta, now_us, load_counters, verdict, first_limited,
+                                  remaining, expires_in_us);
+    // One clock value per request (in_memory.rs:83 reads the clock once per call): the batch is applied as
+    // consecutive runs of requests that share a clock value, each run one device batch.  (A run that fails
+    // leaves the runs before it applied: the requests are sequential calls of the reference.)
+    std::vector<u32> off;
+    for (u32 r0 = 0; r0 < n_req;) {
+        u32 r1 = r0 + 1;
+        while (r1 < n_req && req_now_us[r1] == req_now_us[r0]) ++r1;
+        const u32 h0 = req_off ? req_off[r0] : r0, h1 = req_off ? req_off[r1] : r1;
+        const u32* run_off = nullptr;
+        if (req_off) {
+            off.resize(r1 - r0 + 1);
+            for (u32 r = r0; r <= r1; ++r) off[r - r0] = req_off[r] - h0;
+            run_off = off.data();
+        }
+        rc = check_batch_locked(e, hits + h0, h1 - h0, run_off, r1 - r0, req_delta ? req_delta + r0 : nullptr, req_now_us[r0],
+                                load_counters, verdict + r0, first_limited ? first_limited + r0 : nullptr,
+                                remaining ? remaining + h0 : nullptr, expires_in_us ? expires_in_us + h0 : nullptr);
+        if (rc) return rc;
+        if (first_limited)
+            for (u32 r = r0; r < r1; ++r)
+                if (first_limited[r] >= 0) first_limited[r] += (int32_t)h0;  // index in the caller's batch
+        r0 = r1;
+    }
+    return RL_OK;
+}
+
+int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
+                                  uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t* verdict,
+                                  int32_t* first_limited, uint64_t* remaining, uint64_t* expires_in_us) {
+    return rl_check_and_update_batch_ex(e, hits, n_hits, req_off, n_req, nullptr, nullptr, now_us, load_counters, verdict,
+                                        first_limited, remaining, expires_in_us);
 }
 
 int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
@@ -1095,8 +1264,8 @@ int32_t rl_check_and_update_collect(rl_engine* e) {
     return collect_k1_bucketed(e);
 }
 
-int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us,
-                                  uint8_t* within) {
+int32_t rl_is_within_limits_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint64_t* delta,
+                                     uint64_t now_us, uint8_t* within) {
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, within);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
@@ -1104,10 +1273,11 @@ int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
+    if (delta) HIP_TRY(e, hipMemcpyAsync(e->d_req_delta, delta, (size_t)n_hits * sizeof(u64), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
     k_within<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_hits, n_hits,
-                                                        e->d_limits, (u32)e->h_limits.size(), now_us,
-                                                        e->d_verdict, e->d_status);
+                                                        delta ? e->d_req_delta : nullptr, e->d_limits,
+                                                        (u32)e->h_limits.size(), now_us, e->d_verdict, e->d_status);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(within, e->d_verdict, n_hits, hipMemcpyDeviceToHost, e->stream));
     rc = read_status(e);
@@ -1116,7 +1286,12 @@ int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
     return RL_OK;
 }
 
-int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us) {
+int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us, uint8_t* within) {
+    return rl_is_within_limits_batch_ex(e, hits, n_hits, nullptr, now_us, within);
+}
+
+int32_t rl_update_counter_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint64_t* delta,
+                                   uint64_t now_us) {
     uint8_t dummy = 0;
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, &dummy);
     if (rc) return rc;
@@ -1124,36 +1299,15 @@ int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hit
     if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
-    rc = check_room_lenient(e, n_hits);
-    if (rc) return rc;
+    // the general resolver without the limit test: every hit is admitted (in_memory.rs:47-69 never checks)
     HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-    k_probe<PM_UPDATE><<<std::min(cdiv(n_hits, PROBE_TILE), PROBE_MAX_BLOCKS), PROBE_BLOCK, 0, e->stream>>>(
-        e->table, e->log2cap, e->seed, e->d_hits, n_hits, e->d_limits, (u32)e->h_limits.size(), now_us,
-        (1ull << PEND_SHIFT) / n_hits, e->d_hit_slot, e->d_status);
-    HIP_TRY(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    e->live += e->h_status->n_inserted;
-    if (e->h_status->err == ERRBIT_BIG_DELTA) {
-        k_update_serial<<<1, 64, 0, e->stream>>>(e->table, e->d_hits, n_hits, e->d_limits, now_us, e->d_hit_slot);
-        HIP_TRY(e, hipGetLastError());
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        return RL_OK;
-    }
-    if (e->h_status->err) {
-        k_abort<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, n_hits, e->d_hit_slot);
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        return status_to_error(e, e->h_status->err & ~ERRBIT_BIG_DELTA);
-    }
-    if (e->any_zero_window)
-        k_update_aux<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, e->d_hits, n_hits, e->d_limits,
-                                                               e->d_hit_slot);
-    k_update_commit<<<cdiv(n_hits, 256), 256, 0, e->stream>>>(e->table, n_hits, e->d_limits, now_us,
-                                                              e->d_hit_slot);
-    HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    return RL_OK;
+    if (delta) HIP_TRY(e, hipMemcpyAsync(e->d_req_delta, delta, (size_t)n_hits * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+    return run_check_general(e, GenCall{e->d_hits, n_hits, nullptr, n_hits, delta ? e->d_req_delta : nullptr, now_us, false, true,
+                                        e->d_verdict, nullptr, nullptr, nullptr});
+}
+
+int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us) {
+    return rl_update_counter_batch_ex(e, hits, n_hits, nullptr, now_us);
 }
 
 int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_row* out, uint64_t cap,
@@ -1322,8 +1476,8 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
             return fail(e, RL_ERR_INVALID, "a value id does not fit %u bits: such dictionaries keep the host path", MATCH_VAL_BITS);
         if (e->h_status->err) return status_to_error(e, e->h_status->err);
     }
-    rc = run_check_general(e, e->d_hits, n_hits, e->d_req_off, n_req, now, load, d_verdict, e->d_first, e->d_remaining,
-                           e->d_expires);
+    rc = run_check_general(e, GenCall{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load, false, d_verdict, e->d_first,
+                                      e->d_remaining, e->d_expires});
     if (rc) return rc;
     if (d_limited) {
         k_match_limited_limit<<<g, 256, 0, e->stream>>>(e->d_first, e->d_hits, n_req, d_limited);

@@ -1,36 +1,40 @@
-// rl_general.hpp — the general, exact form of check_and_update for a batch: multi-counter
-// requests (all-or-nothing across the counters of a request, in_memory.rs:141-153) and/or
-// load_counters (remaining / expires_in of every counter, in_memory.rs:87-95,114-116).
+// rl_general.hpp — the general, exact form of check_and_update for a batch: multi-counter requests
+// (all-or-nothing across the counters of a request, in_memory.rs:141-153), load_counters (remaining /
+// expires_in of every counter, in_memory.rs:87-95,114-116), u64 per-request deltas (in_memory.rs:75), and
+// update_counter (in_memory.rs:47-69: the same walk without the limit test).
 //
-// Sequential definition: request i is decided against the table state left by requests < i.
-// With A the set of admitted requests, hit h of request i on cell c reads
+// Sequential definition: request i is decided against the table state left by requests < i.  With A the
+// set of admitted requests, hit h of request i on cell c reads
 //     v_h = value_at(c, now) + SUM{ delta_j : j < i, j in A, j touches c }        (wrapping u64)
-// and passes iff v_h + delta_i <= max_h; request i is admitted iff all its hits pass.  A is the
-// unique fixpoint of that map (induction on i), and iterating from "everything admitted" fixes at
-// least one more request of the trace prefix per round, so the loop below terminates with exactly
-// the sequential answer (SURVEY.md §7 hard part 1).
+// and passes iff v_h + delta_i <= max_h; request i is admitted iff all its hits pass.  A is the unique
+// fixpoint of that map (induction on i), and iterating from "everything admitted" fixes at least one
+// more request of the trace prefix per round, so the rounds below end with exactly the sequential
+// answer (SURVEY.md §7 hard part 1).
 //
-// Data flow per round, over the hits sorted by (cell slot, hit index):
-//   k_gen_contrib   c[j] = admitted[req(j)] ? (delta, 1) : (0, 0)
-//   exclusive scan  G = scan(c)            (one global scan; a cell's prefix is G[j] - G[seg start],
-//                                           exact in modular arithmetic)
-//   k_gen_eval      per hit: v_h, pass, remaining, expires_in
-//   k_gen_requests  per request: AND of its hits' pass flags, first failing hit, changed flag
-// then k_gen_finish publishes each touched cell's final value for k_commit.
+// Bucketed form (second generation; the first sorted all hits with a device radix sort, re-read every
+// cell from the table in every round and went back to the host after each one):
+//
+//   k_bkt_hist / scan / scatter   (rl_bucket.hpp) the batch's hits, stably partitioned by key hash; hot keys
+//                   in buckets of their own
+//   k_gen_sort      per hash bucket, in LDS: a stable counting sort by CELL — afterwards the hits of one
+//                   cell are one contiguous segment in trace order — and ONE table probe per cell: the
+//                   cell's state before the batch (SegInfo).  Nothing is created yet.
+//   k_gen_hot_sum + k_gen_round   one fixpoint round, flat over the sorted hits: "is my request
+//                   admitted" (AND of its hits' pass flags of the previous round), segmented exclusive
+//                   scan of the admitted deltas, pass flag / remaining / expires_in per hit.  Hot
+//                   segments are cut in pieces whose sums k_gen_hot_sum prepares.  A round that finds the
+//                   previous one changed nothing returns at once: the host enqueues a few rounds blind and
+//                   reads ONE status block.
+//   k_gen_final     per request: verdict, first limited counter (in_memory.rs:90-99,141-143), and which
+//                   cells the walk reached before it stopped (in_memory.rs:109-113,129-133: a request
+//                   stops at its first limited counter unless load_counters, so later cells are not created)
+//   k_gen_count     how many cells the batch creates — checked against the table BEFORE anything is applied
+//   k_gen_commit    per cell: AtomicExpiringValue::update for the admitted hits (atomic_expiring_value.rs:
+//                   36-42,87-99), creation of the reached new cells (in_memory.rs:122-127 / :51-62)
 #pragma once
-#include "rl_kernels.hpp"
+#include "rl_bucket.hpp"
 
 namespace rl {
-
-struct Contrib {
-    u64 sum;
-    u64 cnt;
-};
-struct ContribPlus {
-    __host__ __device__ Contrib operator()(const Contrib& a, const Contrib& b) const {
-        return Contrib{a.sum + b.sum, a.cnt + b.cnt};
-    }
-};
 
 // hit index -> request index
 __global__ __launch_bounds__(256) void k_gen_hit_req(const u32* __restrict__ req_off, u32 n_req,
@@ -41,153 +45,744 @@ __global__ __launch_bounds__(256) void k_gen_hit_req(const u32* __restrict__ req
     for (u32 q = b; q < e; ++q) hit_req[q] = r;
 }
 
-__global__ __launch_bounds__(256) void k_gen_keys(const u32* __restrict__ hit_slot, u32 n,
-                                                  u64* __restrict__ keys) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = ((u64)(hit_slot[i] & SLOT_MASK) << 32) | i;
+constexpr int GS_BLOCK = 256;
+constexpr int GS_WAVES = GS_BLOCK / 64;
+constexpr int GS_MAX = 1024;          // hits of one piece of k_gen_round (4 per thread)
+constexpr int GS_LONG_MAX = 65535;    // hits of one hash bucket k_gen_sort takes (per-wave counters are 16 bits)
+constexpr int GS_E_LOG2 = 11;
+constexpr int GS_E = 1 << GS_E_LOG2;  // LDS cells of the in-bucket sort (load <= 1/2)
+constexpr int GS_HOT_BLOCKS = 512;    // extra workgroups that walk the hot buckets' chunks
+constexpr int GEN_ROUNDS_MAX = 30;    // rounds the status block has a `changed` word for
+
+constexpr u32 SF_EXPIRED0 = 1u;  // the cell was expired before the batch: the first admitted hit reopens the window
+constexpr u32 SF_NEW = 2u;       // no cell yet: created at commit if a request's walk reaches it
+constexpr u32 SF_ZEROWIN = 4u;   // 0-second window: expired at every read
+constexpr u32 SF_BAD = 8u;
+
+struct SHit {  // one hit of the cell-sorted batch
+    u32 seg;    // segment = position of the cell's first hit in the sorted batch
+    u32 req;    // request (relative to the pass)
+    u32 idx;    // hit index in the caller's batch (relative to the pass)
+    u32 delta;  // wire delta (the request's u64 delta, if given, is read from req_delta)
+};
+static_assert(sizeof(SHit) == 16, "one dwordx4 per record");
+struct SegInfo {  // a cell's state before the batch
+    u64 s;      // value_at(now)
+    u64 ttl0;   // ttl(now) before the batch (window for a cell the batch creates)
+    u32 slot;   // SLOT_INVALID: no cell yet
+    u32 limit;  // limit id | SIMPLE
+    u32 flags;  // SF_*
+    u32 len;    // hits of the segment
+};
+static_assert(sizeof(SegInfo) == 32, "SegInfo");
+struct SegTot {  // what the admitted hits of the last round add to the cell
+    u64 sum;
+    u64 last;  // delta of the last admitted hit (the value a 0-second window ends with)
+    u32 cnt;
+    u32 pad;
+};
+struct GenStatus {
+    u32 err;         // ERRBIT_*
+    u32 overflow;    // a hash bucket holds more than GS_MAX hits: the host retries with smaller passes
+    u32 n_new;       // cells the batch creates (k_gen_count)
+    u32 n_inserted;  // cells k_gen_commit created
+    u32 last_round;  // last round that ran (its parity picks the pass-flag buffer)
+    u32 last_slot;   // ... and its word of changed[]
+    u32 rounds_run;
+    u32 hot_n;       // keys that qualified for the next hot set (the host adapts the threshold)
+    u32 committed;   // k_gen_commit applied the pass (converged, no error, the new cells fit)
+    u32 pad2[3];
+    u32 changed[GEN_ROUNDS_MAX + 2];  // [slot]: that round changed a pass flag
+};
+
+struct GenArgs {
+    Cell* table;
+    u32 log2cap;
+    u64 seed;
+    const LimitDev* limits;
+    u64 now;
+    const Hit* hits;         // the pass's hits (caller's batch + hit0)
+    const u32* hit_req;      // absolute request of every hit of the caller's batch (null: hit i is request i)
+    const u32* req_off;      // absolute CSR offsets (null: every hit its own request)
+    const u64* req_delta;    // per-request u64 deltas of the caller's batch (null: the wire field)
+    u32 hit0, req0;          // the pass starts at this hit / request of the caller's batch
+    u32 n_hits, n_req;       // size of the pass
+    const BHit* b_hits;
+    const uint2* ranges;
+    u32 nb;
+    const HotParam* hot_param;
+    const unsigned short* chunk_tab;
+    HotSet* hot_next;
+    u32 hot_threshold;
+    SHit* s_hits;
+    SegInfo* seg_info;
+    SegTot* seg_tot;
+    SegTot* piece_sum;       // per hot chunk
+    u32* hit_seg;
+    uint8_t* reached;        // per segment
+    uint8_t* pass[2];
+    uint8_t* admitted;       // per request, by the previous round (k_gen_admit)
+    uint8_t* verdict;        // outputs, already offset to the pass
+    int32_t* first_limited;
+    u64* remaining;
+    u64* expires_in;
+    GenStatus* gst;
+    const Status* pst;       // the partition's status: a refused batch leaves the sorted arrays unwritten
+    u32 load, update_mode, mark_reached;
+};
+
+__device__ __forceinline__ LimitDev gen_limit_row(const GenArgs& A, u32 limit) {
+    const uint4 v = *reinterpret_cast<const uint4*>(&A.limits[limit & ~SIMPLE_FLAG]);
+    LimitDev L;
+    L.max_value = ((u64)v.y << 32) | v.x;
+    L.window_us = ((u64)v.w << 32) | v.z;
+    return L;
 }
 
-__global__ __launch_bounds__(256) void k_gen_fill_u8(uint8_t* __restrict__ p, u32 n, uint8_t v) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = v;
+// The state of `key`'s cell before the batch (one probe chain, nothing is created).
+__device__ __forceinline__ SegInfo gen_resolve(const GenArgs& A, u64 key, u32 hit_limit, u32 len) {
+    SegInfo si{};
+    si.len = len;
+    const u32 mask = (1u << A.log2cap) - 1u;
+    u32 slot = slot_of(key, A.seed, A.log2cap);
+    si.slot = SLOT_INVALID;
+    for (u32 step = 0; step <= mask; ++step) {
+        const Cell* c = &A.table[slot];
+        const uint4 a = *reinterpret_cast<const uint4*>(c);
+        const u64 tag = ((u64)a.y << 32) | a.x;
+        if (tag == key) {
+            const uint4 b = reinterpret_cast<const uint4*>(c)[1];
+            const u64 expiry = ((u64)b.y << 32) | b.x;
+            si.slot = slot;
+            si.limit = b.z;
+            if (expiry <= A.now) si.flags |= SF_EXPIRED0;
+            else {
+                si.s = ((u64)a.w << 32) | a.z;  // value_at(now), atomic_expiring_value.rs:19-24
+                si.ttl0 = expiry - A.now;       // ttl, atomic_expiring_value.rs:68-74
+            }
+            break;
+        }
+        if (tag == TAG_EMPTY) break;
+        slot = (slot + 1) & mask;
+    }
+    if (si.slot == SLOT_INVALID) {
+        si.limit = hit_limit;
+        si.flags |= SF_NEW;
+        if ((hit_limit & SIMPLE_FLAG) && !A.update_mode) {  // in_memory.rs:106-107 (k_bkt_hist checked already)
+            atomicOr(&A.gst->err, ERRBIT_MISSING_SIMPLE);
+            si.flags |= SF_BAD;
+        }
+    } else if (si.limit != hit_limit) {
+        atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
+        si.flags |= SF_BAD;
+    }
+    const LimitDev L = gen_limit_row(A, si.limit);
+    if (L.window_us == 0) {
+        si.flags |= SF_ZEROWIN;  // every read sees an expired cell: value 0, ttl 0
+        si.s = 0;
+        si.ttl0 = 0;
+    } else if (si.flags & SF_NEW) {
+        si.ttl0 = L.window_us;  // AtomicExpiringValue::new(0, now + window), in_memory.rs:123-125
+    }
+    return si;
 }
 
-__global__ __launch_bounds__(256) void k_gen_contrib(const u64* __restrict__ keys, u32 n,
-                                                     const Hit* __restrict__ hits,
-                                                     const u32* __restrict__ hit_req,
-                                                     const uint8_t* __restrict__ admitted,
-                                                     Contrib* __restrict__ c) {
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const u32 idx = (u32)keys[j];
-    const u32 r = hit_req ? hit_req[idx] : idx;
-    const bool a = admitted[r] != 0;
-    c[j] = Contrib{a ? (u64)hits[idx].delta : 0ull, a ? 1ull : 0ull};
-}
-
-// Value a hit reads, pass flag, and the load_counters outputs.
-__global__ __launch_bounds__(256) void k_gen_eval(
-    const Cell* __restrict__ table, const u64* __restrict__ keys, u32 n, const Contrib* __restrict__ G,
-    const Hit* __restrict__ hits, const u32* __restrict__ hit_req, const uint8_t* __restrict__ admitted,
-    const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ pass_hit,
-    u64* __restrict__ remaining, u64* __restrict__ expires_in) {
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const u64 k = keys[j];
-    const u32 idx = (u32)k;
-    const Cell* c = &table[(u32)(k >> 32)];
-    const u32 seg = c->seg;
-    const u32 r = hit_req ? hit_req[idx] : idx;
-    const Contrib g = G[j], g0 = G[seg];
-    u64 pre_sum = g.sum - g0.sum;
-    u64 pre_cnt = g.cnt - g0.cnt;
-    // exclusive BY REQUEST: hits of the same request on the same cell all read the value before
-    // any of them is applied (in_memory.rs:105-139 reads, :146-153 updates afterwards)
-    if (admitted[r]) {
-        for (u32 q = j; q > seg;) {
-            --q;
-            const u32 iq = (u32)keys[q];
-            if ((hit_req ? hit_req[iq] : iq) != r) break;
-            pre_sum -= (u64)hits[iq].delta;
-            pre_cnt -= 1;
+// ---------------------------------------------------------------------------------------------
+// k_gen_sort
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
+    __shared__ u64 ekey[GS_E];
+    __shared__ u32 eoff[GS_E];                       // hits of the cell, then its start offset in the bucket
+    __shared__ unsigned short wcnt[GS_WAVES][GS_E];  // hits of the cell per wave, then the waves' exclusive offsets
+    __shared__ unsigned short wcur[GS_WAVES][GS_E];  // pass 2: hits of the cell this wave has placed
+    __shared__ u32 etot[GS_E];
+    __shared__ uint8_t efold[GS_E];
+    __shared__ u32 s_w[GS_WAVES];
+    __shared__ u32 s_full;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    if (A.pst->err) return;  // k_bkt_hist refused the batch
+    if (blockIdx.x >= A.nb) {
+        // ---- hot buckets: one key each, already in trace order: rewrite the records, chunk by chunk ---
+        const u32 n_chunks = A.hot_param[HOT_MAX].chunk0;
+        for (u32 c = blockIdx.x - A.nb; c < n_chunks; c += gridDim.x - A.nb) {
+            const u32 hb = A.chunk_tab[c];
+            const HotParam hp = A.hot_param[hb];
+            const u32 first = hp.lo + (c - hp.chunk0) * HOT_CHUNK;
+#pragma unroll
+            for (int u = 0; u < HOT_CHUNK / GS_BLOCK; ++u) {
+                const u32 j = first + u * GS_BLOCK + tid;
+                if (j >= hp.hi) continue;
+                const BHit h = load_bhit(A.b_hits, j);
+                const u32 idx = h.idx_tag & 0xFFFFFFu;
+                const u32 req = A.hit_req ? A.hit_req[A.hit0 + idx] - A.req0 : idx;
+                *reinterpret_cast<uint4*>(A.s_hits + j) = make_uint4(hp.lo, req, idx, h.delta);
+                if (A.hit_seg) A.hit_seg[idx] = hp.lo;
+                if ((h.idx_tag >> 24) != limit_fold(hp.limit)) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
+            }
+            if (first == hp.lo && tid == 0)
+                A.seg_info[hp.lo] = gen_resolve(A, A.b_hits[hp.lo].key, hp.limit, hp.hi - hp.lo);
+        }
+        return;
+    }
+    const uint2 r = A.ranges[blockIdx.x];
+    const u32 lo = r.x, L = r.y - r.x;
+    if (L == 0) return;
+    for (u32 e = tid; e < (u32)GS_E; e += GS_BLOCK) {
+        ekey[e] = TAG_EMPTY;
+        eoff[e] = 0;
+#pragma unroll
+        for (int ww = 0; ww < GS_WAVES; ++ww) {
+            wcnt[ww][e] = 0;
+            wcur[ww][e] = 0;
         }
     }
-    const LimitDev L = limits[c->limit & ~SIMPLE_FLAG];
-    const u64 expiry = c->expiry;
-    const bool expired0 = expiry <= now;
-    const u64 s = expired0 ? 0ull : c->value;
-    const u64 v = (L.window_us == 0) ? 0ull : s + pre_sum;
-    const u64 sum = v + (u64)hits[idx].delta;  // wraps like the reference
-    const bool pass = sum <= L.max_value;
-    pass_hit[idx] = pass ? 1 : 0;
-    if (remaining) remaining[idx] = pass ? L.max_value - sum : 0ull;  // checked_sub().unwrap_or_default()
-    if (expires_in) {
-        u64 ttl;
-        if (L.window_us == 0) ttl = 0;
-        else if (!expired0) ttl = expiry - now;
-        else ttl = pre_cnt > 0 ? L.window_us : 0ull;  // an earlier admitted hit reopened the window
-        expires_in[idx] = ttl;
+    if (tid == 0) s_full = 0;
+    __syncthreads();
+    // wave w owns the contiguous (trace-ordered) positions [w * Lw, (w + 1) * Lw) of the bucket and walks them
+    // in 64-hit steps, twice: count, then place (the bucket is re-read; any length up to GS_LONG_MAX)
+    const u32 steps = (L + GS_BLOCK - 1) / GS_BLOCK;
+    const u32 Lw = steps * 64;
+    const u32 w_lo = w * Lw, w_hi = (w + 1) * Lw < L ? (w + 1) * Lw : L;
+    bool too_long = L > (u32)GS_LONG_MAX;
+    // ---- pass 1: the bucket's cells (LDS hash), hits per (wave, cell) ---------------------------------
+    if (!too_long)
+        for (u32 u = 0; u < steps; ++u) {
+            const u32 p = w_lo + u * 64 + lane;
+            const bool ok = p < w_hi;
+            u32 ent = 0;
+            bool lost = false;
+            if (ok) {
+                const BHit h = load_bhit(A.b_hits, lo + p);
+                u32 e = (u32)(fmix64(h.key ^ A.seed) >> 20) & (GS_E - 1);
+                u32 step = 0;
+                for (;; ++step) {
+                    if (step >= (u32)GS_E) {  // more distinct cells than the LDS hash holds
+                        lost = true;
+                        break;
+                    }
+                    u64 prev = ekey[e];
+                    if (prev == TAG_EMPTY) {
+                        prev = atomicCAS(&ekey[e], TAG_EMPTY, h.key);
+                        if (prev == TAG_EMPTY) efold[e] = (uint8_t)(h.idx_tag >> 24);  // the limit id every hit of the key must carry
+                    }
+                    if (prev == TAG_EMPTY || prev == h.key) break;
+                    e = (e + 1) & (GS_E - 1);
+                }
+                ent = e;
+            }
+            if (lost) s_full = 1;
+            const u64 m = match_digit(ent, GS_E_LOG2, __ballot(ok && !lost));
+            if (ok && !lost && (m & lt) == 0ull) wcnt[w][ent] = (unsigned short)(wcnt[w][ent] + (u32)__popcll(m));
+        }
+    __syncthreads();
+    if (too_long || s_full) {
+        // Too long (or too many cells) for the in-LDS sort: a traffic shift, the first batch.  Promote the
+        // heavy keys seen so far: the host retries the pass with THIS set, which gives them buckets of their own.
+        for (u32 e = tid; e < (u32)GS_E; e += GS_BLOCK) {
+            u32 acc = 0;
+#pragma unroll
+            for (int ww = 0; ww < GS_WAVES; ++ww) acc += wcnt[ww][e];
+            if (acc >= A.hot_threshold && A.hot_next && ekey[e] != TAG_EMPTY) {
+                const u32 pos = atomicAdd(&A.hot_next->n, 1u);
+                if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = ekey[e];
+            }
+        }
+        if (tid == 0) atomicOr(&A.gst->overflow, 1u);
+        return;
+    }
+    // per cell: the waves' exclusive offsets, the total; hot-set promotion like k_bkt_apply's commit
+    for (u32 e = tid; e < (u32)GS_E; e += GS_BLOCK) {
+        u32 acc = 0;
+#pragma unroll
+        for (int ww = 0; ww < GS_WAVES; ++ww) {
+            const u32 c = wcnt[ww][e];
+            wcnt[ww][e] = (unsigned short)acc;  // (acc < L <= GS_LONG_MAX)
+            acc += c;
+        }
+        eoff[e] = acc;
+        etot[e] = acc;
+        if (acc >= A.hot_threshold && A.hot_next) {
+            const u32 pos = atomicAdd(&A.hot_next->n, 1u);
+            if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = ekey[e];
+        }
+    }
+    __syncthreads();
+    {  // exclusive scan of eoff over the GS_E cells (8 per thread)
+        constexpr int PER = GS_E / GS_BLOCK;
+        u32 v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            v[q] = eoff[tid * PER + q];
+            sum += v[q];
+        }
+        u32 inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 o = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += o;
+        }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        u32 base = inc - sum;
+        for (u32 ww = 0; ww < w; ++ww) base += s_w[ww];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            eoff[tid * PER + q] = base;
+            base += v[q];
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: placement (the same walk: stable rank inside (wave, cell)); the cell's first hit resolves it
+    for (u32 u = 0; u < steps; ++u) {
+        const u32 p = w_lo + u * 64 + lane;
+        const bool ok = p < w_hi;
+        u32 ent = 0;
+        BHit h{};
+        if (ok) {
+            h = load_bhit(A.b_hits, lo + p);
+            u32 e = (u32)(fmix64(h.key ^ A.seed) >> 20) & (GS_E - 1);
+            while (ekey[e] != h.key) e = (e + 1) & (GS_E - 1);
+            ent = e;
+        }
+        const u64 m = match_digit(ent, GS_E_LOG2, __ballot(ok));
+        if (!ok) continue;
+        const u32 c = wcur[w][ent];
+        const u32 in_seg = (u32)wcnt[w][ent] + c + (u32)__popcll(m & lt);
+        if ((m & lt) == 0ull) wcur[w][ent] = (unsigned short)(c + (u32)__popcll(m));
+        const u32 seg = lo + eoff[ent];
+        const u32 idx = h.idx_tag & 0xFFFFFFu;
+        const u32 req = A.hit_req ? A.hit_req[A.hit0 + idx] - A.req0 : idx;
+        *reinterpret_cast<uint4*>(A.s_hits + seg + in_seg) = make_uint4(seg, req, idx, h.delta);
+        if (A.hit_seg) A.hit_seg[idx] = seg;
+        if ((h.idx_tag >> 24) != (u32)efold[ent]) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
+        if (in_seg == 0) A.seg_info[seg] = gen_resolve(A, h.key, A.hits[idx].limit, etot[ent]);
     }
 }
 
-__global__ __launch_bounds__(256) void k_gen_requests(const u32* __restrict__ req_off, u32 n_req,
-                                                      const uint8_t* __restrict__ pass_hit,
-                                                      uint8_t* __restrict__ admitted,
-                                                      uint8_t* __restrict__ verdict,
-                                                      int32_t* __restrict__ first_limited,
-                                                      u32* __restrict__ changed) {
+// Is the request admitted by the previous round?  (round 0: everything is.)
+__device__ __forceinline__ bool gen_admitted(const GenArgs& A, const uint8_t* __restrict__ pass_prev, u32 req) {
+    return !pass_prev || A.admitted[req] != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_admit: per request, the AND of its hits' pass flags of the previous round (coalesced: a request's
+// flags are contiguous) — what k_gen_hot_sum / k_gen_round of this round read once per hit
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gen_admit(GenArgs A, u32 round, u32 check_slot) {
+    if (A.pst->err || A.gst->overflow) return;
+    if (check_slot && !A.gst->changed[check_slot]) return;
     const u32 r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_req) return;
-    const u32 b = req_off ? req_off[r] : r;
-    const u32 e = req_off ? req_off[r + 1] : r + 1;
+    if (r >= A.n_req || round == 0) return;
+    const uint8_t* pass_prev = A.pass[(round - 1) & 1u];
+    const u32 b = A.req_off ? A.req_off[A.req0 + r] - A.hit0 : r;
+    const u32 e = A.req_off ? A.req_off[A.req0 + r + 1] - A.hit0 : r + 1;
+    uint8_t adm = 1;
+    for (u32 q = b; q < e; ++q)
+        if (!pass_prev[q]) {
+            adm = 0;
+            break;
+        }
+    A.admitted[r] = adm;
+}
+
+__device__ __forceinline__ u64 gen_delta(const GenArgs& A, const SHit& h) {
+    return A.req_delta ? A.req_delta[A.req0 + h.req] : (u64)h.delta;
+}
+
+// Scan state of a run of hits that belong to ONE segment: what its admitted hits add.
+struct Run {
+    u64 sum;
+    u64 last;
+    u32 cnt;
+};
+__device__ __forceinline__ Run run_join(const Run& a, const Run& b) {  // a then b
+    return Run{a.sum + b.sum, b.cnt ? b.last : a.last, a.cnt + b.cnt};
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_hot_sum: what the admitted hits of every chunk of a hot segment add (the carries of k_gen_round)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_BLOCK) void k_gen_hot_sum(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
+    __shared__ Run s_run[GS_WAVES];
+    (void)write_slot;
+    if (A.pst->err || A.gst->overflow) return;
+    if (check_slot && !A.gst->changed[check_slot]) return;  // converged: the round before changed nothing
+    const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 n_chunks = A.hot_param[HOT_MAX].chunk0;
+    for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const u32 hb = A.chunk_tab[c];
+        const HotParam hp = A.hot_param[hb];
+        const u32 first = hp.lo + (c - hp.chunk0) * HOT_CHUNK;
+        Run acc{0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < HOT_CHUNK / GS_BLOCK; ++u) {
+            const u32 j = first + tid * (HOT_CHUNK / GS_BLOCK) + u;  // consecutive hits per thread: `last` is in order
+            if (j >= hp.hi) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + j);
+            const SHit h{v.x, v.y, v.z, v.w};
+            if (gen_admitted(A, pass_prev, h.req)) {
+                const u64 d = gen_delta(A, h);
+                acc = run_join(acc, Run{d, d, 1u});
+            }
+        }
+        // in-order reduction over the lanes, then the waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            Run o;
+            o.sum = __shfl_up(acc.sum, off);
+            o.last = __shfl_up(acc.last, off);
+            o.cnt = __shfl_up(acc.cnt, off);
+            if ((int)lane >= off) acc = run_join(o, acc);
+        }
+        __syncthreads();
+        if (lane == 63) s_run[w] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            Run t = s_run[0];
+            for (int ww = 1; ww < GS_WAVES; ++ww) t = run_join(t, s_run[ww]);
+            A.piece_sum[c] = SegTot{t.sum, t.last, t.cnt, 0u};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_round
+// ---------------------------------------------------------------------------------------------
+// One piece of the sorted batch: a whole hash bucket (<= GS_MAX hits, any number of segments) or one chunk
+// of a hot segment (`carry` = what the earlier chunks' admitted hits add; carry_seg = that segment).
+// Every thread owns 4 consecutive hits; runs of equal segment are scanned inside the thread, then across
+// the threads with a segmented scan (wave shuffles + a fold over the 4 wave aggregates).
+struct GenRoundLds {
+    Run wrun[GS_WAVES];   // the run that is open at the end of each wave
+    u32 wflag[GS_WAVES];  // a run starts inside the wave (the aggregate does not pass through)
+    u32 wlast[GS_WAVES];  // segment of the wave's last hit
+    u32 changed;
+    Run carry;            // hot chunks: the piece carry, broadcast
+    Run out_run;          // the run that is open at the end of the piece ...
+    u32 out_seg;          // ... and its segment (the carry of a long bucket's next piece)
+};
+
+__device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t* __restrict__ pass_prev,
+                                                uint8_t* __restrict__ pass_cur, u32 lo, u32 n, Run carry, u32 carry_seg,
+                                                GenRoundLds& S) {
+    constexpr int PER = GS_MAX / GS_BLOCK;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    SHit h[PER];
+    bool ok[PER], adm[PER];
+    u64 d[PER];
+    Run pre[PER];  // what the admitted hits before this one, in its segment and inside this thread, add
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const u32 p = tid * PER + i;
+        ok[i] = p < n;
+        adm[i] = false;
+        d[i] = 0;
+        h[i] = SHit{0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
+        if (ok[i]) {
+            const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + lo + p);
+            h[i] = SHit{v.x, v.y, v.z, v.w};
+            adm[i] = gen_admitted(A, pass_prev, h[i].req);
+            d[i] = gen_delta(A, h[i]);
+        }
+    }
+    // ---- inside the thread -------------------------------------------------------------------------
+    Run run{0, 0, 0};
+    u32 last_seg = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (!ok[i]) continue;
+        if (i > 0 && h[i].seg != h[i - 1].seg) run = Run{0, 0, 0};
+        pre[i] = run;
+        if (adm[i]) run = run_join(run, Run{d[i], d[i], 1u});
+        last_seg = h[i].seg;
+    }
+    const u32 first_seg = h[0].seg;  // (0xFFFFFFFF for a thread without hits)
+    // ---- across the threads: X(t) = the run open at the end of thread t.  Thread t passes the run of
+    //      thread t-1 through iff all its hits belong to the segment thread t-1 ended with. -------------
+    u32 prev_last = __shfl_up(last_seg, 1);
+    __syncthreads();  // (S is reused by consecutive pieces)
+    if (lane == 63) S.wlast[w] = last_seg;
+    __syncthreads();
+    if (lane == 0) prev_last = w ? S.wlast[w - 1] : carry_seg;
+    const bool link = ok[0] && first_seg == prev_last;  // my first hit continues what came before me
+    const bool through = !ok[0] || (link && first_seg == last_seg);
+    Run X = ok[0] ? run : Run{0, 0, 0};
+    u32 F = through ? 0u : 1u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Run o;
+        o.sum = __shfl_up(X.sum, off);
+        o.last = __shfl_up(X.last, off);
+        o.cnt = __shfl_up(X.cnt, off);
+        const u32 of = __shfl_up(F, off);
+        if ((int)lane >= off && !F) {
+            X = run_join(o, X);
+            F = of;
+        }
+    }
+    if (lane == 63) {
+        S.wrun[w] = X;
+        S.wflag[w] = F;
+    }
+    __syncthreads();
+    Run C = carry;  // the run open at the end of the previous wave (wave 0: the piece carry)
+    for (u32 ww = 0; ww < w; ++ww) C = S.wflag[ww] ? S.wrun[ww] : run_join(C, S.wrun[ww]);
+    if (!F) X = run_join(C, X);
+    Run cin;
+    cin.sum = __shfl_up(X.sum, 1);
+    cin.last = __shfl_up(X.last, 1);
+    cin.cnt = __shfl_up(X.cnt, 1);
+    if (lane == 0) cin = C;
+    if (!link) cin = Run{0, 0, 0};
+    if (n - 1 >= tid * PER && n - 1 < (tid + 1) * PER) {  // the thread that holds the piece's last hit
+        S.out_run = X;
+        S.out_seg = last_seg;
+    }
+    // ---- per hit -------------------------------------------------------------------------------------
+    u32 changed = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (!ok[i]) continue;
+        const u32 pos = lo + tid * PER + i;
+        Run pr = h[i].seg == first_seg ? run_join(cin, pre[i]) : pre[i];
+        // exclusive BY REQUEST: hits of the same request on the same cell all read the value before any of
+        // them is applied (in_memory.rs:105-139 reads, :146-153 updates afterwards)
+        u64 dup_sum = 0;
+        u32 dup_cnt = 0;
+        if (adm[i]) {
+            for (u32 q = pos; q > h[i].seg;) {
+                --q;
+                const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + q);
+                if (v.y != h[i].req) break;
+                dup_sum += gen_delta(A, SHit{v.x, v.y, v.z, v.w});
+                dup_cnt += 1;
+            }
+        }
+        const SegInfo si = A.seg_info[h[i].seg];
+        const LimitDev Lm = gen_limit_row(A, si.limit);
+        const bool zw = (si.flags & SF_ZEROWIN) != 0;
+        const u64 v = zw ? 0ull : si.s + (pr.sum - dup_sum);
+        const u64 sum = v + d[i];  // wraps like the reference's release build (in_memory.rs:88)
+        const bool pass = A.update_mode ? true : sum <= Lm.max_value;
+        pass_cur[h[i].idx] = pass ? 1 : 0;
+        if (pass_prev && pass_prev[h[i].idx] != (pass ? 1 : 0)) changed = 1;
+        if (A.load) {
+            A.remaining[h[i].idx] = pass ? Lm.max_value - sum : 0ull;  // checked_sub().unwrap_or_default(), :88-89
+            u64 ttl;
+            if (zw) ttl = 0;
+            else if (!(si.flags & SF_EXPIRED0)) ttl = si.ttl0;                  // alive, or created by this batch
+            else ttl = (pr.cnt - dup_cnt) > 0 ? Lm.window_us : 0ull;           // an earlier admitted hit reopened the window
+            A.expires_in[h[i].idx] = ttl;
+        }
+        // the segment's last hit publishes what the admitted hits add to the cell
+        if (pos + 1 == h[i].seg + si.len) {
+            const Run tot = adm[i] ? run_join(pr, Run{d[i], d[i], 1u}) : pr;
+            A.seg_tot[h[i].seg] = SegTot{tot.sum, tot.last, tot.cnt, 0u};
+        }
+    }
+    if (!pass_prev && !A.update_mode) changed = 1;  // (round 0 has no previous flags to compare with)
+    if (__ballot(changed != 0) && lane == 0) atomicOr(&S.changed, 1u);
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
+    __shared__ GenRoundLds S;
+    if (A.pst->err || A.gst->overflow) return;
+    if (check_slot && !A.gst->changed[check_slot]) return;  // converged: the round before changed nothing
+    const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
+    uint8_t* pass_cur = A.pass[round & 1u];
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    if (tid == 0) {
+        S.changed = 0;
+        if (blockIdx.x == 0) {
+            A.gst->last_round = round;
+            A.gst->last_slot = write_slot;
+            atomicAdd(&A.gst->rounds_run, 1u);
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x < A.nb) {
+        // a hash bucket, GS_MAX hits at a time: a segment that crosses into the next piece carries its open run
+        const uint2 r = A.ranges[blockIdx.x];
+        const u32 L = r.y - r.x;
+        Run carry{0, 0, 0};
+        u32 carry_seg = 0xFFFFFFFEu;
+        for (u32 first = 0; first < L; first += GS_MAX) {
+            gen_round_piece(A, pass_prev, pass_cur, r.x + first, L - first < (u32)GS_MAX ? L - first : (u32)GS_MAX, carry,
+                            carry_seg, S);
+            __syncthreads();
+            carry = S.out_run;
+            carry_seg = S.out_seg;
+        }
+    } else {
+        const u32 n_chunks = A.hot_param[HOT_MAX].chunk0;
+        for (u32 c = blockIdx.x - A.nb; c < n_chunks; c += gridDim.x - A.nb) {
+            const u32 hb = A.chunk_tab[c];
+            const HotParam hp = A.hot_param[hb];
+            const u32 first = hp.lo + (c - hp.chunk0) * HOT_CHUNK;
+            const u32 n = hp.hi - first < (u32)HOT_CHUNK ? hp.hi - first : (u32)HOT_CHUNK;
+            // what the admitted hits of the segment's earlier chunks add: in-order fold of their sums
+            __syncthreads();
+            if (tid < 64) {
+                const u32 n_before = c - hp.chunk0;
+                const u32 per = (n_before + 63) / 64;
+                Run acc{0, 0, 0};
+                for (u32 q = lane * per; q < (lane + 1) * per && q < n_before; ++q) {
+                    const SegTot t = A.piece_sum[hp.chunk0 + q];
+                    acc = run_join(acc, Run{t.sum, t.last, t.cnt});
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    Run o;
+                    o.sum = __shfl_up(acc.sum, off);
+                    o.last = __shfl_up(acc.last, off);
+                    o.cnt = __shfl_up(acc.cnt, off);
+                    if ((int)lane >= off) acc = run_join(o, acc);
+                }
+                if (lane == 63) S.carry = acc;
+            }
+            __syncthreads();
+            gen_round_piece(A, pass_prev, pass_cur, first, n, S.carry, hp.lo, S);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && S.changed) atomicOr(&A.gst->changed[write_slot], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_final: per request, from the last round's pass flags
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gen_final(GenArgs A) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= A.n_req || A.pst->err || A.gst->overflow) return;
+    const uint8_t* pass = A.pass[A.gst->last_round & 1u];
+    const u32 b = A.req_off ? A.req_off[A.req0 + r] - A.hit0 : r;
+    const u32 e = A.req_off ? A.req_off[A.req0 + r + 1] - A.hit0 : r + 1;
     int32_t first = -1;
     for (u32 q = b; q < e; ++q)
-        if (!pass_hit[q]) {
+        if (!pass[q]) {
             first = (int32_t)q;
             break;
         }
-    const uint8_t adm = first < 0 ? 1 : 0;
-    if (admitted[r] != adm) {
-        admitted[r] = adm;
-        *changed = 1u;
-    }
-    verdict[r] = adm ? 0 : 1;
-    if (first_limited) first_limited[r] = first;
-}
-
-// After convergence: final value of every touched cell (for k_commit) — written by the last
-// element of each segment; 0-second windows record their last admitted delta.
-__global__ __launch_bounds__(256) void k_gen_finish(Cell* __restrict__ table,
-                                                    const u64* __restrict__ keys, u32 n,
-                                                    const Contrib* __restrict__ G,
-                                                    const Hit* __restrict__ hits,
-                                                    const u32* __restrict__ hit_req,
-                                                    const uint8_t* __restrict__ admitted,
-                                                    const LimitDev* __restrict__ limits, u64 now) {
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const u64 k = keys[j];
-    const u32 slot = (u32)(k >> 32);
-    const u32 idx = (u32)k;
-    Cell* c = &table[slot];
-    const u32 r = hit_req ? hit_req[idx] : idx;
-    const bool a = admitted[r] != 0;
-    const u64 d = hits[idx].delta;
-    const LimitDev L = limits[c->limit & ~SIMPLE_FLAG];
-    if (L.window_us == 0) {
-        if (a) atomicMax(&c->aux, ((u64)(j + 1) << 32) | d);
-        return;
-    }
-    const bool last = (j + 1 == n) || ((u32)(keys[j + 1] >> 32) != slot);
-    if (last) {
-        const Contrib g = G[j], g0 = G[c->seg];
-        const u64 tot_sum = g.sum - g0.sum + (a ? d : 0ull);
-        const u64 tot_cnt = g.cnt - g0.cnt + (a ? 1ull : 0ull);
-        const u64 s = (c->expiry <= now) ? 0ull : c->value;
-        c->aux = s + tot_sum;
-        c->amb = tot_cnt ? AMB_ADMIT : AMB_DENY;
+    A.verdict[r] = first < 0 ? 0 : 1;
+    if (A.first_limited) A.first_limited[r] = first < 0 ? -1 : (int32_t)(A.hit0 + (u32)first);  // index in the caller's batch
+    if (A.mark_reached) {
+        // !load_counters: the walk stops at its first limited counter (in_memory.rs:109-113,129-133)
+        const u32 stop = first < 0 ? e : (u32)first + 1;
+        for (u32 q = b; q < stop; ++q) A.reached[A.hit_seg[q]] = 1;
     }
 }
 
-// !load_counters only: a request stops at its first limited counter (in_memory.rs:109-113,
-// 129-133), so the qualified cells of its later counters are never created.  Cells created by
-// k_probe carry pad = 1; every hit that the sequential walk reaches confirms its cell (pad = 2);
-// k_commit drops the unconfirmed ones.
-__global__ __launch_bounds__(256) void k_gen_reach(Cell* __restrict__ table,
-                                                   const u32* __restrict__ req_off, u32 n_req,
-                                                   const u32* __restrict__ hit_slot,
-                                                   const int32_t* __restrict__ first_limited) {
-    const u32 r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_req) return;
-    const u32 b = req_off[r];
-    u32 e = req_off[r + 1];
-    const int32_t f = first_limited[r];
-    if (f >= 0) e = (u32)f + 1;
-    for (u32 q = b; q < e; ++q) {
-        Cell* c = &table[hit_slot[q] & SLOT_MASK];
-        if (c->pad == 1u) c->pad = 2u;
+// Is position j the first hit of a segment?  (the sorted batch covers [0, n_hits) without gaps)
+__device__ __forceinline__ bool gen_is_head(const GenArgs& A, u32 j) { return A.s_hits[j].seg == j; }
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_count: cells the batch creates (new cells some request's walk reached)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gen_count(GenArgs A) {
+    __shared__ u32 s_n;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.hot_next) A.gst->hot_n = A.hot_next->n;
+    if (A.pst->err || A.gst->overflow) return;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    u32 mine = 0;
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < A.n_hits; j += gridDim.x * 256) {
+        if (!gen_is_head(A, j)) continue;
+        const SegInfo si = A.seg_info[j];
+        if ((si.flags & SF_NEW) && !(si.flags & SF_BAD) && (!A.mark_reached || A.reached[j])) ++mine;
     }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(&A.gst->n_new, s_n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_commit: per cell
+// ---------------------------------------------------------------------------------------------
+// Applies the pass only if it is final and fits — decided HERE, on the device, from the status block, so that the
+// host does not have to look at it between k_gen_count and this kernel: the fixpoint has converged (the last
+// round changed nothing), no error, no overflow, and the table keeps 1/16 of its slots empty with the n_new cells
+// the pass creates (`room` = cells that may still be created).  Otherwise nothing is written.
+__global__ __launch_bounds__(256) void k_gen_commit(GenArgs A, u32 room) {
+    __shared__ u32 s_n;
+    {
+        const GenStatus* g = A.gst;
+        if (A.pst->err || g->err || g->overflow || g->n_new > room) return;
+        if (!A.update_mode && g->changed[g->last_slot]) return;  // not converged yet
+    }
+    if (threadIdx.x == 0) {
+        s_n = 0;
+        if (blockIdx.x == 0) A.gst->committed = 1;
+    }
+    __syncthreads();
+    u32 created = 0;
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < A.n_hits; j += gridDim.x * 256) {
+        if (!gen_is_head(A, j)) continue;
+        const SegInfo si = A.seg_info[j];
+        if (si.flags & SF_BAD) continue;
+        if (A.mark_reached && !A.reached[j]) continue;  // no request's walk got here: the cell is not even created
+        const SegTot t = A.seg_tot[j];
+        const LimitDev Lm = gen_limit_row(A, si.limit);
+        u32 slot = si.slot;
+        if (si.flags & SF_NEW) {
+            // first touch creates the cell, admitted or not: AtomicExpiringValue::new(0, now + window)
+            // (in_memory.rs:122-127; update_counter: :51-62)
+            const u64 k = A.hits[A.s_hits[j].idx].key;
+            const u32 mask = (1u << A.log2cap) - 1u;
+            slot = slot_of(k, A.seed, A.log2cap);
+            bool done = false;
+            for (u32 step = 0; step <= mask; ++step) {
+                const u64 old = atomicCAS(&A.table[slot].tag, TAG_EMPTY, k);
+                if (old == TAG_EMPTY) {
+                    done = true;
+                    break;
+                }
+                slot = (slot + 1) & mask;
+            }
+            if (!done) {  // (cannot happen: the host checked the room for n_new cells)
+                atomicOr(&A.gst->err, ERRBIT_TABLE_FULL);
+                continue;
+            }
+            Cell* c = &A.table[slot];
+            c->limit = si.limit;
+            c->value = 0;
+            c->expiry = A.now + Lm.window_us;
+            ++created;
+        }
+        if (t.cnt == 0) continue;  // nothing admitted on this cell
+        Cell* c = &A.table[slot];
+        if (si.flags & SF_ZEROWIN) {  // expired at every update: (last delta, now + 0)
+            c->value = t.last;
+            c->expiry = A.now;
+        } else if (si.flags & SF_EXPIRED0) {  // update_if_expired: the first admitted hit stores, the rest add (:36-42,87-99)
+            c->value = t.sum;
+            c->expiry = A.now + Lm.window_us;
+        } else {
+            c->value = si.s + t.sum;  // fetch_add, wrapping
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) created += __shfl_down(created, off);
+    if ((threadIdx.x & 63u) == 0 && created) atomicAdd(&s_n, created);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(&A.gst->n_inserted, s_n);
+}
+
+// Where a pass that starts at hit `base_hit` ends: out[0] = the largest request r with req_off[r] <= base_hit +
+// sub_max (the pass covers the requests before r), out[1] = req_off[r].
+__global__ void k_gen_cuts(const u32* __restrict__ req_off, u32 n_req, u32 base_hit, u32 sub_max, u32 n_cuts,
+                           u32* __restrict__ out) {
+    if (blockIdx.x || threadIdx.x || !n_cuts) return;
+    const u64 target = (u64)base_hit + sub_max;
+    u32 a = 0, b = n_req;  // the largest r in [0, n_req] with req_off[r] <= target (req_off[0] = 0 qualifies)
+    while (a < b) {
+        const u32 m = (a + b + 1) >> 1;
+        if ((u64)req_off[m] <= target) a = m;
+        else b = m - 1;
+    }
+    out[0] = a;
+    out[1] = req_off[a];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,11 +806,12 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
                                                   const LimitDev* __restrict__ limits, u32 n_limits, u64 now, int load,
                                                   uint8_t* __restrict__ verdict, int32_t* __restrict__ first_limited,
                                                   u64* __restrict__ remaining, u64* __restrict__ expires_in,
-                                                  Status* host_status, u32 done_seq) {
+                                                  const u64* __restrict__ req_delta, Status* host_status, u32 done_seq) {
     __shared__ u64 s_key[GT_ENT], s_value[GT_ENT], s_expiry[GT_ENT];
     __shared__ u32 s_slot[GT_ENT], s_limit[GT_ENT], s_flags[GT_ENT];
     __shared__ u64 h_max[GT_MAX], h_win[GT_MAX];
-    __shared__ u32 h_delta[GT_MAX], h_lim[GT_MAX];
+    __shared__ u64 h_delta[GT_MAX];  // the REQUEST's delta (in_memory.rs:75 `delta: u64`), req_delta[] or the wire field
+    __shared__ u32 h_lim[GT_MAX];
     __shared__ unsigned short h_ent[GT_MAX];
     __shared__ u32 s_req_off[GT_MAX_REQ + 1];  // (req_off may live in host-mapped memory: read it once, in parallel)
     __shared__ u32 s_err, s_created, s_dropped;
@@ -230,6 +826,10 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
     if (tid == 0) s_err = s_created = s_dropped = 0;
     for (u32 r = tid; r <= n_req; r += 256) s_req_off[r] = req_off ? req_off[r] : r;
     __syncthreads();
+    if (req_delta)  // one u64 delta per request, spread over its hits
+        for (u32 r = tid; r < n_req; r += 256)
+            for (u32 j = s_req_off[r]; j < s_req_off[r + 1] && j < GT_MAX; ++j) h_delta[j] = req_delta[r];
+    __syncthreads();
     // ---- 1a: validate, find or create the cell, claim the key's LDS cell ---------------------------
     bool claimer = false;
     u32 my_slot = SLOT_INVALID, my_ent = 0;
@@ -243,7 +843,7 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
             const LimitDev L = limits[h.limit & ~SIMPLE_FLAG];
             h_max[tid] = L.max_value;
             h_win[tid] = L.window_us;
-            h_delta[tid] = h.delta;
+            if (!req_delta) h_delta[tid] = h.delta;
             h_lim[tid] = h.limit;
             u32 created = 0;
             const u32 s0 = slot_of(h.key, seed, log2cap);
@@ -296,7 +896,7 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
                     const u32 e = h_ent[j];
                     s_flags[e] |= GT_REACHED;
                     const u64 value = s_expiry[e] <= now ? 0ull : s_value[e];  // value_at(now)
-                    const u64 sum = value + (u64)h_delta[j];                     // wraps like the release build
+                    const u64 sum = value + h_delta[j];                          // wraps like the release build
                     const bool within = sum <= h_max[j];
                     if (load) {
                         remaining[j] = within ? h_max[j] - sum : 0ull;  // checked_sub().unwrap_or_default(), :88-89
@@ -316,9 +916,9 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
                         const u32 e = h_ent[j];
                         if (s_expiry[e] <= now) {  // atomic_expiring_value.rs:36-42,87-99
                             s_expiry[e] = now + h_win[j];
-                            s_value[e] = (u64)h_delta[j];
+                            s_value[e] = h_delta[j];
                         } else {
-                            s_value[e] += (u64)h_delta[j];
+                            s_value[e] += h_delta[j];
                         }
                         s_flags[e] |= GT_DIRTY;
                     }

@@ -104,9 +104,11 @@ class Engine:
         self._check(self._lib.rl_add_counter(self._h, int(limit), int(key)))
 
     # -- hot path ----------------------------------------------------------------------------
-    def check_and_update(self, hits, now_us, req_off=None, load_counters=False, want_first_limited=True):
+    def check_and_update(self, hits, now_us, req_off=None, load_counters=False, want_first_limited=True,
+                         req_delta=None, req_now_us=None):
         """CounterStorage::check_and_update for a batch.  Returns (verdict u8[n_req],
-        first_limited i32[n_req] | None, remaining u64[n_hits] | None, expires_in_us | None)."""
+        first_limited i32[n_req] | None, remaining u64[n_hits] | None, expires_in_us | None).
+        req_delta: per-request u64 deltas (the trait's `delta: u64`); req_now_us: per-request clock values."""
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
         n_hits = hits.shape[0]
         if req_off is not None:
@@ -114,13 +116,19 @@ class Engine:
             n_req = req_off.shape[0] - 1
         else:
             n_req = n_hits
+        if req_delta is not None:
+            req_delta = np.ascontiguousarray(req_delta, dtype=np.uint64)
+            assert req_delta.shape[0] == n_req
+        if req_now_us is not None:
+            req_now_us = np.ascontiguousarray(req_now_us, dtype=np.uint64)
+            assert req_now_us.shape[0] == n_req
         verdict = np.empty(n_req, dtype=np.uint8)
         first = np.empty(n_req, dtype=np.int32) if want_first_limited else None
         remaining = np.zeros(n_hits, dtype=np.uint64) if load_counters else None
         expires = np.zeros(n_hits, dtype=np.uint64) if load_counters else None
-        self._check(self._lib.rl_check_and_update_batch(
-            self._h, _ptr(hits), n_hits, _ptr(req_off), n_req, int(now_us), int(bool(load_counters)),
-            _ptr(verdict), _ptr(first), _ptr(remaining), _ptr(expires)))
+        self._check(self._lib.rl_check_and_update_batch_ex(
+            self._h, _ptr(hits), n_hits, _ptr(req_off), n_req, _ptr(req_delta), _ptr(req_now_us), int(now_us),
+            int(bool(load_counters)), _ptr(verdict), _ptr(first), _ptr(remaining), _ptr(expires)))
         return verdict, first, remaining, expires
 
     def check_and_update_device(self, d_hits, n_hits, now_us, d_verdict, d_req_off=None, n_req=None,

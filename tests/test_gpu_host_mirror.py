@@ -65,6 +65,23 @@ def test_errors_carry_the_engine_status(host):
     with pytest.raises(StorageError) as e:
         host.check_and_update([(simple, ())], 1, False)
     assert e.value.code == -5
-    with pytest.raises(StorageError) as e:
-        host.check_and_update([(("ns", 5, 60, (), ("u",), None), (("u", "1"),))], 1 << 40, False)
-    assert e.value.code == -1
+
+
+def test_a_delta_beyond_32_bits_is_answered_like_the_reference(host):
+    """The trait's delta is a u64 (storage/mod.rs:283-288): `value + delta <= max_value` with a delta of 2^40
+    is Limited, not an error (in_memory.rs:259-264; HTTP /check_and_report takes a u64 delta), and a limit
+    that large admits it with exact 64-bit arithmetic."""
+    host.set_clock(1_700_000_000_000_000)
+    small = (("ns", 5, 60, (), ("u",), None), (("u", "1"),))
+    huge = (("ns", (1 << 63), 60, (), ("u",), None), (("u", "1"),))
+    limited, idx, _ = host.check_and_update([small], 1 << 40, False)
+    assert limited and idx == 0
+    assert host.is_within_limits(*small, 1 << 40) is False
+    assert host.is_within_limits(*huge, 1 << 40) is True
+    limited, _idx, out = host.check_and_update([huge], (1 << 62) + 5, True)
+    assert not limited and out[0][0] == (1 << 63) - (1 << 62) - 5
+    limited, _idx, out = host.check_and_update([huge], (1 << 62), True)   # 2^62 + 5 + 2^62 > 2^63
+    assert limited and out[0][0] == 0
+    host.update_counter(*huge, (1 << 40))
+    limited, _idx, out = host.check_and_update([huge], 1, True)
+    assert not limited and out[0][0] == (1 << 63) - ((1 << 62) + 5 + (1 << 40) + 1)

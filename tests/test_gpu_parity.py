@@ -300,6 +300,59 @@ def test_sweep_is_an_explicit_eviction_event(make_engine):
     assert_same_state(eng, orc)
 
 
+# ---- the trait's full-width arguments: u64 deltas, one clock value per request --------------------------
+@pytest.mark.parametrize("n_req", [7, 3000])
+def test_u64_deltas_and_per_request_clocks(make_engine, n_req):
+    """rl_check_and_update_batch_ex: req_delta carries the trait's `delta: u64` (a delta beyond 2^32 is
+    Limited / added with wrapping arithmetic like in_memory.rs:259-264, never an error) and req_now_us one
+    clock value per request (in_memory.rs:83).  7 requests take the one-launch kernel, 3000 the passes."""
+    rng = np.random.default_rng(41 + n_req)
+    rows = [(2**64 - 1, 60), (2**40, 1), (1000, 10), (5, 0)]
+    simple = [(0, 9_100_001)]
+    eng, orc = pair(make_engine, rows, simple)
+    now = NOW
+    for step in range(6):
+        hits, off, deltas, nows = [], [0], [], []
+        for r in range(n_req):
+            k = int(rng.integers(1, 4))
+            d = [1, 3, 2**33, 2**40 - 1, 2**63, 2**64 - 2][int(rng.integers(0, 6))]
+            if rng.random() < 0.3:
+                hits.append((9_100_001, 0 | RL_SIMPLE, min(d, 2**32 - 1)))
+            for _ in range(k):
+                lid = int(rng.integers(1, 4))
+                key = int(W.splitmix64(np.array([lid * 1000 + int(rng.integers(0, 40))], dtype=np.uint64))[0])
+                hits.append((key, lid, min(d, 2**32 - 1)))
+            off.append(len(hits))
+            deltas.append(d)
+            if step % 2 and rng.random() < 0.2:
+                now += int(rng.integers(1, 2 * SEC))
+            nows.append(now)
+        arr = np.zeros(len(hits), dtype=HIT_DTYPE)
+        for i, h in enumerate(hits):
+            arr[i] = h
+        kw = dict(req_off=np.array(off, dtype=np.uint32), req_delta=np.array(deltas, dtype=np.uint64),
+                  load_counters=bool(step % 3 == 0))
+        if step % 2:
+            kw["req_now_us"] = np.array(nows, dtype=np.uint64)
+        run_both(eng, orc, arr, now, **kw)
+        now += int(rng.integers(0, SEC))
+    assert_same_state(eng, orc, n_simple_expected=1)
+
+
+def test_single_counter_requests_with_u64_deltas(make_engine):
+    rng = np.random.default_rng(43)
+    eng, orc = pair(make_engine, [(2**63, 60), (100, 60)])
+    keys = W.splitmix64(np.arange(1, 301, dtype=np.uint64))
+    for step in range(3):
+        n = 5000
+        idx = rng.integers(0, 300, size=n)
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        hits["key"], hits["limit"], hits["delta"] = keys[idx], (idx % 2).astype(np.uint32), 1
+        deltas = rng.choice(np.array([1, 2**32, 2**35 + 7, 2**62], dtype=np.uint64), size=n)
+        run_both(eng, orc, hits, NOW + step, req_delta=deltas)
+    assert_same_state(eng, orc)
+
+
 # ---- BASELINE.json configs at full size ----------------------------------------------------------
 def _full_size(make_engine, n_keys, n_hits, steps, zipf):
     rows = [(W.MAX_VALUE, W.WINDOW_S)]
