@@ -193,10 +193,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_keys_total = args.keys * world
-    # table sized for short probe chains, not for footprint: load <= 0.075 (10 M keys -> 2^27 cells = 8.6 GB
-    # of the 288 GB): a displaced key costs its workgroup a dependent HBM round trip (DESIGN.md §3.1;
-    # measured: load 0.30 / 0.15 / 0.075 -> k_bkt_apply 66.9 / 62.0 / 58.3 us)
-    cap = 1 << (int(n_keys_total / world * 8.8 * args.cap_mult - 1).bit_length())
+    # 32-byte cells at load <= 0.30: 10 M keys -> 2^25 cells = 1.07 GB (measured on MI355X, k_bkt_apply one
+    # workgroup per bucket: 2^27 / 2^26 / 2^25 cells -> 14.3 / 14.1 / 13.7 G decisions/s; the first cut needed
+    # load 0.075 of 64-byte cells, 8.6 GB, to hide its probe chains)
+    cap = 1 << (int(n_keys_total / world * 2.2 * args.cap_mult - 1).bit_length())
     max_batch = int(args.batch * 2) if sharded else args.batch
     eng = Engine(capacity_cells=cap, max_batch_hits=max_batch, device=local_rank)
     eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
@@ -209,6 +209,7 @@ def main():
 
         rows = W.torch_universe_rows(n_keys_total, dev, keep=lambda k: owner_mask(k, eng.hash_seed, world, rank))
     chunk = 1 << 20
+    torch.cuda.synchronize()  # (the engine loads on its own stream)
     for lo in range(0, rows.shape[0], chunk):
         part = rows[lo:lo + chunk].contiguous()
         eng.load_cells_device(part.data_ptr(), part.shape[0])
@@ -345,7 +346,7 @@ def main():
                                    "delta=1, single-counter requests" if (args.keys, args.batch, args.zipf) == (10_000_000, 1_000_000, 0.99)
                        else f"{args.keys} keys/GPU, zipf {args.zipf}, {args.batch}-hit batch/GPU",
                        "keys_per_gpu": args.keys, "batch_per_gpu": args.batch, "zipf_s": args.zipf,
-                       "table_capacity_cells": cap, "cell_bytes": 64,
+                       "table_capacity_cells": cap, "cell_bytes": 32, "table_bytes": cap * 32,
                        "parallelism": f"hash-sharded x{world}, RCCL all-to-all" if sharded else "single GPU",
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
                        "overlap": "partition of batch k+1 (own stream) beside k_hot_state + k_bkt_apply of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",

@@ -167,6 +167,12 @@ class Engine:
         self._check(self._lib.rl_get_counters(self._h, int(limit), int(now_us), _ptr(out), cap, C.byref(n)))
         return out[: min(cap, n.value)]
 
+    def count_counters(self, limit, now_us):
+        """Number of rows rl_get_counters would return (counted on the device, nothing copied)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.rl_get_counters(self._h, int(limit), int(now_us), None, 0, C.byref(n)))
+        return n.value
+
     def delete_counters(self, limit):
         self._check(self._lib.rl_delete_counters(self._h, int(limit)))
 
