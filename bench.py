@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1_000_000, help="hits per GPU per step")
     ap.add_argument("--zipf", type=float, default=0.99, help="0 => uniform keys")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--secondary", type=int, default=1, help="0: skip the `secondary` block (other shapes of BASELINE.json)")
     ap.add_argument("--cap-mult", type=float, default=1.0, help="scale the table capacity (experiments)")
     ap.add_argument("--depth", type=int, default=3, choices=(1, 2, 3),
                     help="batches in flight on one GPU: N = submit batch k+N-1 before collecting batch k "
@@ -113,58 +114,178 @@ def cpu_baseline(args, budget_s):
         i += 1
     orc.close()
     single = done / spent
-    # ---- all cores -------------------------------------------------------------------------------
-    cores = min(os.cpu_count() or 1, 64)
-    if cores < 2:
+    # ---- every host core ----------------------------------------------------------------------------
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = logical
+    if logical < 2:
         return {"value": single, "unit": "decisions/s", "cores": 1, "kind": "port",
                 "sample": f"{i} batches x {n} hits, single thread, oracle/limitador_oracle.c"}
+    best = None
+    tried = {}
+    tries = sorted({c for c in (32, 64, physical, logical) if c <= logical})
+    for cores in tries:
+        r = _cpu_sharded(args, cores, batches, n, budget_s / 2 / len(tries))
+        tried[str(cores)] = r[0]
+        if best is None or r[0] > best[0]:
+            best = (r[0], cores, r[1])
+    return {"value": best[0], "unit": "decisions/s", "cores": best[1], "host_physical_cores": physical,
+            "host_logical_cpus": logical, "threads_tried": tried, "kind": "port", "single_thread": single,
+            "sample": f"{best[2]} batches x {n} hits over {best[1]} threads (keys hash-sharded, one table per thread, "
+                      f"partition not timed) + {i} batches on one thread; {args.keys} keys, zipf {args.zipf}; "
+                      f"oracle/limitador_oracle.c (hash-map table, no CEL/moka/tracing)"}
+
+
+def _cpu_sharded(args, cores, batches, n, budget_s):
+    """decisions/s of `cores` oracle tables, one thread each, keys hash-sharded -> (rate, batches timed)."""
+    import threading
+
+    import numpy as np
+
+    import oracle
+    from limitador_amd import workloads as W
+
+    # the universe once, partitioned by owner (a hash of the key), one oracle table per thread
+    uni = W.universe_rows(args.keys)
+    owner = W.splitmix64(uni["key"]) % np.uint64(cores)
+    order = np.argsort(owner, kind="stable")
+    uni = uni[order]
+    bounds = np.searchsorted(owner[order], np.arange(cores + 1, dtype=np.uint64))
     shards = [None] * cores
 
     def build(t):
-        shards[t] = _cpu_shard(args, cores, t)
+        o = oracle.OracleStorage()
+        o.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+        c = uni[bounds[t]:bounds[t + 1]]
+        o.load_cells(c["key"], c["limit"], c["value"], c["expiry_us"])
+        shards[t] = o
 
     ths = [threading.Thread(target=build, args=(t,)) for t in range(cores)]
     [t.start() for t in ths]
     [t.join() for t in ths]
+    del uni
     parts = []
     for h in batches:
         owner = W.splitmix64(h["key"]) % np.uint64(cores)
-        parts.append([np.ascontiguousarray(h[owner == t]) for t in range(cores)])
-    # persistent worker threads, one per shard, released batch by batch (ctypes drops the GIL inside the
-    # oracle call); the timed span of a batch is barrier to barrier
-    start, stop = threading.Barrier(cores + 1), threading.Barrier(cores + 1)
-    state = {"part": None, "now": W.NOW0_US, "run": True}
-
-    def worker(t):
-        while True:
-            start.wait()
-            if not state["run"]:
-                return
-            shards[t].check_and_update(state["part"][t], state["now"], want_first_limited=False)
-            stop.wait()
-
-    ths = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(cores)]
-    [t.start() for t in ths]
-    done_mt, spent_mt, j = 0, 0.0, 0
-    while spent_mt < budget_s / 2 and j < 256:
-        state["part"] = parts[j % len(parts)]
-        t0 = time.perf_counter()
-        start.wait()
-        stop.wait()
-        spent_mt += time.perf_counter() - t0
-        done_mt += n
-        state["now"] += 1000
-        j += 1
-    state["run"] = False
-    start.wait()
-    [t.join() for t in ths]
+        order = np.argsort(owner, kind="stable")
+        hs = h[order]
+        bounds = np.searchsorted(owner[order], np.arange(cores + 1, dtype=np.uint64))
+        parts.append([np.ascontiguousarray(hs[bounds[t]:bounds[t + 1]]) for t in range(cores)])
+    # one C thread per shard (oracle.bench_sharded: pthreads, a barrier between batches): a short run to size the
+    # timed one to the budget
+    warm = oracle.bench_sharded(shards, parts, 2, W.NOW0_US)
+    reps = int(max(4, min(2000, budget_s / max(warm / 2, 1e-6))))
+    sec = oracle.bench_sharded(shards, parts, reps, W.NOW0_US + 10_000)
     for o in shards:
         o.close()
-    return {"value": done_mt / spent_mt, "unit": "decisions/s", "cores": cores, "kind": "port",
-            "single_thread": single,
-            "sample": f"{j} batches x {n} hits over {cores} threads (keys hash-sharded, one table per thread, "
-                      f"partition not timed) + {i} batches on one thread; {args.keys} keys, zipf {args.zipf}; "
-                      f"oracle/limitador_oracle.c (hash-map table, no CEL/moka/tracing)"}
+    return n * reps / sec, reps
+
+
+def secondary(args, eng, dev, gen):
+    """The other shapes of BASELINE.json next to the headline (N = 1 only): each is a measured rate of the same
+    build, none of them is `value`."""
+    import numpy as np
+    import torch
+
+    import oracle
+    from limitador_amd import workloads as W
+    from limitador_amd.engine import Engine
+
+    out = {}
+    now = [W.NOW0_US + 10_000_000]
+
+    def run_device(e, batches, n, steps, depth=3):
+        v = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(4)]
+        torch.cuda.synchronize()
+        pending = 0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            e.submit_device(batches[i % len(batches)].data_ptr(), n, now[0], v[i & 3].data_ptr())
+            now[0] += 1000
+            if pending == depth - 1:
+                e.collect()
+            else:
+                pending += 1
+        while pending:
+            e.collect()
+            pending -= 1
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    # -- a long run of the headline workload (1000 steps over 100 distinct batches)
+    cdf = W.torch_zipf_cdf(args.keys, dev, args.zipf) if args.zipf > 0 else None
+    many = [W.torch_batch(args.keys, args.batch, dev, gen, cdf) for _ in range(100)]
+    run_device(eng, many, args.batch, 20)
+    dt = run_device(eng, many, args.batch, 1000)
+    out["headline_1000_steps"] = {"decisions_per_s": args.batch * 1000 / dt, "ms_per_step": dt}
+    del many
+    # -- uniform keys, same table and batch size (no hot keys: every hit reads and writes a cell)
+    uni = [W.torch_batch(args.keys, args.batch, dev, gen, None) for _ in range(10)]
+    run_device(eng, uni, args.batch, 10)
+    dt = run_device(eng, uni, args.batch, 50)
+    out["uniform_10M_keys_1M_hits"] = {"decisions_per_s": args.batch * 50 / dt, "ms_per_step": dt / 50 * 1e3}
+    # -- the boundary handing over HOST buffers (rl_check_and_update_batch: 21 B/hit over PCIe, pageable memory)
+    rng = np.random.default_rng(W.SEED)
+    cdf_np = W.zipf_cdf(args.keys, args.zipf) if args.zipf > 0 else None
+    hb = [W.zipf_batch(args.keys, args.batch, rng, cdf_np) if cdf_np is not None else W.uniform_batch(args.keys, args.batch, rng)
+          for _ in range(2)]
+    eng.check_and_update(hb[0], now[0], want_first_limited=False)
+    t0 = time.perf_counter()
+    for i in range(6):
+        eng.check_and_update(hb[i & 1], now[0], want_first_limited=False)
+        now[0] += 1000
+    dt = time.perf_counter() - t0
+    out["host_buffers_1M_hits"] = {"decisions_per_s": args.batch * 6 / dt, "ms_per_call": dt / 6 * 1e3,
+                                   "note": "rl_check_and_update_batch from pageable host arrays, PCIe inclusive"}
+    del uni, hb
+    # -- BASELINE.json configs[1]: 1 M keys, uniform 64 k-hit batches
+    e1 = Engine(capacity_cells=1 << 22, max_batch_hits=1 << 16, device=eng.device)
+    e1.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+    rows = W.torch_universe_rows(1 << 20, dev)
+    torch.cuda.synchronize()
+    e1.load_cells_device(rows.data_ptr(), rows.shape[0])
+    b1 = [W.torch_batch(1 << 20, 1 << 16, dev, gen, None) for _ in range(50)]
+    run_device(e1, b1, 1 << 16, 50)
+    dt = run_device(e1, b1, 1 << 16, 500)
+    out["configs1_1M_keys_uniform_64k_hits"] = {"decisions_per_s": (1 << 16) * 500 / dt, "us_per_batch": dt / 500 * 1e6}
+    e1.close()
+    del rows, b1
+    # -- BASELINE.json configs[0]: 3 limits / 1 namespace, 10 k sequential check_and_update calls through the trait
+    #    mirror (rls_check_and_update, one request per call), the single-thread oracle beside it
+    try:
+        from limitador_amd.host_storage import HostStorage
+
+        hs = HostStorage(capacity_cells=1 << 12, max_batch_hits=1 << 10, device=eng.device)
+        hs.set_clock(W.NOW0_US)
+        lims = [("ns", 10, 60, (), (), None), ("ns", 5, 60, (), (), None), ("ns", 50000, 10, (), (), None)]  # sandbox/limits.yaml
+        for la in lims:
+            hs.add_counter(la)
+        ctrs = [(la, ()) for la in lims]
+        hs.check_and_update_repeat(ctrs, 1, 200)
+        sec, limited = hs.check_and_update_repeat(ctrs, 1, 10_000)
+        hs.close()
+        orc = oracle.OracleStorage()
+        orc.set_limits([(10, 60), (5, 60), (50000, 10)])
+        hits = np.zeros(30_000, dtype=oracle.HIT_DTYPE)
+        for q in range(3):
+            orc.add_counter(q | oracle.SIMPLE_FLAG)
+            hits["key"][q::3], hits["limit"][q::3], hits["delta"][q::3] = 7_000_000 + q, q | oracle.SIMPLE_FLAG, 1
+        off = (np.arange(10_001) * 3).astype(np.uint32)
+        t0 = time.perf_counter()
+        v, _f, _r, _e = orc.check_and_update(hits, W.NOW0_US, req_off=off)
+        osec = time.perf_counter() - t0
+        out["configs0_3_limits_10k_sequential_calls"] = {
+            "gpu_calls_per_s": 10_000 / sec, "gpu_us_per_call": sec / 10_000 * 1e6, "gpu_limited": int(limited),
+            "cpu_oracle_calls_per_s": 10_000 / osec, "cpu_limited": int(v.sum()),
+            "note": "one request (3 counters) per call: the GPU path is launch-latency-bound, the reason the transport "
+                    "has to micro-batch"}
+    except Exception as ex:  # the host mirror is optional plumbing for this leg
+        out["configs0_3_limits_10k_sequential_calls"] = {"error": str(ex)[:200]}
+    return out
 
 
 def main():
@@ -251,8 +372,13 @@ def main():
         # timed region ends (drain()).
         pending = [0]
 
+        host_submit = [0.0, 0]
+
         def step(i, now):
+            t_s = time.perf_counter()
             eng.submit_device(batches[i].data_ptr(), args.batch, now, verdicts[i & 3].data_ptr())
+            host_submit[0] += time.perf_counter() - t_s
+            host_submit[1] += 1
             if pending[0] == args.depth - 1:
                 eng.collect()
             else:
@@ -360,8 +486,12 @@ def main():
                          else "HIP events in the breakdown pass before the timed region"},
             "pipeline": {"kernel_ms_per_batch": per, "device_ms_per_batch": pipe_ms,
                          "achieved_GBps_49B": ALGO_BYTES_TOTAL * hits_per_launch / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
-                         "ordered_hits_per_batch": st["ordered_hits"] / max(1, st["batches"])},
+                         "ordered_hits_per_batch": st["ordered_hits"] / max(1, st["batches"]),
+                         "host_submit_us_per_batch": (host_submit[0] / max(1, host_submit[1]) * 1e6)
+                         if (not sharded and args.depth >= 2) else None},
         }
+        if world == 1 and not args.force_sharded and args.secondary:
+            out["secondary"] = secondary(args, eng, dev, gen)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

@@ -88,6 +88,12 @@ int32_t rls_batcher_check_and_update(rls_batcher *b, rls_counter *counters, uint
 /* batches dispatched / requests carried so far */
 void rls_batcher_stats(rls_batcher *b, uint64_t *batches, uint64_t *requests);
 
+/* Measurement helper (bench.py, BASELINE.json configs[0]): `iterations` sequential check_and_update calls with
+ * the same counters, timed in native code — the per-request cost of the trait boundary without a Python loop
+ * around it.  elapsed_ns: wall time of the loop; n_limited: calls answered Limited. */
+int32_t rls_check_and_update_repeat(rls_storage *s, rls_counter *counters, uint32_t n, uint64_t delta,
+                                    uint32_t iterations, uint64_t *elapsed_ns, uint32_t *n_limited);
+
 #ifdef __cplusplus
 }
 #endif

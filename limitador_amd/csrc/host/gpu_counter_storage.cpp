@@ -491,6 +491,24 @@ int32_t rls_batcher_check_and_update(rls_batcher* b, rls_counter* counters, uint
     return RL_OK;
 }
 
+int32_t rls_check_and_update_repeat(rls_storage* s, rls_counter* counters, uint32_t n, uint64_t delta, uint32_t iterations,
+                                    uint64_t* elapsed_ns, uint32_t* n_limited) {
+    if (!s || (n && !counters) || !elapsed_ns) return RL_ERR_INVALID;
+    std::vector<rls::Counter> cs;
+    for (uint32_t i = 0; i < n; ++i) cs.push_back(to_counter(&counters[i]));
+    uint32_t limited = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 0; it < iterations; ++it) {
+        rls::Authorization a;
+        const int rc = s->s->check_and_update(cs, delta, false, &a);
+        if (rc) return rc;
+        limited += a.limited ? 1u : 0u;
+    }
+    *elapsed_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (n_limited) *n_limited = limited;
+    return RL_OK;
+}
+
 void rls_batcher_stats(rls_batcher* b, uint64_t* batches, uint64_t* requests) {
     uint64_t nb = 0, nr = 0;
     if (b) b->b->stats(&nb, &nr);

@@ -57,6 +57,8 @@ def load():
     sig("rls_get_counters", C.c_int32, [p, C.POINTER(RlsLimit), C.c_uint32, EMIT_FN, p])
     sig("rls_delete_counters", C.c_int32, [p, C.POINTER(RlsLimit), C.c_uint32])
     sig("rls_clear", C.c_int32, [p])
+    sig("rls_check_and_update_repeat", C.c_int32, [p, C.POINTER(RlsCounter), C.c_uint32, C.c_uint64, C.c_uint32,
+                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)])
     sig("rls_batcher_create", C.c_int32, [p, C.c_uint32, C.c_uint32, C.POINTER(p)])
     sig("rls_batcher_destroy", None, [p])
     sig("rls_batcher_check_and_update", C.c_int32, [p, C.POINTER(RlsCounter), C.c_uint32, C.c_uint64, C.c_int32,
@@ -158,6 +160,18 @@ class HostStorage:
         loaded = [(arr[i].remaining if arr[i].has_remaining else None,
                    arr[i].expires_in_us if arr[i].has_expires_in else None) for i in range(len(counters))]
         return bool(limited.value), idx.value, loaded
+
+    def check_and_update_repeat(self, counters, delta, iterations):
+        """`iterations` sequential check_and_update calls timed in native code -> (seconds, calls limited)."""
+        arr = (RlsCounter * max(1, len(counters)))()
+        keep = []
+        for i, (la, sv) in enumerate(counters):
+            arr[i], k = c_counter(la, sv)
+            keep.append(k)
+        ns, lim = C.c_uint64(), C.c_uint32()
+        self._check(self._so.rls_check_and_update_repeat(self._h, arr, len(counters), delta, iterations, C.byref(ns),
+                                                         C.byref(lim)))
+        return ns.value * 1e-9, lim.value
 
     def get_counters(self, limits):
         """limits: list of limit_args -> [(limit index, {name: value}, remaining, expires_in_us)]"""

@@ -79,6 +79,8 @@ def lib():
         L.lo_check_and_update_batch_ex.argtypes = [p, p, C.c_size_t, p, C.c_size_t, p, C.c_size_t, p, p, u64, i32, p, p,
                                                    p, p]
         L.lo_is_within_limits_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, u64, p]
+        L.lo_bench_sharded.restype = C.c_double
+        L.lo_bench_sharded.argtypes = [p, C.c_size_t, p, C.c_size_t, p, p, C.c_size_t, C.c_size_t, u64]
         L.lo_update_counter_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, u64]
         _lib = L
     return _lib
@@ -215,3 +217,19 @@ class OracleStorage:
         if not self.L.lo_peek_simple(self.h, int(limit) & ~SIMPLE_FLAG, C.byref(c)):
             return None
         return c.value, c.expiry_us
+
+
+def bench_sharded(shards, parts, reps, now0_us):
+    """Replay single-counter batches over hash-sharded OracleStorages with one C thread per shard
+    (lo_bench_sharded).  parts[d][t] = hits of distinct batch d owned by shard t.  -> wall seconds."""
+    n_shards, n_distinct = len(shards), len(parts)
+    handles = (C.c_void_p * n_shards)(*[s.h for s in shards])
+    flat = [np.ascontiguousarray(parts[d][t], dtype=HIT_DTYPE) for d in range(n_distinct) for t in range(n_shards)]
+    ptrs = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
+    sizes = (C.c_size_t * len(flat))(*[a.shape[0] for a in flat])
+    limits = shards[0].limits
+    sec = lib().lo_bench_sharded(handles, n_shards, _ptr(limits), limits.shape[0], ptrs, sizes, n_distinct, reps,
+                                 int(now0_us))
+    if sec < 0:
+        raise OracleError(int(sec))
+    return sec

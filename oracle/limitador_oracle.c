@@ -6,6 +6,7 @@
  * tests/test_oracle_golden.py (the reference's own vectors) except for
  * moka capacity eviction, which is unpinned and not modelled.
  */
+#define _GNU_SOURCE
 #include "limitador_oracle.h"
 
 #include <stdlib.h>
@@ -519,4 +520,75 @@ int lo_update_counter_batch(lo_storage *s, const lo_limit_row *limits, size_t n_
         if (rc < 0) return rc;
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-threaded replay for bench.py's cpu_baseline leg: n_shards storages, one thread each (keys are
+ * hash-sharded by the caller: valid for single-counter requests, whose cells are independent), `reps`
+ * batches, batch r = parts[(r % n_distinct) * n_shards + t] for thread t; a barrier between batches (a batch
+ * is complete when its slowest shard is).  Returns the wall seconds of the whole replay, < 0 on error.
+ * ---------------------------------------------------------------------------------------- */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    lo_storage *s;
+    const lo_limit_row *limits;
+    size_t n_limits;
+    const lo_hit *const *parts;
+    const size_t *part_n;
+    size_t n_shards, n_distinct, reps, t;
+    uint64_t now0;
+    pthread_barrier_t *bar;
+    int rc;
+} lo_bench_arg;
+
+static void *lo_bench_worker(void *p) {
+    lo_bench_arg *a = (lo_bench_arg *)p;
+    size_t cap = 0;
+    for (size_t d = 0; d < a->n_distinct; d++)
+        if (a->part_n[d * a->n_shards + a->t] > cap) cap = a->part_n[d * a->n_shards + a->t];
+    uint8_t *verdict = (uint8_t *)malloc(cap ? cap : 1);
+    if (!verdict) a->rc = LO_ERR_NOMEM;
+    pthread_barrier_wait(a->bar); /* start */
+    for (size_t r = 0; r < a->reps; r++) {
+        const size_t q = (r % a->n_distinct) * a->n_shards + a->t;
+        if (!a->rc && a->part_n[q]) {
+            int rc = lo_check_and_update_batch(a->s, a->limits, a->n_limits, a->parts[q], a->part_n[q], NULL,
+                                               a->part_n[q], a->now0 + 1000 * r, 0, verdict, NULL, NULL, NULL);
+            if (rc < 0) a->rc = rc;
+        }
+        pthread_barrier_wait(a->bar);
+    }
+    free(verdict);
+    return NULL;
+}
+
+double lo_bench_sharded(lo_storage **shards, size_t n_shards, const lo_limit_row *limits, size_t n_limits,
+                        const lo_hit *const *parts, const size_t *part_n, size_t n_distinct, size_t reps,
+                        uint64_t now0) {
+    pthread_barrier_t bar;
+    if (!n_shards || !n_distinct || pthread_barrier_init(&bar, NULL, (unsigned)n_shards + 1)) return -1.0;
+    pthread_t *th = (pthread_t *)malloc(n_shards * sizeof(pthread_t));
+    lo_bench_arg *args = (lo_bench_arg *)malloc(n_shards * sizeof(lo_bench_arg));
+    if (!th || !args) return -1.0;
+    for (size_t t = 0; t < n_shards; t++) {
+        args[t] = (lo_bench_arg){shards[t], limits, n_limits, parts, part_n, n_shards, n_distinct, reps, t, now0, &bar, 0};
+        if (pthread_create(&th[t], NULL, lo_bench_worker, &args[t])) return -1.0;
+    }
+    struct timespec t0, t1;
+    pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t r = 0; r < reps; r++) pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    int rc = 0;
+    for (size_t t = 0; t < n_shards; t++) {
+        pthread_join(th[t], NULL);
+        if (args[t].rc) rc = args[t].rc;
+    }
+    pthread_barrier_destroy(&bar);
+    free(th);
+    free(args);
+    if (rc) return -1.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

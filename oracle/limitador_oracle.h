@@ -163,6 +163,13 @@ int lo_is_within_limits_batch(lo_storage *s, const lo_limit_row *limits, size_t 
 int lo_update_counter_batch(lo_storage *s, const lo_limit_row *limits, size_t n_limits,
                             const lo_hit *hits, size_t n_hits, uint64_t now_us);
 
+/* Multi-threaded replay of single-counter batches over hash-sharded storages (bench.py's cpu_baseline leg):
+ * thread t owns shards[t] and replays parts[(r % n_distinct) * n_shards + t] for batch r, with a barrier
+ * between batches.  Returns the wall seconds of the `reps` batches, < 0 on error. */
+double lo_bench_sharded(lo_storage **shards, size_t n_shards, const lo_limit_row *limits, size_t n_limits,
+                        const lo_hit *const *parts, const size_t *part_n, size_t n_distinct, size_t reps,
+                        uint64_t now0);
+
 #ifdef __cplusplus
 }
 #endif
