@@ -74,6 +74,8 @@ def lib():
         L.lo_num_qualified.argtypes = [p]
         L.lo_peek_qualified.argtypes = [p, u64, C.POINTER(Cell), C.POINTER(u32)]
         L.lo_peek_simple.argtypes = [p, u32, C.POINTER(Cell)]
+        L.lo_dump_qualified.restype = C.c_size_t
+        L.lo_dump_qualified.argtypes = [p, p, p, p, p, C.c_size_t]
         L.lo_load_qualified.argtypes = [p, p, p, p, p, C.c_size_t]
         L.lo_check_and_update_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, p, C.c_size_t, u64, i32, p, p, p, p]
         L.lo_check_and_update_batch_ex.argtypes = [p, p, C.c_size_t, p, C.c_size_t, p, C.c_size_t, p, p, u64, i32, p, p,
@@ -211,6 +213,16 @@ class OracleStorage:
         if not self.L.lo_peek_qualified(self.h, int(key), C.byref(c), C.byref(lim)):
             return None
         return c.value, c.expiry_us, lim.value
+
+    def dump_qualified(self):
+        """(keys, limits, values, expiries) of every qualified cell, sorted by key."""
+        n = self.num_qualified()
+        k, li = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint32)
+        v, e = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint64)
+        got = self.L.lo_dump_qualified(self.h, _ptr(k), _ptr(li), _ptr(v), _ptr(e), n)
+        assert got == n
+        o = np.argsort(k, kind="stable")
+        return k[o], li[o], v[o], e[o]
 
     def peek_simple(self, limit):
         c = Cell()

@@ -403,6 +403,23 @@ int lo_peek_qualified(const lo_storage *s, uint64_t key, lo_cell *out, uint32_t 
     return 1;
 }
 
+size_t lo_dump_qualified(const lo_storage *s, uint64_t *keys, uint32_t *limits, uint64_t *values,
+                         uint64_t *expiries, size_t cap) {
+    size_t n = 0;
+    for (size_t i = 0; i < s->q_cap; i++) {
+        const qslot *e = &s->q[i];
+        if (e->state != 1) continue;
+        if (n < cap) {
+            keys[n] = e->key;
+            limits[n] = e->limit;
+            values[n] = e->cell.value;
+            expiries[n] = e->cell.expiry_us;
+        }
+        n++;
+    }
+    return n;
+}
+
 int lo_peek_simple(const lo_storage *s, uint32_t limit, lo_cell *out) {
     if ((size_t)limit >= s->simple_cap || !s->simple_present[limit]) return 0;
     if (out) *out = s->simple[limit];

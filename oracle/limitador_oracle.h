@@ -118,6 +118,9 @@ size_t lo_sweep_expired(lo_storage *s, uint64_t now_us);
 size_t lo_num_qualified(const lo_storage *s);
 int lo_peek_qualified(const lo_storage *s, uint64_t key, lo_cell *out, uint32_t *limit);
 int lo_peek_simple(const lo_storage *s, uint32_t limit, lo_cell *out);
+/* Every qualified cell, raw (full-size final-state comparisons): writes up to cap, returns the total. */
+size_t lo_dump_qualified(const lo_storage *s, uint64_t *keys, uint32_t *limits, uint64_t *values,
+                         uint64_t *expiries, size_t cap);
 /* Bulk load of qualified cells (snapshot restore); used to pre-populate tables. */
 int lo_load_qualified(lo_storage *s, const uint64_t *keys, const uint32_t *limits,
                       const uint64_t *values, const uint64_t *expiries, size_t n);

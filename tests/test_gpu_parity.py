@@ -354,9 +354,11 @@ def test_single_counter_requests_with_u64_deltas(make_engine):
 
 
 # ---- BASELINE.json configs at full size ----------------------------------------------------------
-def _full_size(make_engine, n_keys, n_hits, steps, zipf):
+def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False):
+    """in_flight: the bench's entry point and geometry — device-resident batches through
+    rl_check_and_update_submit_device / _collect, three in flight, table at load <= 0.30."""
     rows = [(W.MAX_VALUE, W.WINDOW_S)]
-    cap = 1 << int(np.ceil(np.log2(n_keys * 2)))
+    cap = 1 << (int(n_keys * 2.2 - 1).bit_length())
     eng, orc = pair(make_engine, rows, capacity_cells=cap, max_batch_hits=n_hits)
     chunk = 1 << 20
     for lo in range(0, n_keys, chunk):
@@ -368,17 +370,44 @@ def _full_size(make_engine, n_keys, n_hits, steps, zipf):
     cdf = W.zipf_cdf(n_keys) if zipf else None
     now = NOW
     denied = 0
-    for _ in range(steps):
-        hits = W.zipf_batch(n_keys, n_hits, rng, cdf) if zipf else W.uniform_batch(n_keys, n_hits, rng)
-        denied += int(run_both(eng, orc, hits, now, want_first_limited=True).sum())
-        now += 1000
+    batches = [W.zipf_batch(n_keys, n_hits, rng, cdf) if zipf else W.uniform_batch(n_keys, n_hits, rng) for _ in range(steps)]
+    if not in_flight:
+        for hits in batches:
+            denied += int(run_both(eng, orc, hits, now, want_first_limited=True).sum())
+            now += 1000
+    else:
+        import torch
+
+        dev = torch.device("cuda", 0)
+        d_hits = [torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev) for h in batches]
+        d_verdict = [torch.empty(n_hits, dtype=torch.uint8, device=dev) for _ in batches]
+        d_first = [torch.empty(n_hits, dtype=torch.int32, device=dev) for _ in batches]
+        torch.cuda.synchronize()
+        pending = 0
+        for i in range(steps):
+            eng.submit_device(d_hits[i].data_ptr(), n_hits, now + 1000 * i, d_verdict[i].data_ptr(), d_first[i].data_ptr())
+            if pending == 2:
+                eng.collect()
+            else:
+                pending += 1
+        while pending:
+            eng.collect()
+            pending -= 1
+        torch.cuda.synchronize()
+        for i, hits in enumerate(batches):
+            v, f, _r, _e = orc.check_and_update(hits, now + 1000 * i)
+            assert np.array_equal(d_verdict[i].cpu().numpy(), v), f"verdicts of batch {i}"
+            assert np.array_equal(d_first[i].cpu().numpy(), f), f"first_limited of batch {i}"
+            denied += int(v.sum())
     assert 0 < denied < steps * n_hits  # a real allow/deny mix
-    # final table: same multiset of (key, value, expiry) — compare via order-independent checksums
-    rows_ = eng.dump_cells()
-    assert len(rows_) == orc.num_qualified() == n_keys
-    sample = rows_[:: max(1, n_keys // 20000)]
-    for r in sample:
-        assert (int(r["value"]), int(r["expiry_us"]), int(r["limit"])) == orc.peek(int(r["key"]))
+    # final table: EVERY cell, bit for bit (both sides sorted by key)
+    rows_ = np.sort(eng.dump_cells(), order="key")
+    k, li, v, e = orc.dump_qualified()
+    assert len(rows_) == len(k) == n_keys
+    assert np.array_equal(rows_["key"], k)
+    assert np.array_equal(rows_["limit"], li)
+    assert np.array_equal(rows_["value"], v)
+    assert np.array_equal(rows_["expiry_us"], e)
     return eng
 
 
@@ -391,6 +420,14 @@ def test_config3_zipf_1m_on_10m_keys(make_engine):
     """BASELINE.json configs[2] (fixed-window semantics): 10M keys, Zipf-0.99 1M batches."""
     eng = _full_size(make_engine, 10_000_000, 1_000_000, steps=3, zipf=True)
     assert eng.stats()["hits"] == 3_000_000
+
+
+def test_config3_through_the_bench_entry_point(make_engine):
+    """The same workload the way bench.py drives it: device-resident batches, submit / collect with three
+    batches in flight (the partition of one overlapping the replay of the one before), every verdict,
+    first_limited and final cell compared."""
+    eng = _full_size(make_engine, 10_000_000, 1_000_000, steps=5, zipf=True, in_flight=True)
+    assert eng.stats()["hits"] == 5_000_000
 
 
 # ---- multi-counter requests and load_counters (the general resolver) ------------------------------
