@@ -211,6 +211,9 @@ int32_t rl_clear(rl_engine *e);
  * replaces moka's capacity eviction and is replayed into the oracle by the tests), then
  * compact the table if tombstones exceed 1/8 of capacity. */
 int32_t rl_sweep_expired(rl_engine *e, uint64_t now_us, uint64_t *n_removed);
+/* The same, reporting the swept cells (up to cap rows, raw value / expiry; *n_removed = all of them): what a
+ * host that interns identities needs in order to forget the keys of the cells that are gone. */
+int32_t rl_sweep_expired_rows(rl_engine *e, uint64_t now_us, rl_cell_row *out, uint64_t cap, uint64_t *n_removed);
 /* Force a compaction (rehash of live cells into a fresh table). */
 int32_t rl_compact(rl_engine *e);
 /* Rehash the live cells into a table of capacity_cells (rounded up to a power of two, >= 1024): how a

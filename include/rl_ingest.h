@@ -5,14 +5,21 @@
  * dictionary-encoded request arrays.  C view of limitador_amd/csrc/host/ingest.cpp.
  *
  *   limits    Limit::new(namespace, max_value, seconds, conditions, variables) (limit.rs:54-76) with
- *             conditions of the shapes limit files are made of
- *                 descriptors[0]['key'] == 'value'      descriptors[0]['key'] != 'value'
- *                 descriptors[0].key == 'value'         key == 'value'   (the older form)
- *             and variables  descriptors[0]['key'] | descriptors[0].key | key  (at most two per limit)
- *             -> rows of rl_limits_set + the compiled match table of rl_match_table_set.  Anything else
- *             is CEL: RLI_HOST_ONLY, the caller keeps such a limit on its own evaluation path.
- *             Identity is (namespace, seconds, conditions, variables) (limit.rs:177-214): adding a limit
- *             with a known identity returns its id and refreshes max_value (what update_limit does).
+ *             conditions   <key ref> == 'value'   |   <key ref> != 'value'
+ *             and variables  <key ref>  (at most two per limit), where a key ref is what the caller's Context
+ *             can resolve (rli_set_binding):
+ *               RLI_BIND_DESCRIPTORS (default: the transports bind only the list `descriptors`,
+ *                   envoy_rls/server.rs:136-137, http_api/server.rs:140-141):
+ *                   descriptors[0]['key'] | descriptors[0]["key"] | descriptors[0].ident
+ *               RLI_BIND_ROOT (library callers, Context::from(HashMap), limit/cel.rs:81-96,153-156):  ident
+ *             -> rows of rl_limits_set + the compiled match table of rl_match_table_set.  Anything else —
+ *             a bare identifier under RLI_BIND_DESCRIPTORS included: it is unbound there and the reference
+ *             never applies such a limit — is CEL: RLI_HOST_ONLY, the caller keeps the limit on its own
+ *             evaluation path.
+ *             Identity is (namespace, seconds, conditions, variables) ON THE SOURCE TEXT of the expressions
+ *             (limit.rs:177-214; Predicate / Expression compare by source): two spellings of one predicate
+ *             are two limits with two counters; adding a limit with a known identity returns its id and
+ *             refreshes max_value (what update_limit does).
  *   requests  namespace + descriptors[0] entries + delta -> req_ns / CSR (ent_key, ent_val) / req_delta.
  *             Strings are interned exactly (two different strings never share an id).  A namespace
  *             without limits maps to namespace id 0, which never has limits: no counter, not limited
@@ -70,6 +77,15 @@ int32_t rli_batch_add(rli_ingest *g, const char *namespace_, const char *const *
  * them are RLI_HOST_ONLY).  -> request index, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID for a malformed
  * message (nothing is added). */
 int32_t rli_batch_add_rls(rli_ingest *g, const uint8_t *msg, uint32_t len);
+/* What the caller's Context binds (see the header comment); before the first rli_add_limit. */
+#define RLI_BIND_DESCRIPTORS 0
+#define RLI_BIND_ROOT 1
+int32_t rli_set_binding(rli_ingest *g, int32_t binding);
+/* Most distinct descriptor values the dictionary may hold (default 2^24, at most 2^26: value ids travel in 26
+ * bits).  At the cap a request that carries a value never seen before answers RLI_HOST_ONLY (nothing is added;
+ * requests made of known values go on): descriptor values are caller-controlled and must not grow host state
+ * without bound (the reference bounds its counters with moka's cache_size, in_memory.rs:205-212). */
+int32_t rli_set_value_cap(rli_ingest *g, uint32_t cap);
 uint32_t rli_batch_n_requests(const rli_ingest *g);
 uint32_t rli_batch_n_entries(const rli_ingest *g);
 const uint32_t *rli_batch_req_ns(const rli_ingest *g);    /* [n_requests] */

@@ -76,6 +76,14 @@ int32_t rls_get_counters(rls_storage *s, const rls_limit *limits, uint32_t n_lim
 int32_t rls_delete_counters(rls_storage *s, const rls_limit *limits, uint32_t n_limits);
 int32_t rls_clear(rls_storage *s);
 
+/* No reference analogue: drop every qualified cell whose window has ended and forget its interned identity
+ * (stands in for moka's capacity eviction, in_memory.rs:205-212, which is what bounds the reference's memory
+ * under caller-controlled descriptor values).  It runs by itself once `n_new_counters` new counters have been
+ * interned since the last sweep (default 2^20; 0 = never). */
+int32_t rls_sweep_expired(rls_storage *s, uint64_t *n_removed);
+void rls_set_sweep_after(rls_storage *s, uint64_t n_new_counters);
+uint64_t rls_interned_counters(const rls_storage *s);
+
 /* Micro-batching aggregator: many threads call rls_batcher_check_and_update concurrently; a
  * dispatcher closes a batch at max_batch requests or max_delay_us, stamps it with ONE clock value,
  * runs it as one rl_check_and_update_batch and wakes the callers. */

@@ -105,15 +105,20 @@ uint32_t GpuCounterStorage::limit_id(const Limit& l) {
     return id;
 }
 
-uint64_t GpuCounterStorage::key_of(uint32_t id, const Counter& c) {
+std::string GpuCounterStorage::counter_ident(uint32_t id, const std::vector<std::pair<std::string, std::string>>& vars) {
     std::string k = std::to_string(id);
     k += '|';
-    auto vars = c.set_variables;
-    std::sort(vars.begin(), vars.end());
     for (const auto& kv : vars) {
         append_field(k, kv.first);
         append_field(k, kv.second);
     }
+    return k;
+}
+
+uint64_t GpuCounterStorage::key_of(uint32_t id, const Counter& c) {
+    auto vars = c.set_variables;
+    std::sort(vars.begin(), vars.end());
+    std::string k = counter_ident(id, vars);
     auto it = counter_keys_.find(k);
     if (it != counter_keys_.end()) return it->second;
     // exact and collision-free: a dense sequence number, scrambled (an odd multiplier is a bijection
@@ -124,7 +129,35 @@ uint64_t GpuCounterStorage::key_of(uint32_t id, const Counter& c) {
     } while (key >= 0xFFFFFFFFFFFFFFFEull);
     counter_keys_.emplace(std::move(k), key);
     by_key_.emplace(key, std::make_pair(id, std::move(vars)));
+    if (c.is_qualified()) ++new_since_sweep_;  // (only qualified cells are ever swept)
     return key;
+}
+
+int GpuCounterStorage::sweep_locked(uint64_t* n_removed) {
+    // size the row buffer for every qualified cell that could be swept: the interned counters
+    std::vector<rl_cell_row> rows(by_key_.size());
+    uint64_t n = 0;
+    if (int rc = rl_sweep_expired_rows(eng_, now_us(), rows.data(), rows.size(), &n)) return fail(rc);
+    const uint64_t got = n < rows.size() ? n : rows.size();
+    for (uint64_t q = 0; q < got; ++q) {
+        auto it = by_key_.find(rows[q].key);
+        if (it == by_key_.end()) continue;
+        counter_keys_.erase(counter_ident(it->second.first, it->second.second));
+        by_key_.erase(it);
+    }
+    new_since_sweep_ = 0;
+    if (n_removed) *n_removed = n;
+    return RL_OK;
+}
+
+int GpuCounterStorage::sweep_expired(uint64_t* n_removed) {
+    std::lock_guard<std::mutex> g(mu_);
+    return sweep_locked(n_removed);
+}
+
+int GpuCounterStorage::maybe_sweep() {
+    if (!sweep_after_ || new_since_sweep_ < sweep_after_) return RL_OK;
+    return sweep_locked(nullptr);
 }
 
 int GpuCounterStorage::to_hit(const Counter& c, uint64_t delta, rl_hit* out) {
@@ -175,6 +208,7 @@ int GpuCounterStorage::check_and_update(std::vector<Counter>& counters, uint64_t
 
 int GpuCounterStorage::check_and_update_many(std::vector<Request*>& reqs) {
     std::lock_guard<std::mutex> g(mu_);
+    if (int rc = maybe_sweep()) return rc;  // keeps the interning tables (caller-controlled strings) bounded
     const uint64_t now = now_us();
     size_t begin = 0;
     while (begin < reqs.size()) {
@@ -464,6 +498,14 @@ int32_t rls_delete_counters(rls_storage* s, const rls_limit* limits, uint32_t n_
 }
 
 int32_t rls_clear(rls_storage* s) { return s ? s->s->clear() : RL_ERR_INVALID; }
+
+int32_t rls_sweep_expired(rls_storage* s, uint64_t* n_removed) { return s ? s->s->sweep_expired(n_removed) : RL_ERR_INVALID; }
+
+void rls_set_sweep_after(rls_storage* s, uint64_t n_new_counters) {
+    if (s) s->s->set_sweep_after(n_new_counters);
+}
+
+uint64_t rls_interned_counters(const rls_storage* s) { return s ? (uint64_t)s->s->interned_counters() : 0; }
 
 int32_t rls_batcher_create(rls_storage* s, uint32_t max_batch, uint32_t max_delay_us, rls_batcher** out) {
     if (!s || !out) return RL_ERR_INVALID;

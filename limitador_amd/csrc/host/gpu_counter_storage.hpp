@@ -86,6 +86,14 @@ public:
     // Applies the requests in index order with ONE clock value (the batch semantics of rl_engine.h).
     int check_and_update_many(std::vector<Request*>& reqs);
 
+    // Drop every qualified cell whose window has ended and forget the interned identity of each one (no
+    // reference analogue: it stands in for moka's capacity eviction, in_memory.rs:205-212, which bounds the
+    // reference's memory; it never changes a decision on an unexpired counter).  Runs by itself once
+    // `sweep_after` new counters have been interned since the last sweep (set_sweep_after; 0 = never).
+    int sweep_expired(uint64_t* n_removed);
+    void set_sweep_after(uint64_t n_new_counters) { sweep_after_ = n_new_counters; }
+    size_t interned_counters() const { return by_key_.size(); }
+
     const StorageErr& last_error() const { return err_; }
     void set_clock(uint64_t now_us) { fixed_now_us_ = now_us; }
     uint64_t now_us() const;
@@ -106,6 +114,10 @@ private:
     uint64_t fixed_now_us_ = 0;
     uint32_t max_batch_ = 0;
     uint64_t key_seq_ = 0;
+    uint64_t sweep_after_ = 1u << 20, new_since_sweep_ = 0;
+    int maybe_sweep();  // (mu_ held)
+    int sweep_locked(uint64_t* n_removed);
+    static std::string counter_ident(uint32_t id, const std::vector<std::pair<std::string, std::string>>& sorted_vars);
     std::unordered_map<std::string, uint32_t> limit_ids_;
     std::vector<rl_limit_row> rows_;
     std::vector<Limit> limit_of_id_;

@@ -48,10 +48,14 @@ struct Cond {
 struct LimitSpec {
     std::string ns;
     uint64_t max_value, seconds;
-    std::vector<Cond> conds;        // sorted, unique
-    std::vector<std::string> vars;  // descriptor keys, sorted by name, unique
-    using Identity = std::tuple<std::string, uint64_t, std::vector<Cond>, std::vector<std::string>>;
-    Identity identity() const { return Identity(ns, seconds, conds, vars); }
+    std::vector<Cond> conds;        // parsed, in the order of cond_src
+    std::vector<std::string> vars;  // descriptor keys, in the order of var_src
+    // Identity is on the SOURCE expressions, like the reference's (limit.rs:177-214: namespace, seconds and
+    // the BTreeSets of Predicate / Expression, which compare by their source text): two spellings of one
+    // predicate are two limits with two counters.
+    std::vector<std::string> cond_src, var_src;  // sorted, unique
+    using Identity = std::tuple<std::string, uint64_t, std::vector<std::string>, std::vector<std::string>>;
+    Identity identity() const { return Identity(ns, seconds, cond_src, var_src); }
 };
 
 void skip_ws(const std::string& s, size_t& i) {
@@ -71,34 +75,45 @@ bool parse_quoted(const std::string& s, size_t& i, std::string* out) {
     return true;
 }
 
-// descriptors[0]['key'] | descriptors[0].key | key     (key: letters, digits, '_', '.', '-', ':')
-bool parse_key_ref(const std::string& s, size_t& i, std::string* key) {
-    skip_ws(s, i);
-    static const std::string pre = "descriptors[0]";
-    if (s.compare(i, pre.size(), pre) == 0) {
-        i += pre.size();
-        skip_ws(s, i);
-        if (i < s.size() && s[i] == '[') {
-            ++i;
-            if (!parse_quoted(s, i, key)) return false;
-            skip_ws(s, i);
-            if (i >= s.size() || s[i] != ']') return false;
-            ++i;
-            return !key->empty();
-        }
-        if (i < s.size() && s[i] == '.') ++i;
-        else return false;
-    }
-    const size_t b = i;
-    while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '.' || s[i] == '-' || s[i] == ':')) ++i;
+// How a limit's expressions reach the request's strings depends on what the caller's Context binds:
+//   RLI_BIND_DESCRIPTORS (default; both transports: envoy_rls/server.rs:136-137, http_api/server.rs:140-141 bind
+//       ONLY the list `descriptors`):   descriptors[0]['key'] | descriptors[0]["key"] | descriptors[0].ident
+//       A bare `x == '1'` or `req.method == 'GET'` references an unbound variable there and never applies, and
+//       `descriptors[0].a.b` is nested member access, not the key "a.b".
+//   RLI_BIND_ROOT (library callers, Context::from(HashMap): limit/cel.rs:81-96,153-156 binds every key as a
+//       root variable; what limit.rs:239-348 tests with):   ident
+// Everything else is CEL the device matcher does not restate: RLI_HOST_ONLY.
+static bool cel_ident(const std::string& s, size_t& i, std::string* out) {
+    const size_t b = i;  // [A-Za-z_][A-Za-z0-9_]*
+    while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_')) ++i;
     if (i == b || std::isdigit((unsigned char)s[b])) return false;
-    *key = s.substr(b, i - b);
+    if (i < s.size() && (s[i] == '.' || s[i] == '[' || s[i] == '(')) return false;  // nested access / call: CEL
+    *out = s.substr(b, i - b);
     return true;
 }
+bool parse_key_ref(const std::string& s, size_t& i, std::string* key, int binding) {
+    skip_ws(s, i);
+    if (binding == RLI_BIND_ROOT) return cel_ident(s, i, key);
+    static const std::string pre = "descriptors[0]";
+    if (s.compare(i, pre.size(), pre) != 0) return false;
+    i += pre.size();
+    skip_ws(s, i);
+    if (i < s.size() && s[i] == '[') {
+        ++i;
+        if (!parse_quoted(s, i, key)) return false;
+        skip_ws(s, i);
+        if (i >= s.size() || s[i] != ']') return false;
+        ++i;
+        return true;
+    }
+    if (i >= s.size() || s[i] != '.') return false;
+    ++i;
+    return cel_ident(s, i, key);
+}
 
-bool parse_condition(const std::string& s, Cond* c) {
+bool parse_condition(const std::string& s, Cond* c, int binding) {
     size_t i = 0;
-    if (!parse_key_ref(s, i, &c->key)) return false;
+    if (!parse_key_ref(s, i, &c->key, binding)) return false;
     skip_ws(s, i);
     if (s.compare(i, 2, "==") == 0) c->op = 0;
     else if (s.compare(i, 2, "!=") == 0) c->op = 1;
@@ -109,9 +124,9 @@ bool parse_condition(const std::string& s, Cond* c) {
     return i == s.size();
 }
 
-bool parse_variable(const std::string& s, std::string* key) {
+bool parse_variable(const std::string& s, std::string* key, int binding) {
     size_t i = 0;
-    if (!parse_key_ref(s, i, key)) return false;
+    if (!parse_key_ref(s, i, key, binding)) return false;
     skip_ws(s, i);
     return i == s.size();
 }
@@ -207,6 +222,9 @@ struct rli_ingest {
     std::vector<rl_limit_row> rows;
     std::vector<rl_match_limit> table;
     std::vector<rl_match_cond> conds;
+    int binding = RLI_BIND_DESCRIPTORS;  // rli_set_binding
+    uint32_t n_ns_installed = 0;     // namespaces the installed match table knows (ids beyond it: no limits)
+    uint32_t value_cap = 1u << 24;   // most distinct descriptor values the dictionary takes (rli_set_value_cap)
     // batch
     std::vector<uint32_t> req_ns, req_delta, ent_off{0}, ent_key, ent_val;
     std::string err;
@@ -246,23 +264,31 @@ int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_
     L.ns = ns;
     L.max_value = max_value;
     L.seconds = seconds;
-    std::set<Cond> cs;
+    std::set<std::string> csrc, vsrc;
     for (uint32_t i = 0; i < n_conditions; ++i) {
-        Cond c;
-        if (!conditions[i] || !parse_condition(conditions[i], &c))
-            return gfail(g, RLI_HOST_ONLY, "condition %u is not `key ==|!= 'value'`: stays on the host", i);
-        cs.insert(c);
+        if (!conditions[i]) return gfail(g, RL_ERR_INVALID, "null condition");
+        csrc.insert(conditions[i]);
     }
-    L.conds.assign(cs.begin(), cs.end());
-    std::set<std::string> vs;
     for (uint32_t i = 0; i < n_variables; ++i) {
-        std::string k;
-        if (!variables[i] || !parse_variable(variables[i], &k))
-            return gfail(g, RLI_HOST_ONLY, "variable %u is not a descriptor key: stays on the host", i);
-        vs.insert(k);
+        if (!variables[i]) return gfail(g, RL_ERR_INVALID, "null variable");
+        vsrc.insert(variables[i]);
     }
-    if (vs.size() > 2) return gfail(g, RLI_HOST_ONLY, "more than two variables: stays on the host");
-    L.vars.assign(vs.begin(), vs.end());
+    L.cond_src.assign(csrc.begin(), csrc.end());
+    L.var_src.assign(vsrc.begin(), vsrc.end());
+    for (const std::string& src : L.cond_src) {
+        Cond c;
+        if (!parse_condition(src, &c, g->binding))
+            return gfail(g, RLI_HOST_ONLY, "condition `%s` is not descriptors[0]['key'] ==|!= 'value': stays on the host",
+                         src.c_str());
+        L.conds.push_back(c);
+    }
+    for (const std::string& src : L.var_src) {
+        std::string k;
+        if (!parse_variable(src, &k, g->binding))
+            return gfail(g, RLI_HOST_ONLY, "variable `%s` is not descriptors[0]['key']: stays on the host", src.c_str());
+        L.vars.push_back(k);
+    }
+    if (L.vars.size() > 2) return gfail(g, RLI_HOST_ONLY, "more than two variables: stays on the host");
     auto it = g->by_identity.find(L.identity());
     if (it != g->by_identity.end()) {  // same limit (limit.rs:177-214): max_value is not identity
         g->limits[it->second].max_value = max_value;
@@ -328,6 +354,7 @@ int32_t rli_install(rli_ingest* g, rl_engine* e) {
     rc = rl_match_table_set(e, g->table.data(), (uint32_t)g->table.size(), g->conds.data(), (uint32_t)g->conds.size(),
                             (uint32_t)g->ns_ids.ids.size());
     if (rc) return gfail(g, rc, "rl_match_table_set: %s", rl_last_error(e));
+    g->n_ns_installed = (uint32_t)g->ns_ids.ids.size();
     for (uint32_t id = 0; id < g->limits.size(); ++id)
         if (g->limits[id].vars.empty()) {  // add_counter, in_memory.rs:38-44: limits without variables only
             rc = rl_add_counter(e, id | RL_SIMPLE, rl_match_key(id, 0, 0, 0));
@@ -345,25 +372,74 @@ void rli_batch_clear(rli_ingest* g) {
     g->ent_val.clear();
 }
 
-int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, const char* const* values,
-                      uint32_t n_entries, uint32_t delta) {
-    if (!g || !ns || (n_entries && (!keys || !values))) return RL_ERR_INVALID;
+// One request, strings given with their lengths (protobuf strings may hold NULs).  Nothing is added unless the
+// whole request is valid: the five batch arrays only ever grow together.
+static int32_t batch_add_sv(rli_ingest* g, const std::string& ns, const std::vector<std::pair<std::string, std::string>>& entries,
+                            uint32_t delta) {
     const int64_t nid = g->ns_ids.find(ns);
-    // a namespace no limit names has no counters (lib.rs:434-440): the empty namespace 0; so does one
-    // interned after the table was installed (its id is beyond the table's namespaces)
-    g->req_ns.push_back(nid < 0 ? 0u : (uint32_t)nid);
-    g->req_delta.push_back(delta);
-    for (uint32_t q = 0; q < n_entries; ++q) {
-        if (!keys[q] || !values[q]) return gfail(g, RL_ERR_INVALID, "null descriptor entry");
-        const int64_t kid = g->key_ids.find(keys[q]);
+    // a namespace no limit names has no counters (lib.rs:434-440): the empty namespace 0; so does one interned
+    // after the table was installed (its id is beyond the table's namespaces)
+    const uint32_t ns_id = (nid < 0 || (g->n_ns_installed && (uint32_t)nid >= g->n_ns_installed)) ? 0u : (uint32_t)nid;
+    // a repeated key keeps its LAST value (the reference collects the entries into a HashMap: server.rs:112-127)
+    std::vector<std::pair<uint32_t, const std::string*>> kv;  // (key id, value)
+    for (const auto& e : entries) {
+        const int64_t kid = g->key_ids.find(e.first);
         if (kid < 0) continue;  // a key no limit reads: it cannot influence any condition or variable
-        const uint32_t v = g->val_ids.intern(values[q]);
-        if (v >> 26) return gfail(g, RL_ERR_INVALID, "more than 2^26 distinct values: restart the dictionary");
-        g->ent_key.push_back((uint32_t)kid);
-        g->ent_val.push_back(v);
+        bool replaced = false;
+        for (auto& q : kv)
+            if (q.first == (uint32_t)kid) {
+                q.second = &e.second;
+                replaced = true;
+            }
+        if (!replaced) kv.emplace_back((uint32_t)kid, &e.second);
+    }
+    std::vector<uint32_t> vids;
+    size_t n_new = 0;
+    for (const auto& q : kv) {
+        const int64_t v = g->val_ids.find(*q.second);
+        if (v < 0) ++n_new;
+        vids.push_back(v < 0 ? 0xFFFFFFFFu : (uint32_t)v);
+    }
+    if (g->val_ids.ids.size() + n_new > (size_t)g->value_cap)
+        // The dictionary is at its cap (attacker-controlled values must not grow host state without bound; the
+        // reference bounds its counters with moka's cache_size, in_memory.rs:205-212).  Only THIS request — it
+        // carries a value never seen before — goes to the host path; requests made of known values go on.
+        return gfail(g, RLI_HOST_ONLY, "value dictionary at its cap of %u: request with a new value stays on the host "
+                                       "(sweep, then rli_create a fresh ingest to restart the dictionary)", g->value_cap);
+    for (size_t q = 0; q < kv.size(); ++q)
+        if (vids[q] == 0xFFFFFFFFu) vids[q] = g->val_ids.intern(*kv[q].second);
+    g->req_ns.push_back(ns_id);
+    g->req_delta.push_back(delta);
+    for (size_t q = 0; q < kv.size(); ++q) {
+        g->ent_key.push_back(kv[q].first);
+        g->ent_val.push_back(vids[q]);
     }
     g->ent_off.push_back((uint32_t)g->ent_key.size());
     return (int32_t)g->req_ns.size() - 1;
+}
+
+int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, const char* const* values,
+                      uint32_t n_entries, uint32_t delta) {
+    if (!g || !ns || (n_entries && (!keys || !values))) return RL_ERR_INVALID;
+    std::vector<std::pair<std::string, std::string>> entries;
+    for (uint32_t q = 0; q < n_entries; ++q) {
+        if (!keys[q] || !values[q]) return gfail(g, RL_ERR_INVALID, "null descriptor entry");
+        entries.emplace_back(keys[q], values[q]);
+    }
+    return batch_add_sv(g, ns, entries, delta);
+}
+
+int32_t rli_set_binding(rli_ingest* g, int32_t binding) {
+    if (!g || (binding != RLI_BIND_DESCRIPTORS && binding != RLI_BIND_ROOT)) return RL_ERR_INVALID;
+    if (!g->limits.empty()) return gfail(g, RL_ERR_INVALID, "the binding is chosen before the first limit is added");
+    g->binding = binding;
+    return RL_OK;
+}
+
+int32_t rli_set_value_cap(rli_ingest* g, uint32_t cap) {
+    if (!g || cap == 0 || cap > (1u << 26)) return RL_ERR_INVALID;  // value ids travel in 26 bits (rl_match_key)
+    g->value_cap = cap;
+    return RL_OK;
 }
 
 int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) {
@@ -392,13 +468,11 @@ int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) {
         }
     }
     if (domain.empty()) return RLI_UNKNOWN_DOMAIN;
-    std::vector<const char*> keys, values;
-    for (const auto& kv : entries) {
-        keys.push_back(kv.first.c_str());
-        values.push_back(kv.second.c_str());
-    }
-    const uint32_t delta = hits_addend == 0 ? 1u : (uint32_t)hits_addend;  // server.rs:131-137
-    return rli_batch_add(g, domain.c_str(), keys.data(), values.data(), (uint32_t)keys.size(), delta);
+    // hits_addend is a uint32 on the wire (a longer varint is truncated by the protobuf runtime), and 0 means 1
+    // (server.rs:131-137)
+    uint32_t delta = (uint32_t)hits_addend;
+    if (delta == 0) delta = 1;
+    return batch_add_sv(g, domain, entries, delta);
 }
 
 uint32_t rli_batch_n_requests(const rli_ingest* g) { return g ? (uint32_t)g->req_ns.size() : 0; }
@@ -413,9 +487,6 @@ int32_t rli_check(rli_ingest* g, rl_engine* e, uint64_t now_us, uint8_t* verdict
     if (!g || !e || !verdict) return RL_ERR_INVALID;
     const uint32_t n = (uint32_t)g->req_ns.size();
     if (!n) return RL_OK;
-    // ids interned after the install are unknown to the table: a namespace maps to the empty one
-    const uint32_t n_ns_installed = (uint32_t)g->ns_ids.ids.size();
-    (void)n_ns_installed;
     uint32_t n_hits = 0;
     const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
                                                 g->req_delta.data(), n, now_us, 0, verdict, limited_limit, nullptr,

@@ -1339,16 +1339,20 @@ int32_t rl_clear(rl_engine* e) {
     return scan_locked<SCAN_CLEAR_SIMPLE>(e, 0, 0, nullptr, 0, nullptr);
 }
 
-int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
-    if (!e) return RL_ERR_INVALID;
+int32_t rl_sweep_expired_rows(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_removed) {
+    if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
     if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
     const u64 before = e->live;
-    int rc = scan_locked<SCAN_SWEEP>(e, 0, now_us, nullptr, 0, nullptr);
+    int rc = scan_locked<SCAN_SWEEP>(e, 0, now_us, out, cap, nullptr);
     if (rc) return rc;
     if (n_removed) *n_removed = before - e->live;
     if (e->tombs > e->cap / 8) return do_compact(e, 0);
     return RL_OK;
+}
+
+int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
+    return rl_sweep_expired_rows(e, now_us, nullptr, 0, n_removed);
 }
 
 int32_t rl_compact(rl_engine* e) {

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void k_scan(Cell* __restrict__ table, u64 cap,
         if (MODE == SCAN_DELETE_LIMIT) kill = live && (limit == arg_limit);
         if (MODE == SCAN_CLEAR_SIMPLE) kill = live && (limit & SIMPLE_FLAG) != 0;
         if (MODE == SCAN_SWEEP) kill = live && !(limit & SIMPLE_FLAG) && (expiry <= now);
-        if (MODE == SCAN_GET || MODE == SCAN_DUMP) {
+        if (MODE == SCAN_SWEEP) emit = kill && out_cap != 0;  // (rl_sweep_expired_rows: the swept cells are reported)
+        if (MODE == SCAN_GET || MODE == SCAN_DUMP || (MODE == SCAN_SWEEP && out_cap != 0)) {
             const u64 bal = __ballot(emit);
             if (out_cap == 0) {
                 if (lane == 0) counted += (u64)__popcll(bal);

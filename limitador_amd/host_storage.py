@@ -57,6 +57,9 @@ def load():
     sig("rls_get_counters", C.c_int32, [p, C.POINTER(RlsLimit), C.c_uint32, EMIT_FN, p])
     sig("rls_delete_counters", C.c_int32, [p, C.POINTER(RlsLimit), C.c_uint32])
     sig("rls_clear", C.c_int32, [p])
+    sig("rls_sweep_expired", C.c_int32, [p, C.POINTER(C.c_uint64)])
+    sig("rls_set_sweep_after", None, [p, C.c_uint64])
+    sig("rls_interned_counters", C.c_uint64, [p])
     sig("rls_check_and_update_repeat", C.c_int32, [p, C.POINTER(RlsCounter), C.c_uint32, C.c_uint64, C.c_uint32,
                                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)])
     sig("rls_batcher_create", C.c_int32, [p, C.c_uint32, C.c_uint32, C.POINTER(p)])
@@ -199,6 +202,17 @@ class HostStorage:
 
     def clear(self):
         self._check(self._so.rls_clear(self._h))
+
+    def sweep_expired(self):
+        n = C.c_uint64()
+        self._check(self._so.rls_sweep_expired(self._h, C.byref(n)))
+        return n.value
+
+    def set_sweep_after(self, n_new_counters):
+        self._so.rls_set_sweep_after(self._h, int(n_new_counters))
+
+    def interned_counters(self):
+        return self._so.rls_interned_counters(self._h)
 
     def batcher_stats(self):
         b, r = C.c_uint64(), C.c_uint64()

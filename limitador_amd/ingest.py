@@ -35,6 +35,8 @@ def _lib():
         "rli_batch_clear": (None, [p]),
         "rli_batch_add": (i32, [p, cp, strs, strs, u32, u32]),
         "rli_batch_add_rls": (i32, [p, C.c_char_p, u32]),
+        "rli_set_binding": (i32, [p, i32]),
+        "rli_set_value_cap": (i32, [p, u32]),
         "rli_batch_n_requests": (u32, [p]),
         "rli_batch_n_entries": (u32, [p]),
         "rli_batch_req_ns": (p, [p]),
@@ -76,13 +78,18 @@ class IngestError(RuntimeError):
 
 
 class Ingest:
-    def __init__(self):
+    def __init__(self, binding="descriptors", value_cap=None):
+        """binding: what the caller's Context binds — "descriptors" (the transports: only the list `descriptors`)
+        or "root" (library callers, Context::from(HashMap): every key a root variable)."""
         self._so = _lib()
         h = C.c_void_p()
         rc = SYMBOLS["rli_create"](C.byref(h))
         if rc:
             raise IngestError(rc, "rli_create failed")
         self._h = h
+        self._check(SYMBOLS["rli_set_binding"](self._h, {"descriptors": 0, "root": 1}[binding]))
+        if value_cap is not None:
+            self._check(SYMBOLS["rli_set_value_cap"](self._h, int(value_cap)))
 
     def close(self):
         if self._h:
@@ -125,15 +132,15 @@ class Ingest:
     def batch_add(self, namespace, entries, delta=1):
         """entries: the (key, value) pairs of descriptors[0], in order."""
         keys, vals = [k for k, _ in entries], [v for _, v in entries]
-        return self._check(SYMBOLS["rli_batch_add"](self._h, namespace.encode(), _strs(keys), _strs(vals), len(keys),
-                                                    int(delta)))
+        rc = SYMBOLS["rli_batch_add"](self._h, namespace.encode(), _strs(keys), _strs(vals), len(keys), int(delta))
+        return HOST_ONLY if rc == HOST_ONLY else self._check(rc)  # HOST_ONLY: the value dictionary is at its cap
 
     def batch_add_rls(self, message):
         """message: one serialized envoy.service.ratelimit.v3.RateLimitRequest.
         -> request index, or UNKNOWN_DOMAIN (the reference answers Code::Unknown)."""
         rc = SYMBOLS["rli_batch_add_rls"](self._h, bytes(message), len(message))
-        if rc == UNKNOWN_DOMAIN:
-            return UNKNOWN_DOMAIN
+        if rc in (UNKNOWN_DOMAIN, HOST_ONLY):
+            return rc
         return self._check(rc)
 
     def batch(self):

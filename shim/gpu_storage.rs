@@ -1,0 +1,646 @@
+//! `limitador/src/storage/gpu.rs` — `GpuStorage`, a `CounterStorage` backed by the MI355X counter
+//! engine (`librl_engine.so`, C ABI in `include/rl_engine.h`).
+//!
+//! This file is the reference-side half of the drop-in boundary.  It is written against the reference
+//! tree as of `/root/reference` (`limitador/src/storage/mod.rs:279-339`, `counter.rs`, `limit.rs`) and is
+//! meant to be dropped in as `limitador/src/storage/gpu.rs` behind a cargo feature:
+//!
+//! ```toml
+//! # limitador/Cargo.toml
+//! [features]
+//! gpu_storage = []
+//! ```
+//! ```rust,ignore
+//! // limitador/src/storage/mod.rs, next to the other backends (mod.rs:10-24)
+//! #[cfg(feature = "gpu_storage")]
+//! pub mod gpu;
+//! ```
+//! ```rust,ignore
+//! // limitador/build.rs
+//! #[cfg(feature = "gpu_storage")]
+//! {
+//!     println!("cargo:rustc-link-search=native={}", std::env::var("RL_ENGINE_LIB_DIR").unwrap());
+//!     println!("cargo:rustc-link-lib=dylib=rl_engine");
+//! }
+//! ```
+//! and installed with `RateLimiter::new_with_storage(Box::new(GpuStorage::new(1 << 25, 1 << 16)?))`
+//! (`lib.rs:330-334`).  It lives INSIDE the crate because `StorageErr` has private fields and no public
+//! constructor (`storage/mod.rs:312-339`): like `disk/mod.rs:9-18` it builds the error in place.
+//!
+//! It could not be compiled in the build environment of this repository (no rustc / cargo there); the
+//! same logic — identity interning, counter order, result mapping, micro-batching — is what
+//! `limitador_amd/csrc/host/gpu_counter_storage.cpp` implements in C++ and what the GPU tests run the
+//! reference's scenarios through (`tests/test_gpu_host_mirror.py`).
+//!
+//! What it does per call:
+//!   * interns the identity of a `Limit` (namespace, seconds, conditions, variables — `limit.rs:177-214`;
+//!     `Limit`'s own `Hash`/`Eq`) to a dense `u32` limit id, and the identity of a `Counter` (limit identity
+//!     + `set_variables`, `counter.rs:123-138`) to an exact `u64` key: no hashing of identities, no
+//!     fingerprint collisions;
+//!   * keeps the request-side attributes the reference reads from `Counter.limit` (`max_value`, `seconds`;
+//!     `counter.rs:64-66,76-78`) in the engine's limit table (`rl_limits_set`), following the caller when
+//!     `max_value` changes (pinned by `lib.rs:760-790`);
+//!   * orders a request's counters like `in_memory.rs:105,121` (counters of limits without variables first);
+//!   * aggregates concurrent `check_and_update` callers into one device batch (`max_batch` requests or
+//!     `max_delay`, whichever comes first): a batch is applied exactly like the reference applied to its
+//!     requests one after another, with one clock value for the batch.
+
+use crate::counter::Counter;
+use crate::limit::Limit;
+use crate::storage::{Authorization, CounterStorage, StorageErr};
+use std::collections::{BTreeMap, HashMap, HashSet};
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int};
+use std::sync::{Arc, Condvar, Mutex};
+use std::time::{Duration, Instant, SystemTime, UNIX_EPOCH};
+
+// ---- include/rl_engine.h ------------------------------------------------------------------------
+#[repr(C)]
+struct RlEngine {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+struct RlConfig {
+    device: i32,
+    max_batch_hits: u32,
+    capacity_cells: u64,
+    max_limits: u32,
+    flags: u32,
+    hash_seed: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+struct RlLimitRow {
+    max_value: u64,
+    seconds: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+struct RlHit {
+    key: u64,
+    limit: u32,
+    delta: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+struct RlCellRow {
+    key: u64,
+    limit: u32,
+    reserved: u32,
+    value: u64,
+    expiry_us: u64,
+}
+
+const RL_OK: i32 = 0;
+const RL_SIMPLE: u32 = 0x8000_0000;
+const RL_CFG_AUTO_GROW: u32 = 1;
+
+extern "C" {
+    fn rl_engine_create(cfg: *const RlConfig, out: *mut *mut RlEngine) -> i32;
+    fn rl_engine_destroy(e: *mut RlEngine);
+    fn rl_last_error(e: *const RlEngine) -> *const c_char;
+    fn rl_status_is_transient(status: i32) -> i32;
+    fn rl_limits_set(e: *mut RlEngine, first: u32, rows: *const RlLimitRow, n: u32) -> i32;
+    fn rl_add_counter(e: *mut RlEngine, limit: u32, key: u64) -> i32;
+    #[allow(clippy::too_many_arguments)]
+    fn rl_check_and_update_batch_ex(
+        e: *mut RlEngine,
+        hits: *const RlHit,
+        n_hits: u32,
+        req_off: *const u32,
+        n_req: u32,
+        req_delta: *const u64,
+        req_now_us: *const u64,
+        now_us: u64,
+        load_counters: i32,
+        verdict: *mut u8,
+        first_limited: *mut i32,
+        remaining: *mut u64,
+        expires_in_us: *mut u64,
+    ) -> i32;
+    fn rl_is_within_limits_batch_ex(
+        e: *mut RlEngine,
+        hits: *const RlHit,
+        n_hits: u32,
+        delta: *const u64,
+        now_us: u64,
+        within: *mut u8,
+    ) -> i32;
+    fn rl_update_counter_batch_ex(e: *mut RlEngine, hits: *const RlHit, n_hits: u32, delta: *const u64, now_us: u64) -> i32;
+    fn rl_get_counters(e: *mut RlEngine, limit: u32, now_us: u64, out: *mut RlCellRow, cap: u64, n_out: *mut u64) -> i32;
+    fn rl_delete_counters(e: *mut RlEngine, limit: u32) -> i32;
+    fn rl_clear(e: *mut RlEngine) -> i32;
+    fn rl_sweep_expired(e: *mut RlEngine, now_us: u64, n_removed: *mut u64) -> i32;
+}
+
+// ---- errors ---------------------------------------------------------------------------------------
+/// An `rl_status` with the engine's message; becomes a `StorageErr` (`storage/mod.rs:312-339`).
+#[derive(Debug)]
+pub struct GpuEngineError {
+    pub status: i32,
+    pub message: String,
+}
+
+impl std::fmt::Display for GpuEngineError {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "rl_engine status {}: {}", self.status, self.message)
+    }
+}
+
+impl std::error::Error for GpuEngineError {}
+
+impl From<GpuEngineError> for StorageErr {
+    fn from(error: GpuEngineError) -> Self {
+        // RL_ERR_DEVICE / RL_ERR_BUSY are worth a retry (rl_status_is_transient)
+        let transient = unsafe { rl_status_is_transient(error.status) } != 0;
+        Self {
+            msg: format!("GPU counter engine error: {error}"),
+            source: Some(Box::new(error)),
+            transient,
+        }
+    }
+}
+
+// ---- identity interning -----------------------------------------------------------------------------
+struct Interner {
+    /// Limit identity -> limit id (`Limit`'s Hash/Eq ignore max_value, name and id: limit.rs:177-214)
+    limit_ids: HashMap<Arc<Limit>, u32>,
+    /// id -> the Limit as last seen (its max_value / name may change without a new identity) + its table row
+    limits: Vec<(Arc<Limit>, RlLimitRow)>,
+    /// Counter identity -> exact u64 key
+    counter_keys: HashMap<(u32, BTreeMap<String, String>), u64>,
+    /// key -> the counter's variables (get_counters rebuilds `Counter`s from the engine's rows)
+    by_key: HashMap<u64, BTreeMap<String, String>>,
+    key_seq: u64,
+}
+
+impl Interner {
+    fn new() -> Self {
+        Self {
+            limit_ids: HashMap::new(),
+            limits: Vec::new(),
+            counter_keys: HashMap::new(),
+            by_key: HashMap::new(),
+            key_seq: 0,
+        }
+    }
+
+    /// (limit id, row changed?) — a new identity gets the next dense id; a known one follows the caller's
+    /// max_value (Storage::update_limit, storage/mod.rs:67-83) and name.
+    fn limit_id(&mut self, limit: &Limit) -> (u32, bool) {
+        if let Some(&id) = self.limit_ids.get(limit) {
+            let entry = &mut self.limits[id as usize];
+            let mut changed = false;
+            if entry.1.max_value != limit.max_value() {
+                entry.1.max_value = limit.max_value();
+                changed = true;
+            }
+            if entry.0.max_value() != limit.max_value() || entry.0.name() != limit.name() {
+                entry.0 = Arc::new(limit.clone());
+            }
+            return (id, changed);
+        }
+        let id = self.limits.len() as u32;
+        let arc = Arc::new(limit.clone());
+        self.limit_ids.insert(Arc::clone(&arc), id);
+        self.limits.push((
+            arc,
+            RlLimitRow {
+                max_value: limit.max_value(),
+                seconds: limit.seconds(),
+            },
+        ));
+        (id, true)
+    }
+
+    fn counter_key(&mut self, limit_id: u32, vars: &BTreeMap<String, String>) -> u64 {
+        if let Some(&k) = self.counter_keys.get(&(limit_id, vars.clone())) {
+            return k;
+        }
+        // exact and collision-free: a dense sequence number, scrambled by an odd multiplier (a bijection on
+        // u64) so that table slots spread out; the engine's two reserved tags are skipped
+        let key = loop {
+            self.key_seq += 1;
+            let k = self.key_seq.wrapping_mul(0x9E37_79B9_7F4A_7C15);
+            if k < 0xFFFF_FFFF_FFFF_FFFE {
+                break k;
+            }
+        };
+        self.counter_keys.insert((limit_id, vars.clone()), key);
+        self.by_key.insert(key, vars.clone());
+        key
+    }
+}
+
+// ---- micro-batching of check_and_update -----------------------------------------------------------------
+struct Pending {
+    hits: Vec<RlHit>,
+    /// position in the caller's Vec<Counter> of every hit (counters are reordered: simple first)
+    order: Vec<usize>,
+    delta: u64,
+    load_counters: bool,
+    result: Option<Result<Answer, GpuEngineError>>,
+}
+
+struct Answer {
+    limited: bool,
+    /// index into the caller's Vec<Counter> of the first limited counter
+    first_limited: Option<usize>,
+    /// per hit, in `order`: (remaining, expires_in_us) when load_counters
+    loaded: Vec<(u64, u64)>,
+}
+
+struct BatchQueue {
+    pending: Vec<(u64, Pending)>, // ticket, request
+    done: HashMap<u64, Pending>,
+    next_ticket: u64,
+    leader_active: bool,
+    first_arrival: Option<Instant>,
+}
+
+/// `CounterStorage` on the MI355X engine.
+pub struct GpuStorage {
+    engine: *mut RlEngine,
+    interner: Mutex<Interner>,
+    queue: Mutex<BatchQueue>,
+    queue_cv: Condvar,
+    /// serialises engine calls that are not batched (the engine has its own mutex too; this one keeps the
+    /// interner and the engine's limit table in step)
+    call: Mutex<()>,
+    max_batch: usize,
+    max_delay: Duration,
+}
+
+// The engine handle is only used under `call` / by the batch leader; the engine itself is thread-safe.
+unsafe impl Send for GpuStorage {}
+unsafe impl Sync for GpuStorage {}
+
+impl GpuStorage {
+    /// `capacity_cells`: table slots (replaces moka's `cache_size`, in_memory.rs:205-212; the table grows
+    /// instead of evicting); `max_batch`: most requests one device batch aggregates.
+    pub fn new(capacity_cells: u64, max_batch: usize) -> Result<Self, StorageErr> {
+        Self::with_options(capacity_cells, max_batch, Duration::from_micros(200), 0)
+    }
+
+    pub fn with_options(capacity_cells: u64, max_batch: usize, max_delay: Duration, device: i32) -> Result<Self, StorageErr> {
+        let cfg = RlConfig {
+            device,
+            max_batch_hits: (max_batch.max(1) * 32) as u32, // up to 32 counters per request
+            capacity_cells,
+            max_limits: 4096,
+            flags: RL_CFG_AUTO_GROW, // the reference's storage never refuses a counter
+            hash_seed: 0x9E37_79B9_7F4A_7C15,
+        };
+        let mut engine: *mut RlEngine = std::ptr::null_mut();
+        let rc = unsafe { rl_engine_create(&cfg, &mut engine) };
+        if rc != RL_OK {
+            return Err(GpuEngineError {
+                status: rc,
+                message: "rl_engine_create failed (no MI355X visible? the engine has no CPU path)".into(),
+            }
+            .into());
+        }
+        Ok(Self {
+            engine,
+            interner: Mutex::new(Interner::new()),
+            queue: Mutex::new(BatchQueue {
+                pending: Vec::new(),
+                done: HashMap::new(),
+                next_ticket: 0,
+                leader_active: false,
+                first_arrival: None,
+            }),
+            queue_cv: Condvar::new(),
+            call: Mutex::new(()),
+            max_batch: max_batch.max(1),
+            max_delay,
+        })
+    }
+
+    /// Drop every qualified cell whose window has ended (no reference analogue: it stands in for moka's
+    /// capacity eviction, in_memory.rs:208-210, and never changes a decision of an unexpired counter).
+    pub fn sweep_expired(&self) -> Result<u64, StorageErr> {
+        let _g = self.call.lock().unwrap();
+        let mut removed = 0u64;
+        self.check(unsafe { rl_sweep_expired(self.engine, now_us(), &mut removed) })?;
+        Ok(removed)
+    }
+
+    fn check(&self, rc: i32) -> Result<(), GpuEngineError> {
+        if rc == RL_OK {
+            return Ok(());
+        }
+        let message = unsafe { CStr::from_ptr(rl_last_error(self.engine)) }.to_string_lossy().into_owned();
+        Err(GpuEngineError { status: rc, message })
+    }
+
+    /// Interns the counter and returns its wire record; uploads the limit row when it is new or changed.
+    fn hit_of(&self, interner: &mut Interner, counter: &Counter, delta: u64) -> Result<RlHit, GpuEngineError> {
+        let (id, row_changed) = interner.limit_id(counter.limit());
+        if row_changed {
+            let row = interner.limits[id as usize].1;
+            self.check(unsafe { rl_limits_set(self.engine, id, &row, 1) })?;
+        }
+        let key = interner.counter_key(id, counter.set_variables());
+        Ok(RlHit {
+            key,
+            limit: id | if counter.is_qualified() { 0 } else { RL_SIMPLE },
+            // the 32-bit wire field; a delta beyond it travels in the call's u64 delta array
+            delta: delta.min(u32::MAX as u64) as u32,
+        })
+    }
+
+    /// One device batch for `batch` (all with the same load_counters flag), results stored in place.
+    fn run_batch(&self, batch: &mut [(u64, Pending)]) {
+        let load = batch[0].1.load_counters;
+        let mut hits: Vec<RlHit> = Vec::new();
+        let mut off: Vec<u32> = vec![0];
+        let mut deltas: Vec<u64> = Vec::new();
+        for (_, p) in batch.iter() {
+            hits.extend_from_slice(&p.hits);
+            off.push(hits.len() as u32);
+            deltas.push(p.delta);
+        }
+        let n_req = batch.len();
+        let mut verdict = vec![0u8; n_req];
+        let mut first = vec![-1i32; n_req];
+        let mut rem = vec![0u64; if load { hits.len() } else { 0 }];
+        let mut exp = vec![0u64; if load { hits.len() } else { 0 }];
+        let big_delta = deltas.iter().any(|&d| d > u32::MAX as u64);
+        let rc = {
+            let _g = self.call.lock().unwrap();
+            unsafe {
+                rl_check_and_update_batch_ex(
+                    self.engine,
+                    hits.as_ptr(),
+                    hits.len() as u32,
+                    off.as_ptr(),
+                    n_req as u32,
+                    if big_delta { deltas.as_ptr() } else { std::ptr::null() },
+                    std::ptr::null(),
+                    now_us(),
+                    load as c_int,
+                    verdict.as_mut_ptr(),
+                    first.as_mut_ptr(),
+                    if load { rem.as_mut_ptr() } else { std::ptr::null_mut() },
+                    if load { exp.as_mut_ptr() } else { std::ptr::null_mut() },
+                )
+            }
+        };
+        let outcome = self.check(rc);
+        for (q, (_, p)) in batch.iter_mut().enumerate() {
+            p.result = Some(match &outcome {
+                Err(e) => Err(GpuEngineError {
+                    status: e.status,
+                    message: e.message.clone(),
+                }),
+                Ok(()) => {
+                    let base = off[q] as usize;
+                    Ok(Answer {
+                        limited: verdict[q] != 0,
+                        first_limited: if verdict[q] != 0 {
+                            Some(p.order[first[q] as usize - base])
+                        } else {
+                            None
+                        },
+                        loaded: if load {
+                            (0..p.hits.len()).map(|j| (rem[base + j], exp[base + j])).collect()
+                        } else {
+                            Vec::new()
+                        },
+                    })
+                }
+            });
+        }
+    }
+
+    /// Enqueue one request and wait for its answer.  The first caller to find no leader becomes the leader:
+    /// it waits until the batch is full or `max_delay` has passed since the first arrival, takes the whole
+    /// queue (requests stay in arrival order), runs it as consecutive device batches that share the
+    /// load_counters flag, and wakes everybody up.
+    fn submit(&self, pending: Pending) -> Result<Answer, GpuEngineError> {
+        let mut q = self.queue.lock().unwrap();
+        let ticket = q.next_ticket;
+        q.next_ticket += 1;
+        if q.pending.is_empty() {
+            q.first_arrival = Some(Instant::now());
+        }
+        q.pending.push((ticket, pending));
+        self.queue_cv.notify_all();
+        loop {
+            if let Some(mut p) = q.done.remove(&ticket) {
+                return p.result.take().expect("answered request");
+            }
+            if !q.leader_active && !q.pending.is_empty() {
+                q.leader_active = true;
+                // close the batch: full, or max_delay after its first request arrived
+                loop {
+                    let waited = q.first_arrival.map(|t| t.elapsed()).unwrap_or_default();
+                    if q.pending.len() >= self.max_batch || waited >= self.max_delay {
+                        break;
+                    }
+                    let (guard, _) = self.queue_cv.wait_timeout(q, self.max_delay - waited).unwrap();
+                    q = guard;
+                }
+                let mut batch: Vec<(u64, Pending)> = std::mem::take(&mut q.pending);
+                q.first_arrival = None;
+                drop(q);
+                // runs of equal load_counters (a property of the whole engine call), at most max_batch each
+                let mut start = 0;
+                while start < batch.len() {
+                    let load = batch[start].1.load_counters;
+                    let mut end = start + 1;
+                    while end < batch.len() && end - start < self.max_batch && batch[end].1.load_counters == load {
+                        end += 1;
+                    }
+                    self.run_batch(&mut batch[start..end]);
+                    start = end;
+                }
+                q = self.queue.lock().unwrap();
+                for (t, p) in batch {
+                    q.done.insert(t, p);
+                }
+                q.leader_active = false;
+                self.queue_cv.notify_all();
+                continue;
+            }
+            q = self.queue_cv.wait(q).unwrap();
+        }
+    }
+}
+
+impl Drop for GpuStorage {
+    fn drop(&mut self) {
+        unsafe { rl_engine_destroy(self.engine) };
+    }
+}
+
+fn now_us() -> u64 {
+    // SystemTime::now().duration_since(UNIX_EPOCH) in microseconds: atomic_expiring_value.rs:62-66
+    SystemTime::now().duration_since(UNIX_EPOCH).map(|d| d.as_micros() as u64).unwrap_or(0)
+}
+
+impl CounterStorage for GpuStorage {
+    // in_memory.rs:20-35
+    fn is_within_limits(&self, counter: &Counter, delta: u64) -> Result<bool, StorageErr> {
+        let hit = {
+            let mut interner = self.interner.lock().unwrap();
+            self.hit_of(&mut interner, counter, delta)?
+        };
+        let mut within = 0u8;
+        let _g = self.call.lock().unwrap();
+        self.check(unsafe {
+            rl_is_within_limits_batch_ex(
+                self.engine,
+                &hit,
+                1,
+                if delta > u32::MAX as u64 { &delta } else { std::ptr::null() },
+                now_us(),
+                &mut within,
+            )
+        })?;
+        Ok(within != 0)
+    }
+
+    // in_memory.rs:38-44: only limits without variables get a cell up front, (0, UNIX_EPOCH)
+    fn add_counter(&self, limit: &Limit) -> Result<(), StorageErr> {
+        let mut interner = self.interner.lock().unwrap();
+        let (id, row_changed) = interner.limit_id(limit);
+        if row_changed {
+            let row = interner.limits[id as usize].1;
+            self.check(unsafe { rl_limits_set(self.engine, id, &row, 1) })?;
+        }
+        if !limit.variables().is_empty() {
+            return Ok(());
+        }
+        let key = interner.counter_key(id, &BTreeMap::new());
+        let _g = self.call.lock().unwrap();
+        self.check(unsafe { rl_add_counter(self.engine, id | RL_SIMPLE, key) })?;
+        Ok(())
+    }
+
+    // in_memory.rs:47-69
+    fn update_counter(&self, counter: &Counter, delta: u64) -> Result<(), StorageErr> {
+        let hit = {
+            let mut interner = self.interner.lock().unwrap();
+            self.hit_of(&mut interner, counter, delta)?
+        };
+        let _g = self.call.lock().unwrap();
+        self.check(unsafe {
+            rl_update_counter_batch_ex(
+                self.engine,
+                &hit,
+                1,
+                if delta > u32::MAX as u64 { &delta } else { std::ptr::null() },
+                now_us(),
+            )
+        })?;
+        Ok(())
+    }
+
+    // in_memory.rs:72-156
+    fn check_and_update(
+        &self,
+        counters: &mut Vec<Counter>,
+        delta: u64,
+        load_counters: bool,
+    ) -> Result<Authorization, StorageErr> {
+        if counters.is_empty() {
+            return Ok(Authorization::Ok); // (the façade short-circuits before the storage: lib.rs:434-440)
+        }
+        // counters of limits without variables first, then the qualified ones, each in Vec order
+        // (in_memory.rs:105,121)
+        let mut order: Vec<usize> = (0..counters.len()).filter(|&i| !counters[i].is_qualified()).collect();
+        order.extend((0..counters.len()).filter(|&i| counters[i].is_qualified()));
+        let hits = {
+            let mut interner = self.interner.lock().unwrap();
+            let mut hits = Vec::with_capacity(order.len());
+            for &i in &order {
+                hits.push(self.hit_of(&mut interner, &counters[i], delta)?);
+            }
+            hits
+        };
+        let answer = self.submit(Pending {
+            hits,
+            order: order.clone(),
+            delta,
+            load_counters,
+            result: None,
+        })?;
+        if load_counters {
+            for (j, &i) in order.iter().enumerate() {
+                let (remaining, expires_in_us) = answer.loaded[j];
+                counters[i].set_remaining(remaining); // counter.rs:96-106
+                counters[i].set_expires_in(Duration::from_micros(expires_in_us));
+            }
+        }
+        Ok(if answer.limited {
+            // the name of the first limited counter's limit (in_memory.rs:91-93,97-99)
+            let i = answer.first_limited.expect("a limited request names its counter");
+            Authorization::Limited(counters[i].limit().name().map(|n| n.to_owned()))
+        } else {
+            Authorization::Ok
+        })
+    }
+
+    // in_memory.rs:159-187: every counter of the limits in the set whose ttl is > 0
+    fn get_counters(&self, limits: &HashSet<Arc<Limit>>) -> Result<HashSet<Counter>, StorageErr> {
+        let mut res = HashSet::new();
+        let interner = self.interner.lock().unwrap();
+        let _g = self.call.lock().unwrap();
+        let now = now_us();
+        for limit in limits {
+            let Some(&id) = interner.limit_ids.get(limit.as_ref()) else {
+                continue; // never seen: no counters
+            };
+            let wire = id | if limit.variables().is_empty() { RL_SIMPLE } else { 0 };
+            let mut n = 0u64;
+            self.check(unsafe { rl_get_counters(self.engine, wire, now, std::ptr::null_mut(), 0, &mut n) })?;
+            let mut rows = vec![RlCellRow::default(); n as usize];
+            if n > 0 {
+                self.check(unsafe { rl_get_counters(self.engine, wire, now, rows.as_mut_ptr(), n, &mut n) })?;
+                rows.truncate(n as usize);
+            }
+            for row in rows {
+                let vars: HashMap<String, String> = interner
+                    .by_key
+                    .get(&row.key)
+                    .map(|m| m.iter().map(|(k, v)| (k.clone(), v.clone())).collect())
+                    .unwrap_or_default();
+                let mut counter = Counter::resolved_vars(Arc::clone(limit), vars).map_err(|e| GpuEngineError {
+                    status: -1,
+                    message: format!("cannot rebuild counter: {e}"),
+                })?;
+                // `max_value - value`, unchecked in the reference (in_memory.rs:166,178): wraps in release
+                counter.set_remaining(limit.max_value().wrapping_sub(row.value));
+                counter.set_expires_in(Duration::from_micros(row.expiry_us)); // ttl(now) > 0
+                res.insert(counter);
+            }
+        }
+        Ok(res)
+    }
+
+    // in_memory.rs:190-195,241-257
+    fn delete_counters(&self, limits: &HashSet<Arc<Limit>>) -> Result<(), StorageErr> {
+        let interner = self.interner.lock().unwrap();
+        let _g = self.call.lock().unwrap();
+        for limit in limits {
+            if let Some(&id) = interner.limit_ids.get(limit.as_ref()) {
+                let wire = id | if limit.variables().is_empty() { RL_SIMPLE } else { 0 };
+                self.check(unsafe { rl_delete_counters(self.engine, wire) })?;
+            }
+        }
+        Ok(())
+    }
+
+    // in_memory.rs:198-201: the reference clears only the limits without variables — so does the engine
+    fn clear(&self) -> Result<(), StorageErr> {
+        let _g = self.call.lock().unwrap();
+        self.check(unsafe { rl_clear(self.engine) })?;
+        Ok(())
+    }
+}

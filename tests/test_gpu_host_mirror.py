@@ -85,3 +85,36 @@ def test_a_delta_beyond_32_bits_is_answered_like_the_reference(host):
     host.update_counter(*huge, (1 << 40))
     limited, _idx, out = host.check_and_update([huge], 1, True)
     assert not limited and out[0][0] == (1 << 63) - ((1 << 62) + 5 + (1 << 40) + 1)
+
+
+def test_the_mirror_forgets_the_identities_of_swept_counters(host):
+    """Descriptor values are caller-controlled: the interning tables must not grow without bound.  A TTL sweep
+    (on its own every `sweep_after` new counters, or explicit) drops the expired qualified cells and their
+    interned identities; a counter that comes back afterwards starts from a fresh cell, like after a moka
+    eviction in the reference."""
+    t0 = 1_700_000_000_000_000
+    host.set_clock(t0)
+    host.set_sweep_after(0)
+    lim = ("ns", 3, 1, (), ("u",), None)
+    for i in range(500):
+        limited, _i, _l = host.check_and_update([(lim, (("u", f"user{i}"),))], 1, False)
+        assert not limited
+    assert host.interned_counters() == 500
+    host.set_clock(t0 + 2_000_000)  # every 1-second window has ended
+    assert host.sweep_expired() == 500
+    assert host.interned_counters() == 0
+    # automatic: once 100 new counters have been interned since the last sweep, the next call sweeps first
+    host.set_sweep_after(100)
+    for i in range(150):  # (the sweep after the 100th finds nothing expired yet)
+        host.check_and_update([(lim, (("u", f"again{i}"),))], 1, False)
+    assert host.interned_counters() == 150
+    host.set_clock(t0 + 5_000_000)  # their windows have ended
+    for i in range(101):
+        host.check_and_update([(lim, (("u", f"third{i}"),))], 1, False)
+    assert host.interned_counters() == 101  # the 150 expired ones are gone
+    # a swept counter starts over
+    for _ in range(3):
+        limited, _i, _l = host.check_and_update([(lim, (("u", "again0"),))], 1, False)
+        assert not limited
+    limited, _i, _l = host.check_and_update([(lim, (("u", "again0"),))], 1, False)
+    assert limited

@@ -188,7 +188,7 @@ def test_cpp_ingest_drives_the_device_matcher(make_engine):
     rng = np.random.default_rng(41)
     namespaces = ["ns0", "ns1", "ns2"]
     limits = random_limits(rng, namespaces)
-    g = Ingest()
+    g = Ingest(binding="root")  # the helpers' limits and contexts are the library's: bare identifiers, a HashMap
     for l in limits:
         assert g.add_limit(l.namespace, l.max_value, l.seconds, list(l.conditions), list(l.variables)) >= 0
     t = g.compile()

@@ -20,32 +20,83 @@ def ingest(engine_lib):
 
 
 def test_condition_and_variable_shapes(ingest):
+    """RLI_BIND_DESCRIPTORS (the default: what both transports bind, envoy_rls/server.rs:136-137): only
+    `descriptors[0]['k']` and `descriptors[0].ident` reach the request's strings; identity is on the source text
+    (limit.rs:177-214: Predicate / Expression compare by source)."""
     from limitador_amd.ingest import HOST_ONLY
 
     g = ingest
     a = g.add_limit("ns", 10, 60, ["descriptors[0]['req.method'] == 'GET'", "descriptors[0]['req.path'] != '/json'"],
                     ["descriptors[0]['user_id']"])
     assert a == 0
-    # the same identity in the other spellings: same limit (conditions and variables are sets), max_value refreshed
-    assert g.add_limit("ns", 99, 60, ['descriptors[0].req.path != "/json"', "req.method == 'GET'"], ["user_id"]) == 0
-    assert g.add_limit("ns", 10, 61, ["req.method == 'GET'", "req.path != '/json'"], ["user_id"]) == 1  # seconds IS identity
-    assert g.add_limit("other", 5, 1) == 2
+    # the same sources again (conditions and variables are sets): same limit, max_value refreshed
+    assert g.add_limit("ns", 99, 60, ["descriptors[0]['req.path'] != '/json'", "descriptors[0]['req.method'] == 'GET'",
+                                      "descriptors[0]['req.method'] == 'GET'"], ["descriptors[0]['user_id']"]) == 0
+    # another SPELLING of the same predicate is another limit with its own counters, like in the reference
+    assert g.add_limit("ns", 10, 60, ['descriptors[0]["req.method"] == "GET"', "descriptors[0]['req.path'] != '/json'"],
+                       ["descriptors[0].user_id"]) == 1
+    assert g.add_limit("ns", 10, 61, ["descriptors[0]['req.method'] == 'GET'", "descriptors[0]['req.path'] != '/json'"],
+                       ["descriptors[0]['user_id']"]) == 2  # seconds IS identity
+    assert g.add_limit("other", 5, 1) == 3
+    # unbound under this Context: the reference never applies such a limit; not restated on the device
+    assert g.add_limit("ns", 1, 1, ["x == '1'"]) == HOST_ONLY
+    assert g.add_limit("ns", 1, 1, ["req.method == 'GET'"]) == HOST_ONLY
+    assert g.add_limit("ns", 1, 1, [], ["user_id"]) == HOST_ONLY
+    # nested member access is not the key "req.path"
+    assert g.add_limit("ns", 1, 1, ["descriptors[0].req.path == '/json'"]) == HOST_ONLY
     # CEL the device matcher does not evaluate stays with the caller
     assert g.add_limit("ns", 1, 1, ["descriptors[0]['a'] == descriptors[0]['b']"]) == HOST_ONLY
     assert g.add_limit("ns", 1, 1, ["descriptors[1]['a'] == '1'"]) == HOST_ONLY
-    assert g.add_limit("ns", 1, 1, ["a.startsWith('x')"]) == HOST_ONLY
-    assert g.add_limit("ns", 1, 1, [], ["a", "b", "c"]) == HOST_ONLY
+    assert g.add_limit("ns", 1, 1, ["descriptors[0].a.startsWith('x')"]) == HOST_ONLY
+    assert g.add_limit("ns", 1, 1, [], ["descriptors[0].a", "descriptors[0].b", "descriptors[0].c"]) == HOST_ONLY
     t = g.compile()
-    assert t["limit_rows"]["max_value"].tolist() == [99, 10, 5] and t["limit_rows"]["seconds"].tolist() == [60, 61, 1]
+    assert t["limit_rows"]["max_value"].tolist() == [99, 10, 10, 5] and t["limit_rows"]["seconds"].tolist() == [60, 60, 61, 1]
     assert t["n_namespaces"] == 3  # "", ns, other
     lim = t["limits"]
     assert lim["ns"].tolist() == sorted(lim["ns"].tolist()) and 0 not in lim["ns"].tolist()
     assert (lim["limit"][lim["n_vars"] == 0] & RL_SIMPLE).all() and not (lim["limit"][lim["n_vars"] > 0] & RL_SIMPLE).any()
-    assert len(t["conds"]) == 4
+    assert len(t["conds"]) == 6
 
 
-def test_requests_are_encoded_exactly(ingest):
-    g = ingest
+def test_root_binding_takes_bare_identifiers_only(engine_lib):
+    """RLI_BIND_ROOT: library callers' Context::from(HashMap) binds every key as a root variable
+    (limit/cel.rs:81-96,153-156) — what limit.rs:239-348 tests with."""
+    from limitador_amd.ingest import HOST_ONLY, Ingest
+
+    g = Ingest(binding="root")
+    assert g.add_limit("ns", 10, 60, ["x == '5'"], ["y"]) == 0
+    assert g.add_limit("ns", 10, 60, ["x == '5'", "x == '5'"], ["y"]) == 0
+    assert g.add_limit("ns", 10, 60, ["descriptors[0]['x'] == '5'"], ["y"]) == HOST_ONLY  # `descriptors` is unbound here
+    assert g.add_limit("ns", 10, 60, ["req.method == 'GET'"]) == HOST_ONLY               # member access on an unbound root
+    g.close()
+
+
+def test_a_failed_add_leaves_the_batch_as_it_was_and_the_dictionary_is_bounded(engine_lib):
+    from limitador_amd.ingest import HOST_ONLY, Ingest
+
+    g = Ingest(binding="root", value_cap=6)
+    g.add_limit("ns", 10, 60, ["m == 'GET'"], ["u"])
+    g.compile()
+    assert g.batch_add("ns", [("m", "GET"), ("u", "a")], 1) == 0
+    assert g.batch_add("ns", [("u", "b"), ("u", "c"), ("u", "d")], 1) == 1   # a repeated key keeps its LAST value
+    for u in "efg":
+        g.batch_add("ns", [("u", u)], 1)
+    before = {k: v.tolist() for k, v in g.batch().items()}
+    assert before["ent_val"][2] == g.value_id("d") and g.value_id("b") == -1 and g.value_id("c") == -1
+    # the dictionary is at its cap: a request with a NEW value goes to the host path, nothing is added ...
+    assert g.batch_add("ns", [("m", "GET"), ("u", "never seen")], 1) == HOST_ONLY
+    assert {k: v.tolist() for k, v in g.batch().items()} == before
+    # ... and requests made of known values go on
+    assert g.batch_add("ns", [("m", "GET"), ("u", "a")], 1) == 5
+    b = g.batch()
+    assert len(b["ent_off"]) == len(b["req_ns"]) + 1 and b["ent_off"][-1] == len(b["ent_key"]) == len(b["ent_val"])
+    g.close()
+
+
+def test_requests_are_encoded_exactly(engine_lib):
+    from limitador_amd.ingest import Ingest
+
+    g = Ingest(binding="root")
     g.add_limit("ns", 10, 60, ["m == 'GET'"], ["u"])
     g.compile()
     assert g.batch_add("ns", [("m", "GET"), ("u", "alice"), ("ignored", "x")], 3) == 0
@@ -63,11 +114,13 @@ def test_requests_are_encoded_exactly(ingest):
 
 
 @pytest.mark.parametrize("seed", [1, 2])
-def test_compiled_table_and_encoded_requests_give_counters_that_apply(ingest, seed):
+def test_compiled_table_and_encoded_requests_give_counters_that_apply(engine_lib, seed):
+    from limitador_amd.ingest import Ingest
+
     rng = np.random.default_rng(seed)
     namespaces = ["ns0", "ns1", "ns2"]
     limits = random_limits(rng, namespaces)
-    g = ingest
+    g = Ingest(binding="root")  # the helpers' limits and contexts are the library's: bare identifiers, a HashMap
     ids = [g.add_limit(l.namespace, l.max_value, l.seconds, list(l.conditions), list(l.variables)) for l in limits]
     assert ids == list(range(len(limits)))
     t = g.compile()
