@@ -102,6 +102,35 @@ int32_t rli_check(rli_ingest *g, rl_engine *e, uint64_t now_us, uint8_t *verdict
  * 1 -> OVER_LIMIT, RLI_UNKNOWN_DOMAIN -> UNKNOWN.  Writes at most 2 bytes into out, returns the length. */
 uint32_t rli_rls_response(int32_t verdict, uint8_t out[2]);
 
+/* Limit.name (limit.rs:107-113): not part of the identity, only reported (the `name="..."` of X-RateLimit-Limit). */
+int32_t rli_set_limit_name(rli_ingest *g, uint32_t limit_id, const char *name);
+
+/* ShouldRateLimit for a batch of serialized RateLimitRequests (envoy_rls/server.rs:91-208), applied in index
+ * order with one clock value: decode (rli_batch_add_rls), counters_that_apply + check_and_update on the device,
+ * and the serialized RateLimitResponse of each request in out + i * out_stride (out_len[i] bytes):
+ *   overall_code = 1: OK / OVER_LIMIT; UNKNOWN (no domain) is the empty message;
+ *   with_headers: the draft-03 headers the reference adds with RateLimitHeaders::DraftVersion03
+ *   (response_headers_to_add = 3, sorted by key): X-RateLimit-Limit `{max}, {max};w={secs}[;name="{name}"]...`
+ *   over the request's counters sorted by remaining, X-RateLimit-Remaining, X-RateLimit-Reset of the most
+ *   restrictive one (CheckResult::response_header, lib.rs:235-275; the counters are loaded: load_counters).
+ * status[i]: 0 OK, 1 OVER_LIMIT, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY (the value dictionary is at its cap: the caller
+ * evaluates this request itself; no response is produced), or < 0 for a malformed message. */
+int32_t rli_serve_batch(rli_ingest *g, rl_engine *e, const uint8_t *const *msgs, const uint32_t *lens, uint32_t n,
+                        uint64_t now_us, int32_t with_headers, uint8_t *out, uint32_t out_stride, uint32_t *out_len,
+                        int32_t *status);
+
+/* The micro-batcher of the wire path: thread-safe, blocking; concurrent callers are aggregated into one
+ * rli_serve_batch, closed at max_batch requests or max_delay_us after its first request arrived (the latency
+ * budget), stamped with one clock value.  -> the request's status (as rli_serve_batch), its response in resp. */
+typedef struct rli_frontend rli_frontend;
+int32_t rli_frontend_create(rli_ingest *g, rl_engine *e, uint32_t max_batch, uint32_t max_delay_us, int32_t with_headers,
+                            rli_frontend **out);
+void rli_frontend_destroy(rli_frontend *f);
+void rli_frontend_set_clock(rli_frontend *f, uint64_t now_us); /* tests: a fixed clock instead of the system's */
+int32_t rli_frontend_should_rate_limit(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp,
+                                       uint32_t resp_cap, uint32_t *resp_len);
+void rli_frontend_stats(rli_frontend *f, uint64_t *batches, uint64_t *requests);
+
 /* Dictionary look-ups (tests, diagnostics): id of a string, -1 if it was never interned. */
 int64_t rli_key_id(const rli_ingest *g, const char *key);
 int64_t rli_value_id(const rli_ingest *g, const char *value);

@@ -11,6 +11,11 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
@@ -54,6 +59,8 @@ struct LimitSpec {
     // the BTreeSets of Predicate / Expression, which compare by their source text): two spellings of one
     // predicate are two limits with two counters.
     std::vector<std::string> cond_src, var_src;  // sorted, unique
+    std::string name;                            // Limit.name: not identity, only reported (limit.rs:107-113)
+    bool has_name = false;
     using Identity = std::tuple<std::string, uint64_t, std::vector<std::string>, std::vector<std::string>>;
     Identity identity() const { return Identity(ns, seconds, cond_src, var_src); }
 };
@@ -501,6 +508,254 @@ uint32_t rli_rls_response(int32_t verdict, uint8_t out[2]) {
     out[0] = (1u << 3) | 0u;
     out[1] = verdict ? 2u : 1u;  // OVER_LIMIT : OK
     return 2;
+}
+
+int32_t rli_set_limit_name(rli_ingest* g, uint32_t limit_id, const char* name) {
+    if (!g || limit_id >= g->limits.size()) return RL_ERR_INVALID;
+    g->limits[limit_id].has_name = name != nullptr;
+    g->limits[limit_id].name = name ? name : "";
+    return RL_OK;
+}
+
+// ---- serving: RateLimitRequest bytes in, RateLimitResponse bytes out -----------------------------------------
+namespace {
+
+void put_varint(std::string& o, uint64_t v) {
+    while (v >= 0x80) {
+        o.push_back((char)(v | 0x80));
+        v >>= 7;
+    }
+    o.push_back((char)v);
+}
+void put_string_field(std::string& o, uint32_t field, const std::string& v) {
+    put_varint(o, (field << 3) | 2);
+    put_varint(o, v.size());
+    o += v;
+}
+
+// CheckResult::response_header (limitador/src/lib.rs:235-275) + RateLimitHeaders::headers
+// (envoy_rls/server.rs:44-57: sorted by key) for one request's counters, given in the order the storage saw them.
+struct LoadedCounter {
+    uint64_t max_value, seconds, remaining, expires_in_us;
+    const LimitSpec* limit;
+};
+void response_headers(std::vector<LoadedCounter> cs, std::vector<std::pair<std::string, std::string>>* out) {
+    out->clear();
+    if (cs.empty()) return;
+    // "sort by the limit remaining" (a stable sort: ties keep the storage's order)
+    std::stable_sort(cs.begin(), cs.end(), [](const LoadedCounter& a, const LoadedCounter& b) { return a.remaining < b.remaining; });
+    std::string all;
+    for (const auto& c : cs) {
+        all += ", " + std::to_string(c.max_value) + ";w=" + std::to_string(c.seconds);
+        if (c.limit && c.limit->has_name) {
+            std::string n = c.limit->name;
+            std::replace(n.begin(), n.end(), '"', '\'');
+            all += ";name=\"" + n + "\"";
+        }
+    }
+    const LoadedCounter& f = cs.front();
+    out->emplace_back("X-RateLimit-Limit", std::to_string(f.max_value) + all);
+    out->emplace_back("X-RateLimit-Remaining", std::to_string(f.remaining));
+    out->emplace_back("X-RateLimit-Reset", std::to_string(f.expires_in_us / 1000000ull));  // Duration::as_secs
+    std::sort(out->begin(), out->end());
+}
+
+}  // namespace
+
+int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
+                        uint64_t now_us, int32_t with_headers, uint8_t* out, uint32_t out_stride, uint32_t* out_len,
+                        int32_t* status) {
+    if (!g || !e || (n && (!msgs || !lens || !out || !out_len || !status)) || out_stride < 2) return RL_ERR_INVALID;
+    rli_batch_clear(g);
+    std::vector<int32_t> req_of(n, -1);
+    for (uint32_t i = 0; i < n; ++i) {
+        status[i] = rli_batch_add_rls(g, msgs[i], lens[i]);  // request index, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY, < 0
+        if (status[i] >= 0) req_of[i] = status[i];
+        out_len[i] = 0;
+    }
+    const uint32_t n_req = (uint32_t)g->req_ns.size();
+    std::vector<uint8_t> verdict(n_req ? n_req : 1);
+    std::vector<int32_t> limited(n_req ? n_req : 1);
+    std::vector<uint32_t> req_off(n_req + 1, 0);
+    std::vector<rl_hit> hits;
+    std::vector<uint64_t> rem, exp;
+    if (n_req) {
+        uint32_t n_hits = 0;
+        // every request derives at most one counter per limit of its namespace
+        const size_t cap = with_headers ? (size_t)n_req * std::max<size_t>(1, g->limits.size()) : 0;
+        if (with_headers) {
+            hits.resize(cap);
+            rem.resize(cap);
+            exp.resize(cap);
+        }
+        const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
+                                                    g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict.data(),
+                                                    limited.data(), with_headers ? req_off.data() : nullptr,
+                                                    with_headers ? hits.data() : nullptr, (uint32_t)cap, &n_hits,
+                                                    with_headers ? rem.data() : nullptr, with_headers ? exp.data() : nullptr);
+        if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
+    }
+    std::vector<std::pair<std::string, std::string>> hdrs;
+    for (uint32_t i = 0; i < n; ++i) {
+        std::string o;
+        if (status[i] == RLI_UNKNOWN_DOMAIN) {
+            // Code::Unknown = 0, the proto3 default: an empty message (server.rs:105-115)
+        } else if (status[i] >= 0) {
+            const uint32_t r = (uint32_t)req_of[i];
+            put_varint(o, (1u << 3) | 0u);
+            put_varint(o, verdict[r] ? 2u : 1u);  // OVER_LIMIT : OK
+            if (with_headers) {
+                std::vector<LoadedCounter> cs;
+                for (uint32_t q = req_off[r]; q < req_off[r + 1]; ++q) {
+                    const uint32_t lid = RL_LIMIT_ID(hits[q].limit);
+                    const LimitSpec* L = lid < g->limits.size() ? &g->limits[lid] : nullptr;
+                    cs.push_back(LoadedCounter{L ? L->max_value : 0, L ? L->seconds : 0, rem[q], exp[q], L});
+                }
+                response_headers(std::move(cs), &hdrs);
+                for (const auto& kv : hdrs) {  // response_headers_to_add = 3: HeaderValue { key = 1; value = 2 }
+                    std::string hv;
+                    put_string_field(hv, 1, kv.first);
+                    put_string_field(hv, 2, kv.second);
+                    put_string_field(o, 3, hv);
+                }
+            }
+            status[i] = verdict[r] ? 1 : 0;
+        } else {
+            continue;  // malformed / RLI_HOST_ONLY: no response, the status says why
+        }
+        if (o.size() > out_stride) return gfail(g, RL_ERR_INVALID, "response of %zu bytes does not fit the stride %u", o.size(), out_stride);
+        memcpy(out + (size_t)i * out_stride, o.data(), o.size());
+        out_len[i] = (uint32_t)o.size();
+    }
+    return RL_OK;
+}
+
+// The micro-batcher of the wire path: concurrent ShouldRateLimit callers are aggregated into one device batch,
+// closed at max_batch requests or max_delay_us after its first request arrived, stamped with ONE clock value
+// (what tonic's worker tasks would do around rli_serve_batch: envoy_rls/server.rs:91-208 is one call each).
+struct rli_frontend {
+    rli_ingest* g;
+    rl_engine* e;
+    uint32_t max_batch, max_delay_us, stride;
+    int32_t with_headers;
+    uint64_t fixed_now_us = 0;
+    struct Slot {
+        const uint8_t* msg;
+        uint32_t len;
+        uint8_t* resp;
+        uint32_t resp_cap, resp_len = 0;
+        int32_t status = 0;
+        bool done = false;
+    };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<Slot*> queue;
+    bool stop = false;
+    uint64_t n_batches = 0, n_requests = 0;
+    std::thread worker;
+
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+            if (stop && queue.empty()) return;
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_delay_us);
+            cv_work.wait_until(lk, deadline, [&] { return stop || queue.size() >= max_batch; });
+            std::vector<Slot*> batch;
+            if (queue.size() > max_batch) {
+                batch.assign(queue.begin(), queue.begin() + max_batch);
+                queue.erase(queue.begin(), queue.begin() + max_batch);
+            } else {
+                batch.swap(queue);
+            }
+            lk.unlock();
+            const uint32_t n = (uint32_t)batch.size();
+            std::vector<const uint8_t*> msgs(n);
+            std::vector<uint32_t> lens(n), out_len(n);
+            std::vector<int32_t> status(n);
+            std::vector<uint8_t> out((size_t)n * stride);
+            for (uint32_t i = 0; i < n; ++i) {
+                msgs[i] = batch[i]->msg;
+                lens[i] = batch[i]->len;
+            }
+            uint64_t now = fixed_now_us;
+            if (!now) {
+                using namespace std::chrono;
+                now = (uint64_t)duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
+            }
+            const int32_t rc = rli_serve_batch(g, e, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride,
+                                               out_len.data(), status.data());
+            lk.lock();
+            ++n_batches;
+            n_requests += n;
+            for (uint32_t i = 0; i < n; ++i) {
+                Slot* s = batch[i];
+                s->status = rc ? rc : status[i];
+                if (!rc && out_len[i] <= s->resp_cap) {
+                    memcpy(s->resp, out.data() + (size_t)i * stride, out_len[i]);
+                    s->resp_len = out_len[i];
+                } else if (!rc) {
+                    s->status = RL_ERR_INVALID;
+                }
+                s->done = true;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+int32_t rli_frontend_create(rli_ingest* g, rl_engine* e, uint32_t max_batch, uint32_t max_delay_us, int32_t with_headers,
+                            rli_frontend** out) {
+    if (!g || !e || !out) return RL_ERR_INVALID;
+    rli_frontend* f = new (std::nothrow) rli_frontend();
+    if (!f) return RL_ERR_NOMEM;
+    f->g = g;
+    f->e = e;
+    f->max_batch = max_batch ? max_batch : 1;
+    f->max_delay_us = max_delay_us;
+    f->with_headers = with_headers;
+    f->stride = 1024;
+    f->worker = std::thread([f] { f->run(); });
+    *out = f;
+    return RL_OK;
+}
+
+void rli_frontend_destroy(rli_frontend* f) {
+    if (!f) return;
+    {
+        std::lock_guard<std::mutex> lk(f->mu);
+        f->stop = true;
+    }
+    f->cv_work.notify_all();
+    f->worker.join();
+    delete f;
+}
+
+void rli_frontend_set_clock(rli_frontend* f, uint64_t now_us) {
+    if (f) f->fixed_now_us = now_us;
+}
+
+int32_t rli_frontend_should_rate_limit(rli_frontend* f, const uint8_t* msg, uint32_t len, uint8_t* resp, uint32_t resp_cap,
+                                       uint32_t* resp_len) {
+    if (!f || (len && !msg) || !resp || !resp_len) return RL_ERR_INVALID;
+    rli_frontend::Slot slot;
+    slot.msg = msg;
+    slot.len = len;
+    slot.resp = resp;
+    slot.resp_cap = resp_cap;
+    std::unique_lock<std::mutex> lk(f->mu);
+    f->queue.push_back(&slot);
+    if (f->queue.size() == 1 || f->queue.size() >= f->max_batch) f->cv_work.notify_one();
+    f->cv_done.wait(lk, [&] { return slot.done; });
+    *resp_len = slot.resp_len;
+    return slot.status;
+}
+
+void rli_frontend_stats(rli_frontend* f, uint64_t* batches, uint64_t* requests) {
+    if (!f) return;
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (batches) *batches = f->n_batches;
+    if (requests) *requests = f->n_requests;
 }
 
 int64_t rli_key_id(const rli_ingest* g, const char* s) { return g && s ? g->key_ids.find(s) : -1; }

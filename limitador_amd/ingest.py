@@ -36,6 +36,14 @@ def _lib():
         "rli_batch_add": (i32, [p, cp, strs, strs, u32, u32]),
         "rli_batch_add_rls": (i32, [p, C.c_char_p, u32]),
         "rli_set_binding": (i32, [p, i32]),
+        "rli_set_limit_name": (i32, [p, u32, cp]),
+        "rli_serve_batch": (i32, [p, p, C.POINTER(C.c_char_p), C.POINTER(u32), u32, u64, i32, C.POINTER(C.c_uint8), u32,
+                                  C.POINTER(u32), C.POINTER(i32)]),
+        "rli_frontend_create": (i32, [p, p, u32, u32, i32, C.POINTER(p)]),
+        "rli_frontend_destroy": (None, [p]),
+        "rli_frontend_set_clock": (None, [p, u64]),
+        "rli_frontend_should_rate_limit": (i32, [p, C.c_char_p, u32, C.POINTER(C.c_uint8), u32, C.POINTER(u32)]),
+        "rli_frontend_stats": (None, [p, C.POINTER(u64), C.POINTER(u64)]),
         "rli_set_value_cap": (i32, [p, u32]),
         "rli_batch_n_requests": (u32, [p]),
         "rli_batch_n_entries": (u32, [p]),
@@ -115,6 +123,23 @@ class Ingest:
             return HOST_ONLY
         return self._check(rc)
 
+    def set_limit_name(self, limit_id, name):
+        self._check(SYMBOLS["rli_set_limit_name"](self._h, int(limit_id), None if name is None else name.encode()))
+
+    def serve_batch(self, engine, messages, now_us, with_headers=False, stride=1024):
+        """ShouldRateLimit for a batch of serialized RateLimitRequests -> (status per request, response bytes per
+        request): 0 OK, 1 OVER_LIMIT, UNKNOWN_DOMAIN, HOST_ONLY, or a negative error for a malformed message."""
+        n = len(messages)
+        msgs = (C.c_char_p * max(1, n))(*[bytes(m) for m in messages])
+        lens = (C.c_uint32 * max(1, n))(*[len(m) for m in messages])
+        out = (C.c_uint8 * (max(1, n) * stride))()
+        out_len = (C.c_uint32 * max(1, n))()
+        status = (C.c_int32 * max(1, n))()
+        self._check(SYMBOLS["rli_serve_batch"](self._h, engine._h, msgs, lens, n, int(now_us), int(bool(with_headers)), out,
+                                               stride, out_len, status))
+        raw = bytes(out)
+        return [status[i] for i in range(n)], [raw[i * stride:i * stride + out_len[i]] for i in range(n)]
+
     def compile(self):
         self._check(SYMBOLS["rli_compile"](self._h))
         n, nc = SYMBOLS["rli_n_limits"](self._h), SYMBOLS["rli_n_conds"](self._h)
@@ -176,3 +201,43 @@ class Ingest:
 
     def namespace_id(self, s):
         return SYMBOLS["rli_namespace_id"](self._h, s.encode())
+
+
+
+class Frontend:
+    """The micro-batcher of the wire path (rli_frontend_*): thread-safe, blocking should_rate_limit."""
+
+    def __init__(self, ingest, engine, max_batch=256, max_delay_us=200, with_headers=False):
+        _lib()
+        self._ingest, self._engine = ingest, engine  # keep alive
+        h = C.c_void_p()
+        rc = SYMBOLS["rli_frontend_create"](ingest._h, engine._h, max_batch, max_delay_us, int(bool(with_headers)), C.byref(h))
+        if rc:
+            raise IngestError(rc, "rli_frontend_create failed")
+        self._h = h
+
+    def set_clock(self, now_us):
+        SYMBOLS["rli_frontend_set_clock"](self._h, int(now_us))
+
+    def should_rate_limit(self, message):
+        """-> (status, response bytes)"""
+        out = (C.c_uint8 * 1024)()
+        n = C.c_uint32()
+        rc = SYMBOLS["rli_frontend_should_rate_limit"](self._h, bytes(message), len(message), out, 1024, C.byref(n))
+        return rc, bytes(out[: n.value])
+
+    def stats(self):
+        b, r = C.c_uint64(), C.c_uint64()
+        SYMBOLS["rli_frontend_stats"](self._h, C.byref(b), C.byref(r))
+        return b.value, r.value
+
+    def close(self):
+        if self._h:
+            SYMBOLS["rli_frontend_destroy"](self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Added latency of the wire path vs batch size: rli_serve_batch = decode the serialized
+RateLimitRequests + limit matching + check_and_update on the device + the serialized RateLimitResponses, for a
+batch of N requests (4 namespaces x 8 limits, Zipf users).  A request that waits for a batch of N pays at most
+max_delay (the batcher's budget) + this.  Prints one JSON line: per N the p50 / p99 of the call and requests/s,
+without and with the draft-03 headers (load_counters)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from limitador_amd.engine import Engine  # noqa: E402
+from limitador_amd.ingest import Ingest  # noqa: E402
+from test_ingest_cpu import rls_request  # noqa: E402  (the hand-written wire encoder)
+
+rng = np.random.default_rng(5)
+eng = Engine(capacity_cells=1 << 20, max_batch_hits=1 << 19, max_limits=64)
+g = Ingest()
+methods = ["GET", "POST", "PUT"]
+for n in range(4):
+    for j in range(8):
+        nv = 0 if j < 2 else (1 if j < 5 else 2)
+        conds = [f"descriptors[0]['method'] {'==' if j % 2 == 0 else '!='} '{methods[j % 3]}'"]
+        variables = [] if nv == 0 else (["descriptors[0]['user']"] if nv == 1 else ["descriptors[0]['app']", "descriptors[0]['user']"])
+        lid = g.add_limit(f"ns{n}", 10**9 if j == 0 else 1000, [1, 10, 60, 3600][(n + j) % 4], conds, variables)
+        g.set_limit_name(lid, f"ns{n}-limit{j}")
+g.install(eng)
+
+
+def messages(n):
+    out = []
+    for _ in range(n):
+        out.append(rls_request(f"ns{int(rng.integers(0, 4))}",
+                               [[("method", methods[int(rng.integers(0, 3))]), ("path", "/x"),
+                                 ("user", f"user{int(rng.zipf(1.2)) % 200000}"), ("app", f"app{int(rng.integers(0, 5))}")]]))
+    return out
+
+
+now = 1_700_000_000_000_000
+out = {"what": "rli_serve_batch: wire bytes -> verdicts + RateLimitResponse bytes", "sizes": {}}
+for n in (1, 16, 256, 4096, 32768):
+    msgs = messages(n)
+    row = {}
+    for hdr in (False, True):
+        g.serve_batch(eng, msgs, now, with_headers=hdr)
+        ts = []
+        for _ in range(30 if n <= 4096 else 10):
+            now += 1000
+            t0 = time.perf_counter()
+            g.serve_batch(eng, msgs, now, with_headers=hdr)
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts)
+        row["with_headers" if hdr else "codes_only"] = {"p50_ms": float(np.percentile(ts, 50) * 1e3), "p99_ms": float(np.percentile(ts, 99) * 1e3),
+                                                       "requests_per_s": n / float(np.percentile(ts, 50))}
+    out["sizes"][str(n)] = row
+print(json.dumps(out))

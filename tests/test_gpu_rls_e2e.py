@@ -1,0 +1,152 @@
+"""End to end on the wire path (BASELINE.json configs[4] shape): serialized
+envoy.service.ratelimit.v3.RateLimitRequests in, serialized RateLimitResponses out — decode, limit matching and
+check_and_update on the device, the draft-03 rate-limit headers built by product code (rli_serve_batch) — replayed
+batch by batch against the test-side mirror of RateLimiter over the CPU oracle (tests/helpers/limiter.py, whose
+response_header is pinned by the reference's vectors: envoy_rls/server.rs:390-397,576-583,644-672 in
+tests/scenarios.py).  Then the micro-batcher in front of it, from many threads.  Needs a MI355X."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers.limiter import Limit, TestsLimiter
+from limitador_amd.ingest import UNKNOWN_DOMAIN, Frontend, Ingest
+from test_gpu_parity import make_engine  # noqa: F401
+from test_ingest_cpu import rls_request
+
+pytestmark = pytest.mark.gpu
+
+NOW = 1_700_000_000_000_000
+
+
+def _response_class():
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+    f = descriptor_pb2.FileDescriptorProto(name="rls_e2e.proto", package="e2e", syntax="proto3")
+    hv = descriptor_pb2.DescriptorProto(name="HeaderValue")
+    hv.field.add(name="key", number=1, type=9, label=1)
+    hv.field.add(name="value", number=2, type=9, label=1)
+    resp = descriptor_pb2.DescriptorProto(name="RateLimitResponse")
+    resp.field.add(name="overall_code", number=1, type=13, label=1)  # UNKNOWN 0, OK 1, OVER_LIMIT 2
+    resp.field.add(name="response_headers_to_add", number=3, type=11, label=3, type_name=".e2e.HeaderValue")
+    f.message_type.extend([hv, resp])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("e2e.RateLimitResponse"))
+
+
+def _limits():
+    """4 namespaces x 8 limits: 2 without variables (one generous, one tight), 6 qualified on user / (app, user);
+    conditions on method / path; windows 1, 10, 60, 3600 s.  -> [(namespace, max, seconds, [(key, op, value)], [var keys], name)]"""
+    out = []
+    methods = ["GET", "POST", "PUT"]
+    for n in range(4):
+        ns = f"ns{n}"
+        for j in range(8):
+            nv = 0 if j < 2 else (1 if j < 5 else 2)
+            conds = [("method", "==" if j % 2 == 0 else "!=", methods[j % 3])]
+            if j % 4 == 3:
+                conds.append(("path", "!=", "/admin"))
+            variables = [] if nv == 0 else (["user"] if nv == 1 else ["app", "user"])
+            max_value = 10**6 if j == 0 else [7, 25, 60, 3][(n + j) % 4]
+            out.append((ns, max_value, [1, 10, 60, 3600][(n + j) % 4], conds, variables, f"{ns}-limit{j}"))
+    return out
+
+
+def _install(make_engine):
+    eng = make_engine(capacity_cells=1 << 16, max_batch_hits=1 << 15)
+    g = Ingest()  # the transports' binding: descriptors[0][...]
+    model = TestsLimiter(oracle.OracleStorage(), now_us=NOW)
+    for ns, mx, secs, conds, variables, name in _limits():
+        lid = g.add_limit(ns, mx, secs, [f"descriptors[0]['{k}'] {op} '{v}'" for k, op, v in conds],
+                          [f"descriptors[0]['{k}']" for k in variables])
+        assert lid >= 0
+        g.set_limit_name(lid, name)
+        model.add_limit(Limit(ns, mx, secs, [f"{k} {op} '{v}'" for k, op, v in conds], variables, name=name))
+    g.install(eng)
+    return eng, g, model
+
+
+def test_rate_limit_requests_from_the_wire_to_the_wire(make_engine):
+    rng = np.random.default_rng(77)
+    Resp = _response_class()
+    eng, g, model = _install(make_engine)
+    methods, paths = ["GET", "POST", "PUT"], ["/", "/admin", "/json"]
+    n_ok = n_over = n_unknown = 0
+    for batch in range(20):
+        msgs, ctxs = [], []
+        for _ in range(int(rng.integers(150, 400))):
+            r = rng.random()
+            domain = "" if r < 0.02 else ("elsewhere" if r < 0.05 else f"ns{int(rng.integers(0, 4))}")
+            ctx = {}
+            if rng.random() < 0.95:
+                ctx["method"] = methods[int(rng.integers(0, 3))]
+            if rng.random() < 0.8:
+                ctx["path"] = paths[int(rng.integers(0, 3))]
+            if rng.random() < 0.9:
+                ctx["user"] = f"user{int(rng.zipf(1.4)) % 40}"
+            if rng.random() < 0.7:
+                ctx["app"] = f"app{int(rng.integers(0, 3))}"
+            entries = list(ctx.items())
+            rng.shuffle(entries)
+            if "user" in ctx and rng.random() < 0.1:  # a repeated key keeps its LAST value (server.rs:122-128)
+                entries = [("user", "overwritten")] + entries
+            entries.append(("ignored", "x"))
+            addend = int(rng.integers(0, 4)) if rng.random() < 0.7 else None  # absent or 0 means 1 (server.rs:131-137)
+            msgs.append(rls_request(domain if domain else None, [entries], hits_addend=addend))
+            ctxs.append((domain, ctx, addend if addend else 1))
+        now = model.now_us
+        status, responses = g.serve_batch(eng, msgs, now, with_headers=True)
+        for i, (domain, ctx, delta) in enumerate(ctxs):
+            m = Resp()
+            m.ParseFromString(responses[i])
+            if not domain:  # Code::Unknown, server.rs:105-115
+                assert status[i] == UNKNOWN_DOMAIN and m.overall_code == 0 and not m.response_headers_to_add
+                n_unknown += 1
+                continue
+            want = model.check_rate_limited_and_update(domain, ctx, delta, True)
+            assert status[i] == (1 if want.limited else 0), (batch, i, domain, ctx)
+            assert m.overall_code == (2 if want.limited else 1)
+            got = [(h.key, h.value) for h in m.response_headers_to_add]
+            assert got == sorted(want.response_header().items()), (batch, i, domain, ctx)
+            n_ok += not want.limited
+            n_over += want.limited
+        model.sleep([0.0, 0.3, 1.1, 4.0][batch % 4])  # crosses the 1 s and 10 s windows
+        if batch % 5 == 4:
+            assert eng.sweep_expired(model.now_us) == model.storage.sweep_expired(model.now_us)
+    assert n_ok > 500 and n_over > 500 and n_unknown > 20
+
+
+def test_micro_batcher_in_front_of_the_wire_path(make_engine):
+    """64 threads x 40 ShouldRateLimit calls on one tight limit: the batches are aggregated (fewer device batches
+    than requests), every request gets its own answer, and exactly max_value of them are OK."""
+    Resp = _response_class()
+    eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
+    g = Ingest()
+    assert g.add_limit("shop", 1000, 60, ["descriptors[0]['method'] == 'GET'"], []) == 0
+    assert g.add_limit("shop", 10**6, 60, [], ["descriptors[0]['user']"]) == 1
+    g.install(eng)
+    fe = Frontend(g, eng, max_batch=128, max_delay_us=300, with_headers=True)
+    fe.set_clock(NOW)
+    ok = [0] * 64
+    bad = []
+
+    def worker(t):
+        for q in range(40):
+            st, resp = fe.should_rate_limit(rls_request("shop", [[("method", "GET"), ("user", f"u{t}")]]))
+            m = Resp()
+            m.ParseFromString(resp)
+            if st not in (0, 1) or m.overall_code != (2 if st else 1) or len(m.response_headers_to_add) != 3:
+                bad.append((t, q, st))
+            ok[t] += st == 0
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(64)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    batches, requests = fe.stats()
+    fe.close()
+    assert not bad
+    assert sum(ok) == 1000
+    assert requests == 64 * 40 and batches < requests
+    g.close()
