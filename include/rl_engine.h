@@ -226,6 +226,26 @@ int32_t rl_load_cells(rl_engine *e, const rl_cell_row *rows, uint64_t n);
 int32_t rl_load_cells_device(rl_engine *e, const rl_cell_row *d_rows, uint64_t n);
 int32_t rl_dump_cells(rl_engine *e, rl_cell_row *out, uint64_t cap, uint64_t *n_out);
 
+/* ---- snapshot files, cross-node merge (no CounterStorage analogue) ------------- */
+/* The limit table and every live cell to / from a file: the resume path of this in-memory engine.  Loading
+ * into a fresh engine (same hash_seed not required: keys are re-hashed) gives a table with the same cells. */
+int32_t rl_snapshot_save(rl_engine *e, const char *path);
+int32_t rl_snapshot_load(rl_engine *e, const char *path);
+/* CrCounterValue::merge_at (limitador/src/storage/distributed/cr_counter_value.rs:81-113) for what ONE remote
+ * actor reports: rows[i] = (key, limit, that actor's OWN value, the expiry of its window) — the triples of
+ * CrCounterValue::local_values (:131-141).  A cell's value is the sum over the actors, like read_at (:38-47); per
+ * actor only the largest value seen in the current window counts (:96-110); expired rows are ignored (:83); the
+ * earliest future expiry wins (:84); a cell that is expired at now restarts from the row (:85-87).  actor ==
+ * self_actor: another replica's memory of OUR value, which only counts if it is larger (:91-95).  Actor ids are
+ * 0..7; a key must not appear twice in one call.  Deviation, stated: a window restarted by a LOCAL update
+ * (check_and_update / update_counter follow InMemoryStorage) forgets what the peers contributed to the old
+ * window, where the reference's distributed storage keeps the `others` map until a merge resets it. */
+int32_t rl_merge_cells(rl_engine *e, uint32_t self_actor, uint32_t actor, const rl_cell_row *rows, uint64_t n,
+                       uint64_t now_us);
+/* local_values() of every live, unexpired cell: (key, limit, OUR part of the value, expiry) — what a node
+ * sends to its peers (the input of their rl_merge_cells).  Writes up to cap rows; *n_out = all of them. */
+int32_t rl_export_local(rl_engine *e, uint64_t now_us, rl_cell_row *out, uint64_t cap, uint64_t *n_out);
+
 /* ---- upstream of the trait: limit matching and key derivation on the device --------------------- */
 /* RateLimiter::counters_that_apply (lib.rs:507-522) = Limit::applies (limit.rs:157-174) +
  * Counter::new / resolve_variables (counter.rs:19-31, limit.rs:133-148) for limits whose conditions are

@@ -52,6 +52,7 @@ struct rl_engine {
     u64 live = 0;
     u64 tombs = 0;
 
+    Cell* peer_tables[MERGE_MAX_ACTORS]{};  // what each remote actor is known to have contributed (rl_merge_cells)
     LimitDev* d_limits = nullptr;
     std::vector<LimitDev> h_limits;
     u32 max_limits = 0;
@@ -277,6 +278,16 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
     }
     HIP_TRY(e, hipFree(e->table));
     e->table = fresh;
+    for (auto& pt : e->peer_tables) {  // the peer tables share the main table's geometry
+        if (!pt) continue;
+        Cell* pf = nullptr;
+        const int prc = alloc_table(e, 1ull << new_log2cap, &pf);
+        if (prc) return prc;
+        k_rehash<<<2048, 256, 0, e->stream>>>(pt, e->cap, pf, new_log2cap, e->seed, e->d_status);
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipFree(pt));
+        pt = pf;
+    }
     e->log2cap = new_log2cap;
     e->cap = 1ull << new_log2cap;
     e->stats.capacity_cells = e->cap;
@@ -1001,6 +1012,8 @@ void rl_engine_destroy(rl_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->own_pstream) (void)hipStreamSynchronize(e->own_pstream);
+    for (auto& pt : e->peer_tables)
+        if (pt) (void)hipFree(pt);
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
                     e->d_remaining, e->d_expires, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_hitseg,
@@ -1398,6 +1411,132 @@ int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
                              : fail(e, RL_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(r));
     (void)hipFree(d_rows);
     return rc;
+}
+
+// ---- snapshot files, cross-node merge -----------------------------------------
+namespace {
+struct SnapshotHeader {
+    char magic[8];  // "RLSNAP02"
+    u64 n_cells, n_limits, hash_seed, reserved;
+};
+}  // namespace
+
+int32_t rl_snapshot_save(rl_engine* e, const char* path) {
+    if (!e || !path) return RL_ERR_INVALID;
+    uint64_t n = 0;
+    int rc = rl_dump_cells(e, nullptr, 0, &n);
+    if (rc) return rc;
+    std::vector<rl_cell_row> rows(n);
+    if (n) {
+        rc = rl_dump_cells(e, rows.data(), n, &n);
+        if (rc) return rc;
+        rows.resize(n);
+    }
+    std::lock_guard<std::mutex> g(e->mu);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(e, RL_ERR_INVALID, "cannot open %s for writing", path);
+    SnapshotHeader h{};
+    memcpy(h.magic, "RLSNAP02", 8);
+    h.n_cells = rows.size();
+    h.n_limits = e->h_limits.size();
+    h.hash_seed = e->seed;
+    std::vector<rl_limit_row> lim(e->h_limits.size());
+    for (size_t i = 0; i < lim.size(); ++i) lim[i] = rl_limit_row{e->h_limits[i].max_value, e->h_limits[i].window_us / 1000000ull};
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (lim.empty() || fwrite(lim.data(), sizeof(rl_limit_row), lim.size(), f) == lim.size()) &&
+              (rows.empty() || fwrite(rows.data(), sizeof(rl_cell_row), rows.size(), f) == rows.size());
+    ok = fclose(f) == 0 && ok;
+    return ok ? RL_OK : fail(e, RL_ERR_INVALID, "short write to %s", path);
+}
+
+int32_t rl_snapshot_load(rl_engine* e, const char* path) {
+    if (!e || !path) return RL_ERR_INVALID;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(e, RL_ERR_INVALID, "cannot open %s", path);
+    SnapshotHeader h{};
+    std::vector<rl_limit_row> lim;
+    std::vector<rl_cell_row> rows;
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "RLSNAP02", 8) == 0 && h.n_limits <= (1u << 24) &&
+              h.n_cells <= (1ull << 31);
+    if (ok) {
+        lim.resize(h.n_limits);
+        rows.resize(h.n_cells);
+        ok = (lim.empty() || fread(lim.data(), sizeof(rl_limit_row), lim.size(), f) == lim.size()) &&
+             (rows.empty() || fread(rows.data(), sizeof(rl_cell_row), rows.size(), f) == rows.size());
+    }
+    fclose(f);
+    if (!ok) return fail(e, RL_ERR_INVALID, "%s is not a snapshot of this engine's format", path);
+    int rc = lim.empty() ? RL_OK : rl_limits_set(e, 0, lim.data(), (uint32_t)lim.size());
+    if (rc) return rc;
+    // in chunks: rl_load_cells answers TABLE_FULL (or grows) before anything of a chunk is inserted
+    for (size_t lo = 0; lo < rows.size(); lo += (1u << 20)) {
+        const size_t m = std::min<size_t>(1u << 20, rows.size() - lo);
+        rc = rl_load_cells(e, rows.data() + lo, m);
+        if (rc) return rc;
+    }
+    return RL_OK;
+}
+
+static PeerTables peer_tables_of(rl_engine* e) {
+    PeerTables p{};
+    for (int a = 0; a < MERGE_MAX_ACTORS; ++a) p.t[a] = e->peer_tables[a];
+    p.log2cap = e->log2cap;
+    return p;
+}
+
+int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const rl_cell_row* rows, uint64_t n, uint64_t now_us) {
+    if (!e || (n && !rows)) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (actor >= (u32)MERGE_MAX_ACTORS || self_actor >= (u32)MERGE_MAX_ACTORS)
+        return fail(e, RL_ERR_INVALID, "actor ids are 0..%d", MERGE_MAX_ACTORS - 1);
+    if (n == 0) return RL_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    int rc = check_room(e, n);
+    if (rc) return rc;
+    if (actor != self_actor && !e->peer_tables[actor]) {
+        rc = alloc_table(e, e->cap, &e->peer_tables[actor]);
+        if (rc) return rc;
+    }
+    CellRow* d_rows = nullptr;
+    if (hipMalloc((void**)&d_rows, n * sizeof(CellRow)) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc failed");
+    hipError_t r = hipMemcpyAsync(d_rows, rows, n * sizeof(CellRow), hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream);
+    if (r == hipSuccess) {
+        k_merge_rows<<<cdiv(n, 256), 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, peer_tables_of(e), actor, self_actor,
+                                                          d_rows, n, now_us, e->d_status);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) rc = read_status(e);
+    (void)hipFree(d_rows);
+    if (r != hipSuccess) return fail(e, RL_ERR_DEVICE, "merge failed: %s", hipGetErrorString(r));
+    if (rc) return rc;
+    e->live += e->h_status->n_inserted;
+    if (e->h_status->err) return status_to_error(e, e->h_status->err);
+    return RL_OK;
+}
+
+int32_t rl_export_local(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
+    if (!e || (cap && !out)) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    HIP_TRY(e, hipSetDevice(e->device));
+    CellRow* d_out = nullptr;
+    if (cap && hipMalloc((void**)&d_out, cap * sizeof(CellRow)) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc failed");
+    hipError_t r = hipMemsetAsync(e->d_total, 0, sizeof(unsigned long long), e->stream);
+    if (r == hipSuccess) {
+        k_export_local<<<2048, 256, 0, e->stream>>>(e->table, e->cap, e->seed, peer_tables_of(e), now_us, d_out, cap, e->d_total);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpyAsync(e->h_total, e->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    if (r == hipSuccess && cap) {
+        const u64 m = *e->h_total < cap ? *e->h_total : cap;
+        if (m) r = hipMemcpy(out, d_out, m * sizeof(CellRow), hipMemcpyDeviceToHost);
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (r != hipSuccess) return fail(e, RL_ERR_DEVICE, "export failed: %s", hipGetErrorString(r));
+    if (n_out) *n_out = *e->h_total;
+    return RL_OK;
 }
 
 // ---- on-device limit matching (rl_match.hpp) -------------------------------------------------------

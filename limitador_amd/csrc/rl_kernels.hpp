@@ -283,4 +283,160 @@ __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u6
     if (threadIdx.x == 0 && s_moved) atomicAdd(&st->n_inserted, s_moved);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Cross-node merge: CrCounterValue::merge_at
+// (limitador/src/storage/distributed/cr_counter_value.rs:81-113) for ONE incoming actor's values.
+//
+// The reference keeps, per counter, our own value and a map actor -> value of the others; a read is their sum
+// (:38-47).  Here the cell's `value` is that SUM; what each remote actor is known to have contributed lives in a
+// small table per actor (same cell layout: value = the actor's value, expiry = the window the knowledge belongs
+// to — the cell's expiry when it was recorded; knowledge of another window counts as 0).  One row = what actor
+// `A` reports for one counter (its (expiry, value): local_values(), :131-141).
+//   expired rows are ignored                                     (:83  `if expiry > when`)
+//   the earliest future expiry wins                              (:84  AtomicExpiryTime::merge_at, atomic_expiring_value.rs:113-130)
+//   a cell that is expired at `when` restarts from the row       (:85-87 reset: value 0, others cleared, expiry = other's)
+//   the actor's value only ever grows: max(known, incoming)      (:96-110); a row about OURSELVES raises our own
+//                                                                 part to it (:91-95)
+// ---------------------------------------------------------------------------------------------
+constexpr int MERGE_MAX_ACTORS = 8;
+struct PeerTables {
+    Cell* t[MERGE_MAX_ACTORS];  // null: that actor has never been merged
+    u32 log2cap;
+};
+
+__device__ __forceinline__ Cell* peer_find(Cell* table, u32 log2cap, u64 seed, u64 key, bool create) {
+    const u32 mask = (1u << log2cap) - 1u;
+    u32 slot = slot_of(key, seed, log2cap);
+    for (u32 step = 0; step <= mask; ++step) {
+        u64 tag = table[slot].tag;
+        if (tag == TAG_EMPTY && create) tag = atomicCAS(&table[slot].tag, TAG_EMPTY, key) == TAG_EMPTY ? key : table[slot].tag;
+        if (tag == key) return &table[slot];
+        if (tag == TAG_EMPTY) return nullptr;
+        slot = (slot + 1) & mask;
+    }
+    return nullptr;
+}
+
+__global__ __launch_bounds__(256) void k_merge_rows(Cell* __restrict__ table, u32 log2cap, u64 seed, PeerTables peers,
+                                                    u32 actor, u32 self_actor, const CellRow* __restrict__ rows, u64 n,
+                                                    u64 now, Status* st) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const CellRow r = rows[i];
+    if (r.key >= TAG_TOMB) {
+        atomicOr(&st->err, ERRBIT_RESERVED_KEY);
+        return;
+    }
+    if (r.expiry <= now) return;  // an expired set is ignored
+    // find or create the counter (a counter first heard of from a peer: From<(SystemTime, BTreeMap)>, :163-173)
+    const u32 mask = (1u << log2cap) - 1u;
+    u32 slot = slot_of(r.key, seed, log2cap);
+    Cell* c = nullptr;
+    bool created = false;
+    for (u32 step = 0; step <= mask; ++step) {
+        u64 tag = table[slot].tag;
+        if (tag == TAG_EMPTY) {
+            const u64 old = atomicCAS(&table[slot].tag, TAG_EMPTY, r.key);
+            if (old == TAG_EMPTY) {
+                created = true;
+                tag = r.key;
+            } else {
+                tag = old;
+            }
+        }
+        if (tag == r.key) {
+            c = &table[slot];
+            break;
+        }
+        slot = (slot + 1) & mask;
+    }
+    if (!c) {
+        atomicOr(&st->err, ERRBIT_TABLE_FULL);
+        return;
+    }
+    if (created) {
+        c->value = 0;
+        c->expiry = r.expiry;
+        c->limit = r.limit;
+        atomicAdd(&st->n_inserted, 1u);
+    } else {
+        const u64 cur = c->expiry;
+        if (r.expiry < cur && r.expiry > now) {  // the earliest expiry that is still in the future
+            c->expiry = r.expiry;
+            for (int a = 0; a < MERGE_MAX_ACTORS; ++a)  // what we know of the peers belongs to this same window
+                if (peers.t[a]) {
+                    Cell* p = peer_find(peers.t[a], peers.log2cap, seed, r.key, false);
+                    if (p && p->expiry == cur) p->expiry = r.expiry;
+                }
+        }
+        if (c->expiry <= now) {  // expired here: restart from the incoming set (reset)
+            c->value = 0;
+            c->expiry = r.expiry;  // (knowledge recorded for the old window no longer matches: it counts as 0)
+        }
+    }
+    const u64 window = c->expiry;
+    if (actor == self_actor) {
+        // our own value as another replica remembers it: only a LARGER one is news (we restarted and lost state)
+        u64 others = 0;
+        for (int a = 0; a < MERGE_MAX_ACTORS; ++a)
+            if (peers.t[a]) {
+                const Cell* p = peer_find(peers.t[a], peers.log2cap, seed, r.key, false);
+                if (p && p->expiry == window) others += p->value;
+            }
+        const u64 ours = c->value - others;
+        if (r.value > ours) c->value += r.value - ours;
+        return;
+    }
+    Cell* p = peer_find(peers.t[actor], peers.log2cap, seed, r.key, true);
+    if (!p) {
+        atomicOr(&st->err, ERRBIT_TABLE_FULL);
+        return;
+    }
+    const u64 known = p->expiry == window ? p->value : 0ull;
+    if (r.value > known) {
+        c->value += r.value - known;
+        p->value = r.value;
+        p->expiry = window;
+        p->limit = r.limit;
+    } else if (p->expiry != window) {  // first word of this window from that actor, nothing to add (value 0)
+        p->value = known;
+        p->expiry = window;
+        p->limit = r.limit;
+    }
+}
+
+// local_values() of every live, unexpired counter: (key, limit, OUR OWN part of the value, expiry) — what a node
+// sends to its peers.  Streaming scan; with peers, one probe per peer table per cell.
+__global__ __launch_bounds__(256) void k_export_local(const Cell* __restrict__ table, u64 cap, u64 seed, PeerTables peers,
+                                                      u64 now, CellRow* __restrict__ out, u64 out_cap,
+                                                      unsigned long long* out_total) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 s = gid; s < cap; s += stride) {
+        const uint4* q = reinterpret_cast<const uint4*>(&table[s]);
+        const uint4 a = q[0], b = q[1];
+        const u64 tag = ((u64)a.y << 32) | a.x;
+        const u64 expiry = ((u64)b.y << 32) | b.x;
+        const bool emit = tag < TAG_TOMB && expiry > now;
+        u64 ours = ((u64)a.w << 32) | a.z;
+        if (emit)
+            for (int p = 0; p < MERGE_MAX_ACTORS; ++p)
+                if (peers.t[p]) {
+                    const Cell* e = peer_find(peers.t[p], peers.log2cap, seed, tag, false);
+                    if (e && e->expiry == expiry) ours -= e->value;
+                }
+        const u64 bal = __ballot(emit);
+        if (!bal) continue;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd(out_total, (unsigned long long)__popcll(bal));
+        base = __shfl(base, 0);
+        if (emit) {
+            const u64 pos = base + (u64)__popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < out_cap) out[pos] = CellRow{tag, b.z, 0u, ours, expiry};
+        }
+    }
+}
+
 }  // namespace rl

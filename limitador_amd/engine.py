@@ -205,6 +205,25 @@ class Engine:
         self._check(self._lib.rl_dump_cells(self._h, _ptr(out), out.shape[0], C.byref(n)))
         return out[: min(out.shape[0], n.value)]
 
+    # -- snapshot files, cross-node merge ----------------------------------------------------------
+    def snapshot_save(self, path):
+        self._check(self._lib.rl_snapshot_save(self._h, str(path).encode()))
+
+    def snapshot_load(self, path):
+        self._check(self._lib.rl_snapshot_load(self._h, str(path).encode()))
+
+    def merge_cells(self, self_actor, actor, rows, now_us):
+        """CrCounterValue::merge_at for what one remote actor reports (rows: CELL_ROW_DTYPE, value = its own part)."""
+        rows = np.ascontiguousarray(rows, dtype=CELL_ROW_DTYPE)
+        self._check(self._lib.rl_merge_cells(self._h, int(self_actor), int(actor), _ptr(rows), rows.shape[0], int(now_us)))
+
+    def export_local(self, now_us):
+        n = C.c_uint64(0)
+        self._check(self._lib.rl_export_local(self._h, int(now_us), None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=CELL_ROW_DTYPE)
+        self._check(self._lib.rl_export_local(self._h, int(now_us), _ptr(out), out.shape[0], C.byref(n)))
+        return out[: min(out.shape[0], n.value)]
+
     # -- upstream of the trait: limit matching + key derivation on the device ---------------------
     def set_match_table(self, limits, conds, n_namespaces):
         """limits: MATCH_LIMIT_DTYPE array sorted by ns; conds: MATCH_COND_DTYPE array."""

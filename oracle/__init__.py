@@ -81,6 +81,19 @@ def lib():
         L.lo_check_and_update_batch_ex.argtypes = [p, p, C.c_size_t, p, C.c_size_t, p, C.c_size_t, p, p, u64, i32, p, p,
                                                    p, p]
         L.lo_is_within_limits_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, u64, p]
+        L.lo_cr_new.restype = p
+        L.lo_cr_new.argtypes = [u32, u64, u64]
+        L.lo_cr_from_values.restype = p
+        L.lo_cr_from_values.argtypes = [u64, p, p, C.c_size_t]
+        L.lo_cr_free.argtypes = [p]
+        for name in ("lo_cr_expiry_us", "lo_cr_local_value"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [p]
+        L.lo_cr_read_at.restype = u64
+        L.lo_cr_read_at.argtypes = [p, u64]
+        L.lo_cr_inc_at.argtypes = [p, u64, u64, u64]
+        L.lo_cr_inc_actor_at.argtypes = [p, u32, u64, u64, u64]
+        L.lo_cr_merge_at.argtypes = [p, p, u64]
         L.lo_bench_sharded.restype = C.c_double
         L.lo_bench_sharded.argtypes = [p, C.c_size_t, p, C.c_size_t, p, p, C.c_size_t, C.c_size_t, u64]
         L.lo_update_counter_batch.argtypes = [p, p, C.c_size_t, p, C.c_size_t, u64]
@@ -245,3 +258,46 @@ def bench_sharded(shards, parts, reps, now0_us):
     if sec < 0:
         raise OracleError(int(sec))
     return sec
+
+
+class CrCounterValue:
+    """CrCounterValue<u32> (cr_counter_value.rs) with explicit clocks (microseconds)."""
+
+    def __init__(self, ourselves, max_value, expiry_us, _h=None):
+        self.L = lib()
+        self.h = _h if _h is not None else self.L.lo_cr_new(int(ourselves), int(max_value), int(expiry_us))
+
+    @classmethod
+    def from_values(cls, expiry_us, values):
+        """From<(SystemTime, BTreeMap<A, u64>)>: values = {actor: value}"""
+        actors = np.array(list(values.keys()), dtype=np.uint32)
+        vals = np.array(list(values.values()), dtype=np.uint64)
+        return cls(0, 0, 0, _h=lib().lo_cr_from_values(int(expiry_us), _ptr(actors), _ptr(vals), len(actors)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.lo_cr_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def read_at(self, when_us):
+        return self.L.lo_cr_read_at(self.h, int(when_us))
+
+    def inc_at(self, increment, window_us, when_us):
+        self.L.lo_cr_inc_at(self.h, int(increment), int(window_us), int(when_us))
+
+    def inc_actor_at(self, actor, increment, window_us, when_us):
+        self.L.lo_cr_inc_actor_at(self.h, int(actor), int(increment), int(window_us), int(when_us))
+
+    def merge_at(self, other, when_us):
+        self.L.lo_cr_merge_at(self.h, other.h, int(when_us))
+
+    @property
+    def expiry_us(self):
+        return self.L.lo_cr_expiry_us(self.h)
+
+    @property
+    def local_value(self):
+        return self.L.lo_cr_local_value(self.h)

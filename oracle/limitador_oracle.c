@@ -609,3 +609,107 @@ double lo_bench_sharded(lo_storage **shards, size_t n_shards, const lo_limit_row
     if (rc) return -1.0;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * CrCounterValue<A> (limitador/src/storage/distributed/cr_counter_value.rs:10-149) restated with explicit
+ * clocks: our own value + a map actor -> value of the others, one expiry.  Pinned by the reference's own
+ * vectors (:176-303) in tests/test_oracle_golden.py; the checker of rl_merge_cells / rl_export_local.
+ * ---------------------------------------------------------------------------------------- */
+#define LO_CR_MAX_OTHERS 16
+struct lo_cr {
+    uint32_t ourselves;
+    uint64_t max_value;
+    uint64_t value;
+    uint64_t expiry_us;
+    uint32_t other_actor[LO_CR_MAX_OTHERS];
+    uint64_t other_value[LO_CR_MAX_OTHERS];
+    size_t n_others;
+};
+
+lo_cr *lo_cr_new(uint32_t ourselves, uint64_t max_value, uint64_t expiry_us) { /* :20-28, expiry = now + window */
+    lo_cr *c = (lo_cr *)calloc(1, sizeof(lo_cr));
+    if (!c) return NULL;
+    c->ourselves = ourselves;
+    c->max_value = max_value;
+    c->expiry_us = expiry_us;
+    return c;
+}
+/* From<(SystemTime, BTreeMap<A, u64>)> (:163-173): ourselves = A::default() = 0, value 0, others = the map */
+lo_cr *lo_cr_from_values(uint64_t expiry_us, const uint32_t *actors, const uint64_t *values, size_t n) {
+    lo_cr *c = lo_cr_new(0, 0, expiry_us);
+    if (!c || n > LO_CR_MAX_OTHERS) return c;
+    for (size_t i = 0; i < n; i++) {
+        c->other_actor[i] = actors[i];
+        c->other_value[i] = values[i];
+    }
+    c->n_others = n;
+    return c;
+}
+void lo_cr_free(lo_cr *c) { free(c); }
+uint64_t lo_cr_expiry_us(const lo_cr *c) { return c->expiry_us; }
+uint64_t lo_cr_local_value(const lo_cr *c) { return c->value; } /* local_values(), :131-141 */
+
+uint64_t lo_cr_read_at(const lo_cr *c, uint64_t when_us) { /* :38-47 */
+    if (c->expiry_us <= when_us) return 0;
+    uint64_t sum = c->value;
+    for (size_t i = 0; i < c->n_others; i++) sum += c->other_value[i];
+    return sum;
+}
+static int cr_update_if_expired(lo_cr *c, uint64_t ttl_us, uint64_t when_us) { /* atomic_expiring_value.rs:87-99 */
+    if (c->expiry_us <= when_us) {
+        c->expiry_us = when_us + ttl_us;
+        return 1;
+    }
+    return 0;
+}
+void lo_cr_inc_at(lo_cr *c, uint64_t increment, uint64_t window_us, uint64_t when_us) { /* :53-59 */
+    if (cr_update_if_expired(c, window_us, when_us)) c->value = increment;
+    else c->value += increment;
+}
+static uint64_t *cr_other(lo_cr *c, uint32_t actor, int create) {
+    for (size_t i = 0; i < c->n_others; i++)
+        if (c->other_actor[i] == actor) return &c->other_value[i];
+    if (!create || c->n_others >= LO_CR_MAX_OTHERS) return NULL;
+    c->other_actor[c->n_others] = actor;
+    c->other_value[c->n_others] = 0;
+    return &c->other_value[c->n_others++];
+}
+void lo_cr_inc_actor_at(lo_cr *c, uint32_t actor, uint64_t increment, uint64_t window_us, uint64_t when_us) { /* :65-76 */
+    if (actor == c->ourselves) {
+        lo_cr_inc_at(c, increment, window_us, when_us);
+        return;
+    }
+    uint64_t *v = cr_other(c, actor, 1);
+    if (!v) return;
+    if (cr_update_if_expired(c, window_us, when_us)) *v = increment;
+    else *v += increment;
+}
+void lo_cr_merge_at(lo_cr *c, const lo_cr *other, uint64_t when_us) { /* :81-113 */
+    const uint64_t expiry = other->expiry_us; /* into_inner(): (expiry, others + (ourselves -> value)) */
+    if (!(expiry > when_us)) return;
+    /* AtomicExpiryTime::merge_at, atomic_expiring_value.rs:113-130: the earliest expiry still in the future */
+    if (expiry < c->expiry_us && expiry > when_us) c->expiry_us = expiry;
+    if (c->expiry_us <= when_us) { /* reset(expiry), :144-149 */
+        c->expiry_us = expiry;
+        c->value = 0;
+        c->n_others = 0;
+    }
+    const uint64_t ourselves = c->value;
+    for (size_t i = 0; i <= other->n_others; i++) {
+        const uint32_t actor = i < other->n_others ? other->other_actor[i] : other->ourselves;
+        const uint64_t other_value = i < other->n_others ? other->other_value[i] : other->value;
+        if (actor == c->ourselves) {
+            if (other_value > ourselves) c->value += other_value - ourselves;
+        } else {
+            uint64_t *known = cr_other(c, actor, 0);
+            if (!known) {
+                if (other_value > 0) {
+                    uint64_t *v = cr_other(c, actor, 1);
+                    if (v) *v = other_value;
+                }
+            } else if (other_value > *known) {
+                *known = other_value;
+            }
+        }
+    }
+}

@@ -166,6 +166,19 @@ int lo_is_within_limits_batch(lo_storage *s, const lo_limit_row *limits, size_t 
 int lo_update_counter_batch(lo_storage *s, const lo_limit_row *limits, size_t n_limits,
                             const lo_hit *hits, size_t n_hits, uint64_t now_us);
 
+/* CrCounterValue<A> (limitador/src/storage/distributed/cr_counter_value.rs:10-149) with explicit clocks: the checker
+ * of rl_merge_cells / rl_export_local.  Actors are u32; lo_cr_from_values = From<(SystemTime, BTreeMap)>. */
+typedef struct lo_cr lo_cr;
+lo_cr *lo_cr_new(uint32_t ourselves, uint64_t max_value, uint64_t expiry_us);
+lo_cr *lo_cr_from_values(uint64_t expiry_us, const uint32_t *actors, const uint64_t *values, size_t n);
+void lo_cr_free(lo_cr *c);
+uint64_t lo_cr_expiry_us(const lo_cr *c);
+uint64_t lo_cr_local_value(const lo_cr *c);
+uint64_t lo_cr_read_at(const lo_cr *c, uint64_t when_us);
+void lo_cr_inc_at(lo_cr *c, uint64_t increment, uint64_t window_us, uint64_t when_us);
+void lo_cr_inc_actor_at(lo_cr *c, uint32_t actor, uint64_t increment, uint64_t window_us, uint64_t when_us);
+void lo_cr_merge_at(lo_cr *c, const lo_cr *other, uint64_t when_us);
+
 /* Multi-threaded replay of single-counter batches over hash-sharded storages (bench.py's cpu_baseline leg):
  * thread t owns shards[t] and replays parts[(r % n_distinct) * n_shards + t] for batch r, with a barrier
  * between batches.  Returns the wall seconds of the `reps` batches, < 0 on error. */

@@ -174,3 +174,68 @@ def test_expired_cell_resets_only_on_admitted_update():
     assert v[0] == 1 and st.peek(5) == (3, NOW + 1 * SEC, 0)  # untouched
     v, _, _, _ = st.check_and_update(_hit(5, 0, 2), t2)
     assert v[0] == 0 and st.peek(5) == (2, t2 + 1 * SEC, 0)
+
+
+# ---- CrCounterValue (cr_counter_value.rs:176-303): the vectors behind rl_merge_cells ------------------------------
+def test_cr_counter_value_vectors():
+    """limitador/src/storage/distributed/cr_counter_value.rs:180-303, with explicit clocks (T = now, window 1 s)."""
+    from oracle import CrCounterValue as Cr
+
+    T, W, U64 = 1_700_000_000_000_000, 1_000_000, 2**64 - 1
+    a = Cr(1, U64, T + W)                                  # local_increments_are_readable :180-187
+    a.inc_at(3, W, T)
+    assert a.read_at(T) == 3
+    a.inc_at(2, W, T)
+    assert a.read_at(T) == 5
+    a = Cr(1, U64, T + W)                                  # local_increments_expire :189-198
+    a.inc_at(3, W, T)
+    assert a.read_at(T) == 3
+    a.inc_at(2, W, T + W)
+    assert a.read_at(T + W) == 2
+    a = Cr(1, U64, T + W)                                  # other_increments_are_readable :200-207
+    a.inc_actor_at(2, 3, W, T)
+    assert a.read_at(T) == 3
+    a.inc_actor_at(2, 2, W, T)
+    assert a.read_at(T) == 5
+    a = Cr(1, U64, T + W)                                  # other_increments_expire :209-218
+    a.inc_actor_at(2, 3, W, T)
+    a.inc_actor_at(2, 2, W, T + W)
+    assert a.read_at(T + W) == 2
+
+    def ab():
+        x, y = Cr(1, U64, T + W), Cr(2, U64, T + W)
+        x.inc_at(3, W, T)
+        y.inc_at(2, W, T)
+        return x, y
+
+    a, b = ab()                                            # merges :220-229
+    a.merge_at(b, T)
+    assert a.read_at(T) == 5
+    a, b = ab()                                            # merges_symetric :231-240
+    b.merge_at(a, T)
+    assert b.read_at(T) == 5
+    a, b = ab()                                            # merges_overrides_with_larger_value :242-252
+    b.inc_actor_at(1, 2, W, T)  # older value!
+    b.merge_at(a, T)            # merges the 3
+    assert b.read_at(T) == 5
+    a, b = ab()                                            # merges_ignore_lesser_values :254-264
+    b.inc_actor_at(1, 5, W, T)  # newer value!
+    b.merge_at(a, T)            # ignores the 3 and keeps its own 5 for a
+    assert b.read_at(T) == 7
+    a = Cr(1, U64, T + 0)                                  # merge_ignores_expired_sets :266-275
+    a.inc_at(3, 0, T)
+    b = Cr(2, U64, T + W)
+    b.inc_at(2, W, T)
+    b.merge_at(a, T)
+    assert b.read_at(T) == 2
+    a = Cr(1, U64, T + 0)                                  # merge_ignores_expired_sets_symmetric :277-286
+    a.inc_at(3, 0, T)
+    b = Cr(2, U64, T + W)
+    b.inc_at(2, W, T)
+    a.merge_at(b, T)
+    assert a.read_at(T) == 2
+    a, b = Cr(1, U64, T + W), Cr(2, U64, T + 200_000)      # merge_uses_earliest_expiry :288-302
+    a.inc_at(3, W, T)
+    b.inc_at(2, W, T)
+    a.merge_at(b, T)
+    assert a.expiry_us - T <= 200_000
