@@ -446,6 +446,7 @@ def main():
         launches = max(1, kt["launches"])
         timed = {k: v / launches for k, v in kt["ms"].items() if v > 0}  # the timed region (dominant kernel)
         per = {k: v / max(1, kt_all["launches"]) for k, v in kt_all["ms"].items() if v > 0}  # breakdown pass
+        per_alone = dict(per)
         per.update(timed)
         hits_per_launch = st["hits"] / max(1, st["batches"])
         dom = max(per, key=lambda k: per[k]) if per else "apply"
@@ -456,14 +457,18 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes of the last profiling visit
         # (scripts/gpu_profile.sh -> scripts/summarize_prof.py -> profiles/traffic.json): counters cannot
         # be collected inside this run, so the figure is the committed one for this workload or null.
-        traffic = None
+        traffic = pipeline_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         default_workload = (args.keys, args.batch, args.zipf) == (10_000_000, 1_000_000, 0.99)
         if os.path.exists(tpath) and default_workload and world == 1:
             try:
-                traffic = json.load(open(tpath))["kernels"].get(kname, {}).get("hbm_bytes_per_launch")
+                tk = json.load(open(tpath))["kernels"]
+                traffic = tk.get(kname, {}).get("hbm_bytes_per_launch")
+                # the whole batch pipeline (partition + hot state + replay), for the traffic / algorithmic ratio
+                pipeline_traffic = sum(tk.get(k, {}).get("hbm_bytes_per_launch") or 0.0 for k in
+                                       ("k_bkt_hist", "k_bkt_scan", "k_bkt_scatter", "k_hot_state", "k_bkt_apply"))
             except Exception:
-                traffic = None
+                traffic = pipeline_traffic = None
         out = {
             "metric": "rate-limit decisions/sec", "value": decisions / dt, "unit": "decisions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -479,10 +484,16 @@ def main():
                        "denied_in_last_batch": denied},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                         "pipeline_traffic": pipeline_traffic,
+                         "pipeline_traffic_over_algorithmic": (pipeline_traffic / (ALGO_BYTES_TOTAL * hits_per_launch))
+                         if pipeline_traffic else None,
                          "algorithmic_bytes_per_hit": ALGO_BYTES[dom], "hits_per_launch": hits_per_launch,
                          "avg_launch_ms": per.get(dom, 0.0),
+                         "avg_launch_ms_alone": per_alone.get(dom),
                          "timed_with": (f"HIP events around this kernel on {kt['launches']} of the {args.steps} "
-                                        "launches of the timed region") if dom in timed
+                                        "launches of the timed region (the partition of the next batch runs beside it on a "
+                                        "second stream; avg_launch_ms_alone: the same kernel in the breakdown pass, one "
+                                        "blocking call per batch)") if dom in timed
                          else "HIP events in the breakdown pass before the timed region"},
             "pipeline": {"kernel_ms_per_batch": per, "device_ms_per_batch": pipe_ms,
                          "achieved_GBps_49B": ALGO_BYTES_TOTAL * hits_per_launch / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,

@@ -100,8 +100,9 @@ struct rl_engine {
     // routing scratch
     u32* d_route_cnt = nullptr;
     // bucketed hot path (rl_bucket.hpp)
-    u32 bk_log2_cfg = 10;              // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX): 1024 measured
-                                       // best at 1 M hits (cheaper partition, three rounds per bucket in k_bkt_apply)
+    u32 bk_log2_cfg = BK_LOG2_MAX;     // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX).  Measured at 1 M hits,
+                                       // two streams: 2048 buckets 13.4 G decisions/s with k_bkt_apply at 41 us; 1024 buckets
+                                       // 14.1 G/s (cheaper partition) with k_bkt_apply at 44-48 us (three rounds per bucket)
     u32 bk_tiles_max = 0;
     u32* d_bk_hist = nullptr;
     u32* d_bk_total = nullptr;
@@ -902,7 +903,13 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
     e->stream = e->own_stream;
     if (e->overlap) {
-        if (hipStreamCreateWithFlags(&e->own_pstream, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
+        // the partition stream at a higher priority than the replay stream: its few, fat workgroups (1024 threads,
+        // 100 KB of LDS) then get CU slots ahead of k_bkt_apply's many small ones instead of queueing behind them
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (lo = least urgent, hi = most: numerically lower)
+        int prio = prio_hi;
+        if (const char* v = getenv("RL_PSTREAM_PRIO")) prio = atoi(v) == 0 ? prio_lo : (atoi(v) == 2 ? 0 : prio_hi);
+        if (hipStreamCreateWithPriority(&e->own_pstream, hipStreamNonBlocking, prio) != hipSuccess) return bail(RL_ERR_DEVICE);
         e->pstream = e->own_pstream;
     } else {
         e->pstream = e->stream;

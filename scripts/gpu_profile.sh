@@ -9,7 +9,7 @@ tag=${1:-r01}
 out=$PWD/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 20 --warmup 5 --cpu-seconds 0"
+BENCH="python $PWD/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --secondary 0"
 cd /tmp
 # 1. timing: kernel trace + stats (no counters in this run)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- $BENCH > "$out/bench_under_trace.json" 2> "$out/trace.err"
@@ -24,6 +24,6 @@ cd "$OLDPWD"
 find "$out" -type f -size +8M -delete
 find "$out" -type f | head -50 > "$out/files.txt"
 # 3. the plain bench line (with the CPU baseline) for BENCH comparison
-timeout 600 python bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
+timeout 900 python bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 tail -2 "$out/bench.err"; cat "$out/bench.json" | cut -c1-600
 ls "$out"

@@ -30,7 +30,9 @@ NAN = float("nan")
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+    # `void rl::k_bkt_apply<1, 9, 6>(rl::Cell*, ...)` -> `rl::k_bkt_apply` (template arguments dropped: one
+    # instantiation of each kernel runs in the bench)
+    return name.split("(")[0].split("<")[0].replace("void ", "").strip()
 
 
 # ---- timing ----------------------------------------------------------------------------------
@@ -42,7 +44,7 @@ with open(out + "_kernel_stats.csv", "w") as f:
 eng = [r for r in rows if short(r["Name"]).startswith("rl::")]
 avg_us = {}
 with open(out + "_engine_kernels.md", "w") as f:
-    f.write(f"rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 5 --cpu-seconds 0` ({tag})\n\n")
+    f.write(f"rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --secondary 0` ({tag})\n\n")
     f.write("| kernel | calls | avg us | min us | max us | total ms |\n|---|---|---|---|---|---|\n")
     for r in sorted(eng, key=lambda r: -float(r["TotalDurationNs"])):
         name = short(r["Name"])
@@ -57,7 +59,7 @@ for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_trace.csv"))):
 with open(out + "_engine_kernels.md", "a") as f:
     f.write("\nTimed launches only (the last 20 of 25):\n\n| kernel | avg us | min us | max us |\n|---|---|---|---|\n")
     for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1][-20:])):
-        if name.startswith("rl::k_bkt") and len(v) >= 25:
+        if (name.startswith("rl::k_bkt") or name.startswith("rl::k_hot")) and len(v) >= 25:
             t = v[-20:]
             avg_us[name] = sum(t) / len(t)
             f.write(f"| `{name}` | {avg_us[name]:.1f} | {min(t):.1f} | {max(t):.1f} |\n")
@@ -100,7 +102,7 @@ KNOWN = {  # bytes per launch of the calibration kernels
 }
 fac = {}
 lines = []
-lines.append(f"PMC passes of `python bench.py --steps 20 --warmup 5 --cpu-seconds 0` ({tag}); one counter group per run, "
+lines.append(f"PMC passes of `python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --secondary 0` ({tag}); one counter group per run, "
              "mean over the 20 timed launches.\n")
 lines.append("## Calibration (scripts/microbench/pmc_calib.hip, known bytes per launch)\n")
 lines.append("| kernel | known read MiB | known write MiB | FETCH_SIZE (KiB) | WRITE_SIZE (KiB) | EA RDREQ | EA WRREQ | "

@@ -31,6 +31,19 @@ def delete_limit_also_deletes_associated_counters(rl):
     assert rl.get_counters(NS) == []
 
 
+# :460-491
+def delete_limits_of_a_namespace_also_deletes_counters(rl):
+    rl.add_limit(Limit(NS, 5, 60, ["req_method == 'GET'"], ["app_id"]))
+    rl.update_counters(NS, {"req_method": "GET", "app_id": "1"}, 1)
+    rl.delete_limits(NS)
+    assert rl.get_counters(NS) == []
+
+
+# :493-496
+def delete_limits_of_an_empty_namespace_does_nothing(rl):
+    rl.delete_limits(NS)
+
+
 # :493-532
 def rate_limited(rl):
     max_hits = 3
