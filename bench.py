@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--timing-mode", type=int, default=3, choices=(0, 2, 3),
                     help="HIP events in the timed region: 2 = around k_bkt_apply on every launch, 3 = on every "
                          "fourth launch, 0 = none (roofline then comes from the breakdown pass)")
+    ap.add_argument("--sharded-impl", choices=("torch", "abi"), default=os.environ.get("RL_SHARDED_IMPL"),
+                    help="routed step driven by torch.distributed (limitador_amd/sharded.py) or by the C entry with its own "
+                         "RCCL communicator (include/rl_sharded.h).  Default: abi for --force-sharded on one GPU (measured), "
+                         "torch for N > 1 (the C entry has only run with world 1 over RCCL and world 2-3 over the in-process "
+                         "transport)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the routed (all-to-all) data path even with one rank (exercises the N>1 code on one GPU)")
     return ap.parse_args()
@@ -308,6 +313,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
+    if args.sharded_impl is None:
+        args.sharded_impl = "abi" if world == 1 else "torch"
     if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -348,7 +355,25 @@ def main():
     verdicts = [verdict] + [torch.empty(args.batch, dtype=torch.uint8, device=dev) for _ in range(3)]
     torch.cuda.synchronize()
 
-    if sharded:
+    if sharded and args.sharded_impl == "abi":
+        from limitador_amd import sharded_abi
+
+        idt = torch.zeros(sharded_abi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(sharded_abi.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        torch.cuda.synchronize()
+        sh = sharded_abi.Sharded(eng, world, rank, args.batch, unique_id=bytes(idt.cpu().numpy()))
+        pending = [0]
+        if args.depth == 1:
+            def step(i, now):
+                sh.check_and_update(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
+        else:
+            def step(i, now):
+                sh.submit(batches[i].data_ptr(), args.batch, now, verdicts[i % 3].data_ptr())
+                if sh.in_flight == 3:
+                    sh.collect()
+    elif sharded:
         from limitador_amd.sharded import ShardedEngine
 
         sh = ShardedEngine(eng, dist.group.WORLD, dev, max_local_hits=args.batch)
@@ -389,6 +414,8 @@ def main():
         if sharded:
             while sh.in_flight:
                 sh.collect()
+            if args.sharded_impl == "abi":
+                sh.sync()
         elif args.depth >= 2:
             while pending[0]:
                 eng.collect()
@@ -479,7 +506,7 @@ def main():
                        else f"{args.keys} keys/GPU, zipf {args.zipf}, {args.batch}-hit batch/GPU",
                        "keys_per_gpu": args.keys, "batch_per_gpu": args.batch, "zipf_s": args.zipf,
                        "table_capacity_cells": cap, "cell_bytes": 32, "table_bytes": cap * 32,
-                       "parallelism": f"hash-sharded x{world}, RCCL all-to-all" if sharded else "single GPU",
+                       "parallelism": (f"hash-sharded x{world}, RCCL all-to-all" + (" behind the C ABI (rl_sharded_*)" if args.sharded_impl == "abi" else " (torch.distributed)")) if sharded else "single GPU",
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
                        "overlap": "partition of batch k+1 (own stream) beside k_hot_state + k_bkt_apply of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
                        "denied_in_last_batch": denied},
@@ -509,6 +536,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if sharded and args.sharded_impl == "abi":
+        sh.close()
     eng.close()
     if sharded:
         dist.destroy_process_group()

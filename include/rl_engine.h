@@ -65,8 +65,8 @@ typedef enum {
 typedef struct {
     int32_t device;          /* HIP device ordinal */
     uint32_t max_batch_hits; /* largest n_hits one call may carry */
-    uint64_t capacity_cells; /* table slots; rounded up to a power of two.  Live cells are bounded
-                                by capacity/2 (RL_ERR_TABLE_FULL beyond).  Replaces moka's
+    uint64_t capacity_cells; /* table slots; rounded up to a power of two.  Live cells + tombstones are bounded
+                                by 3/4 of it before a batch, 15/16 after (RL_ERR_TABLE_FULL beyond).  Replaces moka's
                                 `cache_size` (in_memory.rs:205-212) but never evicts silently. */
     uint32_t max_limits;     /* rows of the limit table */
     uint32_t flags;          /* RL_CFG_* */
@@ -118,6 +118,8 @@ void rl_engine_destroy(rl_engine *e);
 const char *rl_last_error(const rl_engine *e);
 int32_t rl_status_is_transient(int32_t status);
 int32_t rl_stats(rl_engine *e, rl_stats_t *out);
+/* The device ordinal and max_batch_hits the engine was created with (either pointer may be NULL). */
+int32_t rl_engine_info(rl_engine *e, int32_t *device, uint32_t *max_batch_hits);
 
 /* ---- limits --------------------------------------------------------------------------- */
 /* Upload rows [first, first+n) of the limit table (max_value / seconds of interned limits). */
@@ -306,6 +308,13 @@ int32_t rl_route_partition_device(rl_engine *e, const rl_hit *d_hits, uint32_t n
 /* d_dst[d_perm[j]] = d_src[j] for j < n (returns verdict bytes to ingress order). */
 int32_t rl_unpermute_u8_device(rl_engine *e, const uint8_t *d_src, const uint32_t *d_perm,
                                uint32_t n, uint8_t *d_dst);
+/* Both on a stream of the caller's (hipStream_t on the engine's device): enqueue and return, never block.
+ * The router keeps one scratch block per engine, so route calls of one engine belong on ONE stream
+ * (include/rl_sharded.h puts them on its exchange stream, beside the engine's batches on another). */
+int32_t rl_route_partition_stream(rl_engine *e, void *stream, const rl_hit *d_hits, uint32_t n_hits,
+                                  uint32_t world, rl_hit *d_out, uint32_t *d_perm, uint32_t *d_counts);
+int32_t rl_unpermute_u8_stream(rl_engine *e, void *stream, const uint8_t *d_src, const uint32_t *d_perm,
+                               uint32_t n, uint8_t *d_dst);
 
 /* The HIP stream (hipStream_t) the engine launches on, for callers that order their own work
  * against it, and a per-kernel timing hook used by bench.py (HIP events on that stream). */
@@ -316,6 +325,11 @@ void *rl_engine_stream(rl_engine *e);
  * routing helpers below enqueue and return without blocking (the caller's stream order is the
  * synchronisation), and submit / collect give the same for the hot path. */
 int32_t rl_engine_set_stream(rl_engine *e, void *stream, int32_t external);
+/* Ordering against the engine's OWN streams without giving up their overlap: everything submitted after
+ * rl_engine_wait_event waits for `event` (a hipEvent_t recorded by the caller, e.g. after the exchange that filled the
+ * batch's buffers); rl_engine_record_event records `event` behind everything submitted so far (verdicts complete). */
+int32_t rl_engine_wait_event(rl_engine *e, void *event);
+int32_t rl_engine_record_event(rl_engine *e, void *event);
 /* HIP-event timing of the kernels of the single-counter hot path (events on the engine's stream):
  * enable = 0 off (no event is recorded at all: completion is a sequence word the last workgroup
  * stores into host-mapped memory), 1 every kernel (an event between any two kernels; each marker

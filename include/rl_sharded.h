@@ -1,0 +1,104 @@
+/*
+ * rl_sharded.h — the multi-GPU step of the counter engine behind a C ABI.
+ *
+ * One process (or thread) per GPU, one rl_engine per rank holding the cells of the keys it owns
+ * (owner = rl_owner_of(key, seed, world): hash partition, no replication, no cross-GPU atomics).
+ * A rank hands in its INGRESS slice of single-counter requests; the step routes every hit to its owner,
+ * applies `InMemoryStorage::check_and_update` (limitador/src/storage/in_memory.rs:72-156) there and
+ * returns the verdicts in ingress order.  The partition by owner is stable and the exchange lays the
+ * received hits out by source rank, so an owner applies "rank 0's slice, then rank 1's, ..." restricted
+ * to its keys: the result is bit-identical to the sequential reference on the concatenated slices.
+ * The reference has no counterpart: its in-memory storage is one process.
+ *
+ * Per slice and rank, on the device, nothing but enqueues on the host side:
+ *     route     stable partition by owner (k_route_*), hits-per-owner counts
+ *     exchange  GROUP A: counts to/from every peer  (+ the verdicts of the slice two back: one launch)
+ *               GROUP B: 16-byte hit records to their owners (sizes known from GROUP A)
+ *     apply     the local batch on the engine (rl_check_and_update_submit_device)
+ *     return    verdict bytes back to the ingress ranks (rides in GROUP A of the slice two ahead, or
+ *               alone when the pipeline drains), un-permute to ingress order
+ * Up to three slices are in flight (routed / applied / returned); routing and exchanges run on one
+ * stream, the engine's batches on another.  submit(i) enqueues
+ * GROUP B of slice i-1 and its local batch, then route(i) and GROUP A(i): the engine never waits for an
+ * exchange that is itself waiting for the engine.
+ *
+ * EVERY rank must issue the same sequence of rl_sharded_submit_device / rl_sharded_collect calls (they
+ * contain collectives), with the same now_us for the same slice.
+ *
+ * Transport: RCCL (ncclCommInitRank + grouped ncclSend / ncclRecv over xGMI) when the communicator is
+ * created from a unique id; or any rl_transport the host supplies — `rl_local_group` below is an
+ * in-process one (ranks = threads of one process, device-to-device copies), which is also how the
+ * world-2 tests run on a single GPU.
+ */
+#ifndef RL_SHARDED_H
+#define RL_SHARDED_H
+
+#include <stdint.h>
+
+#include "rl_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rl_sharded rl_sharded;
+
+/* One segment of a grouped all-to-all: peer p gets send_cnt[p] bytes from send + send_off[p] and
+ * delivers recv_cnt[p] bytes to recv + recv_off[p] (device pointers; offsets / counts host arrays of
+ * `world` entries, in bytes).  Peers agree on the sizes: my send_cnt[p] is p's recv_cnt[me]. */
+typedef struct {
+    const void *send;
+    void *recv;
+    const uint64_t *send_off, *send_cnt, *recv_off, *recv_cnt;
+} rl_xfer;
+
+/* exchange(): enqueue all segments as ONE grouped operation on `stream` (hipStream_t) and return;
+ * 0 or a negative rl_status.  Called by every rank with the same number of segments. */
+typedef struct {
+    void *ctx;
+    int32_t (*exchange)(void *ctx, const rl_xfer *xfers, uint32_t n_xfers, void *stream);
+} rl_transport;
+
+#define RL_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: call on one rank, hand the bytes to all ranks by whatever means the host has. */
+int32_t rl_sharded_unique_id(uint8_t id[RL_UNIQUE_ID_BYTES]);
+
+/* max_slice_hits: largest ingress slice of this rank.  The engine must have been created with
+ * max_batch_hits >= the most hits this rank can RECEIVE for one slice (all ranks' slices may hash here).
+ * The engine is switched to the communicator's apply stream (rl_engine_set_stream) until rl_sharded_destroy
+ * and must not be used directly while slices are in flight. */
+int32_t rl_sharded_create_rccl(rl_engine *e, uint32_t world, uint32_t rank, const uint8_t id[RL_UNIQUE_ID_BYTES],
+                               uint32_t max_slice_hits, rl_sharded **out);
+int32_t rl_sharded_create(rl_engine *e, uint32_t world, uint32_t rank, const rl_transport *t,
+                          uint32_t max_slice_hits, rl_sharded **out);
+void rl_sharded_destroy(rl_sharded *s);
+const char *rl_sharded_last_error(const rl_sharded *s);
+
+/* Enqueue one ingress slice (device pointers; d_hits and d_verdict stay untouched until the matching
+ * collect).  RL_ERR_BUSY with three slices in flight. */
+int32_t rl_sharded_submit_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
+                                 uint8_t *d_verdict);
+/* Finish the OLDEST slice: its verdicts are in its d_verdict once the exchange stream has been
+ * synchronised (rl_sharded_stream) — or use rl_sharded_sync.  -> the status of the local batch this
+ * rank applied for that slice; *n_applied = hits it applied. */
+int32_t rl_sharded_collect(rl_sharded *s, uint32_t *n_applied);
+/* submit + collect + synchronise on an empty pipeline. */
+int32_t rl_sharded_check_and_update_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
+                                           uint8_t *d_verdict, uint32_t *n_applied);
+/* The stream the verdicts are ordered on (hipStream_t), and a host wait on it. */
+void *rl_sharded_stream(rl_sharded *s);
+int32_t rl_sharded_sync(rl_sharded *s);
+uint32_t rl_sharded_in_flight(const rl_sharded *s);
+
+/* In-process transport: `world` ranks in one process (one thread per rank; any mix of devices with peer
+ * access, or all on one device).  exchange() is a rendezvous: it waits for every rank's send buffers,
+ * copies device-to-device and returns when all ranks have read — a correctness transport, not a fast one. */
+typedef struct rl_local_group rl_local_group;
+int32_t rl_local_group_create(uint32_t world, rl_local_group **out);
+void rl_local_group_destroy(rl_local_group *g);
+int32_t rl_local_group_transport(rl_local_group *g, uint32_t rank, rl_transport *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RL_SHARDED_H */

@@ -12,6 +12,7 @@ CSRC = os.path.join(ROOT, "limitador_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "limitador_amd", "lib")
 ENGINE_SO = os.path.join(LIBDIR, "librl_engine.so")
 STORAGE_SO = os.path.join(LIBDIR, "librl_storage.so")
+SHARDED_SO = os.path.join(LIBDIR, "librl_sharded.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liblimitador_oracle.so")
 
@@ -67,6 +68,24 @@ def build_storage(force=False, verbose=False):
     return STORAGE_SO
 
 
+def build_sharded(force=False, verbose=False):
+    """g++ -> limitador_amd/lib/librl_sharded.so (include/rl_sharded.h: the routed multi-GPU step; links RCCL)."""
+    src = os.path.join(CSRC, "host", "rl_sharded.cpp")
+    srcs = [src, os.path.join(ROOT, "include", "rl_sharded.h"), os.path.join(ROOT, "include", "rl_engine.h")]
+    if not force and _newer(SHARDED_SO, srcs) and _newer(SHARDED_SO, [ENGINE_SO] if os.path.exists(ENGINE_SO) else []):
+        return SHARDED_SO
+    build_engine(force=False, verbose=verbose)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-D__HIP_PLATFORM_AMD__",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(rocm, "include"), src, "-o", SHARDED_SO,
+           "-L" + LIBDIR, "-lrl_engine", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return SHARDED_SO
+
+
 def build_oracle(force=False, verbose=False):
     """gcc -> oracle/liblimitador_oracle.so (test infrastructure, never used by the product)."""
     srcs = [os.path.join(ORACLE_DIR, "limitador_oracle.c"), os.path.join(ORACLE_DIR, "limitador_oracle.h")]
@@ -82,4 +101,5 @@ def build_oracle(force=False, verbose=False):
 if __name__ == "__main__":
     print(build_engine(verbose=True))
     print(build_storage(verbose=True))
+    print(build_sharded(verbose=True))
     print(build_oracle(verbose=True))

@@ -1081,6 +1081,23 @@ int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
     return RL_OK;
 }
 
+int32_t rl_engine_wait_event(rl_engine* e, void* event) {
+    if (!e || !event) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, (hipEvent_t)event, 0));
+    if (e->pstream != e->stream) HIP_TRY(e, hipStreamWaitEvent(e->pstream, (hipEvent_t)event, 0));
+    return RL_OK;
+}
+
+int32_t rl_engine_record_event(rl_engine* e, void* event) {
+    if (!e || !event) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipEventRecord((hipEvent_t)event, e->stream));
+    return RL_OK;
+}
+
 int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
@@ -1695,8 +1712,8 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
 
 uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world) { return owner_of(key, hash_seed, world); }
 
-int32_t rl_route_partition_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint32_t world,
-                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
+static int32_t route_partition_on(rl_engine* e, hipStream_t st, bool block, const rl_hit* d_hits, uint32_t n_hits,
+                                  uint32_t world, rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
     if (!e || !d_counts || (n_hits && (!d_hits || !d_out || !d_perm))) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
     if (world == 0 || world > ROUTE_MAX_WORLD) return fail(e, RL_ERR_INVALID, "world %u not in [1,%d]", world, ROUTE_MAX_WORLD);
@@ -1704,26 +1721,56 @@ int32_t rl_route_partition_device(rl_engine* e, const rl_hit* d_hits, uint32_t n
     const u32 nblk = n_hits ? cdiv(n_hits, ROUTE_TILE) : 0;
     if (nblk > ROUTE_MAX_BLOCKS) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u too large for the router", n_hits);
     if (nblk)
-        k_route_count<<<nblk, ROUTE_BLOCK, 0, e->stream>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed,
-                                                            world, e->d_route_cnt);
-    k_route_scan<<<1, 256, 0, e->stream>>>(e->d_route_cnt, nblk, world, d_counts);
+        k_route_count<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world,
+                                                    e->d_route_cnt);
+    k_route_scan<<<1, 256, 0, st>>>(e->d_route_cnt, nblk, world, d_counts);
     if (nblk)
-        k_route_scatter<<<nblk, ROUTE_BLOCK, 0, e->stream>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed,
-                                                              world, e->d_route_cnt,
-                                                              reinterpret_cast<Hit*>(d_out), d_perm);
+        k_route_scatter<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world,
+                                                      e->d_route_cnt, reinterpret_cast<Hit*>(d_out), d_perm);
     HIP_TRY(e, hipGetLastError());
-    if (!e->external_stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (block) HIP_TRY(e, hipStreamSynchronize(st));
+    return RL_OK;
+}
+
+int32_t rl_route_partition_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint32_t world,
+                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
+    if (!e) return RL_ERR_INVALID;
+    return route_partition_on(e, e->stream, !e->external_stream, d_hits, n_hits, world, d_out, d_perm, d_counts);
+}
+
+int32_t rl_route_partition_stream(rl_engine* e, void* stream, const rl_hit* d_hits, uint32_t n_hits, uint32_t world,
+                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
+    if (!e) return RL_ERR_INVALID;
+    return route_partition_on(e, reinterpret_cast<hipStream_t>(stream), false, d_hits, n_hits, world, d_out, d_perm, d_counts);
+}
+
+static int32_t unpermute_on(rl_engine* e, hipStream_t st, bool block, const uint8_t* d_src, const uint32_t* d_perm,
+                            uint32_t n, uint8_t* d_dst) {
+    if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (n) k_unpermute_u8<<<cdiv(n, 256), 256, 0, st>>>(d_src, d_perm, n, d_dst);
+    HIP_TRY(e, hipGetLastError());
+    if (block) HIP_TRY(e, hipStreamSynchronize(st));
     return RL_OK;
 }
 
 int32_t rl_unpermute_u8_device(rl_engine* e, const uint8_t* d_src, const uint32_t* d_perm, uint32_t n,
                                uint8_t* d_dst) {
-    if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
-    HIP_TRY(e, hipSetDevice(e->device));
-    if (n) k_unpermute_u8<<<cdiv(n, 256), 256, 0, e->stream>>>(d_src, d_perm, n, d_dst);
-    HIP_TRY(e, hipGetLastError());
-    if (!e->external_stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (!e) return RL_ERR_INVALID;
+    return unpermute_on(e, e->stream, !e->external_stream, d_src, d_perm, n, d_dst);
+}
+
+int32_t rl_unpermute_u8_stream(rl_engine* e, void* stream, const uint8_t* d_src, const uint32_t* d_perm, uint32_t n,
+                               uint8_t* d_dst) {
+    if (!e) return RL_ERR_INVALID;
+    return unpermute_on(e, reinterpret_cast<hipStream_t>(stream), false, d_src, d_perm, n, d_dst);
+}
+
+int32_t rl_engine_info(rl_engine* e, int32_t* device, uint32_t* max_batch_hits) {
+    if (!e) return RL_ERR_INVALID;
+    if (device) *device = e->device;
+    if (max_batch_hits) *max_batch_hits = e->max_batch;
     return RL_OK;
 }
 

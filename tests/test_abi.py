@@ -91,3 +91,24 @@ def test_ingest_library_exports_every_declared_symbol(engine_lib):
     for name in syms:
         assert hasattr(so, name), f"{name} declared in rl_ingest.h but not exported"
         assert name in ingest.SYMBOLS, f"{name} has no ctypes signature in limitador_amd/ingest.py"
+
+
+def test_sharded_library_exports_every_symbol_of_rl_sharded_h():
+    """include/rl_sharded.h (the routed multi-GPU step): loads without a GPU, every entry has a ctypes signature."""
+    from limitador_amd import sharded_abi
+
+    so = sharded_abi.load()
+    src = open(os.path.join(ROOT, "include", "rl_sharded.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(rl_(?:sharded|local_group)_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(so, name), f"{name} declared in rl_sharded.h but not exported"
+        assert name in sharded_abi.SYMBOLS, f"{name} has no ctypes signature in limitador_amd/sharded_abi.py"
+    # the in-process transport is plain host code: a group can be made and asked for a rank's transport
+    g = sharded_abi.LocalGroup(2)
+    t = g.transport(1)
+    assert t.ctx and t.exchange
+    with pytest.raises(sharded_abi.ShardedError):
+        g.transport(2)
+    g.close()
