@@ -76,6 +76,7 @@ struct rl_engine {
     SegTot* d_g_piece = nullptr;
     u32* d_g_hitseg = nullptr;
     uint8_t* d_g_reached = nullptr;
+    u32* d_g_admdiff = nullptr;     // [gen_cap / 256 + 1]
     uint8_t* d_g_pass = nullptr;    // [2][gen_cap]
     uint8_t* d_g_admitted = nullptr;
     GenStatus* d_gst = nullptr;
@@ -100,6 +101,8 @@ struct rl_engine {
     // routing scratch
     u32* d_route_cnt = nullptr;
     // bucketed hot path (rl_bucket.hpp)
+    int gen_trace = 0;                 // RL_GEN_TRACE=1: one stderr line per pass of the general resolver; 2: + k_gen_sort phases
+    unsigned long long* d_gen_trace = nullptr;
     u32 bk_log2_cfg = BK_LOG2_MAX;     // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX).  Measured at 1 M hits,
                                        // two streams: 2048 buckets 13.4 G decisions/s with k_bkt_apply at 41 us; 1024 buckets
                                        // 14.1 G/s (cheaper partition) with k_bkt_apply at 44-48 us (three rounds per bucket)
@@ -139,6 +142,12 @@ struct rl_engine {
     MatchCond* d_match_conds = nullptr;
     u32* d_match_ns_off = nullptr;
     u32 n_match_limits = 0, n_match_ns = 0, n_match_conds = 0;
+    // the slot form of the table (k_match_fast): few distinct keys, <= 64 limits per namespace, small enough for LDS
+    bool match_fast = false;
+    MatchLimitF* d_match_flimits = nullptr;
+    MatchCondF* d_match_fconds = nullptr;
+    MatchSlots match_slots{};
+    unsigned long long* d_m_mask = nullptr;  // [max_batch] limits of its namespace that apply to a request
     u32* d_m_ns = nullptr;      // staging for host-pointer calls: per request namespace, delta
     u32* d_m_delta = nullptr;
     u32* d_m_ent_off = nullptr;
@@ -541,6 +550,7 @@ struct GenCall {
     int32_t* d_first;
     u64* d_rem;
     u64* d_exp;
+    int32_t* d_limited = nullptr;  // per request: id of the limit that limited it, -1 (rl_match_and_check_batch)
 };
 
 // One pass: requests [req0, req0 + n_req) = hits [hit0, hit0 + n) of the call.  *overflow: a hash bucket was
@@ -551,6 +561,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     if (n == 0) {  // only empty requests: lib.rs:434-440, not limited
         HIP_TRY(e, hipMemsetAsync(c.d_verdict + req0, 0, n_req, st));
         if (c.d_first) HIP_TRY(e, hipMemsetAsync(c.d_first + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
+        if (c.d_limited) HIP_TRY(e, hipMemsetAsync(c.d_limited + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
         return RL_OK;
     }
     int rc = check_room(e, 0);  // (the cells the pass creates are counted exactly below, before the commit)
@@ -558,7 +569,10 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     const u64 p = e->part_seq;
     const u32 par = (u32)(p & 1u);
     BatchScratch* bs = e->d_bs + p % 3;
-    const HotSet* hot_use = e->d_hot + (p + 1) % 3;
+    // Passes are blocking (nothing else is in flight), so a pass partitions with the hot set the pass right before
+    // it produced — not the one from two back that the pipelined single-counter path has to use.  (With the
+    // pipelined rotation every call overflowed once: the retry's promotions were never the set of the next call.)
+    const HotSet* hot_use = e->d_hot + (p + 2) % 3;
     HotSet* hot_prod = e->d_hot + p % 3;
     BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
     uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
@@ -613,8 +627,10 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     A.pass[0] = e->d_g_pass;
     A.pass[1] = e->d_g_pass + e->gen_cap;
     A.admitted = e->d_g_admitted;
+    A.adm_diff = e->d_g_admdiff;
     A.verdict = c.d_verdict + req0;
     A.first_limited = c.d_first ? c.d_first + req0 : nullptr;
+    A.limited_limit = c.d_limited ? c.d_limited + req0 : nullptr;
     A.remaining = c.load ? c.d_rem + hit0 : nullptr;
     A.expires_in = c.load ? c.d_exp + hit0 : nullptr;
     A.gst = e->d_gst;
@@ -622,8 +638,41 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     A.load = c.load ? 1u : 0u;
     A.update_mode = c.update_mode ? 1u : 0u;
     A.mark_reached = mark ? 1u : 0u;
+    if (e->gen_trace >= 2) {
+        if (!e->d_gen_trace) HIP_TRY(e, hipMalloc((void**)&e->d_gen_trace, (size_t)(BK_MAX + HOT_MAX) * 8 * sizeof(unsigned long long)));
+        HIP_TRY(e, hipMemsetAsync(e->d_gen_trace, 0, (size_t)(BK_MAX + HOT_MAX) * 8 * sizeof(unsigned long long), st));
+        A.trace = e->d_gen_trace;
+    }
     k_gen_sort<<<nb + GS_HOT_BLOCKS, GS_BLOCK, 0, st>>>(A);
     HIP_TRY(e, hipGetLastError());
+    if (e->gen_trace >= 2) {
+        std::vector<unsigned long long> t((size_t)nb * 8);
+        HIP_TRY(e, hipMemcpyAsync(t.data(), e->d_gen_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        unsigned long long t_min = ~0ull, t_max = 0;
+        double ph[4] = {0, 0, 0, 0};
+        u32 live = 0, longest = 0, longest_b = 0;
+        double longest_us = 0;
+        for (u32 b = 0; b < nb; ++b) {
+            const unsigned long long* q = &t[(size_t)b * 8];
+            if (!q[4]) continue;
+            ++live;
+            t_min = std::min(t_min, q[0]);
+            t_max = std::max(t_max, q[4]);
+            for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]) / 100.0;  // wall clock: 100 MHz
+            const double us = (double)(q[4] - q[0]) / 100.0;
+            if (us > longest_us) {
+                longest_us = us;
+                longest = (u32)q[7];
+                longest_b = b;
+            }
+        }
+        if (live)
+            std::fprintf(stderr, "[gen] k_gen_sort: %u buckets, span %.1f us; mean per workgroup: init+pass1 %.1f, offsets %.1f, pass2 %.1f, resolve %.1f us; "
+                         "slowest: bucket %u with %u hits, %.1f us\n", live, (double)(t_max - t_min) / 100.0, ph[0] / live, ph[1] / live,
+                         ph[2] / live, ph[3] / live, longest_b, longest, longest_us);
+        A.trace = nullptr;
+    }
     // ---- fixpoint rounds: a few at a time, each returning at once if the one before changed nothing; then
     //      k_gen_commit, which applies the pass only if the status block says it is final and fits -------------
     u32 round = 0;
@@ -636,11 +685,17 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     for (;;) {
         const u32 n_enq = c.update_mode ? 1u : GEN_ROUNDS_ENQ;
         for (u32 q = 0; q < n_enq; ++q, ++round) {
-            // slot of changed[]: rounds of one group use slots 1.., the group's first round runs unconditionally
+            // changed[] slots of one group: round q's k_gen_admit checks slot q (did the round before still change
+            // the admitted set?) and writes slot q + 1, which is what the round's own kernels check.  Round 0 has
+            // no k_gen_admit and runs unconditionally.
             const u32 check = q == 0 ? 0u : q;
-            if (round > 0) k_gen_admit<<<cdiv(n_req, 256), 256, 0, st>>>(A, round, check);
-            k_gen_hot_sum<<<GS_HOT_BLOCKS, GS_BLOCK, 0, st>>>(A, round, check, q + 1);
-            k_gen_round<<<nb + GS_HOT_BLOCKS, GS_BLOCK, 0, st>>>(A, round, check, q + 1);
+            if (round > 0) {
+                k_gen_admit<<<cdiv(n_req, 256), 256, 0, st>>>(A, round, check, q + 1);
+                k_gen_admit_fold<<<1, 1024, 0, st>>>(A, cdiv(n_req, 256), round, check, q + 1);
+            }
+            const u32 run_if = round == 0 ? 0u : q + 1;
+            k_gen_piece_sum<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A, round, run_if);
+            k_gen_round<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A, round, run_if, q + 1);
         }
         k_gen_final<<<cdiv(n_req, 256), 256, 0, st>>>(A);
         k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A);
@@ -655,6 +710,10 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
         else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
         const u32 err = h_bst.err | h_gst.err;
+        if (e->gen_trace)
+            std::fprintf(stderr, "[gen] pass seq=%llu n=%u req=%u round=%u rounds_run=%u overflow=%u committed=%u n_new=%u hot_n=%u thr=%u err=%u\n",
+                         (unsigned long long)p, n, n_req, round, h_gst.rounds_run, h_gst.overflow, h_gst.committed, h_gst.n_new,
+                         h_gst.hot_n, e->hot_threshold, err);
         if (err || h_gst.overflow || h_gst.committed) break;
         if (c.update_mode || !h_gst.changed[h_gst.last_slot]) break;  // converged, yet not committed: no room
         if (round > n_req + 2 + GEN_ROUNDS_ENQ) return fail(e, RL_ERR_DEVICE, "general resolver did not converge (bug)");
@@ -668,9 +727,9 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     }
     if (h_gst.overflow) {
         // nothing was applied.  k_gen_sort promoted the heavy keys of the long buckets into this attempt's hot
-        // set: skipping one step of the rotation makes the retry partition with exactly that set.
+        // set, which is the one the next pass — the retry — partitions with.
         *overflow = true;
-        e->part_seq += 2;
+        e->part_seq += 1;
         return cleanup();
     }
     if (!h_gst.committed) {
@@ -737,6 +796,11 @@ int run_check_general(rl_engine* e, const GenCall& c) {
         e->stats.hits += c.n_hits;
         e->stats.ordered_hits += c.n_hits;
         e->stats.ordered_batches++;
+        if (c.d_limited && c.d_first) {
+            k_match_limited_limit<<<cdiv(c.n_req, 256), 256, 0, e->stream>>>(c.d_first, c.d_hits, c.n_req, c.d_limited);
+            HIP_TRY(e, hipGetLastError());
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+        }
         return RL_OK;
     }
     if (e->tombs > e->cap / 8) {
@@ -870,6 +934,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
+    if (const char* v = getenv("RL_GEN_TRACE")) e->gen_trace = atoi(v);
     if (const char* v = getenv("RL_GEN_SUB_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 1024) e->gen_sub_max = (u32)std::min<long>(b, GEN_SUB_MAX);
@@ -945,10 +1010,11 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_g_shits, (size_t)e->gen_cap * sizeof(SHit));
     ALLOC(e->d_g_seginfo, (size_t)e->gen_cap * sizeof(SegInfo));
     ALLOC(e->d_g_segtot, (size_t)e->gen_cap * sizeof(SegTot));
-    ALLOC(e->d_g_piece, ((size_t)e->gen_cap / HOT_CHUNK + HOT_MAX + 8) * sizeof(SegTot));
+    ALLOC(e->d_g_piece, ((size_t)e->gen_cap / GS_MAX + 8) * sizeof(SegTot));
     ALLOC(e->d_g_hitseg, (size_t)e->gen_cap * sizeof(u32));
     ALLOC(e->d_g_reached, (size_t)e->gen_cap);
     ALLOC(e->d_g_pass, 2 * (size_t)e->gen_cap);
+    ALLOC(e->d_g_admdiff, (mb / 256 + 2) * sizeof(u32));
     ALLOC(e->d_g_admitted, mb);
     ALLOC(e->d_gst, sizeof(GenStatus));
     ALLOC(e->d_row1, sizeof(CellRow));
@@ -979,6 +1045,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_m_ent_val, mb * sizeof(u32));
     ALLOC(e->d_m_count, (mb + 1) * sizeof(u32));
     ALLOC(e->d_m_limited, mb * sizeof(int32_t));
+    ALLOC(e->d_m_mask, mb * sizeof(unsigned long long));
     ALLOC(e->d_m_flags, 16);
     {
         size_t mtmp = 0;
@@ -1024,11 +1091,11 @@ void rl_engine_destroy(rl_engine* e) {
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
                     e->d_remaining, e->d_expires, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_hitseg,
-                    e->d_g_reached, e->d_g_pass,  e->d_g_admitted, e->d_gst,      e->d_row1,
+                    e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
-                    e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp};
+                    e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -1603,6 +1670,50 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
     e->n_match_limits = n_limits;
     e->n_match_ns = n_namespaces;
     e->n_match_conds = n_conds;
+    // ---- the slot form, when the table has it (k_match_fast) ---------------------------------------------
+    e->match_fast = false;
+    if (e->d_match_flimits) (void)hipFree(e->d_match_flimits);
+    if (e->d_match_fconds) (void)hipFree(e->d_match_fconds);
+    e->d_match_flimits = nullptr;
+    e->d_match_fconds = nullptr;
+    bool fast = n_limits && n_limits <= MATCH_LDS_LIMITS && n_conds <= MATCH_LDS_CONDS && n_namespaces <= MATCH_LDS_NS;
+    for (u32 n = 0; fast && n < n_namespaces; ++n) fast = ns_off[n + 1] - ns_off[n] <= 64u;
+    MatchSlots slots{};
+    auto slot_of = [&](u32 key) -> int {
+        for (u32 q = 0; q < slots.n; ++q)
+            if (slots.key[q] == key) return (int)q;
+        if (slots.n == MATCH_SLOTS) return -1;
+        slots.key[slots.n] = key;
+        return (int)slots.n++;
+    };
+    std::vector<MatchLimitF> fl(n_limits);
+    std::vector<MatchCondF> fc(n_conds ? n_conds : 1);
+    for (u32 i = 0; fast && i < n_limits; ++i) {
+        const rl_match_limit& L = limits[i];
+        if (L.n_cond > 255u) fast = false;
+        u32 vs[2] = {0, 0};
+        for (u32 q = 0; fast && q < L.n_vars; ++q) {
+            const int sl = slot_of(L.var_key[q]);
+            if (sl < 0) fast = false;
+            else vs[q] = (u32)sl;
+        }
+        for (u32 c = 0; fast && c < L.n_cond; ++c) {
+            const rl_match_cond& cd = conds[L.cond_off + c];
+            const int sl = slot_of(cd.key);
+            if (sl < 0 || cd.op > 1u) fast = false;
+            else fc[L.cond_off + c] = MatchCondF{(u32)sl | (cd.op << 8), cd.value};
+        }
+        fl[i] = MatchLimitF{L.limit, L.cond_off, L.n_cond | (L.n_vars << 8) | (vs[0] << 16) | (vs[1] << 24)};
+    }
+    if (fast) {
+        if (hipMalloc((void**)&e->d_match_flimits, n_limits * sizeof(MatchLimitF)) != hipSuccess ||
+            hipMalloc((void**)&e->d_match_fconds, fc.size() * sizeof(MatchCondF)) != hipSuccess)
+            return fail(e, RL_ERR_NOMEM, "hipMalloc of the match table failed");
+        HIP_TRY(e, hipMemcpy(e->d_match_flimits, fl.data(), n_limits * sizeof(MatchLimitF), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->d_match_fconds, fc.data(), fc.size() * sizeof(MatchCondF), hipMemcpyHostToDevice));
+        e->match_slots = slots;
+        e->match_fast = getenv("RL_MATCH_GENERIC") == nullptr;
+    }
     return RL_OK;
 }
 
@@ -1619,39 +1730,43 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
                         e->n_match_ns <= MATCH_LDS_NS;
     auto k_count = in_lds ? k_match<false, true> : k_match<false, false>;
     auto k_fill = in_lds ? k_match<true, true> : k_match<true, false>;
-    k_count<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
-                                             e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
-                                             e->n_match_conds, e->d_m_count, nullptr, nullptr, e->d_status);
+    if (e->match_fast)
+        k_match_fast<false><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_flimits,
+                                                      e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_fconds,
+                                                      e->n_match_conds, e->match_slots, e->d_m_count, e->d_m_mask, nullptr,
+                                                      nullptr, e->d_status);
+    else
+        k_count<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
+                                          e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
+                                          e->n_match_conds, e->d_m_count, nullptr, nullptr, e->d_status);
     size_t stmp = e->m_scan_tmp_bytes;
     HIP_TRY(e, rocprim::exclusive_scan(e->d_m_scan_tmp, stmp, e->d_m_count, e->d_req_off, 0u, (size_t)n_req + 1,
                                        rocprim::plus<u32>(), e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_req_off + n_req, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     int rc = read_status(e);
     if (rc) return rc;
+    if (e->h_status->err & ERRBIT_RESERVED_KEY)
+        return fail(e, RL_ERR_INVALID, "a value id does not fit %u bits: such dictionaries keep the host path", MATCH_VAL_BITS);
     if (e->h_status->err) return status_to_error(e, e->h_status->err);
     const u32 n_hits = e->h_m_total[0];
     if (n_hits_out) *n_hits_out = n_hits;
     if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the requests expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
     if (n_hits) {
         HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-        k_fill<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
-                                                e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
-                                                e->n_match_conds, nullptr, e->d_req_off, e->d_hits, e->d_status);
-        rc = read_status(e);
-        if (rc) return rc;
-        if (e->h_status->err & ERRBIT_RESERVED_KEY)
-            return fail(e, RL_ERR_INVALID, "a value id does not fit %u bits: such dictionaries keep the host path", MATCH_VAL_BITS);
-        if (e->h_status->err) return status_to_error(e, e->h_status->err);
+        if (e->match_fast)
+            k_match_fast<true><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req,
+                                                         e->d_match_flimits, e->n_match_limits, e->d_match_ns_off,
+                                                         e->n_match_ns, e->d_match_fconds, e->n_match_conds, e->match_slots,
+                                                         nullptr, e->d_m_mask, e->d_req_off, e->d_hits, e->d_status);
+        else
+            k_fill<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
+                                             e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
+                                             e->n_match_conds, nullptr, e->d_req_off, e->d_hits, e->d_status);
+        HIP_TRY(e, hipGetLastError());  // (the fill pass cannot fail: the count pass saw every value it writes)
     }
-    rc = run_check_general(e, GenCall{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load, false, d_verdict, e->d_first,
-                                      e->d_remaining, e->d_expires});
-    if (rc) return rc;
-    if (d_limited) {
-        k_match_limited_limit<<<g, 256, 0, e->stream>>>(e->d_first, e->d_hits, n_req, d_limited);
-        HIP_TRY(e, hipGetLastError());
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-    }
-    return RL_OK;
+    GenCall gc{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load, false, d_verdict, e->d_first, e->d_remaining, e->d_expires};
+    gc.d_limited = d_limited;
+    return run_check_general(e, gc);
 }
 
 int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, const uint32_t* d_ent_off,

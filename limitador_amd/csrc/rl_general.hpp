@@ -122,13 +122,16 @@ struct GenArgs {
     uint8_t* reached;        // per segment
     uint8_t* pass[2];
     uint8_t* admitted;       // per request, by the previous round (k_gen_admit)
+    u32* adm_diff;           // per workgroup of k_gen_admit: a request's admission changed
     uint8_t* verdict;        // outputs, already offset to the pass
     int32_t* first_limited;
+    int32_t* limited_limit;  // per request: the limit id of the first limited counter, -1 (null: not wanted)
     u64* remaining;
     u64* expires_in;
     GenStatus* gst;
     const Status* pst;       // the partition's status: a refused batch leaves the sorted arrays unwritten
     u32 load, update_mode, mark_reached;
+    unsigned long long* trace;  // debugging (RL_GEN_TRACE=2): k_gen_sort's phase stamps, 8 words per workgroup
 };
 
 __device__ __forceinline__ LimitDev gen_limit_row(const GenArgs& A, u32 limit) {
@@ -139,8 +142,9 @@ __device__ __forceinline__ LimitDev gen_limit_row(const GenArgs& A, u32 limit) {
     return L;
 }
 
-// The state of `key`'s cell before the batch (one probe chain, nothing is created).
-__device__ __forceinline__ SegInfo gen_resolve(const GenArgs& A, u64 key, u32 hit_limit, u32 len) {
+// The state of `key`'s cell before the batch (one probe chain, nothing is created).  (a0, b0) = the two halves
+// of the key's HOME cell, loaded by the caller — early, beside whatever else it waits for.
+__device__ __forceinline__ SegInfo gen_resolve_from(const GenArgs& A, u64 key, u32 hit_limit, u32 len, uint4 a0, uint4 b0) {
     SegInfo si{};
     si.len = len;
     const u32 mask = (1u << A.log2cap) - 1u;
@@ -148,10 +152,10 @@ __device__ __forceinline__ SegInfo gen_resolve(const GenArgs& A, u64 key, u32 hi
     si.slot = SLOT_INVALID;
     for (u32 step = 0; step <= mask; ++step) {
         const Cell* c = &A.table[slot];
-        const uint4 a = *reinterpret_cast<const uint4*>(c);
+        const uint4 a = step ? *reinterpret_cast<const uint4*>(c) : a0;
         const u64 tag = ((u64)a.y << 32) | a.x;
         if (tag == key) {
-            const uint4 b = reinterpret_cast<const uint4*>(c)[1];
+            const uint4 b = step ? reinterpret_cast<const uint4*>(c)[1] : b0;
             const u64 expiry = ((u64)b.y << 32) | b.x;
             si.slot = slot;
             si.limit = b.z;
@@ -186,6 +190,10 @@ __device__ __forceinline__ SegInfo gen_resolve(const GenArgs& A, u64 key, u32 hi
     }
     return si;
 }
+__device__ __forceinline__ SegInfo gen_resolve(const GenArgs& A, u64 key, u32 hit_limit, u32 len) {
+    const uint4* c = reinterpret_cast<const uint4*>(&A.table[slot_of(key, A.seed, A.log2cap)]);
+    return gen_resolve_from(A, key, hit_limit, len, c[0], c[1]);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_gen_sort
@@ -193,12 +201,12 @@ __device__ __forceinline__ SegInfo gen_resolve(const GenArgs& A, u64 key, u32 hi
 __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     __shared__ u64 ekey[GS_E];
     __shared__ u32 eoff[GS_E];                       // hits of the cell, then its start offset in the bucket
-    __shared__ unsigned short wcnt[GS_WAVES][GS_E];  // hits of the cell per wave, then the waves' exclusive offsets
-    __shared__ unsigned short wcur[GS_WAVES][GS_E];  // pass 2: hits of the cell this wave has placed
-    __shared__ u32 etot[GS_E];
+    __shared__ unsigned short wcnt[GS_WAVES][GS_E];  // hits of the cell per wave; then where the wave's next hit of the cell goes
+    __shared__ unsigned short etot[GS_E];   // hits of the cell (<= GS_LONG_MAX)
+    __shared__ unsigned short elist[GS_E];  // the cells in use, in the order they were claimed
     __shared__ uint8_t efold[GS_E];
     __shared__ u32 s_w[GS_WAVES];
-    __shared__ u32 s_full;
+    __shared__ u32 s_full, s_nact;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u64 lt = (1ull << lane) - 1ull;
     if (A.pst->err) return;  // k_bkt_hist refused the batch
@@ -227,55 +235,87 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     }
     const uint2 r = A.ranges[blockIdx.x];
     const u32 lo = r.x, L = r.y - r.x;
+#define GS_STAMP(k) \
+    if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();
+    if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + 7] = L;
+    GS_STAMP(0)
     if (L == 0) return;
+    // wave w owns the contiguous (trace-ordered) positions [w * Lw, (w + 1) * Lw) of the bucket and walks them
+    // in 64-hit steps, twice: count, then place.  A bucket of up to 512 hits — the usual one once the heavy keys
+    // have buckets of their own — is read ONCE, two records per lane, and the requests of its records are gathered
+    // while pass 1 runs; a longer one (any length up to GS_LONG_MAX) is re-read, records and requests requested
+    // a step or two ahead.
+    const u32 steps = (L + GS_BLOCK - 1) / GS_BLOCK;
+    const u32 Lw = steps * 64;
+    const u32 w_lo = w * Lw, w_hi = (w + 1) * Lw < L ? (w + 1) * Lw : L;
+    const bool too_long = L > (u32)GS_LONG_MAX;
+    const bool resident = steps <= 2;
+    BHit hA{}, hB{};
+    const bool okA = w_lo + lane < w_hi, okB = steps > 1 && w_lo + 64 + lane < w_hi;
+    if (resident) {
+        if (okA) hA = load_bhit(A.b_hits, lo + w_lo + lane);
+        if (okB) hB = load_bhit(A.b_hits, lo + w_lo + 64 + lane);
+    }
     for (u32 e = tid; e < (u32)GS_E; e += GS_BLOCK) {
         ekey[e] = TAG_EMPTY;
         eoff[e] = 0;
 #pragma unroll
-        for (int ww = 0; ww < GS_WAVES; ++ww) {
-            wcnt[ww][e] = 0;
-            wcur[ww][e] = 0;
-        }
+        for (int ww = 0; ww < GS_WAVES; ++ww) wcnt[ww][e] = 0;
     }
-    if (tid == 0) s_full = 0;
+    if (tid == 0) {
+        s_full = 0;
+        s_nact = 0;
+    }
     __syncthreads();
-    // wave w owns the contiguous (trace-ordered) positions [w * Lw, (w + 1) * Lw) of the bucket and walks them
-    // in 64-hit steps, twice: count, then place (the bucket is re-read; any length up to GS_LONG_MAX)
-    const u32 steps = (L + GS_BLOCK - 1) / GS_BLOCK;
-    const u32 Lw = steps * 64;
-    const u32 w_lo = w * Lw, w_hi = (w + 1) * Lw < L ? (w + 1) * Lw : L;
-    bool too_long = L > (u32)GS_LONG_MAX;
+    u32 rA = 0, rB = 0;
+    if (resident && A.hit_req) {
+        if (okA) rA = A.hit_req[A.hit0 + (hA.idx_tag & 0xFFFFFFu)];
+        if (okB) rB = A.hit_req[A.hit0 + (hB.idx_tag & 0xFFFFFFu)];
+    }
     // ---- pass 1: the bucket's cells (LDS hash), hits per (wave, cell) ---------------------------------
-    if (!too_long)
+    auto count_step = [&](const BHit& h, bool ok) {
+        u32 ent = 0;
+        bool lost = false;
+        if (ok) {
+            u32 e = (u32)(fmix64(h.key ^ A.seed) >> 20) & (GS_E - 1);
+            u32 step = 0;
+            for (;; ++step) {
+                if (step >= (u32)GS_E) {  // more distinct cells than the LDS hash holds
+                    lost = true;
+                    break;
+                }
+                u64 prev = ekey[e];
+                if (prev == TAG_EMPTY) {
+                    prev = atomicCAS(&ekey[e], TAG_EMPTY, h.key);
+                    if (prev == TAG_EMPTY) {
+                        efold[e] = (uint8_t)(h.idx_tag >> 24);  // the limit id every hit of the key must carry
+                        elist[atomicAdd(&s_nact, 1u)] = (unsigned short)e;
+                    }
+                }
+                if (prev == TAG_EMPTY || prev == h.key) break;
+                e = (e + 1) & (GS_E - 1);
+            }
+            ent = e;
+        }
+        if (lost) s_full = 1;
+        const u64 m = match_digit(ent, GS_E_LOG2, __ballot(ok && !lost));
+        if (ok && !lost && (m & lt) == 0ull) wcnt[w][ent] = (unsigned short)(wcnt[w][ent] + (u32)__popcll(m));
+    };
+    if (resident) {
+        count_step(hA, okA);
+        if (steps > 1) count_step(hB, okB);
+    } else if (!too_long) {
+        BHit nxt{};
+        if (okA) nxt = load_bhit(A.b_hits, lo + w_lo + lane);
         for (u32 u = 0; u < steps; ++u) {
             const u32 p = w_lo + u * 64 + lane;
-            const bool ok = p < w_hi;
-            u32 ent = 0;
-            bool lost = false;
-            if (ok) {
-                const BHit h = load_bhit(A.b_hits, lo + p);
-                u32 e = (u32)(fmix64(h.key ^ A.seed) >> 20) & (GS_E - 1);
-                u32 step = 0;
-                for (;; ++step) {
-                    if (step >= (u32)GS_E) {  // more distinct cells than the LDS hash holds
-                        lost = true;
-                        break;
-                    }
-                    u64 prev = ekey[e];
-                    if (prev == TAG_EMPTY) {
-                        prev = atomicCAS(&ekey[e], TAG_EMPTY, h.key);
-                        if (prev == TAG_EMPTY) efold[e] = (uint8_t)(h.idx_tag >> 24);  // the limit id every hit of the key must carry
-                    }
-                    if (prev == TAG_EMPTY || prev == h.key) break;
-                    e = (e + 1) & (GS_E - 1);
-                }
-                ent = e;
-            }
-            if (lost) s_full = 1;
-            const u64 m = match_digit(ent, GS_E_LOG2, __ballot(ok && !lost));
-            if (ok && !lost && (m & lt) == 0ull) wcnt[w][ent] = (unsigned short)(wcnt[w][ent] + (u32)__popcll(m));
+            const BHit h = nxt;
+            if (u + 1 < steps && p + 64 < w_hi) nxt = load_bhit(A.b_hits, lo + p + 64);
+            count_step(h, p < w_hi);
         }
+    }
     __syncthreads();
+    GS_STAMP(1)
     if (too_long || s_full) {
         // Too long (or too many cells) for the in-LDS sort: a traffic shift, the first batch.  Promote the
         // heavy keys seen so far: the host retries the pass with THIS set, which gives them buckets of their own.
@@ -301,7 +341,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
             acc += c;
         }
         eoff[e] = acc;
-        etot[e] = acc;
+        etot[e] = (unsigned short)acc;
         if (acc >= A.hot_threshold && A.hot_next) {
             const u32 pos = atomicAdd(&A.hot_next->n, 1u);
             if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = ekey[e];
@@ -333,31 +373,91 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
         }
     }
     __syncthreads();
-    // ---- pass 2: placement (the same walk: stable rank inside (wave, cell)); the cell's first hit resolves it
-    for (u32 u = 0; u < steps; ++u) {
-        const u32 p = w_lo + u * 64 + lane;
-        const bool ok = p < w_hi;
+    GS_STAMP(2)
+    // ---- the cells, first half: every distinct cell's home line is requested now and waited for after pass 2 ---
+    const u32 n_act = s_nact;
+    constexpr int RES = 2;  // cells per thread resolved with their loads in flight together (more: one by one below)
+    u32 re[RES];
+    uint4 ra[RES], rb[RES];
+#pragma unroll
+    for (int q = 0; q < RES; ++q) {
+        const u32 k = tid + q * GS_BLOCK;
+        re[q] = k < n_act ? (u32)elist[k] : 0xFFFFFFFFu;
+        if (k < n_act) {
+            const uint4* c = reinterpret_cast<const uint4*>(&A.table[slot_of(ekey[re[q]], A.seed, A.log2cap)]);
+            ra[q] = c[0];
+            rb[q] = c[1];
+        }
+    }
+    // ---- pass 2: placement (the same walk: stable rank inside (wave, cell)) ----------------------------------
+    auto place_step = [&](const BHit& h, u32 req_abs, bool ok) {
         u32 ent = 0;
-        BHit h{};
         if (ok) {
-            h = load_bhit(A.b_hits, lo + p);
             u32 e = (u32)(fmix64(h.key ^ A.seed) >> 20) & (GS_E - 1);
             while (ekey[e] != h.key) e = (e + 1) & (GS_E - 1);
             ent = e;
         }
         const u64 m = match_digit(ent, GS_E_LOG2, __ballot(ok));
-        if (!ok) continue;
-        const u32 c = wcur[w][ent];
-        const u32 in_seg = (u32)wcnt[w][ent] + c + (u32)__popcll(m & lt);
-        if ((m & lt) == 0ull) wcur[w][ent] = (unsigned short)(c + (u32)__popcll(m));
-        const u32 seg = lo + eoff[ent];
-        const u32 idx = h.idx_tag & 0xFFFFFFu;
-        const u32 req = A.hit_req ? A.hit_req[A.hit0 + idx] - A.req0 : idx;
-        *reinterpret_cast<uint4*>(A.s_hits + seg + in_seg) = make_uint4(seg, req, idx, h.delta);
-        if (A.hit_seg) A.hit_seg[idx] = seg;
-        if ((h.idx_tag >> 24) != (u32)efold[ent]) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
-        if (in_seg == 0) A.seg_info[seg] = gen_resolve(A, h.key, A.hits[idx].limit, etot[ent]);
+        if (ok) {
+            const u32 c = wcnt[w][ent];  // where this wave's next hit of the cell goes, inside the segment
+            const u32 in_seg = c + (u32)__popcll(m & lt);
+            if ((m & lt) == 0ull) wcnt[w][ent] = (unsigned short)(c + (u32)__popcll(m));
+            const u32 seg = lo + eoff[ent];
+            const u32 idx = h.idx_tag & 0xFFFFFFu;
+            const u32 req = A.hit_req ? req_abs - A.req0 : idx;
+            *reinterpret_cast<uint4*>(A.s_hits + seg + in_seg) = make_uint4(seg, req, idx, h.delta);
+            if (A.hit_seg) A.hit_seg[idx] = seg;
+            if ((h.idx_tag >> 24) != (u32)efold[ent]) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
+        }
+    };
+    if (resident) {
+        place_step(hA, rA, okA);
+        if (steps > 1) place_step(hB, rB, okB);
+    } else {
+        // two steps ahead: the records; one step ahead: their requests (a gather through the record's index)
+        BHit h0{}, h1{}, h2{};
+        u32 req0 = 0, req1 = 0;
+        if (okA) {
+            h0 = load_bhit(A.b_hits, lo + w_lo + lane);
+            req0 = A.hit_req ? A.hit_req[A.hit0 + (h0.idx_tag & 0xFFFFFFu)] : 0u;
+        }
+        if (okB) h1 = load_bhit(A.b_hits, lo + w_lo + 64 + lane);
+        for (u32 u = 0; u < steps; ++u) {
+            const u32 p = w_lo + u * 64 + lane;
+            if (u + 2 < steps && p + 128 < w_hi) h2 = load_bhit(A.b_hits, lo + p + 128);
+            if (u + 1 < steps && p + 64 < w_hi) req1 = A.hit_req ? A.hit_req[A.hit0 + (h1.idx_tag & 0xFFFFFFu)] : 0u;
+            place_step(h0, req0, p < w_hi);
+            h0 = h1;
+            h1 = h2;
+            req0 = req1;
+        }
     }
+    __syncthreads();  // (the records of this bucket are written: the first of every segment is read back below)
+    GS_STAMP(3)
+    // ---- the cells, second half: the limit id comes with the segment's first hit -------------------------------
+    u32 ridx[RES];
+#pragma unroll
+    for (int q = 0; q < RES; ++q)
+        if (re[q] != 0xFFFFFFFFu) ridx[q] = __builtin_nontemporal_load(&A.s_hits[lo + eoff[re[q]]].idx);
+    u32 rlim[RES];
+#pragma unroll
+    for (int q = 0; q < RES; ++q)
+        if (re[q] != 0xFFFFFFFFu) rlim[q] = A.hits[ridx[q]].limit;
+#pragma unroll
+    for (int q = 0; q < RES; ++q)
+        if (re[q] != 0xFFFFFFFFu)
+            A.seg_info[lo + eoff[re[q]]] = gen_resolve_from(A, ekey[re[q]], rlim[q], etot[re[q]], ra[q], rb[q]);
+    for (u32 k = tid + RES * GS_BLOCK; k < n_act; k += GS_BLOCK) {  // (a bucket with more than 512 distinct cells)
+        const u32 e = elist[k];
+        const u32 seg = lo + eoff[e];
+        const u32 idx = __builtin_nontemporal_load(&A.s_hits[seg].idx);
+        A.seg_info[seg] = gen_resolve(A, ekey[e], A.hits[idx].limit, etot[e]);
+    }
+    if (A.trace) {
+        __syncthreads();
+        GS_STAMP(4)
+    }
+#undef GS_STAMP
 }
 
 // Is the request admitted by the previous round?  (round 0: everything is.)
@@ -367,23 +467,49 @@ __device__ __forceinline__ bool gen_admitted(const GenArgs& A, const uint8_t* __
 
 // ---------------------------------------------------------------------------------------------
 // k_gen_admit: per request, the AND of its hits' pass flags of the previous round (coalesced: a request's
-// flags are contiguous) — what k_gen_hot_sum / k_gen_round of this round read once per hit
+// flags are contiguous) — what k_gen_piece_sum / k_gen_round of this round read once per hit.  It is also where
+// the fixpoint is detected: a round whose admitted set equals the one of the round before would reproduce that
+// round's flags, so it does not have to run (changed[write_slot] stays 0 and everything enqueued behind returns
+// at once).  Round 0 admitted every request.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gen_admit(GenArgs A, u32 round, u32 check_slot) {
-    if (A.pst->err || A.gst->overflow) return;
-    if (check_slot && !A.gst->changed[check_slot]) return;
+__global__ __launch_bounds__(256) void k_gen_admit(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
+    if (A.pst->err || A.gst->overflow || round == 0) return;
+    if (check_slot && !A.gst->changed[check_slot]) return;  // converged already
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.gst->last_slot = write_slot;
+        A.gst->last_round = round - 1;  // the flags in force unless this round runs (the status block may be fresh:
+                                        // the host clears it between groups of rounds)
+    }
     const u32 r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= A.n_req || round == 0) return;
-    const uint8_t* pass_prev = A.pass[(round - 1) & 1u];
-    const u32 b = A.req_off ? A.req_off[A.req0 + r] - A.hit0 : r;
-    const u32 e = A.req_off ? A.req_off[A.req0 + r + 1] - A.hit0 : r + 1;
-    uint8_t adm = 1;
-    for (u32 q = b; q < e; ++q)
-        if (!pass_prev[q]) {
-            adm = 0;
-            break;
-        }
-    A.admitted[r] = adm;
+    bool differs = false;
+    if (r < A.n_req) {
+        const uint8_t* pass_prev = A.pass[(round - 1) & 1u];
+        const u32 b = A.req_off ? A.req_off[A.req0 + r] - A.hit0 : r;
+        const u32 e = A.req_off ? A.req_off[A.req0 + r + 1] - A.hit0 : r + 1;
+        uint8_t adm = 1;
+        for (u32 q = b; q < e; ++q)
+            if (!pass_prev[q]) {
+                adm = 0;
+                break;
+            }
+        const uint8_t before = round == 1 ? (uint8_t)1 : A.admitted[r];
+        differs = adm != before;
+        A.admitted[r] = adm;
+    }
+    // Thousands of workgroups may have something to report, and one word that all of them read or write costs
+    // ~3 ns apiece in the L2 (measured: 48 us for this kernel): one flag per workgroup, folded by k_gen_admit_fold.
+    const int any = __syncthreads_or(differs ? 1 : 0);
+    if (threadIdx.x == 0) A.adm_diff[blockIdx.x] = any ? 1u : 0u;
+}
+
+// changed[write_slot] = OR of the workgroups' flags of the k_gen_admit before it.
+__global__ __launch_bounds__(1024) void k_gen_admit_fold(GenArgs A, u32 n_blocks, u32 round, u32 check_slot, u32 write_slot) {
+    if (A.pst->err || A.gst->overflow || round == 0) return;
+    if (check_slot && !A.gst->changed[check_slot]) return;
+    u32 any = 0;
+    for (u32 b = threadIdx.x; b < n_blocks; b += 1024) any |= A.adm_diff[b];
+    any = __syncthreads_or((int)any) ? 1u : 0u;
+    if (threadIdx.x == 0) A.gst->changed[write_slot] = any;
 }
 
 __device__ __forceinline__ u64 gen_delta(const GenArgs& A, const SHit& h) {
@@ -401,49 +527,52 @@ __device__ __forceinline__ Run run_join(const Run& a, const Run& b) {  // a then
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gen_hot_sum: what the admitted hits of every chunk of a hot segment add (the carries of k_gen_round)
+// k_gen_piece_sum: the sorted batch is cut into PIECES of GS_MAX consecutive positions, whatever bucket or
+// segment they fall into.  A segment that crosses a piece boundary needs, in the later piece, what its admitted
+// hits in the earlier pieces add: piece_sum[k] = that sum for the segment that is open at the end of piece k
+// (only computed when the segment really goes on in piece k + 1).  Most tails are a handful of hits; the
+// pieces inside a heavy key's segment are summed whole.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GS_BLOCK) void k_gen_hot_sum(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
+__global__ __launch_bounds__(GS_BLOCK) void k_gen_piece_sum(GenArgs A, u32 round, u32 check_slot) {
     __shared__ Run s_run[GS_WAVES];
-    (void)write_slot;
     if (A.pst->err || A.gst->overflow) return;
     if (check_slot && !A.gst->changed[check_slot]) return;  // converged: the round before changed nothing
     const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const u32 n_chunks = A.hot_param[HOT_MAX].chunk0;
-    for (u32 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const u32 hb = A.chunk_tab[c];
-        const HotParam hp = A.hot_param[hb];
-        const u32 first = hp.lo + (c - hp.chunk0) * HOT_CHUNK;
-        Run acc{0, 0, 0};
+    const u32 k = blockIdx.x;
+    const u32 lo = k * (u32)GS_MAX, hi = lo + (u32)GS_MAX;
+    if (hi >= A.n_hits) return;                     // the last piece has no successor
+    const u32 t = A.s_hits[hi].seg;                 // the segment the next piece opens with ...
+    if (t == hi) return;                            // ... starts there: nothing is carried over
+    const u32 first = t > lo ? t : lo;              // its hits inside this piece: [first, hi)
+    constexpr int PER = GS_MAX / GS_BLOCK;
+    Run acc{0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < HOT_CHUNK / GS_BLOCK; ++u) {
-            const u32 j = first + tid * (HOT_CHUNK / GS_BLOCK) + u;  // consecutive hits per thread: `last` is in order
-            if (j >= hp.hi) continue;
-            const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + j);
-            const SHit h{v.x, v.y, v.z, v.w};
-            if (gen_admitted(A, pass_prev, h.req)) {
-                const u64 d = gen_delta(A, h);
-                acc = run_join(acc, Run{d, d, 1u});
-            }
+    for (int u = 0; u < PER; ++u) {
+        const u32 j = lo + tid * PER + u;  // consecutive hits per thread: `last` is in order
+        if (j < first) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + j);
+        const SHit h{v.x, v.y, v.z, v.w};
+        if (gen_admitted(A, pass_prev, h.req)) {
+            const u64 d = gen_delta(A, h);
+            acc = run_join(acc, Run{d, d, 1u});
         }
-        // in-order reduction over the lanes, then the waves
+    }
+    // in-order reduction over the lanes, then the waves
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            Run o;
-            o.sum = __shfl_up(acc.sum, off);
-            o.last = __shfl_up(acc.last, off);
-            o.cnt = __shfl_up(acc.cnt, off);
-            if ((int)lane >= off) acc = run_join(o, acc);
-        }
-        __syncthreads();
-        if (lane == 63) s_run[w] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            Run t = s_run[0];
-            for (int ww = 1; ww < GS_WAVES; ++ww) t = run_join(t, s_run[ww]);
-            A.piece_sum[c] = SegTot{t.sum, t.last, t.cnt, 0u};
-        }
+    for (int off = 1; off < 64; off <<= 1) {
+        Run o;
+        o.sum = __shfl_up(acc.sum, off);
+        o.last = __shfl_up(acc.last, off);
+        o.cnt = __shfl_up(acc.cnt, off);
+        if ((int)lane >= off) acc = run_join(o, acc);
+    }
+    if (lane == 63) s_run[w] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        Run r = s_run[0];
+        for (int ww = 1; ww < GS_WAVES; ++ww) r = run_join(r, s_run[ww]);
+        A.piece_sum[k] = SegTot{r.sum, r.last, r.cnt, 0u};
     }
 }
 
@@ -541,7 +670,6 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
         S.out_seg = last_seg;
     }
     // ---- per hit -------------------------------------------------------------------------------------
-    u32 changed = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         if (!ok[i]) continue;
@@ -567,7 +695,6 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
         const u64 sum = v + d[i];  // wraps like the reference's release build (in_memory.rs:88)
         const bool pass = A.update_mode ? true : sum <= Lm.max_value;
         pass_cur[h[i].idx] = pass ? 1 : 0;
-        if (pass_prev && pass_prev[h[i].idx] != (pass ? 1 : 0)) changed = 1;
         if (A.load) {
             A.remaining[h[i].idx] = pass ? Lm.max_value - sum : 0ull;  // checked_sub().unwrap_or_default(), :88-89
             u64 ttl;
@@ -582,8 +709,6 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
             A.seg_tot[h[i].seg] = SegTot{tot.sum, tot.last, tot.cnt, 0u};
         }
     }
-    if (!pass_prev && !A.update_mode) changed = 1;  // (round 0 has no previous flags to compare with)
-    if (__ballot(changed != 0) && lane == 0) atomicOr(&S.changed, 1u);
 }
 
 __global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
@@ -593,61 +718,49 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u3
     const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
     uint8_t* pass_cur = A.pass[round & 1u];
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    if (tid == 0) {
-        S.changed = 0;
-        if (blockIdx.x == 0) {
-            A.gst->last_round = round;
+    if (tid == 0 && blockIdx.x == 0) {
+        A.gst->last_round = round;
+        atomicAdd(&A.gst->rounds_run, 1u);
+        if (round == 0) {  // no k_gen_admit before round 0: round 1 always follows
             A.gst->last_slot = write_slot;
-            atomicAdd(&A.gst->rounds_run, 1u);
+            A.gst->changed[write_slot] = 1u;
         }
     }
+    // One workgroup per piece of GS_MAX positions (k_gen_piece_sum): every piece of every bucket at once — a
+    // bucket that skew made long no longer sets the duration of the round.
+    const u32 k = blockIdx.x;
+    const u32 lo = k * (u32)GS_MAX;
+    const u32 n = A.n_hits - lo < (u32)GS_MAX ? A.n_hits - lo : (u32)GS_MAX;
+    const u32 head = A.s_hits[lo].seg;  // (uniform)
+    u32 carry_seg = 0xFFFFFFFEu;
+    if (tid == 0) S.carry = Run{0, 0, 0};
     __syncthreads();
-    if (blockIdx.x < A.nb) {
-        // a hash bucket, GS_MAX hits at a time: a segment that crosses into the next piece carries its open run
-        const uint2 r = A.ranges[blockIdx.x];
-        const u32 L = r.y - r.x;
-        Run carry{0, 0, 0};
-        u32 carry_seg = 0xFFFFFFFEu;
-        for (u32 first = 0; first < L; first += GS_MAX) {
-            gen_round_piece(A, pass_prev, pass_cur, r.x + first, L - first < (u32)GS_MAX ? L - first : (u32)GS_MAX, carry,
-                            carry_seg, S);
-            __syncthreads();
-            carry = S.out_run;
-            carry_seg = S.out_seg;
-        }
-    } else {
-        const u32 n_chunks = A.hot_param[HOT_MAX].chunk0;
-        for (u32 c = blockIdx.x - A.nb; c < n_chunks; c += gridDim.x - A.nb) {
-            const u32 hb = A.chunk_tab[c];
-            const HotParam hp = A.hot_param[hb];
-            const u32 first = hp.lo + (c - hp.chunk0) * HOT_CHUNK;
-            const u32 n = hp.hi - first < (u32)HOT_CHUNK ? hp.hi - first : (u32)HOT_CHUNK;
-            // what the admitted hits of the segment's earlier chunks add: in-order fold of their sums
-            __syncthreads();
-            if (tid < 64) {
-                const u32 n_before = c - hp.chunk0;
-                const u32 per = (n_before + 63) / 64;
-                Run acc{0, 0, 0};
-                for (u32 q = lane * per; q < (lane + 1) * per && q < n_before; ++q) {
-                    const SegTot t = A.piece_sum[hp.chunk0 + q];
-                    acc = run_join(acc, Run{t.sum, t.last, t.cnt});
-                }
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    Run o;
-                    o.sum = __shfl_up(acc.sum, off);
-                    o.last = __shfl_up(acc.last, off);
-                    o.cnt = __shfl_up(acc.cnt, off);
-                    if ((int)lane >= off) acc = run_join(o, acc);
-                }
-                if (lane == 63) S.carry = acc;
+    if (head < lo) {
+        // the piece opens inside a segment: what the segment's admitted hits in the pieces before add = the
+        // in-order fold of those pieces' sums (all of them end inside this segment)
+        carry_seg = head;
+        if (tid < 64) {
+            const u32 j0 = head / (u32)GS_MAX;
+            const u32 n_before = k - j0;
+            const u32 per = (n_before + 63) / 64;
+            Run acc{0, 0, 0};
+            for (u32 q = lane * per; q < (lane + 1) * per && q < n_before; ++q) {
+                const SegTot t = A.piece_sum[j0 + q];
+                acc = run_join(acc, Run{t.sum, t.last, t.cnt});
             }
-            __syncthreads();
-            gen_round_piece(A, pass_prev, pass_cur, first, n, S.carry, hp.lo, S);
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                Run o;
+                o.sum = __shfl_up(acc.sum, off);
+                o.last = __shfl_up(acc.last, off);
+                o.cnt = __shfl_up(acc.cnt, off);
+                if ((int)lane >= off) acc = run_join(o, acc);
+            }
+            if (lane == 63) S.carry = acc;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0 && S.changed) atomicOr(&A.gst->changed[write_slot], 1u);
+    gen_round_piece(A, pass_prev, pass_cur, lo, n, S.carry, carry_seg, S);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -667,6 +780,8 @@ __global__ __launch_bounds__(256) void k_gen_final(GenArgs A) {
         }
     A.verdict[r] = first < 0 ? 0 : 1;
     if (A.first_limited) A.first_limited[r] = first < 0 ? -1 : (int32_t)(A.hit0 + (u32)first);  // index in the caller's batch
+    // the limit whose name the reference reports (Authorization::Limited(name), in_memory.rs:91-93,97-99)
+    if (A.limited_limit) A.limited_limit[r] = first < 0 ? -1 : (int32_t)(A.hits[first].limit & ~SIMPLE_FLAG);
     if (A.mark_reached) {
         // !load_counters: the walk stops at its first limited counter (in_memory.rs:109-113,129-133)
         const u32 stop = first < 0 ? e : (u32)first + 1;

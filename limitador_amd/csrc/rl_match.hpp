@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void k_match(const u32* __restrict__ req_ns, c
                 if ((L.n_vars != 0u) != (pass == 1)) continue;
                 u32 vars[MATCH_MAX_VARS];
                 if (!limit_applies(L, Cd, R, vars)) continue;
+                if (vars[0] >> MATCH_VAL_BITS || vars[1] >> MATCH_VAL_BITS) atomicOr(&st->err, ERRBIT_RESERVED_KEY);
                 if (FILL) {
-                    if (vars[0] >> MATCH_VAL_BITS || vars[1] >> MATCH_VAL_BITS) atomicOr(&st->err, ERRBIT_RESERVED_KEY);
                     Hit h;
                     h.key = match_key(L.limit & ~SIMPLE_FLAG, L.n_vars, vars[0], vars[1]);
                     h.limit = L.limit;
@@ -166,6 +166,136 @@ __global__ __launch_bounds__(256) void k_match(const u32* __restrict__ req_ns, c
         atomicOr(&st->err, ERRBIT_BAD_LIMIT);  // unknown namespace id
     }
     if (!FILL) count[r] = k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same evaluation for the tables limit files produce: at most MATCH_SLOTS distinct descriptor keys in all
+// conditions and variables, at most 64 limits per namespace, the table in LDS.  The host renames the keys to
+// SLOTS; a request's entries are reduced ONCE to "value of slot s" (static register indexing, no scratch), the
+// conditions read slots, and the count pass leaves a bit mask of the limits that apply, so the fill pass
+// evaluates nothing twice.  (The generic k_match above: 105 + 128 us per 1 M requests x 8 limits, its entry
+// arrays in scratch memory.)
+// ---------------------------------------------------------------------------------------------
+constexpr u32 MATCH_SLOTS = 8;
+struct MatchSlots {
+    u32 key[MATCH_SLOTS];
+    u32 n;
+};
+struct MatchLimitF {
+    u32 limit;     // limit id | SIMPLE_FLAG
+    u32 cond_off;  // first condition in the MatchCondF array
+    u32 shape;     // n_cond | n_vars << 8 | slot of variable 0 << 16 | slot of variable 1 << 24
+};
+struct MatchCondF {
+    u32 slot_op;  // slot | op << 8
+    u32 value;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_match_fast(const u32* __restrict__ req_ns, const u32* __restrict__ ent_off,
+                                                    const u32* __restrict__ ent_key, const u32* __restrict__ ent_val,
+                                                    const u32* __restrict__ req_delta, u32 n_req,
+                                                    const MatchLimitF* __restrict__ limits, u32 n_limits,
+                                                    const u32* __restrict__ ns_off, u32 n_ns,
+                                                    const MatchCondF* __restrict__ conds, u32 n_conds, MatchSlots slots,
+                                                    u32* __restrict__ count, unsigned long long* __restrict__ mask,
+                                                    const u32* __restrict__ hit_off, Hit* __restrict__ hits, Status* st) {
+    __shared__ MatchLimitF s_l[MATCH_LDS_LIMITS];
+    __shared__ MatchCondF s_c[MATCH_LDS_CONDS];
+    __shared__ u32 s_ns[MATCH_LDS_NS + 1];
+    __shared__ u32 s_v[256][MATCH_SLOTS + 1];  // (+1: rows on different banks)
+    const u32 tid = threadIdx.x;
+    for (u32 q = tid; q < n_limits; q += 256) s_l[q] = limits[q];
+    for (u32 q = tid; q < n_conds; q += 256) s_c[q] = conds[q];
+    for (u32 q = tid; q <= n_ns; q += 256) s_ns[q] = ns_off[q];
+    __syncthreads();
+    const u32 r = blockIdx.x * 256 + tid;
+    if (r >= n_req) return;
+    const u32 ns = req_ns[r];
+    const u32 b = ent_off[r], n = ent_off[r + 1] - b;
+    // value of every slot: the FIRST entry with the slot's key wins, like the first insertion into the
+    // reference's context map
+    u32 v[MATCH_SLOTS];
+#pragma unroll
+    for (u32 sl = 0; sl < MATCH_SLOTS; ++sl) v[sl] = MATCH_NO_VALUE;
+#pragma unroll
+    for (u32 q = 0; q < MATCH_REG_ENTRIES; ++q) {
+        if (q < n) {
+            const u32 k = ent_key[b + q], val = ent_val[b + q];
+#pragma unroll
+            for (u32 sl = 0; sl < MATCH_SLOTS; ++sl)
+                if (sl < slots.n && k == slots.key[sl] && v[sl] == MATCH_NO_VALUE) v[sl] = val;
+        }
+    }
+    for (u32 q = MATCH_REG_ENTRIES; q < n; ++q) {
+        const u32 k = ent_key[b + q], val = ent_val[b + q];
+#pragma unroll
+        for (u32 sl = 0; sl < MATCH_SLOTS; ++sl)
+            if (sl < slots.n && k == slots.key[sl] && v[sl] == MATCH_NO_VALUE) v[sl] = val;
+    }
+#pragma unroll
+    for (u32 sl = 0; sl < MATCH_SLOTS; ++sl) s_v[tid][sl] = v[sl];
+    if (ns >= n_ns) {
+        atomicOr(&st->err, ERRBIT_BAD_LIMIT);  // unknown namespace id
+        if (!FILL) {
+            count[r] = 0;
+            mask[r] = 0ull;
+        }
+        return;
+    }
+    const u32 l0 = s_ns[ns], l1 = s_ns[ns + 1];
+    if (!FILL) {
+        unsigned long long m = 0ull;
+        u32 k = 0;
+        for (u32 li = l0; li < l1; ++li) {
+            const MatchLimitF L = s_l[li];
+            const u32 nc = L.shape & 0xFFu, nv = (L.shape >> 8) & 0xFFu;
+            bool ok = true;
+            for (u32 c = 0; c < nc; ++c) {
+                const MatchCondF cd = s_c[L.cond_off + c];
+                const u32 val = s_v[tid][cd.slot_op & 0xFFu];
+                // NoSuchKey -> false, whatever the operator (limit/cel.rs:321-338)
+                ok = ok && val != MATCH_NO_VALUE && ((val == cd.value) == ((cd.slot_op >> 8) == 0u));
+            }
+            if (nv > 0) ok = ok && s_v[tid][(L.shape >> 16) & 0xFFu] != MATCH_NO_VALUE;  // limit/cel.rs:176-191
+            if (nv > 1) ok = ok && s_v[tid][(L.shape >> 24) & 0xFFu] != MATCH_NO_VALUE;
+            if (ok) {
+                // a value id that does not fit the packed key keeps the host path: said here, so that the fill pass
+                // has nothing left to refuse
+                if ((nv > 0 && s_v[tid][(L.shape >> 16) & 0xFFu] >> MATCH_VAL_BITS) ||
+                    (nv > 1 && s_v[tid][(L.shape >> 24) & 0xFFu] >> MATCH_VAL_BITS))
+                    atomicOr(&st->err, ERRBIT_RESERVED_KEY);
+                m |= 1ull << (li - l0);
+                ++k;
+            }
+        }
+        count[r] = k;
+        mask[r] = m;
+    } else {
+        const unsigned long long m = mask[r];
+        const u32 delta = req_delta[r];
+        const u32 out = hit_off[r];
+        u32 k = 0;
+        for (int pass = 0; pass < 2; ++pass) {  // limits without variables first (in_memory.rs:105,121)
+            unsigned long long mm = m;
+            while (mm) {
+                const u32 i = (u32)__builtin_ctzll(mm);
+                mm &= mm - 1ull;
+                const MatchLimitF L = s_l[l0 + i];
+                const u32 nv = (L.shape >> 8) & 0xFFu;
+                if ((nv != 0u) != (pass == 1)) continue;
+                const u32 v0 = nv > 0 ? s_v[tid][(L.shape >> 16) & 0xFFu] : 0u;
+                const u32 v1 = nv > 1 ? s_v[tid][(L.shape >> 24) & 0xFFu] : 0u;
+                if (v0 >> MATCH_VAL_BITS || v1 >> MATCH_VAL_BITS) atomicOr(&st->err, ERRBIT_RESERVED_KEY);
+                Hit h;
+                h.key = match_key(L.limit & ~SIMPLE_FLAG, nv, v0, v1);
+                h.limit = L.limit;
+                h.delta = delta;
+                hits[out + k] = h;
+                ++k;
+            }
+        }
+    }
 }
 
 // first_limited (index into hits) -> the limit id whose name the reference reports

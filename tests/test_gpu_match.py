@@ -55,8 +55,12 @@ def expected_counters(limits, ns, ctx):
     return [c for c in out if not c[1].is_qualified()] + [c for c in out if c[1].is_qualified()]
 
 
+@pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("seed,load", [(1, False), (2, True), (3, False)])
-def test_match_table_against_counters_that_apply(make_engine, seed, load):
+def test_match_table_against_counters_that_apply(make_engine, seed, load, generic, monkeypatch):
+    # the slot form of the table (k_match_fast: what limit files compile to) and the generic kernel (k_match)
+    if generic:
+        monkeypatch.setenv("RL_MATCH_GENERIC", "1")
     rng = np.random.default_rng(seed)
     methods, paths = ["GET", "POST", "PUT"], ["/a", "/b", "/json"]
     limits = []
@@ -126,6 +130,60 @@ def test_match_table_against_counters_that_apply(make_engine, seed, load):
             assert np.array_equal(got["remaining"], r) and np.array_equal(got["expires_in_us"], e)
         now += int(rng.integers(0, 2 * SEC))
     assert_same_state(eng, orc, n_simple_expected=n_simple)
+
+
+def test_slot_form_and_generic_matcher_agree_on_long_and_repeated_entries(make_engine, monkeypatch):
+    """Requests with up to 14 entries: keys no limit mentions, keys repeated with another value (the first entry
+    wins at this level; the RLS ingest has already reduced a repeated key to its last value), entries beyond the
+    eight the kernels keep in registers; plus an unknown namespace id.  Differential: both kernels, same arrays."""
+    rng = np.random.default_rng(77)
+    keys = [f"k{i}" for i in range(6)]
+    limits = []
+    for ns in ("a", "b"):
+        for j in range(10):
+            conds = [f"{keys[int(rng.integers(0, 6))]} {'==' if rng.random() < 0.6 else '!='} 'v{int(rng.integers(0, 3))}'"
+                     for _ in range(int(rng.integers(0, 3)))]
+            variables = tuple(sorted(set(keys[int(rng.integers(0, 6))] for _ in range(int(rng.integers(0, 3)))))) if j else ()
+            lim = Limit(ns, int(rng.integers(1, 30)), 60, conds, variables, name=None)
+            if lim not in limits:
+                limits.append(lim)
+    limits.sort(key=lambda l: l.namespace)
+    n_req = 4000
+    req_ns, ent_off, ent_key, ent_val, delta = [], [0], [], [], []
+    key_id, val_id = Dictionary(), Dictionary()
+    for k in keys + ["junk0", "junk1", "junk2"]:
+        key_id(k)
+    for v in range(5):
+        val_id(f"v{v}")
+    for _ in range(n_req):
+        req_ns.append(int(rng.integers(0, 2)))
+        for _e in range(int(rng.integers(0, 15))):
+            ent_key.append(int(rng.integers(0, 9)))
+            ent_val.append(int(rng.integers(0, 5)))
+        ent_off.append(len(ent_key))
+        delta.append(1)
+    results = []
+    for generic in (True, False):
+        if generic:
+            monkeypatch.setenv("RL_MATCH_GENERIC", "1")
+        else:
+            monkeypatch.delenv("RL_MATCH_GENERIC")
+        eng = make_engine(capacity_cells=1 << 16, max_batch_hits=1 << 16)
+        kid, vid = Dictionary(), Dictionary()
+        kid.ids, vid.ids = dict(key_id.ids), dict(val_id.ids)
+        compile_table(eng, limits, kid, vid)
+        assert kid.ids == key_id.ids and vid.ids == val_id.ids
+        for i, l in enumerate(limits):
+            if not l.variables:
+                eng.add_counter(i | RL_SIMPLE, eng.match_key(i))
+        got = [eng.match_and_check(req_ns, ent_off, ent_key, ent_val, delta, NOW + q * SEC) for q in range(2)]
+        results.append(got)
+        with pytest.raises(Exception):
+            eng.match_and_check([5], [0, 0], [], [], [1], NOW)  # unknown namespace id
+    for a, b in zip(*results):
+        assert len(a["hits"]) > n_req
+        for field in ("req_off", "hits", "verdict", "limited_limit"):
+            assert np.array_equal(a[field], b[field]), field
 
 
 def test_match_table_rejects_what_must_stay_on_the_host(make_engine):
