@@ -74,7 +74,7 @@ struct rl_engine {
     SegInfo* d_g_seginfo = nullptr;
     SegTot* d_g_segtot = nullptr;
     SegTot* d_g_piece = nullptr;
-    u32* d_g_hitseg = nullptr;
+    u32* d_g_reqstop = nullptr;     // [max_batch] per request
     uint8_t* d_g_reached = nullptr;
     u32* d_g_admdiff = nullptr;     // [gen_cap / 256 + 1]
     uint8_t* d_g_pass = nullptr;    // [2][gen_cap]
@@ -622,7 +622,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     A.seg_info = e->d_g_seginfo;
     A.seg_tot = e->d_g_segtot;
     A.piece_sum = e->d_g_piece;
-    A.hit_seg = mark ? e->d_g_hitseg : nullptr;
+    A.req_stop = e->d_g_reqstop;
     A.reached = e->d_g_reached;
     A.pass[0] = e->d_g_pass;
     A.pass[1] = e->d_g_pass + e->gen_cap;
@@ -650,7 +650,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         HIP_TRY(e, hipMemcpyAsync(t.data(), e->d_gen_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(e, hipStreamSynchronize(st));
         unsigned long long t_min = ~0ull, t_max = 0;
-        double ph[4] = {0, 0, 0, 0};
+        double ph[4] = {0, 0, 0, 0}, p2_issue = 0;
         u32 live = 0, longest = 0, longest_b = 0;
         double longest_us = 0;
         for (u32 b = 0; b < nb; ++b) {
@@ -660,6 +660,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
             t_min = std::min(t_min, q[0]);
             t_max = std::max(t_max, q[4]);
             for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]) / 100.0;  // wall clock: 100 MHz
+            p2_issue += (double)(q[5] - q[2]) / 100.0;
             const double us = (double)(q[4] - q[0]) / 100.0;
             if (us > longest_us) {
                 longest_us = us;
@@ -668,9 +669,9 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
             }
         }
         if (live)
-            std::fprintf(stderr, "[gen] k_gen_sort: %u buckets, span %.1f us; mean per workgroup: init+pass1 %.1f, offsets %.1f, pass2 %.1f, resolve %.1f us; "
+            std::fprintf(stderr, "[gen] k_gen_sort: %u buckets, span %.1f us; mean per workgroup: init+pass1 %.1f, offsets %.1f, pass2 %.1f (wave 0 done issuing after %.1f), resolve %.1f us; "
                          "slowest: bucket %u with %u hits, %.1f us\n", live, (double)(t_max - t_min) / 100.0, ph[0] / live, ph[1] / live,
-                         ph[2] / live, ph[3] / live, longest_b, longest, longest_us);
+                         ph[2] / live, p2_issue / live, ph[3] / live, longest_b, longest, longest_us);
         A.trace = nullptr;
     }
     // ---- fixpoint rounds: a few at a time, each returning at once if the one before changed nothing; then
@@ -698,6 +699,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
             k_gen_round<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A, round, run_if, q + 1);
         }
         k_gen_final<<<cdiv(n_req, 256), 256, 0, st>>>(A);
+        if (mark) k_gen_reach<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A);
         k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A);
         const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
         k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
@@ -1011,7 +1013,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_g_seginfo, (size_t)e->gen_cap * sizeof(SegInfo));
     ALLOC(e->d_g_segtot, (size_t)e->gen_cap * sizeof(SegTot));
     ALLOC(e->d_g_piece, ((size_t)e->gen_cap / GS_MAX + 8) * sizeof(SegTot));
-    ALLOC(e->d_g_hitseg, (size_t)e->gen_cap * sizeof(u32));
+    ALLOC(e->d_g_reqstop, mb * sizeof(u32));
     ALLOC(e->d_g_reached, (size_t)e->gen_cap);
     ALLOC(e->d_g_pass, 2 * (size_t)e->gen_cap);
     ALLOC(e->d_g_admdiff, (mb / 256 + 2) * sizeof(u32));
@@ -1090,7 +1092,7 @@ void rl_engine_destroy(rl_engine* e) {
         if (pt) (void)hipFree(pt);
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
                     e->d_remaining, e->d_expires, e->d_status,   e->d_total,    e->d_route_cnt,
-                    e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_hitseg,
+                    e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,

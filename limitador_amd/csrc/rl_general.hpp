@@ -118,7 +118,7 @@ struct GenArgs {
     SegInfo* seg_info;
     SegTot* seg_tot;
     SegTot* piece_sum;       // per hot chunk
-    u32* hit_seg;
+    u32* req_stop;           // per request: its walk covers the hits [.., req_stop) (mark_reached; k_gen_final -> k_gen_reach)
     uint8_t* reached;        // per segment
     uint8_t* pass[2];
     uint8_t* admitted;       // per request, by the previous round (k_gen_admit)
@@ -217,16 +217,24 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
             const u32 hb = A.chunk_tab[c];
             const HotParam hp = A.hot_param[hb];
             const u32 first = hp.lo + (c - hp.chunk0) * HOT_CHUNK;
+            constexpr int CU = HOT_CHUNK / GS_BLOCK;
+            BHit hh[CU];
+            u32 rq[CU];
 #pragma unroll
-            for (int u = 0; u < HOT_CHUNK / GS_BLOCK; ++u) {
+            for (int u = 0; u < CU; ++u) {  // (unconditional loads from clamped positions: all in flight together)
+                const u32 j = first + u * GS_BLOCK + tid;
+                hh[u] = load_bhit(A.b_hits, j < hp.hi ? j : hp.hi - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) rq[u] = A.hit_req ? A.hit_req[A.hit0 + (hh[u].idx_tag & 0xFFFFFFu)] : 0u;
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
                 const u32 j = first + u * GS_BLOCK + tid;
                 if (j >= hp.hi) continue;
-                const BHit h = load_bhit(A.b_hits, j);
-                const u32 idx = h.idx_tag & 0xFFFFFFu;
-                const u32 req = A.hit_req ? A.hit_req[A.hit0 + idx] - A.req0 : idx;
-                *reinterpret_cast<uint4*>(A.s_hits + j) = make_uint4(hp.lo, req, idx, h.delta);
-                if (A.hit_seg) A.hit_seg[idx] = hp.lo;
-                if ((h.idx_tag >> 24) != limit_fold(hp.limit)) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
+                const u32 idx = hh[u].idx_tag & 0xFFFFFFu;
+                const u32 req = A.hit_req ? rq[u] - A.req0 : idx;
+                *reinterpret_cast<uint4*>(A.s_hits + j) = make_uint4(hp.lo, req, idx, hh[u].delta);
+                if ((hh[u].idx_tag >> 24) != limit_fold(hp.limit)) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
             }
             if (first == hp.lo && tid == 0)
                 A.seg_info[hp.lo] = gen_resolve(A, A.b_hits[hp.lo].key, hp.limit, hp.hi - hp.lo);
@@ -252,9 +260,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     const bool resident = steps <= 2;
     BHit hA{}, hB{};
     const bool okA = w_lo + lane < w_hi, okB = steps > 1 && w_lo + 64 + lane < w_hi;
+    // (Loads that sit in a divergent `if` are waited for where the branch ends — the value has to be merged into
+    // its register there — so every prefetch below is UNCONDITIONAL, from a clamped, always valid position.)
     if (resident) {
-        if (okA) hA = load_bhit(A.b_hits, lo + w_lo + lane);
-        if (okB) hB = load_bhit(A.b_hits, lo + w_lo + 64 + lane);
+        hA = load_bhit(A.b_hits, lo + (w_lo + lane < L ? w_lo + lane : L - 1));
+        hB = load_bhit(A.b_hits, lo + (w_lo + 64 + lane < L ? w_lo + 64 + lane : L - 1));
     }
     for (u32 e = tid; e < (u32)GS_E; e += GS_BLOCK) {
         ekey[e] = TAG_EMPTY;
@@ -269,8 +279,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     __syncthreads();
     u32 rA = 0, rB = 0;
     if (resident && A.hit_req) {
-        if (okA) rA = A.hit_req[A.hit0 + (hA.idx_tag & 0xFFFFFFu)];
-        if (okB) rB = A.hit_req[A.hit0 + (hB.idx_tag & 0xFFFFFFu)];
+        rA = A.hit_req[A.hit0 + (hA.idx_tag & 0xFFFFFFu)];
+        rB = A.hit_req[A.hit0 + (hB.idx_tag & 0xFFFFFFu)];
     }
     // ---- pass 1: the bucket's cells (LDS hash), hits per (wave, cell) ---------------------------------
     auto count_step = [&](const BHit& h, bool ok) {
@@ -379,15 +389,15 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     constexpr int RES = 2;  // cells per thread resolved with their loads in flight together (more: one by one below)
     u32 re[RES];
     uint4 ra[RES], rb[RES];
+    bool rok[RES];
 #pragma unroll
     for (int q = 0; q < RES; ++q) {
         const u32 k = tid + q * GS_BLOCK;
-        re[q] = k < n_act ? (u32)elist[k] : 0xFFFFFFFFu;
-        if (k < n_act) {
-            const uint4* c = reinterpret_cast<const uint4*>(&A.table[slot_of(ekey[re[q]], A.seed, A.log2cap)]);
-            ra[q] = c[0];
-            rb[q] = c[1];
-        }
+        rok[q] = k < n_act;
+        re[q] = (u32)elist[rok[q] ? k : 0u];  // (n_act >= 1: the bucket is not empty)
+        const uint4* c = reinterpret_cast<const uint4*>(&A.table[slot_of(ekey[re[q]], A.seed, A.log2cap)]);
+        ra[q] = c[0];
+        rb[q] = c[1];
     }
     // ---- pass 2: placement (the same walk: stable rank inside (wave, cell)) ----------------------------------
     auto place_step = [&](const BHit& h, u32 req_abs, bool ok) {
@@ -406,7 +416,6 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
             const u32 idx = h.idx_tag & 0xFFFFFFu;
             const u32 req = A.hit_req ? req_abs - A.req0 : idx;
             *reinterpret_cast<uint4*>(A.s_hits + seg + in_seg) = make_uint4(seg, req, idx, h.delta);
-            if (A.hit_seg) A.hit_seg[idx] = seg;
             if ((h.idx_tag >> 24) != (u32)efold[ent]) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
         }
     };
@@ -432,21 +441,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
             req0 = req1;
         }
     }
+    GS_STAMP(5)
     __syncthreads();  // (the records of this bucket are written: the first of every segment is read back below)
     GS_STAMP(3)
     // ---- the cells, second half: the limit id comes with the segment's first hit -------------------------------
     u32 ridx[RES];
 #pragma unroll
-    for (int q = 0; q < RES; ++q)
-        if (re[q] != 0xFFFFFFFFu) ridx[q] = __builtin_nontemporal_load(&A.s_hits[lo + eoff[re[q]]].idx);
+    for (int q = 0; q < RES; ++q) ridx[q] = __builtin_nontemporal_load(&A.s_hits[lo + eoff[re[q]]].idx);
     u32 rlim[RES];
 #pragma unroll
-    for (int q = 0; q < RES; ++q)
-        if (re[q] != 0xFFFFFFFFu) rlim[q] = A.hits[ridx[q]].limit;
+    for (int q = 0; q < RES; ++q) rlim[q] = A.hits[ridx[q]].limit;
 #pragma unroll
     for (int q = 0; q < RES; ++q)
-        if (re[q] != 0xFFFFFFFFu)
-            A.seg_info[lo + eoff[re[q]]] = gen_resolve_from(A, ekey[re[q]], rlim[q], etot[re[q]], ra[q], rb[q]);
+        if (rok[q]) A.seg_info[lo + eoff[re[q]]] = gen_resolve_from(A, ekey[re[q]], rlim[q], etot[re[q]], ra[q], rb[q]);
     for (u32 k = tid + RES * GS_BLOCK; k < n_act; k += GS_BLOCK) {  // (a bucket with more than 512 distinct cells)
         const u32 e = elist[k];
         const u32 seg = lo + eoff[e];
@@ -547,16 +554,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_piece_sum(GenArgs A, u32 round
     const u32 first = t > lo ? t : lo;              // its hits inside this piece: [first, hi)
     constexpr int PER = GS_MAX / GS_BLOCK;
     Run acc{0, 0, 0};
+    if (lo + (tid + 1) * PER > first) {  // (a short tail: most threads have nothing to add, and wave-uniformly so)
+        uint4 v[PER];
+        uint8_t ad[PER];
+        u64 dl[PER];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const u32 j = lo + tid * PER + u;  // consecutive hits per thread: `last` is in order
-        if (j < first) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + j);
-        const SHit h{v.x, v.y, v.z, v.w};
-        if (gen_admitted(A, pass_prev, h.req)) {
-            const u64 d = gen_delta(A, h);
-            acc = run_join(acc, Run{d, d, 1u});
-        }
+        for (int u = 0; u < PER; ++u) v[u] = *reinterpret_cast<const uint4*>(A.s_hits + lo + tid * PER + u);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) ad[u] = pass_prev ? A.admitted[v[u].y] : (uint8_t)1;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) dl[u] = A.req_delta ? A.req_delta[A.req0 + v[u].y] : (u64)v[u].w;
+#pragma unroll
+        for (int u = 0; u < PER; ++u)  // consecutive hits per thread: `last` is in order
+            if (lo + tid * PER + u >= first && ad[u]) acc = run_join(acc, Run{dl[u], dl[u], 1u});
     }
     // in-order reduction over the lanes, then the waves
 #pragma unroll
@@ -602,19 +612,39 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
     bool ok[PER], adm[PER];
     u64 d[PER];
     Run pre[PER];  // what the admitted hits before this one, in its segment and inside this thread, add
+    // Everything a hit needs from memory is requested up front, for all of the thread's hits, from clamped (always
+    // valid) positions and with no divergent branch around the loads: a load inside an `if` is waited for where
+    // the branch ends, which turns the thread's four hits into four round trips in a row.
+    uint4 raw[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const u32 p = tid * PER + i;
         ok[i] = p < n;
-        adm[i] = false;
-        d[i] = 0;
-        h[i] = SHit{0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
-        if (ok[i]) {
-            const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + lo + p);
-            h[i] = SHit{v.x, v.y, v.z, v.w};
-            adm[i] = gen_admitted(A, pass_prev, h[i].req);
-            d[i] = gen_delta(A, h[i]);
-        }
+        raw[i] = *reinterpret_cast<const uint4*>(A.s_hits + lo + (ok[i] ? p : n - 1));
+    }
+    const u32 pos0 = lo + tid * PER;
+    const uint4 before = *reinterpret_cast<const uint4*>(A.s_hits + (pos0 ? pos0 - 1 : 0u));  // the record ahead of the thread's first
+    uint8_t adm_raw[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) adm_raw[i] = pass_prev ? A.admitted[raw[i].y] : (uint8_t)1;
+    u64 d_raw[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) d_raw[i] = A.req_delta ? A.req_delta[A.req0 + raw[i].y] : (u64)raw[i].w;
+    uint4 si_a[PER], si_b[PER];  // SegInfo of the hit's segment, as two 16-byte halves
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint4* sp = reinterpret_cast<const uint4*>(&A.seg_info[raw[i].x]);
+        si_a[i] = sp[0];
+        si_b[i] = sp[1];
+    }
+    uint4 lim[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) lim[i] = *reinterpret_cast<const uint4*>(&A.limits[si_b[i].y & ~SIMPLE_FLAG]);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        h[i] = ok[i] ? SHit{raw[i].x, raw[i].y, raw[i].z, raw[i].w} : SHit{0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
+        adm[i] = ok[i] && adm_raw[i] != 0;
+        d[i] = ok[i] ? d_raw[i] : 0ull;
     }
     // ---- inside the thread -------------------------------------------------------------------------
     Run run{0, 0, 0};
@@ -679,17 +709,29 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
         // them is applied (in_memory.rs:105-139 reads, :146-153 updates afterwards)
         u64 dup_sum = 0;
         u32 dup_cnt = 0;
-        if (adm[i]) {
-            for (u32 q = pos; q > h[i].seg;) {
-                --q;
-                const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + q);
-                if (v.y != h[i].req) break;
-                dup_sum += gen_delta(A, SHit{v.x, v.y, v.z, v.w});
-                dup_cnt += 1;
+        {
+            // the record right ahead is in registers; only a request that really repeats a cell walks back further
+            const u32 prev_req = i > 0 ? h[i > 0 ? i - 1 : 0].req : before.y;
+            if (adm[i] && pos > h[i].seg && prev_req == h[i].req) {
+                for (u32 q = pos; q > h[i].seg;) {
+                    --q;
+                    const uint4 v = *reinterpret_cast<const uint4*>(A.s_hits + q);
+                    if (v.y != h[i].req) break;
+                    dup_sum += gen_delta(A, SHit{v.x, v.y, v.z, v.w});
+                    dup_cnt += 1;
+                }
             }
         }
-        const SegInfo si = A.seg_info[h[i].seg];
-        const LimitDev Lm = gen_limit_row(A, si.limit);
+        SegInfo si;
+        si.s = ((u64)si_a[i].y << 32) | si_a[i].x;
+        si.ttl0 = ((u64)si_a[i].w << 32) | si_a[i].z;
+        si.slot = si_b[i].x;
+        si.limit = si_b[i].y;
+        si.flags = si_b[i].z;
+        si.len = si_b[i].w;
+        LimitDev Lm;
+        Lm.max_value = ((u64)lim[i].y << 32) | lim[i].x;
+        Lm.window_us = ((u64)lim[i].w << 32) | lim[i].z;
         const bool zw = (si.flags & SF_ZEROWIN) != 0;
         const u64 v = zw ? 0ull : si.s + (pr.sum - dup_sum);
         const u64 sum = v + d[i];  // wraps like the reference's release build (in_memory.rs:88)
@@ -782,10 +824,32 @@ __global__ __launch_bounds__(256) void k_gen_final(GenArgs A) {
     if (A.first_limited) A.first_limited[r] = first < 0 ? -1 : (int32_t)(A.hit0 + (u32)first);  // index in the caller's batch
     // the limit whose name the reference reports (Authorization::Limited(name), in_memory.rs:91-93,97-99)
     if (A.limited_limit) A.limited_limit[r] = first < 0 ? -1 : (int32_t)(A.hits[first].limit & ~SIMPLE_FLAG);
-    if (A.mark_reached) {
-        // !load_counters: the walk stops at its first limited counter (in_memory.rs:109-113,129-133)
-        const u32 stop = first < 0 ? e : (u32)first + 1;
-        for (u32 q = b; q < stop; ++q) A.reached[A.hit_seg[q]] = 1;
+    // !load_counters: the walk stops at its first limited counter (in_memory.rs:109-113,129-133); k_gen_reach marks
+    // the cells the walks got to
+    if (A.mark_reached) A.req_stop[r] = first < 0 ? e : (u32)first + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_reach: reached[segment] = some request's walk got to this cell.  Only asked for cells the batch would
+// CREATE (a cell a walk never reached is not created, in_memory.rs:109-113,129-133), so only their hits look
+// their request up; from the sorted side, coalesced — the other way round (every hit stores its segment, every
+// request marks the segments of its hits) costs two random 4-byte accesses per hit, which was what bounded
+// k_gen_sort (3.1 M random stores: 85 us).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_BLOCK) void k_gen_reach(GenArgs A) {
+    if (A.pst->err || A.gst->overflow || !A.mark_reached) return;
+    constexpr int PER = GS_MAX / GS_BLOCK;
+    const u32 base = blockIdx.x * (u32)GS_MAX + threadIdx.x * PER;
+    uint4 v[PER];
+    u32 fl[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) v[u] = *reinterpret_cast<const uint4*>(A.s_hits + (base + u < A.n_hits ? base + u : A.n_hits - 1));
+#pragma unroll
+    for (int u = 0; u < PER; ++u) fl[u] = A.seg_info[v[u].x].flags;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (base + u >= A.n_hits || !(fl[u] & SF_NEW)) continue;
+        if (v[u].z < A.req_stop[v[u].y] && !A.reached[v[u].x]) A.reached[v[u].x] = 1;  // (idx < the walk's end)
     }
 }
 
@@ -837,7 +901,9 @@ __global__ __launch_bounds__(256) void k_gen_commit(GenArgs A, u32 room) {
         if (!gen_is_head(A, j)) continue;
         const SegInfo si = A.seg_info[j];
         if (si.flags & SF_BAD) continue;
-        if (A.mark_reached && !A.reached[j]) continue;  // no request's walk got here: the cell is not even created
+        // no request's walk got here: the cell is not even created (k_gen_reach marks NEW cells only; an existing
+        // cell no walk reached has nothing admitted on it and is left alone below)
+        if (A.mark_reached && (si.flags & SF_NEW) && !A.reached[j]) continue;
         const SegTot t = A.seg_tot[j];
         const LimitDev Lm = gen_limit_row(A, si.limit);
         u32 slot = si.slot;
