@@ -291,6 +291,20 @@ def secondary(args, eng, dev, gen):
                     "has to micro-batch"}
     except Exception as ex:  # the host mirror is optional plumbing for this leg
         out["configs0_3_limits_10k_sequential_calls"] = {"error": str(ex)[:200]}
+    # -- BASELINE.json configs[4] shape on one GPU: 4 namespaces x 8 limits, 1 M requests -> ~3.1 M counters per call,
+    #    limit matching + key derivation on the device + the multi-counter resolver (scripts/bench_match.py, own process)
+    try:
+        import subprocess
+
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "bench_match.py"),
+                            "--steps", "10"], capture_output=True, text=True, timeout=180)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        m = json.loads(line)
+        out["configs4_shape_match_and_check_1M_requests"] = {
+            "requests_per_s": m["requests_per_s"], "ms_per_call": m["ms_per_step"], "counters_per_call": m["counters_per_batch"],
+            "note": "rl_match_and_check_batch_device: k_match_fast + general resolver (round 1: 2.03 ms per call)"}
+    except Exception as ex:
+        out["configs4_shape_match_and_check_1M_requests"] = {"error": str(ex)[:200]}
     return out
 
 

@@ -173,26 +173,25 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
     u32 idx[HPT], ent[HPT];
     bool ok[HPT], creator[HPT], leader[HPT];
     // ---- the round's inputs: the hits (coalesced), then every hit's home cell (one 32-byte read) --
+    // Both loads are UNCONDITIONAL (a lane past the end of the round repeats the round's last hit): a load inside
+    // a divergent `if` is waited for where the branch ends, and the home cells are not needed before phase B —
+    // phase A's LDS work runs under their latency.
+    uint4 ca[HPT], cb[HPT];
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
         const u32 p = tid * HPT + u;
         ok[u] = p < n_items;
         creator[u] = leader[u] = false;
         ent[u] = 0;
-        if (ok[u]) h[u] = load_bhit(A.b_hits, first + p);
+        h[u] = load_bhit(A.b_hits, first + (ok[u] ? p : n_items - 1));
     }
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
         idx[u] = ok[u] ? (h[u].idx_tag & 0xFFFFFFu) : 0u;
-        if (!ok[u]) continue;
         hslot[u] = slot_of(h[u].key, A.seed, A.log2cap);
         const Cell* c = &A.table[(A.dbg & 8u) ? (hslot[u] & 0xFFFu) : hslot[u]];
-        const uint4 a = *reinterpret_cast<const uint4*>(c);
-        const uint4 b = reinterpret_cast<const uint4*>(c)[1];  // expiry, limit
-        ctag[u] = ((u64)a.y << 32) | a.x;
-        cvalue[u] = ((u64)a.w << 32) | a.z;
-        cexpiry[u] = ((u64)b.y << 32) | b.x;
-        climit[u] = b.z;
+        ca[u] = *reinterpret_cast<const uint4*>(c);
+        cb[u] = reinterpret_cast<const uint4*>(c)[1];  // expiry, limit
     }
     // ---- A: find or claim the key's LDS cell, add this hit to the round's aggregates ------------
     u32 n_new = 0;
@@ -254,6 +253,10 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
         if (!creator[u]) continue;
         const u32 e = ent[u];
         u32 slot = hslot[u];
+        ctag[u] = ((u64)ca[u].y << 32) | ca[u].x;
+        cvalue[u] = ((u64)ca[u].w << 32) | ca[u].z;
+        cexpiry[u] = ((u64)cb[u].y << 32) | cb[u].x;
+        climit[u] = cb[u].z;
         u64 value = cvalue[u], expiry = cexpiry[u];
         u32 cl = climit[u];
         if (ctag[u] != h[u].key) {
