@@ -16,21 +16,26 @@
 //
 //   k_bkt_hist / scan / scatter   (rl_bucket.hpp) the batch's hits, stably partitioned by key hash; hot keys
 //                   in buckets of their own
-//   k_gen_sort      per hash bucket, in LDS: a stable counting sort by CELL — afterwards the hits of one
-//                   cell are one contiguous segment in trace order — and ONE table probe per cell: the
-//                   cell's state before the batch (SegInfo).  Nothing is created yet.
-//   k_gen_hot_sum + k_gen_round   one fixpoint round, flat over the sorted hits: "is my request
-//                   admitted" (AND of its hits' pass flags of the previous round), segmented exclusive
-//                   scan of the admitted deltas, pass flag / remaining / expires_in per hit.  Hot
-//                   segments are cut in pieces whose sums k_gen_hot_sum prepares.  A round that finds the
-//                   previous one changed nothing returns at once: the host enqueues a few rounds blind and
-//                   reads ONE status block.
-//   k_gen_final     per request: verdict, first limited counter (in_memory.rs:90-99,141-143), and which
-//                   cells the walk reached before it stopped (in_memory.rs:109-113,129-133: a request
-//                   stops at its first limited counter unless load_counters, so later cells are not created)
+//   k_gen_sort      per hash bucket (one workgroup, like k_bkt_apply): a two-pass stable counting sort of its hits
+//                   BY CELL — afterwards the hits of one cell are one contiguous segment in trace order.  The usual
+//                   bucket (<= 512 hits) is read once; its distinct cells are resolved with ONE probe chain each
+//                   (SegInfo: the cell's state before the batch), all chains side by side.  Nothing is created yet.
+//                   A bucket over GS_LONG_MAX hits or GS_E distinct cells sets `overflow` and promotes its heavy keys.
+//   k_gen_admit (+ _fold), k_gen_piece_sum, k_gen_round   one fixpoint round over PIECES of GS_MAX consecutive sorted
+//                   positions (any bucket, any cell): "is my request admitted so far" (AND of its hits' pass flags
+//                   of the previous round) -> segmented exclusive scan of the admitted deltas, the carry of the cell
+//                   that is open at the piece's start folded from the pieces before (k_gen_piece_sum) -> pass flag,
+//                   remaining / expires_in per hit.  k_gen_admit also detects the fixpoint: a round whose admitted
+//                   set equals the previous one does not run, and everything enqueued behind it returns at once:
+//                   the host enqueues a few rounds blind and reads ONE status block.
+//   k_gen_final     per request: verdict, first limited counter (in_memory.rs:90-99,141-143), the limit id to
+//                   report, and where the walk stopped
+//   k_gen_reach     new cells some walk got to (in_memory.rs:109-113,129-133: a request stops at its first limited
+//                   counter unless load_counters, so later cells are not created)
 //   k_gen_count     how many cells the batch creates — checked against the table BEFORE anything is applied
 //   k_gen_commit    per cell: AtomicExpiringValue::update for the admitted hits (atomic_expiring_value.rs:
-//                   36-42,87-99), creation of the reached new cells (in_memory.rs:122-127 / :51-62)
+//                   36-42,87-99), creation of the reached new cells (in_memory.rs:122-127 / :51-62) — only if the
+//                   device saw convergence, no error and room (all-or-nothing)
 #pragma once
 #include "rl_bucket.hpp"
 
