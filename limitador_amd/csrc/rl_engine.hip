@@ -101,6 +101,7 @@ struct rl_engine {
     // routing scratch
     u32* d_route_cnt = nullptr;
     // bucketed hot path (rl_bucket.hpp)
+    u32 gen_bk_log2_max = BK_LOG2_MAX; // RL_GEN_BUCKET_LOG2: cap on the general resolver's hash buckets (tests)
     int gen_trace = 0;                 // RL_GEN_TRACE=1: one stderr line per pass of the general resolver; 2: + k_gen_sort phases
     unsigned long long* d_gen_trace = nullptr;
     u32 bk_log2_cfg = BK_LOG2_MAX;     // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX).  Measured at 1 M hits,
@@ -582,6 +583,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     // ---- partition ----------------------------------------------------------------------------------
     u32 bk_log2 = ceil_log2(cdiv(n, 512));
     if (bk_log2 > (u32)BK_LOG2_MAX) bk_log2 = BK_LOG2_MAX;
+    if (e->gen_bk_log2_max < bk_log2) bk_log2 = e->gen_bk_log2_max;  // (tests: long buckets on purpose)
     const u32 nb = 1u << bk_log2, nbt = nb + HOT_MAX;
     const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
     const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
@@ -937,6 +939,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
     if (const char* v = getenv("RL_GEN_TRACE")) e->gen_trace = atoi(v);
+    if (const char* v = getenv("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
     if (const char* v = getenv("RL_GEN_SUB_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 1024) e->gen_sub_max = (u32)std::min<long>(b, GEN_SUB_MAX);

@@ -657,3 +657,60 @@ def test_auto_grow_doubles_the_table_instead_of_refusing(make_engine):
     st = eng.stats()
     assert st["capacity_cells"] >= 32768 and st["rebuilds"] >= 5
     assert_same_state(eng, orc)
+
+
+def _big_multi_batch(rng, n_req, n_users, n_ns=3):
+    """Vectorised: requests of 1-4 counters — the namespace's simple counter first, then qualified ones on a
+    Zipf user (limit 2 + 3 * ns + j) — as (hits, req_off)."""
+    ns = rng.integers(0, n_ns, size=n_req)
+    user = ((rng.zipf(1.3, size=n_req) - 1) % n_users).astype(np.uint64)
+    has_simple = rng.random(n_req) < 0.6
+    has_q = rng.random((n_req, 3)) < np.array([0.8, 0.5, 0.3])
+    delta = np.where(rng.random(n_req) < 0.85, 1, rng.integers(0, 4, size=n_req)).astype(np.uint32)
+    k = has_simple.astype(np.int64) + has_q.sum(axis=1)
+    off = np.zeros(n_req + 1, dtype=np.uint32)
+    np.cumsum(k, out=off[1:])
+    hits = np.zeros(int(off[-1]), dtype=HIT_DTYPE)
+    pos = off[:-1].astype(np.int64).copy()
+    sel = np.nonzero(has_simple)[0]
+    hits["key"][pos[sel]] = 30_000_000 + ns[sel]
+    hits["limit"][pos[sel]] = ns[sel].astype(np.uint32) | RL_SIMPLE
+    hits["delta"][pos[sel]] = delta[sel]
+    pos[sel] += 1
+    for j in range(3):
+        sel = np.nonzero(has_q[:, j])[0]
+        lid = (n_ns + 3 * ns[sel] + j).astype(np.uint64)
+        hits["key"][pos[sel]] = W.splitmix64(lid * np.uint64(1_000_003) + user[sel])
+        hits["limit"][pos[sel]] = lid.astype(np.uint32)
+        hits["delta"][pos[sel]] = delta[sel]
+        pos[sel] += 1
+    return hits, off
+
+
+@pytest.mark.parametrize("load", [False, True], ids=["noload", "load_counters"])
+@pytest.mark.parametrize("bucket_log2", [None, 8], ids=["default_buckets", "long_buckets"])
+def test_large_multi_counter_batches_against_the_oracle(make_engine, monkeypatch, bucket_log2, load):
+    """The general resolver at a size where its machinery is exercised: hundreds of thousands of hits per call,
+    buckets beyond 512 hits (re-read path; forced longer still with RL_GEN_BUCKET_LOG2), several pieces per bucket
+    and per hot key, a cold first call (overflow, promotion of the heavy keys, retry), windows that run out
+    between calls, duplicates of a counter inside a request — every verdict, first_limited and cell against the
+    oracle."""
+    if bucket_log2 is not None:
+        monkeypatch.setenv("RL_GEN_BUCKET_LOG2", str(bucket_log2))
+    rng = np.random.default_rng(314 + (bucket_log2 or 0) + int(load))
+    n_ns = 3
+    rows = [(10**9, 60), (50_000, 10), (3000, 1)] + [(int(rng.integers(3, 400)), [1, 10, 60][j % 3]) for j in range(3 * n_ns)]
+    simple = [(ns, 30_000_000 + ns) for ns in range(n_ns)]
+    n_req = 120_000 if load else 250_000
+    eng, orc = pair(make_engine, rows, simple, capacity_cells=1 << 20, max_batch_hits=1 << 20)
+    now = NOW
+    for step in range(4):
+        hits, off = _big_multi_batch(rng, n_req - 1000 * step, n_users=40_000, n_ns=n_ns)
+        if step == 2:  # the same counter twice in one request, a few thousand times
+            dup = rng.integers(0, len(off) - 1, size=3000)
+            dup = dup[(off[dup + 1] - off[dup]) >= 2]
+            hits["key"][off[dup + 1] - 1] = hits["key"][off[dup + 1] - 2]
+            hits["limit"][off[dup + 1] - 1] = hits["limit"][off[dup + 1] - 2]
+        run_both(eng, orc, hits, now, req_off=off, load_counters=load)
+        now += [SEC // 3, 2 * SEC, 11 * SEC, 1][step]
+    assert_same_state(eng, orc, n_simple_expected=n_ns)
