@@ -295,6 +295,29 @@ int32_t rl_match_and_check_batch_device(rl_engine *e, const uint32_t *d_req_ns, 
                                         int32_t load_counters, uint8_t *d_verdict, int32_t *d_limited_limit,
                                         uint32_t *n_hits_out);
 
+/* ---- the general resolver in phases: admission decided by the host ----------------------- */
+/* For requests whose counters live on SEVERAL engines (key-sharded multi-counter requests): the per-request AND
+ * of InMemoryStorage::check_and_update (in_memory.rs:141-153) then spans engines, so each fixpoint round goes
+ * through the host.  One pass at a time; every other entry point answers RL_ERR_BUSY until commit / abort.
+ *   begin   the engine's share of the hits, in GLOBAL trace order, each with its request's id (any u32; equal ids =
+ *           same request: hits of one request on one cell all read the value before any of them is applied).
+ *           Validates, sorts by cell, reads the cells.  Nothing is written to the table.
+ *   round   d_admitted[i] != 0: hit i's request is admitted so far (NULL: all are — the first round).  d_pass[i] =
+ *           hit i fits on top of the admitted hits before it on its cell; with load_counters also remaining /
+ *           expires_in of the hit (in_memory.rs:87-95,114-116).  The host ANDs the flags per request, across
+ *           engines, and calls again until the admitted set no longer changes.
+ *   count   d_reached[i] != 0: the request's walk got to hit i (in_memory.rs:109-113,129-133; NULL: all hits).
+ *           -> cells the pass would create, and how many the table still takes: the host decides for ALL engines.
+ *   commit  applies the admitted hits of the LAST round and creates the reached new cells; ends the pass.
+ *   abort   ends the pass, nothing applied. */
+int32_t rl_gen_begin_device(rl_engine *e, const rl_hit *d_hits, const uint32_t *d_req_id, uint32_t n_hits,
+                            uint64_t now_us, int32_t load_counters);
+int32_t rl_gen_round_device(rl_engine *e, const uint8_t *d_admitted, uint8_t *d_pass, uint64_t *d_remaining,
+                            uint64_t *d_expires_in_us);
+int32_t rl_gen_count_device(rl_engine *e, const uint8_t *d_reached, uint32_t *n_new, uint64_t *room);
+int32_t rl_gen_commit_device(rl_engine *e);
+int32_t rl_gen_abort(rl_engine *e);
+
 /* ---- multi-GPU routing helpers (device pointers, engine's stream) ----------------------- */
 /* Owner shard of a key for a world of `world` shards (any world >= 1). */
 uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world);

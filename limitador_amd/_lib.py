@@ -103,6 +103,11 @@ def _declare(lib):
     _sig(lib, "rl_engine_stream", p, [p])
     _sig(lib, "rl_engine_set_stream", C.c_int32, [p, p, C.c_int32])
     _sig(lib, "rl_engine_wait_event", C.c_int32, [p, p])
+    _sig(lib, "rl_gen_begin_device", C.c_int32, [p, p, p, C.c_uint32, C.c_uint64, C.c_int32])
+    _sig(lib, "rl_gen_round_device", C.c_int32, [p, p, p, p, p])
+    _sig(lib, "rl_gen_count_device", C.c_int32, [p, p, u32p, u64p])
+    _sig(lib, "rl_gen_commit_device", C.c_int32, [p])
+    _sig(lib, "rl_gen_abort", C.c_int32, [p])
     _sig(lib, "rl_engine_record_event", C.c_int32, [p, p])
     _sig(lib, "rl_engine_info", C.c_int32, [p, i32p, u32p])
     _sig(lib, "rl_route_partition_stream", C.c_int32, [p, p, p, C.c_uint32, C.c_uint32, p, p, p])

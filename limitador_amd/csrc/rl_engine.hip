@@ -101,6 +101,12 @@ struct rl_engine {
     // routing scratch
     u32* d_route_cnt = nullptr;
     // bucketed hot path (rl_bucket.hpp)
+    // the phased form of the general resolver (rl_gen_begin_device .. rl_gen_commit_device / rl_gen_abort)
+    bool ph_open = false;
+    GenArgs ph_A{};
+    BatchScratch* ph_bs = nullptr;
+    u32 ph_n = 0, ph_rounds = 0;
+    bool ph_counted = false;
     u32 gen_bk_log2_max = BK_LOG2_MAX; // RL_GEN_BUCKET_LOG2: cap on the general resolver's hash buckets (tests)
     int gen_trace = 0;                 // RL_GEN_TRACE=1: one stderr line per pass of the general resolver; 2: + k_gen_sort phases
     unsigned long long* d_gen_trace = nullptr;
@@ -170,6 +176,9 @@ struct rl_engine {
 };
 
 namespace {
+
+inline bool engine_busy(const rl_engine* e) { return e->sub_seq != e->col_seq || e->ph_open; }
+
 
 // layout of rl_engine::h_tiny (host-mapped staging of a one-launch host-buffer call)
 constexpr size_t TIO_HITS = 1024;
@@ -552,21 +561,15 @@ struct GenCall {
     u64* d_rem;
     u64* d_exp;
     int32_t* d_limited = nullptr;  // per request: id of the limit that limited it, -1 (rl_match_and_check_batch)
+    const u32* d_hit_req_ext = nullptr;  // phased form: the caller's request id of every hit (any u32, equal = same request)
 };
 
-// One pass: requests [req0, req0 + n_req) = hits [hit0, hit0 + n) of the call.  *overflow: a hash bucket was
-// too long for k_gen_sort, nothing was applied, the caller retries with smaller passes.
-int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hit0, u32 n, bool* overflow) {
-    *overflow = false;
+// Partition of the pass's hits + k_gen_sort: everything up to the first fixpoint round.  A is filled for the kernels
+// that follow; *bs_out = the pass's scratch block.  Shared by the blocking resolver (run_general_pass) and the phased
+// one (rl_gen_begin_device: admission decided by the host, for requests whose counters live on several GPUs).
+static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hit0, u32 n, bool mark, GenArgs& A_out,
+                              BatchScratch** bs_out) {
     hipStream_t st = e->stream;
-    if (n == 0) {  // only empty requests: lib.rs:434-440, not limited
-        HIP_TRY(e, hipMemsetAsync(c.d_verdict + req0, 0, n_req, st));
-        if (c.d_first) HIP_TRY(e, hipMemsetAsync(c.d_first + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
-        if (c.d_limited) HIP_TRY(e, hipMemsetAsync(c.d_limited + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
-        return RL_OK;
-    }
-    int rc = check_room(e, 0);  // (the cells the pass creates are counted exactly below, before the commit)
-    if (rc) return rc;
     const u64 p = e->part_seq;
     const u32 par = (u32)(p & 1u);
     BatchScratch* bs = e->d_bs + p % 3;
@@ -589,7 +592,6 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
     HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), st));
     HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
-    const bool mark = !c.load && !c.update_mode && c.d_req_off != nullptr;
     if (mark) HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, st));
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
     hist_k<<<ntiles, PT_BLOCK, 0, st>>>(e->table, e->log2cap, e->seed, hits, n, e->d_limits, (u32)e->h_limits.size(), bk_log2,
@@ -606,7 +608,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     A.limits = e->d_limits;
     A.now = c.now;
     A.hits = hits;
-    A.hit_req = c.d_req_off ? e->d_hit_req : nullptr;
+    A.hit_req = c.d_hit_req_ext ? c.d_hit_req_ext : (c.d_req_off ? e->d_hit_req : nullptr);
     A.req_off = c.d_req_off;
     A.req_delta = c.d_req_delta;
     A.hit0 = hit0;
@@ -676,6 +678,30 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
                          ph[2] / live, p2_issue / live, ph[3] / live, longest_b, longest, longest_us);
         A.trace = nullptr;
     }
+    A_out = A;
+    *bs_out = bs;
+    return RL_OK;
+}
+
+// One pass: requests [req0, req0 + n_req) = hits [hit0, hit0 + n) of the call.  *overflow: a hash bucket was
+// too long for k_gen_sort, nothing was applied, the caller retries with smaller passes.
+int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hit0, u32 n, bool* overflow) {
+    *overflow = false;
+    hipStream_t st = e->stream;
+    if (n == 0) {  // only empty requests: lib.rs:434-440, not limited
+        HIP_TRY(e, hipMemsetAsync(c.d_verdict + req0, 0, n_req, st));
+        if (c.d_first) HIP_TRY(e, hipMemsetAsync(c.d_first + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
+        if (c.d_limited) HIP_TRY(e, hipMemsetAsync(c.d_limited + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
+        return RL_OK;
+    }
+    int rc = check_room(e, 0);  // (the cells the pass creates are counted exactly below, before the commit)
+    if (rc) return rc;
+    const bool mark = !c.load && !c.update_mode && c.d_req_off != nullptr;
+    GenArgs A{};
+    BatchScratch* bs = nullptr;
+    rc = gen_setup_and_sort(e, c, req0, n_req, hit0, n, mark, A, &bs);
+    if (rc) return rc;
+    const u64 p = e->part_seq;
     // ---- fixpoint rounds: a few at a time, each returning at once if the one before changed nothing; then
     //      k_gen_commit, which applies the pass only if the status block says it is final and fits -------------
     u32 round = 0;
@@ -1142,7 +1168,7 @@ void* rl_engine_stream(rl_engine* e) { return e ? (void*)e->stream : nullptr; }
 int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->own_pstream) HIP_TRY(e, hipStreamSynchronize(e->own_pstream));
@@ -1173,7 +1199,7 @@ int32_t rl_engine_record_event(rl_engine* e, void* event) {
 int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n && !rows) return fail(e, RL_ERR_INVALID, "rows is null");
     if ((u64)first + n > e->max_limits) return fail(e, RL_ERR_INVALID, "limit rows [%u,%u) exceed max_limits %u", first, first + n, e->max_limits);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -1195,7 +1221,7 @@ int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, ui
 int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (!(limit & RL_SIMPLE)) return RL_OK;  // in_memory.rs:39: only limits without variables
     if (RL_LIMIT_ID(limit) >= e->h_limits.size()) return fail(e, RL_ERR_INVALID, "unknown limit id %u", RL_LIMIT_ID(limit));
     HIP_TRY(e, hipSetDevice(e->device));
@@ -1213,7 +1239,7 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
     int rc = validate_batch(e, d_hits, n_hits, d_req_off, n_req, d_verdict);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     if (load_counters && (!d_remaining || !d_expires_in_us))
@@ -1309,7 +1335,7 @@ int32_t rl_check_and_update_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t 
     int rc = validate_batch(e, hits, n_hits, req_off, n_req, verdict);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     if (load_counters && (!remaining || !expires_in_us))
@@ -1362,6 +1388,7 @@ int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, ui
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
     if (n_hits == 0) return fail(e, RL_ERR_INVALID, "empty batch");
+    if (e->ph_open) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     return submit_k1_bucketed(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
 }
@@ -1378,7 +1405,7 @@ int32_t rl_is_within_limits_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t 
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, within);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
@@ -1405,7 +1432,7 @@ int32_t rl_update_counter_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, &dummy);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     // the general resolver without the limit test: every hit is admitted (in_memory.rs:47-69 never checks)
@@ -1423,35 +1450,35 @@ int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_r
                         uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_GET>(e, limit, now_us, out, cap, n_out);
 }
 
 int32_t rl_dump_cells(rl_engine* e, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_DUMP>(e, 0, 0, out, cap, n_out);
 }
 
 int32_t rl_delete_counters(rl_engine* e, uint32_t limit) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_DELETE_LIMIT>(e, limit, 0, nullptr, 0, nullptr);
 }
 
 int32_t rl_clear(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_CLEAR_SIMPLE>(e, 0, 0, nullptr, 0, nullptr);
 }
 
 int32_t rl_sweep_expired_rows(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_removed) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     const u64 before = e->live;
     int rc = scan_locked<SCAN_SWEEP>(e, 0, now_us, out, cap, nullptr);
     if (rc) return rc;
@@ -1467,7 +1494,7 @@ int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
 int32_t rl_compact(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     return do_compact(e, 0);
 }
@@ -1475,7 +1502,7 @@ int32_t rl_compact(rl_engine* e) {
 int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {
     if (!e) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     const u32 lg = ceil_log2(capacity_cells < 1024 ? 1024 : capacity_cells);
     if (lg > 31) return fail(e, RL_ERR_INVALID, "capacity %llu beyond 2^31 cells", (unsigned long long)capacity_cells);
@@ -1488,7 +1515,7 @@ int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {
 int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n) {
     if (!e || (n && !d_rows)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     if (n == 0) return RL_OK;
     return insert_rows_locked(e, reinterpret_cast<const CellRow*>(d_rows), n, 1);
@@ -1497,7 +1524,7 @@ int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n
 int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
     if (!e || (n && !rows)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     if (n == 0) return RL_OK;
     CellRow* d_rows = nullptr;
@@ -1582,7 +1609,7 @@ static PeerTables peer_tables_of(rl_engine* e) {
 int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const rl_cell_row* rows, uint64_t n, uint64_t now_us) {
     if (!e || (n && !rows)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (actor >= (u32)MERGE_MAX_ACTORS || self_actor >= (u32)MERGE_MAX_ACTORS)
         return fail(e, RL_ERR_INVALID, "actor ids are 0..%d", MERGE_MAX_ACTORS - 1);
     if (n == 0) return RL_OK;
@@ -1614,7 +1641,7 @@ int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const 
 int32_t rl_export_local(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     CellRow* d_out = nullptr;
     if (cap && hipMalloc((void**)&d_out, cap * sizeof(CellRow)) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc failed");
@@ -1640,11 +1667,168 @@ uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t 
     return match_key(limit_id, n_vars, v0, v1);
 }
 
+// ---- the phased form of the general resolver ----------------------------------------------------------------
+// For hosts that decide admission themselves: requests whose counters live on several GPUs (key-sharded
+// multi-counter requests, limitador_amd/sharded.py ShardedMultiCounterEngine) — the per-request AND of
+// in_memory.rs:141-153 then spans engines, so every fixpoint round goes through the host.
+static int32_t gen_phase_close(rl_engine* e) {
+    e->ph_open = false;
+    e->ph_counted = false;
+    HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
+}
+
+int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* d_req_id, uint32_t n_hits, uint64_t now_us,
+                            int32_t load_counters) {
+    if (!e || (n_hits && (!d_hits || !d_req_id))) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight or a phased pass is open");
+    if (n_hits > e->gen_cap) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u > %u: split the slice", n_hits, e->gen_cap);
+    HIP_TRY(e, hipSetDevice(e->device));
+    e->ph_n = n_hits;
+    e->ph_rounds = 0;
+    e->ph_counted = false;
+    if (n_hits == 0) {
+        e->ph_open = true;
+        return RL_OK;
+    }
+    if (e->tombs > e->cap / 8) {
+        const int crc = do_compact(e, 0);
+        if (crc) return crc;
+    }
+    int rc = check_room(e, 0);
+    if (rc) return rc;
+    GenCall c{reinterpret_cast<const Hit*>(d_hits), n_hits, nullptr, n_hits, nullptr, now_us, load_counters != 0, false,
+              nullptr, nullptr, e->d_remaining, e->d_expires};
+    c.d_hit_req_ext = d_req_id;
+    for (int attempt = 0;; ++attempt) {
+        GenArgs A{};
+        BatchScratch* bs = nullptr;
+        rc = gen_setup_and_sort(e, c, 0, n_hits, 0, n_hits, !c.load, A, &bs);
+        if (rc) return rc;
+        Status h_bst;
+        GenStatus h_gst;
+        HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(&h_bst, &bs->st, sizeof(Status), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (h_bst.err | h_gst.err) {
+            HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), e->stream));
+            return status_to_error(e, h_bst.err | h_gst.err);
+        }
+        if (h_gst.overflow) {  // the heavy keys were promoted: partition again with that set
+            e->part_seq += 1;
+            HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), e->stream));
+            if (attempt >= 2)
+                return fail(e, RL_ERR_BATCH_TOO_LARGE, "a hash bucket of this slice holds more than %d hits or %d cells: split the slice", GS_LONG_MAX, GS_E);
+            continue;
+        }
+        e->ph_A = A;
+        e->ph_bs = bs;
+        break;
+    }
+    e->ph_open = true;
+    return RL_OK;
+}
+
+int32_t rl_gen_round_device(rl_engine* e, const uint8_t* d_admitted, uint8_t* d_pass, uint64_t* d_remaining,
+                            uint64_t* d_expires_in_us) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
+    if (e->ph_n == 0) return RL_OK;
+    if (!d_pass) return fail(e, RL_ERR_INVALID, "d_pass is null");
+    HIP_TRY(e, hipSetDevice(e->device));
+    GenArgs A = e->ph_A;
+    A.admitted_hit = d_admitted;  // null: every hit admitted (the first round)
+    A.pass[0] = A.pass[1] = d_pass;
+    A.remaining = A.load ? reinterpret_cast<u64*>(d_remaining) : nullptr;
+    A.expires_in = A.load ? reinterpret_cast<u64*>(d_expires_in_us) : nullptr;
+    if (A.load && (!d_remaining || !d_expires_in_us)) return fail(e, RL_ERR_INVALID, "load_counters: remaining / expires_in are null");
+    const u32 n = e->ph_n;
+    // (round number 0: no pass flags of a previous round are read; the admission comes with the call)
+    k_gen_piece_sum<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, e->stream>>>(A, 0u, 0u);
+    k_gen_round<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, e->stream>>>(A, 0u, 0u, 1u);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->ph_rounds++;
+    e->ph_counted = false;
+    return RL_OK;
+}
+
+int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_new, uint64_t* room) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
+    const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
+    if (room) *room = used < bound ? bound - used : 0;
+    if (n_new) *n_new = 0;
+    e->ph_counted = true;
+    if (e->ph_n == 0) return RL_OK;
+    if (e->ph_rounds == 0) return fail(e, RL_ERR_INVALID, "rl_gen_round_device has not run");
+    HIP_TRY(e, hipSetDevice(e->device));
+    GenArgs A = e->ph_A;
+    const u32 n = e->ph_n;
+    A.reached_hit = d_reached;
+    A.mark_reached = d_reached ? 1u : 0u;  // null: every hit was reached (load_counters walks all counters)
+    e->ph_A.mark_reached = A.mark_reached;
+    if (d_reached) {
+        HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, e->stream));
+        k_gen_reach<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, e->stream>>>(A);
+    }
+    HIP_TRY(e, hipMemsetAsync(&e->d_gst->n_new, 0, sizeof(u32), e->stream));
+    k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A);
+    GenStatus h_gst;
+    HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
+    else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
+    if (n_new) *n_new = h_gst.n_new;
+    return RL_OK;
+}
+
+int32_t rl_gen_commit_device(rl_engine* e) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
+    if (e->ph_n == 0) return gen_phase_close(e);
+    if (!e->ph_counted) return fail(e, RL_ERR_INVALID, "rl_gen_count_device must follow the last round");
+    HIP_TRY(e, hipSetDevice(e->device));
+    GenArgs A = e->ph_A;
+    A.update_mode = 1u;  // (k_gen_commit: the caller has seen the fixpoint; the device-side convergence test does not apply)
+    const u32 n = e->ph_n;
+    const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
+    k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
+    GenStatus h_gst;
+    HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (!h_gst.committed) {
+        (void)gen_phase_close(e);
+        return fail(e, RL_ERR_TABLE_FULL, "refused, nothing applied: the slice creates %u cells in a table with live=%llu tombstones=%llu capacity=%llu",
+                    h_gst.n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
+    }
+    e->live += h_gst.n_new;
+    e->part_seq++;
+    e->stats.batches++;
+    e->stats.hits += n;
+    e->stats.ordered_hits += n;
+    e->stats.ordered_batches++;
+    return gen_phase_close(e);
+}
+
+int32_t rl_gen_abort(rl_engine* e) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->ph_open) return RL_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    return gen_phase_close(e);
+}
+
 int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t n_limits, const rl_match_cond* conds,
                            uint32_t n_conds, uint32_t n_namespaces) {
     if (!e || (n_limits && !limits) || (n_conds && !conds)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     std::vector<u32> ns_off(n_namespaces + 1, 0);
     for (u32 i = 0; i < n_limits; ++i) {
@@ -1781,7 +1965,7 @@ int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, 
                                         uint32_t* n_hits_out) {
     if (!e || !n_req || !d_req_ns || !d_ent_off || !d_req_delta || !d_verdict) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
     HIP_TRY(e, hipSetDevice(e->device));
     return match_and_check_locked(e, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, n_req, now_us,
@@ -1795,7 +1979,7 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
                                  uint64_t* expires_in_us) {
     if (!e || !n_req || !req_ns || !ent_off || !req_delta || !verdict) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->sub_seq != e->col_seq) return fail(e, RL_ERR_BUSY, "batches are in flight: rl_check_and_update_collect first");
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
     const u32 n_ent = ent_off[n_req];
     if (n_ent > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "descriptor entries %u > max_batch_hits %u", n_ent, e->max_batch);

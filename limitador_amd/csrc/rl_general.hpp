@@ -128,6 +128,8 @@ struct GenArgs {
     uint8_t* pass[2];
     uint8_t* admitted;       // per request, by the previous round (k_gen_admit)
     u32* adm_diff;           // per workgroup of k_gen_admit: a request's admission changed
+    const uint8_t* admitted_hit;  // phased form (rl_gen_round_device): admission per HIT, decided by the host; else null
+    const uint8_t* reached_hit;   // phased form (rl_gen_count_device): did the request's walk get to this hit; else null
     uint8_t* verdict;        // outputs, already offset to the pass
     int32_t* first_limited;
     int32_t* limited_limit;  // per request: the limit id of the first limited counter, -1 (null: not wanted)
@@ -476,6 +478,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
 __device__ __forceinline__ bool gen_admitted(const GenArgs& A, const uint8_t* __restrict__ pass_prev, u32 req) {
     return !pass_prev || A.admitted[req] != 0;
 }
+// The admission byte of a sorted record (req, idx): per request from k_gen_admit, or per hit from the host.
+__device__ __forceinline__ uint8_t gen_adm_byte(const GenArgs& A, const uint8_t* __restrict__ pass_prev, u32 req, u32 idx) {
+    if (A.admitted_hit) return A.admitted_hit[idx];
+    return pass_prev ? A.admitted[req] : (uint8_t)1;
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_gen_admit: per request, the AND of its hits' pass flags of the previous round (coalesced: a request's
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_piece_sum(GenArgs A, u32 round
 #pragma unroll
         for (int u = 0; u < PER; ++u) v[u] = *reinterpret_cast<const uint4*>(A.s_hits + lo + tid * PER + u);
 #pragma unroll
-        for (int u = 0; u < PER; ++u) ad[u] = pass_prev ? A.admitted[v[u].y] : (uint8_t)1;
+        for (int u = 0; u < PER; ++u) ad[u] = gen_adm_byte(A, pass_prev, v[u].y, v[u].z);
 #pragma unroll
         for (int u = 0; u < PER; ++u) dl[u] = A.req_delta ? A.req_delta[A.req0 + v[u].y] : (u64)v[u].w;
 #pragma unroll
@@ -631,7 +638,7 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
     const uint4 before = *reinterpret_cast<const uint4*>(A.s_hits + (pos0 ? pos0 - 1 : 0u));  // the record ahead of the thread's first
     uint8_t adm_raw[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) adm_raw[i] = pass_prev ? A.admitted[raw[i].y] : (uint8_t)1;
+    for (int i = 0; i < PER; ++i) adm_raw[i] = gen_adm_byte(A, pass_prev, raw[i].y, raw[i].z);
     u64 d_raw[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) d_raw[i] = A.req_delta ? A.req_delta[A.req0 + raw[i].y] : (u64)raw[i].w;
@@ -854,7 +861,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_reach(GenArgs A) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         if (base + u >= A.n_hits || !(fl[u] & SF_NEW)) continue;
-        if (v[u].z < A.req_stop[v[u].y] && !A.reached[v[u].x]) A.reached[v[u].x] = 1;  // (idx < the walk's end)
+        const bool got_here = A.reached_hit ? A.reached_hit[v[u].z] != 0 : v[u].z < A.req_stop[v[u].y];  // (idx < the walk's end)
+        if (got_here && !A.reached[v[u].x]) A.reached[v[u].x] = 1;
     }
 }
 

@@ -271,6 +271,25 @@ class Engine:
             int(bool(load_counters)), d_verdict, d_limited_limit, C.byref(n_hits)))
         return n_hits.value
 
+    # -- the general resolver in phases (admission decided by the caller; raw device pointers) ------
+    def gen_begin(self, d_hits, d_req_id, n_hits, now_us, load_counters=False):
+        self._check(self._lib.rl_gen_begin_device(self._h, d_hits, d_req_id, int(n_hits), int(now_us), int(bool(load_counters))))
+
+    def gen_round(self, d_admitted, d_pass, d_remaining=None, d_expires=None):
+        self._check(self._lib.rl_gen_round_device(self._h, d_admitted, d_pass, d_remaining, d_expires))
+
+    def gen_count(self, d_reached):
+        """-> (cells the pass would create, cells the table still takes)"""
+        n_new, room = C.c_uint32(0), C.c_uint64(0)
+        self._check(self._lib.rl_gen_count_device(self._h, d_reached, C.byref(n_new), C.byref(room)))
+        return n_new.value, room.value
+
+    def gen_commit(self):
+        self._check(self._lib.rl_gen_commit_device(self._h))
+
+    def gen_abort(self):
+        self._check(self._lib.rl_gen_abort(self._h))
+
     # -- routing helpers (multi-GPU) -------------------------------------------------------------
     def owner_of(self, key, world):
         return self._lib.rl_owner_of(int(key), self.hash_seed, int(world))

@@ -297,3 +297,234 @@ class ShardedRequestEngine:
         verdict[perm] = s_verdict
         limited[perm] = s_limited
         return verdict, limited
+
+
+# ---------------------------------------------------------------------------------------------------
+# Requests with several counters, sharded by KEY: a request's counters live on several GPUs
+# ---------------------------------------------------------------------------------------------------
+class TorchTransport:
+    """The exchanges of ShardedMultiCounterEngine over a torch.distributed group (RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, group, device):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device)
+
+    def all_gather_int(self, value):
+        parts = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(parts, torch.tensor([int(value)], dtype=torch.int64, device=self.device), group=self.group)
+        return [int(p.item()) for p in parts]
+
+    def all_reduce_max(self, value):
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def all_to_all_v(self, send, send_counts, recv_counts):
+        out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
+                               group=self.group)
+        return out
+
+
+class InProcessGroup:
+    """Ranks as threads of one process (tests on a single GPU, or a host that drives several GPUs itself): a
+    mailbox per exchange and a barrier on either side of it."""
+
+    def __init__(self, world):
+        import threading
+
+        self.world = world
+        self._barrier = threading.Barrier(world)
+        self._box = [None] * world
+
+    def transport(self, rank, device):
+        return _InProcessTransport(self, rank, device)
+
+
+class _InProcessTransport:
+    def __init__(self, group, rank, device):
+        self.g, self.rank, self.world, self.device = group, rank, group.world, torch.device(device)
+
+    def _swap(self, item):
+        self.g._box[self.rank] = item
+        self.g._barrier.wait()
+        got = list(self.g._box)
+        self.g._barrier.wait()
+        return got
+
+    def all_gather_int(self, value):
+        return [int(v) for v in self._swap(int(value))]
+
+    def all_reduce_max(self, value):
+        return max(int(v) for v in self._swap(int(value)))
+
+    def all_to_all_v(self, send, send_counts, recv_counts):
+        if send.is_cuda:
+            torch.cuda.current_stream(send.device).synchronize()  # the peers read my rows from another thread
+        offs = [0]
+        for c in send_counts:
+            offs.append(offs[-1] + int(c))
+        got = self._swap((send, offs))
+        parts = [got[p][0][got[p][1][self.rank]:got[p][1][self.rank + 1]] for p in range(self.world)]
+        assert [int(p.shape[0]) for p in parts] == [int(c) for c in recv_counts]
+        out = torch.cat(parts) if parts else send[:0]
+        if out.is_cuda:
+            torch.cuda.current_stream(out.device).synchronize()
+        self.g._barrier.wait()  # every rank has copied: the send buffers may change again
+        return out
+
+
+class HipGenLocal:
+    """Owner-side work of ShardedMultiCounterEngine on the HIP engine: the general resolver in phases
+    (rl_gen_begin_device .. rl_gen_commit_device).  The engine works on its own stream and every call returns with
+    its results complete; the tensors handed in were produced on torch's stream, hence the synchronise."""
+
+    def __init__(self, engine, device):
+        self.engine = engine
+        self.device = torch.device(device)
+        self.n = 0
+        self.load = False
+
+    def _ptr(self, t):
+        return t.data_ptr() if t is not None and t.numel() else None
+
+    def begin(self, hits, req_id, now_us, load):
+        self.n, self.load = int(hits.shape[0]), bool(load)
+        dev = self.device
+        self._keep = (hits.contiguous(), req_id.contiguous())
+        self.pass_ = torch.empty(max(self.n, 1), dtype=torch.uint8, device=dev)
+        self.rem = torch.zeros(max(self.n, 1), dtype=torch.int64, device=dev) if load else None
+        self.exp = torch.zeros(max(self.n, 1), dtype=torch.int64, device=dev) if load else None
+        torch.cuda.synchronize(dev)
+        self.engine.gen_begin(self._ptr(self._keep[0]), self._ptr(self._keep[1]), self.n, now_us, load)
+
+    def round(self, admitted):
+        """admitted: uint8[n] or None (all) -> pass flags uint8[n]"""
+        adm = admitted.contiguous() if admitted is not None else None
+        torch.cuda.synchronize(self.device)
+        self.engine.gen_round(self._ptr(adm), self._ptr(self.pass_), self._ptr(self.rem), self._ptr(self.exp))
+        return self.pass_[: self.n]
+
+    def count(self, reached):
+        r = reached.contiguous() if reached is not None else None
+        torch.cuda.synchronize(self.device)
+        return self.engine.gen_count(self._ptr(r))
+
+    def loaded(self):
+        return self.rem[: self.n], self.exp[: self.n]
+
+    def commit(self):
+        self.engine.gen_commit()
+
+    def abort(self):
+        self.engine.gen_abort()
+
+
+class ShardedTableFull(RuntimeError):
+    pass
+
+
+class ShardedMultiCounterEngine:
+    """check(): one ingress slice of requests with SEVERAL counters each, the counters sharded by key like the
+    single-counter path — so a request's counters live on several GPUs, and the all-or-nothing rule of
+    InMemoryStorage::check_and_update (in_memory.rs:141-153) spans them.  SURVEY.md §8(e) "k > 1":
+
+        hits -> owners (stable partition by owner, exchanged with the id of their request)
+        owners: sort by cell, read the cells                                       (rl_gen_begin_device)
+        repeat  owners: per hit "fits on top of the admitted hits before it"       (rl_gen_round_device)
+                flags back to the ingress ranks; per request AND; admitted bits out to the owners again
+        until no rank saw the admitted set change                                  (Jacobi rounds: the unique fixpoint)
+        walks' ends -> owners; cells to create, room: all ranks fit or none does   (rl_gen_count_device)
+        owners commit                                                              (rl_gen_commit_device)
+
+    Global trace order is "rank 0's requests, then rank 1's, ..." per call; the owners see that order restricted to
+    their keys, so verdicts, first_limited, remaining / expires_in and the tables equal ONE sequential storage fed
+    the concatenated slices (tests/test_sharded_multi_gloo.py: 2 gloo ranks with a CPU stand-in for the owner-side
+    phases; tests/test_gpu_sharded_multi.py: the HIP engine, world 1 over RCCL and world 2-3 as threads).
+    Two exchanges of one byte per hit per round: namespace sharding (ShardedRequestEngine) is cheaper whenever the
+    namespaces balance; this one has no unit of distribution coarser than a key.  Every rank calls check() for
+    every slice."""
+
+    def __init__(self, transport, local, hash_seed):
+        self.t = transport
+        self.local = local
+        self.hash_seed = int(hash_seed)
+        self.rounds = 0
+
+    def check(self, hits, req_off, now_us, load_counters=False):
+        """hits: [n, 2] int64 rows laid out as rl_hit, simple counters first inside a request; req_off: int64[n_req + 1].
+        -> (verdict uint8[n_req], first_limited int64[n_req] (index into hits, -1), remaining, expires_in_us (per hit,
+        int64 bit patterns; None unless load_counters))"""
+        T, W = self.t, self.t.world
+        dev = hits.device
+        i64 = torch.int64
+        n, n_req = int(hits.shape[0]), int(req_off.shape[0]) - 1
+        req_off = req_off.to(i64)
+        all_req = T.all_gather_int(n_req)
+        if sum(all_req) >= 2**32:
+            raise ValueError("more than 2^32 requests in one step")
+        base = sum(all_req[: T.rank])
+        lens = req_off[1:] - req_off[:-1]
+        req_of_hit = torch.repeat_interleave(torch.arange(n_req, dtype=i64, device=dev), lens)
+        req_id = (req_of_hit + base).to(torch.int32)  # (bit pattern of the u32 id)
+        owner = owner_of_tensor(hits[:, 0], self.hash_seed, W) if n else torch.zeros(0, dtype=i64, device=dev)
+        order = torch.sort(owner, stable=True).indices
+        send = torch.bincount(owner, minlength=W).tolist() if n else [0] * W
+        recv = [int(x) for x in T.all_to_all_v(torch.tensor(send, dtype=i64, device=dev), [1] * W, [1] * W).tolist()]
+        r_hits = T.all_to_all_v(hits[order], send, recv)
+        r_req = T.all_to_all_v(req_id[order], send, recv)
+        err = None
+        try:
+            self.local.begin(r_hits, r_req, now_us, load_counters)
+        except Exception as ex:  # a malformed slice on one owner refuses the step on every rank
+            err = ex
+        if T.all_reduce_max(1 if err is not None else 0):
+            if err is None:
+                self.local.abort()
+                raise RuntimeError("another rank refused the step")
+            raise err
+        zero_front = torch.zeros(1, dtype=i64, device=dev)
+        admitted_recv, adm_prev = None, None
+        rounds = 0
+        while True:
+            pass_recv = self.local.round(admitted_recv)
+            rounds += 1
+            pass_home = torch.empty(n, dtype=torch.uint8, device=dev)
+            pass_home[order] = T.all_to_all_v(pass_recv, recv, send)
+            fail = pass_home == 0
+            c = torch.cat([zero_front, torch.cumsum(fail.to(i64), 0)])
+            adm_req = (c[req_off[1:]] - c[req_off[:-1]]) == 0
+            changed = (not bool(adm_req.all())) if adm_prev is None else bool((adm_req != adm_prev).any())
+            if not T.all_reduce_max(1 if changed else 0):
+                break  # the admitted set of this round is the one the flags were computed with: the fixpoint
+            adm_prev = adm_req
+            adm_hit = adm_req[req_of_hit].to(torch.uint8)
+            admitted_recv = T.all_to_all_v(adm_hit[order], send, recv)
+        self.rounds = rounds
+        verdict = (~adm_req).to(torch.uint8)
+        pos = torch.arange(n, dtype=i64, device=dev)
+        first = torch.full((n_req,), n, dtype=i64, device=dev)
+        if n:
+            first.scatter_reduce_(0, req_of_hit, torch.where(fail, pos, torch.full_like(pos, n)), "amin")
+        first_limited = torch.where(first < n, first, torch.full_like(first, -1))
+        reached_recv = None
+        if not load_counters:
+            # the walk stops at its first limited counter (in_memory.rs:109-113,129-133)
+            stop = torch.where(first < n, first + 1, req_off[1:])
+            reached = (pos < stop[req_of_hit]).to(torch.uint8)
+            reached_recv = T.all_to_all_v(reached[order], send, recv)
+        n_new, room = self.local.count(reached_recv)
+        if T.all_reduce_max(1 if n_new > room else 0):
+            self.local.abort()
+            raise ShardedTableFull("refused, nothing applied on any rank: a shard cannot take the cells the step creates")
+        self.local.commit()
+        rem = exp = None
+        if load_counters:
+            l_rem, l_exp = self.local.loaded()
+            rem = torch.empty(n, dtype=i64, device=dev)
+            exp = torch.empty(n, dtype=i64, device=dev)
+            rem[order] = T.all_to_all_v(l_rem, recv, send)
+            exp[order] = T.all_to_all_v(l_exp, recv, send)
+        return verdict, first_limited, rem, exp
