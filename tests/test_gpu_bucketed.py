@@ -274,3 +274,53 @@ def test_a_batch_that_does_not_fit_is_refused_before_anything_is_applied(make_en
     eng.resize(1 << 14)
     run_both(eng, orc, big, NOW + 4)
     assert_same_state(eng, orc)
+
+
+def test_soak_of_the_two_stream_pipeline_with_batches_of_every_size(make_engine):
+    """150 batches through submit / collect, three in flight, sizes from one hit to 400 k (the one-launch path, the
+    small-tile partition, the full one, in any succession), Zipf keys with a shifting head (promotion and demotion
+    of hot keys while batches are in flight), mixed deltas now and then, windows that run out: every verdict and the
+    final table against the oracle.  The partition of batch k+1 runs beside k_bkt_apply of batch k on rotating
+    buffers — this is the test that would see a buffer reused too early."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    n_max = 400_000
+    rows = [(60, 60), (2000, 2), (7, 1)]
+    eng, orc = pair(make_engine, rows, max_batch_hits=n_max, capacity_cells=1 << 19)
+    dev = torch.device("cuda", 0)
+    sizes = [1, 7, 300, 1024, 1025, 5000, 70_000, 262_144, 262_145, n_max]
+    plan = [int(sizes[int(rng.integers(0, len(sizes)))] if rng.random() < 0.6 else rng.integers(1, n_max)) for _ in range(150)]
+    now = NOW
+    in_engine, later = [], []
+    done = 0
+    for step, n in enumerate(plan):
+        shift = (step // 25) * 37_000  # the popular keys move on every 25 batches
+        idx = ((rng.zipf(1.15, size=n) - 1) % 150_000 + shift) % 200_000
+        delta = 1 if step % 7 else rng.integers(0, 4, size=n).astype(np.uint32)
+        h = make_hits(W.splitmix64(idx.astype(np.uint64)), (idx % 3).astype(np.uint32), delta)
+        want = orc.check_and_update(h, now)[0]
+        t = torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev)
+        out = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.submit_device(t.data_ptr(), n, now, out.data_ptr())
+        in_engine.append((t, out, want, step))
+        if len(in_engine) == 3:
+            eng.collect()
+            rec = in_engine.pop(0)
+            if rec[3] % 5 == 0:  # (checking every batch at once would drain the pipeline every time)
+                torch.cuda.synchronize()
+                assert np.array_equal(rec[1].cpu().numpy(), rec[2]), f"batch {rec[3]} ({plan[rec[3]]} hits)"
+                done += 1
+            else:
+                later.append(rec)
+        now += int(rng.choice([0, 1, 1000, 400_000, 1_100_000]))
+    for rec in in_engine:
+        eng.collect()
+        later.append(rec)
+    torch.cuda.synchronize()
+    for _t, out, want, s in later:
+        assert np.array_equal(out.cpu().numpy(), want), f"batch {s} ({plan[s]} hits)"
+        done += 1
+    assert done == len(plan)
+    assert_same_state(eng, orc)
