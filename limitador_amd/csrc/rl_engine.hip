@@ -562,6 +562,7 @@ struct GenCall {
     u64* d_exp;
     int32_t* d_limited = nullptr;  // per request: id of the limit that limited it, -1 (rl_match_and_check_batch)
     const u32* d_hit_req_ext = nullptr;  // phased form: the caller's request id of every hit (any u32, equal = same request)
+    bool hit_req_filled = false;         // e->d_hit_req already holds the request of every hit (k_match_fast wrote it)
 };
 
 // Partition of the pass's hits + k_gen_sort: everything up to the first fixpoint round.  A is filled for the kernels
@@ -692,6 +693,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         HIP_TRY(e, hipMemsetAsync(c.d_verdict + req0, 0, n_req, st));
         if (c.d_first) HIP_TRY(e, hipMemsetAsync(c.d_first + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
         if (c.d_limited) HIP_TRY(e, hipMemsetAsync(c.d_limited + req0, 0xFF, (size_t)n_req * sizeof(int32_t), st));
+        HIP_TRY(e, hipStreamSynchronize(st));
         return RL_OK;
     }
     int rc = check_room(e, 0);  // (the cells the pass creates are counted exactly below, before the commit)
@@ -837,7 +839,7 @@ int run_check_general(rl_engine* e, const GenCall& c) {
         const int crc = do_compact(e, 0);
         if (crc) return crc;
     }
-    if (c.d_req_off) k_gen_hit_req<<<cdiv(c.n_req, 256), 256, 0, e->stream>>>(c.d_req_off, c.n_req, e->d_hit_req);
+    if (c.d_req_off && !c.hit_req_filled) k_gen_hit_req<<<cdiv(c.n_req, 256), 256, 0, e->stream>>>(c.d_req_off, c.n_req, e->d_hit_req);
     // ---- passes of at most sub_max hits (consecutive requests: the semantics are sequential anyway) -----
     u32 sub_max = std::min(e->gen_sub_max, e->gen_cap);
     u32 req_cur = 0, hit_cur = 0, attempts = 0;
@@ -882,7 +884,8 @@ int run_check_general(rl_engine* e, const GenCall& c) {
         req_cur = req_end;
         hit_cur = hit_end;
     }
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    // (every pass ends with a stream synchronisation after its last kernel: the results are complete; only the
+    // memset that leaves the scratch blocks clean may still be queued, and whatever comes next is ordered behind it)
     return RL_OK;
 }
 
@@ -1126,7 +1129,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
-                    e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds};
+                    e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -1923,7 +1926,7 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
         k_match_fast<false><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_flimits,
                                                       e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_fconds,
                                                       e->n_match_conds, e->match_slots, e->d_m_count, e->d_m_mask, nullptr,
-                                                      nullptr, e->d_status);
+                                                      nullptr, e->d_status, nullptr);
     else
         k_count<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
                                           e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
@@ -1946,7 +1949,7 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
             k_match_fast<true><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req,
                                                          e->d_match_flimits, e->n_match_limits, e->d_match_ns_off,
                                                          e->n_match_ns, e->d_match_fconds, e->n_match_conds, e->match_slots,
-                                                         nullptr, e->d_m_mask, e->d_req_off, e->d_hits, e->d_status);
+                                                         nullptr, e->d_m_mask, e->d_req_off, e->d_hits, e->d_status, e->d_hit_req);
         else
             k_fill<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
                                              e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
@@ -1955,6 +1958,7 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
     }
     GenCall gc{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load, false, d_verdict, e->d_first, e->d_remaining, e->d_expires};
     gc.d_limited = d_limited;
+    gc.hit_req_filled = e->match_fast && n_hits > 0;
     return run_check_general(e, gc);
 }
 

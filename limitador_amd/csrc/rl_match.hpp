@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void k_match_fast(const u32* __restrict__ req_
                                                     const u32* __restrict__ ns_off, u32 n_ns,
                                                     const MatchCondF* __restrict__ conds, u32 n_conds, MatchSlots slots,
                                                     u32* __restrict__ count, unsigned long long* __restrict__ mask,
-                                                    const u32* __restrict__ hit_off, Hit* __restrict__ hits, Status* st) {
+                                                    const u32* __restrict__ hit_off, Hit* __restrict__ hits, Status* st,
+                                                    u32* __restrict__ hit_req) {
     __shared__ MatchLimitF s_l[MATCH_LDS_LIMITS];
     __shared__ MatchCondF s_c[MATCH_LDS_CONDS];
     __shared__ u32 s_ns[MATCH_LDS_NS + 1];
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void k_match_fast(const u32* __restrict__ req_
                 h.limit = L.limit;
                 h.delta = delta;
                 hits[out + k] = h;
+                if (hit_req) hit_req[out + k] = r;  // (what k_gen_hit_req would derive from the offsets again)
                 ++k;
             }
         }
