@@ -50,11 +50,11 @@ def parse():
     ap.add_argument("--timing-mode", type=int, default=3, choices=(0, 2, 3),
                     help="HIP events in the timed region: 2 = around k_bkt_apply on every launch, 3 = on every "
                          "fourth launch, 0 = none (roofline then comes from the breakdown pass)")
-    ap.add_argument("--sharded-impl", choices=("torch", "abi"), default=os.environ.get("RL_SHARDED_IMPL"),
-                    help="routed step driven by torch.distributed (limitador_amd/sharded.py) or by the C entry with its own "
-                         "RCCL communicator (include/rl_sharded.h).  Default: abi for --force-sharded on one GPU (measured), "
-                         "torch for N > 1 (the C entry has only run with world 1 over RCCL and world 2-3 over the in-process "
-                         "transport)")
+    ap.add_argument("--sharded-impl", choices=("torch", "abi"), default=os.environ.get("RL_SHARDED_IMPL", "abi"),
+                    help="routed step driven by the C entry with its own RCCL communicator (include/rl_sharded.h: 105 us per "
+                         "1 M-hit slice at world 1) or by torch.distributed from Python (limitador_amd/sharded.py: 181 us).  "
+                         "RL_SHARDED_IMPL=torch selects the latter.  A watchdog ends a routed run that makes no progress for "
+                         "five minutes instead of leaving the ranks at a collective.")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the routed (all-to-all) data path even with one rank (exercises the N>1 code on one GPU)")
     return ap.parse_args()
@@ -327,8 +327,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
-    if args.sharded_impl is None:
-        args.sharded_impl = "abi" if world == 1 else "torch"
+    if sharded:
+        import threading
+
+        def _stuck():
+            sys.stderr.write(f"bench.py rank {rank}: the routed run did not finish within 300 s (impl {args.sharded_impl}); "
+                             "set RL_SHARDED_IMPL=torch to drive it through torch.distributed\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        watchdog = threading.Timer(300.0, _stuck)
+        watchdog.daemon = True
+        watchdog.start()
     if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -552,6 +562,8 @@ def main():
         print(json.dumps(out), flush=True)
     if sharded and args.sharded_impl == "abi":
         sh.close()
+    if sharded:
+        watchdog.cancel()
     eng.close()
     if sharded:
         dist.destroy_process_group()
