@@ -13,5 +13,5 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 echo "smoke exit: $?" >> gpurun_out/smoke.log
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench exit: $?" >> gpurun_out/bench.err
-tail -4 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.err
+for f in gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.err; do tail -n 4 $f; done
 cat gpurun_out/bench.json
