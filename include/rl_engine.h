@@ -106,7 +106,7 @@ typedef struct {
     uint64_t batches;
     uint64_t hits;
     uint64_t ordered_hits;     /* hits that needed trace-order resolution */
-    uint64_t ordered_batches;  /* batches that ran the ordered resolver */
+    uint64_t ordered_batches;  /* batches that went through the general resolver (multi-counter / load_counters / u64 deltas) */
     uint64_t probe_steps;      /* reserved (0 unless built with RL_PROBE_STATS) */
     uint64_t rebuilds;
 } rl_stats_t;
@@ -164,7 +164,7 @@ int32_t rl_check_and_update_batch_ex(rl_engine *e, const rl_hit *hits, uint32_t 
                                      uint64_t *expires_in_us);
 /* Same, every pointer a DEVICE pointer on the engine's device (the rate quoted by bench.py).
  * Work is enqueued on the engine's stream and the call returns after the batch has completed
- * (it must read the batch status word to decide whether the ordered resolver is needed). */
+ * (its status — errors, cells created — is read back before the call returns). */
 int32_t rl_check_and_update_batch_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits,
                                          const uint32_t *d_req_off, uint32_t n_req,
                                          uint64_t now_us, int32_t load_counters,

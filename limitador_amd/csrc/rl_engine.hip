@@ -1,6 +1,6 @@
 // rl_engine.hip — C ABI (include/rl_engine.h) over the gfx950 kernels.
 //
-// The engine owns: the counter table in HBM (64-byte cells), the device limit table, the
+// The engine owns: the counter table in HBM (32-byte cells), the device limit table, the
 // per-batch scratch (hit -> slot map, ordered list, sort buffers, verdict staging) and one HIP
 // stream.  There is no CPU implementation of any entry point: without a HIP device
 // rl_engine_create fails with RL_ERR_NO_DEVICE.
@@ -85,7 +85,7 @@ struct rl_engine {
     Status* h_status = nullptr; // pinned
     BatchScratch* d_bs = nullptr;   // [3], rotating: batch k uses [k % 3] and zeroes [(k + 2) % 3] (rl_bucket.hpp)
     u64 bs_seq = 0;                 // batches of the bucketed path (partitioned or tiny) submitted so far
-    // batches of the bucketed path submitted but not yet collected (at most two)
+    // batches of the bucketed path submitted but not yet collected (at most three)
     struct Inflight {
         hipEvent_t tev[7]{};   // see collect_k1_bucketed
         Status* h_st = nullptr;  // host-mapped: written by the batch's last workgroup

@@ -29,7 +29,7 @@ constexpr int PM_LOOKUP = 0;         // never insert
 constexpr int PM_CHECK = 1;          // insert qualified, simple must pre-exist (in_memory.rs:106-107)
 constexpr int PM_UPDATE = 2;         // insert both (update_counter, in_memory.rs:51-62)
 
-// Linear probing over 64-byte cells.  Returns the slot or SLOT_INVALID.
+// Linear probing over 32-byte cells.  Returns the slot or SLOT_INVALID.
 // `first_tag` is the tag already loaded from the start slot.
 template <int MODE>
 __device__ __forceinline__ u32 probe_from(Cell* __restrict__ table, u32 log2cap, u32 slot,

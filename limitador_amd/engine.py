@@ -139,7 +139,7 @@ class Engine:
             int(bool(load_counters)), d_verdict, d_first_limited, d_remaining, d_expires))
 
     def submit_device(self, d_hits, n_hits, now_us, d_verdict, d_first_limited=None):
-        """Enqueue a single-counter batch (raw device pointers) without waiting; at most two in flight."""
+        """Enqueue a single-counter batch (raw device pointers) without waiting; at most three in flight."""
         self._check(self._lib.rl_check_and_update_submit_device(self._h, d_hits, n_hits, int(now_us), d_verdict,
                                                                 d_first_limited))
 

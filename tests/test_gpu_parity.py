@@ -112,7 +112,7 @@ def test_random_single_counter_batches(make_engine, seed):
 
 
 def test_one_hot_key_nonuniform_deltas(make_engine):
-    """Every hit on one cell, mixed deltas: the sequential walk of the ordered resolver."""
+    """Every hit on one cell, mixed deltas: the one-lane replay of the round (mixed deltas)."""
     rng = np.random.default_rng(7)
     eng, orc = pair(make_engine, [(5000, 60)])
     for step in range(4):
