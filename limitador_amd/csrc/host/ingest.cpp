@@ -10,15 +10,18 @@
 #include "../../../include/rl_ingest.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <tuple>
@@ -235,6 +238,15 @@ struct rli_ingest {
     // batch
     std::vector<uint32_t> req_ns, req_delta, ent_off{0}, ent_key, ent_val;
     std::string err;
+    // The dictionaries are read by many decoding threads at once (rli_serve_batch splits a large batch over
+    // threads) and written when a request brings a value never seen before: readers share, a writer excludes.
+    mutable std::shared_mutex dict_mu;
+};
+
+// One request, dictionary-encoded: what batch_add_sv appends to the batch arrays.
+struct EncReq {
+    uint32_t ns = 0, delta = 1;
+    std::vector<std::pair<uint32_t, uint32_t>> kv;  // (key id, value id), a repeated key reduced to its last value
 };
 
 static int32_t gfail(rli_ingest* g, int32_t rc, const char* fmt, ...) {
@@ -245,6 +257,30 @@ static int32_t gfail(rli_ingest* g, int32_t rc, const char* fmt, ...) {
     va_end(ap);
     g->err = buf;
     return rc;
+}
+
+// Threads for the host side of a batch (decode + dictionary encoding before the device call, response bytes after
+// it): one per 1024 messages, at most half the hardware threads and 32; RLI_THREADS overrides (1 = serial).
+static uint32_t serve_threads(uint32_t n) {
+    uint32_t cap = std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2));
+    if (const char* v = getenv("RLI_THREADS")) cap = (uint32_t)std::max(1, atoi(v));
+    return std::max(1u, std::min(cap, n / 1024));
+}
+
+template <class F>
+static void parallel_chunks(uint32_t n, uint32_t threads, F f) {  // f(lo, hi)
+    if (threads <= 1 || n == 0) {
+        f(0u, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const uint32_t per = (n + threads - 1) / threads;
+    for (uint32_t t = 1; t < threads; ++t) {
+        const uint32_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
+        if (lo < hi) th.emplace_back([=] { f(lo, hi); });
+    }
+    f(0u, std::min(n, per));
+    for (auto& x : th) x.join();
 }
 
 extern "C" {
@@ -379,50 +415,92 @@ void rli_batch_clear(rli_ingest* g) {
     g->ent_val.clear();
 }
 
-// One request, strings given with their lengths (protobuf strings may hold NULs).  Nothing is added unless the
-// whole request is valid: the five batch arrays only ever grow together.
-static int32_t batch_add_sv(rli_ingest* g, const std::string& ns, const std::vector<std::pair<std::string, std::string>>& entries,
-                            uint32_t delta) {
-    const int64_t nid = g->ns_ids.find(ns);
-    // a namespace no limit names has no counters (lib.rs:434-440): the empty namespace 0; so does one interned
-    // after the table was installed (its id is beyond the table's namespaces)
-    const uint32_t ns_id = (nid < 0 || (g->n_ns_installed && (uint32_t)nid >= g->n_ns_installed)) ? 0u : (uint32_t)nid;
-    // a repeated key keeps its LAST value (the reference collects the entries into a HashMap: server.rs:112-127)
+// One request, strings given with their lengths (protobuf strings may hold NULs) -> its dictionary-encoded form.
+// Thread-safe: lookups under the shared lock; a request that carries a value never seen before takes the exclusive
+// lock to intern it.  0, or RLI_HOST_ONLY when the value dictionary is at its cap (nothing is interned then).
+static int32_t encode_request(const rli_ingest* g_c, const std::string& ns, const std::vector<std::pair<std::string, std::string>>& entries,
+                              uint32_t delta, EncReq* out, std::shared_lock<std::shared_mutex>* held = nullptr) {
+    rli_ingest* g = const_cast<rli_ingest*>(g_c);
     std::vector<std::pair<uint32_t, const std::string*>> kv;  // (key id, value)
-    for (const auto& e : entries) {
-        const int64_t kid = g->key_ids.find(e.first);
-        if (kid < 0) continue;  // a key no limit reads: it cannot influence any condition or variable
-        bool replaced = false;
-        for (auto& q : kv)
-            if (q.first == (uint32_t)kid) {
-                q.second = &e.second;
-                replaced = true;
-            }
-        if (!replaced) kv.emplace_back((uint32_t)kid, &e.second);
-    }
     std::vector<uint32_t> vids;
     size_t n_new = 0;
-    for (const auto& q : kv) {
-        const int64_t v = g->val_ids.find(*q.second);
-        if (v < 0) ++n_new;
-        vids.push_back(v < 0 ? 0xFFFFFFFFu : (uint32_t)v);
+    {
+        // (a thread that encodes many requests holds the shared lock across them — taking it per request makes
+        // every thread write the lock's cache line 30 000 times per batch, and nothing scales)
+        std::shared_lock<std::shared_mutex> own;
+        if (!held) own = std::shared_lock<std::shared_mutex>(g->dict_mu);
+        const int64_t nid = g->ns_ids.find(ns);
+        // a namespace no limit names has no counters (lib.rs:434-440): the empty namespace 0; so does one interned
+        // after the table was installed (its id is beyond the table's namespaces)
+        out->ns = (nid < 0 || (g->n_ns_installed && (uint32_t)nid >= g->n_ns_installed)) ? 0u : (uint32_t)nid;
+        out->delta = delta;
+        // a repeated key keeps its LAST value (the reference collects the entries into a HashMap: server.rs:112-127)
+        for (const auto& e : entries) {
+            const int64_t kid = g->key_ids.find(e.first);
+            if (kid < 0) continue;  // a key no limit reads: it cannot influence any condition or variable
+            bool replaced = false;
+            for (auto& q : kv)
+                if (q.first == (uint32_t)kid) {
+                    q.second = &e.second;
+                    replaced = true;
+                }
+            if (!replaced) kv.emplace_back((uint32_t)kid, &e.second);
+        }
+        for (const auto& q : kv) {
+            const int64_t v = g->val_ids.find(*q.second);
+            if (v < 0) ++n_new;
+            vids.push_back(v < 0 ? 0xFFFFFFFFu : (uint32_t)v);
+        }
     }
-    if (g->val_ids.ids.size() + n_new > (size_t)g->value_cap)
+    if (n_new) {
+        if (held) held->unlock();
+        struct Relock {
+            std::shared_lock<std::shared_mutex>* h;
+            ~Relock() {
+                if (h) h->lock();
+            }
+        } relock{held};
+        std::unique_lock<std::shared_mutex> wr(g->dict_mu);
+        n_new = 0;  // (another thread may have interned some of them meanwhile)
+        for (size_t q = 0; q < kv.size(); ++q)
+            if (vids[q] == 0xFFFFFFFFu) {
+                const int64_t v = g->val_ids.find(*kv[q].second);
+                if (v < 0) ++n_new;
+                else vids[q] = (uint32_t)v;
+            }
         // The dictionary is at its cap (attacker-controlled values must not grow host state without bound; the
         // reference bounds its counters with moka's cache_size, in_memory.rs:205-212).  Only THIS request — it
         // carries a value never seen before — goes to the host path; requests made of known values go on.
-        return gfail(g, RLI_HOST_ONLY, "value dictionary at its cap of %u: request with a new value stays on the host "
-                                       "(sweep, then rli_create a fresh ingest to restart the dictionary)", g->value_cap);
-    for (size_t q = 0; q < kv.size(); ++q)
-        if (vids[q] == 0xFFFFFFFFu) vids[q] = g->val_ids.intern(*kv[q].second);
-    g->req_ns.push_back(ns_id);
-    g->req_delta.push_back(delta);
-    for (size_t q = 0; q < kv.size(); ++q) {
-        g->ent_key.push_back(kv[q].first);
-        g->ent_val.push_back(vids[q]);
+        if (g->val_ids.ids.size() + n_new > (size_t)g->value_cap) return RLI_HOST_ONLY;
+        for (size_t q = 0; q < kv.size(); ++q)
+            if (vids[q] == 0xFFFFFFFFu) vids[q] = g->val_ids.intern(*kv[q].second);
+    }
+    out->kv.clear();
+    for (size_t q = 0; q < kv.size(); ++q) out->kv.emplace_back(kv[q].first, vids[q]);
+    return 0;
+}
+
+// Nothing is added unless the whole request is valid: the five batch arrays only ever grow together.
+static int32_t batch_append(rli_ingest* g, const EncReq& r) {
+    g->req_ns.push_back(r.ns);
+    g->req_delta.push_back(r.delta);
+    for (const auto& q : r.kv) {
+        g->ent_key.push_back(q.first);
+        g->ent_val.push_back(q.second);
     }
     g->ent_off.push_back((uint32_t)g->ent_key.size());
     return (int32_t)g->req_ns.size() - 1;
+}
+
+static int32_t batch_add_sv(rli_ingest* g, const std::string& ns, const std::vector<std::pair<std::string, std::string>>& entries,
+                            uint32_t delta) {
+    EncReq r;
+    const int32_t rc = encode_request(g, ns, entries, delta, &r);
+    if (rc == RLI_HOST_ONLY)
+        return gfail(g, RLI_HOST_ONLY, "value dictionary at its cap of %u: request with a new value stays on the host "
+                                       "(sweep, then rli_create a fresh ingest to restart the dictionary)", g->value_cap);
+    if (rc) return rc;
+    return batch_append(g, r);
 }
 
 int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, const char* const* values,
@@ -449,36 +527,48 @@ int32_t rli_set_value_cap(rli_ingest* g, uint32_t cap) {
     return RL_OK;
 }
 
-int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) {
-    if (!g || (len && !msg)) return RL_ERR_INVALID;
+// A serialized RateLimitRequest -> (domain, entries of descriptors[0], delta).  Pure: no ingest state.
+// 0, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID with *what = the part that is malformed.
+static int32_t decode_rls(const uint8_t* msg, uint32_t len, std::string* domain, std::vector<std::pair<std::string, std::string>>* entries,
+                          uint32_t* delta, const char** what) {
     Wire w{msg, msg + len};
-    std::string domain;
-    std::vector<std::pair<std::string, std::string>> entries;
     uint64_t hits_addend = 0;
     uint32_t n_descriptors = 0;
+    *what = "";
     while (!w.done()) {
         uint64_t tag;
-        if (!w.varint(&tag)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (tag)");
+        if (!w.varint(&tag)) return *what = "tag", RL_ERR_INVALID;
         const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
         Wire sub;
         if (field == 1 && wt == 2) {
-            if (!w.bytes(&sub)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (domain)");
-            domain.assign(reinterpret_cast<const char*>(sub.p), (size_t)(sub.end - sub.p));
+            if (!w.bytes(&sub)) return *what = "domain", RL_ERR_INVALID;
+            domain->assign(reinterpret_cast<const char*>(sub.p), (size_t)(sub.end - sub.p));
         } else if (field == 2 && wt == 2) {
-            if (!w.bytes(&sub)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (descriptor)");
-            if (n_descriptors++ == 0 && !parse_descriptor(sub, &entries))
-                return gfail(g, RL_ERR_INVALID, "malformed RateLimitDescriptor");
+            if (!w.bytes(&sub)) return *what = "descriptor", RL_ERR_INVALID;
+            if (n_descriptors++ == 0 && !parse_descriptor(sub, entries)) return *what = "RateLimitDescriptor", RL_ERR_INVALID;
         } else if (field == 3 && wt == 0) {
-            if (!w.varint(&hits_addend)) return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (hits_addend)");
+            if (!w.varint(&hits_addend)) return *what = "hits_addend", RL_ERR_INVALID;
         } else if (!w.skip(wt)) {
-            return gfail(g, RL_ERR_INVALID, "malformed RateLimitRequest (field %u)", field);
+            return *what = "unknown field", RL_ERR_INVALID;
         }
     }
-    if (domain.empty()) return RLI_UNKNOWN_DOMAIN;
+    if (domain->empty()) return RLI_UNKNOWN_DOMAIN;
     // hits_addend is a uint32 on the wire (a longer varint is truncated by the protobuf runtime), and 0 means 1
     // (server.rs:131-137)
-    uint32_t delta = (uint32_t)hits_addend;
-    if (delta == 0) delta = 1;
+    *delta = (uint32_t)hits_addend;
+    if (*delta == 0) *delta = 1;
+    return 0;
+}
+
+int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) {
+    if (!g || (len && !msg)) return RL_ERR_INVALID;
+    std::string domain;
+    std::vector<std::pair<std::string, std::string>> entries;
+    uint32_t delta = 1;
+    const char* what = "";
+    const int32_t rc = decode_rls(msg, len, &domain, &entries, &delta, &what);
+    if (rc == RLI_UNKNOWN_DOMAIN) return rc;
+    if (rc) return gfail(g, rc, "malformed RateLimitRequest (%s)", what);
     return batch_add_sv(g, domain, entries, delta);
 }
 
@@ -567,66 +657,111 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
                         int32_t* status) {
     if (!g || !e || (n && (!msgs || !lens || !out || !out_len || !status)) || out_stride < 2) return RL_ERR_INVALID;
     rli_batch_clear(g);
+    const uint32_t threads = serve_threads(n);
+    const bool trace = getenv("RLI_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (trace)
+            std::fprintf(stderr, "[rli] %-10s at %8.1f us\n", what,
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    // ---- decode + dictionary encoding: every message on its own, many at a time ---------------------------
+    std::vector<EncReq> enc(n);
+    parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
+        std::string domain;
+        std::vector<std::pair<std::string, std::string>> entries;
+        std::shared_lock<std::shared_mutex> rd(g->dict_mu);
+        for (uint32_t i = lo; i < hi; ++i) {
+            if (((i - lo) & 255u) == 255u) {  // let a thread that has a new value to intern get its turn
+                rd.unlock();
+                rd.lock();
+            }
+            domain.clear();
+            entries.clear();
+            uint32_t delta = 1;
+            const char* what = "";
+            int32_t rc = (lens[i] && !msgs[i]) ? (int32_t)RL_ERR_INVALID : decode_rls(msgs[i], lens[i], &domain, &entries, &delta, &what);
+            if (rc == 0) rc = encode_request(g, domain, entries, delta, &enc[i], &rd);
+            status[i] = rc;  // 0, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY, < 0
+            out_len[i] = 0;
+        }
+    });
+    lap("decoded");
+    // ---- the batch, in message order --------------------------------------------------------------------
     std::vector<int32_t> req_of(n, -1);
-    for (uint32_t i = 0; i < n; ++i) {
-        status[i] = rli_batch_add_rls(g, msgs[i], lens[i]);  // request index, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY, < 0
-        if (status[i] >= 0) req_of[i] = status[i];
-        out_len[i] = 0;
-    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (status[i] == 0) req_of[i] = batch_append(g, enc[i]);
     const uint32_t n_req = (uint32_t)g->req_ns.size();
+    lap("appended");
     std::vector<uint8_t> verdict(n_req ? n_req : 1);
     std::vector<int32_t> limited(n_req ? n_req : 1);
     std::vector<uint32_t> req_off(n_req + 1, 0);
-    std::vector<rl_hit> hits;
-    std::vector<uint64_t> rem, exp;
+    std::unique_ptr<rl_hit[]> hits;  // (new T[n]: no zero fill — tens of megabytes per call otherwise)
+    std::unique_ptr<uint64_t[]> rem, exp;
     if (n_req) {
         uint32_t n_hits = 0;
         // every request derives at most one counter per limit of its namespace
-        const size_t cap = with_headers ? (size_t)n_req * std::max<size_t>(1, g->limits.size()) : 0;
+        size_t per_ns = 1;
+        {
+            std::map<std::string, size_t> cnt;
+            for (const auto& L : g->limits) per_ns = std::max(per_ns, ++cnt[L.ns]);
+        }
+        const size_t cap = with_headers ? (size_t)n_req * per_ns : 0;
         if (with_headers) {
-            hits.resize(cap);
-            rem.resize(cap);
-            exp.resize(cap);
+            hits.reset(new rl_hit[cap]);
+            rem.reset(new uint64_t[cap]);
+            exp.reset(new uint64_t[cap]);
         }
         const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
                                                     g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict.data(),
                                                     limited.data(), with_headers ? req_off.data() : nullptr,
-                                                    with_headers ? hits.data() : nullptr, (uint32_t)cap, &n_hits,
-                                                    with_headers ? rem.data() : nullptr, with_headers ? exp.data() : nullptr);
+                                                    with_headers ? hits.get() : nullptr, (uint32_t)cap, &n_hits,
+                                                    with_headers ? rem.get() : nullptr, with_headers ? exp.get() : nullptr);
         if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
     }
-    std::vector<std::pair<std::string, std::string>> hdrs;
-    for (uint32_t i = 0; i < n; ++i) {
-        std::string o;
-        if (status[i] == RLI_UNKNOWN_DOMAIN) {
-            // Code::Unknown = 0, the proto3 default: an empty message (server.rs:105-115)
-        } else if (status[i] >= 0) {
-            const uint32_t r = (uint32_t)req_of[i];
-            put_varint(o, (1u << 3) | 0u);
-            put_varint(o, verdict[r] ? 2u : 1u);  // OVER_LIMIT : OK
-            if (with_headers) {
-                std::vector<LoadedCounter> cs;
-                for (uint32_t q = req_off[r]; q < req_off[r + 1]; ++q) {
-                    const uint32_t lid = RL_LIMIT_ID(hits[q].limit);
-                    const LimitSpec* L = lid < g->limits.size() ? &g->limits[lid] : nullptr;
-                    cs.push_back(LoadedCounter{L ? L->max_value : 0, L ? L->seconds : 0, rem[q], exp[q], L});
+    lap("device");
+    // ---- the responses: independent of one another ----------------------------------------------------------
+    std::atomic<uint32_t> too_long{0};
+    parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
+        std::vector<std::pair<std::string, std::string>> hdrs;
+        std::string o, hv;
+        for (uint32_t i = lo; i < hi; ++i) {
+            o.clear();
+            if (status[i] == RLI_UNKNOWN_DOMAIN) {
+                // Code::Unknown = 0, the proto3 default: an empty message (server.rs:105-115)
+            } else if (status[i] == 0) {
+                const uint32_t r = (uint32_t)req_of[i];
+                put_varint(o, (1u << 3) | 0u);
+                put_varint(o, verdict[r] ? 2u : 1u);  // OVER_LIMIT : OK
+                if (with_headers) {
+                    std::vector<LoadedCounter> cs;
+                    for (uint32_t q = req_off[r]; q < req_off[r + 1]; ++q) {
+                        const uint32_t lid = RL_LIMIT_ID(hits[q].limit);
+                        const LimitSpec* L = lid < g->limits.size() ? &g->limits[lid] : nullptr;
+                        cs.push_back(LoadedCounter{L ? L->max_value : 0, L ? L->seconds : 0, rem[q], exp[q], L});
+                    }
+                    response_headers(std::move(cs), &hdrs);
+                    for (const auto& kv : hdrs) {  // response_headers_to_add = 3: HeaderValue { key = 1; value = 2 }
+                        hv.clear();
+                        put_string_field(hv, 1, kv.first);
+                        put_string_field(hv, 2, kv.second);
+                        put_string_field(o, 3, hv);
+                    }
                 }
-                response_headers(std::move(cs), &hdrs);
-                for (const auto& kv : hdrs) {  // response_headers_to_add = 3: HeaderValue { key = 1; value = 2 }
-                    std::string hv;
-                    put_string_field(hv, 1, kv.first);
-                    put_string_field(hv, 2, kv.second);
-                    put_string_field(o, 3, hv);
-                }
+                status[i] = verdict[r] ? 1 : 0;
+            } else {
+                continue;  // malformed / RLI_HOST_ONLY: no response, the status says why
             }
-            status[i] = verdict[r] ? 1 : 0;
-        } else {
-            continue;  // malformed / RLI_HOST_ONLY: no response, the status says why
+            if (o.size() > out_stride) {
+                too_long.store((uint32_t)o.size());
+                continue;
+            }
+            memcpy(out + (size_t)i * out_stride, o.data(), o.size());
+            out_len[i] = (uint32_t)o.size();
         }
-        if (o.size() > out_stride) return gfail(g, RL_ERR_INVALID, "response of %zu bytes does not fit the stride %u", o.size(), out_stride);
-        memcpy(out + (size_t)i * out_stride, o.data(), o.size());
-        out_len[i] = (uint32_t)o.size();
-    }
+    });
+    lap("responses");
+    if (too_long.load()) return gfail(g, RL_ERR_INVALID, "a response of %u bytes does not fit the stride %u", too_long.load(), out_stride);
     return RL_OK;
 }
 

@@ -150,3 +150,38 @@ def test_micro_batcher_in_front_of_the_wire_path(make_engine):
     assert sum(ok) == 1000
     assert requests == 64 * 40 and batches < requests
     g.close()
+
+
+def test_large_batches_are_decoded_and_answered_by_several_threads(make_engine, monkeypatch):
+    """rli_serve_batch splits the host side of a batch of more than a thousand messages over threads (decode +
+    dictionary encoding before the device call, response bytes after it).  Two identical engines, the same three
+    batches of 6000 messages (new dictionary values arriving from all threads at once, unknown domains, a few
+    malformed messages): the threaded run must answer byte for byte what the serial one (RLI_THREADS=1) answers."""
+    rng = np.random.default_rng(5)
+    methods, paths = ["GET", "POST", "PUT"], ["/", "/admin", "/json"]
+    batches = []
+    for b in range(3):
+        msgs = []
+        for i in range(6000):
+            r = rng.random()
+            domain = None if r < 0.02 else ("elsewhere" if r < 0.04 else f"ns{int(rng.integers(0, 4))}")
+            entries = [("method", methods[int(rng.integers(0, 3))]), ("path", paths[int(rng.integers(0, 3))]),
+                       ("user", f"u{b}-{int(rng.zipf(1.3)) % 3000}"), ("app", f"app{int(rng.integers(0, 3))}")]
+            m = rls_request(domain, [entries], hits_addend=int(rng.integers(0, 3)))
+            if r > 0.995:
+                m = m[: len(m) // 2]  # cut in the middle: malformed
+            msgs.append(m)
+        batches.append(msgs)
+    results = []
+    for threads in ("1", "7"):
+        monkeypatch.setenv("RLI_THREADS", threads)
+        eng, g, _model = _install(make_engine)
+        out = []
+        for b, msgs in enumerate(batches):
+            out.append(g.serve_batch(eng, msgs, NOW + b * 700_000, with_headers=bool(b % 2)))
+        results.append(out)
+    for b in range(3):
+        (s1, r1), (s7, r7) = results[0][b], results[1][b]
+        assert s1 == s7, f"batch {b}: statuses"
+        assert r1 == r7, f"batch {b}: response bytes"
+        assert sum(1 for s in s1 if s == 1) > 100 and sum(1 for s in s1 if s == 0) > 100 and any(s < -1 for s in s1)
