@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_gen_hit_req(const u32* __restrict__ req
 
 constexpr int GS_BLOCK = 256;
 constexpr int GS_WAVES = GS_BLOCK / 64;
-constexpr int GS_MAX = 1024;          // hits of one piece of k_gen_round (4 per thread)
+constexpr int GS_MAX = 512;           // hits of one piece of k_gen_round (2 per thread: 1024 -> 0.590, 512 -> 0.574, 256 -> 0.599 ms per bench_match call)
 constexpr int GS_LONG_MAX = 65535;    // hits of one hash bucket k_gen_sort takes (per-wave counters are 16 bits)
 constexpr int GS_E_LOG2 = 11;
 constexpr int GS_E = 1 << GS_E_LOG2;  // LDS cells of the in-bucket sort (load <= 1/2)
