@@ -546,7 +546,9 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
 }
 
 // ---- the general form (rl_general.hpp): multi-counter requests, load_counters, u64 deltas, update_counter ----
-constexpr u32 GEN_ROUNDS_ENQ = 4;           // fixpoint rounds enqueued blind between two looks at the status block
+constexpr u32 GEN_ROUNDS_ENQ = 3;           // fixpoint rounds enqueued blind before the first look at the status block (enough when
+                                            // the second round's admitted set is already the fixpoint: the usual large batch) ...
+constexpr u32 GEN_ROUNDS_ENQ_MORE = 6;      // ... and between two looks after that (long chains of dependent requests)
 
 struct GenCall {
     const Hit* d_hits;
@@ -714,7 +716,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         return RL_OK;
     };
     for (;;) {
-        const u32 n_enq = c.update_mode ? 1u : GEN_ROUNDS_ENQ;
+        const u32 n_enq = c.update_mode ? 1u : (round == 0 ? GEN_ROUNDS_ENQ : GEN_ROUNDS_ENQ_MORE);
         for (u32 q = 0; q < n_enq; ++q, ++round) {
             // changed[] slots of one group: round q's k_gen_admit checks slot q (did the round before still change
             // the admitted set?) and writes slot q + 1, which is what the round's own kernels check.  Round 0 has
@@ -748,7 +750,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
                          h_gst.hot_n, e->hot_threshold, err);
         if (err || h_gst.overflow || h_gst.committed) break;
         if (c.update_mode || !h_gst.changed[h_gst.last_slot]) break;  // converged, yet not committed: no room
-        if (round > n_req + 2 + GEN_ROUNDS_ENQ) return fail(e, RL_ERR_DEVICE, "general resolver did not converge (bug)");
+        if (round > n_req + 2 + GEN_ROUNDS_ENQ_MORE) return fail(e, RL_ERR_DEVICE, "general resolver did not converge (bug)");
         // not yet: forget this group's flags, counts and reached marks, go on from the last round's pass flags
         HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
         if (mark) HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, st));
