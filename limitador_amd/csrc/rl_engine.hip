@@ -595,7 +595,6 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
     HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), st));
     HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
-    if (mark) HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, st));
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
     hist_k<<<ntiles, PT_BLOCK, 0, st>>>(e->table, e->log2cap, e->seed, hits, n, e->d_limits, (u32)e->h_limits.size(), bk_log2,
                                         ntiles, e->d_bk_hist, bs, hot_use, c.update_mode ? 0u : 1u, nullptr);
@@ -732,8 +731,11 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         }
         k_gen_final<<<cdiv(n_req, 256), 256, 0, st>>>(A);
         if (mark) k_gen_reach<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A);
-        k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A);
         const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
+        // the exact count of the cells the pass creates is only needed when they might not fit: a pass of n hits
+        // creates at most n (k_gen_commit reports how many it created)
+        const bool count_first = used + n > bound;
+        if (count_first) k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A);
         k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
         HIP_TRY(e, hipGetLastError());
         HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, st));
@@ -784,7 +786,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
                     "capacity=%llu (bound 15/16): rl_resize, sweep, compact or create a larger engine",
                     h_gst.n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
     }
-    e->live += h_gst.n_new;
+    e->live += h_gst.n_inserted;  // (== n_new when k_gen_count ran)
     e->part_seq++;
     rc = cleanup();
     if (rc) return rc;

@@ -243,8 +243,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
                 *reinterpret_cast<uint4*>(A.s_hits + j) = make_uint4(hp.lo, req, idx, hh[u].delta);
                 if ((hh[u].idx_tag >> 24) != limit_fold(hp.limit)) atomicOr(&A.gst->err, ERRBIT_KEY_LIMIT);
             }
-            if (first == hp.lo && tid == 0)
+            if (first == hp.lo && tid == 0) {
                 A.seg_info[hp.lo] = gen_resolve(A, A.b_hits[hp.lo].key, hp.limit, hp.hi - hp.lo);
+                A.reached[hp.lo] = 0;  // (k_gen_reach sets it; only segment heads are ever read)
+            }
         }
         return;
     }
@@ -460,12 +462,16 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     for (int q = 0; q < RES; ++q) rlim[q] = A.hits[ridx[q]].limit;
 #pragma unroll
     for (int q = 0; q < RES; ++q)
-        if (rok[q]) A.seg_info[lo + eoff[re[q]]] = gen_resolve_from(A, ekey[re[q]], rlim[q], etot[re[q]], ra[q], rb[q]);
+        if (rok[q]) {
+            A.seg_info[lo + eoff[re[q]]] = gen_resolve_from(A, ekey[re[q]], rlim[q], etot[re[q]], ra[q], rb[q]);
+            A.reached[lo + eoff[re[q]]] = 0;
+        }
     for (u32 k = tid + RES * GS_BLOCK; k < n_act; k += GS_BLOCK) {  // (a bucket with more than 512 distinct cells)
         const u32 e = elist[k];
         const u32 seg = lo + eoff[e];
         const u32 idx = __builtin_nontemporal_load(&A.s_hits[seg].idx);
         A.seg_info[seg] = gen_resolve(A, ekey[e], A.hits[idx].limit, etot[e]);
+        A.reached[seg] = 0;
     }
     if (A.trace) {
         __syncthreads();
@@ -821,6 +827,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u3
 // k_gen_final: per request, from the last round's pass flags
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gen_final(GenArgs A) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.hot_next) A.gst->hot_n = A.hot_next->n;  // (the host adapts the threshold)
     const u32 r = blockIdx.x * 256 + threadIdx.x;
     if (r >= A.n_req || A.pst->err || A.gst->overflow) return;
     const uint8_t* pass = A.pass[A.gst->last_round & 1u];
