@@ -67,6 +67,7 @@ struct Apply2Args {
     const HotParam* hot_param;
     const unsigned short* chunk_tab;  // hot chunk -> index of its hot bucket
     u32 hot_threshold;
+    u32* hot_arrive;  // [HOT_MAX] chunks of a hot bucket that have read the key's cell (self_hot); zero between kernels
     u32 dbg;  // RL_DEBUG_APPLY2 (timing experiments only): 1 no ticket, 2 no verdict stores, 4 no write-back, 8 no cell reads
 };
 
@@ -536,6 +537,115 @@ __device__ __forceinline__ void apply2_hot_chunk(const Apply2Args& A, u32 c) {
     }
 }
 
+// The same chunk without k_hot_state (`self_hot`): every chunk's workgroup reads the key's cell itself — three
+// dependent loads (chunk table, hot-bucket row, cell) that overlap the other workgroups' chains instead of a
+// one-workgroup kernel in front of k_bkt_apply (5-7 us on the apply stream).  The cell must not change before every
+// chunk of the bucket has read it, so the workgroups count themselves in (hot_arrive) AFTER their read has returned
+// and the LAST one in applies AtomicExpiringValue::update for the bucket's admitted hits — or, when the cell's state
+// does not allow deciding from positions (every chunk comes to that same conclusion from the same unchanged cell),
+// replays the bucket with the general bucket code.  Nobody waits for anybody: no spinning, no ordering between
+// workgroups beyond the counter.
+template <int HPT, int ENT_LOG2>
+__device__ __forceinline__ void apply2_hot_chunk_self(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, u32 c) {
+    constexpr int PER = HOT_CHUNK / AP_BLOCK;
+    const u32 tid = threadIdx.x;
+    const u32 hb = A.chunk_tab[c];
+    const HotParam hp = A.hot_param[hb];
+    const u32 n_chunks_b = A.hot_param[hb + 1].chunk0 - hp.chunk0;
+    const u32 lo = hp.lo, hi = hp.hi;
+    const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
+    // the chunk's records are requested first: the cell's latency runs under theirs
+    BHit h[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const u32 j = first + u * AP_BLOCK + tid;
+        h[u] = load_bhit(A.b_hits, j < hi ? j : hi - 1);
+    }
+    // ---- the key's cell as it is before this batch (every lane reads the same addresses) --------------------
+    const u64 key = hp.key;
+    const u32 limit = hp.limit;
+    const LimitDev L = limit_row2(A, limit);
+    const u32 mask = (1u << A.log2cap) - 1u;
+    u32 slot = slot_of(key, A.seed, A.log2cap);
+    u64 value = 0, expiry = 0;
+    u32 cl = limit;
+    bool found = false;
+    for (u32 step = 0; step <= mask; ++step) {
+        const Cell* cp = &A.table[slot];
+        const uint4 a = *reinterpret_cast<const uint4*>(cp);
+        const uint4 b = reinterpret_cast<const uint4*>(cp)[1];
+        const u64 tag = ((u64)a.y << 32) | a.x;
+        if (tag == key) {
+            value = ((u64)a.w << 32) | a.z;
+            expiry = ((u64)b.y << 32) | b.x;
+            cl = b.z;
+            found = true;
+            break;
+        }
+        if (tag == TAG_EMPTY) break;
+        slot = (slot + 1) & mask;
+    }
+    const bool expired = found && expiry <= A.now;
+    const u64 s = (found && !expired) ? value : 0ull;  // value_at(now), atomic_expiring_value.rs:19-24
+    // the rule of k_hot_state (only uniform buckets own chunks, so hp.uni holds here)
+    const bool fast = L.window_us != 0 && s < (1ull << 62) && (!found || cl == limit) && (found || !(limit & SIMPLE_FLAG));
+    const u64 room = s > L.max_value ? 0ull : (hp.d ? (L.max_value - s) / hp.d : ~0ull);
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const u32 j = first + u * AP_BLOCK + tid;
+            if (j >= hi) continue;
+            const u32 i = h[u].idx_tag & 0xFFFFFFu;
+            uint8_t v = (u64)(j - lo) < room ? 0 : 1;
+            if ((h[u].idx_tag >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
+                atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
+                v = 1;
+            }
+            if (!(A.dbg & 2u)) A.verdict[i] = v;
+            if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
+        }
+    }
+    // ---- count this workgroup in: every lane's read of the cell has returned --------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) S.n_keep = atomicAdd(&A.hot_arrive[hb], 1u);
+    __syncthreads();
+    const bool last = S.n_keep + 1u == n_chunks_b;  // (block-uniform)
+    __syncthreads();  // S.n_keep is free again
+    if (!last) return;
+    if (tid == 0) atomicExch(&A.hot_arrive[hb], 0u);  // for the next kernel
+    if (!fast) {
+        // 0-second window, a value near 2^64, a cell that belongs to another limit id, a missing simple cell:
+        // the reference's arithmetic hit by hit, by this workgroup
+        apply2_clear(S);
+        if (tid == 0) S.promote_ok = 0;  // its key is kept or dropped by count (k_bkt_scatter), not promoted
+        __syncthreads();
+        apply2_bucket(S, A, lo, hi);
+        __syncthreads();
+        return;
+    }
+    if (tid == 0) {
+        // AtomicExpiringValue::update for the admitted hits
+        const u64 cnt = hi - lo;
+        const u64 n_adm = cnt < room ? cnt : room;
+        u32 wslot = found ? slot : SLOT_INVALID;
+        bool reset = expired;
+        if (!found) {  // first touch creates the cell (in_memory.rs:122-127), verdict or not
+            u32 created = 0;
+            wslot = slot_of(key, A.seed, A.log2cap);
+            wslot = probe_from<PM_CHECK>(A.table, A.log2cap, wslot, A.table[wslot].tag, key, limit, A.limits, A.now, A.st,
+                                         created);
+            if (created) atomicAdd(&A.st->n_inserted, created);
+            reset = false;
+        }
+        if (n_adm && wslot != SLOT_INVALID) {
+            Cell* cell = &A.table[wslot];
+            cell->value = s + n_adm * hp.d;
+            if (reset) cell->expiry = A.now + L.window_us;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_bkt_count_new: how many cells would this (already partitioned) batch create?  Same walk as
 // k_bkt_apply up to the point where a new key's probe chain ends at an empty slot — counted, not
@@ -624,11 +734,12 @@ __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
     const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab,
     const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
     int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
-    HotSet* hot_next, u32 hot_threshold, u32 dbg) {
+    HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive) {
     __shared__ Apply2Lds<HPT, ENT_LOG2> S;
     const u32 tid = threadIdx.x, G = gridDim.x;
+    const bool self_hot = hot_arrive != nullptr;  // no k_hot_state ran: the chunks read the hot keys' cells themselves
     Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                 hot_next, hot_param, chunk_tab, hot_threshold, dbg};
+                 hot_next, hot_param, chunk_tab, hot_threshold, hot_arrive, dbg};
     // ranges[] is in processing order (longest buckets first): the hardware hands workgroups out in
     // index order, so the long buckets start first and the short ones fill the tail
     const uint2 r = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
@@ -641,10 +752,16 @@ __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
     __syncthreads();
     if (r.x != r.y) apply2_bucket(S, A, r.x, r.y);
     // ---- the hot buckets: fast chunks from positions, the rest replayed by one workgroup each ------
-    for (u32 c = G - 1 - blockIdx.x; c < n_chunks; c += G) apply2_hot_chunk(A, c);
+    if (self_hot) {
+        __syncthreads();  // (the workgroup's own bucket is done with S)
+        for (u32 c = G - 1 - blockIdx.x; c < n_chunks; c += G) apply2_hot_chunk_self(S, A, c);
+    } else {
+        for (u32 c = G - 1 - blockIdx.x; c < n_chunks; c += G) apply2_hot_chunk(A, c);
+    }
     for (u32 hk = G - 1 - blockIdx.x; hk < (u32)HOT_MAX; hk += G) {
         const HotParam hp = hot_param[hk];  // (block-uniform)
-        if (hp.fast || hp.hi == hp.lo) continue;
+        // (self_hot: a uniform bucket is its chunks' business, whatever its cell's state turns out to be)
+        if ((self_hot ? hp.uni : hp.fast) || hp.hi == hp.lo) continue;
         __syncthreads();
         apply2_clear(S);
         if (tid == 0) S.promote_ok = 0;  // its key is kept or dropped by count (k_bkt_scatter), not promoted
@@ -704,7 +821,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
         if (tid == 0) atomicOr(&bs->st.err, s_err);
     } else if (n) {
         Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, 0u};
+                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, nullptr, 0u};
         apply2_bucket(S, A, 0, n);
     }
     // the verdicts may go straight to host-mapped memory (rl_check_and_update_batch): every wave's stores

@@ -96,7 +96,9 @@ struct HotParam {
     u32 slot;     // the key's cell, SLOT_INVALID if it has none yet                               [k_hot_state]
     u32 expired;  // the cell was expired: the first admitted hit resets the window                [k_hot_state]
     u32 uni;      // every hit of the bucket carries the same delta: the bucket owns chunks
+    u64 key;      // the bucket's key (k_bkt_apply reads the cell itself when no k_hot_state runs: self_hot)
 };
+static_assert(sizeof(HotParam) == 64, "four dwordx4 per hot bucket");
 
 // Record of the partitioned batch: the hit's key and delta, its index in the caller's batch (where
 // the verdict goes) and an 8-bit fold of its limit id — one 16-byte store per hit.  The limit id
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
             hp.lo = s_lo[tid];
             hp.hi = hp.lo + cnt;
             if (tid < nh && cnt) {
+                hp.key = hot->key[tid];
                 hp.limit = total[nbt_ + 2 * HOT_MAX + tid];
                 const u32 dmax = total[nbt_ + tid], dmin = ~total[nbt_ + HOT_MAX + tid];
                 hp.d = dmax;

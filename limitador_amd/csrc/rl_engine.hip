@@ -38,6 +38,19 @@ static_assert(sizeof(rl_match_cond) == sizeof(MatchCond), "rl_match_cond layout"
 
 constexpr u32 GEN_SUB_MAX = 4u << 20;  // most hits of one pass of the general resolver (its scratch is ~80 B per hit)
 
+// Rotation of the bucketed path's per-batch buffers.  Up to three batches are in flight and the partition of a
+// batch may run as soon as the batch `pipe_depth` (2 or 3) before it has been applied:
+//   PB_SETS  partitioned records / ranges / hot-bucket table / chunk table: batch p writes set p % 3, last read by
+//            k_bkt_apply of batch p - 3
+//   BS_ROT   scratch blocks: batch p uses [p % 4]; its k_bkt_apply zeroes [(p + 3) % 4] (= batch p - 1's, done) for
+//            batch p + 3; one more block ([BS_ROT]) belongs to k_bkt_tiny
+//   HS_SETS  hot sets: batch p picks set p % 8 and is partitioned with the one batch p - pipe_depth picked; eight,
+//            so that the set a partition rewrites is never one a batch still in flight reads (k_hot_state of batch
+//            p - 1 and p - 2 read the sets of p - 1 - depth and p - 2 - depth)
+constexpr u32 PB_SETS = 3;
+constexpr u32 BS_ROT = 4;
+constexpr u32 HS_SETS = 8;
+
 struct rl_engine {
     std::mutex mu;
     std::string err;
@@ -83,7 +96,7 @@ struct rl_engine {
     CellRow* d_row1 = nullptr;      // one staged row (rl_add_counter)
     Status* d_status = nullptr;
     Status* h_status = nullptr; // pinned
-    BatchScratch* d_bs = nullptr;   // [3], rotating: batch k uses [k % 3] and zeroes [(k + 2) % 3] (rl_bucket.hpp)
+    BatchScratch* d_bs = nullptr;   // [BS_ROT + 1], rotating (see BS_ROT)
     u64 bs_seq = 0;                 // batches of the bucketed path (partitioned or tiny) submitted so far
     // batches of the bucketed path submitted but not yet collected (at most three)
     struct Inflight {
@@ -116,10 +129,10 @@ struct rl_engine {
     u32 bk_tiles_max = 0;
     u32* d_bk_hist = nullptr;
     u32* d_bk_total = nullptr;
-    uint2* d_bk_ranges = nullptr;   // [2][BK_MAX], by partitioned batch parity
-    // Hot sets, [3], rotating: partitioned batch p is partitioned with the set batch p-2 picked ([(p+1) % 3])
-    // and picks the set of batch p+2 ([p % 3]) — two interleaved lineages, so that the partition of batch
-    // p+1 never waits for k_bkt_apply of batch p (any stale set is valid, see HotSet).
+    uint2* d_bk_ranges = nullptr;   // [PB_SETS][BK_MAX]
+    // Hot sets, [HS_SETS], rotating: partitioned batch p is partitioned with the set batch p - pipe_depth picked and
+    // picks set p % HS_SETS — interleaved lineages, so that the partition of batch p+1 never waits for k_bkt_apply
+    // of batch p (any stale set is valid, see HotSet).
     HotSet* d_hot = nullptr;
     u64 part_seq = 0;               // partitioned batches submitted so far
     // Two streams: the partition of batch k+1 (k_bkt_hist / scan / scatter, on `pstream`) overlaps
@@ -127,9 +140,12 @@ struct rl_engine {
     // or RL_OVERLAP=0 both are the same stream.
     hipStream_t pstream = nullptr, own_pstream = nullptr;
     bool overlap = true;
+    bool self_hot = true;           // RL_SELF_HOT=0: k_hot_state in front of k_bkt_apply instead of the chunks reading the hot cells
+    u32* d_hot_arrive = nullptr;    // [HOT_MAX] (apply2_hot_chunk_self)
+    u32 pipe_depth = 3;             // RL_PIPE_DEPTH (2 or 3): the partition of batch p waits for k_bkt_apply of batch p - depth
     hipEvent_t ev_parted[4]{}, ev_applied[4]{};
     u32 hot_threshold = HOT_PROMOTE;  // doubled while more keys qualify than there are hot buckets
-    HotParam* d_hot_param = nullptr;  // [2][HOT_MAX + 1], by partitioned batch parity
+    HotParam* d_hot_param = nullptr;  // [PB_SETS][HOT_MAX + 1]
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
@@ -137,9 +153,9 @@ struct rl_engine {
     u32 gen_seq = 0;
     uint8_t* h_tiny = nullptr;  // host-mapped staging of a tiny host-buffer call: the kernel reads and writes it directly
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
-    BHit* d_bk_hits = nullptr;              // [2][max_batch], by partitioned batch parity
+    BHit* d_bk_hits = nullptr;              // [PB_SETS][max_batch]
     BHit* d_tiny_hits = nullptr;            // k_bkt_tiny's record buffer
-    unsigned short* d_chunk_tab = nullptr;  // [2][...] hot chunk -> hot bucket (k_bkt_scatter -> k_bkt_apply)
+    unsigned short* d_chunk_tab = nullptr;  // [PB_SETS][...] hot chunk -> hot bucket (k_bkt_scatter -> k_bkt_apply)
     size_t chunk_tab_len = 0;
     u32 dbg_apply2 = 0;     // RL_DEBUG_APPLY2 (timing experiments only)
     int apply2_cfg = 0;     // RL_APPLY2_CFG: which instantiation of k_bkt_apply (see launch_apply)
@@ -358,7 +374,8 @@ void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u6
 #define RL_AP2(HPT, EL, MW)                                                                                     \
     k_bkt_apply<HPT, EL, MW><<<n_wg, AP_BLOCK, 0, e->stream>>>(                                                 \
         e->table, e->log2cap, e->seed, b_hits, d_hits, ranges, nb, hot_param, chunk_tab, e->d_limits, now,      \
-        d_verdict, d_first, bs, bs_zero, h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2)
+        d_verdict, d_first, bs, bs_zero, h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2,                  \
+        e->self_hot ? e->d_hot_arrive : nullptr)
     switch (e->apply2_cfg) {
         default:
         case 0: RL_AP2(1, 9, 6); break;
@@ -370,11 +387,14 @@ void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u6
 
 // Enqueue one batch of the bucketed path (no host synchronisation): the partition on `pstream`, then
 // k_hot_state + k_bkt_apply on `stream`, which therefore overlap the partition of the NEXT batch.
-//   partitioned batch p:  buffers [p % 2] (records, ranges, hot-bucket table, chunk table); scratch [p % 3],
-//   zeroes scratch [(p + 2) % 3]; partitioned with hot set [(p + 1) % 3], picks hot set [p % 3].
-//   stream order:  pstream: wait applied(p-2) | hist scan scatter | record parted(p)
+//   partitioned batch p:  buffers [p % PB_SETS] (records, ranges, hot-bucket table, chunk table); scratch [p % BS_ROT],
+//   zeroes scratch [(p + 3) % BS_ROT]; partitioned with the hot set of batch p - depth, picks hot set [p % HS_SETS].
+//   stream order:  pstream: wait applied(p - depth) | hist scan scatter | record parted(p)
 //                  stream:  wait parted(p) | k_hot_state k_bkt_apply | record applied(p)
-// (the partition of batch p+2 rewrites the buffers k_bkt_apply of batch p reads: hence the first wait.)
+// depth = pipe_depth.  With 3 the batch the partition waits for has been collected by the caller already (at most
+// three batches are in flight), so the wait never holds the partition stream back and the partitions run ahead of the
+// apply stream; with 2 (the first cut) the partition of batch p+2 started when k_bkt_apply of batch p ended, and
+// every step paid the cross-stream hand-over (~10 us of idle device, profiles/r02c trace).
 int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
     if (e->sub_seq - e->col_seq >= 3) return fail(e, RL_ERR_BUSY, "three batches are already in flight: collect one first");
     bool need_count = false;
@@ -396,7 +416,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         // untouched
         if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
         k_bkt_tiny<<<1, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_tiny_hits, e->d_limits,
-                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, e->d_bs + 3, e->d_bs + 3,
+                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, e->d_bs + BS_ROT, e->d_bs + BS_ROT,
                                                   f.h_st, (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2);
         if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[5], e->stream));
         HIP_TRY(e, hipGetLastError());
@@ -418,18 +438,19 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
     const u32 nbt = nb + HOT_MAX;
     const u64 p = e->part_seq;
-    const u32 par = (u32)(p & 1u);
-    BatchScratch* bs = e->d_bs + p % 3;
-    BatchScratch* bs_zero = e->d_bs + (p + 2) % 3;
-    const HotSet* hot_use = e->d_hot + (p + 1) % 3;
-    HotSet* hot_prod = e->d_hot + p % 3;
+    const u32 par = (u32)(p % PB_SETS);
+    const u32 depth = e->pipe_depth;
+    BatchScratch* bs = e->d_bs + p % BS_ROT;
+    BatchScratch* bs_zero = e->d_bs + (p + 3) % BS_ROT;
+    const HotSet* hot_use = e->d_hot + (p + HS_SETS - depth) % HS_SETS;
+    HotSet* hot_prod = e->d_hot + p % HS_SETS;
     BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
     uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
     HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
     unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
     hipStream_t ps = e->pstream;
     // ---- partition ----------------------------------------------------------------------------------
-    if (two_streams && p >= 2) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - 2) & 3u], 0));
+    if (two_streams && p >= depth) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - depth) & 3u], 0));
     if (t) HIP_TRY(e, hipEventRecord(f.tev[0], ps));
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
     hist_k<<<ntiles, PT_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(),
@@ -469,7 +490,8 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     }
     // ---- apply --------------------------------------------------------------------------------------
     if (t) HIP_TRY(e, hipEventRecord(f.tev[6], e->stream));
-    k_hot_state<<<1, HOT_MAX, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_limits, now, hot_use, hot_param, &bs->st);
+    if (!e->self_hot)
+        k_hot_state<<<1, HOT_MAX, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_limits, now, hot_use, hot_param, &bs->st);
     if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
     // one workgroup per hash bucket (at least 64, so that the hot chunks of a small batch still spread); the
     // last one out writes the status block straight into f.h_st (host-mapped)
@@ -574,13 +596,13 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
                               BatchScratch** bs_out) {
     hipStream_t st = e->stream;
     const u64 p = e->part_seq;
-    const u32 par = (u32)(p & 1u);
-    BatchScratch* bs = e->d_bs + p % 3;
+    const u32 par = (u32)(p % PB_SETS);
+    BatchScratch* bs = e->d_bs + p % BS_ROT;
     // Passes are blocking (nothing else is in flight), so a pass partitions with the hot set the pass right before
     // it produced — not the one from two back that the pipelined single-counter path has to use.  (With the
     // pipelined rotation every call overflowed once: the retry's promotions were never the set of the next call.)
-    const HotSet* hot_use = e->d_hot + (p + 2) % 3;
-    HotSet* hot_prod = e->d_hot + p % 3;
+    const HotSet* hot_use = e->d_hot + (p + HS_SETS - 1) % HS_SETS;
+    HotSet* hot_prod = e->d_hot + p % HS_SETS;
     BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
     uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
     HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
@@ -711,7 +733,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     Status h_bst;
     GenStatus h_gst;
     auto cleanup = [&]() -> int {  // leave the rotating scratches clean for whatever batch comes next
-        HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), st));
+        HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), st));
         return RL_OK;
     };
     for (;;) {
@@ -971,6 +993,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
+    if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
+    if (const char* v = getenv("RL_SELF_HOT")) e->self_hot = atoi(v) != 0;
     if (const char* v = getenv("RL_GEN_TRACE")) e->gen_trace = atoi(v);
     if (const char* v = getenv("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
     if (const char* v = getenv("RL_GEN_SUB_MAX")) {
@@ -1057,8 +1081,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_gst, sizeof(GenStatus));
     ALLOC(e->d_row1, sizeof(CellRow));
     ALLOC(e->d_status, sizeof(Status));
-    ALLOC(e->d_bs, 4 * sizeof(BatchScratch));  // three rotating + k_bkt_tiny's own
-    if (hipMemset(e->d_bs, 0, 4 * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_bs, (BS_ROT + 1) * sizeof(BatchScratch));  // the rotating ones + k_bkt_tiny's own
+    if (hipMemset(e->d_bs, 0, (BS_ROT + 1) * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_total, sizeof(unsigned long long));
     {
         const u32 big = cdiv(mb, PT_TILE), sm = cdiv(mb, PT_TILE_SMALL) < PT_SMALL_MAX_TILES ? cdiv(mb, PT_TILE_SMALL) : PT_SMALL_MAX_TILES;
@@ -1066,15 +1090,17 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     }
     ALLOC(e->d_bk_hist, (size_t)ROW_MAX * e->bk_tiles_max * sizeof(u32));
     ALLOC(e->d_bk_total, (size_t)ROW_MAX * sizeof(u32));
-    ALLOC(e->d_bk_ranges, 2 * (size_t)BK_MAX * sizeof(uint2));
-    ALLOC(e->d_hot, 3 * sizeof(HotSet));
-    if (hipMemset(e->d_hot, 0, 3 * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);
-    ALLOC(e->d_hot_param, 2 * (size_t)(HOT_MAX + 1) * sizeof(HotParam));
-    if (hipMemset(e->d_hot_param, 0, 2 * (size_t)(HOT_MAX + 1) * sizeof(HotParam)) != hipSuccess) return bail(RL_ERR_DEVICE);
-    ALLOC(e->d_bk_hits, 2 * mb * sizeof(BHit));
+    ALLOC(e->d_bk_ranges, PB_SETS * (size_t)BK_MAX * sizeof(uint2));
+    ALLOC(e->d_hot, HS_SETS * sizeof(HotSet));
+    if (hipMemset(e->d_hot, 0, HS_SETS * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_hot_param, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotParam));
+    if (hipMemset(e->d_hot_param, 0, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotParam)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_bk_hits, PB_SETS * mb * sizeof(BHit));
+    ALLOC(e->d_hot_arrive, (size_t)HOT_MAX * sizeof(u32));
+    if (hipMemset(e->d_hot_arrive, 0, (size_t)HOT_MAX * sizeof(u32)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_tiny_hits, (size_t)TINY_MAX * sizeof(BHit));
     e->chunk_tab_len = (size_t)mb / HOT_CHUNK + HOT_MAX + 8;
-    ALLOC(e->d_chunk_tab, 2 * e->chunk_tab_len * sizeof(unsigned short));
+    ALLOC(e->d_chunk_tab, PB_SETS * e->chunk_tab_len * sizeof(unsigned short));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
     ALLOC(e->d_m_ns, mb * sizeof(u32));
     ALLOC(e->d_m_delta, mb * sizeof(u32));
@@ -1131,7 +1157,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)
@@ -1681,7 +1707,7 @@ uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t 
 static int32_t gen_phase_close(rl_engine* e) {
     e->ph_open = false;
     e->ph_counted = false;
-    HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
 }
@@ -1720,12 +1746,12 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
         HIP_TRY(e, hipMemcpyAsync(&h_bst, &bs->st, sizeof(Status), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         if (h_bst.err | h_gst.err) {
-            HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), e->stream));
+            HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));
             return status_to_error(e, h_bst.err | h_gst.err);
         }
         if (h_gst.overflow) {  // the heavy keys were promoted: partition again with that set
             e->part_seq += 1;
-            HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, 3 * sizeof(BatchScratch), e->stream));
+            HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));
             if (attempt >= 2)
                 return fail(e, RL_ERR_BATCH_TOO_LARGE, "a hash bucket of this slice holds more than %d hits or %d cells: split the slice", GS_LONG_MAX, GS_E);
             continue;
