@@ -28,22 +28,45 @@ namespace rl {
 
 constexpr u32 AP2_BIG_DELTA = 1u << 23;  // 512 hits x (2^23 - 1) < 2^32: the round's sum fits 32 bits
 
-template <int HPT, int ENT_LOG2>
+// NARROW: the cell's limit attribute in 16 bits (id < 2^15 | simple flag).  With it the workgroup's LDS is 19.5 KB and
+// EIGHT workgroups fit a CU (160 KB), i.e. all 2048 buckets of a full-size batch are resident at once — with 22 KB
+// (seven per CU) the last 256 buckets were a second generation that started when the first workgroups ended and ran at
+// one workgroup per CU: the SQ counters of that kernel show 17 resident waves per CU on average of 28 possible
+// (scripts/exp/v1.sh).  Engines with more than 32768 limit rows take the wide form.
+template <bool NARROW>
+struct LimitWord {
+    typedef u32 type;
+};
+template <>
+struct LimitWord<true> {
+    typedef unsigned short type;
+};
+template <bool NARROW>
+__device__ __forceinline__ typename LimitWord<NARROW>::type pack_limit(u32 l) {
+    if (NARROW) return (typename LimitWord<NARROW>::type)((l & 0x7FFFu) | ((l & SIMPLE_FLAG) ? 0x8000u : 0u));
+    return (typename LimitWord<NARROW>::type)l;
+}
+template <bool NARROW>
+__device__ __forceinline__ u32 unpack_limit(typename LimitWord<NARROW>::type x) {
+    if (NARROW) return ((u32)x & 0x7FFFu) | (((u32)x & 0x8000u) ? SIMPLE_FLAG : 0u);
+    return (u32)x;
+}
+
+template <int HPT, int ENT_LOG2, bool NARROW = false>
 struct Apply2Lds {
     static constexpr int E = 1 << ENT_LOG2;
     static constexpr int R = AP_BLOCK * HPT;          // hits per decide/commit round
     static constexpr int KEEP = E * 3 / 4 - R;        // rebuild the LDS cells before a round if more are live
+    static constexpr bool narrow = NARROW;
     static_assert(KEEP > 0, "the LDS hash must hold one round at load <= 3/4");
     u64 key[E];
     u64 run[E];    // value the next hit reads; for 0-second windows: the last admitted delta
     u64 agg[E];    // this round: hits per wave (4 x 8 bits, bits 32..63) | sum of deltas < 2^23 (bits 0..31)
     u32 slot[E];
-    u32 limit[E];  // the CELL's limit attribute
     u32 dmax[E];   // this round: largest delta
     u32 flags[E];  // EF_* | hits absorbed << EF_COUNT_SHIFT
-    u32 h_delta[R];
-    unsigned short h_ent[R];
-    uint8_t h_verdict[R];
+    typename LimitWord<NARROW>::type limit[E];  // the CELL's limit attribute (pack_limit)
+    unsigned short h_ent[R];  // the round's hits -> LDS cell (for the sequential replay of slow cells)
     u32 n_ent;
     u32 bucket_len;
     u32 promote_ok;
@@ -87,13 +110,15 @@ __device__ __forceinline__ u32 agg_count(u64 agg) {
 
 // Write the dirty LDS cells back; optionally rebuild the LDS hash keeping only the hot entries.
 // Ends with every thread past a barrier when `rebuild`.
-template <int HPT, int ENT_LOG2>
-__device__ __forceinline__ void apply2_commit(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, bool rebuild) {
-    constexpr int E = 1 << ENT_LOG2;
+template <class LDS>
+__device__ __forceinline__ void apply2_commit(LDS& S, const Apply2Args& A, bool rebuild) {
+    constexpr int E = LDS::E;
     constexpr int PER = E / AP_BLOCK;
-    constexpr int KEEP = Apply2Lds<HPT, ENT_LOG2>::KEEP;
+    constexpr int KEEP = LDS::KEEP;
+    constexpr bool NARROW = LDS::narrow;
     u64 k_key[PER], k_run[PER];
-    u32 k_slot[PER], k_limit[PER], k_flags[PER];
+    u32 k_slot[PER], k_flags[PER];
+    typename LimitWord<NARROW>::type k_limit[PER];
     bool keep[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -111,7 +136,7 @@ __device__ __forceinline__ void apply2_commit(Apply2Lds<HPT, ENT_LOG2>& S, const
         }
         if ((f & EF_DIRTY) && !(A.dbg & 4u)) {
             Cell* c = &A.table[S.slot[e]];
-            const LimitDev L = limit_row2(A, S.limit[e]);
+            const LimitDev L = limit_row2(A, unpack_limit<NARROW>(S.limit[e]));
             c->value = S.run[e];
             if (f & EF_EXPIRED) c->expiry = A.now + L.window_us;  // update_if_expired, atomic_expiring_value.rs:87-99
             // the window is open again — except a 0-second one, which is expired at every read
@@ -161,10 +186,11 @@ __device__ __forceinline__ void apply2_commit(Apply2Lds<HPT, ENT_LOG2>& S, const
 
 // One decide/commit round over the hits [first, first + n_items) of the partitioned batch
 // (n_items <= R), in trace order.  Ends with every thread past a barrier.
-template <int HPT, int ENT_LOG2>
-__device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, u32 first,
-                                             u32 n_items) {
-    constexpr int E = 1 << ENT_LOG2;
+template <class LDS>
+__device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 first, u32 n_items) {
+    constexpr int E = LDS::E;
+    constexpr int HPT = LDS::R / AP_BLOCK;
+    constexpr bool NARROW = LDS::narrow;
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, w = tid >> 6;
     const u64 lt = (1ull << lane) - 1ull;
@@ -237,7 +263,6 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
         before[u] = atomicAdd(&S.agg[ent[u]], (1ull << (32 + 8 * w)) | (u64)(d < AP2_BIG_DELTA ? d : 0u));
         seen_dmax[u] = S.dmax[ent[u]];
         S.h_ent[p] = (unsigned short)ent[u];
-        S.h_delta[p] = d;
     }
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
@@ -313,7 +338,7 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
         const bool expired = expiry <= A.now;
         S.run[e] = expired ? 0ull : value;  // value_at(now), atomic_expiring_value.rs:19-24
         S.slot[e] = slot;
-        S.limit[e] = cl;
+        S.limit[e] = pack_limit<NARROW>(cl);
         S.flags[e] = (expired ? EF_EXPIRED : 0u) | (slot == SLOT_INVALID ? EF_BAD : 0u);
     }
     if (created) atomicAdd(&S.n_created, created);
@@ -329,7 +354,7 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
         room[u] = 0;
         if (!ok[u]) continue;
         const u32 e = ent[u];
-        const u32 el = S.limit[e];
+        const u32 el = unpack_limit<NARROW>(S.limit[e]);
         if (limit_fold(el) != (h[u].idx_tag >> 24)) {
             atomicOr(&S.flags[e], EF_BAD);
             atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
@@ -392,14 +417,17 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
     }
     __syncthreads();
     // ---- slow entries: one lane replays the round in trace order, reference arithmetic -----------
+    // (rare: the lane reads each hit's record again and stores its verdict itself — no LDS copies of the round's
+    // deltas and verdicts, which is what lets eight workgroups share a CU)
     if (S.any_slow) {
         if (tid == 0) {
             for (u32 p = 0; p < n_items; ++p) {
                 const u32 e = S.h_ent[p];
                 const u32 f = S.flags[e];
                 if (!(f & EF_SLOW) || (f & EF_BAD)) continue;
-                const LimitDev Le = limit_row2(A, S.limit[e]);
-                const u64 d = S.h_delta[p];
+                const LimitDev Le = limit_row2(A, unpack_limit<NARROW>(S.limit[e]));
+                const BHit hp = load_bhit(A.b_hits, first + p);
+                const u64 d = hp.delta;
                 const u64 cur = Le.window_us == 0 ? 0ull : S.run[e];
                 const u64 sum = cur + d;  // wraps like the reference's release build (in_memory.rs:88)
                 const bool adm = sum <= Le.max_value;
@@ -407,28 +435,29 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
                     S.run[e] = Le.window_us == 0 ? d : sum;
                     S.flags[e] = f | EF_DIRTY | (Le.window_us == 0 ? EF_EXPIRED : 0u);
                 }
-                S.h_verdict[p] = adm ? 0 : 1;
+                const u32 i = hp.idx_tag & 0xFFFFFFu;
+                if (!(A.dbg & 2u)) A.verdict[i] = adm ? 0 : 1;
+                if (A.first_limited) A.first_limited[i] = adm ? -1 : (int32_t)i;
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < HPT; ++u)
-            if (slow[u]) v[u] = S.h_verdict[tid * HPT + u];
     }
     // ---- D: the round's first arriver of each key folds the round into `run` --------------------
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
         if (!ok[u]) continue;
         const u32 i = idx[u];
-        if (!(A.dbg & 2u)) A.verdict[i] = v[u];
-        if (A.first_limited) A.first_limited[i] = v[u] ? (int32_t)i : -1;
+        if (!slow[u]) {  // (a slow hit's verdict was stored by the replay above)
+            if (!(A.dbg & 2u)) A.verdict[i] = v[u];
+            if (A.first_limited) A.first_limited[i] = v[u] ? (int32_t)i : -1;
+        }
         if (!leader[u]) continue;
         const u32 e = ent[u];
         u32 f = S.flags[e];
         const u64 agg = S.agg[e];
         const u64 cnt = agg_count(agg);
         if (!(f & (EF_SLOW | EF_BAD))) {
-            const LimitDev Le = limit_row2(A, S.limit[e]);
+            const LimitDev Le = limit_row2(A, unpack_limit<NARROW>(S.limit[e]));
             const u64 run = S.run[e], sum = agg & 0xFFFFFFFFull;
             const u64 dm = S.dmax[e];
             if (run + sum <= Le.max_value) {  // no overflow here: overflowing rounds are slow
@@ -454,9 +483,9 @@ __device__ __forceinline__ void apply2_round(Apply2Lds<HPT, ENT_LOG2>& S, const 
 }
 
 // Empty LDS cells (all threads; the caller places the barrier).
-template <int HPT, int ENT_LOG2>
-__device__ __forceinline__ void apply2_clear(Apply2Lds<HPT, ENT_LOG2>& S) {
-    constexpr int E = 1 << ENT_LOG2;
+template <class LDS>
+__device__ __forceinline__ void apply2_clear(LDS& S) {
+    constexpr int E = LDS::E;
     for (u32 e = threadIdx.x; e < (u32)E; e += AP_BLOCK) {
         S.key[e] = TAG_EMPTY;
         S.agg[e] = 0;
@@ -468,10 +497,10 @@ __device__ __forceinline__ void apply2_clear(Apply2Lds<HPT, ENT_LOG2>& S) {
 // A whole bucket [lo, hi) of the partitioned batch, in trace order, by one workgroup.  The LDS
 // cells must be empty on entry; they are NOT cleared on exit (callers that replay a second bucket
 // clear them again).
-template <int HPT, int ENT_LOG2>
-__device__ __forceinline__ void apply2_bucket(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, u32 lo, u32 hi) {
-    constexpr int R = AP_BLOCK * HPT;
-    constexpr int KEEP = Apply2Lds<HPT, ENT_LOG2>::KEEP;
+template <class LDS>
+__device__ __forceinline__ void apply2_bucket(LDS& S, const Apply2Args& A, u32 lo, u32 hi) {
+    constexpr int R = LDS::R;
+    constexpr int KEEP = LDS::KEEP;
     if (threadIdx.x == 0) {
         S.n_ent = 0;
         S.any_slow = 0;
@@ -545,8 +574,8 @@ __device__ __forceinline__ void apply2_hot_chunk(const Apply2Args& A, u32 c) {
 // does not allow deciding from positions (every chunk comes to that same conclusion from the same unchanged cell),
 // replays the bucket with the general bucket code.  Nobody waits for anybody: no spinning, no ordering between
 // workgroups beyond the counter.
-template <int HPT, int ENT_LOG2>
-__device__ __forceinline__ void apply2_hot_chunk_self(Apply2Lds<HPT, ENT_LOG2>& S, const Apply2Args& A, u32 c) {
+template <class LDS>
+__device__ __forceinline__ void apply2_hot_chunk_self(LDS& S, const Apply2Args& A, u32 c) {
     constexpr int PER = HOT_CHUNK / AP_BLOCK;
     const u32 tid = threadIdx.x;
     const u32 hb = A.chunk_tab[c];
@@ -555,11 +584,11 @@ __device__ __forceinline__ void apply2_hot_chunk_self(Apply2Lds<HPT, ENT_LOG2>& 
     const u32 lo = hp.lo, hi = hp.hi;
     const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
     // the chunk's records are requested first: the cell's latency runs under theirs
-    BHit h[PER];
+    u32 h_tag[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const u32 j = first + u * AP_BLOCK + tid;
-        h[u] = load_bhit(A.b_hits, j < hi ? j : hi - 1);
+        h_tag[u] = A.b_hits[j < hi ? j : hi - 1].idx_tag;
     }
     // ---- the key's cell as it is before this batch (every lane reads the same addresses) --------------------
     const u64 key = hp.key;
@@ -595,9 +624,9 @@ __device__ __forceinline__ void apply2_hot_chunk_self(Apply2Lds<HPT, ENT_LOG2>& 
         for (int u = 0; u < PER; ++u) {
             const u32 j = first + u * AP_BLOCK + tid;
             if (j >= hi) continue;
-            const u32 i = h[u].idx_tag & 0xFFFFFFu;
+            const u32 i = h_tag[u] & 0xFFFFFFu;
             uint8_t v = (u64)(j - lo) < room ? 0 : 1;
-            if ((h[u].idx_tag >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
+            if ((h_tag[u] >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
                 atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
                 v = 1;
             }
@@ -727,7 +756,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restri
     if (tid == 0 && s_new) atomicAdd(n_new_out, s_new);
 }
 
-template <int HPT, int ENT_LOG2, int MIN_WAVES>
+template <int HPT, int ENT_LOG2, int MIN_WAVES, bool NARROW>
 __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
     Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits,
     const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
@@ -735,7 +764,7 @@ __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
     const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
     int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
     HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive) {
-    __shared__ Apply2Lds<HPT, ENT_LOG2> S;
+    __shared__ Apply2Lds<HPT, ENT_LOG2, NARROW> S;
     const u32 tid = threadIdx.x, G = gridDim.x;
     const bool self_hot = hot_arrive != nullptr;  // no k_hot_state ran: the chunks read the hot keys' cells themselves
     Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
@@ -790,7 +819,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
     const LimitDev* __restrict__ limits, u32 n_limits, u64 now, uint8_t* __restrict__ verdict,
     int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
     u32 hot_n_report) {
-    __shared__ Apply2Lds<1, 9> S;
+    __shared__ Apply2Lds<1, 9, false> S;
     __shared__ u32 s_err;
     const u32 tid = threadIdx.x;
     if (tid == 0) {

@@ -144,6 +144,7 @@ struct rl_engine {
     u32* d_hot_arrive = nullptr;    // [HOT_MAX] (apply2_hot_chunk_self)
     u32 pipe_depth = 3;             // RL_PIPE_DEPTH (2 or 3): the partition of batch p waits for k_bkt_apply of batch p - depth
     hipEvent_t ev_parted[4]{}, ev_applied[4]{};
+    hipEvent_t ev_match = nullptr;  // behind the copies of the matcher's count pass (match_and_check_locked)
     u32 hot_threshold = HOT_PROMOTE;  // doubled while more keys qualify than there are hot buckets
     HotParam* d_hot_param = nullptr;  // [PB_SETS][HOT_MAX + 1]
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
@@ -364,23 +365,26 @@ int settle_inflight(rl_engine* e) {
     return RL_OK;
 }
 
-// k_bkt_apply in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD>.
+// k_bkt_apply in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD, 16-bit limit ids>.
 void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u64 now, uint8_t* d_verdict,
                   int32_t* d_first, BatchScratch* bs, BatchScratch* bs_zero, Status* h_st, u32 seq, HotSet* hot_prod) {
     const BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
     const uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
     const HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
     const unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
-#define RL_AP2(HPT, EL, MW)                                                                                     \
-    k_bkt_apply<HPT, EL, MW><<<n_wg, AP_BLOCK, 0, e->stream>>>(                                                 \
+#define RL_AP2(HPT, EL, MW, NARROW)                                                                             \
+    k_bkt_apply<HPT, EL, MW, NARROW><<<n_wg, AP_BLOCK, 0, e->stream>>>(                                         \
         e->table, e->log2cap, e->seed, b_hits, d_hits, ranges, nb, hot_param, chunk_tab, e->d_limits, now,      \
         d_verdict, d_first, bs, bs_zero, h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2,                  \
         e->self_hot ? e->d_hot_arrive : nullptr)
-    switch (e->apply2_cfg) {
+    // 0 (default): 19.5 KB of LDS, eight workgroups per CU — limit ids in 16 bits, so engines with more than 32768 limit
+    // rows take 1: the same kernel with 32-bit limit ids (21.5 KB, seven per CU).  2 / 3: 1024 LDS cells (experiments).
+    switch (e->apply2_cfg == 0 && e->max_limits > 32768u ? 1 : e->apply2_cfg) {
         default:
-        case 0: RL_AP2(1, 9, 6); break;
-        case 2: RL_AP2(1, 10, 3); break;
-        case 3: RL_AP2(2, 10, 3); break;
+        case 0: RL_AP2(1, 9, 8, true); break;
+        case 1: RL_AP2(1, 9, 6, false); break;
+        case 2: RL_AP2(1, 10, 3, false); break;
+        case 3: RL_AP2(2, 10, 3, false); break;
     }
 #undef RL_AP2
 }
@@ -1045,6 +1049,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
     for (auto& ev : e->ev_applied)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
+    if (hipEventCreateWithFlags(&e->ev_match, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0)
@@ -1177,6 +1182,7 @@ void rl_engine_destroy(rl_engine* e) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_applied)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_match) (void)hipEventDestroy(e->ev_match);
     if (e->own_pstream) (void)hipStreamDestroy(e->own_pstream);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -1956,7 +1962,7 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
         k_match_fast<false><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_flimits,
                                                       e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_fconds,
                                                       e->n_match_conds, e->match_slots, e->d_m_count, e->d_m_mask, nullptr,
-                                                      nullptr, e->d_status, nullptr);
+                                                      nullptr, e->d_status, nullptr, 0u);
     else
         k_count<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
                                           e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
@@ -1965,21 +1971,40 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
     HIP_TRY(e, rocprim::exclusive_scan(e->d_m_scan_tmp, stmp, e->d_m_count, e->d_req_off, 0u, (size_t)n_req + 1,
                                        rocprim::plus<u32>(), e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_req_off + n_req, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-    int rc = read_status(e);
-    if (rc) return rc;
+    int rc = RL_OK;
+    bool filled = false;
+    if (e->match_fast && e->ev_match) {
+        // the slot form: the fill pass goes into the queue right away (it reads the total on the device) and the host
+        // waits for the two copies only — its round trip and the launches of the resolver run under the fill pass
+        HIP_TRY(e, hipMemcpyAsync(e->h_status, e->d_status, sizeof(Status), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipEventRecord(e->ev_match, e->stream));
+        k_match_fast<true><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req,
+                                                     e->d_match_flimits, e->n_match_limits, e->d_match_ns_off,
+                                                     e->n_match_ns, e->d_match_fconds, e->n_match_conds, e->match_slots,
+                                                     nullptr, e->d_m_mask, e->d_req_off, e->d_hits, e->d_status, e->d_hit_req,
+                                                     e->max_batch);
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipEventSynchronize(e->ev_match));
+        filled = true;
+        if (e->h_status->err || e->h_m_total[0] > e->max_batch) HIP_TRY(e, hipStreamSynchronize(e->stream));  // refused below
+    } else {
+        rc = read_status(e);
+        if (rc) return rc;
+    }
     if (e->h_status->err & ERRBIT_RESERVED_KEY)
         return fail(e, RL_ERR_INVALID, "a value id does not fit %u bits: such dictionaries keep the host path", MATCH_VAL_BITS);
     if (e->h_status->err) return status_to_error(e, e->h_status->err);
     const u32 n_hits = e->h_m_total[0];
     if (n_hits_out) *n_hits_out = n_hits;
     if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the requests expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
-    if (n_hits) {
+    if (n_hits && !filled) {
         HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
         if (e->match_fast)
             k_match_fast<true><<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req,
                                                          e->d_match_flimits, e->n_match_limits, e->d_match_ns_off,
                                                          e->n_match_ns, e->d_match_fconds, e->n_match_conds, e->match_slots,
-                                                         nullptr, e->d_m_mask, e->d_req_off, e->d_hits, e->d_status, e->d_hit_req);
+                                                         nullptr, e->d_m_mask, e->d_req_off, e->d_hits, e->d_status, e->d_hit_req,
+                                                         e->max_batch);
         else
             k_fill<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
                                              e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,

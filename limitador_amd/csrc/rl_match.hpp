@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void k_match_fast(const u32* __restrict__ req_
                                                     const MatchCondF* __restrict__ conds, u32 n_conds, MatchSlots slots,
                                                     u32* __restrict__ count, unsigned long long* __restrict__ mask,
                                                     const u32* __restrict__ hit_off, Hit* __restrict__ hits, Status* st,
-                                                    u32* __restrict__ hit_req) {
+                                                    u32* __restrict__ hit_req, u32 max_hits) {
+    // The fill pass is enqueued before the host has seen the total of the count pass (its round trip runs under this
+    // kernel): a batch that expands to more counters than the staging buffers hold writes nothing — the host refuses it.
+    if (FILL && hit_off[n_req] > max_hits) return;
     __shared__ MatchLimitF s_l[MATCH_LDS_LIMITS];
     __shared__ MatchCondF s_c[MATCH_LDS_CONDS];
     __shared__ u32 s_ns[MATCH_LDS_NS + 1];
