@@ -450,9 +450,8 @@ def main():
         step(i, now)
         now += 1000
     drain()
-    # Per-kernel breakdown, OUTSIDE the timed region: events between all four kernels (each event marker
-    # idles the device ~5 us, so this mode is not the one the throughput is quoted in).  The warm-up
-    # batches are replayed.
+    # Per-kernel breakdown, OUTSIDE the timed region: every kernel of a batch launched with its own start / stop
+    # events, one blocking call per batch (so each kernel runs alone).  The warm-up batches are replayed.
     eng.kernel_timing(1)
     eng.kernel_timing_read(reset=True)
     for i in range(min(args.warmup, 5)):
@@ -532,7 +531,7 @@ def main():
                        "table_capacity_cells": cap, "cell_bytes": 32, "table_bytes": cap * 32,
                        "parallelism": (f"hash-sharded x{world}, RCCL all-to-all" + (" behind the C ABI (rl_sharded_*)" if args.sharded_impl == "abi" else " (torch.distributed)")) if sharded else "single GPU",
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
-                       "overlap": "partition of batch k+1 (own stream) beside k_hot_state + k_bkt_apply of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
+                       "overlap": "partition of batches k+1, k+2 (own stream) beside k_bkt_apply of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
                        "denied_in_last_batch": denied},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
@@ -542,10 +541,11 @@ def main():
                          "algorithmic_bytes_per_hit": ALGO_BYTES[dom], "hits_per_launch": hits_per_launch,
                          "avg_launch_ms": per.get(dom, 0.0),
                          "avg_launch_ms_alone": per_alone.get(dom),
-                         "timed_with": (f"HIP events around this kernel on {kt['launches']} of the {args.steps} "
-                                        "launches of the timed region (the partition of the next batch runs beside it on a "
+                         "timed_with": (f"HIP events on {kt['launches']} of the {args.steps} launches of the timed region: "
+                                        "the launch carries its own start / stop events (hipExtLaunchKernelGGL), no marker "
+                                        "commands around the kernel; the partition of the next batches runs beside it on a "
                                         "second stream; avg_launch_ms_alone: the same kernel in the breakdown pass, one "
-                                        "blocking call per batch)") if dom in timed
+                                        "blocking call per batch") if dom in timed
                          else "HIP events in the breakdown pass before the timed region"},
             "pipeline": {"kernel_ms_per_batch": per, "device_ms_per_batch": pipe_ms,
                          "achieved_GBps_49B": ALGO_BYTES_TOTAL * hits_per_launch / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,

@@ -90,6 +90,7 @@ struct Apply2Args {
     const HotParam* hot_param;
     const unsigned short* chunk_tab;  // hot chunk -> index of its hot bucket
     u32 hot_threshold;
+    u32 sparse_out;   // verdict[] / first_limited[] already say "admitted" (k_bkt_hist): only denials are stored
     u32* hot_arrive;  // [HOT_MAX] chunks of a hot bucket that have read the key's cell (self_hot); zero between kernels
     u32 dbg;  // RL_DEBUG_APPLY2 (timing experiments only): 1 no ticket, 2 no verdict stores, 4 no write-back, 8 no cell reads
 };
@@ -136,11 +137,14 @@ __device__ __forceinline__ void apply2_commit(LDS& S, const Apply2Args& A, bool 
         }
         if ((f & EF_DIRTY) && !(A.dbg & 4u)) {
             Cell* c = &A.table[S.slot[e]];
-            const LimitDev L = limit_row2(A, unpack_limit<NARROW>(S.limit[e]));
             c->value = S.run[e];
-            if (f & EF_EXPIRED) c->expiry = A.now + L.window_us;  // update_if_expired, atomic_expiring_value.rs:87-99
-            // the window is open again — except a 0-second one, which is expired at every read
-            if (L.window_us != 0) f &= ~EF_EXPIRED;
+            if (f & EF_EXPIRED) {  // (the limit row is only read when the window is reset: no dependent load in front of
+                                   // the usual write-back)
+                const LimitDev L = limit_row2(A, unpack_limit<NARROW>(S.limit[e]));
+                c->expiry = A.now + L.window_us;  // update_if_expired, atomic_expiring_value.rs:87-99
+                // the window is open again — except a 0-second one, which is expired at every read
+                if (L.window_us != 0) f &= ~EF_EXPIRED;
+            }
             f &= ~EF_DIRTY;
         }
         if (rebuild && (f >> EF_COUNT_SHIFT) >= EF_HOT_MIN && !(f & EF_BAD)) {
@@ -436,8 +440,10 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
                     S.flags[e] = f | EF_DIRTY | (Le.window_us == 0 ? EF_EXPIRED : 0u);
                 }
                 const u32 i = hp.idx_tag & 0xFFFFFFu;
-                if (!(A.dbg & 2u)) A.verdict[i] = adm ? 0 : 1;
-                if (A.first_limited) A.first_limited[i] = adm ? -1 : (int32_t)i;
+                if (!adm || !A.sparse_out) {
+                    if (!(A.dbg & 2u)) A.verdict[i] = adm ? 0 : 1;
+                    if (A.first_limited) A.first_limited[i] = adm ? -1 : (int32_t)i;
+                }
             }
         }
         __syncthreads();
@@ -447,7 +453,7 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
     for (int u = 0; u < HPT; ++u) {
         if (!ok[u]) continue;
         const u32 i = idx[u];
-        if (!slow[u]) {  // (a slow hit's verdict was stored by the replay above)
+        if (!slow[u] && (v[u] || !A.sparse_out)) {  // (a slow hit's verdict was stored by the replay above)
             if (!(A.dbg & 2u)) A.verdict[i] = v[u];
             if (A.first_limited) A.first_limited[i] = v[u] ? (int32_t)i : -1;
         }
@@ -539,6 +545,7 @@ __device__ __forceinline__ void apply2_hot_chunk(const Apply2Args& A, u32 c) {
             atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
             v = 1;
         }
+        if (!v && A.sparse_out) continue;
         if (!(A.dbg & 2u)) A.verdict[i] = v;
         if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
     }
@@ -630,6 +637,7 @@ __device__ __forceinline__ void apply2_hot_chunk_self(LDS& S, const Apply2Args& 
                 atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
                 v = 1;
             }
+            if (!v && A.sparse_out) continue;
             if (!(A.dbg & 2u)) A.verdict[i] = v;
             if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
         }
@@ -763,12 +771,12 @@ __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
     const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab,
     const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
     int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
-    HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive) {
+    HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out) {
     __shared__ Apply2Lds<HPT, ENT_LOG2, NARROW> S;
     const u32 tid = threadIdx.x, G = gridDim.x;
     const bool self_hot = hot_arrive != nullptr;  // no k_hot_state ran: the chunks read the hot keys' cells themselves
     Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                 hot_next, hot_param, chunk_tab, hot_threshold, hot_arrive, dbg};
+                 hot_next, hot_param, chunk_tab, hot_threshold, sparse_out, hot_arrive, dbg};
     // ranges[] is in processing order (longest buckets first): the hardware hands workgroups out in
     // index order, so the long buckets start first and the short ones fill the tail
     const uint2 r = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
         if (tid == 0) atomicOr(&bs->st.err, s_err);
     } else if (n) {
         Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, nullptr, 0u};
+                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, 0u, nullptr, 0u};
         apply2_bucket(S, A, 0, n);
     }
     // the verdicts may go straight to host-mapped memory (rl_check_and_update_batch): every wave's stores

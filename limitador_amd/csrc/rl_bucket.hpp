@@ -192,7 +192,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
                                                        u32 n_limits, u32 bk_log2, u32 ntiles,
                                                        u32* __restrict__ hist, BatchScratch* bs,
                                                        const HotSet* __restrict__ hot, u32 check_simple,
-                                                       u64* htrace) {
+                                                       u64* htrace, uint8_t* __restrict__ verdict_fill,
+                                                       int32_t* __restrict__ first_fill) {
     __shared__ u32 s_hist[BKT_MAX];
     __shared__ u64 s_hot_key[HOT_HASH];
     __shared__ u32 s_hot_idx[HOT_HASH];
@@ -224,6 +225,18 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
     for (int r = 0; r < STEPS; ++r) {
         const u32 i = base + r * PT_BLOCK + tid;
         if (i < n) h[r] = load_hit(hits, i);
+    }
+    // "admitted" is the default answer, written here as coalesced stores while the batch streams by; k_bkt_apply then
+    // scatters only the denials (a scattered 1-byte store per hit was 5.8 us of its 39: scripts/exp/v2.sh)
+    if (verdict_fill) {
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) {
+            const u32 i = base + r * PT_BLOCK + tid;
+            if (i < n) {
+                verdict_fill[i] = 0;
+                if (first_fill) first_fill[i] = -1;
+            }
+        }
     }
     RL_HSTAMP(1);
     hot_table_build(hot, seed, s_hot_key, s_hot_idx);

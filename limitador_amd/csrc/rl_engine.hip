@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rocprim/device/device_scan.hpp>
 #include <algorithm>
 #include <chrono>
@@ -100,7 +101,7 @@ struct rl_engine {
     u64 bs_seq = 0;                 // batches of the bucketed path (partitioned or tiny) submitted so far
     // batches of the bucketed path submitted but not yet collected (at most three)
     struct Inflight {
-        hipEvent_t tev[7]{};   // see collect_k1_bucketed
+        hipEvent_t tev[10]{};  // start / stop of each kernel of a timed batch, see collect_k1_bucketed
         Status* h_st = nullptr;  // host-mapped: written by the batch's last workgroup
         u32 n = 0, n_wg = 0, ntiles = 0;
         int timed = 0;
@@ -365,18 +366,32 @@ int settle_inflight(rl_engine* e) {
     return RL_OK;
 }
 
+// A launch that is timed carries its own start / stop events (hipExtLaunchKernelGGL: the events get the dispatch's
+// begin and end timestamps), so a timed kernel has no marker commands around it — two hipEventRecord markers added
+// 4-6 us to the interval and ~5 us of idle device each (the figure then disagreed with rocprofv3's by that much).
+#define RL_LAUNCH_T(timed, ev0, ev1, kern, grid, block, stream, ...)                                               \
+    do {                                                                                                           \
+        if (timed) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, ev0, ev1, 0, __VA_ARGS__);      \
+        else kern<<<dim3(grid), dim3(block), 0, stream>>>(__VA_ARGS__);                                            \
+    } while (0)
+
 // k_bkt_apply in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD, 16-bit limit ids>.
 void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u64 now, uint8_t* d_verdict,
-                  int32_t* d_first, BatchScratch* bs, BatchScratch* bs_zero, Status* h_st, u32 seq, HotSet* hot_prod) {
+                  int32_t* d_first, BatchScratch* bs, BatchScratch* bs_zero, Status* h_st, u32 seq, HotSet* hot_prod,
+                  bool timed, hipEvent_t ev0, hipEvent_t ev1) {
     const BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
     const uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
     const HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
     const unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
+    u32* hot_arrive = e->self_hot ? e->d_hot_arrive : nullptr;
+    const LimitDev* limits = e->d_limits;
 #define RL_AP2(HPT, EL, MW, NARROW)                                                                             \
-    k_bkt_apply<HPT, EL, MW, NARROW><<<n_wg, AP_BLOCK, 0, e->stream>>>(                                         \
-        e->table, e->log2cap, e->seed, b_hits, d_hits, ranges, nb, hot_param, chunk_tab, e->d_limits, now,      \
-        d_verdict, d_first, bs, bs_zero, h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2,                  \
-        e->self_hot ? e->d_hot_arrive : nullptr)
+    do {                                                                                                        \
+        auto kp = k_bkt_apply<HPT, EL, MW, NARROW>;                                                             \
+        RL_LAUNCH_T(timed, ev0, ev1, kp, n_wg, AP_BLOCK, e->stream, e->table, e->log2cap, e->seed, b_hits,      \
+                    d_hits, ranges, nb, hot_param, chunk_tab, limits, now, d_verdict, d_first, bs, bs_zero,     \
+                    h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2, hot_arrive, 1u);                      \
+    } while (0)
     // 0 (default): 19.5 KB of LDS, eight workgroups per CU — limit ids in 16 bits, so engines with more than 32768 limit
     // rows take 1: the same kernel with 32-bit limit ids (21.5 KB, seven per CU).  2 / 3: 1024 LDS cells (experiments).
     switch (e->apply2_cfg == 0 && e->max_limits > 32768u ? 1 : e->apply2_cfg) {
@@ -418,11 +433,12 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         // one launch: the batch is one bucket (k_bkt_tiny), on the apply stream, with a scratch and a record
         // buffer of its own (a partitioned batch's partition may be running beside it); the hot sets are left
         // untouched
-        if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
-        k_bkt_tiny<<<1, AP_BLOCK, 0, e->stream>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_tiny_hits, e->d_limits,
-                                                  (u32)e->h_limits.size(), now, d_verdict, d_first, e->d_bs + BS_ROT, e->d_bs + BS_ROT,
-                                                  f.h_st, (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2);
-        if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[5], e->stream));
+        {
+            const LimitDev* limits = e->d_limits;
+            RL_LAUNCH_T(t_apply, f.tev[4], f.tev[5], k_bkt_tiny, 1, AP_BLOCK, e->stream, e->table, e->log2cap, e->seed, d_hits, n,
+                        e->d_tiny_hits, limits, (u32)e->h_limits.size(), now, d_verdict, d_first, e->d_bs + BS_ROT,
+                        e->d_bs + BS_ROT, f.h_st, (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2);
+        }
         HIP_TRY(e, hipGetLastError());
         f.n = n;
         f.n_wg = 1;
@@ -455,18 +471,16 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     hipStream_t ps = e->pstream;
     // ---- partition ----------------------------------------------------------------------------------
     if (two_streams && p >= depth) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - depth) & 3u], 0));
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[0], ps));
+    const Cell* ctable = e->table;
+    const LimitDev* climits = e->d_limits;
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
-    hist_k<<<ntiles, PT_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, d_hits, n, e->d_limits, (u32)e->h_limits.size(),
-                                        bk_log2, ntiles, e->d_bk_hist, bs, hot_use, 1u, nullptr);
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[1], ps));
-    k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, ps>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[2], ps));
+    RL_LAUNCH_T(t, f.tev[0], f.tev[1], hist_k, ntiles, PT_BLOCK, ps, ctable, e->log2cap, e->seed, d_hits, n, climits,
+                (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot_use, 1u, (u64*)nullptr, d_verdict, d_first);
+    RL_LAUNCH_T(t, f.tev[2], f.tev[3], k_bkt_scan, cdiv(nbt + HOT_COLS, 32), 1024, ps, e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
-    scatter_k<<<ntiles + 1, PT_BLOCK, 0, ps>>>(d_hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits,
-                                               ranges, &bs->st, ntiles, hot_param, hot_prod, e->hot_threshold, chunk_tab,
-                                               0u, nullptr);
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[3], ps));
+    RL_LAUNCH_T(t, f.tev[6], f.tev[7], scatter_k, ntiles + 1, PT_BLOCK, ps, d_hits, n, e->seed, bk_log2,
+                (const u32*)e->d_bk_hist, (const u32*)e->d_bk_total, hot_use, b_hits, ranges, (const Status*)&bs->st, ntiles,
+                hot_param, hot_prod, e->hot_threshold, chunk_tab, 0u, (u64*)nullptr);
     HIP_TRY(e, hipGetLastError());
     if (need_count) {
         // the cheap bound (every hit a new key) does not fit: count the batch's new keys exactly, before
@@ -493,15 +507,14 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
     }
     // ---- apply --------------------------------------------------------------------------------------
-    if (t) HIP_TRY(e, hipEventRecord(f.tev[6], e->stream));
     if (!e->self_hot)
-        k_hot_state<<<1, HOT_MAX, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_limits, now, hot_use, hot_param, &bs->st);
-    if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[4], e->stream));
+        RL_LAUNCH_T(t, f.tev[8], f.tev[9], k_hot_state, 1, HOT_MAX, e->stream, ctable, e->log2cap, e->seed, climits, now, hot_use,
+                    hot_param, &bs->st);
     // one workgroup per hash bucket (at least 64, so that the hot chunks of a small batch still spread); the
     // last one out writes the status block straight into f.h_st (host-mapped)
     const u32 n_wg = nb < 64u ? 64u : nb;
-    launch_apply(e, n_wg, d_hits, nb, par, now, d_verdict, d_first, bs, bs_zero, f.h_st, (u32)(e->sub_seq + 1), hot_prod);
-    if (t_apply) HIP_TRY(e, hipEventRecord(f.tev[5], e->stream));
+    launch_apply(e, n_wg, d_hits, nb, par, now, d_verdict, d_first, bs, bs_zero, f.h_st, (u32)(e->sub_seq + 1), hot_prod,
+                 t_apply, f.tev[4], f.tev[5]);
     HIP_TRY(e, hipGetLastError());
     if (two_streams) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
     e->part_seq++;
@@ -540,13 +553,15 @@ int collect_k1_bucketed(rl_engine* e) {
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
     if (f.timed) {
-        // tev: [0..3] on the partition stream (before hist / scan / scatter, after scatter), [6] [4] [5] on the
-        // apply stream (before k_hot_state, before and after k_bkt_apply)
+        // tev: start / stop of k_bkt_hist [0,1], k_bkt_scan [2,3], k_bkt_scatter [6,7], k_hot_state [8,9] (if it ran),
+        // k_bkt_apply or k_bkt_tiny [4,5]
         float ms[5] = {0, 0, 0, 0, 0};
         HIP_TRY(e, hipEventSynchronize(f.tev[5]));
         if (f.timed == 1) {
-            for (int q = 0; q < 3; ++q) HIP_TRY(e, hipEventElapsedTime(&ms[q], f.tev[q], f.tev[q + 1]));
-            HIP_TRY(e, hipEventElapsedTime(&ms[4], f.tev[6], f.tev[4]));
+            HIP_TRY(e, hipEventElapsedTime(&ms[0], f.tev[0], f.tev[1]));
+            HIP_TRY(e, hipEventElapsedTime(&ms[1], f.tev[2], f.tev[3]));
+            HIP_TRY(e, hipEventElapsedTime(&ms[2], f.tev[6], f.tev[7]));
+            if (!e->self_hot) HIP_TRY(e, hipEventElapsedTime(&ms[4], f.tev[8], f.tev[9]));
         }
         HIP_TRY(e, hipEventElapsedTime(&ms[3], f.tev[4], f.tev[5]));
         e->ms_slot[RL_T_HIST] += ms[0];
@@ -623,7 +638,7 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
     hist_k<<<ntiles, PT_BLOCK, 0, st>>>(e->table, e->log2cap, e->seed, hits, n, e->d_limits, (u32)e->h_limits.size(), bk_log2,
-                                        ntiles, e->d_bk_hist, bs, hot_use, c.update_mode ? 0u : 1u, nullptr);
+                                        ntiles, e->d_bk_hist, bs, hot_use, c.update_mode ? 0u : 1u, nullptr, nullptr, nullptr);
     k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, st>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
     scatter_k<<<ntiles + 1, PT_BLOCK, 0, st>>>(hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits, ranges,

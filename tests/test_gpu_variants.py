@@ -1,0 +1,114 @@
+"""The build variants of the bucketed hot path, each bit-exact against the CPU oracle on a trace that takes every
+branch of the hot-key code (promotion, decided by position, replayed, created by the hot path, demoted):
+
+  default            pipeline depth 3, the hot chunks of k_bkt_apply read the hot keys' cells themselves (self_hot),
+                     19.5 KB of LDS per workgroup with 16-bit limit ids, verdicts prefilled by k_bkt_hist
+  RL_SELF_HOT=0      k_hot_state in front of k_bkt_apply
+  RL_PIPE_DEPTH=2    the partition of batch p waits for k_bkt_apply of batch p - 2
+  RL_APPLY2_CFG=1    32-bit limit ids in LDS (what an engine with more than 32768 limit rows takes by itself)
+
+and the output contract of the sparse verdict stores: every byte of verdict[] / every word of first_limited[] of a
+batch is defined when it is collected, whatever the buffers held before.  Needs a MI355X."""
+import numpy as np
+import pytest
+
+from limitador_amd import workloads as W
+from limitador_amd.wire import CELL_ROW_DTYPE, RL_SIMPLE
+from test_gpu_bucketed import make_hits
+from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_both  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [{}, {"RL_SELF_HOT": "0"}, {"RL_PIPE_DEPTH": "2"}, {"RL_APPLY2_CFG": "1"},
+            {"RL_SELF_HOT": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "1"}]
+
+
+def hot_trace(eng, orc, rng, n=60_000):
+    """Background keys + 6 hot keys on limits with different maxima, a 0-second window, a simple counter every request
+    of a namespace hits, and a value next to 2^64."""
+    bg = W.splitmix64(np.arange(1000, 21_000, dtype=np.uint64))
+    hot = W.splitmix64(np.arange(10, 16, dtype=np.uint64))
+    hot_limit = np.array([0, 0, 1, 2, 3, 1])
+    cell = np.zeros(1, dtype=CELL_ROW_DTYPE)
+    cell[0] = (int(hot[5]), 1, 0, 2**64 - 25, NOW + 30 * SEC)  # wraps inside the first batch
+    eng.load_cells(cell)
+    orc.load_cells([int(hot[5])], [1], [2**64 - 25], [NOW + 30 * SEC])
+
+    def batch(hot_share, deltas):
+        which = rng.random(n)
+        is_hot = which < hot_share
+        is_simple = (~is_hot) & (which < hot_share + 0.15)
+        hi = rng.integers(0, len(hot), size=n)
+        bi = rng.integers(0, len(bg), size=n)
+        keys = np.where(is_hot, hot[hi], np.where(is_simple, 7_000_001, bg[bi]))
+        limits = np.where(is_hot, hot_limit[hi], np.where(is_simple, 4 | RL_SIMPLE, bi % 3)).astype(np.uint32)
+        return make_hits(keys, limits, deltas(n))
+
+    ones = lambda m: np.ones(m, dtype=np.uint32)  # noqa: E731
+    now = NOW
+    for step in range(4):  # promotion (depth 3: the set of batch p is used by batch p + 3), then decided by position
+        run_both(eng, orc, batch(0.5, ones), now)
+        now += 1000
+    run_both(eng, orc, batch(0.5, lambda m: rng.integers(0, 4, size=m).astype(np.uint32)), now)  # mixed deltas: replayed
+    now += 61 * SEC  # windows rolled over: the first admitted hit of a hot bucket resets the window
+    run_both(eng, orc, batch(0.5, lambda m: np.full(m, 3, dtype=np.uint32)), now)
+    now += 61 * SEC
+    assert eng.sweep_expired(now) == orc.sweep_expired(now)  # the hot keys' cells are gone: the hot path creates them
+    run_both(eng, orc, batch(0.5, ones), now)
+    for step in range(4):  # traffic moves away, and back
+        now += 1000
+        run_both(eng, orc, batch(0.0 if step < 3 else 0.5, ones), now)
+    assert_same_state(eng, orc, n_simple_expected=1)
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: "+".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
+def test_hot_path_variants_against_the_oracle(make_engine, monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rows = [(5000, 60), (100, 60), (10**9, 60), (50, 0), (20_000, 60)]
+    eng, orc = pair(make_engine, rows, simple_keys=[(4, 7_000_001)], max_batch_hits=60_000, capacity_cells=1 << 17)
+    hot_trace(eng, orc, np.random.default_rng(31))
+
+
+def test_more_than_32768_limit_rows_take_the_wide_kernel(make_engine):
+    """Limit ids do not fit the 16-bit LDS field: the engine picks the 32-bit instantiation of k_bkt_apply by itself."""
+    rng = np.random.default_rng(32)
+    n_rows = 40_000
+    rows = [(int(m), 60) for m in rng.integers(1, 40, size=n_rows)]
+    eng, orc = pair(make_engine, rows, max_limits=n_rows, max_batch_hits=50_000, capacity_cells=1 << 17)
+    idx = rng.integers(0, 9000, size=50_000)
+    lim = (idx * 4 + 3) % n_rows  # ids on both sides of 32768, one id per key
+    hits = make_hits(W.splitmix64(idx.astype(np.uint64)), lim.astype(np.uint32), 1)
+    for step in range(3):
+        run_both(eng, orc, hits, NOW + step)
+    assert int(lim.max()) > 32768
+    assert_same_state(eng, orc)
+
+
+@pytest.mark.parametrize("n", [700, 30_000])
+def test_every_output_of_a_batch_is_defined_whatever_the_buffers_held(make_engine, n):
+    """k_bkt_hist writes "admitted" for every request and k_bkt_apply stores only the denials (k_bkt_tiny, the
+    one-launch path of the 700-hit batch, stores every verdict): poisoned output buffers come back exact."""
+    import ctypes as C
+
+    import torch
+
+    rng = np.random.default_rng(33)
+    eng, orc = pair(make_engine, [(3, 60), (200, 60)], max_batch_hits=n, capacity_cells=1 << 16)
+    dev = torch.device("cuda", 0)
+    now = NOW
+    for step in range(4):
+        idx = (rng.zipf(1.3, size=n) - 1) % 5000
+        h = make_hits(W.splitmix64(idx.astype(np.uint64)), (idx % 2).astype(np.uint32), 1)
+        v, f, _r, _e = orc.check_and_update(h, now)
+        d_hits = torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev)
+        d_v = torch.full((n,), 0xCC, dtype=torch.uint8, device=dev)
+        d_f = torch.full((n,), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        eng.submit_device(d_hits.data_ptr(), n, now, d_v.data_ptr(), C.c_void_p(d_f.data_ptr()))
+        eng.collect()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_v.cpu().numpy(), v), f"batch {step}"
+        assert np.array_equal(d_f.cpu().numpy(), f), f"batch {step}"
+        now += 1000
+    assert_same_state(eng, orc)
