@@ -191,7 +191,8 @@ __device__ __forceinline__ void apply2_commit(LDS& S, const Apply2Args& A, bool 
 // One decide/commit round over the hits [first, first + n_items) of the partitioned batch
 // (n_items <= R), in trace order.  Ends with every thread past a barrier.
 template <class LDS>
-__device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 first, u32 n_items) {
+__device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 first, u32 n_items, u32 n_next,
+                                             uint4 (&hnext)[LDS::R / AP_BLOCK]) {
     constexpr int E = LDS::E;
     constexpr int HPT = LDS::R / AP_BLOCK;
     constexpr bool NARROW = LDS::narrow;
@@ -207,6 +208,9 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
     // Both loads are UNCONDITIONAL (a lane past the end of the round repeats the round's last hit): a load inside
     // a divergent `if` is waited for where the branch ends, and the home cells are not needed before phase B —
     // phase A's LDS work runs under their latency.
+    // The round's records were requested a round ago (`hnext`, by apply2_bucket for the first round); the NEXT round's
+    // are requested now, so that with the four rounds of a 1024-bucket batch only the cell reads are a dependent trip to
+    // HBM per round.  (The next round's cells are not read ahead: a rebuild between the rounds writes cells back.)
     uint4 ca[HPT], cb[HPT];
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
@@ -214,7 +218,16 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
         ok[u] = p < n_items;
         creator[u] = leader[u] = false;
         ent[u] = 0;
-        h[u] = load_bhit(A.b_hits, first + (ok[u] ? p : n_items - 1));
+        h[u].key = ((u64)hnext[u].y << 32) | hnext[u].x;
+        h[u].delta = hnext[u].z;
+        h[u].idx_tag = hnext[u].w;
+    }
+    if (n_next) {  // (block-uniform)
+#pragma unroll
+        for (int u = 0; u < HPT; ++u) {
+            const u32 p = tid * HPT + u;
+            hnext[u] = *reinterpret_cast<const uint4*>(A.b_hits + (first + n_items + (p < n_next ? p : n_next - 1)));
+        }
     }
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
@@ -513,12 +526,23 @@ __device__ __forceinline__ void apply2_bucket(LDS& S, const Apply2Args& A, u32 l
         S.bucket_len = hi - lo;
     }
     __syncthreads();
+    uint4 hnext[R / AP_BLOCK];
+    {
+        const u32 n0 = (hi - lo) < (u32)R ? (hi - lo) : (u32)R;
+#pragma unroll
+        for (int u = 0; u < R / AP_BLOCK; ++u) {
+            const u32 p = threadIdx.x * (R / AP_BLOCK) + u;
+            hnext[u] = *reinterpret_cast<const uint4*>(A.b_hits + (lo + (p < n0 ? p : n0 - 1)));
+        }
+    }
     for (u32 first = lo; first < hi; first += R) {
         if (first != lo && S.n_ent > (u32)KEEP) {  // block-uniform (read after the previous round's barrier)
             __syncthreads();
             apply2_commit(S, A, true);
         }
-        apply2_round(S, A, first, (hi - first) < (u32)R ? (hi - first) : (u32)R);
+        const u32 n_items = (hi - first) < (u32)R ? (hi - first) : (u32)R;
+        const u32 left = hi - first - n_items;
+        apply2_round(S, A, first, n_items, left < (u32)R ? left : (u32)R, hnext);
     }
     apply2_commit(S, A, false);
 }
@@ -764,8 +788,10 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restri
     if (tid == 0 && s_new) atomicAdd(n_new_out, s_new);
 }
 
-template <int HPT, int ENT_LOG2, int MIN_WAVES, bool NARROW>
-__global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
+// k_bkt_apply's body (the __global__ entry below only adds the launch bounds).
+template <int HPT, int ENT_LOG2, bool NARROW>
+__device__ __forceinline__ void bkt_apply_body(
+
     Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits,
     const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
     const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab,
@@ -817,6 +843,19 @@ __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(
     }
 }
 
+#define RL_APPLY_PARAMS \
+    Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits, \
+        const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb, \
+        const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab, \
+        const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict, \
+        int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq, \
+        HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out
+#define RL_APPLY_ARGS table, log2cap, seed, b_hits, hits, ranges, nb, hot_param, chunk_tab, limits, now, verdict, first_limited, bs, bs_zero, host_status, done_seq, hot_next, hot_threshold, dbg, hot_arrive, sparse_out
+
+template <int HPT, int ENT_LOG2, int MIN_WAVES, bool NARROW>
+__global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(RL_APPLY_PARAMS) {
+    bkt_apply_body<HPT, ENT_LOG2, NARROW>(RL_APPLY_ARGS);
+}
 // ---------------------------------------------------------------------------------------------
 // k_bkt_tiny: a batch of at most TINY_MAX hits IS one bucket — it is in trace order already — so one
 // workgroup validates it (the checks of k_bkt_hist), rewrites it as BHit records and replays it with

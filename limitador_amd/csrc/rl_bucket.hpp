@@ -375,7 +375,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                                                           HotSet* __restrict__ hot_next, u32 hot_threshold,
                                                           unsigned short* __restrict__ chunk_tab, u32 all_chunks,
                                                           u64* htrace) {
-    __shared__ __align__(16) unsigned short s_cnt[PT_WAVES][BKT_MAX];
+    // wave-private counters, [PT_WAVES][nbt] — dynamic, sized by the launch for the batch's bucket count
+    // (PT_WAVES * nbt * 2 bytes: 80 KB with 2048 hash buckets, 48 KB with 1024), so that with fewer buckets the
+    // workgroup fits a CU beside k_bkt_apply's workgroups
+    extern __shared__ __align__(16) unsigned short s_cnt[];
     __shared__ u32 s_base[BKT_MAX];
     __shared__ u32 s_w[PT_WAVES];
     __shared__ u64 s_hot_key[HOT_HASH];
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
     RL_HSTAMP(1);
     for (u32 b = tid; b < nbt; b += PT_BLOCK) {
 #pragma unroll
-        for (int ww = 0; ww < PT_WAVES; ++ww) s_cnt[ww][b] = 0;
+        for (int ww = 0; ww < PT_WAVES; ++ww) s_cnt[ww * nbt + b] = 0;
     }
     __syncthreads();
     RL_HSTAMP(2);
@@ -541,9 +544,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         const u64 m = match_digit(d, (bk_log2 > 9u ? bk_log2 : 9u) + 1u, valid);
         u32 r = 0;
         if (ok) {
-            const u32 c = s_cnt[w][d];
+            const u32 c = s_cnt[w * nbt + d];
             r = c + (u32)__popcll(m & lt);
-            if ((m & lt) == 0ull) s_cnt[w][d] = (unsigned short)(c + (u32)__popcll(m));
+            if ((m & lt) == 0ull) s_cnt[w * nbt + d] = (unsigned short)(c + (u32)__popcll(m));
         }
         rank[u] = (unsigned short)r;
         dig[u] = (unsigned short)d;
@@ -556,8 +559,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         u32 acc = 0;
 #pragma unroll
         for (int ww = 0; ww < PT_WAVES; ++ww) {
-            const u32 c = s_cnt[ww][b];
-            s_cnt[ww][b] = (unsigned short)acc;
+            const u32 c = s_cnt[ww * nbt + b];
+            s_cnt[ww * nbt + b] = (unsigned short)acc;
             acc += c;
         }
     }
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
         const u32 i = wbase + u * 64 + lane;
         if (i < n) {
             const u32 d = dig[u];
-            const u32 dst = s_base[d] + s_cnt[w][d] + rank[u];
+            const u32 dst = s_base[d] + s_cnt[w * nbt + d] + rank[u];
             *reinterpret_cast<uint4*>(b_hits + dst) =
                 make_uint4(raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24));
         }

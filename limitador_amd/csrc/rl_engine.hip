@@ -124,9 +124,11 @@ struct rl_engine {
     u32 gen_bk_log2_max = BK_LOG2_MAX; // RL_GEN_BUCKET_LOG2: cap on the general resolver's hash buckets (tests)
     int gen_trace = 0;                 // RL_GEN_TRACE=1: one stderr line per pass of the general resolver; 2: + k_gen_sort phases
     unsigned long long* d_gen_trace = nullptr;
-    u32 bk_log2_cfg = BK_LOG2_MAX;     // RL_BUCKET_LOG2: buckets for a full-size batch (<= BK_LOG2_MAX).  Measured at 1 M hits,
-                                       // two streams: 2048 buckets 13.4 G decisions/s with k_bkt_apply at 41 us; 1024 buckets
-                                       // 14.1 G/s (cheaper partition) with k_bkt_apply at 44-48 us (three rounds per bucket)
+    u32 bk_log2_cfg = 10;              // RL_BUCKET_LOG2: most hash buckets for a batch of up to 2 M hits (larger: BK_LOG2_MAX).  1024, not
+                                       // 2048: k_bkt_apply then has 1024 workgroups = four per CU, which leaves 16 wave slots and 80 KB of
+                                       // LDS on every CU, and the partition kernels of the next batches (16-wave workgroups; k_bkt_scatter's
+                                       // LDS is 70 KB with 1024 buckets) run BESIDE it instead of waiting for it to drain.  1 M-hit batches:
+                                       // 2048 buckets 72 us per step (k_bkt_apply 33 us alone), 1024 buckets 66 us (39 us alone), 512: 79 us
     u32 bk_tiles_max = 0;
     u32* d_bk_hist = nullptr;
     u32* d_bk_total = nullptr;
@@ -141,6 +143,8 @@ struct rl_engine {
     // or RL_OVERLAP=0 both are the same stream.
     hipStream_t pstream = nullptr, own_pstream = nullptr;
     bool overlap = true;
+    bool ext_events = true;         // RL_EXT_EVENTS=0: hipEventRecord markers behind k_bkt_scatter / k_bkt_apply instead of the
+                                    // launches' own stop events (two marker commands fewer per batch on the two streams)
     bool self_hot = true;           // RL_SELF_HOT=0: k_hot_state in front of k_bkt_apply instead of the chunks reading the hot cells
     u32* d_hot_arrive = nullptr;    // [HOT_MAX] (apply2_hot_chunk_self)
     u32 pipe_depth = 3;             // RL_PIPE_DEPTH (2 or 3): the partition of batch p waits for k_bkt_apply of batch p - depth
@@ -366,14 +370,19 @@ int settle_inflight(rl_engine* e) {
     return RL_OK;
 }
 
+// k_bkt_scatter's wave-private counters (dynamic LDS): PT_WAVES x (hash buckets + hot buckets) x 2 bytes
+inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof(unsigned short); }
+
 // A launch that is timed carries its own start / stop events (hipExtLaunchKernelGGL: the events get the dispatch's
 // begin and end timestamps), so a timed kernel has no marker commands around it — two hipEventRecord markers added
 // 4-6 us to the interval and ~5 us of idle device each (the figure then disagreed with rocprofv3's by that much).
-#define RL_LAUNCH_T(timed, ev0, ev1, kern, grid, block, stream, ...)                                               \
+#define RL_LAUNCH_TS(timed, ev0, ev1, kern, grid, block, lds, stream, ...)                                         \
     do {                                                                                                           \
-        if (timed) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, ev0, ev1, 0, __VA_ARGS__);      \
-        else kern<<<dim3(grid), dim3(block), 0, stream>>>(__VA_ARGS__);                                            \
+        if (timed) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, ev0, ev1, 0, __VA_ARGS__);    \
+        else kern<<<dim3(grid), dim3(block), lds, stream>>>(__VA_ARGS__);                                          \
     } while (0)
+#define RL_LAUNCH_T(timed, ev0, ev1, kern, grid, block, stream, ...) \
+    RL_LAUNCH_TS(timed, ev0, ev1, kern, grid, block, 0, stream, __VA_ARGS__)
 
 // k_bkt_apply in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD, 16-bit limit ids>.
 void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u64 now, uint8_t* d_verdict,
@@ -396,7 +405,10 @@ void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u6
     // rows take 1: the same kernel with 32-bit limit ids (21.5 KB, seven per CU).  2 / 3: 1024 LDS cells (experiments).
     switch (e->apply2_cfg == 0 && e->max_limits > 32768u ? 1 : e->apply2_cfg) {
         default:
-        case 0: RL_AP2(1, 9, 8, true); break;
+        // (64 VGPRs matter even at four workgroups per CU: they leave half of the register file to the 16-wave
+        // workgroups of the partition kernels, which all stay below 64 VGPRs themselves; at 72+ VGPRs k_bkt_hist waited
+        // for k_bkt_apply to drain again — gpurun_out/v6)
+        case 0: RL_AP2(1, 9, 8, true); break;  // (three VGPRs in scratch, outside the bucket rounds)
         case 1: RL_AP2(1, 9, 6, false); break;
         case 2: RL_AP2(1, 10, 3, false); break;
         case 3: RL_AP2(2, 10, 3, false); break;
@@ -451,7 +463,8 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         return RL_OK;
     }
     u32 bk_log2 = ceil_log2(cdiv(n, 384));
-    if (bk_log2 > e->bk_log2_cfg) bk_log2 = e->bk_log2_cfg;
+    const u32 bk_cap = n > (2u << 20) ? (u32)BK_LOG2_MAX : e->bk_log2_cfg;
+    if (bk_log2 > bk_cap) bk_log2 = bk_cap;
     const u32 nb = 1u << bk_log2;
     // small batches: quarter-size tiles, so that the two partition passes still spread over the CUs
     const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
@@ -478,7 +491,11 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                 (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot_use, 1u, (u64*)nullptr, d_verdict, d_first);
     RL_LAUNCH_T(t, f.tev[2], f.tev[3], k_bkt_scan, cdiv(nbt + HOT_COLS, 32), 1024, ps, e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
-    RL_LAUNCH_T(t, f.tev[6], f.tev[7], scatter_k, ntiles + 1, PT_BLOCK, ps, d_hits, n, e->seed, bk_log2,
+    // "partitioned" / "applied" for the other stream: the stop event of the launch itself where possible (no marker command)
+    const bool chain_p = two_streams && e->ext_events && !t && !need_count;
+    const bool chain_a = two_streams && e->ext_events && !t_apply;
+    RL_LAUNCH_TS(t || chain_p, t ? f.tev[6] : nullptr, t ? f.tev[7] : e->ev_parted[p & 3u], scatter_k, ntiles + 1, PT_BLOCK,
+                 scatter_lds_bytes(nbt), ps, d_hits, n, e->seed, bk_log2,
                 (const u32*)e->d_bk_hist, (const u32*)e->d_bk_total, hot_use, b_hits, ranges, (const Status*)&bs->st, ntiles,
                 hot_param, hot_prod, e->hot_threshold, chunk_tab, 0u, (u64*)nullptr);
     HIP_TRY(e, hipGetLastError());
@@ -503,7 +520,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         }
     }
     if (two_streams) {
-        HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
+        if (!chain_p) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
     }
     // ---- apply --------------------------------------------------------------------------------------
@@ -514,9 +531,9 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     // last one out writes the status block straight into f.h_st (host-mapped)
     const u32 n_wg = nb < 64u ? 64u : nb;
     launch_apply(e, n_wg, d_hits, nb, par, now, d_verdict, d_first, bs, bs_zero, f.h_st, (u32)(e->sub_seq + 1), hot_prod,
-                 t_apply, f.tev[4], f.tev[5]);
+                 t_apply || chain_a, t_apply ? f.tev[4] : nullptr, t_apply ? f.tev[5] : e->ev_applied[p & 3u]);
     HIP_TRY(e, hipGetLastError());
-    if (two_streams) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
+    if (two_streams && !chain_a) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
     e->part_seq++;
     f.n = n;
     f.n_wg = n_wg;
@@ -641,7 +658,7 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
                                         ntiles, e->d_bk_hist, bs, hot_use, c.update_mode ? 0u : 1u, nullptr, nullptr, nullptr);
     k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, st>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
-    scatter_k<<<ntiles + 1, PT_BLOCK, 0, st>>>(hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits, ranges,
+    scatter_k<<<ntiles + 1, PT_BLOCK, scatter_lds_bytes(nbt), st>>>(hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits, ranges,
                                                &bs->st, ntiles, hot_param, hot_prod, e->hot_threshold, chunk_tab, 1u, nullptr);
     // ---- sort by cell, resolve the cells ---------------------------------------------------------------
     GenArgs A{};
@@ -1014,6 +1031,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
     if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
     if (const char* v = getenv("RL_SELF_HOT")) e->self_hot = atoi(v) != 0;
+    if (const char* v = getenv("RL_EXT_EVENTS")) e->ext_events = atoi(v) != 0;
     if (const char* v = getenv("RL_GEN_TRACE")) e->gen_trace = atoi(v);
     if (const char* v = getenv("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
     if (const char* v = getenv("RL_GEN_SUB_MAX")) {
@@ -1060,11 +1078,17 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     } else {
         e->pstream = e->stream;
     }
-    for (auto& ev : e->ev_parted)
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
+    for (auto& ev : e->ev_parted)  // (timing-capable: they are also the stop events of launches, see ext_events)
+        if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
     for (auto& ev : e->ev_applied)
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
+        if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
     if (hipEventCreateWithFlags(&e->ev_match, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
+    // k_bkt_scatter's dynamic LDS goes up to 80 KB (beside 23 KB of static LDS)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_scatter<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_scatter<PT_STEPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess)
+        return bail(RL_ERR_DEVICE);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0)

@@ -29,7 +29,8 @@ def fmix64(x):
 def bucket_log2(n_hits):
     """rl_engine.hip run_check_k1_bucketed: buckets for a batch of n_hits."""
     per = -(-n_hits // 384)
-    return min(11, max(0, int(np.ceil(np.log2(per))) if per > 1 else 0))
+    cap = 11 if n_hits > (2 << 20) else 10  # (RL_BUCKET_LOG2 default: 1024 buckets up to 2 M hits)
+    return min(cap, max(0, int(np.ceil(np.log2(per))) if per > 1 else 0))
 
 
 def keys_in_bucket(n_keys, n_hits, bucket=0, start=1):
