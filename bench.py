@@ -454,7 +454,10 @@ def main():
     # events, one blocking call per batch (so each kernel runs alone).  The warm-up batches are replayed.
     eng.kernel_timing(1)
     eng.kernel_timing_read(reset=True)
-    for i in range(min(args.warmup, 5)):
+    # (a dozen batches, cycling through the warm-up ones: the hot-key set and its promotion threshold adapt over a few
+    # generations of three batches each, and a cold engine's first three batches run without any hot set)
+    for j in range(12 if args.warmup else 0):
+        i = j % max(1, min(args.warmup, 5))
         if sharded:
             step(i, now)
         else:  # one blocking call per batch: every kernel runs alone (no overlap with the next batch's partition)

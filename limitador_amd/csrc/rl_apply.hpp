@@ -90,6 +90,7 @@ struct Apply2Args {
     const HotParam* hot_param;
     const unsigned short* chunk_tab;  // hot chunk -> index of its hot bucket
     u32 hot_threshold;
+    u32 hot_long;     // a hash bucket of at least this many hits is long BECAUSE of a key (twice the batch's mean bucket)
     u32 sparse_out;   // verdict[] / first_limited[] already say "admitted" (k_bkt_hist): only denials are stored
     u32* hot_arrive;  // [HOT_MAX] chunks of a hot bucket that have read the key's cell (self_hot); zero between kernels
     u32 dbg;  // RL_DEBUG_APPLY2 (timing experiments only): 1 no ticket, 2 no verdict stores, 4 no write-back, 8 no cell reads
@@ -131,7 +132,7 @@ __device__ __forceinline__ void apply2_commit(LDS& S, const Apply2Args& A, bool 
         // promote: the key absorbed hot_threshold hits, or it is what made this bucket long
         if (!rebuild && !(f & EF_BAD) && S.promote_ok &&
             ((f >> EF_COUNT_SHIFT) >= A.hot_threshold ||
-             ((f >> EF_COUNT_SHIFT) >= A.hot_threshold / 4 && S.bucket_len >= HOT_LONG_BUCKET))) {
+             ((f >> EF_COUNT_SHIFT) >= A.hot_threshold / 4 && S.bucket_len >= A.hot_long))) {
             const u32 pos = atomicAdd(&A.hot_next->n, 1u);
             if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = key;
         }
@@ -797,12 +798,12 @@ __device__ __forceinline__ void bkt_apply_body(
     const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab,
     const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
     int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
-    HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out) {
+    HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out, u32 hot_long) {
     __shared__ Apply2Lds<HPT, ENT_LOG2, NARROW> S;
     const u32 tid = threadIdx.x, G = gridDim.x;
     const bool self_hot = hot_arrive != nullptr;  // no k_hot_state ran: the chunks read the hot keys' cells themselves
     Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                 hot_next, hot_param, chunk_tab, hot_threshold, sparse_out, hot_arrive, dbg};
+                 hot_next, hot_param, chunk_tab, hot_threshold, hot_long, sparse_out, hot_arrive, dbg};
     // ranges[] is in processing order (longest buckets first): the hardware hands workgroups out in
     // index order, so the long buckets start first and the short ones fill the tail
     const uint2 r = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
@@ -849,8 +850,8 @@ __device__ __forceinline__ void bkt_apply_body(
         const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab, \
         const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict, \
         int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq, \
-        HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out
-#define RL_APPLY_ARGS table, log2cap, seed, b_hits, hits, ranges, nb, hot_param, chunk_tab, limits, now, verdict, first_limited, bs, bs_zero, host_status, done_seq, hot_next, hot_threshold, dbg, hot_arrive, sparse_out
+        HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out, u32 hot_long
+#define RL_APPLY_ARGS table, log2cap, seed, b_hits, hits, ranges, nb, hot_param, chunk_tab, limits, now, verdict, first_limited, bs, bs_zero, host_status, done_seq, hot_next, hot_threshold, dbg, hot_arrive, sparse_out, hot_long
 
 template <int HPT, int ENT_LOG2, int MIN_WAVES, bool NARROW>
 __global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(RL_APPLY_PARAMS) {
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
         if (tid == 0) atomicOr(&bs->st.err, s_err);
     } else if (n) {
         Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, 0u, nullptr, 0u};
+                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, nullptr, 0u};
         apply2_bucket(S, A, 0, n);
     }
     // the verdicts may go straight to host-mapped memory (rl_check_and_update_batch): every wave's stores

@@ -151,6 +151,9 @@ struct rl_engine {
     hipEvent_t ev_parted[4]{}, ev_applied[4]{};
     hipEvent_t ev_match = nullptr;  // behind the copies of the matcher's count pass (match_and_check_locked)
     u32 hot_threshold = HOT_PROMOTE;  // doubled while more keys qualify than there are hot buckets
+    u32 hot_floor = HOT_PROMOTE;      // RL_HOT_PROMOTE: the floor of hot_threshold
+    u32 hot_long_cfg = HOT_LONG_BUCKET;  // RL_HOT_LONG: a hash bucket of this many hits has its middling keys promoted too
+    u32 hot_seen = 0;                 // keys that qualified for a hot bucket in the batch collected last
     HotParam* d_hot_param = nullptr;  // [PB_SETS][HOT_MAX + 1]
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
@@ -387,7 +390,7 @@ inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof
 // k_bkt_apply in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD, 16-bit limit ids>.
 void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u64 now, uint8_t* d_verdict,
                   int32_t* d_first, BatchScratch* bs, BatchScratch* bs_zero, Status* h_st, u32 seq, HotSet* hot_prod,
-                  bool timed, hipEvent_t ev0, hipEvent_t ev1) {
+                  bool timed, hipEvent_t ev0, hipEvent_t ev1, u32 hot_long) {
     const BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
     const uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
     const HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
@@ -399,7 +402,7 @@ void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u6
         auto kp = k_bkt_apply<HPT, EL, MW, NARROW>;                                                             \
         RL_LAUNCH_T(timed, ev0, ev1, kp, n_wg, AP_BLOCK, e->stream, e->table, e->log2cap, e->seed, b_hits,      \
                     d_hits, ranges, nb, hot_param, chunk_tab, limits, now, d_verdict, d_first, bs, bs_zero,     \
-                    h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2, hot_arrive, 1u);                      \
+                    h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2, hot_arrive, 1u, hot_long);            \
     } while (0)
     // 0 (default): 19.5 KB of LDS, eight workgroups per CU — limit ids in 16 bits, so engines with more than 32768 limit
     // rows take 1: the same kernel with 32-bit limit ids (21.5 KB, seven per CU).  2 / 3: 1024 LDS cells (experiments).
@@ -483,7 +486,14 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
     hipStream_t ps = e->pstream;
     // ---- partition ----------------------------------------------------------------------------------
-    if (two_streams && p >= depth) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - depth) & 3u], 0));
+    // The batch whose buffers and hot set this partition takes over (p - depth) has, with depth 3, been collected by
+    // the caller: the host asks the event itself — once it has seen it complete, everything enqueued from here on is
+    // ordered behind that batch — and the partition stream is spared a wait command (a satisfied wait still held the
+    // stream ~9 us per batch, gpurun_out/v7 trace).  Only a batch that is really still running gets the device-side wait.
+    if (two_streams && p >= depth && hipEventQuery(e->ev_applied[(p - depth) & 3u]) != hipSuccess) {
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
+        HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - depth) & 3u], 0));
+    }
     const Cell* ctable = e->table;
     const LimitDev* climits = e->d_limits;
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
@@ -531,7 +541,13 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     // last one out writes the status block straight into f.h_st (host-mapped)
     const u32 n_wg = nb < 64u ? 64u : nb;
     launch_apply(e, n_wg, d_hits, nb, par, now, d_verdict, d_first, bs, bs_zero, f.h_st, (u32)(e->sub_seq + 1), hot_prod,
-                 t_apply || chain_a, t_apply ? f.tev[4] : nullptr, t_apply ? f.tev[5] : e->ev_applied[p & 3u]);
+                 t_apply || chain_a, t_apply ? f.tev[4] : nullptr, t_apply ? f.tev[5] : e->ev_applied[p & 3u],
+                 // The long-bucket rule (keys with a quarter of the threshold are promoted out of buckets of >= 1024 hits)
+                 // evens the buckets out — with 1024 buckets it fills all 512 hot buckets and is worth ~4 us per step
+                 // (gpurun_out/v8) — but on a cold start every bucket is long and the first set would be 512 keys in
+                 // arrival order, the Zipf head not necessarily among them (six slow batches instead of three): it only
+                 // applies once a collected batch has reported a populated set.
+                 e->hot_seen >= 64u ? e->hot_long_cfg : 0xFFFFFFFFu);
     HIP_TRY(e, hipGetLastError());
     if (two_streams && !chain_a) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
     e->part_seq++;
@@ -564,8 +580,9 @@ int collect_k1_bucketed(rl_engine* e) {
     }
     e->col_seq++;
     // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
+    if (f.n_wg > 1) e->hot_seen = f.h_st->pad[2];  // (a partitioned batch: k_bkt_tiny leaves the hot sets alone)
     if (f.h_st->pad[2] > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
-    else if (f.h_st->pad[2] < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
+    else if (f.h_st->pad[2] < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
     e->stats.batches++;
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
@@ -802,7 +819,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         e->stats.probe_steps += h_gst.rounds_run;
         // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
         if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
-        else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
+        else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
         const u32 err = h_bst.err | h_gst.err;
         if (e->gen_trace)
             std::fprintf(stderr, "[gen] pass seq=%llu n=%u req=%u round=%u rounds_run=%u overflow=%u committed=%u n_new=%u hot_n=%u thr=%u err=%u\n",
@@ -1032,6 +1049,11 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
     if (const char* v = getenv("RL_SELF_HOT")) e->self_hot = atoi(v) != 0;
     if (const char* v = getenv("RL_EXT_EVENTS")) e->ext_events = atoi(v) != 0;
+    if (const char* v = getenv("RL_HOT_PROMOTE")) {
+        const long b = strtol(v, nullptr, 10);
+        if (b >= 16 && b <= (1 << 20)) e->hot_floor = e->hot_threshold = (u32)b;
+    }
+    if (const char* v = getenv("RL_HOT_LONG")) e->hot_long_cfg = (u32)std::max<unsigned long>(1ul, strtoul(v, nullptr, 10));
     if (const char* v = getenv("RL_GEN_TRACE")) e->gen_trace = atoi(v);
     if (const char* v = getenv("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
     if (const char* v = getenv("RL_GEN_SUB_MAX")) {
@@ -1860,7 +1882,7 @@ int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_
     HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
-    else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > HOT_PROMOTE) e->hot_threshold /= 2;
+    else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
     if (n_new) *n_new = h_gst.n_new;
     return RL_OK;
 }
