@@ -57,7 +57,7 @@ per = defaultdict(list)
 for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_trace.csv"))):
     per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(out + "_engine_kernels.md", "a") as f:
-    f.write("\nTimed launches only (the last 20 of 25):\n\n| kernel | avg us | min us | max us |\n|---|---|---|---|\n")
+    f.write("\nTimed launches only (the last 20):\n\n| kernel | avg us | min us | max us |\n|---|---|---|---|\n")
     for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1][-20:])):
         if (name.startswith("rl::k_bkt") or name.startswith("rl::k_hot")) and len(v) >= 25:
             t = v[-20:]
