@@ -177,7 +177,9 @@ int32_t rl_check_and_update_batch_device(rl_engine *e, const rl_hit *d_hits, uin
  * and first_limited of that batch are then complete for work ordered after the batch on the engine's stream;
  * a reader on another stream, or the host, synchronises with that stream first).  At most three batches may
  * be in flight; they are applied in submission order, so the sequential contract holds across them, and the
- * partition of one overlaps the replay of the one before (two streams inside the engine).  While batches
+ * partition of one overlaps the replay of the one before (two streams inside the engine).  d_verdict and
+ * d_first_limited belong to the engine from _submit to the matching _collect (the partition pass writes the default
+ * answer into them, the decision pass the denials): every element is defined at _collect.  While batches
  * are in flight every other entry point returns RL_ERR_BUSY. */
 int32_t rl_check_and_update_submit_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
                                           uint8_t *d_verdict, int32_t *d_first_limited);
