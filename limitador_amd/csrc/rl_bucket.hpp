@@ -294,8 +294,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_hist(const Cell* __restrict__ 
 // total[bucket] = its hit count.  A workgroup owns 32 columns; its 32 thread groups split the
 // tiles, sum their part, exchange the part sums through LDS and rewrite their part.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_bkt_scan(u32* __restrict__ hist, u32 ntiles, u32 nbt,
-                                                   u32* __restrict__ total) {
+constexpr u32 SC_REG = 8;  // tiles per thread group that k_bkt_scan keeps in registers (batches of up to 256 tiles = 1 M hits)
+__global__ __launch_bounds__(1024, 8) void k_bkt_scan(u32* __restrict__ hist, u32 ntiles, u32 nbt,
+                                                      u32* __restrict__ total) {
     __shared__ u32 s_part[32][32];
     const u32 nrow = nbt + HOT_COLS;
     const u32 cl = threadIdx.x & 31u;
@@ -305,12 +306,29 @@ __global__ __launch_bounds__(1024) void k_bkt_scan(u32* __restrict__ hist, u32 n
     const u32 per = (ntiles + 31) / 32;
     const u32 t_lo = g * per < ntiles ? g * per : ntiles;
     const u32 t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
+    // Up to SC_REG tiles per group (the usual batch): the group's counts are read ONCE, all loads in flight together,
+    // and stay in registers for the rewrite — one trip to memory instead of two (the kernel is pure latency, and
+    // beside k_bkt_apply a trip costs three times what it costs alone).  (64 VGPRs: see launch_apply.)
+    const bool cached = per <= SC_REG;  // (block-uniform)
+    u32 v8[SC_REG];
     u32 sum = 0;
     if (c < nrow) {
+        if (cached) {
+#pragma unroll
+            for (u32 q = 0; q < SC_REG; ++q) {
+                const u32 t = t_lo + q;
+                const u32 tc = t < t_hi ? t : ntiles - 1;  // (unconditional load of a valid row; masked below)
+                const u32 v = hist[(size_t)tc * nrow + c];
+                v8[q] = t < t_hi ? v : 0u;
+            }
+#pragma unroll
+            for (u32 q = 0; q < SC_REG; ++q) sum = is_max ? (v8[q] > sum ? v8[q] : sum) : sum + v8[q];
+        } else {
 #pragma unroll 8
-        for (u32 t = t_lo; t < t_hi; ++t) {
-            const u32 v = hist[(size_t)t * nrow + c];
-            sum = is_max ? (v > sum ? v : sum) : sum + v;
+            for (u32 t = t_lo; t < t_hi; ++t) {
+                const u32 v = hist[(size_t)t * nrow + c];
+                sum = is_max ? (v > sum ? v : sum) : sum + v;
+            }
         }
     }
     s_part[g][cl] = sum;
@@ -323,11 +341,20 @@ __global__ __launch_bounds__(1024) void k_bkt_scan(u32* __restrict__ hist, u32 n
         all = is_max ? (x > all ? x : all) : all + x;
     }
     if (!is_max) {
+        if (cached) {
+#pragma unroll
+            for (u32 q = 0; q < SC_REG; ++q) {
+                const u32 t = t_lo + q;
+                if (t < t_hi) hist[(size_t)t * nrow + c] = run;
+                run += v8[q];
+            }
+        } else {
 #pragma unroll 8
-        for (u32 t = t_lo; t < t_hi; ++t) {
-            const u32 v = hist[(size_t)t * nrow + c];
-            hist[(size_t)t * nrow + c] = run;
-            run += v;
+            for (u32 t = t_lo; t < t_hi; ++t) {
+                const u32 v = hist[(size_t)t * nrow + c];
+                hist[(size_t)t * nrow + c] = run;
+                run += v;
+            }
         }
     }
     if (g == 0) total[c] = all;
