@@ -511,18 +511,19 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes of the last profiling visit
         # (scripts/gpu_profile.sh -> scripts/summarize_prof.py -> profiles/traffic.json): counters cannot
         # be collected inside this run, so the figure is the committed one for this workload or null.
-        traffic = pipeline_traffic = None
+        traffic = pipeline_traffic = l2_hit = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         default_workload = (args.keys, args.batch, args.zipf) == (10_000_000, 1_000_000, 0.99)
         if os.path.exists(tpath) and default_workload and world == 1:
             try:
                 tk = json.load(open(tpath))["kernels"]
                 traffic = tk.get(kname, {}).get("hbm_bytes_per_launch")
+                l2_hit = tk.get(kname, {}).get("tcc_hit_rate")
                 # the whole batch pipeline (partition + hot state + replay), for the traffic / algorithmic ratio
                 pipeline_traffic = sum(tk.get(k, {}).get("hbm_bytes_per_launch") or 0.0 for k in
                                        ("k_bkt_hist", "k_bkt_scan", "k_bkt_scatter", "k_hot_state", "k_bkt_apply"))
             except Exception:
-                traffic = pipeline_traffic = None
+                traffic = pipeline_traffic = l2_hit = None
         out = {
             "metric": "rate-limit decisions/sec", "value": decisions / dt, "unit": "decisions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -538,6 +539,9 @@ def main():
                        "denied_in_last_batch": denied},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                         # SURVEY.md §8(d)'s three figures: algorithmic GB/s (`achieved`), counter-derived GB/s, L2 hit rate
+                         "counter_GBps": (traffic / (per[dom] * 1e-3) / 1e9) if (traffic and per.get(dom, 0) > 0) else None,
+                         "l2_hit_rate": l2_hit,
                          "pipeline_traffic": pipeline_traffic,
                          "pipeline_traffic_over_algorithmic": (pipeline_traffic / (ALGO_BYTES_TOTAL * hits_per_launch))
                          if pipeline_traffic else None,
