@@ -24,9 +24,9 @@ if ROOT not in sys.path:
 # Algorithmic bytes per (request x counter), SURVEY.md §8(d): 16 B descriptor read + 24 B cell read
 # (key, value, expiry) + 8 B value write-back + 1 B verdict = 49 B.  k_bkt_apply is the kernel that
 # reads the descriptor and the cell, writes the value back and emits the verdict, so all 49 B are
-# its algorithmic bytes; the partition kernels (hist / scan / scatter) only reorder the batch —
-# ranking traffic is overhead, not algorithmic — and are charged 0.
-ALGO_BYTES = {"apply": 49, "hist": 0, "scan": 0, "scatter": 0, "hot_state": 0}
+# its algorithmic bytes; the partition kernel (k_bkt_part) only reorders the batch —
+# ranking traffic is overhead, not algorithmic — and is charged 0.
+ALGO_BYTES = {"apply": 49, "part": 0}
 ALGO_BYTES_TOTAL = 49
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -48,8 +48,8 @@ def parse():
                          "overlaps k_bkt_apply of this one), 1 = one blocking call per batch; "
                          "the routed path keeps 3 ingress slices in flight at depth >= 2 (ShardedEngine)")
     ap.add_argument("--timing-mode", type=int, default=3, choices=(0, 2, 3),
-                    help="HIP events in the timed region: 2 = around k_bkt_apply on every launch, 3 = on every "
-                         "fourth launch, 0 = none (roofline then comes from the breakdown pass)")
+                    help="HIP events in the timed region: 2 = k_bkt_apply of every batch, 3 = k_bkt_part and k_bkt_apply "
+                         "of every fourth batch, 0 = none (roofline then comes from the breakdown pass)")
     ap.add_argument("--sharded-impl", choices=("torch", "abi"), default=os.environ.get("RL_SHARDED_IMPL", "abi"),
                     help="routed step driven by the C entry with its own RCCL communicator (include/rl_sharded.h: 105 us per "
                          "1 M-hit slice at world 1) or by torch.distributed from Python (limitador_amd/sharded.py: 181 us).  "
@@ -506,8 +506,7 @@ def main():
         dom = max(per, key=lambda k: per[k]) if per else "apply"
         dom_gbps = ALGO_BYTES[dom] * hits_per_launch / (per[dom] * 1e-3) / 1e9 if per.get(dom, 0) > 0 else 0.0
         pipe_ms = sum(per.values())
-        kname = {"apply": "k_bkt_apply", "hist": "k_bkt_hist", "scan": "k_bkt_scan", "scatter": "k_bkt_scatter"}.get(
-            dom, "k_" + dom)
+        kname = {"apply": "k_bkt_apply", "part": "k_bkt_part"}.get(dom, "k_" + dom)
         # HBM bytes per launch of that kernel from the PMC passes of the last profiling visit
         # (scripts/gpu_profile.sh -> scripts/summarize_prof.py -> profiles/traffic.json): counters cannot
         # be collected inside this run, so the figure is the committed one for this workload or null.
@@ -521,7 +520,7 @@ def main():
                 l2_hit = tk.get(kname, {}).get("tcc_hit_rate")
                 # the whole batch pipeline (partition + hot state + replay), for the traffic / algorithmic ratio
                 pipeline_traffic = sum(tk.get(k, {}).get("hbm_bytes_per_launch") or 0.0 for k in
-                                       ("k_bkt_hist", "k_bkt_scan", "k_bkt_scatter", "k_hot_state", "k_bkt_apply"))
+                                       ("k_bkt_part", "k_bkt_apply"))
             except Exception:
                 traffic = pipeline_traffic = l2_hit = None
         out = {
@@ -554,7 +553,8 @@ def main():
                                         "second stream; avg_launch_ms_alone: the same kernel in the breakdown pass, one "
                                         "blocking call per batch") if dom in timed
                          else "HIP events in the breakdown pass before the timed region"},
-            "pipeline": {"kernel_ms_per_batch": per, "device_ms_per_batch": pipe_ms,
+            "pipeline": {"kernel_ms_per_batch": per, "kernel_ms_per_batch_alone": per_alone,
+                         "kernel_ms_per_batch_in_pipeline": timed, "device_ms_per_batch": pipe_ms,
                          "achieved_GBps_49B": ALGO_BYTES_TOTAL * hits_per_launch / (pipe_ms * 1e-3) / 1e9 if pipe_ms else 0.0,
                          "ordered_hits_per_batch": st["ordered_hits"] / max(1, st["batches"]),
                          "host_submit_us_per_batch": (host_submit[0] / max(1, host_submit[1]) * 1e6)

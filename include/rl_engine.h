@@ -358,16 +358,16 @@ int32_t rl_engine_record_event(rl_engine *e, void *event);
 /* HIP-event timing of the kernels of the single-counter hot path: a timed launch carries its own
  * start / stop events (hipExtLaunchKernelGGL — no marker commands around the kernel, the interval is
  * the kernel's own begin..end on its stream).  enable = 0 off (completion is a sequence word the last
- * workgroup stores into host-mapped memory), 1 every kernel, 2 only the dominant kernel, k_bkt_apply,
- * 3 the same on every fourth batch.  rl_kernel_timing_read copies
+ * workgroup stores into host-mapped memory), 1 both kernels (k_bkt_part, k_bkt_apply) of every batch, 2 only the
+ * dominant kernel, k_bkt_apply, 3 both kernels of every fourth batch.  rl_kernel_timing_read copies
  * the milliseconds accumulated per slot since the last reset into ms[RL_TIMING_SLOTS] and the number
  * of timed batches into *launches. */
 enum {
-    RL_T_HIST = 0,           /* k_bkt_hist: per-tile bucket histogram + batch validation */
-    RL_T_SCAN = 1,           /* k_bkt_scan */
-    RL_T_SCATTER = 2,        /* k_bkt_scatter: stable partition into bucket order */
+    RL_T_PART = 0,           /* k_bkt_part: batch validation + single-pass stable partition (tile-local runs) */
+    RL_T_RESERVED1 = 1,
+    RL_T_RESERVED2 = 2,
     RL_T_APPLY = 3,          /* k_bkt_apply: probe, decide, commit — the dominant kernel */
-    RL_T_HOT_STATE = 4,      /* k_hot_state: the hot keys' cells before the batch (0 unless RL_SELF_HOT=0: k_bkt_apply reads them) */
+    RL_T_RESERVED4 = 4,
     RL_TIMING_SLOTS = 8
 };
 int32_t rl_kernel_timing(rl_engine *e, int32_t enable);

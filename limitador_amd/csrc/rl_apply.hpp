@@ -22,7 +22,7 @@
 //   k_bkt_tiny       a batch of <= TINY_MAX hits is one bucket: validate + replay in ONE launch
 //   k_bkt_count_new  dry run: how many cells would the batch create (all-or-nothing under TABLE_FULL)
 #pragma once
-#include "rl_bucket.hpp"
+#include "rl_part.hpp"
 
 namespace rl {
 
@@ -52,7 +52,7 @@ __device__ __forceinline__ u32 unpack_limit(typename LimitWord<NARROW>::type x) 
     return (u32)x;
 }
 
-template <int HPT, int ENT_LOG2, bool NARROW = false>
+template <int HPT, int ENT_LOG2, bool NARROW = false, int TT = TT_SMALL>
 struct Apply2Lds {
     static constexpr int E = 1 << ENT_LOG2;
     static constexpr int R = AP_BLOCK * HPT;          // hits per decide/commit round
@@ -67,6 +67,7 @@ struct Apply2Lds {
     u32 flags[E];  // EF_* | hits absorbed << EF_COUNT_SHIFT
     typename LimitWord<NARROW>::type limit[E];  // the CELL's limit attribute (pack_limit)
     unsigned short h_ent[R];  // the round's hits -> LDS cell (for the sequential replay of slow cells)
+    BucketView<TT> V;         // where the bucket's hits are (rl_part.hpp)
     u32 n_ent;
     u32 bucket_len;
     u32 promote_ok;
@@ -87,13 +88,14 @@ struct Apply2Args {
     int32_t* first_limited;
     Status* st;
     HotSet* hot_next;
-    const HotParam* hot_param;
-    const unsigned short* chunk_tab;  // hot chunk -> index of its hot bucket
+    const HotPlan* plan;              // the hot buckets' work items (k_bkt_part)
+    const unsigned short* chunk_tab;  // hot work item -> index of its hot bucket
+    const u32* runs;                  // [bin][run_tt] the tiles' runs (k_bkt_part)
+    u32 run_tt, ntiles, tile_shift, nb;
     u32 hot_threshold;
     u32 hot_long;     // a hash bucket of at least this many hits is long BECAUSE of a key (twice the batch's mean bucket)
     u32 sparse_out;   // verdict[] / first_limited[] already say "admitted" (k_bkt_hist): only denials are stored
-    u32* hot_arrive;  // [HOT_MAX] chunks of a hot bucket that have read the key's cell (self_hot); zero between kernels
-    u32 dbg;  // RL_DEBUG_APPLY2 (timing experiments only): 1 no ticket, 2 no verdict stores, 4 no write-back, 8 no cell reads
+    u32* hot_arrive;  // [HOT_MAX] work items of a hot bucket that have read the key's cell; zero between kernels
 };
 
 __device__ __forceinline__ LimitDev limit_row2(const Apply2Args& A, u32 limit) {
@@ -133,10 +135,11 @@ __device__ __forceinline__ void apply2_commit(LDS& S, const Apply2Args& A, bool 
         if (!rebuild && !(f & EF_BAD) && S.promote_ok &&
             ((f >> EF_COUNT_SHIFT) >= A.hot_threshold ||
              ((f >> EF_COUNT_SHIFT) >= A.hot_threshold / 4 && S.bucket_len >= A.hot_long))) {
-            const u32 pos = atomicAdd(&A.hot_next->n, 1u);
-            if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = key;
+            // (predicted delta 1: a key whose hits carry another one is replayed in its first hot batch, and the last
+            // work item of that bucket then hands the delta it saw to the next set)
+            hot_append(A.hot_next, key, f >> EF_COUNT_SHIFT, 1u);
         }
-        if ((f & EF_DIRTY) && !(A.dbg & 4u)) {
+        if (f & EF_DIRTY) {
             Cell* c = &A.table[S.slot[e]];
             c->value = S.run[e];
             if (f & EF_EXPIRED) {  // (the limit row is only read when the window is reset: no dependent load in front of
@@ -205,13 +208,14 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
     u64 ctag[HPT], cvalue[HPT], cexpiry[HPT];
     u32 idx[HPT], ent[HPT];
     bool ok[HPT], creator[HPT], leader[HPT];
-    // ---- the round's inputs: the hits (coalesced), then every hit's home cell (one 32-byte read) --
+    // ---- the round's inputs: the hits, then every hit's home cell (one 32-byte read) --------------
     // Both loads are UNCONDITIONAL (a lane past the end of the round repeats the round's last hit): a load inside
     // a divergent `if` is waited for where the branch ends, and the home cells are not needed before phase B —
     // phase A's LDS work runs under their latency.
     // The round's records were requested a round ago (`hnext`, by apply2_bucket for the first round); the NEXT round's
-    // are requested now, so that with the four rounds of a 1024-bucket batch only the cell reads are a dependent trip to
-    // HBM per round.  (The next round's cells are not read ahead: a rebuild between the rounds writes cells back.)
+    // are requested now — after the cell reads, so that finding them in the bucket view (a binary search in LDS) also
+    // runs under the cells' latency — and with the rounds of a bucket only the cell reads are a dependent trip to HBM
+    // per round.  (The next round's cells are not read ahead: a rebuild between the rounds writes cells back.)
     uint4 ca[HPT], cb[HPT];
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
@@ -223,20 +227,20 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
         h[u].delta = hnext[u].z;
         h[u].idx_tag = hnext[u].w;
     }
-    if (n_next) {  // (block-uniform)
-#pragma unroll
-        for (int u = 0; u < HPT; ++u) {
-            const u32 p = tid * HPT + u;
-            hnext[u] = *reinterpret_cast<const uint4*>(A.b_hits + (first + n_items + (p < n_next ? p : n_next - 1)));
-        }
-    }
 #pragma unroll
     for (int u = 0; u < HPT; ++u) {
         idx[u] = ok[u] ? (h[u].idx_tag & 0xFFFFFFu) : 0u;
         hslot[u] = slot_of(h[u].key, A.seed, A.log2cap);
-        const Cell* c = &A.table[(A.dbg & 8u) ? (hslot[u] & 0xFFFu) : hslot[u]];
+        const Cell* c = &A.table[hslot[u]];
         ca[u] = *reinterpret_cast<const uint4*>(c);
         cb[u] = reinterpret_cast<const uint4*>(c)[1];  // expiry, limit
+    }
+    if (n_next) {  // (block-uniform)
+#pragma unroll
+        for (int u = 0; u < HPT; ++u) {
+            const u32 p = tid * HPT + u;
+            hnext[u] = *reinterpret_cast<const uint4*>(A.b_hits + view_src(S.V, first + n_items + (p < n_next ? p : n_next - 1)));
+        }
     }
     // ---- A: find or claim the key's LDS cell, add this hit to the round's aggregates ------------
     u32 n_new = 0;
@@ -444,7 +448,7 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
                 const u32 f = S.flags[e];
                 if (!(f & EF_SLOW) || (f & EF_BAD)) continue;
                 const LimitDev Le = limit_row2(A, unpack_limit<NARROW>(S.limit[e]));
-                const BHit hp = load_bhit(A.b_hits, first + p);
+                const BHit hp = load_bhit(A.b_hits, view_src(S.V, first + p));
                 const u64 d = hp.delta;
                 const u64 cur = Le.window_us == 0 ? 0ull : S.run[e];
                 const u64 sum = cur + d;  // wraps like the reference's release build (in_memory.rs:88)
@@ -455,7 +459,7 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
                 }
                 const u32 i = hp.idx_tag & 0xFFFFFFu;
                 if (!adm || !A.sparse_out) {
-                    if (!(A.dbg & 2u)) A.verdict[i] = adm ? 0 : 1;
+                    A.verdict[i] = adm ? 0 : 1;
                     if (A.first_limited) A.first_limited[i] = adm ? -1 : (int32_t)i;
                 }
             }
@@ -468,7 +472,7 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
         if (!ok[u]) continue;
         const u32 i = idx[u];
         if (!slow[u] && (v[u] || !A.sparse_out)) {  // (a slow hit's verdict was stored by the replay above)
-            if (!(A.dbg & 2u)) A.verdict[i] = v[u];
+            A.verdict[i] = v[u];
             if (A.first_limited) A.first_limited[i] = v[u] ? (int32_t)i : -1;
         }
         if (!leader[u]) continue;
@@ -514,9 +518,9 @@ __device__ __forceinline__ void apply2_clear(LDS& S) {
     }
 }
 
-// A whole bucket [lo, hi) of the partitioned batch, in trace order, by one workgroup.  The LDS
-// cells must be empty on entry; they are NOT cleared on exit (callers that replay a second bucket
-// clear them again).
+// Positions [lo, hi) of the bucket S.V describes, in trace order, by one workgroup.  The LDS cells
+// must be empty on entry; they are NOT cleared on exit (callers that replay a second bucket clear
+// them again).
 template <class LDS>
 __device__ __forceinline__ void apply2_bucket(LDS& S, const Apply2Args& A, u32 lo, u32 hi) {
     constexpr int R = LDS::R;
@@ -533,7 +537,7 @@ __device__ __forceinline__ void apply2_bucket(LDS& S, const Apply2Args& A, u32 l
 #pragma unroll
         for (int u = 0; u < R / AP_BLOCK; ++u) {
             const u32 p = threadIdx.x * (R / AP_BLOCK) + u;
-            hnext[u] = *reinterpret_cast<const uint4*>(A.b_hits + (lo + (p < n0 ? p : n0 - 1)));
+            hnext[u] = *reinterpret_cast<const uint4*>(A.b_hits + view_src(S.V, lo + (p < n0 ? p : n0 - 1)));
         }
     }
     for (u32 first = lo; first < hi; first += R) {
@@ -548,88 +552,32 @@ __device__ __forceinline__ void apply2_bucket(LDS& S, const Apply2Args& A, u32 l
     apply2_commit(S, A, false);
 }
 
-// Hot buckets (one key each, see apply_hot in rl_bucket.hpp): chunk c of the fast buckets is decided
-// from positions alone; chunk_tab[c] names its bucket.
-__device__ __forceinline__ void apply2_hot_chunk(const Apply2Args& A, u32 c) {
-    const u32 tid = threadIdx.x;
-    const u32 hb = A.chunk_tab[c];
-    const HotParam hp = A.hot_param[hb];
-    if (!hp.fast) return;  // (block-uniform) uniform deltas, but the cell's state asks for the replay below
-    const u32 lo = hp.lo, hi = hp.hi;
-    const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
-    const u64 room = hp.room;
-    const u32 limit = hp.limit;
-#pragma unroll
-    for (int u = 0; u < HOT_CHUNK / AP_BLOCK; ++u) {
-        const u32 j = first + u * AP_BLOCK + tid;
-        if (j >= hi) continue;
-        const BHit h = load_bhit(A.b_hits, j);
-        const u32 i = h.idx_tag & 0xFFFFFFu;
-        uint8_t v = (u64)(j - lo) < room ? 0 : 1;
-        if ((h.idx_tag >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
-            atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
-            v = 1;
-        }
-        if (!v && A.sparse_out) continue;
-        if (!(A.dbg & 2u)) A.verdict[i] = v;
-        if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
-    }
-    if (first == lo && tid == 0) {
-        // the bucket's first chunk also applies AtomicExpiringValue::update for the admitted hits
-        const LimitDev L = limit_row2(A, limit);
-        const u64 cnt = hi - lo;
-        const u64 n_adm = cnt < room ? cnt : room;
-        u32 slot = hp.slot;
-        bool expired = hp.expired != 0;
-        if (slot == SLOT_INVALID) {  // first touch creates the cell (in_memory.rs:122-127), verdict or not
-            u32 created = 0;
-            const u64 key = A.b_hits[lo].key;
-            slot = slot_of(key, A.seed, A.log2cap);
-            slot = probe_from<PM_CHECK>(A.table, A.log2cap, slot, A.table[slot].tag, key, limit, A.limits, A.now,
-                                        A.st, created);
-            if (created) atomicAdd(&A.st->n_inserted, created);
-            expired = false;
-        }
-        if (n_adm && slot != SLOT_INVALID) {
-            Cell* cell = &A.table[slot];
-            cell->value = hp.s + n_adm * hp.d;
-            if (expired) cell->expiry = A.now + L.window_us;
-        }
-    }
-}
-
-// The same chunk without k_hot_state (`self_hot`): every chunk's workgroup reads the key's cell itself — three
-// dependent loads (chunk table, hot-bucket row, cell) that overlap the other workgroups' chains instead of a
-// one-workgroup kernel in front of k_bkt_apply (5-7 us on the apply stream).  The cell must not change before every
-// chunk of the bucket has read it, so the workgroups count themselves in (hot_arrive) AFTER their read has returned
-// and the LAST one in applies AtomicExpiringValue::update for the bucket's admitted hits — or, when the cell's state
-// does not allow deciding from positions (every chunk comes to that same conclusion from the same unchanged cell),
-// replays the bucket with the general bucket code.  Nobody waits for anybody: no spinning, no ordering between
-// workgroups beyond the counter.
+// Hot buckets (one key each; bins nb.. of the partition): stable partition + one key per bucket means a hit's position
+// in the bucket IS its trace-order rank on the key, so with one delta value d for the whole bucket the reference admits
+// exactly the first (max - value_at(now)) / d positions (in_memory.rs:85-102 applied hit by hit) and any number of
+// workgroups can decide their share of the positions in parallel.  Work item c (k of the bucket's nk, chunk_tab / plan
+// from k_bkt_part) takes the 1024-position chunks k, k + nk, ...: whatever the bucket's real length, the items cover it.
+// Every item's workgroup reads the key's cell itself — dependent loads that overlap the other workgroups' chains.  The cell
+// must not change before every item of the bucket has read it, so the workgroups count themselves in (hot_arrive) AFTER
+// their read has returned and the LAST one in applies AtomicExpiringValue::update for the bucket's admitted hits — or,
+// when the bucket cannot be decided from positions (a tile saw a delta the set did not predict, a 0-second window, a
+// value near 2^64, a missing simple cell: every item comes to that same conclusion from the same unchanged cell and
+// the same runs), replays the bucket with the general bucket code.  Nobody waits for anybody: no spinning, no ordering
+// between workgroups beyond the counter.  The last one in also keeps the key in the next hot set if it still earns it.
 template <class LDS>
-__device__ __forceinline__ void apply2_hot_chunk_self(LDS& S, const Apply2Args& A, u32 c) {
+__device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32 c) {
     constexpr int PER = HOT_CHUNK / AP_BLOCK;
     const u32 tid = threadIdx.x;
     const u32 hb = A.chunk_tab[c];
-    const HotParam hp = A.hot_param[hb];
-    const u32 n_chunks_b = A.hot_param[hb + 1].chunk0 - hp.chunk0;
-    const u32 lo = hp.lo, hi = hp.hi;
-    const u32 first = lo + (c - hp.chunk0) * HOT_CHUNK;
-    // the chunk's records are requested first: the cell's latency runs under theirs
-    u32 h_tag[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const u32 j = first + u * AP_BLOCK + tid;
-        h_tag[u] = A.b_hits[j < hi ? j : hi - 1].idx_tag;
-    }
+    const uint4 pa = *reinterpret_cast<const uint4*>(&A.plan[hb]);
+    const uint4 pb = reinterpret_cast<const uint4*>(&A.plan[hb])[1];
+    const u64 key = ((u64)pa.y << 32) | pa.x;
+    const u32 k = c - pa.z, nk = pa.w, d_pred = pb.x;
     // ---- the key's cell as it is before this batch (every lane reads the same addresses) --------------------
-    const u64 key = hp.key;
-    const u32 limit = hp.limit;
-    const LimitDev L = limit_row2(A, limit);
     const u32 mask = (1u << A.log2cap) - 1u;
     u32 slot = slot_of(key, A.seed, A.log2cap);
     u64 value = 0, expiry = 0;
-    u32 cl = limit;
+    u32 cl = 0;
     bool found = false;
     for (u32 step = 0; step <= mask; ++step) {
         const Cell* cp = &A.table[slot];
@@ -646,25 +594,41 @@ __device__ __forceinline__ void apply2_hot_chunk_self(LDS& S, const Apply2Args& 
         if (tag == TAG_EMPTY) break;
         slot = (slot + 1) & mask;
     }
+    __syncthreads();  // (the previous user of S.V and S.n_keep is done)
+    view_build(S.V, A.runs + (size_t)(A.nb + hb) * A.run_tt, A.ntiles, A.tile_shift);
+    const u32 total = view_total(S.V);
+    const bool mis = S.V.flags != 0u;
+    // the limit id is the CELL's attribute; a key without a cell takes it from its first hit in the caller's batch
+    u32 limit = cl;
+    if (!found && total) limit = A.hits[A.b_hits[view_src(S.V, 0)].idx_tag & 0xFFFFFFu].limit;
+    LimitDev L{0, 0};
+    if (total) L = limit_row2(A, limit);
     const bool expired = found && expiry <= A.now;
     const u64 s = (found && !expired) ? value : 0ull;  // value_at(now), atomic_expiring_value.rs:19-24
-    // the rule of k_hot_state (only uniform buckets own chunks, so hp.uni holds here)
-    const bool fast = L.window_us != 0 && s < (1ull << 62) && (!found || cl == limit) && (found || !(limit & SIMPLE_FLAG));
-    const u64 room = s > L.max_value ? 0ull : (hp.d ? (L.max_value - s) / hp.d : ~0ull);
+    const bool fast = total && !mis && L.window_us != 0 && s < (1ull << 62) && (found || !(limit & SIMPLE_FLAG));
+    const u64 room = s > L.max_value ? 0ull : (d_pred ? (L.max_value - s) / d_pred : ~0ull);
     if (fast) {
+        for (u32 cb = k * HOT_CHUNK; cb < total; cb += nk * HOT_CHUNK) {
+            u32 h_tag[PER];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const u32 j = first + u * AP_BLOCK + tid;
-            if (j >= hi) continue;
-            const u32 i = h_tag[u] & 0xFFFFFFu;
-            uint8_t v = (u64)(j - lo) < room ? 0 : 1;
-            if ((h_tag[u] >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
-                atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
-                v = 1;
+            for (int u = 0; u < PER; ++u) {
+                const u32 j = cb + u * AP_BLOCK + tid;
+                h_tag[u] = A.b_hits[view_src(S.V, j < total ? j : total - 1)].idx_tag;
             }
-            if (!v && A.sparse_out) continue;
-            if (!(A.dbg & 2u)) A.verdict[i] = v;
-            if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const u32 j = cb + u * AP_BLOCK + tid;
+                if (j >= total) continue;
+                const u32 i = h_tag[u] & 0xFFFFFFu;
+                uint8_t v = (u64)j < room ? 0 : 1;
+                if ((h_tag[u] >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
+                    atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
+                    v = 1;
+                }
+                if (!v && A.sparse_out) continue;
+                A.verdict[i] = v;
+                if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
+            }
         }
     }
     // ---- count this workgroup in: every lane's read of the cell has returned --------------------------------
@@ -672,24 +636,27 @@ __device__ __forceinline__ void apply2_hot_chunk_self(LDS& S, const Apply2Args& 
     __syncthreads();
     if (tid == 0) S.n_keep = atomicAdd(&A.hot_arrive[hb], 1u);
     __syncthreads();
-    const bool last = S.n_keep + 1u == n_chunks_b;  // (block-uniform)
+    const bool last = S.n_keep + 1u == nk;  // (block-uniform)
     __syncthreads();  // S.n_keep is free again
     if (!last) return;
-    if (tid == 0) atomicExch(&A.hot_arrive[hb], 0u);  // for the next kernel
+    if (tid == 0) {
+        atomicExch(&A.hot_arrive[hb], 0u);  // for the next kernel
+        // still hot?  (with the delta its hits carry now, if it was not the predicted one)
+        if (total >= A.hot_threshold) hot_append(A.hot_next, key, total, mis ? A.b_hits[view_src(S.V, 0)].delta : d_pred);
+    }
+    if (!total) return;
     if (!fast) {
-        // 0-second window, a value near 2^64, a cell that belongs to another limit id, a missing simple cell:
         // the reference's arithmetic hit by hit, by this workgroup
         apply2_clear(S);
-        if (tid == 0) S.promote_ok = 0;  // its key is kept or dropped by count (k_bkt_scatter), not promoted
+        if (tid == 0) S.promote_ok = 0;  // kept or dropped by count (above), not promoted
         __syncthreads();
-        apply2_bucket(S, A, lo, hi);
+        apply2_bucket(S, A, 0, total);
         __syncthreads();
         return;
     }
     if (tid == 0) {
         // AtomicExpiringValue::update for the admitted hits
-        const u64 cnt = hi - lo;
-        const u64 n_adm = cnt < room ? cnt : room;
+        const u64 n_adm = (u64)total < room ? (u64)total : room;
         u32 wslot = found ? slot : SLOT_INVALID;
         bool reset = expired;
         if (!found) {  // first touch creates the cell (in_memory.rs:122-127), verdict or not
@@ -702,7 +669,7 @@ __device__ __forceinline__ void apply2_hot_chunk_self(LDS& S, const Apply2Args& 
         }
         if (n_adm && wslot != SLOT_INVALID) {
             Cell* cell = &A.table[wslot];
-            cell->value = s + n_adm * hp.d;
+            cell->value = s + n_adm * d_pred;
             if (reset) cell->expiry = A.now + L.window_us;
         }
     }
@@ -717,25 +684,28 @@ __device__ __forceinline__ void apply2_hot_chunk_self(LDS& S, const Apply2Args& 
 // that is dropped by a rebuild of the LDS cells of a long bucket and met again is counted twice
 // (an over-estimate, never an under-estimate).
 // ---------------------------------------------------------------------------------------------
-template <int ENT_LOG2>
+template <int ENT_LOG2, int TT>
 __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restrict__ table, u32 log2cap, u64 seed,
                                                             const BHit* __restrict__ b_hits,
-                                                            const uint2* __restrict__ ranges, u32 nb,
-                                                            const HotParam* __restrict__ hot_param,
-                                                            u32* __restrict__ n_new_out) {
+                                                            const u32* __restrict__ runs, u32 run_tt, u32 ntiles,
+                                                            u32 tile_shift, u32 nb, u32* __restrict__ n_new_out) {
     constexpr int E = 1 << ENT_LOG2;
     constexpr u32 KEEP = E * 3 / 4 - AP_BLOCK;
     __shared__ u64 s_key[E];
+    __shared__ BucketView<TT> V;
     __shared__ u32 s_n_ent, s_new;
     const u32 tid = threadIdx.x, G = gridDim.x;
     if (tid == 0) s_new = 0;
     u32 my_new = 0;
-    auto count_bucket = [&](u32 lo, u32 hi) {
+    for (u32 bin = blockIdx.x; bin < nb + (u32)HOT_MAX; bin += G) {
         __syncthreads();
+        view_build(V, runs + (size_t)bin * run_tt, ntiles, tile_shift);
+        const u32 hi = view_total(V);
+        if (!hi) continue;
         for (u32 e = tid; e < (u32)E; e += AP_BLOCK) s_key[e] = TAG_EMPTY;
         if (tid == 0) s_n_ent = 0;
         __syncthreads();
-        for (u32 first = lo; first < hi; first += AP_BLOCK) {
+        for (u32 first = 0; first < hi; first += AP_BLOCK) {
             if (s_n_ent > KEEP) {  // block-uniform (read after a barrier)
                 __syncthreads();
                 for (u32 e = tid; e < (u32)E; e += AP_BLOCK) s_key[e] = TAG_EMPTY;
@@ -746,7 +716,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restri
             bool creator = false;
             u64 key = 0;
             if (j < hi) {
-                key = load_bhit(b_hits, j).key;
+                key = load_bhit(b_hits, view_src(V, j)).key;
                 u32 e = (u32)(fmix64(key ^ seed) >> 20) & (E - 1);
                 for (;;) {
                     u64 prev = s_key[e];
@@ -775,13 +745,6 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restri
             }
             __syncthreads();
         }
-    };
-    const uint2 r = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
-    if (r.x != r.y) count_bucket(r.x, r.y);
-    for (u32 hk = blockIdx.x; hk < (u32)HOT_MAX; hk += G) {
-        const HotParam hp = hot_param[hk];  // (block-uniform)
-        if (hp.hi == hp.lo) continue;
-        count_bucket(hp.lo, hp.hi);  // (a bucket of a single key: one LDS cell, one probe per round of a rebuild)
     }
     for (int off = 32; off > 0; off >>= 1) my_new += __shfl_down(my_new, off);
     if ((tid & 63u) == 0 && my_new) atomicAdd(&s_new, my_new);
@@ -790,84 +753,97 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_count_new(const Cell* __restri
 }
 
 // k_bkt_apply's body (the __global__ entry below only adds the launch bounds).
-template <int HPT, int ENT_LOG2, bool NARROW>
-__device__ __forceinline__ void bkt_apply_body(
+struct ApplyParams {
+    Cell* table;
+    u32 log2cap;
+    u64 seed;
+    const BHit* b_hits;
+    const Hit* hits;
+    const u32* runs;
+    u32 run_tt, ntiles, tile_shift, nb;
+    const HotPlan* plan;
+    const unsigned short* chunk_tab;
+    u32 chunk_tab_len;
+    const LimitDev* limits;
+    u64 now;
+    uint8_t* verdict;
+    int32_t* first_limited;
+    BatchScratch* bs;
+    BatchScratch* bs_zero;
+    Status* host_status;
+    u32 done_seq;
+    HotSet* hot_next;
+    u32 hot_threshold;
+    u32* hot_arrive;
+    u32 sparse_out;
+    u32 hot_long;
+};
 
-    Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits,
-    const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb,
-    const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab,
-    const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict,
-    int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
-    HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out, u32 hot_long) {
-    __shared__ Apply2Lds<HPT, ENT_LOG2, NARROW> S;
+template <int HPT, int ENT_LOG2, bool NARROW, int TT>
+__device__ __forceinline__ void bkt_apply_body(const ApplyParams& P) {
+    // The workgroup's LDS is DYNAMIC (the launch passes sizeof(Apply2Lds)): the compiler derives the register budget
+    // from the occupancy the static LDS allows, and with 21 KB of it (seven workgroups per CU) it hands the kernel 88
+    // VGPRs whatever waves_per_eu asks for.  The budget that matters here is 64 (see RL_DEF_APPLY).
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    Apply2Lds<HPT, ENT_LOG2, NARROW, TT>& S = *reinterpret_cast<Apply2Lds<HPT, ENT_LOG2, NARROW, TT>*>(s_dyn);
     const u32 tid = threadIdx.x, G = gridDim.x;
-    const bool self_hot = hot_arrive != nullptr;  // no k_hot_state ran: the chunks read the hot keys' cells themselves
-    Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                 hot_next, hot_param, chunk_tab, hot_threshold, hot_long, sparse_out, hot_arrive, dbg};
-    // ranges[] is in processing order (longest buckets first): the hardware hands workgroups out in
-    // index order, so the long buckets start first and the short ones fill the tail
-    const uint2 r = blockIdx.x < nb ? ranges[blockIdx.x] : make_uint2(0, 0);
-    const u32 n_chunks = hot_param[HOT_MAX].chunk0;
-    apply2_clear(S);
-    if (tid == 0) {
-        S.n_created = 0;
-        S.promote_ok = 1;
-    }
-    __syncthreads();
-    if (r.x != r.y) apply2_bucket(S, A, r.x, r.y);
-    // ---- the hot buckets: fast chunks from positions, the rest replayed by one workgroup each ------
-    if (self_hot) {
-        __syncthreads();  // (the workgroup's own bucket is done with S)
-        for (u32 c = G - 1 - blockIdx.x; c < n_chunks; c += G) apply2_hot_chunk_self(S, A, c);
-    } else {
-        for (u32 c = G - 1 - blockIdx.x; c < n_chunks; c += G) apply2_hot_chunk(A, c);
-    }
-    for (u32 hk = G - 1 - blockIdx.x; hk < (u32)HOT_MAX; hk += G) {
-        const HotParam hp = hot_param[hk];  // (block-uniform)
-        // (self_hot: a uniform bucket is its chunks' business, whatever its cell's state turns out to be)
-        if ((self_hot ? hp.uni : hp.fast) || hp.hi == hp.lo) continue;
-        __syncthreads();
+    Apply2Args A{P.table, P.log2cap, P.seed, P.b_hits, P.hits, P.limits, P.now, P.verdict, P.first_limited, &P.bs->st,
+                 P.hot_next, P.plan, P.chunk_tab, P.runs, P.run_tt, P.ntiles, P.tile_shift, P.nb, P.hot_threshold,
+                 P.hot_long, P.sparse_out, P.hot_arrive};
+    // k_bkt_part refused the batch (a malformed hit): nothing is applied, the status block says why
+    const bool refused = __hip_atomic_load(&P.bs->st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (!refused) {
+        // the row of the workgroup's own bucket is requested first; the LDS cells are cleared under its latency
+        const bool own = blockIdx.x < P.nb;
+        const u32 bin = own ? bucket_of_workgroup(blockIdx.x, P.nb) : 0u;
+        u32 n_items = P.plan[HOT_MAX].chunk0;
+        if (n_items > P.chunk_tab_len) n_items = P.chunk_tab_len;
         apply2_clear(S);
-        if (tid == 0) S.promote_ok = 0;  // its key is kept or dropped by count (k_bkt_scatter), not promoted
-        __syncthreads();
-        apply2_bucket(S, A, hp.lo, hp.hi);
+        if (tid == 0) {
+            S.n_created = 0;
+            S.promote_ok = 1;
+        }
+        if (own) {
+            view_build(S.V, P.runs + (size_t)bin * P.run_tt, P.ntiles, P.tile_shift);  // (its barriers also cover the clear)
+            const u32 total = view_total(S.V);
+            if (total) apply2_bucket(S, A, 0, total);
+        } else {
+            __syncthreads();
+        }
+        // ---- the hot buckets' work items -------------------------------------------------------------------
+        for (u32 c = G - 1 - blockIdx.x; c < n_items; c += G) apply2_hot_item(S, A, c);
     }
     // every wave's stores have been acknowledged before the workgroup's ticket is taken
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        if (dbg & 1u) {  // timing experiment: workgroup 0 reports completion, nobody takes a ticket
-            if (blockIdx.x == 0) apply_finish(0u, bs, bs_zero, host_status, done_seq, 1u, &hot_next->n, 0u);
-        } else {
-            apply_finish(S.n_created, bs, bs_zero, host_status, done_seq, G, &hot_next->n, 0u);
-        }
+    if (tid == 0) apply_finish(refused ? 0u : S.n_created, P.bs, P.bs_zero, P.host_status, P.done_seq, G, &P.hot_next->n, 0u);
+}
+
+// The register budget is pinned (waves_per_eu), not left to the occupancy the compiler derives from the LDS size: at 64
+// VGPRs four of these workgroups per CU leave half of the register file to the 16-wave workgroups of k_bkt_part.
+#define RL_DEF_APPLY(NAME, HPT, ENT_LOG2, MAX_VGPR, NARROW, TT)                                                            \
+    typedef Apply2Lds<HPT, ENT_LOG2, NARROW, TT> NAME##_lds;                                                               \
+    __global__ __launch_bounds__(AP_BLOCK) __attribute__((amdgpu_waves_per_eu(512 / MAX_VGPR, 512 / MAX_VGPR))) void NAME( \
+        const ApplyParams P) {                                                                                             \
+        bkt_apply_body<HPT, ENT_LOG2, NARROW, TT>(P);                                                                      \
     }
-}
-
-#define RL_APPLY_PARAMS \
-    Cell* __restrict__ table, u32 log2cap, u64 seed, const BHit* __restrict__ b_hits, \
-        const Hit* __restrict__ hits, const uint2* __restrict__ ranges, u32 nb, \
-        const HotParam* __restrict__ hot_param, const unsigned short* __restrict__ chunk_tab, \
-        const LimitDev* __restrict__ limits, u64 now, uint8_t* __restrict__ verdict, \
-        int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq, \
-        HotSet* hot_next, u32 hot_threshold, u32 dbg, u32* hot_arrive, u32 sparse_out, u32 hot_long
-#define RL_APPLY_ARGS table, log2cap, seed, b_hits, hits, ranges, nb, hot_param, chunk_tab, limits, now, verdict, first_limited, bs, bs_zero, host_status, done_seq, hot_next, hot_threshold, dbg, hot_arrive, sparse_out, hot_long
-
-template <int HPT, int ENT_LOG2, int MIN_WAVES, bool NARROW>
-__global__ __launch_bounds__(AP_BLOCK, MIN_WAVES) void k_bkt_apply(RL_APPLY_PARAMS) {
-    bkt_apply_body<HPT, ENT_LOG2, NARROW>(RL_APPLY_ARGS);
-}
+RL_DEF_APPLY(k_bkt_apply, 1, 9, 64, true, TT_SMALL)         // the usual one: limit ids in 16 bits, views of up to 256 tiles
+RL_DEF_APPLY(k_bkt_apply_wide, 1, 9, 64, false, TT_SMALL)   // engines with more than 32768 limit rows
+RL_DEF_APPLY(k_bkt_apply_large, 1, 9, 96, false, TT_LARGE)  // batches of more than 256 tiles
+RL_DEF_APPLY(k_bkt_apply_v80, 1, 9, 80, true, TT_SMALL)     // (RL_APPLY2_CFG experiments)
+RL_DEF_APPLY(k_bkt_apply_v96, 1, 9, 96, true, TT_SMALL)
+#undef RL_DEF_APPLY
 // ---------------------------------------------------------------------------------------------
 // k_bkt_tiny: a batch of at most TINY_MAX hits IS one bucket — it is in trace order already — so one
-// workgroup validates it (the checks of k_bkt_hist), rewrites it as BHit records and replays it with
-// the bucket code: one launch instead of five.  The hot set is left as it is.
+// workgroup validates it (the checks of k_bkt_part), rewrites it as BHit records and replays it with
+// the bucket code: one launch instead of two.  The hot set is left as it is.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
     Cell* __restrict__ table, u32 log2cap, u64 seed, const Hit* __restrict__ hits, u32 n, BHit* __restrict__ b_hits,
     const LimitDev* __restrict__ limits, u32 n_limits, u64 now, uint8_t* __restrict__ verdict,
     int32_t* __restrict__ first_limited, BatchScratch* bs, BatchScratch* bs_zero, Status* host_status, u32 done_seq,
     u32 hot_n_report) {
-    __shared__ Apply2Lds<1, 9, false> S;
+    __shared__ Apply2Lds<1, 9, false, TT_SMALL> S;
     __shared__ u32 s_err;
     const u32 tid = threadIdx.x;
     if (tid == 0) {
@@ -876,6 +852,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
         S.promote_ok = 0;  // no promotion from here: the hot set belongs to the partitioned path
     }
     apply2_clear(S);
+    view_single(S.V, 0u, n);
     __syncthreads();
     u32 err = 0;
     for (u32 i = tid; i < n; i += AP_BLOCK) {
@@ -898,7 +875,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
         if (tid == 0) atomicOr(&bs->st.err, s_err);
     } else if (n) {
         Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                     nullptr, nullptr, nullptr, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, nullptr, 0u};
+                     nullptr, nullptr, nullptr, nullptr, 0u, 1u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, nullptr};
         apply2_bucket(S, A, 0, n);
     }
     // the verdicts may go straight to host-mapped memory (rl_check_and_update_batch): every wave's stores

@@ -66,7 +66,21 @@ struct HotSet {
     u32 n;
     u32 pad;
     u64 key[HOT_MAX];
+    // What the key looked like in the batch that picked it — a PREDICTION for the batch that uses the set: `cnt` sizes
+    // the key's share of k_bkt_apply's hot work items (any split covers the bucket, rl_part.hpp), `d` is the delta its
+    // hits are expected to carry (a bucket whose hits all carry it is decided from positions alone).
+    u32 cnt[HOT_MAX];
+    u32 d[HOT_MAX];
 };
+// Append a key to the set a batch picks (any thread of any workgroup).
+__device__ __forceinline__ void hot_append(HotSet* hs, u64 key, u32 cnt, u32 d) {
+    const u32 pos = atomicAdd(&hs->n, 1u);
+    if (pos < (u32)HOT_MAX) {
+        hs->key[pos] = key;
+        hs->cnt[pos] = cnt;
+        hs->d[pos] = d;
+    }
+}
 // Per-batch scratch of the bucketed path.  Two of them alternate: the last workgroup of a batch's
 // k_bkt_apply mirrors the status block to host-mapped memory (no copy command behind the batch) and
 // zeroes the OTHER one for the next batch (no memset command in front of it).
@@ -480,10 +494,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                 const u32 dmax = total[nbt_ + tid], dmin = ~total[nbt_ + HOT_MAX + tid];
                 hp.d = dmax;
                 hp.uni = dmin == dmax ? 1u : 0u;
-                if (cnt >= hot_threshold) {
-                    const u32 pos = atomicAdd(&hot_next->n, 1u);
-                    if (pos < (u32)HOT_MAX) hot_next->key[pos] = hot->key[tid];
-                }
+                if (cnt >= hot_threshold) hot_append(hot_next, hot->key[tid], cnt, dmax);
             }
             // (the general resolver walks EVERY hot bucket in chunks: all_chunks)
             s_nchunk[tid] = (hp.uni || all_chunks) ? (cnt + HOT_CHUNK - 1) / HOT_CHUNK : 0u;

@@ -104,7 +104,8 @@ struct rl_engine {
         hipEvent_t tev[10]{};  // start / stop of each kernel of a timed batch, see collect_k1_bucketed
         Status* h_st = nullptr;  // host-mapped: written by the batch's last workgroup
         u32 n = 0, n_wg = 0, ntiles = 0;
-        int timed = 0;
+        int timed = 0;         // bit 0: k_bkt_part timed, bit 1: k_bkt_apply / k_bkt_tiny timed
+        hipEvent_t ev_p_stop = nullptr, ev_a_stop = nullptr;  // the stop events of the timed launches (see submit_k1_bucketed)
         u32 seq = 0;  // value the batch's last workgroup stores into h_st->n_removed
         bool settled = false;  // completion seen and its new cells already added to `live` (settle_inflight)
     } inflight[4];  // at most three in flight
@@ -145,8 +146,29 @@ struct rl_engine {
     bool overlap = true;
     bool ext_events = true;         // RL_EXT_EVENTS=0: hipEventRecord markers behind k_bkt_scatter / k_bkt_apply instead of the
                                     // launches' own stop events (two marker commands fewer per batch on the two streams)
-    bool self_hot = true;           // RL_SELF_HOT=0: k_hot_state in front of k_bkt_apply instead of the chunks reading the hot cells
-    u32* d_hot_arrive = nullptr;    // [HOT_MAX] (apply2_hot_chunk_self)
+    u32* d_hot_arrive = nullptr;    // [HOT_MAX] (apply2_hot_item)
+    // the single-pass partition (rl_part.hpp): per set, the tiles' runs and the hot buckets' work items
+    u32* d_runs = nullptr;          // [PB_SETS][BKT_MAX * run_tt_max]
+    u32 run_tt_max = TT_SMALL;      // TT_SMALL, or TT_LARGE for engines whose largest batch has more than TT_SMALL tiles
+    HotPlan* d_plan = nullptr;      // [PB_SETS][HOT_MAX + 1]
+    size_t bk_stride = 0;           // records per set of d_bk_hits: max_batch rounded up to the largest tile
+    bool defer_apply = true;        // RL_DEFER_APPLY=0: enqueue k_bkt_apply at submit (see PendingApply)
+    // k_bkt_apply of the batch submitted last, not yet enqueued.  Its partition was enqueued at submit; the apply waits
+    // for the NEXT submit (or its own collect), by when the host usually sees the partition's event complete and the
+    // apply stream is spared a wait command — a satisfied hipStreamWaitEvent still idles the stream ~9 us, the gap that
+    // used to sit in front of every k_bkt_apply.
+    struct PendingApply {
+        bool valid = false;
+        u64 p = 0;       // partitioned-batch number
+        u32 slot = 0;    // inflight slot
+        const Hit* d_hits = nullptr;
+        u32 n = 0, nb = 0, ntiles = 0, tile_shift = 0, run_tt = 0, n_wg = 0;
+        u64 now = 0;
+        uint8_t* d_verdict = nullptr;
+        int32_t* d_first = nullptr;
+        bool t_apply = false;
+        u32 hot_long = 0;
+    } pend;
     u32 pipe_depth = 3;             // RL_PIPE_DEPTH (2 or 3): the partition of batch p waits for k_bkt_apply of batch p - depth
     hipEvent_t ev_parted[4]{}, ev_applied[4]{};
     hipEvent_t ev_match = nullptr;  // behind the copies of the matcher's count pass (match_and_check_locked)
@@ -166,7 +188,6 @@ struct rl_engine {
     BHit* d_tiny_hits = nullptr;            // k_bkt_tiny's record buffer
     unsigned short* d_chunk_tab = nullptr;  // [PB_SETS][...] hot chunk -> hot bucket (k_bkt_scatter -> k_bkt_apply)
     size_t chunk_tab_len = 0;
-    u32 dbg_apply2 = 0;     // RL_DEBUG_APPLY2 (timing experiments only)
     int apply2_cfg = 0;     // RL_APPLY2_CFG: which instantiation of k_bkt_apply (see launch_apply)
 
     // on-device limit matching (rl_match.hpp)
@@ -358,22 +379,7 @@ int wait_done(rl_engine* e, rl_engine::Inflight& f) {
     return RL_OK;
 }
 
-// Wait for every batch in flight and add the cells they created to `live` now (their status is still
-// handed out by rl_check_and_update_collect): used when a new batch needs the exact occupancy.
-int settle_inflight(rl_engine* e) {
-    for (u64 q = e->col_seq; q < e->sub_seq; ++q) {
-        rl_engine::Inflight& f = e->inflight[q & 3u];
-        if (f.settled) continue;
-        const int rc = wait_done(e, f);
-        if (rc) return rc;
-        e->live += f.h_st->n_inserted;
-        e->inflight_hits -= f.n;
-        f.settled = true;
-    }
-    return RL_OK;
-}
-
-// k_bkt_scatter's wave-private counters (dynamic LDS): PT_WAVES x (hash buckets + hot buckets) x 2 bytes
+// the partition kernels' wave-private counters (dynamic LDS): PT_WAVES x (hash buckets + hot buckets) x 2 bytes
 inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof(unsigned short); }
 
 // A launch that is timed carries its own start / stop events (hipExtLaunchKernelGGL: the events get the dispatch's
@@ -387,48 +393,103 @@ inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof
 #define RL_LAUNCH_T(timed, ev0, ev1, kern, grid, block, stream, ...) \
     RL_LAUNCH_TS(timed, ev0, ev1, kern, grid, block, 0, stream, __VA_ARGS__)
 
-// k_bkt_apply in the instantiation RL_APPLY2_CFG selects: <hits per thread, log2 LDS cells, min waves per SIMD, 16-bit limit ids>.
-void launch_apply(rl_engine* e, u32 n_wg, const Hit* d_hits, u32 nb, u32 par, u64 now, uint8_t* d_verdict,
-                  int32_t* d_first, BatchScratch* bs, BatchScratch* bs_zero, Status* h_st, u32 seq, HotSet* hot_prod,
-                  bool timed, hipEvent_t ev0, hipEvent_t ev1, u32 hot_long) {
-    const BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
-    const uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
-    const HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
-    const unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
-    u32* hot_arrive = e->self_hot ? e->d_hot_arrive : nullptr;
-    const LimitDev* limits = e->d_limits;
-#define RL_AP2(HPT, EL, MW, NARROW)                                                                             \
-    do {                                                                                                        \
-        auto kp = k_bkt_apply<HPT, EL, MW, NARROW>;                                                             \
-        RL_LAUNCH_T(timed, ev0, ev1, kp, n_wg, AP_BLOCK, e->stream, e->table, e->log2cap, e->seed, b_hits,      \
-                    d_hits, ranges, nb, hot_param, chunk_tab, limits, now, d_verdict, d_first, bs, bs_zero,     \
-                    h_st, seq, hot_prod, e->hot_threshold, e->dbg_apply2, hot_arrive, 1u, hot_long);            \
-    } while (0)
-    // 0 (default): 19.5 KB of LDS, eight workgroups per CU — limit ids in 16 bits, so engines with more than 32768 limit
-    // rows take 1: the same kernel with 32-bit limit ids (21.5 KB, seven per CU).  2 / 3: 1024 LDS cells (experiments).
+// k_bkt_apply in the instantiation RL_APPLY2_CFG selects (see RL_DEF_APPLY).
+void launch_apply(rl_engine* e, const ApplyParams& P, u32 n_wg, bool timed, hipEvent_t ev0, hipEvent_t ev1) {
+#define RL_AP2(KERN) RL_LAUNCH_TS(timed, ev0, ev1, KERN, n_wg, AP_BLOCK, sizeof(KERN##_lds), e->stream, P)
+    if (P.run_tt == (u32)TT_LARGE) {  // the largest batches (more than TT_SMALL tiles): a bucket view of 1024 tiles
+        RL_AP2(k_bkt_apply_large);
+        return;
+    }
+    // 0 (default): 21 KB of LDS, seven workgroups per CU — limit ids in 16 bits, so engines with more than 32768 limit
+    // rows take 1: the same kernel with 32-bit limit ids (22 KB).  2 / 3: larger register budgets (experiments).
     switch (e->apply2_cfg == 0 && e->max_limits > 32768u ? 1 : e->apply2_cfg) {
         default:
-        // (64 VGPRs matter even at four workgroups per CU: they leave half of the register file to the 16-wave
-        // workgroups of the partition kernels, which all stay below 64 VGPRs themselves; at 72+ VGPRs k_bkt_hist waited
-        // for k_bkt_apply to drain again — gpurun_out/v6)
-        case 0: RL_AP2(1, 9, 8, true); break;  // (three VGPRs in scratch, outside the bucket rounds)
-        case 1: RL_AP2(1, 9, 6, false); break;
-        case 2: RL_AP2(1, 10, 3, false); break;
-        case 3: RL_AP2(2, 10, 3, false); break;
+        case 0: RL_AP2(k_bkt_apply); break;
+        case 1: RL_AP2(k_bkt_apply_wide); break;
+        case 2: RL_AP2(k_bkt_apply_v80); break;
+        case 3: RL_AP2(k_bkt_apply_v96); break;
     }
 #undef RL_AP2
 }
 
-// Enqueue one batch of the bucketed path (no host synchronisation): the partition on `pstream`, then
-// k_hot_state + k_bkt_apply on `stream`, which therefore overlap the partition of the NEXT batch.
-//   partitioned batch p:  buffers [p % PB_SETS] (records, ranges, hot-bucket table, chunk table); scratch [p % BS_ROT],
+// Enqueue the k_bkt_apply that submit_k1_bucketed left pending (see rl_engine::PendingApply).
+int flush_pending_apply(rl_engine* e) {
+    rl_engine::PendingApply& q = e->pend;
+    if (!q.valid) return RL_OK;
+    q.valid = false;
+    rl_engine::Inflight& f = e->inflight[q.slot];
+    const u64 p = q.p;
+    const u32 par = (u32)(p % PB_SETS);
+    const bool two_streams = e->pstream != e->stream;
+    if (two_streams && hipEventQuery(e->ev_parted[p & 3u]) != hipSuccess) {
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
+    }
+    ApplyParams P{};
+    P.table = e->table;
+    P.log2cap = e->log2cap;
+    P.seed = e->seed;
+    P.b_hits = e->d_bk_hits + (size_t)par * e->bk_stride;
+    P.hits = q.d_hits;
+    P.runs = e->d_runs + (size_t)par * BKT_MAX * e->run_tt_max;
+    P.run_tt = q.run_tt;
+    P.ntiles = q.ntiles;
+    P.tile_shift = q.tile_shift;
+    P.nb = q.nb;
+    P.plan = e->d_plan + (size_t)par * (HOT_MAX + 1);
+    P.chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
+    P.chunk_tab_len = (u32)e->chunk_tab_len;
+    P.limits = e->d_limits;
+    P.now = q.now;
+    P.verdict = q.d_verdict;
+    P.first_limited = q.d_first;
+    P.bs = e->d_bs + p % BS_ROT;
+    P.bs_zero = e->d_bs + (p + 3) % BS_ROT;
+    P.host_status = f.h_st;
+    P.done_seq = f.seq;
+    P.hot_next = e->d_hot + p % HS_SETS;
+    P.hot_threshold = e->hot_threshold;
+    P.hot_arrive = e->d_hot_arrive;
+    P.sparse_out = 1u;
+    P.hot_long = q.hot_long;
+    // "applied" for the partition stream: the stop event of the launch itself where possible (no marker command); a
+    // timed launch only adds a start event
+    const bool chain_a = two_streams && e->ext_events;
+    f.ev_a_stop = chain_a ? e->ev_applied[p & 3u] : (q.t_apply ? f.tev[5] : nullptr);
+    launch_apply(e, P, q.n_wg, q.t_apply || chain_a, q.t_apply ? f.tev[4] : nullptr, f.ev_a_stop);
+    HIP_TRY(e, hipGetLastError());
+    if (two_streams && !chain_a) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
+    return RL_OK;
+}
+
+// Wait for every batch in flight and add the cells they created to `live` now (their status is still
+// handed out by rl_check_and_update_collect): used when a new batch needs the exact occupancy.
+int settle_inflight(rl_engine* e) {
+    int rc = flush_pending_apply(e);
+    if (rc) return rc;
+    for (u64 q = e->col_seq; q < e->sub_seq; ++q) {
+        rl_engine::Inflight& f = e->inflight[q & 3u];
+        if (f.settled) continue;
+        rc = wait_done(e, f);
+        if (rc) return rc;
+        e->live += f.h_st->n_inserted;
+        e->inflight_hits -= f.n;
+        f.settled = true;
+    }
+    return RL_OK;
+}
+
+// Enqueue one batch of the bucketed path (no host synchronisation): the partition on `pstream`, k_bkt_apply on
+// `stream`, which therefore overlaps the partition of the NEXT batches.
+//   partitioned batch p:  buffers [p % PB_SETS] (records, runs, hot work items, chunk table); scratch [p % BS_ROT],
 //   zeroes scratch [(p + 3) % BS_ROT]; partitioned with the hot set of batch p - depth, picks hot set [p % HS_SETS].
-//   stream order:  pstream: wait applied(p - depth) | hist scan scatter | record parted(p)
-//                  stream:  wait parted(p) | k_hot_state k_bkt_apply | record applied(p)
+//   stream order:  pstream: (wait applied(p - depth)) | k_bkt_part | parted(p)
+//                  stream:  (wait parted(p)) | k_bkt_apply | applied(p)
 // depth = pipe_depth.  With 3 the batch the partition waits for has been collected by the caller already (at most
 // three batches are in flight), so the wait never holds the partition stream back and the partitions run ahead of the
-// apply stream; with 2 (the first cut) the partition of batch p+2 started when k_bkt_apply of batch p ended, and
-// every step paid the cross-stream hand-over (~10 us of idle device, profiles/r02c trace).
+// apply stream.  Both waits are answered by the HOST where it can see the event complete (hipEventQuery): a wait command
+// costs the stream ~9 us even when its event completed long ago.  For "parted" that works because k_bkt_apply of batch p
+// is only enqueued when batch p + 1 is submitted (or batch p collected): PendingApply.
 int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_verdict, int32_t* d_first) {
     if (e->sub_seq - e->col_seq >= 3) return fail(e, RL_ERR_BUSY, "three batches are already in flight: collect one first");
     bool need_count = false;
@@ -441,13 +502,16 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         if (rc) return rc;
     }
     rl_engine::Inflight& f = e->inflight[e->sub_seq & 3u];
-    const bool t = e->timing == 1;  // events between all kernels
+    // timing: 1 both kernels of every batch, 2 k_bkt_apply of every batch, 3 both kernels of every fourth batch
     const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
+    const bool t = e->timing == 1 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
     const bool two_streams = e->pstream != e->stream;
     if (n <= e->tiny_max && !need_count) {
-        // one launch: the batch is one bucket (k_bkt_tiny), on the apply stream, with a scratch and a record
-        // buffer of its own (a partitioned batch's partition may be running beside it); the hot sets are left
-        // untouched
+        // one launch: the batch is one bucket (k_bkt_tiny), on the apply stream (behind the k_bkt_apply of every batch
+        // submitted before it), with a scratch and a record buffer of its own (a partitioned batch's partition may be
+        // running beside it); the hot sets are left untouched
+        rc = flush_pending_apply(e);
+        if (rc) return rc;
         {
             const LimitDev* limits = e->d_limits;
             RL_LAUNCH_T(t_apply, f.tev[4], f.tev[5], k_bkt_tiny, 1, AP_BLOCK, e->stream, e->table, e->log2cap, e->seed, d_hits, n,
@@ -459,6 +523,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         f.n_wg = 1;
         f.ntiles = 0;
         f.timed = t_apply ? 2 : 0;
+        f.ev_a_stop = f.tev[5];
         f.seq = (u32)(e->sub_seq + 1);
         f.settled = false;
         e->inflight_hits += n;
@@ -469,52 +534,65 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     const u32 bk_cap = n > (2u << 20) ? (u32)BK_LOG2_MAX : e->bk_log2_cfg;
     if (bk_log2 > bk_cap) bk_log2 = bk_cap;
     const u32 nb = 1u << bk_log2;
-    // small batches: quarter-size tiles, so that the two partition passes still spread over the CUs
-    const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
-    const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
+    // Hits per tile: 1024 for small batches (so that the partition still spreads over the CUs), else the smallest of
+    // 4096 / 8192 / 16384 that keeps the batch within TT_SMALL tiles (a bucket view of 256 tiles); the largest batches
+    // take 16384-hit tiles and the TT_LARGE view.
+    u32 steps = 1;
+    if (!(cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES))
+        for (steps = PT_STEPS; steps < PT_STEPS_MAX && cdiv(n, PT_BLOCK * steps) > (u32)TT_SMALL; steps *= 2) {}
+    const u32 tile_shift = 10u + (steps == 1 ? 0u : steps == 4 ? 2u : steps == 8 ? 3u : 4u);
+    const u32 ntiles = cdiv(n, 1u << tile_shift);
+    const u32 run_tt = ntiles <= (u32)TT_SMALL ? (u32)TT_SMALL : (u32)TT_LARGE;
     const u32 nbt = nb + HOT_MAX;
     const u64 p = e->part_seq;
     const u32 par = (u32)(p % PB_SETS);
     const u32 depth = e->pipe_depth;
     BatchScratch* bs = e->d_bs + p % BS_ROT;
-    BatchScratch* bs_zero = e->d_bs + (p + 3) % BS_ROT;
     const HotSet* hot_use = e->d_hot + (p + HS_SETS - depth) % HS_SETS;
     HotSet* hot_prod = e->d_hot + p % HS_SETS;
-    BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
-    uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
-    HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
+    BHit* b_hits = e->d_bk_hits + (size_t)par * e->bk_stride;
+    u32* runs = e->d_runs + (size_t)par * BKT_MAX * e->run_tt_max;
+    HotPlan* plan = e->d_plan + (size_t)par * (HOT_MAX + 1);
     unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
     hipStream_t ps = e->pstream;
     // ---- partition ----------------------------------------------------------------------------------
     // The batch whose buffers and hot set this partition takes over (p - depth) has, with depth 3, been collected by
     // the caller: the host asks the event itself — once it has seen it complete, everything enqueued from here on is
-    // ordered behind that batch — and the partition stream is spared a wait command (a satisfied wait still held the
-    // stream ~9 us per batch, gpurun_out/v7 trace).  Only a batch that is really still running gets the device-side wait.
+    // ordered behind that batch — and the partition stream is spared a wait command.  Only a batch that is really
+    // still running gets the device-side wait.  (A batch whose k_bkt_apply is still pending is p - 1: never p - depth.)
     if (two_streams && p >= depth && hipEventQuery(e->ev_applied[(p - depth) & 3u]) != hipSuccess) {
         (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
         HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - depth) & 3u], 0));
     }
     const Cell* ctable = e->table;
     const LimitDev* climits = e->d_limits;
-    auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
-    RL_LAUNCH_T(t, f.tev[0], f.tev[1], hist_k, ntiles, PT_BLOCK, ps, ctable, e->log2cap, e->seed, d_hits, n, climits,
-                (u32)e->h_limits.size(), bk_log2, ntiles, e->d_bk_hist, bs, hot_use, 1u, (u64*)nullptr, d_verdict, d_first);
-    RL_LAUNCH_T(t, f.tev[2], f.tev[3], k_bkt_scan, cdiv(nbt + HOT_COLS, 32), 1024, ps, e->d_bk_hist, ntiles, nbt, e->d_bk_total);
-    auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
-    // "partitioned" / "applied" for the other stream: the stop event of the launch itself where possible (no marker command)
-    const bool chain_p = two_streams && e->ext_events && !t && !need_count;
-    const bool chain_a = two_streams && e->ext_events && !t_apply;
-    RL_LAUNCH_TS(t || chain_p, t ? f.tev[6] : nullptr, t ? f.tev[7] : e->ev_parted[p & 3u], scatter_k, ntiles + 1, PT_BLOCK,
-                 scatter_lds_bytes(nbt), ps, d_hits, n, e->seed, bk_log2,
-                (const u32*)e->d_bk_hist, (const u32*)e->d_bk_total, hot_use, b_hits, ranges, (const Status*)&bs->st, ntiles,
-                hot_param, hot_prod, e->hot_threshold, chunk_tab, 0u, (u64*)nullptr);
+    // "partitioned" for the other stream: the stop event of the launch itself where possible (no marker command); a
+    // timed launch only adds a start event
+    const bool chain_p = two_streams && e->ext_events && !need_count;
+    f.ev_p_stop = chain_p ? e->ev_parted[p & 3u] : (t ? f.tev[1] : nullptr);
+#define RL_PART(STEPS)                                                                                                         \
+    RL_LAUNCH_TS(t || chain_p, t ? f.tev[0] : nullptr, f.ev_p_stop, k_bkt_part<STEPS>, ntiles + 1,                            \
+                 PT_BLOCK, scatter_lds_bytes(nbt), ps, ctable, e->log2cap, e->seed, d_hits, n, climits,                        \
+                 (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, plan,    \
+                 chunk_tab, (u32)e->chunk_tab_len, hot_prod)
+    switch (steps) {
+        case 1: RL_PART(1); break;
+        case 4: RL_PART(4); break;
+        case 8: RL_PART(8); break;
+        default: RL_PART(16); break;
+    }
+#undef RL_PART
     HIP_TRY(e, hipGetLastError());
     if (need_count) {
         // the cheap bound (every hit a new key) does not fit: count the batch's new keys exactly, before
         // anything is applied, and refuse the whole batch if they do not fit (nothing is in flight here)
         HIP_TRY(e, hipMemsetAsync(e->d_m_flags, 0, sizeof(u32), ps));
-        k_bkt_count_new<10><<<nb < 64u ? 64u : nb, AP_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, b_hits, ranges, nb,
-                                                                      hot_param, e->d_m_flags);
+        if (run_tt == (u32)TT_SMALL)
+            k_bkt_count_new<10, TT_SMALL><<<nb < 64u ? 64u : nb, AP_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, b_hits, runs, run_tt,
+                                                                                    ntiles, tile_shift, nb, e->d_m_flags);
+        else
+            k_bkt_count_new<10, TT_LARGE><<<nb < 64u ? 64u : nb, AP_BLOCK, 0, ps>>>(e->table, e->log2cap, e->seed, b_hits, runs, run_tt,
+                                                                                    ntiles, tile_shift, nb, e->d_m_flags);
         HIP_TRY(e, hipGetLastError());
         HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_m_flags, sizeof(u32), hipMemcpyDeviceToHost, ps));
         HIP_TRY(e, hipStreamSynchronize(ps));
@@ -529,36 +607,45 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                         n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
         }
     }
-    if (two_streams) {
-        if (!chain_p) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
-        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
-    }
+    if (two_streams && !chain_p) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
     // ---- apply --------------------------------------------------------------------------------------
-    if (!e->self_hot)
-        RL_LAUNCH_T(t, f.tev[8], f.tev[9], k_hot_state, 1, HOT_MAX, e->stream, ctable, e->log2cap, e->seed, climits, now, hot_use,
-                    hot_param, &bs->st);
-    // one workgroup per hash bucket (at least 64, so that the hot chunks of a small batch still spread); the
+    // the batch before this one first (its partition is usually complete by now: no wait command), then this one —
+    // now, or when the next batch is submitted / this one collected
+    rc = flush_pending_apply(e);
+    if (rc) return rc;
+    rl_engine::PendingApply& q = e->pend;
+    q.valid = true;
+    q.p = p;
+    q.slot = (u32)(e->sub_seq & 3u);
+    q.d_hits = d_hits;
+    q.n = n;
+    q.nb = nb;
+    q.ntiles = ntiles;
+    q.tile_shift = tile_shift;
+    q.run_tt = run_tt;
+    // one workgroup per hash bucket (at least 64, so that the hot work items of a small batch still spread); the
     // last one out writes the status block straight into f.h_st (host-mapped)
-    const u32 n_wg = nb < 64u ? 64u : nb;
-    launch_apply(e, n_wg, d_hits, nb, par, now, d_verdict, d_first, bs, bs_zero, f.h_st, (u32)(e->sub_seq + 1), hot_prod,
-                 t_apply || chain_a, t_apply ? f.tev[4] : nullptr, t_apply ? f.tev[5] : e->ev_applied[p & 3u],
-                 // The long-bucket rule (keys with a quarter of the threshold are promoted out of buckets of >= 1024 hits)
-                 // evens the buckets out — with 1024 buckets it fills all 512 hot buckets and is worth ~4 us per step
-                 // (gpurun_out/v8) — but on a cold start every bucket is long and the first set would be 512 keys in
-                 // arrival order, the Zipf head not necessarily among them (six slow batches instead of three): it only
-                 // applies once a collected batch has reported a populated set.
-                 e->hot_seen >= 64u ? e->hot_long_cfg : 0xFFFFFFFFu);
-    HIP_TRY(e, hipGetLastError());
-    if (two_streams && !chain_a) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
+    q.n_wg = nb < 64u ? 64u : nb;
+    q.now = now;
+    q.d_verdict = d_verdict;
+    q.d_first = d_first;
+    q.t_apply = t_apply;
+    // The long-bucket rule (keys with a quarter of the threshold are promoted out of buckets of >= 1024 hits)
+    // evens the buckets out — with 1024 buckets it fills all 512 hot buckets and is worth ~4 us per step — but on a
+    // cold start every bucket is long and the first set would be 512 keys in arrival order, the Zipf head not
+    // necessarily among them (six slow batches instead of three): it only applies once a collected batch has
+    // reported a populated set.
+    q.hot_long = e->hot_seen >= 64u ? e->hot_long_cfg : 0xFFFFFFFFu;
     e->part_seq++;
     f.n = n;
-    f.n_wg = n_wg;
+    f.n_wg = q.n_wg;
     f.ntiles = ntiles;
-    f.timed = t_apply ? (e->timing == 1 ? 1 : 2) : 0;
+    f.timed = (t ? 1 : 0) | (t_apply ? 2 : 0);
     f.seq = (u32)(e->sub_seq + 1);
     f.settled = false;
     e->inflight_hits += n;
     e->sub_seq++;
+    if (!two_streams || !e->defer_apply) return flush_pending_apply(e);
     return RL_OK;
 }
 
@@ -566,6 +653,10 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 int collect_k1_bucketed(rl_engine* e) {
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
     rl_engine::Inflight& f = e->inflight[e->col_seq & 3u];
+    if (e->pend.valid && e->pend.slot == (u32)(e->col_seq & 3u)) {  // nothing was submitted behind it: its k_bkt_apply goes out now
+        const int prc = flush_pending_apply(e);
+        if (prc) return prc;
+    }
     if (!f.settled) {
         const int wrc = wait_done(e, f);
         if (wrc) {
@@ -587,23 +678,20 @@ int collect_k1_bucketed(rl_engine* e) {
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
     if (f.timed) {
-        // tev: start / stop of k_bkt_hist [0,1], k_bkt_scan [2,3], k_bkt_scatter [6,7], k_hot_state [8,9] (if it ran),
-        // k_bkt_apply or k_bkt_tiny [4,5]
-        float ms[5] = {0, 0, 0, 0, 0};
-        HIP_TRY(e, hipEventSynchronize(f.tev[5]));
-        if (f.timed == 1) {
-            HIP_TRY(e, hipEventElapsedTime(&ms[0], f.tev[0], f.tev[1]));
-            HIP_TRY(e, hipEventElapsedTime(&ms[1], f.tev[2], f.tev[3]));
-            HIP_TRY(e, hipEventElapsedTime(&ms[2], f.tev[6], f.tev[7]));
-            if (!e->self_hot) HIP_TRY(e, hipEventElapsedTime(&ms[4], f.tev[8], f.tev[9]));
+        // start events: k_bkt_part tev[0], k_bkt_apply / k_bkt_tiny tev[4]; the stop events are the ones the streams
+        // hand to each other anyway ("partitioned" / "applied") or tev[1] / tev[5]
+        float ms[2] = {0, 0};
+        if ((f.timed & 1) && f.ev_p_stop) {
+            HIP_TRY(e, hipEventSynchronize(f.ev_p_stop));
+            HIP_TRY(e, hipEventElapsedTime(&ms[0], f.tev[0], f.ev_p_stop));
         }
-        HIP_TRY(e, hipEventElapsedTime(&ms[3], f.tev[4], f.tev[5]));
-        e->ms_slot[RL_T_HIST] += ms[0];
-        e->ms_slot[RL_T_SCAN] += ms[1];
-        e->ms_slot[RL_T_SCATTER] += ms[2];
-        e->ms_slot[RL_T_APPLY] += ms[3];
-        e->ms_slot[RL_T_HOT_STATE] += ms[4];
-        e->timed_launches++;
+        if ((f.timed & 2) && f.ev_a_stop) {
+            HIP_TRY(e, hipEventSynchronize(f.ev_a_stop));
+            HIP_TRY(e, hipEventElapsedTime(&ms[1], f.tev[4], f.ev_a_stop));
+        }
+        e->ms_slot[RL_T_PART] += ms[0];
+        e->ms_slot[RL_T_APPLY] += ms[1];
+        if (f.timed & 2) e->timed_launches++;
     }
     return RL_OK;
 }
@@ -656,7 +744,7 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     // pipelined rotation every call overflowed once: the retry's promotions were never the set of the next call.)
     const HotSet* hot_use = e->d_hot + (p + HS_SETS - 1) % HS_SETS;
     HotSet* hot_prod = e->d_hot + p % HS_SETS;
-    BHit* b_hits = e->d_bk_hits + (size_t)par * e->max_batch;
+    BHit* b_hits = e->d_bk_hits + (size_t)par * e->bk_stride;
     uint2* ranges = e->d_bk_ranges + (size_t)par * BK_MAX;
     HotParam* hot_param = e->d_hot_param + (size_t)par * (HOT_MAX + 1);
     unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
@@ -1047,7 +1135,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
     if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
-    if (const char* v = getenv("RL_SELF_HOT")) e->self_hot = atoi(v) != 0;
+    if (const char* v = getenv("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
     if (const char* v = getenv("RL_EXT_EVENTS")) e->ext_events = atoi(v) != 0;
     if (const char* v = getenv("RL_HOT_PROMOTE")) {
         const long b = strtol(v, nullptr, 10);
@@ -1061,7 +1149,6 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         if (b >= 1024) e->gen_sub_max = (u32)std::min<long>(b, GEN_SUB_MAX);
     }
     if (const char* v = getenv("RL_APPLY2_CFG")) e->apply2_cfg = atoi(v);
-    if (const char* v = getenv("RL_DEBUG_APPLY2")) e->dbg_apply2 = (u32)strtoul(v, nullptr, 0);
     if (const char* v = getenv("RL_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= (long)TINY_MAX) e->tiny_max = (u32)b;
@@ -1105,8 +1192,16 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     for (auto& ev : e->ev_applied)
         if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
     if (hipEventCreateWithFlags(&e->ev_match, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
-    // k_bkt_scatter's dynamic LDS goes up to 80 KB (beside 23 KB of static LDS)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_scatter<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    // the partition kernels' dynamic LDS goes up to 80 KB (beside their static LDS)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_part<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_part<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_part<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_scatter<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_scatter<PT_STEPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)scatter_lds_bytes(BKT_MAX)) != hipSuccess)
@@ -1161,11 +1256,16 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (hipMemset(e->d_hot, 0, HS_SETS * sizeof(HotSet)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_hot_param, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotParam));
     if (hipMemset(e->d_hot_param, 0, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotParam)) != hipSuccess) return bail(RL_ERR_DEVICE);
-    ALLOC(e->d_bk_hits, PB_SETS * mb * sizeof(BHit));
+    e->bk_stride = (mb + (PT_BLOCK * PT_STEPS_MAX - 1)) / (PT_BLOCK * PT_STEPS_MAX) * (PT_BLOCK * PT_STEPS_MAX);
+    ALLOC(e->d_bk_hits, PB_SETS * e->bk_stride * sizeof(BHit));
+    e->run_tt_max = cdiv(mb, PT_BLOCK * PT_STEPS_MAX) > (u32)TT_SMALL ? (u32)TT_LARGE : (u32)TT_SMALL;
+    ALLOC(e->d_runs, PB_SETS * (size_t)BKT_MAX * e->run_tt_max * sizeof(u32));
+    ALLOC(e->d_plan, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotPlan));
+    if (hipMemset(e->d_plan, 0, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotPlan)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_hot_arrive, (size_t)HOT_MAX * sizeof(u32));
     if (hipMemset(e->d_hot_arrive, 0, (size_t)HOT_MAX * sizeof(u32)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_tiny_hits, (size_t)TINY_MAX * sizeof(BHit));
-    e->chunk_tab_len = (size_t)mb / HOT_CHUNK + HOT_MAX + 8;
+    e->chunk_tab_len = std::max<size_t>((size_t)mb / HOT_CHUNK + HOT_MAX + 8, (size_t)HOT_MAX * HOT_NK_MAX);
     ALLOC(e->d_chunk_tab, PB_SETS * e->chunk_tab_len * sizeof(unsigned short));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
     ALLOC(e->d_m_ns, mb * sizeof(u32));
@@ -1223,7 +1323,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_plan,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)

@@ -342,10 +342,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
             u32 acc = 0;
 #pragma unroll
             for (int ww = 0; ww < GS_WAVES; ++ww) acc += wcnt[ww][e];
-            if (acc >= A.hot_threshold && A.hot_next && ekey[e] != TAG_EMPTY) {
-                const u32 pos = atomicAdd(&A.hot_next->n, 1u);
-                if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = ekey[e];
-            }
+            if (acc >= A.hot_threshold && A.hot_next && ekey[e] != TAG_EMPTY) hot_append(A.hot_next, ekey[e], acc, 1u);
         }
         if (tid == 0) atomicOr(&A.gst->overflow, 1u);
         return;
@@ -361,10 +358,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
         }
         eoff[e] = acc;
         etot[e] = (unsigned short)acc;
-        if (acc >= A.hot_threshold && A.hot_next) {
-            const u32 pos = atomicAdd(&A.hot_next->n, 1u);
-            if (pos < (u32)HOT_MAX) A.hot_next->key[pos] = ekey[e];
-        }
+        if (acc >= A.hot_threshold && A.hot_next) hot_append(A.hot_next, ekey[e], acc, 1u);
     }
     __syncthreads();
     {  // exclusive scan of eoff over the GS_E cells (8 per thread)

@@ -1,0 +1,363 @@
+// rl_part.hpp — the single-pass stable partition of the measured hot path, and the "bucket view" through which
+// k_bkt_apply reads it.
+//
+// Why it exists.  The replay of CounterStorage::check_and_update (reference limitador/src/storage/in_memory.rs:72-156,
+// one call per request, in trace order) needs every hit of one key in ONE workgroup and in trace order; nothing else.
+// The first design produced that with a GLOBAL stable partition — k_bkt_hist (read the batch), k_bkt_scan (a
+// latency-bound launch over the tiles x buckets matrix), k_bkt_scatter (read the batch again, write it in 16-64-byte
+// runs): three dependent launches, the batch read twice, 35 us alone and 59 us beside k_bkt_apply — the critical path
+// of the step.  A global order is more than the replay needs:
+//
+//   k_bkt_part   every 4096-hit tile of the batch is sorted by bucket INSIDE ITS OWN 64 KB of the record buffer
+//                (stable: wave-private LDS counters + ballot ranks, as before) and publishes, per bucket, where its
+//                run starts and how long it is: runs[bucket][tile].  No tile needs anything from another tile: no
+//                scan, no look-back, no second read — the batch is read once (16 B/hit) and written once (16 B/hit,
+//                every line complete inside one workgroup's window), and the kernel is one wave of independent
+//                workgroups.  It also validates the batch and writes the default verdict, as k_bkt_hist did.
+//   BucketView   the owner of bucket b reads row b of `runs` (one coalesced 1 KB read), scans it in LDS, and from
+//                then on maps "position p of my bucket, in trace order" to the record's address: tile t with
+//                pre[t] <= p < pre[t+1], record start[t] + (p - pre[t]) of that tile.  Tiles are in trace order and
+//                runs are stable, so positions ARE trace order.  The reads become 64-byte gathers instead of one
+//                contiguous range — the same number of memory requests (a 1 M-hit batch has ~4 hits per (tile, bucket)).
+//
+// Hot keys (rl_bucket.hpp) keep their buckets of their own: bins nb .. nb+HOT_MAX-1 of every tile.  What used to need
+// the scanned totals is now decided without them: the split of a hot bucket into work items comes from the count
+// the key had when it was PICKED (HotSet::cnt — any split covers the bucket: item k of nk walks the 1024-position
+// chunks k, k+nk, ...), and "every hit carries the same delta" is checked by every tile against the delta the set
+// PREDICTS (one flag bit per run), so a workgroup knows from the row it reads anyway whether positions decide the bucket.
+#pragma once
+#include "rl_bucket.hpp"
+
+namespace rl {
+
+constexpr int TT_SMALL = 256;    // tiles a bucket view holds: the usual instantiation (batches up to 256 tiles)
+constexpr int TT_LARGE = 1024;   // ... and the one for the largest batches (MAX_BATCH_HITS / 16384 tiles)
+constexpr u32 PT_STEPS_MAX = 16; // 64-hit steps per wave in the largest tile (16384 hits)
+constexpr u32 HOT_NK_MAX = 64;   // most work items one hot bucket is split into (beyond: the items stride)
+
+// runs[bin * TT + tile]: where the tile's hits of `bin` start inside the tile's window, how many there are, and (hot
+// bins) whether one of them carries another delta than the hot set predicts.
+constexpr u32 RUN_FLAG = 1u << 30;
+__host__ __device__ inline u32 run_pack(u32 start, u32 cnt, bool flag) { return start | (cnt << 15) | (flag ? RUN_FLAG : 0u); }
+__host__ __device__ inline u32 run_start(u32 v) { return v & 0x7FFFu; }
+__host__ __device__ inline u32 run_count(u32 v) { return (v >> 15) & 0x7FFFu; }
+
+// One hot bucket's share of k_bkt_apply's work items (written by k_bkt_part's extra workgroup, from the hot set alone).
+struct HotPlan {
+    u64 key;
+    u32 chunk0;  // work items of the hot buckets before this one (entry HOT_MAX: all of them)
+    u32 nk;      // work items of this bucket: >= 1 for a key of the set
+    u32 d;       // the delta the set predicts for the key's hits
+    u32 pad[3];
+};
+static_assert(sizeof(HotPlan) == 32, "two dwordx4 per hot bucket");
+
+// ---------------------------------------------------------------------------------------------
+// BucketView: position in the bucket (trace order) -> index of the record in the partitioned batch
+// ---------------------------------------------------------------------------------------------
+template <int TT>
+struct BucketView {
+    u32 pre[TT + 1];           // pre[t] = hits of the bucket in tiles < t; pre[TT] = all of them
+    unsigned short start[TT];  // the run's first record inside tile t's window
+    u32 w[4];                  // scan scratch (one per wave of a 256-thread workgroup)
+    u32 tile_shift;            // log2(hits per tile)
+    u32 base;                  // added to every index (a contiguous range: one "tile" at `base`)
+    u32 flags;                 // 1: some run of a hot bucket carries a delta the set did not predict
+};
+
+// A contiguous range [lo, lo + n) of the record buffer as a view (k_bkt_tiny; n < 2^32).  Thread 0 only writes; the
+// caller places the barrier.
+template <int TT>
+__device__ __forceinline__ void view_single(BucketView<TT>& V, u32 lo, u32 n) {
+    for (u32 t = threadIdx.x; t <= (u32)TT; t += blockDim.x) V.pre[t] = t ? n : 0u;
+    for (u32 t = threadIdx.x; t < (u32)TT; t += blockDim.x) V.start[t] = 0;
+    if (threadIdx.x == 0) {
+        V.tile_shift = 0;
+        V.base = lo;
+        V.flags = 0;
+    }
+}
+
+// Row `row` of the runs matrix -> view.  All 256 threads; ends past a barrier.  The caller must have a barrier
+// between the last use of the previous view and this call.
+template <int TT>
+__device__ __forceinline__ void view_build(BucketView<TT>& V, const u32* __restrict__ row, u32 ntiles, u32 tile_shift) {
+    constexpr int PER = TT / AP_BLOCK;
+    static_assert(PER == 1 || PER == 4, "one run or one dwordx4 of runs per thread");
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    u32 v[PER];
+    if (PER == 1) {
+        v[0] = tid < ntiles ? row[tid] : 0u;
+    } else {
+        const uint4 q = tid * 4 < ntiles ? *reinterpret_cast<const uint4*>(row + tid * 4) : make_uint4(0, 0, 0, 0);
+        v[0] = q.x;
+        v[PER > 1 ? 1 : 0] = q.y;
+        v[PER > 2 ? 2 : 0] = q.z;
+        v[PER > 3 ? 3 : 0] = q.w;
+    }
+    if (tid == 0) {
+        V.tile_shift = tile_shift;
+        V.base = 0;
+        V.flags = 0;
+    }
+    u32 c[PER], sum = 0;
+    bool mis = false;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 t = tid * PER + q;
+        c[q] = t < ntiles ? run_count(v[q]) : 0u;
+        sum += c[q];
+        mis = mis || (c[q] && (v[q] & RUN_FLAG));
+    }
+    u32 inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 o = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += o;
+    }
+    if (lane == 63) V.w[w] = inc;
+    __syncthreads();
+    u32 ex = inc - sum;
+#pragma unroll
+    for (u32 ww = 0; ww < (u32)(AP_BLOCK / 64); ++ww)
+        if (ww < w) ex += V.w[ww];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 t = tid * PER + q;
+        V.pre[t] = ex;
+        V.start[t] = (unsigned short)run_start(v[q]);
+        ex += c[q];
+    }
+    if (tid == AP_BLOCK - 1) V.pre[TT] = ex;
+    if (mis) atomicOr(&V.flags, 1u);
+    __syncthreads();
+}
+
+template <int TT>
+__device__ __forceinline__ u32 view_total(const BucketView<TT>& V) {
+    return V.pre[TT];
+}
+
+// Index (into the partitioned batch) of the bucket's p-th hit in trace order; p < view_total.
+template <int TT>
+__device__ __forceinline__ u32 view_src(const BucketView<TT>& V, u32 p) {
+    u32 t = 0;
+#pragma unroll
+    for (u32 s = TT / 2; s >= 1; s >>= 1)
+        if (V.pre[t + s] <= p) t += s;  // the largest t with pre[t] <= p: its run holds position p
+    return V.base + (t << V.tile_shift) + (u32)V.start[t] + (p - V.pre[t]);
+}
+
+// Hash bucket a workgroup of k_bkt_apply takes: workgroups go round-robin over the 8 XCDs, and neighbouring buckets'
+// runs are neighbours in every tile's window, so each XCD is given a CONTIGUOUS range of buckets — the 64-byte
+// segments two neighbouring runs share are then fetched into one L2, once.
+__device__ __forceinline__ u32 bucket_of_workgroup(u32 wg, u32 nb) {
+    if (nb < 8u) return wg;
+    return (wg & 7u) * (nb >> 3) + (wg >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bkt_part
+// ---------------------------------------------------------------------------------------------
+template <int STEPS>
+__global__ __launch_bounds__(PT_BLOCK) void k_bkt_part(const Cell* __restrict__ table, u32 log2cap, u64 seed,
+                                                       const Hit* __restrict__ hits, u32 n,
+                                                       const LimitDev* __restrict__ limits, u32 n_limits, u32 bk_log2,
+                                                       u32 ntiles, u32 run_tt, BatchScratch* bs,
+                                                       const HotSet* __restrict__ hot, u32 check_simple,
+                                                       uint8_t* __restrict__ verdict_fill, int32_t* __restrict__ first_fill,
+                                                       BHit* __restrict__ b_hits, u32* __restrict__ runs,
+                                                       HotPlan* __restrict__ plan, unsigned short* __restrict__ chunk_tab,
+                                                       u32 chunk_tab_len, HotSet* __restrict__ hot_next) {
+    // wave-private counters, [PT_WAVES][nbt] — dynamic, sized by the launch for the batch's bucket count
+    extern __shared__ __align__(16) unsigned short s_cnt[];
+    __shared__ u32 s_base[BKT_MAX];
+    __shared__ u32 s_w[PT_WAVES];
+    __shared__ u64 s_hot_key[HOT_HASH];
+    __shared__ u32 s_hot_idx[HOT_HASH];
+    __shared__ u32 s_hot_d[HOT_MAX];
+    __shared__ u32 s_mis[HOT_MAX];
+    const u32 tid = threadIdx.x;
+    if (blockIdx.x == ntiles) {
+        // ---- one extra workgroup: k_bkt_apply's hot work items, from the hot set alone (nothing here waits for a tile) ----
+        const u32 nh = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
+        u32 nk = 0, d = 1;
+        u64 key = TAG_EMPTY;
+        if (tid < nh) {
+            key = hot->key[tid];
+            d = hot->d[tid];
+            const u32 want = (hot->cnt[tid] + HOT_CHUNK - 1) / HOT_CHUNK;
+            nk = want < 1u ? 1u : (want > HOT_NK_MAX ? HOT_NK_MAX : want);
+        }
+        u32 all;
+        const u32 c0 = block_excl_scan_1024(nk, s_w, all);
+        u32* s_c0 = s_base;
+        if (tid < (u32)HOT_MAX) {
+            HotPlan p{};
+            p.key = key;
+            p.chunk0 = c0;
+            p.nk = nk;
+            p.d = d;
+            plan[tid] = p;
+            s_c0[tid] = c0;
+        }
+        if (tid == (u32)HOT_MAX) {
+            HotPlan p{};
+            p.key = TAG_EMPTY;
+            p.chunk0 = all;
+            plan[HOT_MAX] = p;
+            s_c0[HOT_MAX] = all;
+            hot_next->n = 0;  // k_bkt_apply appends the keys it promotes or keeps
+        }
+        __syncthreads();
+        // chunk_tab[c] = the bucket that owns item c: the LAST h with chunk0[h] <= c (a bucket without items shares its
+        // successor's chunk0, so it is never the last one)
+        const u32 n_items = all < chunk_tab_len ? all : chunk_tab_len;
+        for (u32 c = tid; c < n_items; c += PT_BLOCK) {
+            u32 a = 0, b = HOT_MAX;  // invariant: chunk0[a] <= c < chunk0[b]
+            while (b - a > 1) {
+                const u32 m = (a + b) >> 1;
+                if (s_c0[m] <= c) a = m;
+                else b = m;
+            }
+            chunk_tab[c] = (unsigned short)a;
+        }
+        return;
+    }
+    // Workgroups go round-robin over the 8 XCDs, each with its own L2; every XCD takes a CONTIGUOUS run of tiles, so
+    // the 4-byte entries neighbouring tiles write into one row of `runs` meet in one L2 and leave it as whole lines.
+    u32 tile;
+    {
+        const u32 x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = ntiles >> 3, rem = ntiles & 7u;
+        tile = x * per + (x < rem ? x : rem) + j;
+    }
+    Status* st = &bs->st;
+    const u32 lane = tid & 63u, w = tid >> 6;
+    const u32 nb = 1u << bk_log2;
+    const u32 nbt = nb + HOT_MAX;
+    constexpr u32 TILE = PT_BLOCK * STEPS;
+    const u32 tbase = tile * TILE;
+    const u32 wbase = tbase + w * (64 * STEPS);
+    uint4 raw[STEPS];
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        if (i < n) raw[u] = *reinterpret_cast<const uint4*>(hits + i);
+    }
+    // "admitted" is the default answer, written here as coalesced stores while the batch streams by; k_bkt_apply then
+    // scatters only the denials
+    if (verdict_fill) {
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            const u32 i = wbase + u * 64 + lane;
+            if (i < n) {
+                verdict_fill[i] = 0;
+                if (first_fill) first_fill[i] = -1;
+            }
+        }
+    }
+    {
+        const u32 hd = tid < (u32)HOT_MAX ? hot->d[tid] : 0u;
+        hot_table_build(hot, seed, s_hot_key, s_hot_idx);
+        if (tid < (u32)HOT_MAX) {
+            s_hot_d[tid] = hd;
+            s_mis[tid] = 0;
+        }
+    }
+    for (u32 b = tid; b < nbt; b += PT_BLOCK) {
+#pragma unroll
+        for (int ww = 0; ww < PT_WAVES; ++ww) s_cnt[ww * nbt + b] = 0;
+    }
+    __syncthreads();
+    // ---- every hit: validated, its bin, its rank among the wave's hits of that bin (trace order) ----------------
+    unsigned short rank[STEPS];
+    unsigned short dig[STEPS];
+    const u64 lt = (1ull << lane) - 1ull;
+    u32 err = 0;
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        const bool ok = i < n;
+        const u64 valid = __ballot(ok);
+        const u64 key = ((u64)raw[u].y << 32) | raw[u].x;
+        const u32 limit = raw[u].z, delta = raw[u].w;
+        u32 d = 0;
+        if (ok) {
+            // the only place the batch is validated (k_bkt_apply refuses to touch the table when `err` is set): limit
+            // id range, reserved keys, and (in_memory.rs:106-107) a simple counter must already have its cell
+            if ((limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
+            else if (key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
+            else if ((limit & SIMPLE_FLAG) && check_simple) {
+                u32 dummy = 0;
+                u32 slot = slot_of(key, seed, log2cap);
+                slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, key, limit, limits, 0ull,
+                                             st, dummy);
+                if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
+            }
+            const u64 hh = fmix64(key ^ seed);
+            const int hi = hot_lookup(s_hot_key, s_hot_idx, key, hh);
+            if (hi >= 0) {
+                d = nb + (u32)hi;
+                if (delta != s_hot_d[hi]) s_mis[hi] = 1;  // (plain store: every writer writes 1)
+            } else {
+                d = bucket_of_hash(hh, bk_log2);
+            }
+        }
+        const u64 m = match_digit(d, (bk_log2 > 9u ? bk_log2 : 9u) + 1u, valid);
+        u32 r = 0;
+        if (ok) {
+            const u32 c = s_cnt[w * nbt + d];
+            r = c + (u32)__popcll(m & lt);
+            if ((m & lt) == 0ull) s_cnt[w * nbt + d] = (unsigned short)(c + (u32)__popcll(m));
+        }
+        rank[u] = (unsigned short)r;
+        dig[u] = (unsigned short)d;
+    }
+    if (err) atomicOr(&st->err, err);
+    __syncthreads();
+    // ---- per bin: the waves' exclusive offsets, the tile's count; exclusive scan over the bins = the runs' starts ----
+    {
+        const u32 b0 = 3 * tid;  // (nbt <= 2560 < 3 * 1024)
+        u32 c[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const u32 b = b0 + q;
+            u32 acc = 0;
+            if (b < nbt) {
+#pragma unroll
+                for (int ww = 0; ww < PT_WAVES; ++ww) {
+                    const u32 x = s_cnt[ww * nbt + b];
+                    s_cnt[ww * nbt + b] = (unsigned short)acc;
+                    acc += x;
+                }
+            }
+            c[q] = acc;
+        }
+        u32 all;
+        u32 ex = block_excl_scan_1024(c[0] + c[1] + c[2], s_w, all);
+        u32* row = runs + tile;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const u32 b = b0 + q;
+            if (b < nbt) {
+                s_base[b] = ex;
+                row[(size_t)b * run_tt] = run_pack(ex, c[q], b >= nb && s_mis[b - nb] != 0u);
+            }
+            ex += c[q];
+        }
+    }
+    __syncthreads();
+    // ---- the records, into the tile's own window: bins in order, every bin in trace order -----------------------
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        if (i < n) {
+            const u32 d = dig[u];
+            const u32 dst = tbase + s_base[d] + s_cnt[w * nbt + d] + rank[u];
+            *reinterpret_cast<uint4*>(b_hits + dst) =
+                make_uint4(raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24));
+        }
+    }
+}
+
+}  // namespace rl

@@ -302,11 +302,11 @@ class Engine:
 
     # -- measurement -----------------------------------------------------------------------------
     def kernel_timing(self, mode=1):
-        """0 off, 1 events between all kernels of the hot path, 2 around k_bkt_apply only, 3 around
-        k_bkt_apply of every fourth batch (rl_engine.h)."""
+        """0 off, 1 both kernels of the hot path (k_bkt_part, k_bkt_apply) on every batch, 2 k_bkt_apply only,
+        3 both kernels of every fourth batch (rl_engine.h)."""
         self._check(self._lib.rl_kernel_timing(self._h, int(mode)))
 
-    TIMING_SLOTS = ("hist", "scan", "scatter", "apply", "hot_state", "reserved5", "reserved6",
+    TIMING_SLOTS = ("part", "reserved1", "reserved2", "apply", "reserved4", "reserved5", "reserved6",
                     "reserved7")  # RL_T_* of include/rl_engine.h
 
     def kernel_timing_read(self, reset=True):

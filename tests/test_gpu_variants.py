@@ -1,11 +1,12 @@
 """The build variants of the bucketed hot path, each bit-exact against the CPU oracle on a trace that takes every
 branch of the hot-key code (promotion, decided by position, replayed, created by the hot path, demoted):
 
-  default            pipeline depth 3, the hot chunks of k_bkt_apply read the hot keys' cells themselves (self_hot),
-                     19.5 KB of LDS per workgroup with 16-bit limit ids, verdicts prefilled by k_bkt_hist
-  RL_SELF_HOT=0      k_hot_state in front of k_bkt_apply
+  default            pipeline depth 3, k_bkt_apply enqueued one submit late (PendingApply), 16-bit limit ids in LDS,
+                     verdicts prefilled by k_bkt_part
+  RL_DEFER_APPLY=0   k_bkt_apply enqueued at submit, behind a wait for its partition
   RL_PIPE_DEPTH=2    the partition of batch p waits for k_bkt_apply of batch p - 2
   RL_APPLY2_CFG=1    32-bit limit ids in LDS (what an engine with more than 32768 limit rows takes by itself)
+  RL_OVERLAP=0       one stream
 
 and the output contract of the sparse verdict stores: every byte of verdict[] / every word of first_limited[] of a
 batch is defined when it is collected, whatever the buffers held before.  Needs a MI355X."""
@@ -19,8 +20,8 @@ from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [{}, {"RL_SELF_HOT": "0"}, {"RL_PIPE_DEPTH": "2"}, {"RL_APPLY2_CFG": "1"},
-            {"RL_SELF_HOT": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "1"}]
+VARIANTS = [{}, {"RL_DEFER_APPLY": "0"}, {"RL_PIPE_DEPTH": "2"}, {"RL_APPLY2_CFG": "1"}, {"RL_OVERLAP": "0"},
+            {"RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"}]
 
 
 def hot_trace(eng, orc, rng, n=60_000):
@@ -87,7 +88,7 @@ def test_more_than_32768_limit_rows_take_the_wide_kernel(make_engine):
 
 @pytest.mark.parametrize("n", [700, 30_000])
 def test_every_output_of_a_batch_is_defined_whatever_the_buffers_held(make_engine, n):
-    """k_bkt_hist writes "admitted" for every request and k_bkt_apply stores only the denials (k_bkt_tiny, the
+    """k_bkt_part writes "admitted" for every request and k_bkt_apply stores only the denials (k_bkt_tiny, the
     one-launch path of the 700-hit batch, stores every verdict): poisoned output buffers come back exact."""
     import ctypes as C
 
