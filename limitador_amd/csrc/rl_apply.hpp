@@ -573,6 +573,9 @@ __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32
     const uint4 pb = reinterpret_cast<const uint4*>(&A.plan[hb])[1];
     const u64 key = ((u64)pa.y << 32) | pa.x;
     const u32 k = c - pa.z, nk = pa.w, d_pred = pb.x;
+    // the bucket's row of runs is requested first: its latency runs under the cell's
+    constexpr int TTV = decltype(S.V)::tiles;
+    const ViewRow<TTV> vrow = view_load<TTV>(A.runs + (size_t)(A.nb + hb) * A.run_tt, A.ntiles);
     // ---- the key's cell as it is before this batch (every lane reads the same addresses) --------------------
     const u32 mask = (1u << A.log2cap) - 1u;
     u32 slot = slot_of(key, A.seed, A.log2cap);
@@ -595,7 +598,7 @@ __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32
         slot = (slot + 1) & mask;
     }
     __syncthreads();  // (the previous user of S.V and S.n_keep is done)
-    view_build(S.V, A.runs + (size_t)(A.nb + hb) * A.run_tt, A.ntiles, A.tile_shift);
+    view_scan(S.V, vrow, A.ntiles, A.tile_shift);
     const u32 total = view_total(S.V);
     const bool mis = S.V.flags != 0u;
     // the limit id is the CELL's attribute; a key without a cell takes it from its first hit in the caller's batch
@@ -777,6 +780,7 @@ struct ApplyParams {
     u32* hot_arrive;
     u32 sparse_out;
     u32 hot_long;
+    u64* trace;  // RL_APPLY_TRACE: [workgroup][8] wall-clock stamps (100 MHz) of the phases below, else null
 };
 
 template <int HPT, int ENT_LOG2, bool NARROW, int TT>
@@ -790,6 +794,11 @@ __device__ __forceinline__ void bkt_apply_body(const ApplyParams& P) {
     Apply2Args A{P.table, P.log2cap, P.seed, P.b_hits, P.hits, P.limits, P.now, P.verdict, P.first_limited, &P.bs->st,
                  P.hot_next, P.plan, P.chunk_tab, P.runs, P.run_tt, P.ntiles, P.tile_shift, P.nb, P.hot_threshold,
                  P.hot_long, P.sparse_out, P.hot_arrive};
+#define RL_ASTAMP(k)                                                                            \
+    do {                                                                                        \
+        if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();        \
+    } while (0)
+    RL_ASTAMP(0);
     // k_bkt_part refused the batch (a malformed hit): nothing is applied, the status block says why
     const bool refused = __hip_atomic_load(&P.bs->st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (!refused) {
@@ -798,25 +807,33 @@ __device__ __forceinline__ void bkt_apply_body(const ApplyParams& P) {
         const u32 bin = own ? bucket_of_workgroup(blockIdx.x, P.nb) : 0u;
         u32 n_items = P.plan[HOT_MAX].chunk0;
         if (n_items > P.chunk_tab_len) n_items = P.chunk_tab_len;
+        const ViewRow<TT> vrow = view_load<TT>(P.runs + (size_t)bin * P.run_tt, P.ntiles);
         apply2_clear(S);
         if (tid == 0) {
             S.n_created = 0;
             S.promote_ok = 1;
         }
         if (own) {
-            view_build(S.V, P.runs + (size_t)bin * P.run_tt, P.ntiles, P.tile_shift);  // (its barriers also cover the clear)
+            view_scan(S.V, vrow, P.ntiles, P.tile_shift);  // (its barriers also cover the clear)
+            RL_ASTAMP(1);
             const u32 total = view_total(S.V);
             if (total) apply2_bucket(S, A, 0, total);
+            if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + 6] = total;
         } else {
             __syncthreads();
         }
+        RL_ASTAMP(2);
         // ---- the hot buckets' work items -------------------------------------------------------------------
         for (u32 c = G - 1 - blockIdx.x; c < n_items; c += G) apply2_hot_item(S, A, c);
+        RL_ASTAMP(3);
     }
     // every wave's stores have been acknowledged before the workgroup's ticket is taken
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    RL_ASTAMP(4);
     if (tid == 0) apply_finish(refused ? 0u : S.n_created, P.bs, P.bs_zero, P.host_status, P.done_seq, G, &P.hot_next->n, 0u);
+    RL_ASTAMP(5);
+#undef RL_ASTAMP
 }
 
 // The register budget is pinned (waves_per_eu), not left to the occupancy the compiler derives from the LDS size: at 64

@@ -152,6 +152,9 @@ struct rl_engine {
     u32 run_tt_max = TT_SMALL;      // TT_SMALL, or TT_LARGE for engines whose largest batch has more than TT_SMALL tiles
     HotPlan* d_plan = nullptr;      // [PB_SETS][HOT_MAX + 1]
     size_t bk_stride = 0;           // records per set of d_bk_hits: max_batch rounded up to the largest tile
+    int apply_trace = 0;            // RL_APPLY_TRACE=1: phase stamps of k_bkt_apply, one stderr line per collected batch (diagnostics)
+    unsigned long long* d_apply_trace = nullptr;
+    u32 part_steps_cfg = 0;         // RL_PART_STEPS (4, 8, 16): at least this many 64-hit steps per wave of k_bkt_part (experiments)
     bool defer_apply = true;        // RL_DEFER_APPLY=0: enqueue k_bkt_apply at submit (see PendingApply)
     // k_bkt_apply of the batch submitted last, not yet enqueued.  Its partition was enqueued at submit; the apply waits
     // for the NEXT submit (or its own collect), by when the host usually sees the partition's event complete and the
@@ -452,6 +455,11 @@ int flush_pending_apply(rl_engine* e) {
     P.hot_arrive = e->d_hot_arrive;
     P.sparse_out = 1u;
     P.hot_long = q.hot_long;
+    if (e->apply_trace) {
+        if (!e->d_apply_trace) HIP_TRY(e, hipMalloc((void**)&e->d_apply_trace, (size_t)BK_MAX * 8 * sizeof(unsigned long long)));
+        HIP_TRY(e, hipMemsetAsync(e->d_apply_trace, 0, (size_t)BK_MAX * 8 * sizeof(unsigned long long), e->stream));
+        P.trace = e->d_apply_trace;
+    }
     // "applied" for the partition stream: the stop event of the launch itself where possible (no marker command); a
     // timed launch only adds a start event
     const bool chain_a = two_streams && e->ext_events;
@@ -540,6 +548,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     u32 steps = 1;
     if (!(cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES))
         for (steps = PT_STEPS; steps < PT_STEPS_MAX && cdiv(n, PT_BLOCK * steps) > (u32)TT_SMALL; steps *= 2) {}
+    if (e->part_steps_cfg > steps && n > (u32)PT_BLOCK * e->part_steps_cfg) steps = e->part_steps_cfg;  // (experiments)
     const u32 tile_shift = 10u + (steps == 1 ? 0u : steps == 4 ? 2u : steps == 8 ? 3u : 4u);
     const u32 ntiles = cdiv(n, 1u << tile_shift);
     const u32 run_tt = ntiles <= (u32)TT_SMALL ? (u32)TT_SMALL : (u32)TT_LARGE;
@@ -670,6 +679,35 @@ int collect_k1_bucketed(rl_engine* e) {
         e->live += f.h_st->n_inserted;
     }
     e->col_seq++;
+    if (e->apply_trace && f.n_wg > 1 && e->d_apply_trace) {
+        // diagnostics: where the workgroups of k_bkt_apply spent their time (wall clock, 100 MHz)
+        std::vector<unsigned long long> t((size_t)f.n_wg * 8);
+        HIP_TRY(e, hipMemcpy(t.data(), e->d_apply_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t_min = ~0ull, t_max = 0, first_end = ~0ull;
+        double ph[5] = {0, 0, 0, 0, 0}, hits = 0, longest = 0;
+        u32 live = 0;
+        for (u32 b = 0; b < f.n_wg; ++b) {
+            const unsigned long long* q = &t[(size_t)b * 8];
+            if (!q[5]) continue;
+            ++live;
+            t_min = std::min(t_min, q[0]);
+            t_max = std::max(t_max, q[5]);
+            first_end = std::min(first_end, q[5]);
+            const unsigned long long q1 = q[1] ? q[1] : q[0];
+            ph[0] += (double)(q1 - q[0]) / 100.0;
+            ph[1] += (double)(q[2] - q1) / 100.0;
+            ph[2] += (double)(q[3] - q[2]) / 100.0;
+            ph[3] += (double)(q[4] - q[3]) / 100.0;
+            ph[4] += (double)(q[5] - q[4]) / 100.0;
+            hits += (double)q[6];
+            longest = std::max(longest, (double)(q[5] - q[0]) / 100.0);
+        }
+        if (live)
+            std::fprintf(stderr, "[apply] %u workgroups, span %.1f us (first one out after %.1f); mean per workgroup: view %.2f, bucket %.2f "
+                         "(%.0f hits), hot items %.2f, drain %.2f, finish %.2f us; longest workgroup %.1f us\n", live,
+                         (double)(t_max - t_min) / 100.0, (double)(first_end - t_min) / 100.0, ph[0] / live, ph[1] / live, hits / live,
+                         ph[2] / live, ph[3] / live, ph[4] / live, longest);
+    }
     // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
     if (f.n_wg > 1) e->hot_seen = f.h_st->pad[2];  // (a partitioned batch: k_bkt_tiny leaves the hot sets alone)
     if (f.h_st->pad[2] > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
@@ -1136,6 +1174,11 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
     if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
     if (const char* v = getenv("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
+    if (const char* v = getenv("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
+    if (const char* v = getenv("RL_PART_STEPS")) {
+        const int b = atoi(v);
+        if (b == 4 || b == 8 || b == 16) e->part_steps_cfg = (u32)b;
+    }
     if (const char* v = getenv("RL_EXT_EVENTS")) e->ext_events = atoi(v) != 0;
     if (const char* v = getenv("RL_HOT_PROMOTE")) {
         const long b = strtol(v, nullptr, 10);
@@ -1323,7 +1366,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_plan,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_plan,   e->d_apply_trace,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)

@@ -57,6 +57,7 @@ static_assert(sizeof(HotPlan) == 32, "two dwordx4 per hot bucket");
 // ---------------------------------------------------------------------------------------------
 template <int TT>
 struct BucketView {
+    static constexpr int tiles = TT;
     u32 pre[TT + 1];           // pre[t] = hits of the bucket in tiles < t; pre[TT] = all of them
     unsigned short start[TT];  // the run's first record inside tile t's window
     u32 w[4];                  // scan scratch (one per wave of a 256-thread workgroup)
@@ -78,23 +79,34 @@ __device__ __forceinline__ void view_single(BucketView<TT>& V, u32 lo, u32 n) {
     }
 }
 
-// Row `row` of the runs matrix -> view.  All 256 threads; ends past a barrier.  The caller must have a barrier
-// between the last use of the previous view and this call.
+// Row `row` of the runs matrix -> view, in two steps so that the row's latency can run under something else:
+// view_load requests the thread's share of the row, view_scan (all 256 threads; ends past a barrier) builds the view.
+// The caller must have a barrier between the last use of the previous view and view_scan.
 template <int TT>
-__device__ __forceinline__ void view_build(BucketView<TT>& V, const u32* __restrict__ row, u32 ntiles, u32 tile_shift) {
+struct ViewRow {
+    u32 v[TT / AP_BLOCK];
+};
+template <int TT>
+__device__ __forceinline__ ViewRow<TT> view_load(const u32* __restrict__ row, u32 ntiles) {
     constexpr int PER = TT / AP_BLOCK;
     static_assert(PER == 1 || PER == 4, "one run or one dwordx4 of runs per thread");
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    u32 v[PER];
+    const u32 tid = threadIdx.x;
+    ViewRow<TT> r;
     if (PER == 1) {
-        v[0] = tid < ntiles ? row[tid] : 0u;
+        r.v[0] = row[tid < ntiles ? tid : 0u];  // (unconditional: a load inside a branch is waited for where the branch ends)
     } else {
-        const uint4 q = tid * 4 < ntiles ? *reinterpret_cast<const uint4*>(row + tid * 4) : make_uint4(0, 0, 0, 0);
-        v[0] = q.x;
-        v[PER > 1 ? 1 : 0] = q.y;
-        v[PER > 2 ? 2 : 0] = q.z;
-        v[PER > 3 ? 3 : 0] = q.w;
+        const uint4 q = *reinterpret_cast<const uint4*>(row + (tid * 4 < ntiles ? tid * 4 : 0u));
+        r.v[0] = q.x;
+        r.v[PER > 1 ? 1 : 0] = q.y;
+        r.v[PER > 2 ? 2 : 0] = q.z;
+        r.v[PER > 3 ? 3 : 0] = q.w;
     }
+    return r;
+}
+template <int TT>
+__device__ __forceinline__ void view_scan(BucketView<TT>& V, const ViewRow<TT>& r, u32 ntiles, u32 tile_shift) {
+    constexpr int PER = TT / AP_BLOCK;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     if (tid == 0) {
         V.tile_shift = tile_shift;
         V.base = 0;
@@ -105,9 +117,9 @@ __device__ __forceinline__ void view_build(BucketView<TT>& V, const u32* __restr
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const u32 t = tid * PER + q;
-        c[q] = t < ntiles ? run_count(v[q]) : 0u;
+        c[q] = t < ntiles ? run_count(r.v[q]) : 0u;
         sum += c[q];
-        mis = mis || (c[q] && (v[q] & RUN_FLAG));
+        mis = mis || (c[q] && (r.v[q] & RUN_FLAG));
     }
     u32 inc = sum;
 #pragma unroll
@@ -125,12 +137,17 @@ __device__ __forceinline__ void view_build(BucketView<TT>& V, const u32* __restr
     for (int q = 0; q < PER; ++q) {
         const u32 t = tid * PER + q;
         V.pre[t] = ex;
-        V.start[t] = (unsigned short)run_start(v[q]);
+        V.start[t] = (unsigned short)run_start(r.v[q]);
         ex += c[q];
     }
     if (tid == AP_BLOCK - 1) V.pre[TT] = ex;
     if (mis) atomicOr(&V.flags, 1u);
     __syncthreads();
+}
+template <int TT>
+__device__ __forceinline__ void view_build(BucketView<TT>& V, const u32* __restrict__ row, u32 ntiles, u32 tile_shift) {
+    const ViewRow<TT> r = view_load<TT>(row, ntiles);
+    view_scan(V, r, ntiles, tile_shift);
 }
 
 template <int TT>
