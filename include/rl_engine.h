@@ -364,8 +364,8 @@ int32_t rl_engine_record_event(rl_engine *e, void *event);
  * of timed batches into *launches. */
 enum {
     RL_T_PART = 0,           /* k_bkt_part: batch validation + single-pass stable partition (tile-local runs) */
-    RL_T_RESERVED1 = 1,
-    RL_T_RESERVED2 = 2,
+    RL_T_APPLY_GAP = 1,      /* idle time of the apply stream between two k_bkt_apply (timed launches, two streams) */
+    RL_T_PART_SLACK = 2,     /* k_bkt_part's end to the start of the k_bkt_apply that consumes it */
     RL_T_APPLY = 3,          /* k_bkt_apply: probe, decide, commit — the dominant kernel */
     RL_T_RESERVED4 = 4,
     RL_TIMING_SLOTS = 8

@@ -88,8 +88,7 @@ struct Apply2Args {
     int32_t* first_limited;
     Status* st;
     HotSet* hot_next;
-    const HotPlan* plan;              // the hot buckets' work items (k_bkt_part)
-    const unsigned short* chunk_tab;  // hot work item -> index of its hot bucket
+    const HotItems* items;            // the hot buckets' work items (k_bkt_part)
     const u32* runs;                  // [bin][run_tt] the tiles' runs (k_bkt_part)
     u32 run_tt, ntiles, tile_shift, nb;
     u32 hot_threshold;
@@ -137,7 +136,7 @@ __device__ __forceinline__ void apply2_commit(LDS& S, const Apply2Args& A, bool 
              ((f >> EF_COUNT_SHIFT) >= A.hot_threshold / 4 && S.bucket_len >= A.hot_long))) {
             // (predicted delta 1: a key whose hits carry another one is replayed in its first hot batch, and the last
             // work item of that bucket then hands the delta it saw to the next set)
-            hot_append(A.hot_next, key, f >> EF_COUNT_SHIFT, 1u);
+            hot_append(A.hot_next, key, f >> EF_COUNT_SHIFT, 1u, unpack_limit<NARROW>(S.limit[e]));
         }
         if (f & EF_DIRTY) {
             Cell* c = &A.table[S.slot[e]];
@@ -555,27 +554,32 @@ __device__ __forceinline__ void apply2_bucket(LDS& S, const Apply2Args& A, u32 l
 // Hot buckets (one key each; bins nb.. of the partition): stable partition + one key per bucket means a hit's position
 // in the bucket IS its trace-order rank on the key, so with one delta value d for the whole bucket the reference admits
 // exactly the first (max - value_at(now)) / d positions (in_memory.rs:85-102 applied hit by hit) and any number of
-// workgroups can decide their share of the positions in parallel.  Work item c (k of the bucket's nk, chunk_tab / plan
-// from k_bkt_part) takes the 1024-position chunks k, k + nk, ...: whatever the bucket's real length, the items cover it.
-// Every item's workgroup reads the key's cell itself — dependent loads that overlap the other workgroups' chains.  The cell
-// must not change before every item of the bucket has read it, so the workgroups count themselves in (hot_arrive) AFTER
-// their read has returned and the LAST one in applies AtomicExpiringValue::update for the bucket's admitted hits — or,
-// when the bucket cannot be decided from positions (a tile saw a delta the set did not predict, a 0-second window, a
-// value near 2^64, a missing simple cell: every item comes to that same conclusion from the same unchanged cell and
-// the same runs), replays the bucket with the general bucket code.  Nobody waits for anybody: no spinning, no ordering
-// between workgroups beyond the counter.  The last one in also keeps the key in the next hot set if it still earns it.
+// workgroups can decide their share of the positions in parallel.  Work item k of the bucket's nk (HotItem, from
+// k_bkt_part) takes the 1024-position chunks k, k + nk, ...: whatever the bucket's real length, the items cover it.
+// k_bkt_part wrote a DEFAULT answer for the bucket's hits — "limited" if the key's window was full when the set was
+// picked, else "admitted" — so only the positions whose answer differs are visited at all: for a key that stays
+// saturated (or stays far from its limit) an item reads the key's cell and its row of runs, and nothing else.
+// Every item's workgroup reads the key's cell itself.  The cell must not change before every item of the bucket has read
+// it, so the workgroups count themselves in (hot_arrive) once their waves' reads have returned and the LAST one in applies
+// AtomicExpiringValue::update for the bucket's admitted hits — or, when the bucket cannot be decided from positions (a
+// tile saw a hit the set did not predict — another delta, another limit id —, a 0-second window, a value near 2^64, a
+// missing simple cell: every item comes to that same conclusion from the same unchanged cell and the same runs), replays
+// the bucket with the general bucket code.  Nobody waits for anybody: no spinning, no ordering between workgroups beyond
+// the counter.  The last one in also keeps the key in the next hot set if it still earns it.
 template <class LDS>
 __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32 c) {
     constexpr int PER = HOT_CHUNK / AP_BLOCK;
-    const u32 tid = threadIdx.x;
-    const u32 hb = A.chunk_tab[c];
-    const uint4 pa = *reinterpret_cast<const uint4*>(&A.plan[hb]);
-    const uint4 pb = reinterpret_cast<const uint4*>(&A.plan[hb])[1];
-    const u64 key = ((u64)pa.y << 32) | pa.x;
-    const u32 k = c - pa.z, nk = pa.w, d_pred = pb.x;
-    // the bucket's row of runs is requested first: its latency runs under the cell's
     constexpr int TTV = decltype(S.V)::tiles;
+    const u32 tid = threadIdx.x;
+    const uint4 ia = *reinterpret_cast<const uint4*>(&A.items->it[c]);
+    const uint4 ib = reinterpret_cast<const uint4*>(&A.items->it[c])[1];
+    const u64 key = ((u64)ia.y << 32) | ia.x;
+    const u32 hb = ia.z & 0xFFFFu, k = ia.z >> 16, nk = ia.w, d_pred = ib.x, limit = ib.y;
+    const bool dv = (ib.z & HOT_FLG_DENY) != 0u;
+    const bool limit_known = limit != HOT_LIMIT_UNKNOWN;
+    // requested together: the bucket's row of runs, the limit's row, the key's cell
     const ViewRow<TTV> vrow = view_load<TTV>(A.runs + (size_t)(A.nb + hb) * A.run_tt, A.ntiles);
+    const LimitDev L = limit_row2(A, limit_known ? limit : 0u);
     // ---- the key's cell as it is before this batch (every lane reads the same addresses) --------------------
     const u32 mask = (1u << A.log2cap) - 1u;
     u32 slot = slot_of(key, A.seed, A.log2cap);
@@ -599,19 +603,23 @@ __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32
     }
     __syncthreads();  // (the previous user of S.V and S.n_keep is done)
     view_scan(S.V, vrow, A.ntiles, A.tile_shift);
+    // ---- count this workgroup in: every wave's read of the cell has returned (they are past the barriers above).
+    //      The answer is only needed at the end: it travels under the position loop.
+    u32 arrived = 0;
+    if (tid == 0) arrived = atomicAdd(&A.hot_arrive[hb], 1u);
     const u32 total = view_total(S.V);
     const bool mis = S.V.flags != 0u;
-    // the limit id is the CELL's attribute; a key without a cell takes it from its first hit in the caller's batch
-    u32 limit = cl;
-    if (!found && total) limit = A.hits[A.b_hits[view_src(S.V, 0)].idx_tag & 0xFFFFFFu].limit;
-    LimitDev L{0, 0};
-    if (total) L = limit_row2(A, limit);
     const bool expired = found && expiry <= A.now;
     const u64 s = (found && !expired) ? value : 0ull;  // value_at(now), atomic_expiring_value.rs:19-24
-    const bool fast = total && !mis && L.window_us != 0 && s < (1ull << 62) && (found || !(limit & SIMPLE_FLAG));
+    const bool fast = total && !mis && limit_known && (!found || cl == limit) && L.window_us != 0 && s < (1ull << 62) &&
+                      (found || !(limit & SIMPLE_FLAG));
     const u64 room = s > L.max_value ? 0ull : (d_pred ? (L.max_value - s) / d_pred : ~0ull);
+    const u32 n_adm = room < (u64)total ? (u32)room : total;  // the reference admits the first n_adm positions
     if (fast) {
-        for (u32 cb = k * HOT_CHUNK; cb < total; cb += nk * HOT_CHUNK) {
+        // positions whose answer is not the default one
+        const u32 dlo = dv ? 0u : n_adm, dhi = dv ? n_adm : total;
+        for (u32 cb = k * HOT_CHUNK; cb < dhi; cb += nk * HOT_CHUNK) {
+            if (cb + HOT_CHUNK <= dlo) continue;
             u32 h_tag[PER];
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
@@ -621,45 +629,46 @@ __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const u32 j = cb + u * AP_BLOCK + tid;
-                if (j >= total) continue;
+                if (j < dlo || j >= dhi) continue;
                 const u32 i = h_tag[u] & 0xFFFFFFu;
-                uint8_t v = (u64)j < room ? 0 : 1;
-                if ((h_tag[u] >> 24) != limit_fold(limit)) {  // one key, two limit ids: caller contract violation
-                    atomicOr(&A.st->err, ERRBIT_KEY_LIMIT);
-                    v = 1;
-                }
-                if (!v && A.sparse_out) continue;
-                A.verdict[i] = v;
-                if (A.first_limited) A.first_limited[i] = v ? (int32_t)i : -1;
+                A.verdict[i] = dv ? 0 : 1;
+                if (A.first_limited) A.first_limited[i] = dv ? -1 : (int32_t)i;
             }
         }
     }
-    // ---- count this workgroup in: every lane's read of the cell has returned --------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) S.n_keep = atomicAdd(&A.hot_arrive[hb], 1u);
+    if (tid == 0) S.n_keep = arrived;
     __syncthreads();
     const bool last = S.n_keep + 1u == nk;  // (block-uniform)
     __syncthreads();  // S.n_keep is free again
     if (!last) return;
     if (tid == 0) {
         atomicExch(&A.hot_arrive[hb], 0u);  // for the next kernel
-        // still hot?  (with the delta its hits carry now, if it was not the predicted one)
-        if (total >= A.hot_threshold) hot_append(A.hot_next, key, total, mis ? A.b_hits[view_src(S.V, 0)].delta : d_pred);
+        // still hot?  Then with what this batch showed: the delta and the limit id its hits carry, and whether its
+        // window is full now (the next default answer).
+        if (total >= A.hot_threshold) {
+            u32 d_next = d_pred, l_next = found ? cl : limit;
+            if (mis || !limit_known) {
+                const BHit h0 = load_bhit(A.b_hits, view_src(S.V, 0));
+                d_next = h0.delta;
+                if (!found) l_next = A.hits[h0.idx_tag & 0xFFFFFFu].limit;
+            }
+            hot_append(A.hot_next, key, total, d_next, l_next, (fast && room <= (u64)total) ? HOT_FLG_DENY : 0u);
+        }
     }
     if (!total) return;
     if (!fast) {
-        // the reference's arithmetic hit by hit, by this workgroup
+        // the reference's arithmetic hit by hit, by this workgroup; every answer is stored if the default was "limited"
+        Apply2Args B = A;
+        if (dv) B.sparse_out = 0;
         apply2_clear(S);
         if (tid == 0) S.promote_ok = 0;  // kept or dropped by count (above), not promoted
         __syncthreads();
-        apply2_bucket(S, A, 0, total);
+        apply2_bucket(S, B, 0, total);
         __syncthreads();
         return;
     }
     if (tid == 0) {
         // AtomicExpiringValue::update for the admitted hits
-        const u64 n_adm = (u64)total < room ? (u64)total : room;
         u32 wslot = found ? slot : SLOT_INVALID;
         bool reset = expired;
         if (!found) {  // first touch creates the cell (in_memory.rs:122-127), verdict or not
@@ -672,7 +681,7 @@ __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32
         }
         if (n_adm && wslot != SLOT_INVALID) {
             Cell* cell = &A.table[wslot];
-            cell->value = s + n_adm * d_pred;
+            cell->value = s + (u64)n_adm * d_pred;
             if (reset) cell->expiry = A.now + L.window_us;
         }
     }
@@ -764,9 +773,7 @@ struct ApplyParams {
     const Hit* hits;
     const u32* runs;
     u32 run_tt, ntiles, tile_shift, nb;
-    const HotPlan* plan;
-    const unsigned short* chunk_tab;
-    u32 chunk_tab_len;
+    const HotItems* items;
     const LimitDev* limits;
     u64 now;
     uint8_t* verdict;
@@ -783,16 +790,17 @@ struct ApplyParams {
     u64* trace;  // RL_APPLY_TRACE: [workgroup][8] wall-clock stamps (100 MHz) of the phases below, else null
 };
 
+// G: workgroups of the launch that replay (the first G of the grid).
 template <int HPT, int ENT_LOG2, bool NARROW, int TT>
-__device__ __forceinline__ void bkt_apply_body(const ApplyParams& P) {
+__device__ __forceinline__ void bkt_apply_body(const ApplyParams& P, const u32 G) {
     // The workgroup's LDS is DYNAMIC (the launch passes sizeof(Apply2Lds)): the compiler derives the register budget
     // from the occupancy the static LDS allows, and with 21 KB of it (seven workgroups per CU) it hands the kernel 88
     // VGPRs whatever waves_per_eu asks for.  The budget that matters here is 64 (see RL_DEF_APPLY).
     extern __shared__ __align__(16) unsigned char s_dyn[];
     Apply2Lds<HPT, ENT_LOG2, NARROW, TT>& S = *reinterpret_cast<Apply2Lds<HPT, ENT_LOG2, NARROW, TT>*>(s_dyn);
-    const u32 tid = threadIdx.x, G = gridDim.x;
+    const u32 tid = threadIdx.x;
     Apply2Args A{P.table, P.log2cap, P.seed, P.b_hits, P.hits, P.limits, P.now, P.verdict, P.first_limited, &P.bs->st,
-                 P.hot_next, P.plan, P.chunk_tab, P.runs, P.run_tt, P.ntiles, P.tile_shift, P.nb, P.hot_threshold,
+                 P.hot_next, P.items, P.runs, P.run_tt, P.ntiles, P.tile_shift, P.nb, P.hot_threshold,
                  P.hot_long, P.sparse_out, P.hot_arrive};
 #define RL_ASTAMP(k)                                                                            \
     do {                                                                                        \
@@ -802,29 +810,37 @@ __device__ __forceinline__ void bkt_apply_body(const ApplyParams& P) {
     // k_bkt_part refused the batch (a malformed hit): nothing is applied, the status block says why
     const bool refused = __hip_atomic_load(&P.bs->st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (!refused) {
-        // the row of the workgroup's own bucket is requested first; the LDS cells are cleared under its latency
+        // Workgroups [0, nb) take one hash bucket each; the rest walk the hot buckets' work items.  (Appended to the
+        // bucket workgroups, an item was 7 us on top of the longest buckets: the kernel's span is its slowest workgroup.)
         const bool own = blockIdx.x < P.nb;
-        const u32 bin = own ? bucket_of_workgroup(blockIdx.x, P.nb) : 0u;
-        u32 n_items = P.plan[HOT_MAX].chunk0;
-        if (n_items > P.chunk_tab_len) n_items = P.chunk_tab_len;
-        const ViewRow<TT> vrow = view_load<TT>(P.runs + (size_t)bin * P.run_tt, P.ntiles);
-        apply2_clear(S);
-        if (tid == 0) {
-            S.n_created = 0;
-            S.promote_ok = 1;
-        }
         if (own) {
+            // the row of the workgroup's own bucket is requested first; the LDS cells are cleared under its latency
+            const u32 bin = bucket_of_workgroup(blockIdx.x, P.nb);
+            const ViewRow<TT> vrow = view_load<TT>(P.runs + (size_t)bin * P.run_tt, P.ntiles);
+            apply2_clear(S);
+            if (tid == 0) {
+                S.n_created = 0;
+                S.promote_ok = 1;
+            }
             view_scan(S.V, vrow, P.ntiles, P.tile_shift);  // (its barriers also cover the clear)
             RL_ASTAMP(1);
             const u32 total = view_total(S.V);
             if (total) apply2_bucket(S, A, 0, total);
             if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + 6] = total;
+            RL_ASTAMP(2);
         } else {
-            __syncthreads();
+            u32 n_items = P.items->n;
+            if (n_items > (u32)(HOT_MAX * HOT_NK_MAX)) n_items = HOT_MAX * HOT_NK_MAX;
+            if (tid == 0) {
+                S.n_created = 0;
+                S.promote_ok = 0;
+            }
+            RL_ASTAMP(1);
+            RL_ASTAMP(2);
+            u32 done = 0;
+            for (u32 c = blockIdx.x - P.nb; c < n_items; c += G - P.nb, ++done) apply2_hot_item(S, A, c);
+            if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + 7] = done;
         }
-        RL_ASTAMP(2);
-        // ---- the hot buckets' work items -------------------------------------------------------------------
-        for (u32 c = G - 1 - blockIdx.x; c < n_items; c += G) apply2_hot_item(S, A, c);
         RL_ASTAMP(3);
     }
     // every wave's stores have been acknowledged before the workgroup's ticket is taken
@@ -836,20 +852,46 @@ __device__ __forceinline__ void bkt_apply_body(const ApplyParams& P) {
 #undef RL_ASTAMP
 }
 
-// The register budget is pinned (waves_per_eu), not left to the occupancy the compiler derives from the LDS size: at 64
-// VGPRs four of these workgroups per CU leave half of the register file to the 16-wave workgroups of k_bkt_part.
-#define RL_DEF_APPLY(NAME, HPT, ENT_LOG2, MAX_VGPR, NARROW, TT)                                                            \
+// ---------------------------------------------------------------------------------------------
+// k_bkt_step: ONE launch per step of the pipeline — the replay of batch j (workgroups [0, n_apply_wgs): one per hash
+// bucket, then the ones that walk the hot work items) and, beside it, the partition of batch j + 1 (one workgroup per
+// tile + one for its hot work items: part_role / plan_role, rl_part.hpp).  The two halves share nothing but the device:
+// the partition writes the buffers the NEXT launch replays.  Either half may be absent (n_*_wgs = 0): the first batch
+// of a burst is only partitioned, the last one only replayed.
+// The register budget is pinned (waves_per_eu), not left to the occupancy the compiler derives from the LDS size: 64
+// VGPRs and ~21 KB of LDS per workgroup let every workgroup of a 1 M-hit step (1024 buckets + 256 + 246) be resident at once.
+// ---------------------------------------------------------------------------------------------
+struct StepParams {
+    ApplyParams A;
+    PartParams Q;
+    u32 n_apply_wgs;
+    u32 n_part_wgs;  // tiles + 1
+};
+#define RL_DEF_STEP(NAME, HPT, ENT_LOG2, MAX_VGPR, NARROW, TT)                                                             \
     typedef Apply2Lds<HPT, ENT_LOG2, NARROW, TT> NAME##_lds;                                                               \
     __global__ __launch_bounds__(AP_BLOCK) __attribute__((amdgpu_waves_per_eu(512 / MAX_VGPR, 512 / MAX_VGPR))) void NAME( \
-        const ApplyParams P) {                                                                                             \
-        bkt_apply_body<HPT, ENT_LOG2, NARROW, TT>(P);                                                                      \
+        const StepParams S) {                                                                                              \
+        if (blockIdx.x < S.n_apply_wgs) {                                                                                  \
+            bkt_apply_body<HPT, ENT_LOG2, NARROW, TT>(S.A, S.n_apply_wgs);                                                 \
+        } else {                                                                                                           \
+            extern __shared__ __align__(16) unsigned char s_dyn[];                                                         \
+            PartLds& L = *reinterpret_cast<PartLds*>(s_dyn);                                                               \
+            const u32 j = blockIdx.x - S.n_apply_wgs, ntiles = S.Q.ntiles;                                                 \
+            if (j >= ntiles) {                                                                                             \
+                plan_role(L, S.Q);                                                                                         \
+            } else {                                                                                                       \
+                /* every XCD takes a CONTIGUOUS run of tiles (n_apply_wgs is a multiple of 8: j & 7 is the XCD) */         \
+                const u32 x = j & 7u, per = ntiles >> 3, rem = ntiles & 7u;                                                \
+                part_role(L, S.Q, x * per + (x < rem ? x : rem) + (j >> 3), S.A.trace);                                               \
+            }                                                                                                              \
+        }                                                                                                                  \
     }
-RL_DEF_APPLY(k_bkt_apply, 1, 9, 64, true, TT_SMALL)         // the usual one: limit ids in 16 bits, views of up to 256 tiles
-RL_DEF_APPLY(k_bkt_apply_wide, 1, 9, 64, false, TT_SMALL)   // engines with more than 32768 limit rows
-RL_DEF_APPLY(k_bkt_apply_large, 1, 9, 96, false, TT_LARGE)  // batches of more than 256 tiles
-RL_DEF_APPLY(k_bkt_apply_v80, 1, 9, 80, true, TT_SMALL)     // (RL_APPLY2_CFG experiments)
-RL_DEF_APPLY(k_bkt_apply_v96, 1, 9, 96, true, TT_SMALL)
-#undef RL_DEF_APPLY
+RL_DEF_STEP(k_bkt_step, 1, 9, 64, true, TT_SMALL)         // the usual one: limit ids in 16 bits, views of up to 256 tiles
+RL_DEF_STEP(k_bkt_step_wide, 1, 9, 64, false, TT_SMALL)   // engines with more than 32768 limit rows
+RL_DEF_STEP(k_bkt_step_large, 1, 9, 96, false, TT_LARGE)  // batches of more than 256 tiles
+RL_DEF_STEP(k_bkt_step_v80, 1, 9, 80, true, TT_SMALL)     // (RL_APPLY2_CFG experiments)
+RL_DEF_STEP(k_bkt_step_v96, 1, 9, 96, true, TT_SMALL)
+#undef RL_DEF_STEP
 // ---------------------------------------------------------------------------------------------
 // k_bkt_tiny: a batch of at most TINY_MAX hits IS one bucket — it is in trace order already — so one
 // workgroup validates it (the checks of k_bkt_part), rewrites it as BHit records and replays it with
@@ -892,7 +934,7 @@ __global__ __launch_bounds__(AP_BLOCK) void k_bkt_tiny(
         if (tid == 0) atomicOr(&bs->st.err, s_err);
     } else if (n) {
         Apply2Args A{table, log2cap, seed, b_hits, hits, limits, now, verdict, first_limited, &bs->st,
-                     nullptr, nullptr, nullptr, nullptr, 0u, 1u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, nullptr};
+                     nullptr, nullptr, nullptr, 0u, 1u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, nullptr};
         apply2_bucket(S, A, 0, n);
     }
     // the verdicts may go straight to host-mapped memory (rl_check_and_update_batch): every wave's stores

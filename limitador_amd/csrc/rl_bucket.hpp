@@ -66,19 +66,33 @@ struct HotSet {
     u32 n;
     u32 pad;
     u64 key[HOT_MAX];
-    // What the key looked like in the batch that picked it — a PREDICTION for the batch that uses the set: `cnt` sizes
-    // the key's share of k_bkt_apply's hot work items (any split covers the bucket, rl_part.hpp), `d` is the delta its
-    // hits are expected to carry (a bucket whose hits all carry it is decided from positions alone).
+    // What the key looked like in the batch that picked it — PREDICTIONS for the batch that uses the set, each checked
+    // where it is used (rl_part.hpp): `cnt` sizes the key's share of k_bkt_apply's hot work items (any split covers the
+    // bucket); `d` is the delta and `limit` the limit id its hits are expected to carry (a bucket whose hits all do is
+    // decided from positions alone); `flg & 1`: the key's window was full when the batch ended, so "limited" is the
+    // default answer k_bkt_part writes for its hits and k_bkt_apply only stores the exceptions.
     u32 cnt[HOT_MAX];
     u32 d[HOT_MAX];
+    u32 limit[HOT_MAX];
+    u32 flg[HOT_MAX];
+    // the same predictions as ONE 16-byte record per key — key | d + (HOT_FLG_DENY << 31) | limit — for the partition
+    // role of k_bkt_step, which keeps only key fingerprints in LDS and checks a match with a single load
+    uint4 rec[HOT_MAX];
 };
+constexpr u32 HOT_LIMIT_UNKNOWN = 0xFFFFFFFFu;  // (never a valid limit id: ids are range-checked against the limit table)
+constexpr u32 HOT_FLG_DENY = 1u;
 // Append a key to the set a batch picks (any thread of any workgroup).
-__device__ __forceinline__ void hot_append(HotSet* hs, u64 key, u32 cnt, u32 d) {
+__device__ __forceinline__ void hot_append(HotSet* hs, u64 key, u32 cnt, u32 d, u32 limit = HOT_LIMIT_UNKNOWN, u32 flg = 0u) {
     const u32 pos = atomicAdd(&hs->n, 1u);
     if (pos < (u32)HOT_MAX) {
         hs->key[pos] = key;
         hs->cnt[pos] = cnt;
         hs->d[pos] = d;
+        hs->limit[pos] = limit;
+        hs->flg[pos] = flg;
+        // (a predicted delta that does not fit 31 bits is never matched: such a bucket is replayed anyway)
+        hs->rec[pos] = make_uint4((u32)key, (u32)(key >> 32), (d & 0x7FFFFFFFu) | ((flg & HOT_FLG_DENY) << 31),
+                                  d < 0x80000000u ? limit : HOT_LIMIT_UNKNOWN);
     }
 }
 // Per-batch scratch of the bucketed path.  Two of them alternate: the last workgroup of a batch's
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                 const u32 dmax = total[nbt_ + tid], dmin = ~total[nbt_ + HOT_MAX + tid];
                 hp.d = dmax;
                 hp.uni = dmin == dmax ? 1u : 0u;
-                if (cnt >= hot_threshold) hot_append(hot_next, hot->key[tid], cnt, dmax);
+                if (cnt >= hot_threshold) hot_append(hot_next, hot->key[tid], cnt, dmax, hp.limit);
             }
             // (the general resolver walks EVERY hot bucket in chunks: all_chunks)
             s_nchunk[tid] = (hp.uni || all_chunks) ? (cnt + HOT_CHUNK - 1) / HOT_CHUNK : 0u;

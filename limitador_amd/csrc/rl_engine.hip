@@ -106,6 +106,7 @@ struct rl_engine {
         u32 n = 0, n_wg = 0, ntiles = 0;
         int timed = 0;         // bit 0: k_bkt_part timed, bit 1: k_bkt_apply / k_bkt_tiny timed
         hipEvent_t ev_p_stop = nullptr, ev_a_stop = nullptr;  // the stop events of the timed launches (see submit_k1_bucketed)
+        hipEvent_t ev_a_prev = nullptr;  // "applied" of the partitioned batch before this one (idle time in front of a timed k_bkt_apply)
         u32 seq = 0;  // value the batch's last workgroup stores into h_st->n_removed
         bool settled = false;  // completion seen and its new cells already added to `live` (settle_inflight)
     } inflight[4];  // at most three in flight
@@ -150,11 +151,17 @@ struct rl_engine {
     // the single-pass partition (rl_part.hpp): per set, the tiles' runs and the hot buckets' work items
     u32* d_runs = nullptr;          // [PB_SETS][BKT_MAX * run_tt_max]
     u32 run_tt_max = TT_SMALL;      // TT_SMALL, or TT_LARGE for engines whose largest batch has more than TT_SMALL tiles
-    HotPlan* d_plan = nullptr;      // [PB_SETS][HOT_MAX + 1]
+    HotItems* d_items = nullptr;    // [PB_SETS]
+    u32 hot_wgs = 256;              // workgroups of k_bkt_apply that walk the hot work items (RL_HOT_WGS)
     size_t bk_stride = 0;           // records per set of d_bk_hits: max_batch rounded up to the largest tile
     int apply_trace = 0;            // RL_APPLY_TRACE=1: phase stamps of k_bkt_apply, one stderr line per collected batch (diagnostics)
     unsigned long long* d_apply_trace = nullptr;
     u32 part_steps_cfg = 0;         // RL_PART_STEPS (4, 8, 16): at least this many 64-hit steps per wave of k_bkt_part (experiments)
+    u64 n_wait_parted = 0, n_wait_applied = 0, n_part_batches = 0;  // wait commands that had to be enqueued (RL_APPLY_TRACE: printed at destroy)
+    bool last_k1_was_part = false;  // the batch submitted last went through k_bkt_part / k_bkt_apply (not k_bkt_tiny)
+    bool fuse = false;              // RL_FUSE=1: one stream, the partition of batch j + 1 as a role of the launch that replays batch j
+                                    // (k_bkt_step; parity-green, but the role's 4-wave workgroups walk a tile in 2 x 16 dependent steps:
+                                    // 57 us alone against 24 us for k_bkt_part's 16 waves — measured slower, kept for the record)
     bool defer_apply = true;        // RL_DEFER_APPLY=0: enqueue k_bkt_apply at submit (see PendingApply)
     // k_bkt_apply of the batch submitted last, not yet enqueued.  Its partition was enqueued at submit; the apply waits
     // for the NEXT submit (or its own collect), by when the host usually sees the partition's event complete and the
@@ -396,77 +403,108 @@ inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof
 #define RL_LAUNCH_T(timed, ev0, ev1, kern, grid, block, stream, ...) \
     RL_LAUNCH_TS(timed, ev0, ev1, kern, grid, block, 0, stream, __VA_ARGS__)
 
-// k_bkt_apply in the instantiation RL_APPLY2_CFG selects (see RL_DEF_APPLY).
-void launch_apply(rl_engine* e, const ApplyParams& P, u32 n_wg, bool timed, hipEvent_t ev0, hipEvent_t ev1) {
-#define RL_AP2(KERN) RL_LAUNCH_TS(timed, ev0, ev1, KERN, n_wg, AP_BLOCK, sizeof(KERN##_lds), e->stream, P)
-    if (P.run_tt == (u32)TT_LARGE) {  // the largest batches (more than TT_SMALL tiles): a bucket view of 1024 tiles
-        RL_AP2(k_bkt_apply_large);
+// k_bkt_step in the instantiation RL_APPLY2_CFG selects (see RL_DEF_STEP).
+void launch_step(rl_engine* e, const StepParams& S, bool timed, hipEvent_t ev0, hipEvent_t ev1) {
+    const u32 n_wg = S.n_apply_wgs + S.n_part_wgs;
+#define RL_ST(KERN)                                                                                                  \
+    RL_LAUNCH_TS(timed, ev0, ev1, KERN, n_wg, AP_BLOCK, std::max(sizeof(KERN##_lds), sizeof(PartLds)), e->stream, S)
+    if (S.A.run_tt == (u32)TT_LARGE) {  // the largest batches (more than TT_SMALL tiles): a bucket view of 1024 tiles
+        RL_ST(k_bkt_step_large);
         return;
     }
     // 0 (default): 21 KB of LDS, seven workgroups per CU — limit ids in 16 bits, so engines with more than 32768 limit
     // rows take 1: the same kernel with 32-bit limit ids (22 KB).  2 / 3: larger register budgets (experiments).
     switch (e->apply2_cfg == 0 && e->max_limits > 32768u ? 1 : e->apply2_cfg) {
         default:
-        case 0: RL_AP2(k_bkt_apply); break;
-        case 1: RL_AP2(k_bkt_apply_wide); break;
-        case 2: RL_AP2(k_bkt_apply_v80); break;
-        case 3: RL_AP2(k_bkt_apply_v96); break;
+        case 0: RL_ST(k_bkt_step); break;
+        case 1: RL_ST(k_bkt_step_wide); break;
+        case 2: RL_ST(k_bkt_step_v80); break;
+        case 3: RL_ST(k_bkt_step_v96); break;
     }
-#undef RL_AP2
+#undef RL_ST
 }
 
-// Enqueue the k_bkt_apply that submit_k1_bucketed left pending (see rl_engine::PendingApply).
-int flush_pending_apply(rl_engine* e) {
+// The partition half of a k_bkt_step launch (submit_k1_bucketed).
+struct PartLaunch {
+    PartParams Q;
+    u32 slot;    // inflight slot of the batch being partitioned
+    bool timed;  // events around a launch that only partitions
+};
+
+// One k_bkt_step launch: the replay that submit_k1_bucketed left pending (rl_engine::PendingApply), if any, and —
+// `part`, engines in the fused mode — the partition of the batch being submitted.
+int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
     rl_engine::PendingApply& q = e->pend;
-    if (!q.valid) return RL_OK;
-    q.valid = false;
-    rl_engine::Inflight& f = e->inflight[q.slot];
-    const u64 p = q.p;
-    const u32 par = (u32)(p % PB_SETS);
+    if (!q.valid && !part) return RL_OK;
+    StepParams S{};
+    bool timed = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool two_streams = e->pstream != e->stream;
-    if (two_streams && hipEventQuery(e->ev_parted[p & 3u]) != hipSuccess) {
-        (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
-        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
+    rl_engine::Inflight* fa = nullptr;
+    u64 p = 0;
+    if (q.valid) {
+        q.valid = false;
+        rl_engine::Inflight& f = e->inflight[q.slot];
+        fa = &f;
+        p = q.p;
+        const u32 par = (u32)(p % PB_SETS);
+        if (two_streams && hipEventQuery(e->ev_parted[p & 3u]) != hipSuccess) {
+            (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
+            e->n_wait_parted++;
+        }
+        ApplyParams& P = S.A;
+        P.table = e->table;
+        P.log2cap = e->log2cap;
+        P.seed = e->seed;
+        P.b_hits = e->d_bk_hits + (size_t)par * e->bk_stride;
+        P.hits = q.d_hits;
+        P.runs = e->d_runs + (size_t)par * BKT_MAX * e->run_tt_max;
+        P.run_tt = q.run_tt;
+        P.ntiles = q.ntiles;
+        P.tile_shift = q.tile_shift;
+        P.nb = q.nb;
+        P.items = e->d_items + par;
+        P.limits = e->d_limits;
+        P.now = q.now;
+        P.verdict = q.d_verdict;
+        P.first_limited = q.d_first;
+        P.bs = e->d_bs + p % BS_ROT;
+        P.bs_zero = e->d_bs + (p + 3) % BS_ROT;
+        P.host_status = f.h_st;
+        P.done_seq = f.seq;
+        P.hot_next = e->d_hot + p % HS_SETS;
+        P.hot_threshold = e->hot_threshold;
+        P.hot_arrive = e->d_hot_arrive;
+        P.sparse_out = 1u;
+        P.hot_long = q.hot_long;
+        if (e->apply_trace) {
+            if (!e->d_apply_trace) HIP_TRY(e, hipMalloc((void**)&e->d_apply_trace, (size_t)(BK_MAX + 1024) * 8 * sizeof(unsigned long long)));
+            HIP_TRY(e, hipMemsetAsync(e->d_apply_trace, 0, (size_t)(BK_MAX + 1024) * 8 * sizeof(unsigned long long), e->stream));
+            P.trace = e->d_apply_trace;
+        }
+        S.n_apply_wgs = q.n_wg;
+        // "applied" for the partition stream (two-stream engines): the stop event of the launch itself where possible
+        // (no marker command); a timed launch only adds a start event
+        const bool chain_a = two_streams && e->ext_events;
+        f.ev_a_stop = chain_a ? e->ev_applied[p & 3u] : (q.t_apply ? f.tev[5] : nullptr);
+        timed = q.t_apply || chain_a;
+        ev0 = q.t_apply ? f.tev[4] : nullptr;
+        ev1 = f.ev_a_stop;
     }
-    ApplyParams P{};
-    P.table = e->table;
-    P.log2cap = e->log2cap;
-    P.seed = e->seed;
-    P.b_hits = e->d_bk_hits + (size_t)par * e->bk_stride;
-    P.hits = q.d_hits;
-    P.runs = e->d_runs + (size_t)par * BKT_MAX * e->run_tt_max;
-    P.run_tt = q.run_tt;
-    P.ntiles = q.ntiles;
-    P.tile_shift = q.tile_shift;
-    P.nb = q.nb;
-    P.plan = e->d_plan + (size_t)par * (HOT_MAX + 1);
-    P.chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
-    P.chunk_tab_len = (u32)e->chunk_tab_len;
-    P.limits = e->d_limits;
-    P.now = q.now;
-    P.verdict = q.d_verdict;
-    P.first_limited = q.d_first;
-    P.bs = e->d_bs + p % BS_ROT;
-    P.bs_zero = e->d_bs + (p + 3) % BS_ROT;
-    P.host_status = f.h_st;
-    P.done_seq = f.seq;
-    P.hot_next = e->d_hot + p % HS_SETS;
-    P.hot_threshold = e->hot_threshold;
-    P.hot_arrive = e->d_hot_arrive;
-    P.sparse_out = 1u;
-    P.hot_long = q.hot_long;
-    if (e->apply_trace) {
-        if (!e->d_apply_trace) HIP_TRY(e, hipMalloc((void**)&e->d_apply_trace, (size_t)BK_MAX * 8 * sizeof(unsigned long long)));
-        HIP_TRY(e, hipMemsetAsync(e->d_apply_trace, 0, (size_t)BK_MAX * 8 * sizeof(unsigned long long), e->stream));
-        P.trace = e->d_apply_trace;
+    if (part) {
+        S.Q = part->Q;
+        S.n_part_wgs = part->Q.ntiles + 1;
+        if (!fa && part->timed) {  // a launch that only partitions, timed as such
+            rl_engine::Inflight& fp = e->inflight[part->slot];
+            timed = true;
+            ev0 = fp.tev[0];
+            ev1 = fp.ev_p_stop = fp.tev[1];
+        }
     }
-    // "applied" for the partition stream: the stop event of the launch itself where possible (no marker command); a
-    // timed launch only adds a start event
-    const bool chain_a = two_streams && e->ext_events;
-    f.ev_a_stop = chain_a ? e->ev_applied[p & 3u] : (q.t_apply ? f.tev[5] : nullptr);
-    launch_apply(e, P, q.n_wg, q.t_apply || chain_a, q.t_apply ? f.tev[4] : nullptr, f.ev_a_stop);
+    launch_step(e, S, timed, ev0, ev1);
     HIP_TRY(e, hipGetLastError());
-    if (two_streams && !chain_a) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
+    if (fa && two_streams && !(e->ext_events)) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
     return RL_OK;
 }
 
@@ -532,6 +570,8 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         f.ntiles = 0;
         f.timed = t_apply ? 2 : 0;
         f.ev_a_stop = f.tev[5];
+        f.ev_a_prev = nullptr;
+        e->last_k1_was_part = false;
         f.seq = (u32)(e->sub_seq + 1);
         f.settled = false;
         e->inflight_hits += n;
@@ -557,13 +597,47 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     const u32 par = (u32)(p % PB_SETS);
     const u32 depth = e->pipe_depth;
     BatchScratch* bs = e->d_bs + p % BS_ROT;
-    const HotSet* hot_use = e->d_hot + (p + HS_SETS - depth) % HS_SETS;
+    // (one-stream engines partition batch p inside the launch that replays batch p - 1: the newest complete hot set is
+    // the one batch p - 2 picked)
+    const HotSet* hot_use = e->d_hot + (p + HS_SETS - (two_streams ? depth : 2u)) % HS_SETS;
     HotSet* hot_prod = e->d_hot + p % HS_SETS;
     BHit* b_hits = e->d_bk_hits + (size_t)par * e->bk_stride;
     u32* runs = e->d_runs + (size_t)par * BKT_MAX * e->run_tt_max;
-    HotPlan* plan = e->d_plan + (size_t)par * (HOT_MAX + 1);
-    unsigned short* chunk_tab = e->d_chunk_tab + (size_t)par * e->chunk_tab_len;
+    HotItems* items = e->d_items + par;
     hipStream_t ps = e->pstream;
+    const Cell* ctable = e->table;
+    const LimitDev* climits = e->d_limits;
+    // ---- one stream: the partition of this batch rides in the launch that replays the batch before it (k_bkt_step) ----
+    const bool fused = e->fuse && !two_streams && nbt <= (u32)PART_ROLE_BINS && !need_count;
+    if (fused) {
+        PartLaunch PL{};
+        PartParams& Q = PL.Q;
+        Q.table = ctable;
+        Q.log2cap = e->log2cap;
+        Q.seed = e->seed;
+        Q.hits = d_hits;
+        Q.n = n;
+        Q.limits = climits;
+        Q.n_limits = (u32)e->h_limits.size();
+        Q.bk_log2 = bk_log2;
+        Q.ntiles = ntiles;
+        Q.run_tt = run_tt;
+        Q.tile_shift = tile_shift;
+        Q.check_simple = 1u;
+        Q.bs = bs;
+        Q.hot = hot_use;
+        Q.verdict_fill = d_verdict;
+        Q.first_fill = d_first;
+        Q.b_hits = b_hits;
+        Q.runs = runs;
+        Q.items = items;
+        Q.hot_next = hot_prod;
+        PL.slot = (u32)(e->sub_seq & 3u);
+        PL.timed = t;
+        f.ev_p_stop = nullptr;
+        rc = flush_pending_apply(e, &PL);
+        if (rc) return rc;
+    } else {
     // ---- partition ----------------------------------------------------------------------------------
     // The batch whose buffers and hot set this partition takes over (p - depth) has, with depth 3, been collected by
     // the caller: the host asks the event itself — once it has seen it complete, everything enqueued from here on is
@@ -572,9 +646,8 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     if (two_streams && p >= depth && hipEventQuery(e->ev_applied[(p - depth) & 3u]) != hipSuccess) {
         (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
         HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - depth) & 3u], 0));
+        e->n_wait_applied++;
     }
-    const Cell* ctable = e->table;
-    const LimitDev* climits = e->d_limits;
     // "partitioned" for the other stream: the stop event of the launch itself where possible (no marker command); a
     // timed launch only adds a start event
     const bool chain_p = two_streams && e->ext_events && !need_count;
@@ -582,8 +655,13 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 #define RL_PART(STEPS)                                                                                                         \
     RL_LAUNCH_TS(t || chain_p, t ? f.tev[0] : nullptr, f.ev_p_stop, k_bkt_part<STEPS>, ntiles + 1,                            \
                  PT_BLOCK, scatter_lds_bytes(nbt), ps, ctable, e->log2cap, e->seed, d_hits, n, climits,                        \
-                 (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, plan,    \
-                 chunk_tab, (u32)e->chunk_tab_len, hot_prod)
+                 (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, items,   \
+                 hot_prod)
+    static const bool fake_part = getenv("RL_FAKE_PART") != nullptr;  // (timing experiment: results are garbage)
+    if (fake_part && p >= 12) {
+        if (two_streams) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
+        f.ev_p_stop = nullptr;
+    } else
     switch (steps) {
         case 1: RL_PART(1); break;
         case 4: RL_PART(4); break;
@@ -616,12 +694,13 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                         n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
         }
     }
-    if (two_streams && !chain_p) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
+    if (two_streams && !chain_p && !(fake_part && p >= 12)) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
     // ---- apply --------------------------------------------------------------------------------------
     // the batch before this one first (its partition is usually complete by now: no wait command), then this one —
     // now, or when the next batch is submitted / this one collected
     rc = flush_pending_apply(e);
     if (rc) return rc;
+    }
     rl_engine::PendingApply& q = e->pend;
     q.valid = true;
     q.p = p;
@@ -632,9 +711,9 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     q.ntiles = ntiles;
     q.tile_shift = tile_shift;
     q.run_tt = run_tt;
-    // one workgroup per hash bucket (at least 64, so that the hot work items of a small batch still spread); the
-    // last one out writes the status block straight into f.h_st (host-mapped)
-    q.n_wg = nb < 64u ? 64u : nb;
+    // one workgroup per hash bucket + the ones that walk the hot work items; the last one out writes the status block
+    // straight into f.h_st (host-mapped)
+    q.n_wg = nb + e->hot_wgs;
     q.now = now;
     q.d_verdict = d_verdict;
     q.d_first = d_first;
@@ -646,15 +725,21 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     // reported a populated set.
     q.hot_long = e->hot_seen >= 64u ? e->hot_long_cfg : 0xFFFFFFFFu;
     e->part_seq++;
+    e->n_part_batches++;
     f.n = n;
     f.n_wg = q.n_wg;
     f.ntiles = ntiles;
     f.timed = (t ? 1 : 0) | (t_apply ? 2 : 0);
+    f.ev_a_prev = (two_streams && e->ext_events && p >= 1 && e->last_k1_was_part) ? e->ev_applied[(p - 1) & 3u] : nullptr;
+    e->last_k1_was_part = true;
     f.seq = (u32)(e->sub_seq + 1);
     f.settled = false;
     e->inflight_hits += n;
     e->sub_seq++;
-    if (!two_streams || !e->defer_apply) return flush_pending_apply(e);
+    // The replay of this batch goes out with the next submit (one-stream engines: in one launch with that batch's
+    // partition; two-stream engines: by then the host sees the partition's event complete) or with its own collect — unless
+    // the caller orders its own work on the engine's stream, which must then hold everything submitted so far.
+    if (!e->defer_apply || e->external_stream || !(two_streams || e->fuse)) return flush_pending_apply(e);
     return RL_OK;
 }
 
@@ -681,8 +766,18 @@ int collect_k1_bucketed(rl_engine* e) {
     e->col_seq++;
     if (e->apply_trace && f.n_wg > 1 && e->d_apply_trace) {
         // diagnostics: where the workgroups of k_bkt_apply spent their time (wall clock, 100 MHz)
-        std::vector<unsigned long long> t((size_t)f.n_wg * 8);
+        std::vector<unsigned long long> t((size_t)(BK_MAX + 1024) * 8);  // (the rows behind the replay's: the partition role's)
         HIP_TRY(e, hipMemcpy(t.data(), e->d_apply_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        bool has_part = false;  // (a launch that only replays — the last batch of a burst — does not overwrite a full one)
+        for (size_t r = f.n_wg; r < (size_t)(BK_MAX + 1024) && !has_part; ++r) has_part = t[r * 8] != 0;
+        if (const char* path = getenv("RL_APPLY_TRACE_FILE"); path && (has_part || e->stats.batches < 2)) {  // raw stamps, for offline analysis
+            if (FILE* fp = std::fopen(path, "wb")) {
+                const unsigned long long hdr[8] = {f.n_wg, e->hot_wgs, 0, 0, 0, 0, 0, 0};
+                std::fwrite(hdr, sizeof(unsigned long long), 8, fp);
+                std::fwrite(t.data(), sizeof(unsigned long long), t.size(), fp);
+                std::fclose(fp);
+            }
+        }
         unsigned long long t_min = ~0ull, t_max = 0, first_end = ~0ull;
         double ph[5] = {0, 0, 0, 0, 0}, hits = 0, longest = 0;
         u32 live = 0;
@@ -701,6 +796,21 @@ int collect_k1_bucketed(rl_engine* e) {
             ph[4] += (double)(q[5] - q[4]) / 100.0;
             hits += (double)q[6];
             longest = std::max(longest, (double)(q[5] - q[0]) / 100.0);
+        }
+        {   // the partition role's workgroups of the same launch (the next batch), if any
+            double pp[6] = {0, 0, 0, 0, 0, 0}, p_end = 0;
+            u32 np = 0;
+            for (size_t r = f.n_wg; r < (size_t)(BK_MAX + 1024); ++r) {
+                const unsigned long long* q = &t[r * 8];
+                if (!q[0] || !q[6]) continue;
+                ++np;
+                for (int k = 0; k < 6; ++k) pp[k] += (double)(q[k + 1] - q[k]) / 100.0;
+                p_end = std::max(p_end, (double)(q[6] - t_min) / 100.0);
+            }
+            if (np)
+                std::fprintf(stderr, "[part]  %u workgroups beside it, last one out after %.1f us; mean per workgroup: init %.2f, hot table %.2f, "
+                             "walk 1 %.2f, scan %.2f, walk 2 %.2f, flags %.2f us\n", np, p_end, pp[0] / np, pp[1] / np, pp[2] / np, pp[3] / np,
+                             pp[4] / np, pp[5] / np);
         }
         if (live)
             std::fprintf(stderr, "[apply] %u workgroups, span %.1f us (first one out after %.1f); mean per workgroup: view %.2f, bucket %.2f "
@@ -729,6 +839,14 @@ int collect_k1_bucketed(rl_engine* e) {
         }
         e->ms_slot[RL_T_PART] += ms[0];
         e->ms_slot[RL_T_APPLY] += ms[1];
+        if ((f.timed & 2) && f.n_wg > 1 && f.ev_a_prev && f.ev_a_stop != f.tev[5]) {
+            // how long the apply stream sat idle in front of this k_bkt_apply, and how long its partition had been ready
+            float gap = 0, slack = 0;
+            if (hipEventElapsedTime(&gap, f.ev_a_prev, f.tev[4]) == hipSuccess) e->ms_slot[RL_T_APPLY_GAP] += gap;
+            if ((f.timed & 1) && f.ev_p_stop && hipEventElapsedTime(&slack, f.ev_p_stop, f.tev[4]) == hipSuccess)
+                e->ms_slot[RL_T_PART_SLACK] += slack;
+            (void)hipGetLastError();
+        }
         if (f.timed & 2) e->timed_launches++;
     }
     return RL_OK;
@@ -1174,7 +1292,10 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
     if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
     if (const char* v = getenv("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
+    if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
+    if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch
     if (const char* v = getenv("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
+    if (const char* v = getenv("RL_HOT_WGS")) e->hot_wgs = (u32)std::min(std::max(atoi(v), 8), 1024);
     if (const char* v = getenv("RL_PART_STEPS")) {
         const int b = atoi(v);
         if (b == 4 || b == 8 || b == 16) e->part_steps_cfg = (u32)b;
@@ -1225,15 +1346,26 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (lo = least urgent, hi = most: numerically lower)
         int prio = prio_hi;
         if (const char* v = getenv("RL_PSTREAM_PRIO")) prio = atoi(v) == 0 ? prio_lo : (atoi(v) == 2 ? 0 : prio_hi);
+        if (const char* v = getenv("RL_PSTREAM_CUS")) {  // (experiment) the partition stream on the first N CUs of the mask order only
+            const int ncu = atoi(v);
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < ncu && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+            if (hipExtStreamCreateWithCUMask(&e->own_pstream, 8, mask) != hipSuccess) return bail(RL_ERR_DEVICE);
+        } else
         if (hipStreamCreateWithPriority(&e->own_pstream, hipStreamNonBlocking, prio) != hipSuccess) return bail(RL_ERR_DEVICE);
         e->pstream = e->own_pstream;
     } else {
         e->pstream = e->stream;
     }
-    for (auto& ev : e->ev_parted)  // (timing-capable: they are also the stop events of launches, see ext_events)
-        if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
+    // "partitioned" / "applied": timing-capable (they are also the stop events of timed launches, see ext_events), and
+    // WITHOUT the system-scope fence an event carries by default: they order two streams of one device, nothing the
+    // host reads depends on them (the status block is fine-grained memory written with explicit stores).
+    unsigned ev_flags = hipEventDisableSystemFence;
+    if (const char* v = getenv("RL_EVENT_FLAGS")) ev_flags = (unsigned)strtoul(v, nullptr, 0);
+    for (auto& ev : e->ev_parted)
+        if (hipEventCreateWithFlags(&ev, ev_flags) != hipSuccess) return bail(RL_ERR_DEVICE);
     for (auto& ev : e->ev_applied)
-        if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
+        if (hipEventCreateWithFlags(&ev, ev_flags) != hipSuccess) return bail(RL_ERR_DEVICE);
     if (hipEventCreateWithFlags(&e->ev_match, hipEventDisableTiming) != hipSuccess) return bail(RL_ERR_DEVICE);
     // the partition kernels' dynamic LDS goes up to 80 KB (beside their static LDS)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bkt_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1303,8 +1435,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_bk_hits, PB_SETS * e->bk_stride * sizeof(BHit));
     e->run_tt_max = cdiv(mb, PT_BLOCK * PT_STEPS_MAX) > (u32)TT_SMALL ? (u32)TT_LARGE : (u32)TT_SMALL;
     ALLOC(e->d_runs, PB_SETS * (size_t)BKT_MAX * e->run_tt_max * sizeof(u32));
-    ALLOC(e->d_plan, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotPlan));
-    if (hipMemset(e->d_plan, 0, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotPlan)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_items, PB_SETS * sizeof(HotItems));
+    if (hipMemset(e->d_items, 0, PB_SETS * sizeof(HotItems)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_hot_arrive, (size_t)HOT_MAX * sizeof(u32));
     if (hipMemset(e->d_hot_arrive, 0, (size_t)HOT_MAX * sizeof(u32)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_tiny_hits, (size_t)TINY_MAX * sizeof(BHit));
@@ -1344,7 +1476,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
     for (auto& f : e->inflight) {
         for (auto& ev : f.tev)
-            if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
+            if (hipEventCreateWithFlags(&ev, ev_flags) != hipSuccess) return bail(RL_ERR_DEVICE);
         if (!host_block((void**)&f.h_st, sizeof(Status))) return bail(RL_ERR_NOMEM);
         memset(f.h_st, 0, sizeof(Status));
     }
@@ -1356,6 +1488,9 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
 
 void rl_engine_destroy(rl_engine* e) {
     if (!e) return;
+    if (e->apply_trace)
+        std::fprintf(stderr, "[engine] %llu partitioned batches; wait commands enqueued: %llu for a partition, %llu for an apply\n",
+                     (unsigned long long)e->n_part_batches, (unsigned long long)e->n_wait_parted, (unsigned long long)e->n_wait_applied);
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->own_pstream) (void)hipStreamSynchronize(e->own_pstream);
@@ -1366,7 +1501,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_plan,   e->d_apply_trace,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_items,  e->d_apply_trace,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)
@@ -1435,6 +1570,8 @@ int32_t rl_engine_record_event(rl_engine* e, void* event) {
     if (!e || !event) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
     HIP_TRY(e, hipSetDevice(e->device));
+    const int rc = flush_pending_apply(e);  // "everything submitted so far" includes a replay that was waiting for the next submit
+    if (rc) return rc;
     HIP_TRY(e, hipEventRecord((hipEvent_t)event, e->stream));
     return RL_OK;
 }

@@ -306,7 +306,7 @@ class Engine:
         3 both kernels of every fourth batch (rl_engine.h)."""
         self._check(self._lib.rl_kernel_timing(self._h, int(mode)))
 
-    TIMING_SLOTS = ("part", "reserved1", "reserved2", "apply", "reserved4", "reserved5", "reserved6",
+    TIMING_SLOTS = ("part", "apply_gap", "part_slack", "apply", "reserved4", "reserved5", "reserved6",
                     "reserved7")  # RL_T_* of include/rl_engine.h
 
     def kernel_timing_read(self, reset=True):

@@ -1,0 +1,35 @@
+#!/bin/bash
+set -u
+out=$PWD/gpurun_out/r3d; rm -rf "$out"; mkdir -p "$out"
+export TMPDIR=/tmp
+timeout 400 python -m pytest tests/test_gpu_bucketed.py tests/test_gpu_variants.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -12 > "$out/pytest.log"
+tail -4 "$out/pytest.log"
+summ() {
+python - "$1" <<'PY'
+import json,sys
+try:
+    d=[json.loads(l) for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1]
+    p=d["pipeline"]
+    print(sys.argv[1].split("/")[-1], round(d["value"]/1e9,2),"G/s", round(d["ms_per_step"]*1e3,1),"us/step", "alone", {k:round(v*1e3,1) for k,v in p["kernel_ms_per_batch_alone"].items()}, "in-pipe", {k:round(v*1e3,1) for k,v in p["kernel_ms_per_batch_in_pipeline"].items()}, "frac", round(d["roofline"]["frac"],4), "denied", d["config"]["denied_in_last_batch"])
+except Exception as ex:
+    print(sys.argv[1], "FAILED", ex)
+PY
+}
+run() {  # name, env..., then bench args after --
+  name=$1; shift
+  envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 120 python bench.py --cpu-seconds 0 --secondary 0 "$@" > "$out/$name.json" 2> "$out/$name.err"
+  summ "$out/$name.json"
+}
+run base X=1 -- --steps 100 --warmup 5
+run base20 X=1 -- --steps 20 --warmup 5
+run one RL_OVERLAP=0 -- --steps 100 --warmup 5
+run hw128 RL_HOT_WGS=128 -- --steps 100 --warmup 5
+run hw512 RL_HOT_WGS=512 -- --steps 100 --warmup 5
+run bk11 RL_BUCKET_LOG2=11 -- --steps 100 --warmup 5
+run v80 RL_APPLY2_CFG=2 -- --steps 100 --warmup 5
+run uniform X=1 -- --steps 100 --warmup 5 --zipf 0
+RL_APPLY_TRACE=1 RL_APPLY_TRACE_FILE=$out/trace_d1.bin timeout 120 python bench.py --cpu-seconds 0 --secondary 0 --steps 8 --warmup 5 --depth 1 --timing-mode 0 > "$out/d1.json" 2> "$out/d1.err"
+python scripts/apply_trace.py $out/trace_d1.bin
+RL_APPLY_TRACE=1 RL_APPLY_TRACE_FILE=$out/trace_d3.bin timeout 120 python bench.py --cpu-seconds 0 --secondary 0 --steps 8 --warmup 5 --timing-mode 0 > "$out/d3.json" 2> "$out/d3.err"
+python scripts/apply_trace.py $out/trace_d3.bin | head -12

@@ -1,12 +1,14 @@
 """The build variants of the bucketed hot path, each bit-exact against the CPU oracle on a trace that takes every
 branch of the hot-key code (promotion, decided by position, replayed, created by the hot path, demoted):
 
-  default            pipeline depth 3, k_bkt_apply enqueued one submit late (PendingApply), 16-bit limit ids in LDS,
-                     verdicts prefilled by k_bkt_part
-  RL_DEFER_APPLY=0   k_bkt_apply enqueued at submit, behind a wait for its partition
-  RL_PIPE_DEPTH=2    the partition of batch p waits for k_bkt_apply of batch p - 2
+  default            two streams: k_bkt_part (1024-thread workgroups) on a stream of its own, the replay (k_bkt_step) enqueued
+                     one submit late (PendingApply); 16-bit limit ids in LDS, default verdicts written by the partition
+  RL_DEFER_APPLY=0   the replay enqueued at submit, behind a wait for its partition
+  RL_PIPE_DEPTH=2    the partition of batch p waits for the replay of batch p - 2
   RL_APPLY2_CFG=1    32-bit limit ids in LDS (what an engine with more than 32768 limit rows takes by itself)
-  RL_OVERLAP=0       one stream
+  RL_OVERLAP=0       k_bkt_part and the replay on one stream
+  RL_FUSE=1          one stream, one k_bkt_step launch per step: the replay of batch j and, beside it, the partition of batch
+                     j + 1 as a role of 256-thread workgroups
 
 and the output contract of the sparse verdict stores: every byte of verdict[] / every word of first_limited[] of a
 batch is defined when it is collected, whatever the buffers held before.  Needs a MI355X."""
@@ -20,8 +22,8 @@ from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [{}, {"RL_DEFER_APPLY": "0"}, {"RL_PIPE_DEPTH": "2"}, {"RL_APPLY2_CFG": "1"}, {"RL_OVERLAP": "0"},
-            {"RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"}]
+VARIANTS = [{}, {"RL_DEFER_APPLY": "0"}, {"RL_APPLY2_CFG": "1"}, {"RL_FUSE": "1"}, {"RL_OVERLAP": "0"},
+            {"RL_FUSE": "1", "RL_DEFER_APPLY": "0"}, {"RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"}]
 
 
 def hot_trace(eng, orc, rng, n=60_000):
