@@ -22,7 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # Algorithmic bytes per (request x counter), SURVEY.md §8(d): 16 B descriptor read + 24 B cell read
-# (key, value, expiry) + 8 B value write-back + 1 B verdict = 49 B.  k_bkt_apply is the kernel that
+# (key, value, expiry) + 8 B value write-back + 1 B verdict = 49 B.  k_bkt_step is the kernel that
 # reads the descriptor and the cell, writes the value back and emits the verdict, so all 49 B are
 # its algorithmic bytes; the partition kernel (k_bkt_part) only reorders the batch —
 # ranking traffic is overhead, not algorithmic — and is charged 0.
@@ -46,10 +46,10 @@ def parse():
     ap.add_argument("--depth", type=int, default=3, choices=(1, 2, 3),
                     help="batches in flight on one GPU: N = submit batch k+N-1 before collecting batch k "
                          "(rl_check_and_update_submit_device / _collect; with 2+ the partition of the next batch "
-                         "overlaps k_bkt_apply of this one), 1 = one blocking call per batch; "
+                         "overlaps k_bkt_step of this one), 1 = one blocking call per batch; "
                          "the routed path keeps 3 ingress slices in flight at depth >= 2 (ShardedEngine)")
     ap.add_argument("--timing-mode", type=int, default=3, choices=(0, 2, 3),
-                    help="HIP events in the timed region: 2 = k_bkt_apply of every batch, 3 = k_bkt_part and k_bkt_apply "
+                    help="HIP events in the timed region: 2 = k_bkt_step of every batch, 3 = k_bkt_part and k_bkt_step "
                          "of every fourth batch, 0 = none (roofline then comes from the breakdown pass)")
     ap.add_argument("--sharded-impl", choices=("torch", "abi"), default=os.environ.get("RL_SHARDED_IMPL", "abi"),
                     help="routed step driven by the C entry with its own RCCL communicator (include/rl_sharded.h: 105 us per "
@@ -347,7 +347,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_keys_total = args.keys * world
-    # 32-byte cells at load <= 0.30: 10 M keys -> 2^25 cells = 1.07 GB (measured on MI355X, k_bkt_apply one
+    # 32-byte cells at load <= 0.30: 10 M keys -> 2^25 cells = 1.07 GB (measured on MI355X, k_bkt_step one
     # workgroup per bucket: 2^27 / 2^26 / 2^25 cells -> 14.3 / 14.1 / 13.7 G decisions/s; the first cut needed
     # load 0.075 of 64-byte cells, 8.6 GB, to hide its probe chains)
     cap = 1 << (int(n_keys_total / world * 2.2 * args.cap_mult - 1).bit_length())
@@ -418,7 +418,7 @@ def main():
             eng.check_and_update_device(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
     else:
         # `depth` batches in flight: batch i is enqueued before the host waits for batch i-depth+1, so the
-        # device never idles between batches and the partition of batch i+1 (own stream) overlaps k_bkt_apply
+        # device never idles between batches and the partition of batch i+1 (own stream) overlaps k_bkt_step
         # of batch i.  Batches are applied in submission order; every step's batch has completed when the
         # timed region ends (drain()).
         pending = [0]
@@ -466,7 +466,7 @@ def main():
         now += 1000
     drain()
     kt_all = eng.kernel_timing_read(reset=True)
-    # Timed region: events around the dominant kernel only (k_bkt_apply), for the roofline.
+    # Timed region: events around the dominant kernel only (k_bkt_step), for the roofline.
     eng.kernel_timing(args.timing_mode)
     denied = 0
     torch.cuda.synchronize()
@@ -505,24 +505,28 @@ def main():
         per_alone = dict(per)
         per.update(timed)
         hits_per_launch = st["hits"] / max(1, st["batches"])
-        dom = max(per, key=lambda k: per[k]) if per else "apply"
+        # the dominant kernel for the roofline is the one that does the algorithmic work (k_bkt_step: the replay); the
+        # partition kernel beside it is overhead and is reported in `pipeline`
+        dom = "apply"
         dom_gbps = ALGO_BYTES[dom] * hits_per_launch / (per[dom] * 1e-3) / 1e9 if per.get(dom, 0) > 0 else 0.0
         pipe_ms = sum(per.values())
-        kname = {"apply": "k_bkt_apply", "part": "k_bkt_part"}.get(dom, "k_" + dom)
+        kname = {"apply": "k_bkt_step", "part": "k_bkt_part"}.get(dom, "k_" + dom)
         # HBM bytes per launch of that kernel from the PMC passes of the last profiling visit
         # (scripts/gpu_profile.sh -> scripts/summarize_prof.py -> profiles/traffic.json): counters cannot
         # be collected inside this run, so the figure is the committed one for this workload or null.
-        traffic = pipeline_traffic = l2_hit = None
+        traffic = pipeline_traffic = l2_hit = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         default_workload = (args.keys, args.batch, args.zipf) == (10_000_000, 1_000_000, 0.99)
         if os.path.exists(tpath) and default_workload and world == 1:
             try:
-                tk = json.load(open(tpath))["kernels"]
+                tj = json.load(open(tpath))
+                tk = tj["kernels"]
+                traffic_source = {"profile": tj.get("source"), "commit": tj.get("commit"), "file": "profiles/traffic.json"}
                 traffic = tk.get(kname, {}).get("hbm_bytes_per_launch")
                 l2_hit = tk.get(kname, {}).get("tcc_hit_rate")
                 # the whole batch pipeline (partition + hot state + replay), for the traffic / algorithmic ratio
                 pipeline_traffic = sum(tk.get(k, {}).get("hbm_bytes_per_launch") or 0.0 for k in
-                                       ("k_bkt_part", "k_bkt_apply"))
+                                       ("k_bkt_part", "k_bkt_step"))
             except Exception:
                 traffic = pipeline_traffic = l2_hit = None
         out = {
@@ -536,13 +540,18 @@ def main():
                        "table_capacity_cells": cap, "cell_bytes": 32, "table_bytes": cap * 32,
                        "parallelism": (f"hash-sharded x{world}, RCCL all-to-all" + (" behind the C ABI (rl_sharded_*)" if args.sharded_impl == "abi" else " (torch.distributed)")) if sharded else "single GPU",
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
-                       "overlap": "partition of batches k+1, k+2 (own stream) beside k_bkt_apply of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
-                       "denied_in_last_batch": denied},
+                       "overlap": "partition of batches k+1, k+2 (own stream) beside k_bkt_step of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
+                       "denied_in_last_batch": denied,
+                       # every engine knob the process saw (rl_engine_create reads RL_*, the ingest layer RLI_*)
+                       "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("RL_", "RLI_"))}},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": dom_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                          # SURVEY.md §8(d)'s three figures: algorithmic GB/s (`achieved`), counter-derived GB/s, L2 hit rate
                          "counter_GBps": (traffic / (per[dom] * 1e-3) / 1e9) if (traffic and per.get(dom, 0) > 0) else None,
                          "l2_hit_rate": l2_hit,
+                         # traffic / counter_GBps / l2_hit_rate are NOT measured in this run: they are the committed PMC
+                         # passes of the profiling visit named here (scripts/gpu_profile.sh + summarize_prof.py)
+                         "traffic_measured_at": traffic_source,
                          "pipeline_traffic": pipeline_traffic,
                          "pipeline_traffic_over_algorithmic": (pipeline_traffic / (ALGO_BYTES_TOTAL * hits_per_launch))
                          if pipeline_traffic else None,

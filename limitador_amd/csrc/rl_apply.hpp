@@ -858,8 +858,8 @@ __device__ __forceinline__ void bkt_apply_body(const ApplyParams& P, const u32 G
 // tile + one for its hot work items: part_role / plan_role, rl_part.hpp).  The two halves share nothing but the device:
 // the partition writes the buffers the NEXT launch replays.  Either half may be absent (n_*_wgs = 0): the first batch
 // of a burst is only partitioned, the last one only replayed.
-// The register budget is pinned (waves_per_eu), not left to the occupancy the compiler derives from the LDS size: 64
-// VGPRs and ~21 KB of LDS per workgroup let every workgroup of a 1 M-hit step (1024 buckets + 256 + 246) be resident at once.
+// The register budget is pinned (waves_per_eu), not left to the occupancy the compiler derives from the LDS size: 80
+// VGPRs and ~21 KB of LDS per workgroup keep every workgroup of a 1 M-hit replay (1024 buckets + 256) resident at once.
 // ---------------------------------------------------------------------------------------------
 struct StepParams {
     ApplyParams A;
@@ -886,10 +886,10 @@ struct StepParams {
             }                                                                                                              \
         }                                                                                                                  \
     }
-RL_DEF_STEP(k_bkt_step, 1, 9, 64, true, TT_SMALL)         // the usual one: limit ids in 16 bits, views of up to 256 tiles
-RL_DEF_STEP(k_bkt_step_wide, 1, 9, 64, false, TT_SMALL)   // engines with more than 32768 limit rows
+RL_DEF_STEP(k_bkt_step, 1, 9, 80, true, TT_SMALL)         // the usual one: limit ids in 16 bits, views of up to 256 tiles
+RL_DEF_STEP(k_bkt_step_wide, 1, 9, 80, false, TT_SMALL)   // engines with more than 32768 limit rows
 RL_DEF_STEP(k_bkt_step_large, 1, 9, 96, false, TT_LARGE)  // batches of more than 256 tiles
-RL_DEF_STEP(k_bkt_step_v80, 1, 9, 80, true, TT_SMALL)     // (RL_APPLY2_CFG experiments)
+RL_DEF_STEP(k_bkt_step_v64, 1, 9, 64, true, TT_SMALL)     // (RL_APPLY2_CFG: other register budgets)
 RL_DEF_STEP(k_bkt_step_v96, 1, 9, 96, true, TT_SMALL)
 #undef RL_DEF_STEP
 // ---------------------------------------------------------------------------------------------

@@ -43,13 +43,14 @@ constexpr u32 GEN_SUB_MAX = 4u << 20;  // most hits of one pass of the general r
 // batch may run as soon as the batch `pipe_depth` (2 or 3) before it has been applied:
 //   PB_SETS  partitioned records / ranges / hot-bucket table / chunk table: batch p writes set p % 3, last read by
 //            k_bkt_apply of batch p - 3
-//   BS_ROT   scratch blocks: batch p uses [p % 4]; its k_bkt_apply zeroes [(p + 3) % 4] (= batch p - 1's, done) for
-//            batch p + 3; one more block ([BS_ROT]) belongs to k_bkt_tiny
+//   BS_ROT   scratch blocks: batch p uses [p % 5]; its replay zeroes [(p + 4) % 5] (= batch p - 1's, done) for batch
+//            p + 4 — FOUR ahead, so that the partition of a batch only ever depends on a replay kernel that has ENDED
+//            (see apply_events); one more block ([BS_ROT]) belongs to k_bkt_tiny
 //   HS_SETS  hot sets: batch p picks set p % 8 and is partitioned with the one batch p - pipe_depth picked; eight,
 //            so that the set a partition rewrites is never one a batch still in flight reads (k_hot_state of batch
 //            p - 1 and p - 2 read the sets of p - 1 - depth and p - 2 - depth)
 constexpr u32 PB_SETS = 3;
-constexpr u32 BS_ROT = 4;
+constexpr u32 BS_ROT = 5;
 constexpr u32 HS_SETS = 8;
 
 struct rl_engine {
@@ -159,6 +160,14 @@ struct rl_engine {
     u32 part_steps_cfg = 0;         // RL_PART_STEPS (4, 8, 16): at least this many 64-hit steps per wave of k_bkt_part (experiments)
     u64 n_wait_parted = 0, n_wait_applied = 0, n_part_batches = 0;  // wait commands that had to be enqueued (RL_APPLY_TRACE: printed at destroy)
     bool last_k1_was_part = false;  // the batch submitted last went through k_bkt_part / k_bkt_apply (not k_bkt_tiny)
+    // Events on the replay launches ("applied", for the partition stream).  RL_APPLY_EVENTS=0: the replay is a plain launch
+    // and the partition stream takes its ordering from what the HOST has seen instead — the partition of batch p takes
+    // over buffers last read by the replay of batch p - 3, whose completion word the caller has collected (its workgroups
+    // are done reading), and everything it needs a replay kernel to have WRITTEN (its hot set, its zeroed scratch) comes
+    // from batch p - 4, whose kernel had ended before the replay of batch p - 3 could start.  Measured: no difference
+    // (50 us per step either way) — the ~11 us the replay's stream idles between two launches while the partition's queue
+    // is busy (4.9 us when it is not, 1.7 us between plain launches of one queue) are not the events'.
+    bool apply_events = true;
     bool fuse = false;              // RL_FUSE=1: one stream, the partition of batch j + 1 as a role of the launch that replays batch j
                                     // (k_bkt_step; parity-green, but the role's 4-wave workgroups walk a tile in 2 x 16 dependent steps:
                                     // 57 us alone against 24 us for k_bkt_part's 16 waves — measured slower, kept for the record)
@@ -412,13 +421,14 @@ void launch_step(rl_engine* e, const StepParams& S, bool timed, hipEvent_t ev0, 
         RL_ST(k_bkt_step_large);
         return;
     }
-    // 0 (default): 21 KB of LDS, seven workgroups per CU — limit ids in 16 bits, so engines with more than 32768 limit
-    // rows take 1: the same kernel with 32-bit limit ids (22 KB).  2 / 3: larger register budgets (experiments).
+    // 0 (default): 80 VGPRs (no scratch), limit ids in 16 bits — engines with more than 32768 limit rows take 1: the
+    // same kernel with 32-bit limit ids.  2: 64 VGPRs (eleven of them in scratch: 1.5-2 us slower per 1 M-hit step,
+    // measured in both halves of this round), 3: 96.
     switch (e->apply2_cfg == 0 && e->max_limits > 32768u ? 1 : e->apply2_cfg) {
         default:
         case 0: RL_ST(k_bkt_step); break;
         case 1: RL_ST(k_bkt_step_wide); break;
-        case 2: RL_ST(k_bkt_step_v80); break;
+        case 2: RL_ST(k_bkt_step_v64); break;
         case 3: RL_ST(k_bkt_step_v96); break;
     }
 #undef RL_ST
@@ -470,7 +480,7 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
         P.verdict = q.d_verdict;
         P.first_limited = q.d_first;
         P.bs = e->d_bs + p % BS_ROT;
-        P.bs_zero = e->d_bs + (p + 3) % BS_ROT;
+        P.bs_zero = e->d_bs + (p + 4) % BS_ROT;
         P.host_status = f.h_st;
         P.done_seq = f.seq;
         P.hot_next = e->d_hot + p % HS_SETS;
@@ -486,7 +496,7 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
         S.n_apply_wgs = q.n_wg;
         // "applied" for the partition stream (two-stream engines): the stop event of the launch itself where possible
         // (no marker command); a timed launch only adds a start event
-        const bool chain_a = two_streams && e->ext_events;
+        const bool chain_a = two_streams && e->ext_events && e->apply_events;
         f.ev_a_stop = chain_a ? e->ev_applied[p & 3u] : (q.t_apply ? f.tev[5] : nullptr);
         timed = q.t_apply || chain_a;
         ev0 = q.t_apply ? f.tev[4] : nullptr;
@@ -504,7 +514,7 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
     }
     launch_step(e, S, timed, ev0, ev1);
     HIP_TRY(e, hipGetLastError());
-    if (fa && two_streams && !(e->ext_events)) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
+    if (fa && two_streams && e->apply_events && !e->ext_events) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
     return RL_OK;
 }
 
@@ -599,7 +609,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     BatchScratch* bs = e->d_bs + p % BS_ROT;
     // (one-stream engines partition batch p inside the launch that replays batch p - 1: the newest complete hot set is
     // the one batch p - 2 picked)
-    const HotSet* hot_use = e->d_hot + (p + HS_SETS - (two_streams ? depth : 2u)) % HS_SETS;
+    const HotSet* hot_use = e->d_hot + (p + HS_SETS - (two_streams ? (e->apply_events ? depth : 4u) : 2u)) % HS_SETS;
     HotSet* hot_prod = e->d_hot + p % HS_SETS;
     BHit* b_hits = e->d_bk_hits + (size_t)par * e->bk_stride;
     u32* runs = e->d_runs + (size_t)par * BKT_MAX * e->run_tt_max;
@@ -643,7 +653,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     // the caller: the host asks the event itself — once it has seen it complete, everything enqueued from here on is
     // ordered behind that batch — and the partition stream is spared a wait command.  Only a batch that is really
     // still running gets the device-side wait.  (A batch whose k_bkt_apply is still pending is p - 1: never p - depth.)
-    if (two_streams && p >= depth && hipEventQuery(e->ev_applied[(p - depth) & 3u]) != hipSuccess) {
+    if (two_streams && e->apply_events && p >= depth && hipEventQuery(e->ev_applied[(p - depth) & 3u]) != hipSuccess) {
         (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
         HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_applied[(p - depth) & 3u], 0));
         e->n_wait_applied++;
@@ -657,11 +667,6 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                  PT_BLOCK, scatter_lds_bytes(nbt), ps, ctable, e->log2cap, e->seed, d_hits, n, climits,                        \
                  (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, items,   \
                  hot_prod)
-    static const bool fake_part = getenv("RL_FAKE_PART") != nullptr;  // (timing experiment: results are garbage)
-    if (fake_part && p >= 12) {
-        if (two_streams) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
-        f.ev_p_stop = nullptr;
-    } else
     switch (steps) {
         case 1: RL_PART(1); break;
         case 4: RL_PART(4); break;
@@ -694,7 +699,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                         n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
         }
     }
-    if (two_streams && !chain_p && !(fake_part && p >= 12)) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
+    if (two_streams && !chain_p) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
     // ---- apply --------------------------------------------------------------------------------------
     // the batch before this one first (its partition is usually complete by now: no wait command), then this one —
     // now, or when the next batch is submitted / this one collected
@@ -730,7 +735,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     f.n_wg = q.n_wg;
     f.ntiles = ntiles;
     f.timed = (t ? 1 : 0) | (t_apply ? 2 : 0);
-    f.ev_a_prev = (two_streams && e->ext_events && p >= 1 && e->last_k1_was_part) ? e->ev_applied[(p - 1) & 3u] : nullptr;
+    f.ev_a_prev = (two_streams && e->ext_events && e->apply_events && p >= 1 && e->last_k1_was_part) ? e->ev_applied[(p - 1) & 3u] : nullptr;
     e->last_k1_was_part = true;
     f.seq = (u32)(e->sub_seq + 1);
     f.settled = false;
@@ -1292,6 +1297,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
     if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
     if (const char* v = getenv("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
+    if (const char* v = getenv("RL_APPLY_EVENTS")) e->apply_events = atoi(v) != 0;
     if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
     if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch
     if (const char* v = getenv("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
@@ -1346,12 +1352,6 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (lo = least urgent, hi = most: numerically lower)
         int prio = prio_hi;
         if (const char* v = getenv("RL_PSTREAM_PRIO")) prio = atoi(v) == 0 ? prio_lo : (atoi(v) == 2 ? 0 : prio_hi);
-        if (const char* v = getenv("RL_PSTREAM_CUS")) {  // (experiment) the partition stream on the first N CUs of the mask order only
-            const int ncu = atoi(v);
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < ncu && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
-            if (hipExtStreamCreateWithCUMask(&e->own_pstream, 8, mask) != hipSuccess) return bail(RL_ERR_DEVICE);
-        } else
         if (hipStreamCreateWithPriority(&e->own_pstream, hipStreamNonBlocking, prio) != hipSuccess) return bail(RL_ERR_DEVICE);
         e->pstream = e->own_pstream;
     } else {

@@ -372,8 +372,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_part(const Cell* __restrict__ 
         if (i < n) {
             const u32 d = dig[u];
             const u32 dst = tbase + s_base[d] + s_cnt[w * nbt + d] + rank[u];
-            *reinterpret_cast<uint4*>(b_hits + dst) =
-                make_uint4(raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24));
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 recv = {raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24)};
+            *reinterpret_cast<u32x4*>(b_hits + dst) = recv;
         }
     }
 }

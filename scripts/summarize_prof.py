@@ -30,7 +30,7 @@ NAN = float("nan")
 
 
 def short(name):
-    # `void rl::k_bkt_apply<1, 9, 6>(rl::Cell*, ...)` -> `rl::k_bkt_apply` (template arguments dropped: one
+    # `void rl::k_bkt_part<4>(rl::Cell*, ...)` -> `rl::k_bkt_part` (template arguments dropped: one
     # instantiation of each kernel runs in the bench)
     return name.split("(")[0].split("<")[0].replace("void ", "").strip()
 
@@ -126,7 +126,7 @@ lines.append("## Engine kernels (per launch)\n")
 lines.append("| kernel | avg us | FETCH_SIZE KiB | WRITE_SIZE KiB | TCC hit rate | EA RDREQ | EA WRREQ | HBM read MB | "
              "HBM write MB | pattern |")
 lines.append("|---|---|---|---|---|---|---|---|---|---|")
-PATTERN = {"rl::k_bkt_apply": "random"}
+PATTERN = {"rl::k_bkt_step": "random"}
 traffic = {}
 for k in sorted(eng_c, key=lambda k: -avg_us.get(k, 0)):
     if not k.startswith("rl::"):
@@ -149,7 +149,12 @@ for k in sorted(eng_c, key=lambda k: -avg_us.get(k, 0)):
                  f"{c.get('TCC_EA0_WRREQ_sum', NAN):.0f} | {rd_b / 1e6:.1f} | {wr_b / 1e6:.1f} | {pat} |")
 open(out + "_pmc.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
-json.dump({"source": tag, "kernels": traffic}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+import subprocess
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    commit = None
+json.dump({"source": tag, "commit": commit, "kernels": traffic}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for name in ("bench.json", "bench_under_trace.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
