@@ -18,7 +18,7 @@ $(LIB)/librl_storage.so: $(LIB)/librl_engine.so $(wildcard $(CSRC)/host/*.cpp $(
 
 $(LIB)/librl_sharded.so: $(LIB)/librl_engine.so $(CSRC)/host/rl_sharded.cpp include/rl_sharded.h
 	g++ -O2 -std=c++17 -fPIC -shared -pthread -D__HIP_PLATFORM_AMD__ -Iinclude -I$(ROCM)/include $(CSRC)/host/rl_sharded.cpp -o $@ \
-	    -L$(LIB) -lrl_engine -L$(ROCM)/lib -lamdhip64 -lrccl '-Wl,-rpath,$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+	    -L$(LIB) -lrl_engine -L$(ROCM)/lib -lamdhip64 -ldl '-Wl,-rpath,$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
 
 oracle/liblimitador_oracle.so: oracle/limitador_oracle.c oracle/limitador_oracle.h
 	$(MAKE) -C oracle

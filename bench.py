@@ -380,15 +380,37 @@ def main():
     verdicts = [verdict] + [torch.empty(args.batch, dtype=torch.uint8, device=dev) for _ in range(3)]
     torch.cuda.synchronize()
 
+    sharded_note = ""
     if sharded and args.sharded_impl == "abi":
+        # The C entry with its own RCCL communicator.  If ANY rank cannot bring it up (librccl not found or mapped twice,
+        # ncclCommInitRank failing on this node's topology, ...) EVERY rank falls back to the torch.distributed driver —
+        # the same routed step, driven from Python — and the line says so in config.parallelism.
         from limitador_amd import sharded_abi
 
-        idt = torch.zeros(sharded_abi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(sharded_abi.unique_id()), dtype=torch.uint8))
+        sh, why = None, ""
+        try:
+            idt = torch.zeros(sharded_abi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(sharded_abi.unique_id()), dtype=torch.uint8))
+        except Exception as ex:  # rank 0 could not even make an id: broadcast zeros, everybody fails below
+            why = f"unique_id: {ex}"
         dist.broadcast(idt, 0)
         torch.cuda.synchronize()
-        sh = sharded_abi.Sharded(eng, world, rank, args.batch, unique_id=bytes(idt.cpu().numpy()))
+        if not why:
+            try:
+                sh = sharded_abi.Sharded(eng, world, rank, args.batch, unique_id=bytes(idt.cpu().numpy()))
+            except Exception as ex:
+                why = f"rl_sharded_create_rccl: {ex}"
+        ok = torch.tensor([1 if sh is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if sh is not None:
+                sh.close()
+                sh = None
+            sys.stderr.write(f"bench.py rank {rank}: falling back to --sharded-impl torch ({why or 'another rank failed'})\n")
+            args.sharded_impl = "torch"
+            sharded_note = " [fell back from the C-ABI router: " + (why or "another rank failed") + "]"
+    if sharded and args.sharded_impl == "abi":
         pending = [0]
         if args.depth == 1:
             def step(i, now):
@@ -538,7 +560,7 @@ def main():
                        else f"{args.keys} keys/GPU, zipf {args.zipf}, {args.batch}-hit batch/GPU",
                        "keys_per_gpu": args.keys, "batch_per_gpu": args.batch, "zipf_s": args.zipf,
                        "table_capacity_cells": cap, "cell_bytes": 32, "table_bytes": cap * 32,
-                       "parallelism": (f"hash-sharded x{world}, RCCL all-to-all" + (" behind the C ABI (rl_sharded_*)" if args.sharded_impl == "abi" else " (torch.distributed)")) if sharded else "single GPU",
+                       "parallelism": (f"hash-sharded x{world}, RCCL all-to-all" + (" behind the C ABI (rl_sharded_*)" if args.sharded_impl == "abi" else " (torch.distributed)") + sharded_note) if sharded else "single GPU",
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
                        "overlap": "partition of batches k+1, k+2 (own stream) beside k_bkt_step of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
                        "denied_in_last_batch": denied,

@@ -179,8 +179,15 @@ int32_t rl_check_and_update_batch_device(rl_engine *e, const rl_hit *d_hits, uin
  * be in flight; they are applied in submission order, so the sequential contract holds across them, and the
  * partition of one overlaps the replay of the one before (two streams inside the engine).  d_verdict and
  * d_first_limited belong to the engine from _submit to the matching _collect (the partition pass writes the default
- * answer into them, the decision pass the denials): every element is defined at _collect.  While batches
- * are in flight every other entry point returns RL_ERR_BUSY. */
+ * answer into them, the decision pass the denials): every element is defined at _collect.  The replay of a batch is
+ * enqueued when the NEXT command is submitted or the batch itself is collected (rl_engine_record_event flushes it too).
+ * While batches are in flight:
+ *   - rl_is_within_limits_batch(_ex) and rl_get_counters are served — the reference serves them under the read lock
+ *     check_and_update itself holds (in_memory.rs:20-35,78,159-187): they are enqueued behind every batch submitted
+ *     so far, wait for that, and leave the batches in flight;
+ *   - rl_sweep_expired_submit joins the pipeline as a command of its own (below);
+ *   - every other entry point (the mutating ones, which take the reference's WRITE lock, in_memory.rs:40,48,199,243;
+ *     dumps, snapshots, resize) returns RL_ERR_BUSY. */
 int32_t rl_check_and_update_submit_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
                                           uint8_t *d_verdict, int32_t *d_first_limited);
 int32_t rl_check_and_update_collect(rl_engine *e);
@@ -218,6 +225,14 @@ int32_t rl_sweep_expired(rl_engine *e, uint64_t now_us, uint64_t *n_removed);
 /* The same, reporting the swept cells (up to cap rows, raw value / expiry; *n_removed = all of them): what a
  * host that interns identities needs in order to forget the keys of the cells that are gone. */
 int32_t rl_sweep_expired_rows(rl_engine *e, uint64_t now_us, rl_cell_row *out, uint64_t cap, uint64_t *n_removed);
+/* The sweep as a STREAM-ORDERED command of the batch pipeline (BASELINE.json configs[4]: "concurrent expiry sweep"):
+ * enqueued behind every batch submitted so far and in front of every later one, without draining the pipeline — it
+ * takes one of the three in-flight slots, like a batch of rl_check_and_update_submit_device, and is collected in
+ * submission order: rl_sweep_expired_collect (or rl_check_and_update_collect, which drops the count) when it is the
+ * oldest command in flight.  The result is the same as a blocking rl_sweep_expired called at that point of the
+ * sequence; the table is not compacted by it (tombstones are counted, the next blocking sweep / rl_compact compacts). */
+int32_t rl_sweep_expired_submit(rl_engine *e, uint64_t now_us);
+int32_t rl_sweep_expired_collect(rl_engine *e, uint64_t *n_removed);
 /* Force a compaction (rehash of live cells into a fresh table). */
 int32_t rl_compact(rl_engine *e);
 /* Rehash the live cells into a table of capacity_cells (rounded up to a power of two, >= 1024): how a
@@ -241,9 +256,15 @@ int32_t rl_snapshot_load(rl_engine *e, const char *path);
  * actor only the largest value seen in the current window counts (:96-110); expired rows are ignored (:83); the
  * earliest future expiry wins (:84); a cell that is expired at now restarts from the row (:85-87).  actor ==
  * self_actor: another replica's memory of OUR value, which only counts if it is larger (:91-95).  Actor ids are
- * 0..7; a key must not appear twice in one call.  Deviation, stated: a window restarted by a LOCAL update
- * (check_and_update / update_counter follow InMemoryStorage) forgets what the peers contributed to the old
- * window, where the reference's distributed storage keeps the `others` map until a merge resets it. */
+ * 0..7; a key must not appear twice in one call.
+ * DEVIATION (pinned by tests/test_gpu_merge.py::test_a_local_window_restart_drops_the_stale_peer_part_the_reference_keeps
+ * and exercised, not avoided, by ::test_merge_cells_matches_cr_counter_value): a window restarted by a LOCAL update.
+ * check_and_update / update_counter follow InMemoryStorage (atomic_expiring_value.rs:36-42: value = delta, expiry = now +
+ * window) and a peer's entry belongs to the window it was reported for, so the restarted cell reads `delta` and the
+ * peer's next report counts in full; CrCounterValue::inc_at (cr_counter_value.rs:53-59) resets only its own value and
+ * keeps the `others` of the expired window until a merge resets them (:85-87,144-149), so it reads delta + the stale
+ * part, and a later report of that peer only counts if it exceeds the stale figure (:96-110).  What a node exports as
+ * its own part (rl_export_local) is the same on both sides. */
 int32_t rl_merge_cells(rl_engine *e, uint32_t self_actor, uint32_t actor, const rl_cell_row *rows, uint64_t n,
                        uint64_t now_us);
 /* local_values() of every live, unexpired cell: (key, limit, OUR part of the value, expiry) — what a node

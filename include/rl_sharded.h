@@ -25,6 +25,14 @@
  * EVERY rank must issue the same sequence of rl_sharded_submit_device / rl_sharded_collect calls (they
  * contain collectives), with the same now_us for the same slice.
  *
+ * Failure is an outcome of the collective step, not an exit from it.  A slice that fails on ONE rank — more hits
+ * routed to it than its engine takes in one batch (RL_ERR_BATCH_TOO_LARGE), a full table (RL_ERR_TABLE_FULL), a
+ * malformed hit — still has every one of its exchanges issued by that rank (the receive buffers hold world x
+ * max_slice_hits records, so any skew can be received): its peers never wait for a send that does not come.  The
+ * failing rank answers 0xFF for every hit it owns in that slice (what an ingress rank then finds in d_verdict for
+ * those requests: neither 0 nor 1), applies nothing of it, and gets the error from rl_sharded_collect of THAT slice;
+ * the slices behind it proceed.
+ *
  * Transport: RCCL (ncclCommInitRank + grouped ncclSend / ncclRecv over xGMI) when the communicator is
  * created from a unique id; or any rl_transport the host supplies — `rl_local_group` below is an
  * in-process one (ranks = threads of one process, device-to-device copies), which is also how the
@@ -63,8 +71,10 @@ typedef struct {
 /* ncclGetUniqueId: call on one rank, hand the bytes to all ranks by whatever means the host has. */
 int32_t rl_sharded_unique_id(uint8_t id[RL_UNIQUE_ID_BYTES]);
 
-/* max_slice_hits: largest ingress slice of this rank.  The engine must have been created with
- * max_batch_hits >= the most hits this rank can RECEIVE for one slice (all ranks' slices may hash here).
+/* max_slice_hits: largest ingress slice of this rank.  The engine's max_batch_hits bounds what this rank can APPLY for
+ * one slice (all ranks' slices may hash here): create it with world x max_slice_hits to rule the failure above out.
+ * RCCL is bound at run time, to the librccl.so the process has already mapped if there is one (a host that uses
+ * torch.distributed): one process, one RCCL; two mapped copies are refused.
  * The engine is switched to the communicator's apply stream (rl_engine_set_stream) until rl_sharded_destroy
  * and must not be used directly while slices are in flight. */
 int32_t rl_sharded_create_rccl(rl_engine *e, uint32_t world, uint32_t rank, const uint8_t id[RL_UNIQUE_ID_BYTES],

@@ -82,6 +82,8 @@ def _declare(lib):
     _sig(lib, "rl_clear", C.c_int32, [p])
     _sig(lib, "rl_sweep_expired", C.c_int32, [p, C.c_uint64, u64p])
     _sig(lib, "rl_sweep_expired_rows", C.c_int32, [p, C.c_uint64, p, C.c_uint64, u64p])
+    _sig(lib, "rl_sweep_expired_submit", C.c_int32, [p, C.c_uint64])
+    _sig(lib, "rl_sweep_expired_collect", C.c_int32, [p, u64p])
     _sig(lib, "rl_compact", C.c_int32, [p])
     _sig(lib, "rl_resize", C.c_int32, [p, C.c_uint64])
     _sig(lib, "rl_load_cells", C.c_int32, [p, p, C.c_uint64])

@@ -78,7 +78,7 @@ def build_sharded(force=False, verbose=False):
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-D__HIP_PLATFORM_AMD__",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(rocm, "include"), src, "-o", SHARDED_SO,
-           "-L" + LIBDIR, "-lrl_engine", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
+           "-L" + LIBDIR, "-lrl_engine", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-ldl",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
         print(" ".join(cmd))

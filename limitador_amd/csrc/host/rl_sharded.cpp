@@ -5,7 +5,9 @@
 // must preserve are the sequential ones of check_and_update (in_memory.rs:72-156) on the concatenated slices.
 #include "rl_sharded.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <condition_variable>
@@ -13,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <deque>
 #include <mutex>
 #include <new>
@@ -32,9 +35,91 @@ struct Slice {
     int stage = ROUTED;
     uint32_t n_recv = 0;
     bool waits = false;  // a local batch was submitted to the engine for this slice
+    // The slice failed ON THIS RANK (more routed hits than the engine takes in one batch, a full table, ...).  A failure
+    // is an outcome of the collective step, not an exit from it: every exchange of the slice is still issued — a rank
+    // that returned early would leave its peers' grouped send / recv unmatched for ever — the hits this rank owns are
+    // answered 0xFF, and the error comes out of THIS slice's collect.
+    int32_t err = RL_OK;
+    char errmsg[200] = {0};
 };
 
+// RCCL is bound at RUN time, to the copy the process has already mapped if there is one: a host that also uses
+// torch.distributed has torch's own librccl.so loaded, and a second copy (the ROCm one this library used to link) in the
+// same process means two sets of proxy threads and IPC state for one set of GPUs.  One process, one RCCL.
+struct RcclApi {
+    void* handle = nullptr;
+    char path[512] = {0};
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+};
+
+struct RcclScan {
+    char first[512];
+    int count;
+};
+int rccl_phdr_cb(struct dl_phdr_info* info, size_t, void* data) {
+    auto* sc = static_cast<RcclScan*>(data);
+    const char* nm = info->dlpi_name;
+    if (!nm || !*nm) return 0;
+    const char* base = std::strrchr(nm, '/');
+    base = base ? base + 1 : nm;
+    if (std::strncmp(base, "librccl.so", 10) != 0) return 0;
+    if (sc->count == 0) std::snprintf(sc->first, sizeof(sc->first), "%s", nm);
+    sc->count++;
+    return 0;
+}
+
+RcclApi* rccl_api(char* err, size_t err_len) {
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (api.handle) return &api;
+    RcclScan sc{};
+    dl_iterate_phdr(rccl_phdr_cb, &sc);
+    if (sc.count > 1) {
+        std::snprintf(err, err_len, "%d copies of librccl.so are mapped into this process (first: %.300s): refusing to add a communicator", sc.count, sc.first);
+        return nullptr;
+    }
+    const char* candidates[] = {sc.count ? sc.first : nullptr, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* c : candidates) {
+        if (!c) continue;
+        h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            std::snprintf(api.path, sizeof(api.path), "%s", c);
+            break;
+        }
+    }
+    if (!h) {
+        std::snprintf(err, err_len, "librccl.so not found (%s)", dlerror());
+        return nullptr;
+    }
+#define RL_BIND(field, sym)                                                                  \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, sym));                        \
+    if (!api.field) {                                                                        \
+        std::snprintf(err, err_len, "%s has no %s", api.path, sym);                          \
+        dlclose(h);                                                                          \
+        return nullptr;                                                                      \
+    }
+    RL_BIND(GetUniqueId, "ncclGetUniqueId")
+    RL_BIND(CommInitRank, "ncclCommInitRank")
+    RL_BIND(CommDestroy, "ncclCommDestroy")
+    RL_BIND(GroupStart, "ncclGroupStart")
+    RL_BIND(GroupEnd, "ncclGroupEnd")
+    RL_BIND(Send, "ncclSend")
+    RL_BIND(Recv, "ncclRecv")
+#undef RL_BIND
+    api.handle = h;
+    return &api;
+}
+
 struct RcclTransport {
+    RcclApi* api = nullptr;
     ncclComm_t comm = nullptr;
     uint32_t world = 0;
 };
@@ -44,18 +129,18 @@ int32_t rccl_exchange(void* ctx, const rl_xfer* xs, uint32_t n, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     // one group = one launch: every segment's sends and receives to all peers travel concurrently over the
     // point-to-point xGMI links (RCCL's all-to-all-v as grouped ncclSend / ncclRecv)
-    if (ncclGroupStart() != ncclSuccess) return RL_ERR_DEVICE;
+    if (t->api->GroupStart() != ncclSuccess) return RL_ERR_DEVICE;
     bool ok = true;
     for (uint32_t k = 0; k < n && ok; ++k)
         for (uint32_t p = 0; p < t->world && ok; ++p) {
             if (xs[k].send_cnt[p])
-                ok = ncclSend(static_cast<const char*>(xs[k].send) + xs[k].send_off[p], xs[k].send_cnt[p], ncclUint8,
-                              (int)p, t->comm, st) == ncclSuccess;
+                ok = t->api->Send(static_cast<const char*>(xs[k].send) + xs[k].send_off[p], xs[k].send_cnt[p], ncclUint8,
+                                  (int)p, t->comm, st) == ncclSuccess;
             if (ok && xs[k].recv_cnt[p])
-                ok = ncclRecv(static_cast<char*>(xs[k].recv) + xs[k].recv_off[p], xs[k].recv_cnt[p], ncclUint8, (int)p,
-                              t->comm, st) == ncclSuccess;
+                ok = t->api->Recv(static_cast<char*>(xs[k].recv) + xs[k].recv_off[p], xs[k].recv_cnt[p], ncclUint8, (int)p,
+                                  t->comm, st) == ncclSuccess;
         }
-    if (ncclGroupEnd() != ncclSuccess) ok = false;
+    if (t->api->GroupEnd() != ncclSuccess) ok = false;
     return ok ? RL_OK : RL_ERR_DEVICE;
 }
 
@@ -176,11 +261,8 @@ int32_t apply(rl_sharded* s, Slice& p) {
         s->recv_cnt[slot][q] = s->h_counts[slot][W + q];
         ro += s->h_counts[slot][W + q];
     }
-    if (so != p.n) return fail(s, RL_ERR_DEVICE, "router counted %llu of %u hits", (unsigned long long)so, p.n);
-    if (ro > s->max_recv)
-        return fail(s, RL_ERR_BATCH_TOO_LARGE, "rank %u: %llu routed hits exceed the engine's max_batch_hits (%u)", s->rank,
-                    (unsigned long long)ro, s->max_recv);
-    p.n_recv = (uint32_t)ro;
+    if (so != p.n) return fail(s, RL_ERR_DEVICE, "router counted %llu of %u hits", (unsigned long long)so, p.n);  // (an engine bug, not an input)
+    p.n_recv = (uint32_t)ro;  // (the receive buffers hold world x max_slice hits: whatever the skew, it can be received)
     for (uint32_t q = 0; q < W; ++q) {
         s->b_so[q] = s->send_off[slot][q] * sizeof(rl_hit);
         s->b_sc[q] = s->send_cnt[slot][q] * sizeof(rl_hit);
@@ -195,16 +277,27 @@ int32_t apply(rl_sharded* s, Slice& p) {
     x.recv_off = s->b_ro.data();
     x.recv_cnt = s->b_rc.data();
     const int32_t rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
-    if (rc != RL_OK) return fail(s, rc, "exchange (hits) failed");
+    if (rc != RL_OK) return fail(s, rc, "exchange (hits) failed");  // (the transport itself is gone: nothing to keep in step with)
     HIP_S(s, hipEventRecord(s->ev_exchanged[slot], s->cs));
     if (s->as)
         HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[slot], 0));
     else
         ENG_S(s, rl_engine_wait_event(s->e, s->ev_exchanged[slot]));
-    if (p.n_recv) {
-        ENG_S(s, rl_check_and_update_submit_device(s->e, s->recv_hits[slot], p.n_recv, p.now, s->recv_verdict[slot], nullptr));
-        p.waits = true;
+    if (ro > s->max_recv) {
+        p.err = RL_ERR_BATCH_TOO_LARGE;
+        std::snprintf(p.errmsg, sizeof(p.errmsg), "rank %u: %llu routed hits exceed the engine's max_batch_hits (%u)", s->rank,
+                      (unsigned long long)ro, s->max_recv);
+    } else if (p.n_recv) {
+        const int32_t brc = rl_check_and_update_submit_device(s->e, s->recv_hits[slot], p.n_recv, p.now, s->recv_verdict[slot], nullptr);
+        if (brc == RL_OK) {
+            p.waits = true;
+        } else {
+            p.err = brc;
+            std::snprintf(p.errmsg, sizeof(p.errmsg), "rank %u: local batch refused: %s", s->rank, rl_last_error(s->e));
+        }
     }
+    if (p.err && p.n_recv)  // what this rank owed its peers: "failed" (on the exchange stream, in front of the verdict exchange)
+        HIP_S(s, hipMemsetAsync(s->recv_verdict[slot], 0xFF, p.n_recv, s->cs));
     if (s->as)
         HIP_S(s, hipEventRecord(s->ev_applied[slot], s->as));
     else
@@ -249,7 +342,10 @@ int32_t create_common(rl_engine* e, uint32_t world, uint32_t rank, uint32_t max_
     } else {
         ENG_S(s, rl_engine_set_stream(e, nullptr, 0));
     }
-    const size_t ms = max_slice_hits ? max_slice_hits : 1, mr = s->max_recv ? s->max_recv : 1;
+    // receive side: every rank's whole slice may hash to this one (the engine's max_batch_hits only bounds what it can
+    // APPLY in one batch: a slice that exceeds it fails as a collective outcome, see Slice::err)
+    const size_t ms = max_slice_hits ? max_slice_hits : 1;
+    const size_t mr = std::max<size_t>(s->max_recv ? s->max_recv : 1, (size_t)world * ms);
     for (int q = 0; q < SLOTS; ++q) {
         HIP_S(s, hipMalloc(&s->sorted[q], ms * sizeof(rl_hit)));
         HIP_S(s, hipMalloc(&s->perm[q], ms * sizeof(uint32_t)));
@@ -282,8 +378,14 @@ extern "C" {
 int32_t rl_sharded_unique_id(uint8_t id[RL_UNIQUE_ID_BYTES]) {
     static_assert(sizeof(ncclUniqueId) == RL_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
     if (!id) return RL_ERR_INVALID;
+    char why[600];
+    RcclApi* api = rccl_api(why, sizeof(why));
+    if (!api) {
+        std::fprintf(stderr, "rl_sharded_unique_id: %s\n", why);
+        return RL_ERR_DEVICE;
+    }
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess) return RL_ERR_DEVICE;
+    if (api->GetUniqueId(&u) != ncclSuccess) return RL_ERR_DEVICE;
     std::memcpy(id, &u, sizeof(u));
     return RL_OK;
 }
@@ -310,12 +412,19 @@ int32_t rl_sharded_create_rccl(rl_engine* e, uint32_t world, uint32_t rank, cons
     int32_t dev = 0;
     if (rl_engine_info(e, &dev, nullptr) != RL_OK) return RL_ERR_INVALID;
     if (hipSetDevice(dev) != hipSuccess) return RL_ERR_DEVICE;
+    char why[600];
+    RcclApi* api = rccl_api(why, sizeof(why));
+    if (!api) {
+        std::fprintf(stderr, "rl_sharded_create_rccl: %s\n", why);
+        return RL_ERR_DEVICE;
+    }
     auto* r = new (std::nothrow) RcclTransport();
     if (!r) return RL_ERR_NOMEM;
+    r->api = api;
     r->world = world;
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
-    if (ncclCommInitRank(&r->comm, (int)world, u, (int)rank) != ncclSuccess) {
+    if (api->CommInitRank(&r->comm, (int)world, u, (int)rank) != ncclSuccess) {
         delete r;
         return RL_ERR_DEVICE;
     }
@@ -324,7 +433,7 @@ int32_t rl_sharded_create_rccl(rl_engine* e, uint32_t world, uint32_t rank, cons
     t.exchange = rccl_exchange;
     const int32_t rc = rl_sharded_create(e, world, rank, &t, max_slice_hits, out);
     if (rc != RL_OK) {
-        ncclCommDestroy(r->comm);
+        api->CommDestroy(r->comm);
         delete r;
         return rc;
     }
@@ -337,9 +446,15 @@ void rl_sharded_destroy(rl_sharded* s) {
     (void)hipSetDevice(s->device);
     if (s->cs) (void)hipStreamSynchronize(s->cs);
     if (s->as) (void)hipStreamSynchronize(s->as);
-    if (s->e && s->as) (void)rl_engine_set_stream(s->e, nullptr, 0);  // back to the engine's own streams
+    // the local batches of slices nobody collected are still in flight on the engine: it would refuse to change streams
+    // (RL_ERR_BUSY) and keep pointing at the stream destroyed below
+    if (s->e)
+        for (const Slice& p : s->pending)
+            if (p.waits) (void)rl_check_and_update_collect(s->e);
+    bool engine_released = true;
+    if (s->e && s->as) engine_released = rl_engine_set_stream(s->e, nullptr, 0) == RL_OK;  // back to the engine's own streams
     if (s->rccl) {
-        ncclCommDestroy(s->rccl->comm);
+        s->rccl->api->CommDestroy(s->rccl->comm);
         delete s->rccl;
     }
     for (int q = 0; q < SLOTS; ++q) {
@@ -355,7 +470,7 @@ void rl_sharded_destroy(rl_sharded* s) {
         if (s->ev_applied[q]) (void)hipEventDestroy(s->ev_applied[q]);
     }
     if (s->cs) (void)hipStreamDestroy(s->cs);
-    if (s->as) (void)hipStreamDestroy(s->as);
+    if (s->as && engine_released) (void)hipStreamDestroy(s->as);  // (never destroy a stream the engine still references)
     delete s;
 }
 
@@ -393,11 +508,12 @@ int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) {
     if (p.stage == APPLIED && (rc = give_back(s, p)) != RL_OK) return rc;
     const Slice done = p;
     s->pending.pop_front();
-    if (n_applied) *n_applied = done.n_recv;
+    if (n_applied) *n_applied = done.err ? 0u : done.n_recv;
     if (done.waits) {
         rc = rl_check_and_update_collect(s->e);  // the status of the local batch this rank applied for the slice
         if (rc != RL_OK) return fail(s, rc, "local batch: %s", rl_last_error(s->e));
     }
+    if (done.err) return fail(s, done.err, "%s (every exchange of the slice was issued; the hits this rank owns were answered 0xFF)", done.errmsg);
     return RL_OK;
 }
 

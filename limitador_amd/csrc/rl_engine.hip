@@ -97,6 +97,8 @@ struct rl_engine {
     GenStatus* d_gst = nullptr;
     CellRow* d_row1 = nullptr;      // one staged row (rl_add_counter)
     Status* d_status = nullptr;
+    Status* d_sweep_st = nullptr;   // [4] status blocks of the stream-ordered sweeps, by in-flight slot
+    u64 last_sweep_removed = 0;
     Status* h_status = nullptr; // pinned
     BatchScratch* d_bs = nullptr;   // [BS_ROT + 1], rotating (see BS_ROT)
     u64 bs_seq = 0;                 // batches of the bucketed path (partitioned or tiny) submitted so far
@@ -110,6 +112,7 @@ struct rl_engine {
         hipEvent_t ev_a_prev = nullptr;  // "applied" of the partitioned batch before this one (idle time in front of a timed k_bkt_apply)
         u32 seq = 0;  // value the batch's last workgroup stores into h_st->n_removed
         bool settled = false;  // completion seen and its new cells already added to `live` (settle_inflight)
+        int kind = 0;          // 0: a batch; 1: a stream-ordered sweep (rl_sweep_expired_submit): h_st->n_ord = cells it removed
     } inflight[4];  // at most three in flight
     u64 sub_seq = 0, col_seq = 0;
     u64 inflight_hits = 0;
@@ -201,6 +204,7 @@ struct rl_engine {
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
     u32 gen_tiny_max = 64;   // general form: calls of up to this many hits take k_gen_tiny (RL_GEN_TINY_MAX=0 disables)
     u32 gen_seq = 0;
+    bool h_tiny_coherent = false;  // h_status / h_tiny are fine-grained (hipHostMallocCoherent): device stores reach the host in order
     uint8_t* h_tiny = nullptr;  // host-mapped staging of a tiny host-buffer call: the kernel reads and writes it directly
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
     BHit* d_bk_hits = nullptr;              // [PB_SETS][max_batch]
@@ -243,6 +247,10 @@ struct rl_engine {
 namespace {
 
 inline bool engine_busy(const rl_engine* e) { return e->sub_seq != e->col_seq || e->ph_open; }
+// The read-only entry points (is_within_limits, get_counters: the reference serves them under the read lock
+// check_and_update holds too, in_memory.rs:20-35,78,159-187) only refuse while a phased pass is open: with batches in
+// flight they are enqueued behind every batch submitted so far and wait for THAT, the batches stay in flight.
+inline bool engine_busy_for_reads(const rl_engine* e) { return e->ph_open; }
 
 
 // layout of rl_engine::h_tiny (host-mapped staging of a one-launch host-buffer call)
@@ -528,7 +536,12 @@ int settle_inflight(rl_engine* e) {
         if (f.settled) continue;
         rc = wait_done(e, f);
         if (rc) return rc;
-        e->live += f.h_st->n_inserted;
+        if (f.kind == 1) {
+            e->live -= f.h_st->n_ord;
+            e->tombs += f.h_st->n_ord;
+        } else {
+            e->live += f.h_st->n_inserted;
+        }
         e->inflight_hits -= f.n;
         f.settled = true;
     }
@@ -575,6 +588,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                         e->d_bs + BS_ROT, f.h_st, (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2);
         }
         HIP_TRY(e, hipGetLastError());
+        f.kind = 0;
         f.n = n;
         f.n_wg = 1;
         f.ntiles = 0;
@@ -731,6 +745,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     q.hot_long = e->hot_seen >= 64u ? e->hot_long_cfg : 0xFFFFFFFFu;
     e->part_seq++;
     e->n_part_batches++;
+    f.kind = 0;
     f.n = n;
     f.n_wg = q.n_wg;
     f.ntiles = ntiles;
@@ -766,9 +781,19 @@ int collect_k1_bucketed(rl_engine* e) {
             return wrc;
         }
         e->inflight_hits -= f.n;
-        e->live += f.h_st->n_inserted;
+        if (f.kind == 1) {
+            e->live -= f.h_st->n_ord;
+            e->tombs += f.h_st->n_ord;
+        } else {
+            e->live += f.h_st->n_inserted;
+        }
     }
     e->col_seq++;
+    if (f.kind == 1) {  // a stream-ordered sweep: nothing else to account for
+        e->last_sweep_removed = f.h_st->n_ord;
+        if (f.h_st->err) return status_to_error(e, f.h_st->err);
+        return RL_OK;
+    }
     if (e->apply_trace && f.n_wg > 1 && e->d_apply_trace) {
         // diagnostics: where the workgroups of k_bkt_apply spent their time (wall clock, 100 MHz)
         std::vector<unsigned long long> t((size_t)(BK_MAX + 1024) * 8);  // (the rows behind the replay's: the partition role's)
@@ -889,6 +914,7 @@ struct GenCall {
     int32_t* d_limited = nullptr;  // per request: id of the limit that limited it, -1 (rl_match_and_check_batch)
     const u32* d_hit_req_ext = nullptr;  // phased form: the caller's request id of every hit (any u32, equal = same request)
     bool hit_req_filled = false;         // e->d_hit_req already holds the request of every hit (k_match_fast wrote it)
+    bool host_mapped_results = false;    // every result pointer is fine-grained host-mapped memory (rl_engine::h_tiny)
 };
 
 // Partition of the pass's hits + k_gen_sort: everything up to the first fixpoint round.  A is filled for the kernels
@@ -1144,9 +1170,12 @@ int run_check_general(rl_engine* e, const GenCall& c) {
                 std::this_thread::yield();
             }
         }
-        // return only once the kernel has ended: the results (device or host-mapped memory) are then
-        // visible to any reader, not just to this stream
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        // Results in DEVICE memory: return only once the kernel has ended — they are then visible to any reader, not
+        // just to this stream.  Results in fine-grained host-mapped memory were stored, and acknowledged (the barrier
+        // in front of the completion word waits for every wave's stores), BEFORE the completion word went out on the
+        // same path, exactly like the rest of the status block: nothing to wait for (a stream synchronise is 10-15 us
+        // of a 45 us call).
+        if (!(c.host_mapped_results && e->h_tiny_coherent)) HIP_TRY(e, hipStreamSynchronize(e->stream));
         const u32 err = e->h_status->err, dropped = e->h_status->n_ord, created = e->h_status->n_inserted;
         e->live += created;
         if (err) return status_to_error(e, err);
@@ -1417,6 +1446,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_gst, sizeof(GenStatus));
     ALLOC(e->d_row1, sizeof(CellRow));
     ALLOC(e->d_status, sizeof(Status));
+    ALLOC(e->d_sweep_st, 4 * sizeof(Status));
     ALLOC(e->d_bs, (BS_ROT + 1) * sizeof(BatchScratch));  // the rotating ones + k_bkt_tiny's own
     if (hipMemset(e->d_bs, 0, (BS_ROT + 1) * sizeof(BatchScratch)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_total, sizeof(unsigned long long));
@@ -1464,13 +1494,16 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
 #undef ALLOC
     // Host-mapped blocks the device writes while the host polls them: fine-grained (coherent) memory, so a
     // device store is on its way to the host when the wave's vmcnt says so, not when the kernel ends.
-    auto host_block = [](void** p, size_t bytes) {
+    bool all_coherent = true;
+    auto host_block = [&all_coherent](void** p, size_t bytes) {
         if (hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) return true;
         (void)hipGetLastError();
+        all_coherent = false;
         return hipHostMalloc(p, bytes, hipHostMallocMapped) == hipSuccess;
     };
     if (!host_block((void**)&e->h_status, sizeof(Status))) return bail(RL_ERR_NOMEM);
     if (!host_block((void**)&e->h_tiny, TIO_BYTES)) return bail(RL_ERR_NOMEM);
+    e->h_tiny_coherent = all_coherent;
     if (hipHostMalloc((void**)&e->h_total, sizeof(unsigned long long)) != hipSuccess) return bail(RL_ERR_NOMEM);
     for (auto& ev : e->ev)
         if (hipEventCreate(&ev) != hipSuccess) return bail(RL_ERR_DEVICE);
@@ -1501,7 +1534,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_items,  e->d_apply_trace,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)
@@ -1660,14 +1693,19 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
             if (req_off) memcpy(t_off, req_off, ((size_t)n_req + 1) * sizeof(u32));
             u64* t_delta = reinterpret_cast<u64*>(e->h_tiny + TIO_OFF_DELTA);
             if (req_delta) memcpy(t_delta, req_delta, (size_t)n_req * sizeof(u64));
-            rc = general ? run_check_general(e, GenCall{t_hits, n_hits, req_off ? t_off : nullptr, n_req,
-                                                        req_delta ? t_delta : nullptr, now_us, load_counters != 0, false,
-                                                        t_verdict, t_first, t_rem, t_exp})
-                         : run_check_k1(e, t_hits, n_hits, now_us, t_verdict, first_limited ? t_first : nullptr);
+            if (general) {
+                GenCall gc{t_hits, n_hits, req_off ? t_off : nullptr, n_req, req_delta ? t_delta : nullptr, now_us, load_counters != 0,
+                           false, t_verdict, t_first, t_rem, t_exp};
+                gc.host_mapped_results = true;
+                rc = run_check_general(e, gc);
+            } else {
+                rc = run_check_k1(e, t_hits, n_hits, now_us, t_verdict, first_limited ? t_first : nullptr);
+            }
             if (rc) return rc;
-            // The completion word has been seen; the RESULTS are read only after the kernel has ended
-            // (its end-of-kernel release makes every store host-visible whatever the memory's caching).
-            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            // The completion word has been seen.  Fine-grained (coherent) staging: the results were stored and
+            // acknowledged before it, on the same path — they are there.  Otherwise they are read only after the kernel
+            // has ended (its end-of-kernel release makes every store host-visible whatever the memory's caching).
+            if (!e->h_tiny_coherent) HIP_TRY(e, hipStreamSynchronize(e->stream));
             memcpy(verdict, t_verdict, n_req);
             if (first_limited) memcpy(first_limited, t_first, (size_t)n_req * sizeof(int32_t));
             if (load_counters) {
@@ -1785,9 +1823,11 @@ int32_t rl_is_within_limits_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t 
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, within);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
-    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    if (engine_busy_for_reads(e)) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
+    rc = flush_pending_apply(e);  // behind every batch submitted so far
+    if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice, e->stream));
     if (delta) HIP_TRY(e, hipMemcpyAsync(e->d_req_delta, delta, (size_t)n_hits * sizeof(u64), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
@@ -1830,7 +1870,9 @@ int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_r
                         uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
-    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    if (engine_busy_for_reads(e)) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    const int rc = flush_pending_apply(e);  // behind every batch submitted so far
+    if (rc) return rc;
     return scan_locked<SCAN_GET>(e, limit, now_us, out, cap, n_out);
 }
 
@@ -1869,6 +1911,43 @@ int32_t rl_sweep_expired_rows(rl_engine* e, uint64_t now_us, rl_cell_row* out, u
 
 int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
     return rl_sweep_expired_rows(e, now_us, nullptr, 0, n_removed);
+}
+
+int32_t rl_sweep_expired_submit(rl_engine* e, uint64_t now_us) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->ph_open) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    if (e->sub_seq - e->col_seq >= 3) return fail(e, RL_ERR_BUSY, "three commands are already in flight: collect one first");
+    HIP_TRY(e, hipSetDevice(e->device));
+    int rc = flush_pending_apply(e);  // the sweep runs behind every batch submitted so far, in front of every later one
+    if (rc) return rc;
+    rl_engine::Inflight& f = e->inflight[e->sub_seq & 3u];
+    Status* ds = e->d_sweep_st + (e->sub_seq & 3u);
+    HIP_TRY(e, hipMemsetAsync(ds, 0, sizeof(Status), e->stream));
+    k_scan<SCAN_SWEEP><<<2048, 256, 0, e->stream>>>(e->table, e->cap, 0u, now_us, (CellRow*)nullptr, 0ull, ds, e->d_total);
+    k_post_status<<<1, 64, 0, e->stream>>>(ds, f.h_st, (u32)(e->sub_seq + 1));
+    HIP_TRY(e, hipGetLastError());
+    f.kind = 1;
+    f.n = 0;
+    f.n_wg = 0;
+    f.ntiles = 0;
+    f.timed = 0;
+    f.seq = (u32)(e->sub_seq + 1);
+    f.settled = false;
+    e->last_k1_was_part = false;
+    e->sub_seq++;
+    return RL_OK;
+}
+
+int32_t rl_sweep_expired_collect(rl_engine* e, uint64_t* n_removed) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "nothing in flight");
+    if (e->inflight[e->col_seq & 3u].kind != 1) return fail(e, RL_ERR_INVALID, "the oldest command in flight is a batch: rl_check_and_update_collect");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int rc = collect_k1_bucketed(e);
+    if (n_removed) *n_removed = e->last_sweep_removed;
+    return rc;
 }
 
 int32_t rl_compact(rl_engine* e) {

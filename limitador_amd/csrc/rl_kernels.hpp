@@ -439,4 +439,16 @@ __global__ __launch_bounds__(256) void k_export_local(const Cell* __restrict__ t
     }
 }
 
+// End of a stream-ordered maintenance command (rl_sweep_expired_submit): hand its device-side status to the host-mapped
+// block the caller polls, with the pipeline's completion protocol (apply_finish, rl_bucket.hpp) — the first 16 bytes
+// {err, n_ord = cells removed, n_inserted = 0, n_removed = the command's sequence number} are ONE store, written last.
+__global__ void k_post_status(const Status* __restrict__ d_st, Status* host_status, u32 done_seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* hp = reinterpret_cast<u32x4*>(host_status);
+    for (int q = 1; q < 4; ++q) hp[q] = u32x4{0, 0, 0, 0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_nontemporal_store(u32x4{d_st->err, d_st->n_removed, 0u, done_seq}, hp);
+}
+
 }  // namespace rl

@@ -184,6 +184,15 @@ class Engine:
         self._check(self._lib.rl_sweep_expired(self._h, int(now_us), C.byref(n)))
         return n.value
 
+    def sweep_expired_submit(self, now_us):
+        """The sweep as a stream-ordered command between the batches in flight (takes one of the three slots)."""
+        self._check(self._lib.rl_sweep_expired_submit(self._h, int(now_us)))
+
+    def sweep_expired_collect(self):
+        n = C.c_uint64(0)
+        self._check(self._lib.rl_sweep_expired_collect(self._h, C.byref(n)))
+        return n.value
+
     def compact(self):
         self._check(self._lib.rl_compact(self._h))
 

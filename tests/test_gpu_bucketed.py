@@ -325,3 +325,59 @@ def test_soak_of_the_two_stream_pipeline_with_batches_of_every_size(make_engine)
         done += 1
     assert done == len(plan)
     assert_same_state(eng, orc)
+
+
+def test_sweeps_between_batches_in_flight_and_reads_beside_them(make_engine):
+    """BASELINE.json configs[4]: "mixed TTLs with concurrent expiry sweep".  rl_sweep_expired_submit is a command of the
+    pipeline — three commands in flight, batches and sweeps interleaved, nothing drained in between — and the result is the
+    same events replayed into the oracle in submission order (the sweep is an explicit eviction event there).  The
+    read-only calls (is_within_limits, get_counters) are answered while batches are in flight: they see every batch
+    submitted before them."""
+    import ctypes as C
+
+    import torch
+
+    rng = np.random.default_rng(77)
+    rows = [(40, 1), (25, 2), (10**6, 60), (3, 0)]
+    eng, orc = pair(make_engine, rows, max_batch_hits=20_000, capacity_cells=1 << 16)
+    dev = torch.device("cuda", 0)
+    n = 20_000
+    now = NOW
+    pend = []  # ("batch", expected verdicts, device verdict tensor) | ("sweep", expected count)
+
+    def collect_one():
+        kind, want, got = pend.pop(0)
+        if kind == "batch":
+            eng.collect()
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy(), want)
+        else:
+            assert eng.sweep_expired_collect() == want
+
+    keep = []
+    for step in range(24):
+        if step % 3 == 2:
+            if len(pend) == 3:
+                collect_one()
+            eng.sweep_expired_submit(now)
+            pend.append(("sweep", orc.sweep_expired(now), None))
+        else:
+            idx = rng.integers(0, 6000, size=n)
+            h = make_hits(W.splitmix64(idx.astype(np.uint64)), (idx % 4).astype(np.uint32), rng.integers(1, 3, size=n).astype(np.uint32))
+            v, _f, _r, _e = orc.check_and_update(h, now)
+            d_hits = torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev)
+            d_v = torch.full((n,), 0xCC, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            keep.append((d_hits, d_v))
+            if len(pend) == 3:
+                collect_one()
+            eng.submit_device(d_hits.data_ptr(), n, now, d_v.data_ptr())
+            pend.append(("batch", v, d_v))
+        if step % 5 == 4:  # reads beside the commands in flight: as of everything submitted so far
+            probe = make_hits(W.splitmix64(np.arange(0, 300, dtype=np.uint64)), (np.arange(300) % 4).astype(np.uint32), 1)
+            assert np.array_equal(eng.is_within_limits(probe, now), orc.is_within_limits(probe, now))
+            assert eng.count_counters(0, now) == len(orc.get_counters(0, now))
+        now += int(rng.choice([1000, 300_000, 700_000]))
+    while pend:
+        collect_one()
+    assert_same_state(eng, orc)

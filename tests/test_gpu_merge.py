@@ -60,7 +60,10 @@ def test_merge_cells_matches_cr_counter_value(make_engine):
     keys = [int(k) for k in W.splitmix64(np.arange(1, 301, dtype=np.uint64))]
     window_of = {k: (LONG if i % 4 else SHORT) for i, k in enumerate(keys)}   # a quarter of the counters: 2 s windows
     limit_of = {k: (0 if window_of[k] == LONG else 1) for k in keys}
-    ours = {}                                   # key -> Cr(ourselves = 0): node 0 as the reference would hold it
+    ours = {}                                   # key -> Cr(ourselves = 0): node 0 as the ENGINE holds it (see "local" below)
+    ref = {}                                    # key -> Cr(ourselves = 0): node 0 as the reference would hold it
+    diverged = {}                               # keys on which a local restart has already separated the two
+    restarts = [0, 0]                           # local restarts seen; of those, with a stale `others` part
     peers = {p: {} for p in (1, 2, 3)}          # actor -> key -> Cr(ourselves = actor)
     now = NOW
 
@@ -81,9 +84,13 @@ def test_merge_cells_matches_cr_counter_value(make_engine):
     for step in range(40):
         op = rng.choice(["local", "peer_inc", "merge", "merge", "echo"])
         if op == "local":
-            # long-window counters only: a LOCAL restart of a window forgets the peers' part here, the reference's
-            # distributed storage keeps it (stated deviation, rl_engine.h); within a window both add to our own part
-            ks = [keys[i] for i in rng.choice(len(keys), size=60, replace=False) if window_of[keys[i]] == LONG]
+            # Every counter, the 2-second windows included.  Within a window both sides add to our own part.  A LOCAL
+            # RESTART of an expired window is the stated deviation (rl_engine.h): the engine follows InMemoryStorage —
+            # the cell restarts at `delta` — where CrCounterValue::inc_at (cr_counter_value.rs:53-59) resets only our own
+            # value and keeps the `others` map of the old window until a merge resets it (:85-87,144-149).  `ours` is the
+            # engine's side of that (a restart = a fresh CrCounterValue); `ref` stays the reference's, and at every restart
+            # the two differ by exactly the stale `others` the reference still adds.
+            ks = [keys[i] for i in rng.choice(len(keys), size=60, replace=False)]
             h = np.zeros(len(ks), dtype=HIT_DTYPE)
             for i, k in enumerate(ks):
                 d = int(rng.integers(1, 5))
@@ -91,7 +98,22 @@ def test_merge_cells_matches_cr_counter_value(make_engine):
                 c = ours.get(k)
                 if c is None:
                     c = ours[k] = Cr(0, U64, now + window_of[k])   # created by the update: (0, now + window)
-                c.inc_at(d, window_of[k], now)
+                    ref[k] = Cr(0, U64, now + window_of[k])
+                elif c.expiry_us <= now:
+                    c = ours[k] = Cr(0, U64, now + window_of[k])   # the engine's restart: nothing of the old window survives
+                    restarts[0] += 1
+                if ref[k].expiry_us <= now:
+                    ref[k].inc_at(d, window_of[k], now)
+                    stale = ref[k].read_at(now) - ref[k].local_value   # what the reference's `others` still hold
+                    c.inc_at(d, window_of[k], now)
+                    if not diverged.get(k):   # both sides agreed until this restart: the difference IS the stale part
+                        assert ref[k].read_at(now) - c.read_at(now) == stale, (k, stale)
+                    if stale:
+                        restarts[1] += 1
+                        diverged[k] = True
+                else:
+                    ref[k].inc_at(d, window_of[k], now)
+                    c.inc_at(d, window_of[k], now)
             eng.update_counters(h, now)
         elif op == "peer_inc":
             p = int(rng.integers(1, 4))
@@ -115,8 +137,11 @@ def test_merge_cells_matches_cr_counter_value(make_engine):
                         if c.expiry_us > now:   # first heard of from a peer
                             mine = ours[k] = Cr(0, U64, c.expiry_us)
                             mine.merge_at(incoming, now)
+                            ref[k] = Cr(0, U64, c.expiry_us)
+                            ref[k].merge_at(Cr.from_values(c.expiry_us, {p: c.local_value}), now)
                     else:
                         mine.merge_at(incoming, now)
+                        ref[k].merge_at(Cr.from_values(c.expiry_us, {p: c.local_value}), now)
                 eng.merge_cells(0, p, rows, now)
         else:  # a replica echoes what it remembers of OUR value: larger only after we lost state
             ks = [k for k in ours if window_of[k] == LONG and rng.random() < 0.2]
@@ -126,8 +151,68 @@ def test_merge_cells_matches_cr_counter_value(make_engine):
                     c = ours[k]
                     remembered = c.local_value + int(rng.integers(0, 3)) - 1 if c.local_value else 0
                     rows[i] = (k, limit_of[k], 0, max(0, remembered), c.expiry_us)
+                    ref[k].merge_at(Cr.from_values(c.expiry_us, {0: max(0, remembered)}), now)
                     c.merge_at(Cr.from_values(c.expiry_us, {0: max(0, remembered)}), now)
                 eng.merge_cells(0, 0, rows, now)
         check()
         now += int(rng.choice([0, 1000, SEC // 3, SEC]))
     assert len(ours) > 200
+    assert restarts[0] > 20 and restarts[1] > 5, restarts   # the deviation was exercised, not avoided
+
+
+def test_a_local_window_restart_drops_the_stale_peer_part_the_reference_keeps(make_engine):
+    """The one place rl_merge_cells' bookkeeping departs from CrCounterValue, pinned number by number: a window that is
+    restarted by a LOCAL update.  Reference (cr_counter_value.rs:53-59): inc_at stores the increment into our own value
+    and leaves `others` alone, so the next read is increment + what the peers had contributed to the OLD window, and a
+    later report of that peer only counts if it is larger than the stale figure (:96-110).  Engine: the update follows
+    InMemoryStorage (atomic_expiring_value.rs:36-42: value = delta, expiry = now + window) and a peer's entry belongs to
+    the window it was reported for, so the restarted cell reads `delta` and the peer's next report counts in full."""
+    from oracle import CrCounterValue as Cr
+
+    U64 = 2**64 - 1
+    W2 = 2 * SEC
+    eng = make_engine(capacity_cells=1 << 10)
+    eng.set_limits([(U64, 2)])
+    k = 0xABCDEF
+    ref = Cr(0, U64, NOW + W2)
+
+    def eng_read(now):
+        r = {int(x["key"]): x for x in eng.dump_cells()}.get(k)
+        return 0 if r is None or int(r["expiry_us"]) <= now else int(r["value"])
+
+    def one(key, limit, v, exp):
+        row = np.zeros(1, dtype=CELL_ROW_DTYPE)
+        row[0] = (key, limit, 0, v, exp)
+        return row
+
+    def hit(d):
+        h = np.zeros(1, dtype=HIT_DTYPE)
+        h[0] = (k, 0, d)
+        return h
+
+    t0 = NOW
+    # peer 1 reports 5 for the window that ends at t0 + 2 s; then 3 local hits: both sides read 8
+    eng.merge_cells(0, 1, one(k, 0, 5, t0 + W2), t0)
+    ref.merge_at(Cr.from_values(t0 + W2, {1: 5}), t0)
+    eng.update_counters(hit(3), t0)
+    ref.inc_at(3, W2, t0)
+    assert eng_read(t0) == ref.read_at(t0) == 8
+    # the window expires: both read 0
+    t1 = t0 + 3 * SEC
+    assert eng_read(t1) == ref.read_at(t1) == 0
+    # a LOCAL update restarts it: the reference still adds peer 1's 5 of the old window, the engine does not
+    eng.update_counters(hit(2), t1)
+    ref.inc_at(2, W2, t1)
+    assert ref.read_at(t1) == 7 and eng_read(t1) == 2
+    # peer 1 reports 1 for ITS new window: the reference keeps the larger stale 5, the engine counts the report
+    eng.merge_cells(0, 1, one(k, 0, 1, t1 + W2), t1)
+    ref.merge_at(Cr.from_values(t1 + W2, {1: 1}), t1)
+    assert ref.read_at(t1) == 7 and eng_read(t1) == 3
+    # what each side would send to its peers as "our own part" is the same: 2
+    assert ref.local_value == 2
+    assert {int(r["key"]): int(r["value"]) for r in eng.export_local(t1)}[k] == 2
+    # once the restarted window has expired too, a merge resets both (:85-87) and they agree again
+    t2 = t1 + 3 * SEC
+    eng.merge_cells(0, 1, one(k, 0, 4, t2 + W2), t2)
+    ref.merge_at(Cr.from_values(t2 + W2, {1: 4}), t2)
+    assert eng_read(t2) == ref.read_at(t2) == 4

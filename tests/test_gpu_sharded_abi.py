@@ -141,3 +141,83 @@ def test_routed_step_world_n_with_the_in_process_transport(world):
     for e in engines:
         e.close()
     group.close()
+
+
+def test_a_slice_that_fails_on_one_rank_is_a_collective_outcome_not_a_hang():
+    """a rank-local error used to leave the collective sequence (the failing rank returned before its
+    exchanges, its peers waited for ever) and the slice stuck in flight.  Now: rank 1's engine takes 12 000 hits per
+    batch; slice 1 routes more than that to it.  Every exchange of the slice is still issued, rank 1 answers 0xFF for
+    the hits it owns and gets RL_ERR_BATCH_TOO_LARGE from THAT slice's collect, rank 0 gets a normal collect; the slices
+    before and after are decided like one sequential storage that never saw the failed slice's hits on rank 1's keys."""
+    dev = torch.device("cuda", 0)
+    world, n, n_keys = 2, 10_000, 4000
+    group = sharded_abi.LocalGroup(world)
+    engines = [Engine(capacity_cells=1 << 16, max_batch_hits=(world * n if r == 0 else 12_000)) for r in range(world)]
+    for e in engines:
+        e.set_limits(ROWS)
+    ranks = [sharded_abi.Sharded(engines[r], world, r, n, transport=group.transport(r)) for r in range(world)]
+    rng = np.random.default_rng(21)
+    steps = 4
+    slices = [[_slice(rng, n, n_keys) for r in range(world)] for s in range(steps)]
+    # slice 1: keys owned by rank 1 only, on both ingress ranks -> 20 000 hits routed to an engine that takes 12 000
+    pool = W.splitmix64(np.arange(1, 60_000, dtype=np.uint64))
+    own1 = np.array([k for k in pool if engines[0].owner_of(k, world) == 1][:3000], dtype=np.uint64)
+    for r in range(world):
+        h = slices[1][r]
+        h["key"] = own1[rng.integers(0, len(own1), size=n)]
+        h["limit"] = (h["key"] % 2).astype(np.uint32)
+    owner = lambda hits: np.array([engines[0].owner_of(k, world) for k in hits["key"][:200]])  # noqa: E731
+    orc = oracle.OracleStorage()
+    orc.set_limits(ROWS)
+    now0 = W.NOW0_US
+    want = {}
+    for s in range(steps):
+        for r in range(world):
+            if s == 1:
+                want[(s, r)] = np.full(n, 0xFF, dtype=np.uint8)  # every hit of slice 1 is rank 1's: nothing applied
+            else:
+                want[(s, r)] = orc.check_and_update(slices[s][r], now0 + 1000 * s)[0]
+    dev_in = [[_to_dev(slices[s][r], dev) for r in range(world)] for s in range(steps)]
+    dev_out = [[torch.full((n,), 7, dtype=torch.uint8, device=dev) for r in range(world)] for s in range(steps)]
+    torch.cuda.synchronize()
+    outcomes = [[] for _ in range(world)]
+    errors = []
+
+    def run(r):
+        try:
+            sh = ranks[r]
+            for s in range(steps):
+                sh.submit(dev_in[s][r].data_ptr(), n, now0 + 1000 * s, dev_out[s][r].data_ptr())
+                if sh.in_flight == 3:
+                    outcomes[r].append(_collect(sh))
+            while sh.in_flight:
+                outcomes[r].append(_collect(sh))
+            sh.sync()
+        except Exception as ex:
+            errors.append((r, ex))
+
+    def _collect(sh):
+        try:
+            return ("ok", sh.collect())
+        except sharded_abi.ShardedError as ex:
+            return ("err", ex.code)
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck at the rendezvous"
+    torch.cuda.synchronize()
+    assert [o[0] for o in outcomes[0]] == ["ok"] * steps
+    assert [o[0] for o in outcomes[1]] == ["ok", "err", "ok", "ok"] and outcomes[1][1][1] == -7  # RL_ERR_BATCH_TOO_LARGE
+    assert owner(slices[1][0]).min() == 1
+    for s in range(steps):
+        for r in range(world):
+            assert np.array_equal(dev_out[s][r].cpu().numpy(), want[(s, r)]), f"slice {s} rank {r}"
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        e.close()
+    group.close()
