@@ -191,6 +191,15 @@ int32_t rl_check_and_update_batch_device(rl_engine *e, const rl_hit *d_hits, uin
 int32_t rl_check_and_update_submit_device(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
                                           uint8_t *d_verdict, int32_t *d_first_limited);
 int32_t rl_check_and_update_collect(rl_engine *e);
+/* _submit with the caller's event (hipEvent_t) recorded behind the batch's REPLAY — whenever the engine enqueues it (the
+ * next submit, the batch's collect, or rl_engine_flush): what a host that chains its own device work behind the verdicts
+ * (the multi-GPU router's verdict exchange) waits on, without forcing the replay out early.  An event that has not been
+ * recorded yet does not hold a stream that waits on it: call rl_engine_flush before waiting on the event of a batch
+ * that may still be the last one submitted. */
+int32_t rl_check_and_update_submit_device_ev(rl_engine *e, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
+                                             uint8_t *d_verdict, int32_t *d_first_limited, void *done_event);
+/* Enqueue whatever the engine is holding back (the replay of the batch submitted last). */
+int32_t rl_engine_flush(rl_engine *e);
 
 /* CounterStorage::is_within_limits (in_memory.rs:20-35), one verdict per hit, read-only:
  * within[i] = max_value >= value_at(now) + delta; a missing cell reads as 0. */
@@ -371,9 +380,10 @@ void *rl_engine_stream(rl_engine *e);
  * routing helpers below enqueue and return without blocking (the caller's stream order is the
  * synchronisation), and submit / collect give the same for the hot path. */
 int32_t rl_engine_set_stream(rl_engine *e, void *stream, int32_t external);
-/* Ordering against the engine's OWN streams without giving up their overlap: everything submitted after
- * rl_engine_wait_event waits for `event` (a hipEvent_t recorded by the caller, e.g. after the exchange that filled the
- * batch's buffers); rl_engine_record_event records `event` behind everything submitted so far (verdicts complete). */
+/* Ordering against the engine's OWN streams without giving up their overlap: the batch submitted NEXT
+ * (rl_check_and_update_submit_device*) reads its inputs only after `event` (a hipEvent_t recorded by the caller, e.g.
+ * after the exchange that filled the batch's buffers) — call it right in front of that submit; rl_engine_record_event
+ * records `event` behind everything submitted so far (verdicts complete). */
 int32_t rl_engine_wait_event(rl_engine *e, void *event);
 int32_t rl_engine_record_event(rl_engine *e, void *event);
 /* HIP-event timing of the kernels of the single-counter hot path: a timed launch carries its own

@@ -73,6 +73,8 @@ def _declare(lib):
          [p, p, C.c_uint32, p, C.c_uint32, C.c_uint64, C.c_int32, p, p, p, p])
     _sig(lib, "rl_check_and_update_submit_device", C.c_int32, [p, p, C.c_uint32, C.c_uint64, p, p])
     _sig(lib, "rl_check_and_update_collect", C.c_int32, [p])
+    _sig(lib, "rl_check_and_update_submit_device_ev", C.c_int32, [p, p, C.c_uint32, C.c_uint64, p, p, p])
+    _sig(lib, "rl_engine_flush", C.c_int32, [p])
     _sig(lib, "rl_is_within_limits_batch", C.c_int32, [p, p, C.c_uint32, C.c_uint64, p])
     _sig(lib, "rl_update_counter_batch", C.c_int32, [p, p, C.c_uint32, C.c_uint64])
     _sig(lib, "rl_is_within_limits_batch_ex", C.c_int32, [p, p, C.c_uint32, p, C.c_uint64, p])

@@ -41,6 +41,8 @@ struct Slice {
     // answered 0xFF, and the error comes out of THIS slice's collect.
     int32_t err = RL_OK;
     char errmsg[200] = {0};
+    bool applied_recorded = false;  // ev_applied[slot] has been recorded behind the slice's local batch
+    uint64_t id = 0;                // the slice's sequence number
 };
 
 // RCCL is bound at RUN time, to the copy the process has already mapped if there is one: a host that also uses
@@ -171,6 +173,7 @@ struct rl_sharded {
     std::vector<uint64_t> b_so, b_sc, b_ro, b_rc, v_so[2], v_sc[2], v_ro[2], v_rc[2], c_off, c_cnt;
     std::deque<Slice> pending;
     uint64_t seq = 0;
+    uint64_t last_engine_slice = ~0ull;  // the slice whose local batch was submitted to the engine last (its replay may be held back)
     mutable std::mutex mu;
     char err[320] = {0};
 };
@@ -212,6 +215,8 @@ void verdict_xfer(rl_sharded* s, const Slice& p, int which, rl_xfer* x) {
     x->recv_cnt = s->v_rc[which].data();
 }
 
+int32_t applied_event(rl_sharded* s, Slice& p);
+
 // ROUTED: partition by owner + GROUP A (counts of this slice, verdicts of the slices in `returned`)
 int32_t route(rl_sharded* s, const rl_hit* d_hits, uint32_t n, uint64_t now, uint8_t* out, const std::vector<Slice*>& returned) {
     const int slot = (int)(s->seq % SLOTS);
@@ -226,6 +231,8 @@ int32_t route(rl_sharded* s, const rl_hit* d_hits, uint32_t n, uint64_t now, uin
     ++nx;
     int which = 0;
     for (Slice* p : returned) {
+        const int32_t erc = applied_event(s, *p);
+        if (erc != RL_OK) return erc;
         HIP_S(s, hipStreamWaitEvent(s->cs, s->ev_applied[p->slot], 0));
         verdict_xfer(s, *p, which++, &xs[nx++]);
     }
@@ -242,6 +249,7 @@ int32_t route(rl_sharded* s, const rl_hit* d_hits, uint32_t n, uint64_t now, uin
     sl.n = n;
     sl.now = now;
     sl.out = out;
+    sl.id = s->seq;
     s->pending.push_back(sl);
     ++s->seq;
     return RL_OK;
@@ -288,9 +296,13 @@ int32_t apply(rl_sharded* s, Slice& p) {
         std::snprintf(p.errmsg, sizeof(p.errmsg), "rank %u: %llu routed hits exceed the engine's max_batch_hits (%u)", s->rank,
                       (unsigned long long)ro, s->max_recv);
     } else if (p.n_recv) {
-        const int32_t brc = rl_check_and_update_submit_device(s->e, s->recv_hits[slot], p.n_recv, p.now, s->recv_verdict[slot], nullptr);
+        // (an engine that keeps its two streams records "applied" itself, behind the replay, whenever that goes out)
+        const int32_t brc = rl_check_and_update_submit_device_ev(s->e, s->recv_hits[slot], p.n_recv, p.now, s->recv_verdict[slot],
+                                                                 nullptr, s->as ? nullptr : s->ev_applied[slot]);
         if (brc == RL_OK) {
             p.waits = true;
+            s->last_engine_slice = p.id;
+            if (!s->as) p.applied_recorded = true;
         } else {
             p.err = brc;
             std::snprintf(p.errmsg, sizeof(p.errmsg), "rank %u: local batch refused: %s", s->rank, rl_last_error(s->e));
@@ -298,16 +310,34 @@ int32_t apply(rl_sharded* s, Slice& p) {
     }
     if (p.err && p.n_recv)  // what this rank owed its peers: "failed" (on the exchange stream, in front of the verdict exchange)
         HIP_S(s, hipMemsetAsync(s->recv_verdict[slot], 0xFF, p.n_recv, s->cs));
-    if (s->as)
+    // "applied": on the communicator's own apply stream the event goes in right behind the batch.  An engine that keeps
+    // its two streams enqueues the batch's replay one submit LATE (so that the wait for its partition is answered by the
+    // host, rl_engine.h) and recording an event now would force it out behind a wait command: the event is recorded when
+    // the verdict exchange needs it (applied_event), two submits from now, by when the replay has long been enqueued.
+    if (s->as) {
         HIP_S(s, hipEventRecord(s->ev_applied[slot], s->as));
-    else
-        ENG_S(s, rl_engine_record_event(s->e, s->ev_applied[slot]));
+        p.applied_recorded = true;
+    }
     p.stage = APPLIED;
+    return RL_OK;
+}
+
+// ev_applied[slot] of an APPLIED slice, recorded by now
+int32_t applied_event(rl_sharded* s, Slice& p) {
+    // (the replay of the batch the engine was given LAST may still be held back, and its event with it; every earlier one
+    // went out when the next batch was submitted)
+    if (!s->as && p.id == s->last_engine_slice) ENG_S(s, rl_engine_flush(s->e));
+    if (!p.applied_recorded) {  // (no local batch for this slice: nothing received, or the slice failed here)
+        ENG_S(s, rl_engine_record_event(s->e, s->ev_applied[p.slot]));
+        p.applied_recorded = true;
+    }
     return RL_OK;
 }
 
 // RETURNED, outside a submit (the pipeline drains): the verdict exchange alone
 int32_t give_back(rl_sharded* s, Slice& p) {
+    const int32_t erc = applied_event(s, p);
+    if (erc != RL_OK) return erc;
     HIP_S(s, hipStreamWaitEvent(s->cs, s->ev_applied[p.slot], 0));
     rl_xfer x;
     verdict_xfer(s, p, 0, &x);

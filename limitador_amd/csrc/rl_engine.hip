@@ -190,7 +190,10 @@ struct rl_engine {
         int32_t* d_first = nullptr;
         bool t_apply = false;
         u32 hot_long = 0;
+        hipEvent_t done_event = nullptr;  // the caller's, recorded behind the replay when it goes out (rl_check_and_update_submit_device_ev)
     } pend;
+    hipEvent_t submit_done_event = nullptr;  // (argument of the submit being processed)
+    hipEvent_t input_event = nullptr;        // rl_engine_wait_event on a two-stream engine: gates the next batch's inputs
     u32 pipe_depth = 3;             // RL_PIPE_DEPTH (2 or 3): the partition of batch p waits for k_bkt_apply of batch p - depth
     hipEvent_t ev_parted[4]{}, ev_applied[4]{};
     hipEvent_t ev_match = nullptr;  // behind the copies of the matcher's count pass (match_and_check_locked)
@@ -520,9 +523,12 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
             ev1 = fp.ev_p_stop = fp.tev[1];
         }
     }
+    const hipEvent_t done_event = fa ? q.done_event : nullptr;
+    q.done_event = nullptr;
     launch_step(e, S, timed, ev0, ev1);
     HIP_TRY(e, hipGetLastError());
     if (fa && two_streams && e->apply_events && !e->ext_events) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
+    if (done_event) HIP_TRY(e, hipEventRecord(done_event, e->stream));
     return RL_OK;
 }
 
@@ -581,6 +587,10 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         // running beside it); the hot sets are left untouched
         rc = flush_pending_apply(e);
         if (rc) return rc;
+        if (e->input_event) {
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, e->input_event, 0));
+            e->input_event = nullptr;
+        }
         {
             const LimitDev* limits = e->d_limits;
             RL_LAUNCH_T(t_apply, f.tev[4], f.tev[5], k_bkt_tiny, 1, AP_BLOCK, e->stream, e->table, e->log2cap, e->seed, d_hits, n,
@@ -588,6 +598,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                         e->d_bs + BS_ROT, f.h_st, (u32)(e->sub_seq + 1), (u32)HOT_MAX / 2);
         }
         HIP_TRY(e, hipGetLastError());
+        if (e->submit_done_event) HIP_TRY(e, hipEventRecord(e->submit_done_event, e->stream));
         f.kind = 0;
         f.n = n;
         f.n_wg = 1;
@@ -629,6 +640,10 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     u32* runs = e->d_runs + (size_t)par * BKT_MAX * e->run_tt_max;
     HotItems* items = e->d_items + par;
     hipStream_t ps = e->pstream;
+    if (e->input_event) {  // (rl_engine_wait_event: this batch's inputs)
+        HIP_TRY(e, hipStreamWaitEvent(ps, e->input_event, 0));
+        e->input_event = nullptr;
+    }
     const Cell* ctable = e->table;
     const LimitDev* climits = e->d_limits;
     // ---- one stream: the partition of this batch rides in the launch that replays the batch before it (k_bkt_step) ----
@@ -737,6 +752,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     q.d_verdict = d_verdict;
     q.d_first = d_first;
     q.t_apply = t_apply;
+    q.done_event = e->submit_done_event;
     // The long-bucket rule (keys with a quarter of the threshold are promoted out of buckets of >= 1024 hits)
     // evens the buckets out — with 1024 buckets it fills all 512 hot buckets and is worth ~4 us per step — but on a
     // cold start every bucket is long and the first set would be 512 keys in arrival order, the Zipf head not
@@ -1594,8 +1610,18 @@ int32_t rl_engine_wait_event(rl_engine* e, void* event) {
     if (!e || !event) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);
     HIP_TRY(e, hipSetDevice(e->device));
+    if (e->pstream != e->stream) {
+        // Two streams: the event gates the NEXT batch's inputs, and the first kernel that reads them is its partition
+        // (the replay waits for the partition anyway).  Making the replay stream wait as well would hold back the
+        // replay of the batch BEFORE it, which goes out with the next submit and has nothing to do with these inputs.
+        if (e->input_event) {  // (one already waiting: it gates everything, the old way)
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, e->input_event, 0));
+            HIP_TRY(e, hipStreamWaitEvent(e->pstream, e->input_event, 0));
+        }
+        e->input_event = (hipEvent_t)event;
+        return RL_OK;
+    }
     HIP_TRY(e, hipStreamWaitEvent(e->stream, (hipEvent_t)event, 0));
-    if (e->pstream != e->stream) HIP_TRY(e, hipStreamWaitEvent(e->pstream, (hipEvent_t)event, 0));
     return RL_OK;
 }
 
@@ -1800,15 +1826,30 @@ int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_h
                                         first_limited, remaining, expires_in_us);
 }
 
-int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
-                                          uint8_t* d_verdict, int32_t* d_first_limited) {
+int32_t rl_check_and_update_submit_device_ev(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
+                                             uint8_t* d_verdict, int32_t* d_first_limited, void* done_event) {
     int rc = validate_batch(e, d_hits, n_hits, nullptr, n_hits, d_verdict);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->mu);
     if (n_hits == 0) return fail(e, RL_ERR_INVALID, "empty batch");
     if (e->ph_open) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
-    return submit_k1_bucketed(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
+    e->submit_done_event = (hipEvent_t)done_event;
+    rc = submit_k1_bucketed(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
+    e->submit_done_event = nullptr;
+    return rc;
+}
+
+int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
+                                          uint8_t* d_verdict, int32_t* d_first_limited) {
+    return rl_check_and_update_submit_device_ev(e, d_hits, n_hits, now_us, d_verdict, d_first_limited, nullptr);
+}
+
+int32_t rl_engine_flush(rl_engine* e) {
+    if (!e) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    return flush_pending_apply(e);
 }
 
 int32_t rl_check_and_update_collect(rl_engine* e) {
