@@ -41,6 +41,9 @@ extern "C" {
 typedef struct rli_ingest rli_ingest;
 
 #define RLI_HOST_ONLY (-100)      /* a condition or variable the device matcher does not evaluate */
+#define RLI_RESPONSE_TOO_LARGE (-102) /* rli_serve_batch: the request was decided and counted, its serialized response
+                                     * does not fit out_stride (rli_last_error names the size); every other
+                                     * request of the batch has its response */
 #define RLI_UNKNOWN_DOMAIN (-101) /* RateLimitRequest without a domain: the reference answers Code::Unknown
                                      without consulting the storage (envoy_rls/server.rs:105-115) */
 
@@ -114,7 +117,8 @@ int32_t rli_set_limit_name(rli_ingest *g, uint32_t limit_id, const char *name);
  *   over the request's counters sorted by remaining, X-RateLimit-Remaining, X-RateLimit-Reset of the most
  *   restrictive one (CheckResult::response_header, lib.rs:235-275; the counters are loaded: load_counters).
  * status[i]: 0 OK, 1 OVER_LIMIT, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY (the value dictionary is at its cap: the caller
- * evaluates this request itself; no response is produced), or < 0 for a malformed message. */
+ * evaluates this request itself; no response is produced), RLI_RESPONSE_TOO_LARGE (counted, but its response does not
+ * fit out_stride: out_len[i] = 0), or another value < 0 for a malformed message. */
 int32_t rli_serve_batch(rli_ingest *g, rl_engine *e, const uint8_t *const *msgs, const uint32_t *lens, uint32_t n,
                         uint64_t now_us, int32_t with_headers, uint8_t *out, uint32_t out_stride, uint32_t *out_len,
                         int32_t *status);

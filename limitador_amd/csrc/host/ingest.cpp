@@ -753,7 +753,11 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
                 continue;  // malformed / RLI_HOST_ONLY: no response, the status says why
             }
             if (o.size() > out_stride) {
+                // The request was decided and counted like the others; only ITS response does not fit the caller's
+                // stride (the reference has no bound on X-RateLimit-Limit: one entry per counter).  It alone is told.
                 too_long.store((uint32_t)o.size());
+                status[i] = RLI_RESPONSE_TOO_LARGE;
+                out_len[i] = 0;
                 continue;
             }
             memcpy(out + (size_t)i * out_stride, o.data(), o.size());
@@ -761,7 +765,8 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
         }
     });
     lap("responses");
-    if (too_long.load()) return gfail(g, RL_ERR_INVALID, "a response of %u bytes does not fit the stride %u", too_long.load(), out_stride);
+    if (too_long.load())  // (not an error of the call: the message names the size a retry needs)
+        (void)gfail(g, RL_OK, "a response of %u bytes does not fit the stride %u: status RLI_RESPONSE_TOO_LARGE for it", too_long.load(), out_stride);
     return RL_OK;
 }
 

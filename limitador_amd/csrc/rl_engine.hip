@@ -358,32 +358,55 @@ int check_room(rl_engine* e, u64 incoming, bool* need_count = nullptr) {
     }
 }
 
-// Rehash the live cells into a fresh table of 2^new_log2cap cells (0: same size — a compaction).
+// Rehash the live cells into a fresh table of 2^new_log2cap cells (0: same size — a compaction).  The peer tables
+// (rl_merge_cells) share the main table's geometry: EVERY new table is allocated and filled first and the pointers, the
+// capacity and the counters are committed together — a failure half-way frees the new ones and leaves the engine as it was.
 int do_compact(rl_engine* e, u32 new_log2cap) {
     if (!new_log2cap) new_log2cap = e->log2cap;
     Cell* fresh = nullptr;
+    Cell* fresh_peer[MERGE_MAX_ACTORS] = {};
+    auto undo = [&]() {
+        if (fresh) (void)hipFree(fresh);
+        for (auto& pf : fresh_peer)
+            if (pf) (void)hipFree(pf);
+    };
     int rc = alloc_table(e, 1ull << new_log2cap, &fresh);
-    if (rc) return rc;
-    HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-    k_rehash<<<2048, 256, 0, e->stream>>>(e->table, e->cap, fresh, new_log2cap, e->seed, e->d_status);
-    HIP_TRY(e, hipGetLastError());
-    rc = read_status(e);
+    for (u32 a = 0; a < (u32)MERGE_MAX_ACTORS && !rc; ++a)
+        if (e->peer_tables[a]) rc = alloc_table(e, 1ull << new_log2cap, &fresh_peer[a]);
     if (rc) {
-        (void)hipFree(fresh);
+        undo();
         return rc;
     }
-    HIP_TRY(e, hipFree(e->table));
-    e->table = fresh;
-    for (auto& pt : e->peer_tables) {  // the peer tables share the main table's geometry
-        if (!pt) continue;
-        Cell* pf = nullptr;
-        const int prc = alloc_table(e, 1ull << new_log2cap, &pf);
-        if (prc) return prc;
-        k_rehash<<<2048, 256, 0, e->stream>>>(pt, e->cap, pf, new_log2cap, e->seed, e->d_status);
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        HIP_TRY(e, hipFree(pt));
-        pt = pf;
+    hipError_t r = hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream);
+    if (r == hipSuccess) {
+        // (peer entries of windows that are over are not carried along: k_rehash copies live cells; a peer cell is "live"
+        // like any other, its expiry is checked where it is read)
+        for (u32 a = 0; a < (u32)MERGE_MAX_ACTORS; ++a)
+            if (e->peer_tables[a])
+                k_rehash<<<2048, 256, 0, e->stream>>>(e->peer_tables[a], e->cap, fresh_peer[a], new_log2cap, e->seed, e->d_status);
+        r = hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream);  // (n_inserted below counts the MAIN table's cells only)
     }
+    if (r == hipSuccess) {
+        k_rehash<<<2048, 256, 0, e->stream>>>(e->table, e->cap, fresh, new_log2cap, e->seed, e->d_status);
+        r = hipGetLastError();
+    }
+    if (r != hipSuccess) {
+        (void)hipStreamSynchronize(e->stream);
+        undo();
+        return fail(e, RL_ERR_DEVICE, "rehash failed: %s", hipGetErrorString(r));
+    }
+    rc = read_status(e);
+    if (rc) {
+        undo();
+        return rc;
+    }
+    (void)hipFree(e->table);
+    e->table = fresh;
+    for (u32 a = 0; a < (u32)MERGE_MAX_ACTORS; ++a)
+        if (e->peer_tables[a]) {
+            (void)hipFree(e->peer_tables[a]);
+            e->peer_tables[a] = fresh_peer[a];
+        }
     e->log2cap = new_log2cap;
     e->cap = 1ull << new_log2cap;
     e->stats.capacity_cells = e->cap;

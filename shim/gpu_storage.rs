@@ -134,8 +134,13 @@ extern "C" {
     fn rl_get_counters(e: *mut RlEngine, limit: u32, now_us: u64, out: *mut RlCellRow, cap: u64, n_out: *mut u64) -> i32;
     fn rl_delete_counters(e: *mut RlEngine, limit: u32) -> i32;
     fn rl_clear(e: *mut RlEngine) -> i32;
-    fn rl_sweep_expired(e: *mut RlEngine, now_us: u64, n_removed: *mut u64) -> i32;
+    fn rl_sweep_expired_rows(e: *mut RlEngine, now_us: u64, out: *mut RlCellRow, cap: u64, n_removed: *mut u64) -> i32;
 }
+
+// rl_status values this file looks at (include/rl_engine.h)
+const RL_ERR_INVALID: i32 = -1;
+const RL_ERR_MISSING_SIMPLE: i32 = -5;
+const RL_ERR_KEY_LIMIT: i32 = -6;
 
 // ---- errors ---------------------------------------------------------------------------------------
 /// An `rl_status` with the engine's message; becomes a `StorageErr` (`storage/mod.rs:312-339`).
@@ -173,8 +178,9 @@ struct Interner {
     limits: Vec<(Arc<Limit>, RlLimitRow)>,
     /// Counter identity -> exact u64 key
     counter_keys: HashMap<(u32, BTreeMap<String, String>), u64>,
-    /// key -> the counter's variables (get_counters rebuilds `Counter`s from the engine's rows)
-    by_key: HashMap<u64, BTreeMap<String, String>>,
+    /// key -> (limit id, the counter's variables): get_counters rebuilds `Counter`s from the engine's rows, and a
+    /// swept / deleted cell's identity is forgotten through it
+    by_key: HashMap<u64, (u32, BTreeMap<String, String>)>,
     key_seq: u64,
 }
 
@@ -231,8 +237,31 @@ impl Interner {
             }
         };
         self.counter_keys.insert((limit_id, vars.clone()), key);
-        self.by_key.insert(key, vars.clone());
+        self.by_key.insert(key, (limit_id, vars.clone()));
         key
+    }
+
+    /// The cell of `key` is gone (swept or deleted): forget the identity.  The key is never handed out again
+    /// (`key_seq` only grows), so a later counter with the same identity simply gets a fresh key and a fresh cell —
+    /// which is what the reference does when moka has evicted an entry (in_memory.rs:122-127).
+    fn forget_key(&mut self, key: u64) {
+        if let Some((limit_id, vars)) = self.by_key.remove(&key) {
+            self.counter_keys.remove(&(limit_id, vars));
+        }
+    }
+
+    /// Every qualified counter of `limit_id` is gone (delete_counters).  The simple counter's key stays: add_counter
+    /// re-creates its cell under the same identity (in_memory.rs:241-257 keeps no trace either way).
+    fn forget_limit(&mut self, limit_id: u32) {
+        let gone: Vec<u64> = self
+            .by_key
+            .iter()
+            .filter(|(_, (id, vars))| *id == limit_id && !vars.is_empty())
+            .map(|(k, _)| *k)
+            .collect();
+        for k in gone {
+            self.forget_key(k);
+        }
     }
 }
 
@@ -243,6 +272,8 @@ struct Pending {
     order: Vec<usize>,
     delta: u64,
     load_counters: bool,
+    /// the clock when the caller arrived (in_memory.rs:83 reads it per call): travels as the request's `req_now_us`
+    arrived_us: u64,
     result: Option<Result<Answer, GpuEngineError>>,
 }
 
@@ -272,7 +303,12 @@ pub struct GpuStorage {
     /// interner and the engine's limit table in step)
     call: Mutex<()>,
     max_batch: usize,
+    /// hits one engine batch may carry (the engine's max_batch_hits)
+    max_batch_hits: usize,
     max_delay: Duration,
+    /// interned qualified counters beyond which a batch leader sweeps the expired cells first — the bound moka's
+    /// `cache_size` gives the reference (in_memory.rs:205-212); 0 = never (the table grows, RL_CFG_AUTO_GROW)
+    sweep_after: usize,
 }
 
 // The engine handle is only used under `call` / by the batch leader; the engine itself is thread-safe.
@@ -287,11 +323,26 @@ impl GpuStorage {
     }
 
     pub fn with_options(capacity_cells: u64, max_batch: usize, max_delay: Duration, device: i32) -> Result<Self, StorageErr> {
+        Self::with_all_options(capacity_cells, max_batch, max_delay, device, 4096, (capacity_cells / 2) as usize)
+    }
+
+    /// `max_limits`: rows of the engine's limit table (limit identities ever seen; ids are not recycled);
+    /// `sweep_after`: see the field.
+    pub fn with_all_options(
+        capacity_cells: u64,
+        max_batch: usize,
+        max_delay: Duration,
+        device: i32,
+        max_limits: u32,
+        sweep_after: usize,
+    ) -> Result<Self, StorageErr> {
+        // up to 32 counters per request, within what the engine's 24-bit hit index allows
+        let max_batch_hits = max_batch.max(1).saturating_mul(32).min((1usize << 24) - 1);
         let cfg = RlConfig {
             device,
-            max_batch_hits: (max_batch.max(1) * 32) as u32, // up to 32 counters per request
+            max_batch_hits: max_batch_hits as u32,
             capacity_cells,
-            max_limits: 4096,
+            max_limits,
             flags: RL_CFG_AUTO_GROW, // the reference's storage never refuses a counter
             hash_seed: 0x9E37_79B9_7F4A_7C15,
         };
@@ -317,16 +368,30 @@ impl GpuStorage {
             queue_cv: Condvar::new(),
             call: Mutex::new(()),
             max_batch: max_batch.max(1),
+            max_batch_hits,
             max_delay,
+            sweep_after,
         })
     }
 
-    /// Drop every qualified cell whose window has ended (no reference analogue: it stands in for moka's
-    /// capacity eviction, in_memory.rs:208-210, and never changes a decision of an unexpired counter).
+    /// Drop every qualified cell whose window has ended, and forget the interned identity of each (no reference
+    /// analogue: it stands in for moka's capacity eviction, in_memory.rs:208-210, and never changes a decision of an
+    /// unexpired counter).  Runs by itself once more than `sweep_after` qualified counters are interned.
     pub fn sweep_expired(&self) -> Result<u64, StorageErr> {
+        let mut interner = self.interner.lock().unwrap();
         let _g = self.call.lock().unwrap();
+        Ok(self.sweep_locked(&mut interner)?)
+    }
+
+    /// (both locks held)
+    fn sweep_locked(&self, interner: &mut Interner) -> Result<u64, GpuEngineError> {
+        let cap = interner.by_key.len();
+        let mut rows = vec![RlCellRow::default(); cap];
         let mut removed = 0u64;
-        self.check(unsafe { rl_sweep_expired(self.engine, now_us(), &mut removed) })?;
+        self.check(unsafe { rl_sweep_expired_rows(self.engine, now_us(), rows.as_mut_ptr(), cap as u64, &mut removed) })?;
+        for row in rows.iter().take((removed as usize).min(cap)) {
+            interner.forget_key(row.key);
+        }
         Ok(removed)
     }
 
@@ -354,16 +419,33 @@ impl GpuStorage {
         })
     }
 
-    /// One device batch for `batch` (all with the same load_counters flag), results stored in place.
+    /// One device batch for `batch` (all with the same load_counters flag), results stored in place.  A batch the
+    /// engine REFUSES for what one request carries (a simple counter that was never add_counter'ed, a malformed hit:
+    /// validation errors, nothing applied) is re-run request by request, so that only the offending caller gets the
+    /// error — the reference fails that caller alone.
     fn run_batch(&self, batch: &mut [(u64, Pending)]) {
+        let rc = self.run_batch_once(batch);
+        if batch.len() > 1 && matches!(rc, RL_ERR_INVALID | RL_ERR_MISSING_SIMPLE | RL_ERR_KEY_LIMIT) {
+            for q in 0..batch.len() {
+                self.run_batch_once(&mut batch[q..q + 1]);
+            }
+        }
+    }
+
+    /// -> the engine's status (every request of `batch` has its `result` set)
+    fn run_batch_once(&self, batch: &mut [(u64, Pending)]) -> i32 {
         let load = batch[0].1.load_counters;
         let mut hits: Vec<RlHit> = Vec::new();
         let mut off: Vec<u32> = vec![0];
         let mut deltas: Vec<u64> = Vec::new();
+        let mut clocks: Vec<u64> = Vec::new();
         for (_, p) in batch.iter() {
             hits.extend_from_slice(&p.hits);
             off.push(hits.len() as u32);
             deltas.push(p.delta);
+            // one clock value per request, as each caller would have read it; the engine wants them non-decreasing
+            let t = p.arrived_us.max(clocks.last().copied().unwrap_or(0));
+            clocks.push(t);
         }
         let n_req = batch.len();
         let mut verdict = vec![0u8; n_req];
@@ -381,8 +463,8 @@ impl GpuStorage {
                     off.as_ptr(),
                     n_req as u32,
                     if big_delta { deltas.as_ptr() } else { std::ptr::null() },
-                    std::ptr::null(),
-                    now_us(),
+                    clocks.as_ptr(),
+                    *clocks.last().unwrap(),
                     load as c_int,
                     verdict.as_mut_ptr(),
                     first.as_mut_ptr(),
@@ -416,6 +498,7 @@ impl GpuStorage {
                 }
             });
         }
+        rc
     }
 
     /// Enqueue one request and wait for its answer.  The first caller to find no leader becomes the leader:
@@ -449,12 +532,28 @@ impl GpuStorage {
                 let mut batch: Vec<(u64, Pending)> = std::mem::take(&mut q.pending);
                 q.first_arrival = None;
                 drop(q);
-                // runs of equal load_counters (a property of the whole engine call), at most max_batch each
+                // the bound moka's cache_size gives the reference: past it, the expired cells go first
+                if self.sweep_after > 0 {
+                    let mut interner = self.interner.lock().unwrap();
+                    if interner.by_key.len() > self.sweep_after {
+                        let _g = self.call.lock().unwrap();
+                        let _ = self.sweep_locked(&mut interner);
+                    }
+                }
+                // runs of equal load_counters (a property of the whole engine call), at most max_batch requests and
+                // max_batch_hits counters each (a request with more counters than that is a batch by itself and the
+                // engine answers RL_ERR_BATCH_TOO_LARGE for it alone)
                 let mut start = 0;
                 while start < batch.len() {
                     let load = batch[start].1.load_counters;
                     let mut end = start + 1;
-                    while end < batch.len() && end - start < self.max_batch && batch[end].1.load_counters == load {
+                    let mut n_hits = batch[start].1.hits.len();
+                    while end < batch.len()
+                        && end - start < self.max_batch
+                        && batch[end].1.load_counters == load
+                        && n_hits + batch[end].1.hits.len() <= self.max_batch_hits
+                    {
+                        n_hits += batch[end].1.hits.len();
                         end += 1;
                     }
                     self.run_batch(&mut batch[start..end]);
@@ -569,6 +668,7 @@ impl CounterStorage for GpuStorage {
             order: order.clone(),
             delta,
             load_counters,
+            arrived_us: now_us(),
             result: None,
         })?;
         if load_counters {
@@ -587,7 +687,8 @@ impl CounterStorage for GpuStorage {
         })
     }
 
-    // in_memory.rs:159-187: every counter of the limits in the set whose ttl is > 0
+    // in_memory.rs:159-187: every counter of the limits in the set whose ttl is > 0.  (The reference walks its two
+    // maps and keeps what `limits` contains; asking the engine limit by limit returns the same set.)
     fn get_counters(&self, limits: &HashSet<Arc<Limit>>) -> Result<HashSet<Counter>, StorageErr> {
         let mut res = HashSet::new();
         let interner = self.interner.lock().unwrap();
@@ -609,7 +710,7 @@ impl CounterStorage for GpuStorage {
                 let vars: HashMap<String, String> = interner
                     .by_key
                     .get(&row.key)
-                    .map(|m| m.iter().map(|(k, v)| (k.clone(), v.clone())).collect())
+                    .map(|(_, m)| m.iter().map(|(k, v)| (k.clone(), v.clone())).collect())
                     .unwrap_or_default();
                 let mut counter = Counter::resolved_vars(Arc::clone(limit), vars).map_err(|e| GpuEngineError {
                     status: -1,
@@ -626,12 +727,14 @@ impl CounterStorage for GpuStorage {
 
     // in_memory.rs:190-195,241-257
     fn delete_counters(&self, limits: &HashSet<Arc<Limit>>) -> Result<(), StorageErr> {
-        let interner = self.interner.lock().unwrap();
+        let mut interner = self.interner.lock().unwrap();
         let _g = self.call.lock().unwrap();
         for limit in limits {
-            if let Some(&id) = interner.limit_ids.get(limit.as_ref()) {
+            let found = interner.limit_ids.get(limit.as_ref()).copied();
+            if let Some(id) = found {
                 let wire = id | if limit.variables().is_empty() { RL_SIMPLE } else { 0 };
                 self.check(unsafe { rl_delete_counters(self.engine, wire) })?;
+                interner.forget_limit(id); // the cells are gone: so are the interned identities of its counters
             }
         }
         Ok(())

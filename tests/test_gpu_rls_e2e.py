@@ -185,3 +185,67 @@ def test_large_batches_are_decoded_and_answered_by_several_threads(make_engine, 
         assert s1 == s7, f"batch {b}: statuses"
         assert r1 == r7, f"batch {b}: response bytes"
         assert sum(1 for s in s1 if s == 1) > 100 and sum(1 for s in s1 if s == 0) > 100 and any(s < -1 for s in s1)
+
+
+# The reference's own sandbox fixture, transcribed: limitador-server/sandbox/limits.yaml:1-22 (three variable-less limits
+# of one namespace, two conditions each on descriptors[0]['req.method'] / ['req.path']) and
+# limitador-server/sandbox/load-test.json (the request its load test sends: GET /json, hits_addend 1).
+SANDBOX_LIMITS = [
+    ("test_namespace", 10, 60, ["descriptors[0]['req.method'] == 'GET'", "descriptors[0]['req.path'] != '/json'"], []),
+    ("test_namespace", 5, 60, ["descriptors[0]['req.method'] == 'POST'", "descriptors[0]['req.path'] != '/json'"], []),
+    ("test_namespace", 50000, 10, ["descriptors[0]['req.method'] == 'GET'", "descriptors[0]['req.path'] == '/json'"], []),
+]
+SANDBOX_REQUEST = ("test_namespace", [[("req.method", "GET"), ("req.path", "/json")]], 1)
+
+
+def test_the_reference_sandbox_fixture_through_the_wire_path(make_engine):
+    """BASELINE.json configs[0]'s shape as the reference ships it: the limits FILE text through rli_add_limit, the load
+    test's request as wire bytes.  GET /json only meets the 50000 / 10 s limit: exactly 50 000 of 50 400 requests inside
+    one window are OK, the rest OVER_LIMIT, the headers count down; after the window everything is OK again.  Beside it
+    a mix of the other two limits' traffic.  Every status and every response byte against the pinned model + oracle."""
+    import re
+
+    Resp = _response_class()
+    eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 15)
+    g = Ingest()
+    model = TestsLimiter(oracle.OracleStorage(), now_us=NOW)
+    for ns, mx, secs, conds, variables in SANDBOX_LIMITS:
+        assert g.add_limit(ns, mx, secs, conds, variables) >= 0
+        # (the model takes the same conditions in its `key op 'value'` spelling)
+        model.add_limit(Limit(ns, mx, secs, [re.sub(r"descriptors\[0\]\['([^']+)'\]", r"\1", c) for c in conds], variables))
+    g.install(eng)
+    domain, descriptors, addend = SANDBOX_REQUEST
+    load = rls_request(domain, descriptors, hits_addend=addend)
+    ctx = dict(descriptors[0])
+    n_ok = n_over = 0
+    for batch in range(14):  # 14 x 3600 = 50 400 requests, 1 ms apart: all inside the 10 s window
+        now = model.now_us
+        status, responses = g.serve_batch(eng, [load] * 3600, now, with_headers=True)
+        for i in range(3600):
+            want = model.check_rate_limited_and_update(domain, ctx, addend, True)
+            assert status[i] == (1 if want.limited else 0), (batch, i)
+            if i % 97 == 0 or want.limited != (n_over > 0):
+                m = Resp()
+                m.ParseFromString(responses[i])
+                assert m.overall_code == (2 if want.limited else 1)
+                assert [(h.key, h.value) for h in m.response_headers_to_add] == sorted(want.response_header().items())
+            n_ok += not want.limited
+            n_over += want.limited
+        model.sleep(0.001)
+    assert (n_ok, n_over) == (50_000, 400)
+    # the other two limits of the file: GET elsewhere (10 / 60 s), POST elsewhere (5 / 60 s); POST /json meets none
+    mixed = [("GET", "/"), ("POST", "/x"), ("POST", "/json"), ("GET", "/json")] * 6
+    msgs = [rls_request(domain, [[("req.method", m_), ("req.path", p_)]], hits_addend=1) for m_, p_ in mixed]
+    status, responses = g.serve_batch(eng, msgs, model.now_us, with_headers=True)
+    for i, (m_, p_) in enumerate(mixed):
+        want = model.check_rate_limited_and_update(domain, {"req.method": m_, "req.path": p_}, 1, True)
+        assert status[i] == (1 if want.limited else 0), (i, m_, p_)
+        m = Resp()
+        m.ParseFromString(responses[i])
+        assert [(h.key, h.value) for h in m.response_headers_to_add] == sorted(want.response_header().items())
+    assert [status[i] for i in (1, 5, 9, 13, 17, 21)] == [0, 0, 0, 0, 0, 1]  # the sixth POST /x is the first over 5
+    # the 10 s window runs out: the load test's request is OK again
+    model.sleep(10.5)
+    status, _ = g.serve_batch(eng, [load] * 10, model.now_us, with_headers=False)
+    assert status == [0] * 10
+    g.close()
