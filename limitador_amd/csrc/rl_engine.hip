@@ -1209,12 +1209,12 @@ int run_check_general(rl_engine* e, const GenCall& c) {
                 std::this_thread::yield();
             }
         }
-        // Results in DEVICE memory: return only once the kernel has ended — they are then visible to any reader, not
-        // just to this stream.  Results in fine-grained host-mapped memory were stored, and acknowledged (the barrier
-        // in front of the completion word waits for every wave's stores), BEFORE the completion word went out on the
-        // same path, exactly like the rest of the status block: nothing to wait for (a stream synchronise is 10-15 us
-        // of a 45 us call).
-        if (!(c.host_mapped_results && e->h_tiny_coherent)) HIP_TRY(e, hipStreamSynchronize(e->stream));
+        // return only once the kernel has ended: the results (device or host-mapped memory) are then visible to any
+        // reader, not just to this stream
+        // (Tried and withdrawn: skipping the synchronise when the results live in fine-grained host memory — the stores were
+        // acknowledged before the completion word went out, but acknowledged is not "arrived in host memory in that
+        // order": tests/test_gpu_parity.py::test_u64_deltas_and_per_request_clocks failed one run in three.)
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
         const u32 err = e->h_status->err, dropped = e->h_status->n_ord, created = e->h_status->n_inserted;
         e->live += created;
         if (err) return status_to_error(e, err);
@@ -1751,10 +1751,9 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
                 rc = run_check_k1(e, t_hits, n_hits, now_us, t_verdict, first_limited ? t_first : nullptr);
             }
             if (rc) return rc;
-            // The completion word has been seen.  Fine-grained (coherent) staging: the results were stored and
-            // acknowledged before it, on the same path — they are there.  Otherwise they are read only after the kernel
-            // has ended (its end-of-kernel release makes every store host-visible whatever the memory's caching).
-            if (!e->h_tiny_coherent) HIP_TRY(e, hipStreamSynchronize(e->stream));
+            // The completion word has been seen; the RESULTS are read only after the kernel has ended
+            // (its end-of-kernel release makes every store host-visible whatever the memory's caching).
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
             memcpy(verdict, t_verdict, n_req);
             if (first_limited) memcpy(first_limited, t_first, (size_t)n_req * sizeof(int32_t));
             if (load_counters) {
