@@ -20,6 +20,7 @@
 #include <thread>
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -267,20 +268,101 @@ static uint32_t serve_threads(uint32_t n) {
     return std::max(1u, std::min(cap, n / 1024));
 }
 
+// The helper threads of the wire path's host side, started once (spawning and joining 31 threads twice per batch was
+// ~0.9 ms of a 3.8 ms batch of 32 768 messages): chunk c of a job is run by whichever thread takes it.
+class ChunkPool {
+    struct Job {
+        const std::function<void(uint32_t)>* f;
+        uint32_t total;
+        std::atomic<uint32_t> next{0};
+    };
+
+public:
+    static ChunkPool& get() {
+        static ChunkPool p;
+        return p;
+    }
+    // f(chunk) for chunk in [0, n_chunks), on the pool's threads and the caller's; returns when every chunk is done and
+    // no helper is inside the job any more.  One job at a time (callers queue up on `job_mu`).
+    void run(uint32_t n_chunks, const std::function<void(uint32_t)>& f) {
+        if (n_chunks <= 1 || workers.empty()) {
+            for (uint32_t c = 0; c < n_chunks; ++c) f(c);
+            return;
+        }
+        std::lock_guard<std::mutex> one(job_mu);
+        Job j;
+        j.f = &f;
+        j.total = n_chunks;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            job = &j;
+            ++generation;
+        }
+        cv_work.notify_all();
+        work(j);
+        std::unique_lock<std::mutex> l(mu);
+        job = nullptr;  // (a helper that wakes up late finds no job)
+        cv_done.wait(l, [&] { return active == 0; });
+    }
+
+private:
+    ChunkPool() {
+        uint32_t nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2));
+        if (const char* v = getenv("RLI_THREADS")) nt = (uint32_t)std::max(1, atoi(v));
+        for (uint32_t t = 1; t < nt; ++t) workers.emplace_back([this] { loop(); });
+    }
+    ~ChunkPool() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto& w : workers) w.join();
+    }
+    static void work(Job& j) {
+        for (;;) {
+            const uint32_t c = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= j.total) break;
+            (*j.f)(c);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> l(mu);
+        for (;;) {
+            cv_work.wait(l, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            Job* j = job;
+            if (!j) continue;
+            ++active;  // (under the lock: run() cannot return, and the job cannot die, while active != 0)
+            l.unlock();
+            work(*j);
+            l.lock();
+            if (--active == 0) cv_done.notify_all();
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex mu, job_mu;
+    std::condition_variable cv_work, cv_done;
+    Job* job = nullptr;
+    uint32_t active = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+};
+
 template <class F>
 static void parallel_chunks(uint32_t n, uint32_t threads, F f) {  // f(lo, hi)
     if (threads <= 1 || n == 0) {
         f(0u, n);
         return;
     }
-    std::vector<std::thread> th;
     const uint32_t per = (n + threads - 1) / threads;
-    for (uint32_t t = 1; t < threads; ++t) {
+    const std::function<void(uint32_t)> job = [&](uint32_t t) {
         const uint32_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
-        if (lo < hi) th.emplace_back([=] { f(lo, hi); });
-    }
-    f(0u, std::min(n, per));
-    for (auto& x : th) x.join();
+        if (lo < hi) f(lo, hi);
+    };
+    ChunkPool::get().run(threads, job);
 }
 
 extern "C" {
@@ -421,8 +503,11 @@ void rli_batch_clear(rli_ingest* g) {
 static int32_t encode_request(const rli_ingest* g_c, const std::string& ns, const std::vector<std::pair<std::string, std::string>>& entries,
                               uint32_t delta, EncReq* out, std::shared_lock<std::shared_mutex>* held = nullptr) {
     rli_ingest* g = const_cast<rli_ingest*>(g_c);
-    std::vector<std::pair<uint32_t, const std::string*>> kv;  // (key id, value)
-    std::vector<uint32_t> vids;
+    // (scratch that keeps its capacity from one request to the next: no allocation per request)
+    static thread_local std::vector<std::pair<uint32_t, const std::string*>> kv;  // (key id, value)
+    static thread_local std::vector<uint32_t> vids;
+    kv.clear();
+    vids.clear();
     size_t n_new = 0;
     {
         // (a thread that encodes many requests holds the shared lock across them — taking it per request makes
@@ -657,6 +742,7 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
                         int32_t* status) {
     if (!g || !e || (n && (!msgs || !lens || !out || !out_len || !status)) || out_stride < 2) return RL_ERR_INVALID;
     rli_batch_clear(g);
+    if (n == 0) return RL_OK;
     const uint32_t threads = serve_threads(n);
     const bool trace = getenv("RLI_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -665,11 +751,23 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
             std::fprintf(stderr, "[rli] %-10s at %8.1f us\n", what,
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    // ---- decode + dictionary encoding: every message on its own, many at a time ---------------------------
-    std::vector<EncReq> enc(n);
+    // ---- decode + dictionary encoding: every message on its own, many at a time.  A thread keeps the encoded entries
+    //      of its share of the messages in ONE flat list (no allocation per request) ------------------------------
+    struct EncSlot {
+        uint32_t ns, delta, kv_off, kv_cnt;
+    };
+    std::vector<EncSlot> enc(n);
+    const uint32_t per = threads > 1 ? (n + threads - 1) / threads : n;
+    const uint32_t n_chunks = per ? (n + per - 1) / per : 0;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> chunk_kv(n_chunks ? n_chunks : 1);
+    std::vector<uint32_t> chunk_req(n_chunks + 1, 0), chunk_ent(n_chunks + 1, 0);
     parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
         std::string domain;
         std::vector<std::pair<std::string, std::string>> entries;
+        EncReq tmp;
+        auto& flat = chunk_kv[lo / per];
+        flat.reserve((size_t)(hi - lo) * 4);
+        uint32_t n_ok = 0;
         std::shared_lock<std::shared_mutex> rd(g->dict_mu);
         for (uint32_t i = lo; i < hi; ++i) {
             if (((i - lo) & 255u) == 255u) {  // let a thread that has a new value to intern get its turn
@@ -681,16 +779,49 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
             uint32_t delta = 1;
             const char* what = "";
             int32_t rc = (lens[i] && !msgs[i]) ? (int32_t)RL_ERR_INVALID : decode_rls(msgs[i], lens[i], &domain, &entries, &delta, &what);
-            if (rc == 0) rc = encode_request(g, domain, entries, delta, &enc[i], &rd);
+            if (rc == 0) rc = encode_request(g, domain, entries, delta, &tmp, &rd);
+            if (rc == 0) {
+                enc[i] = EncSlot{tmp.ns, tmp.delta, (uint32_t)flat.size(), (uint32_t)tmp.kv.size()};
+                flat.insert(flat.end(), tmp.kv.begin(), tmp.kv.end());
+                ++n_ok;
+            }
             status[i] = rc;  // 0, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY, < 0
             out_len[i] = 0;
         }
+        chunk_req[lo / per + 1] = n_ok;
+        chunk_ent[lo / per + 1] = (uint32_t)flat.size();
     });
     lap("decoded");
-    // ---- the batch, in message order --------------------------------------------------------------------
+    // ---- the batch, in message order: every thread's share lands at its offset --------------------------------
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        chunk_req[c + 1] += chunk_req[c];
+        chunk_ent[c + 1] += chunk_ent[c];
+    }
     std::vector<int32_t> req_of(n, -1);
-    for (uint32_t i = 0; i < n; ++i)
-        if (status[i] == 0) req_of[i] = batch_append(g, enc[i]);
+    g->req_ns.resize(chunk_req[n_chunks]);
+    g->req_delta.resize(chunk_req[n_chunks]);
+    g->ent_off.resize((size_t)chunk_req[n_chunks] + 1);
+    g->ent_key.resize(chunk_ent[n_chunks]);
+    g->ent_val.resize(chunk_ent[n_chunks]);
+    g->ent_off[0] = 0;
+    parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
+        const uint32_t c = lo / per;
+        const auto& flat = chunk_kv[c];
+        uint32_t r = chunk_req[c];
+        const uint32_t e0 = chunk_ent[c];
+        for (uint32_t i = lo; i < hi; ++i) {
+            if (status[i] != 0) continue;
+            const EncSlot& q = enc[i];
+            g->req_ns[r] = q.ns;
+            g->req_delta[r] = q.delta;
+            for (uint32_t k = 0; k < q.kv_cnt; ++k) {
+                g->ent_key[e0 + q.kv_off + k] = flat[q.kv_off + k].first;
+                g->ent_val[e0 + q.kv_off + k] = flat[q.kv_off + k].second;
+            }
+            g->ent_off[r + 1] = e0 + q.kv_off + q.kv_cnt;
+            req_of[i] = (int32_t)r++;
+        }
+    });
     const uint32_t n_req = (uint32_t)g->req_ns.size();
     lap("appended");
     std::vector<uint8_t> verdict(n_req ? n_req : 1);
