@@ -301,11 +301,47 @@ def secondary(args, eng, dev, gen):
                             "--steps", "10"], capture_output=True, text=True, timeout=180)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         m = json.loads(line)
+        gbps = m["counters_per_batch"] * ALGO_BYTES_TOTAL / (m["ms_per_step"] * 1e-3) / 1e9
         out["configs4_shape_match_and_check_1M_requests"] = {
             "requests_per_s": m["requests_per_s"], "ms_per_call": m["ms_per_step"], "counters_per_call": m["counters_per_batch"],
+            # the same 49 B per (request x counter) as the headline, over the whole call (matcher + resolver)
+            "achieved_GBps_49B": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
             "note": "rl_match_and_check_batch_device: k_match_fast + general resolver (round 1: 2.03 ms per call)"}
     except Exception as ex:
         out["configs4_shape_match_and_check_1M_requests"] = {"error": str(ex)[:200]}
+    # -- the streaming maintenance kernels over the headline's table (LAST: they change it): a sweep that finds nothing
+    #    expired is a pure scan of the table (the kernel expected near the HBM roofline); a sweep as a
+    #    command between two batches in flight; a compaction (rehash of every live cell into a fresh table)
+    try:
+        table_bytes = eng.stats()["capacity_cells"] * 32
+        eng.sweep_expired(W.NOW0_US)  # (warm)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.sweep_expired(W.NOW0_US)
+        dt = (time.perf_counter() - t0) / 5
+        b2 = [W.torch_batch(args.keys, args.batch, dev, gen, None) for _ in range(2)]
+        v2 = [torch.empty(args.batch, dtype=torch.uint8, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.submit_device(b2[0].data_ptr(), args.batch, now[0], v2[0].data_ptr())
+        eng.sweep_expired_submit(W.NOW0_US)
+        eng.submit_device(b2[1].data_ptr(), args.batch, now[0] + 1000, v2[1].data_ptr())
+        eng.collect()
+        swept = eng.sweep_expired_collect()
+        eng.collect()
+        torch.cuda.synchronize()
+        dt_mix = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng.compact()
+        dt_c = time.perf_counter() - t0
+        out["sweep_and_compact_10M_keys"] = {
+            "sweep_ms": dt * 1e3, "sweep_GBps": table_bytes / dt / 1e9, "sweep_frac_of_8TBps": table_bytes / dt / 1e9 / HBM_PEAK_GBPS,
+            "batch_sweep_batch_in_flight_ms": dt_mix * 1e3, "swept_between_batches": int(swept),
+            "compact_ms": dt_c * 1e3, "table_bytes": table_bytes,
+            "note": "rl_sweep_expired (host call incl. its status read-back) over the 32-byte cells; rl_sweep_expired_submit "
+                    "between two 1 M-hit batches in flight; rl_compact"}
+    except Exception as ex:
+        out["sweep_and_compact_10M_keys"] = {"error": str(ex)[:200]}
     return out
 
 
