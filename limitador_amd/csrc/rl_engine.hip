@@ -1343,6 +1343,23 @@ static int32_t scan_locked(rl_engine* e, u32 limit, u64 now, rl_cell_row* out, u
     const u32 removed = e->h_status->n_removed;
     e->live -= removed;
     e->tombs += removed;
+    // The peer tables (rl_merge_cells) follow: what a remote actor contributed to a counter that is deleted or cleared,
+    // or to a window that is over, is dropped with it — they would otherwise only ever grow.  Their
+    // tombstones go with the main table's at the next compaction (do_compact rehashes all of them together).
+    if (MODE == SCAN_DELETE_LIMIT || MODE == SCAN_CLEAR_SIMPLE || MODE == SCAN_SWEEP) {
+        const u32 arg = MODE == SCAN_DELETE_LIMIT ? limit : (MODE == SCAN_CLEAR_SIMPLE ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+        const u64 t = MODE == SCAN_SWEEP ? now : 0ull;  // (expiry <= 0 never holds: only the sweep drops by time)
+        bool any = false;
+        for (Cell* pt : e->peer_tables)
+            if (pt) {
+                k_scan<SCAN_PEER><<<2048, 256, 0, e->stream>>>(pt, e->cap, arg, t, (CellRow*)nullptr, 0ull, e->d_status, e->d_total);
+                any = true;
+            }
+        if (any) {
+            HIP_TRY(e, hipGetLastError());
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+        }
+    }
     return RL_OK;
 }
 

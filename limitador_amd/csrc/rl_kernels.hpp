@@ -169,6 +169,9 @@ constexpr int SCAN_DELETE_LIMIT = 1; // tombstone cells of `arg_limit`          
 constexpr int SCAN_CLEAR_SIMPLE = 2; // tombstone simple cells                          (clear)
 constexpr int SCAN_SWEEP = 3;        // tombstone QUALIFIED cells with expiry <= now    (sweep_expired)
 constexpr int SCAN_DUMP = 4;         // append every live cell, raw                     (dump_cells)
+constexpr int SCAN_PEER = 5;         // a PEER table (rl_merge_cells): tombstone entries of windows that are over
+                                     // (expiry <= now), of `arg_limit` (delete_counters; ~0u: none) or — arg_limit ==
+                                     // 0xFFFFFFFE — of every simple limit (clear)
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_scan(Cell* __restrict__ table, u64 cap, u32 arg_limit,
@@ -196,6 +199,8 @@ __global__ __launch_bounds__(256) void k_scan(Cell* __restrict__ table, u64 cap,
         if (MODE == SCAN_CLEAR_SIMPLE) kill = live && (limit & SIMPLE_FLAG) != 0;
         if (MODE == SCAN_SWEEP) kill = live && !(limit & SIMPLE_FLAG) && (expiry <= now);
         if (MODE == SCAN_SWEEP) emit = kill && out_cap != 0;  // (rl_sweep_expired_rows: the swept cells are reported)
+        if (MODE == SCAN_PEER)
+            kill = live && (expiry <= now || limit == arg_limit || (arg_limit == 0xFFFFFFFEu && (limit & SIMPLE_FLAG) != 0));
         if (MODE == SCAN_GET || MODE == SCAN_DUMP || (MODE == SCAN_SWEEP && out_cap != 0)) {
             const u64 bal = __ballot(emit);
             if (out_cap == 0) {
