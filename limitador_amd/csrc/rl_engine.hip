@@ -171,6 +171,8 @@ struct rl_engine {
     // (50 us per step either way) — the ~11 us the replay's stream idles between two launches while the partition's queue
     // is busy (4.9 us when it is not, 1.7 us between plain launches of one queue) are not the events'.
     bool apply_events = true;
+    bool part_compact = true;       // RL_PART_COMPACT=0: k_bkt_part (1024 threads, ~78 KB of LDS) for 4096-hit tiles too instead of
+                                    // k_bkt_part_c (512 threads, ~41 KB: resident beside the replay's workgroups; 1.7 us per step)
     bool fuse = false;              // RL_FUSE=1: one stream, the partition of batch j + 1 as a role of the launch that replays batch j
                                     // (k_bkt_step; parity-green, but the role's 4-wave workgroups walk a tile in 2 x 16 dependent steps:
                                     // 57 us alone against 24 us for k_bkt_part's 16 waves — measured slower, kept for the record)
@@ -719,12 +721,20 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                  PT_BLOCK, scatter_lds_bytes(nbt), ps, ctable, e->log2cap, e->seed, d_hits, n, climits,                        \
                  (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, items,   \
                  hot_prod)
+#define RL_PART_C(STEPS)                                                                                                       \
+    RL_LAUNCH_TS(t || chain_p, t ? f.tev[0] : nullptr, f.ev_p_stop, k_bkt_part_c<STEPS>, ntiles + 1, PC_BLOCK,                 \
+                 (u32)PC_WAVES * nbt * (u32)sizeof(unsigned short) + 4u, ps, ctable, e->log2cap, e->seed, d_hits, n, climits,  \
+                 (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, items,   \
+                 hot_prod)
+    if (e->part_compact && steps == 4) RL_PART_C(8);  // (1024-hit tiles of small batches: the 1024-thread kernel is 1 us faster)
+    else
     switch (steps) {
         case 1: RL_PART(1); break;
         case 4: RL_PART(4); break;
         case 8: RL_PART(8); break;
         default: RL_PART(16); break;
     }
+#undef RL_PART_C
 #undef RL_PART
     HIP_TRY(e, hipGetLastError());
     if (need_count) {
@@ -1384,6 +1394,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
     if (const char* v = getenv("RL_APPLY_EVENTS")) e->apply_events = atoi(v) != 0;
     if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
+    if (const char* v = getenv("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0;
     if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch
     if (const char* v = getenv("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
     if (const char* v = getenv("RL_HOT_WGS")) e->hot_wgs = (u32)std::min(std::max(atoi(v), 8), 1024);

@@ -34,6 +34,8 @@ constexpr int TT_SMALL = 256;    // tiles a bucket view holds: the usual instant
 constexpr int TT_LARGE = 1024;   // ... and the one for the largest batches (MAX_BATCH_HITS / 16384 tiles)
 constexpr u32 PT_STEPS_MAX = 16; // 64-hit steps per wave in the largest tile (16384 hits)
 constexpr u32 HOT_NK_MAX = 64;   // most work items one hot bucket is split into (beyond: the items stride)
+constexpr int HOT_SLOTS = 2048;  // slots of the compact hot-set table (16-bit entries over the set's keys; load <= 1/4: a lookup looks
+                                 // at 1.3 slots on average)
 
 // runs[bin * TT + tile]: where the tile's hits of `bin` start inside the tile's window, how many there are, and (hot
 // bins) whether one of them carries another delta than the hot set predicts.
@@ -380,6 +382,258 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_part(const Cell* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_bkt_part_c: the same kernel in a COMPACT shape — 512 threads (8 waves, 8 x 64 hits per wave for a 4096-hit tile) and
+// ~41 KB of LDS instead of 1024 threads and ~78 KB: small enough to be resident on a CU BESIDE the five workgroups of
+// the replay (5 x 21.5 KB), where k_bkt_part's workgroups had to wait for two of them to leave (the replay's in-pipeline
+// stretch of the partition, 24 -> 40 us, is mostly that wait).  What shrank: wave-private counters for 8 waves, the hot
+// set as a 16-bit slot table over its keys (part_role's scheme), 16-bit bin starts.
+// ---------------------------------------------------------------------------------------------
+constexpr int PC_BLOCK = 512;
+constexpr int PC_WAVES = PC_BLOCK / 64;
+
+__device__ __forceinline__ u32 block_excl_scan_512(u32 v, u32* s_w, u32& total) {
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 o = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += o;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+#pragma unroll
+    for (u32 ww = 0; ww < (u32)PC_WAVES; ++ww) {
+        const u32 x = s_w[ww];
+        if (ww < w) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + inc - v;
+}
+
+template <int STEPS>
+__global__ __launch_bounds__(PC_BLOCK) void k_bkt_part_c(const Cell* __restrict__ table, u32 log2cap, u64 seed,
+                                                         const Hit* __restrict__ hits, u32 n,
+                                                         const LimitDev* __restrict__ limits, u32 n_limits, u32 bk_log2,
+                                                         u32 ntiles, u32 run_tt, BatchScratch* bs,
+                                                         const HotSet* __restrict__ hot, u32 check_simple,
+                                                         uint8_t* __restrict__ verdict_fill, int32_t* __restrict__ first_fill,
+                                                         BHit* __restrict__ b_hits, u32* __restrict__ runs,
+                                                         HotItems* __restrict__ items, HotSet* __restrict__ hot_next) {
+    extern __shared__ __align__(16) unsigned short s_cnt[];  // [PC_WAVES][nbt]
+    __shared__ unsigned short s_base[BKT_MAX];
+    __shared__ u64 s_hkey[HOT_MAX];
+    __shared__ unsigned short s_hslot[HOT_SLOTS];
+    __shared__ u32 s_hot_d[HOT_MAX], s_hot_limit[HOT_MAX];
+    __shared__ u32 s_mis[HOT_MAX / 32];
+    __shared__ u32 s_w[PC_WAVES];
+    const u32 tid = threadIdx.x;
+    if (blockIdx.x == ntiles) {
+        // ---- one extra workgroup: the replay's hot work items, from the hot set alone ----------------------------------
+        const u32 nh = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
+        u32 nk = 0;
+        if (tid < nh) {
+            const u32 want = (hot->cnt[tid] + HOT_CHUNK - 1) / HOT_CHUNK;
+            nk = want < 1u ? 1u : (want > HOT_NK_MAX ? HOT_NK_MAX : want);
+        }
+        u32 all;
+        const u32 c0 = block_excl_scan_512(nk, s_w, all);
+        u32* s_c0 = reinterpret_cast<u32*>(s_hkey);  // chunk0[0 .. HOT_MAX]
+        s_c0[tid] = c0;
+        if (tid == 0) {
+            s_c0[HOT_MAX] = all;
+            items->n = all;
+            hot_next->n = 0;  // the replay appends the keys it promotes or keeps
+        }
+        __syncthreads();
+        for (u32 c = tid; c < all; c += PC_BLOCK) {
+            u32 a = 0, b = HOT_MAX;  // invariant: chunk0[a] <= c < chunk0[b]
+            while (b - a > 1) {
+                const u32 m = (a + b) >> 1;
+                if (s_c0[m] <= c) a = m;
+                else b = m;
+            }
+            HotItem it{};
+            it.key = hot->key[a];
+            it.hb_k = a | ((c - s_c0[a]) << 16);
+            it.nk = s_c0[a + 1] - s_c0[a];
+            it.d = hot->d[a];
+            it.limit = hot->limit[a];
+            it.flg = hot->flg[a];
+            items->it[c] = it;
+        }
+        return;
+    }
+    u32 tile;
+    {
+        const u32 x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = ntiles >> 3, rem = ntiles & 7u;
+        tile = x * per + (x < rem ? x : rem) + j;
+    }
+    Status* st = &bs->st;
+    const u32 lane = tid & 63u, w = tid >> 6;
+    const u32 nb = 1u << bk_log2;
+    const u32 nbt = nb + HOT_MAX;
+    constexpr u32 TILE = PC_BLOCK * STEPS;
+    const u32 tbase = tile * TILE;
+    const u32 wbase = tbase + w * (64 * STEPS);
+    uint4 raw[STEPS];
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        raw[u] = *reinterpret_cast<const uint4*>(hits + (i < n ? i : n - 1));
+    }
+    // ---- LDS: empty tables; the hot set (one slot per key: a key listed twice keeps the smaller index) -------------
+    const u32 nh = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
+    const u64 hk = hot->key[tid < nh ? tid : 0u];
+    const u32 hd = hot->d[tid < nh ? tid : 0u], hl = hot->limit[tid < nh ? tid : 0u], hf = hot->flg[tid < nh ? tid : 0u];
+    for (u32 b = tid; b < (u32)(HOT_SLOTS / 2); b += PC_BLOCK) reinterpret_cast<u32*>(s_hslot)[b] = 0xFFFFFFFFu;
+    for (u32 b = tid; b < (PC_WAVES * nbt + 1) / 2; b += PC_BLOCK) reinterpret_cast<u32*>(s_cnt)[b] = 0u;
+    if (tid < (u32)(HOT_MAX / 32)) s_mis[tid] = 0u;
+    s_hkey[tid] = tid < nh ? hk : TAG_EMPTY;
+    s_hot_d[tid] = hd;
+    s_hot_limit[tid] = hl;
+    __syncthreads();
+    if (tid < nh) {
+        const u32 mine = tid | ((hf & HOT_FLG_DENY) ? 0x8000u : 0u);
+        u32 s = (u32)(fmix64(hk ^ seed) >> 8) & (HOT_SLOTS - 1);
+        for (;;) {
+            u32* wp = reinterpret_cast<u32*>(s_hslot) + (s >> 1);
+            const u32 sh = (s & 1u) * 16u;
+            u32 old = *wp;
+            bool done = false;
+            for (;;) {
+                const u32 x = (old >> sh) & 0xFFFFu;
+                const bool same = x != 0xFFFFu && s_hkey[x & 0x7FFFu] == hk;
+                if (x != 0xFFFFu && !same) break;       // another key's slot: probe on
+                if (same && (x & 0x7FFFu) <= tid) {     // the same key with a smaller index is there already
+                    done = true;
+                    break;
+                }
+                const u32 prev = atomicCAS(wp, old, (old & ~(0xFFFFu << sh)) | (mine << sh));
+                if (prev == old) {
+                    done = true;
+                    break;
+                }
+                old = prev;
+            }
+            if (done) break;
+            s = (s + 1) & (HOT_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    // ---- every hit: validated, its bin, its rank among the wave's hits of that bin (trace order) ----------------
+    unsigned short rank[STEPS];
+    unsigned short dig[STEPS];  // bin | (default answer "limited") << 15
+    const u64 lt = (1ull << lane) - 1ull;
+    u32 err = 0;
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        const bool ok = i < n;
+        const u64 valid = __ballot(ok);
+        const u64 key = ((u64)raw[u].y << 32) | raw[u].x;
+        const u32 limit = raw[u].z, delta = raw[u].w;
+        u32 d = 0;
+        bool deny = false;
+        if (ok) {
+            if ((limit & ~SIMPLE_FLAG) >= n_limits) err |= ERRBIT_BAD_LIMIT;
+            else if (key >= TAG_TOMB) err |= ERRBIT_RESERVED_KEY;
+            else if ((limit & SIMPLE_FLAG) && check_simple) {
+                u32 dummy = 0;
+                u32 slot = slot_of(key, seed, log2cap);
+                slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, key, limit, limits, 0ull,
+                                             st, dummy);
+                if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
+            }
+            const u64 hh = fmix64(key ^ seed);
+            int hi = -1;
+            u32 q = (u32)(hh >> 8) & (HOT_SLOTS - 1);
+            for (;;) {
+                const u32 x = s_hslot[q];
+                if (x == 0xFFFFu) break;
+                if (s_hkey[x & 0x7FFFu] == key) {
+                    hi = (int)(x & 0x7FFFu);
+                    deny = (x >> 15) != 0u;
+                    break;
+                }
+                q = (q + 1) & (HOT_SLOTS - 1);
+            }
+            if (hi >= 0) {
+                d = nb + (u32)hi;
+                // a hit that is not what the set predicts: the bucket is replayed hit by hit
+                if (delta != s_hot_d[hi] || limit != s_hot_limit[hi]) atomicOr(&s_mis[hi >> 5], 1u << (hi & 31));
+            } else {
+                d = bucket_of_hash(hh, bk_log2);
+            }
+            if (verdict_fill) {
+                verdict_fill[i] = deny ? 1 : 0;
+                if (first_fill) first_fill[i] = deny ? (int32_t)i : -1;
+            }
+        }
+        const u64 m = match_digit(d, (bk_log2 > 9u ? bk_log2 : 9u) + 1u, valid);
+        u32 r = 0;
+        if (ok) {
+            const u32 c = s_cnt[w * nbt + d];
+            r = c + (u32)__popcll(m & lt);
+            if ((m & lt) == 0ull) s_cnt[w * nbt + d] = (unsigned short)(c + (u32)__popcll(m));
+        }
+        rank[u] = (unsigned short)r;
+        dig[u] = (unsigned short)d;
+    }
+    if (err) atomicOr(&st->err, err);
+    __syncthreads();
+    // ---- per bin: the waves' exclusive offsets, the tile's count; exclusive scan over the bins = the runs' starts ----
+    {
+        constexpr int PER = 5;  // (nbt <= 2560 = 5 * 512)
+        const u32 b0 = PER * tid;
+        u32 c[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const u32 b = b0 + q;
+            u32 acc = 0;
+            if (b < nbt) {
+#pragma unroll
+                for (int ww = 0; ww < PC_WAVES; ++ww) {
+                    const u32 x = s_cnt[ww * nbt + b];
+                    s_cnt[ww * nbt + b] = (unsigned short)acc;
+                    acc += x;
+                }
+            }
+            c[q] = acc;
+            sum += acc;
+        }
+        u32 all;
+        u32 ex = block_excl_scan_512(sum, s_w, all);
+        u32* row = runs + tile;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const u32 b = b0 + q;
+            if (b < nbt) {
+                s_base[b] = (unsigned short)ex;
+                const bool mis = b >= nb && ((s_mis[(b - nb) >> 5] >> ((b - nb) & 31)) & 1u);
+                row[(size_t)b * run_tt] = run_pack(ex, c[q], mis);
+            }
+            ex += c[q];
+        }
+    }
+    __syncthreads();
+    // ---- the records, into the tile's own window: bins in order, every bin in trace order -----------------------
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+        const u32 i = wbase + u * 64 + lane;
+        if (i < n) {
+            const u32 d = dig[u];
+            const u32 dst = tbase + (u32)s_base[d] + s_cnt[w * nbt + d] + rank[u];
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 recv = {raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24)};
+            *reinterpret_cast<u32x4*>(b_hits + dst) = recv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The same partition as a ROLE of 256-thread workgroups, for k_bkt_step (rl_apply.hpp): the partition of batch j + 1
 // runs INSIDE the launch that replays batch j — one stream, one launch per step, no event between the two.  (As a
 // kernel of its own on a second stream, k_bkt_part cost the step 15 us: the replay slowed down beside its 16-wave
@@ -411,7 +665,6 @@ struct PartParams {
     HotItems* items;
     HotSet* hot_next;
 };
-constexpr int HOT_SLOTS = 2048;  // slots of the role's hot-set table (load <= 1/4: a lookup looks at 1.3 slots on average)
 struct PartLds {
     unsigned short cnt[PR_WAVES][PART_ROLE_BINS];  // wave-private counts, then every (wave, bin)'s first record in the tile's window
     u64 hkey[HOT_MAX];                             // the hot set's keys, by index

@@ -7,6 +7,7 @@ branch of the hot-key code (promotion, decided by position, replayed, created by
   RL_PIPE_DEPTH=2    the partition of batch p waits for the replay of batch p - 2
   RL_APPLY2_CFG=1    32-bit limit ids in LDS (what an engine with more than 32768 limit rows takes by itself)
   RL_OVERLAP=0       k_bkt_part and the replay on one stream
+  RL_PART_COMPACT=0  k_bkt_part (1024 threads) for 4096-hit tiles instead of k_bkt_part_c (512 threads, half the LDS)
   RL_APPLY_EVENTS=0  the replay as a plain launch; the partition stream ordered by what the host has collected
   RL_FUSE=1          one stream, one k_bkt_step launch per step: the replay of batch j and, beside it, the partition of batch
                      j + 1 as a role of 256-thread workgroups
@@ -24,7 +25,7 @@ from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [{}, {"RL_DEFER_APPLY": "0"}, {"RL_APPLY2_CFG": "1"}, {"RL_FUSE": "1"}, {"RL_OVERLAP": "0"},
-            {"RL_FUSE": "1", "RL_DEFER_APPLY": "0"}, {"RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"}, {"RL_APPLY_EVENTS": "0"}]
+            {"RL_FUSE": "1", "RL_DEFER_APPLY": "0"}, {"RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"}, {"RL_APPLY_EVENTS": "0"}, {"RL_PART_COMPACT": "0"}]
 
 
 def hot_trace(eng, orc, rng, n=60_000):
