@@ -117,3 +117,21 @@ def test_every_output_of_a_batch_is_defined_whatever_the_buffers_held(make_engin
         assert np.array_equal(d_f.cpu().numpy(), f), f"batch {step}"
         now += 1000
     assert_same_state(eng, orc)
+
+
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_both_shapes_of_the_partition_on_4096_hit_tiles(make_engine, monkeypatch, compact):
+    """Batches of more than 256 x 1024 hits take 4096-hit tiles: k_bkt_part_c (512 threads, the default) or k_bkt_part
+    (1024 threads, RL_PART_COMPACT=0).  300 000 Zipf hits per batch (74 tiles, the last one ragged), hot keys with mixed
+    limits, four batches so that the hot set is in use: every verdict and the final table against the oracle."""
+    monkeypatch.setenv("RL_PART_COMPACT", compact)
+    rng = np.random.default_rng(41)
+    n, n_keys = 300_000, 200_000
+    eng, orc = pair(make_engine, [(900, 60), (40, 60), (10**6, 60)], max_batch_hits=n, capacity_cells=1 << 20)
+    now = NOW
+    for step in range(4):
+        idx = (rng.zipf(1.15, size=n) - 1) % n_keys
+        h = make_hits(W.splitmix64(idx.astype(np.uint64)), (idx % 3).astype(np.uint32), 1 + (idx % 5 == 0).astype(np.uint32))
+        run_both(eng, orc, h, now)
+        now += 1000
+    assert_same_state(eng, orc)
