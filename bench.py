@@ -583,8 +583,8 @@ def main():
                 traffic = tk.get(kname, {}).get("hbm_bytes_per_launch")
                 l2_hit = tk.get(kname, {}).get("tcc_hit_rate")
                 # the whole batch pipeline (partition + hot state + replay), for the traffic / algorithmic ratio
-                pipeline_traffic = sum(tk.get(k, {}).get("hbm_bytes_per_launch") or 0.0 for k in
-                                       ("k_bkt_part", "k_bkt_step"))
+                pipeline_traffic = sum((v.get("hbm_bytes_per_launch") or 0.0) for k, v in tk.items()
+                                       if k.startswith("k_bkt_part") or k == "k_bkt_step")
             except Exception:
                 traffic = pipeline_traffic = l2_hit = None
         out = {
