@@ -247,6 +247,25 @@ def secondary(args, eng, dev, gen):
     dt = time.perf_counter() - t0
     out["host_buffers_1M_hits"] = {"decisions_per_s": args.batch * 6 / dt, "ms_per_call": dt / 6 * 1e3,
                                    "note": "rl_check_and_update_batch from pageable host arrays, PCIe inclusive"}
+    # the same call with the caller's arrays pinned in place once (rl_host_register: what a binding does with the
+    # staging buffers it reuses): the copies are DMA from / into the caller's pages
+    try:
+        vout = np.empty(args.batch, dtype=np.uint8)
+        for a in (hb[0], hb[1], vout):
+            eng.host_register(a)
+        eng.check_and_update(hb[0], now[0], want_first_limited=False, verdict_out=vout)
+        now[0] += 1000
+        t0 = time.perf_counter()
+        for i in range(6):
+            eng.check_and_update(hb[i & 1], now[0], want_first_limited=False, verdict_out=vout)
+            now[0] += 1000
+        dt = time.perf_counter() - t0
+        for a in (hb[0], hb[1], vout):
+            eng.host_unregister(a)
+        out["host_buffers_1M_hits_registered"] = {"decisions_per_s": args.batch * 6 / dt, "ms_per_call": dt / 6 * 1e3,
+                                                  "note": "the same arrays after rl_host_register (pinned in place), PCIe inclusive"}
+    except Exception as ex:  # noqa: BLE001
+        out["host_buffers_1M_hits_registered"] = {"error": str(ex)[:200]}
     del uni, hb
     # -- BASELINE.json configs[1]: 1 M keys, uniform 64 k-hit batches
     e1 = Engine(capacity_cells=1 << 22, max_batch_hits=1 << 16, device=eng.device)

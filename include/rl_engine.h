@@ -121,6 +121,14 @@ int32_t rl_stats(rl_engine *e, rl_stats_t *out);
 /* The device ordinal and max_batch_hits the engine was created with (either pointer may be NULL). */
 int32_t rl_engine_info(rl_engine *e, int32_t *device, uint32_t *max_batch_hits);
 
+/* Host arrays the caller reuses from call to call (the binding's batch staging: hits in, verdicts out) can be PINNED
+ * in place once: the copies of every later host-buffer call that reads or writes inside [ptr, ptr + bytes) are then
+ * plain DMA from / into the caller's own pages instead of the runtime's pageable path (staging copies on a CPU thread).
+ * No reference analogue (the reference has no device).  The range must stay mapped until rl_host_unregister(ptr) —
+ * unregister before freeing or reallocating the array.  Returns RL_ERR_INVALID if the runtime refuses the range. */
+int32_t rl_host_register(rl_engine *e, void *ptr, uint64_t bytes);
+int32_t rl_host_unregister(rl_engine *e, void *ptr);
+
 /* ---- limits --------------------------------------------------------------------------- */
 /* Upload rows [first, first+n) of the limit table (max_value / seconds of interned limits). */
 int32_t rl_limits_set(rl_engine *e, uint32_t first, const rl_limit_row *rows, uint32_t n);

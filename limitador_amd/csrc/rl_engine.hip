@@ -240,6 +240,17 @@ struct rl_engine {
     u32* d_m_flags = nullptr;
     void* d_m_scan_tmp = nullptr;
     size_t m_scan_tmp_bytes = 0;
+    // the slot form without library scan / copies / marker (k_match_count2 -> k_match_scan2 -> k_match_fill2): the
+    // workgroups' totals, the call counter, and the host-mapped 16 bytes {total, error bits, 0, call} the scan stores
+    MatchScan* d_m_scan1 = nullptr;
+    u32* h_m_word = nullptr;
+    u32 m_call = 0;
+    bool match_one = true;      // RL_MATCH_ONE=0: count pass + library scan + two copies + an event + fill pass
+    // end of a general pass: {error bits, cells created, flags, sequence number} as one 16-byte store (k_gen_post)
+    bool gen_clean = false;     // d_bs[0..BS_ROT) and d_gst are zero (the last stream command was a general pass's clean-up)
+    u32* h_gen_word = nullptr;
+    u32 gen_post_seq = 0;
+    bool gen_post = true;       // RL_GEN_POST=0: two copy commands + a stream synchronise
 
     rl_stats_t stats{};
 
@@ -434,6 +445,20 @@ int wait_done(rl_engine* e, rl_engine::Inflight& f) {
     return RL_OK;
 }
 
+// Poll a host-mapped word a kernel stores last (the 16-byte block it is part of is ONE store).
+int wait_word(rl_engine* e, const u32* word, u32 seq, const char* what) {
+    const auto t_start = std::chrono::steady_clock::now();
+    for (u64 spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0xFFFFu) {
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                return fail(e, RL_ERR_DEVICE, "%s did not complete within 60 s", what);
+            std::this_thread::yield();
+        }
+    }
+    return RL_OK;
+}
+
 // the partition kernels' wave-private counters (dynamic LDS): PT_WAVES x (hash buckets + hot buckets) x 2 bytes
 inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof(unsigned short); }
 
@@ -601,6 +626,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         if (!rc) rc = check_room(e, n + e->inflight_hits, &need_count);
         if (rc) return rc;
     }
+    e->gen_clean = false;  // (this batch's scratch block is not the general resolver's to find clean)
     rl_engine::Inflight& f = e->inflight[e->sub_seq & 3u];
     // timing: 1 both kernels of every batch, 2 k_bkt_apply of every batch, 3 both kernels of every fourth batch
     const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
@@ -992,8 +1018,13 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     const u32 nb = 1u << bk_log2, nbt = nb + HOT_MAX;
     const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
     const u32 ntiles = cdiv(n, small ? PT_TILE_SMALL : PT_TILE);
-    HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), st));
-    HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
+    // (a pass that follows a pass finds both blocks as its predecessor's clean-up left them: two fill commands less
+    // in front of the first kernel)
+    if (!e->gen_clean) {
+        HIP_TRY(e, hipMemsetAsync(bs, 0, sizeof(BatchScratch), st));
+        HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
+    }
+    e->gen_clean = false;
     auto hist_k = small ? k_bkt_hist<1> : k_bkt_hist<PT_STEPS>;
     hist_k<<<ntiles, PT_BLOCK, 0, st>>>(e->table, e->log2cap, e->seed, hits, n, e->d_limits, (u32)e->h_limits.size(), bk_log2,
                                         ntiles, e->d_bk_hist, bs, hot_use, c.update_mode ? 0u : 1u, nullptr, nullptr, nullptr);
@@ -1111,6 +1142,8 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     GenStatus h_gst;
     auto cleanup = [&]() -> int {  // leave the rotating scratches clean for whatever batch comes next
         HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), st));
+        HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
+        e->gen_clean = true;
         return RL_OK;
     };
     for (;;) {
@@ -1137,9 +1170,35 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         if (count_first) k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A);
         k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
         HIP_TRY(e, hipGetLastError());
+        if (e->gen_post) {
+            // what the host decides on, as ONE 16-byte store into host-mapped memory behind the last kernel: no copy
+            // command, no stream synchronise (the pass's results are complete when the word is there: k_gen_post runs
+            // behind the kernels that wrote them)
+            const u32 seq = ++e->gen_post_seq ? e->gen_post_seq : ++e->gen_post_seq;
+            k_gen_post<<<1, 64, 0, st>>>(e->d_gst, &bs->st, e->h_gen_word, seq);
+            HIP_TRY(e, hipGetLastError());
+            const int wrc = wait_word(e, e->h_gen_word + 3, seq, "the general resolver's pass");
+            if (wrc) return wrc;
+            const u32 w0 = e->h_gen_word[0], w1 = e->h_gen_word[1], w2 = e->h_gen_word[2];
+            h_gst = GenStatus{};
+            h_bst = Status{};
+            h_gst.err = w0;
+            h_gst.n_inserted = w1;
+            h_gst.overflow = w2 & 1u;
+            h_gst.committed = (w2 >> 1) & 1u;
+            h_gst.last_slot = 0;
+            h_gst.changed[0] = (w2 >> 2) & 1u;
+            h_gst.rounds_run = (w2 >> 8) & 0xFFu;
+            h_gst.hot_n = w2 >> 16 == 0xFFFFu ? 0xFFFFFFFFu : w2 >> 16;
+            if (!h_gst.err && !h_gst.overflow && !h_gst.committed && !h_gst.changed[0]) {
+                // converged but refused for room (rare): the message wants the exact count
+                HIP_TRY(e, hipMemcpy(&h_gst.n_new, &e->d_gst->n_new, sizeof(u32), hipMemcpyDeviceToHost));
+            }
+        } else {
         HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, st));
         HIP_TRY(e, hipMemcpyAsync(&h_bst, &bs->st, sizeof(Status), hipMemcpyDeviceToHost, st));
         HIP_TRY(e, hipStreamSynchronize(st));
+        }
         e->stats.probe_steps += h_gst.rounds_run;
         // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
         if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
@@ -1558,6 +1617,13 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         ALLOC(e->d_m_scan_tmp, e->m_scan_tmp_bytes);
     }
     if (hipHostMalloc((void**)&e->h_m_total, 16) != hipSuccess) return bail(RL_ERR_NOMEM);
+    {
+        const size_t bytes = sizeof(MatchScan) + (size_t)cdiv(mb, 256) * sizeof(u32);
+        ALLOC(e->d_m_scan1, bytes);
+        if (hipMemsetAsync(e->d_m_scan1, 0, bytes, e->stream) != hipSuccess) return bail(RL_ERR_DEVICE);
+    }
+    if (const char* v = getenv("RL_MATCH_ONE")) e->match_one = atoi(v) != 0;
+    if (const char* v = getenv("RL_GEN_POST")) e->gen_post = atoi(v) != 0;
 #undef ALLOC
     // Host-mapped blocks the device writes while the host polls them: fine-grained (coherent) memory, so a
     // device store is on its way to the host when the wave's vmcnt says so, not when the kernel ends.
@@ -1570,6 +1636,10 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     };
     if (!host_block((void**)&e->h_status, sizeof(Status))) return bail(RL_ERR_NOMEM);
     if (!host_block((void**)&e->h_tiny, TIO_BYTES)) return bail(RL_ERR_NOMEM);
+    if (!host_block((void**)&e->h_m_word, 64)) return bail(RL_ERR_NOMEM);
+    if (!host_block((void**)&e->h_gen_word, 64)) return bail(RL_ERR_NOMEM);
+    memset(e->h_m_word, 0, 64);
+    memset(e->h_gen_word, 0, 64);
     e->h_tiny_coherent = all_coherent;
     if (hipHostMalloc((void**)&e->h_total, sizeof(unsigned long long)) != hipSuccess) return bail(RL_ERR_NOMEM);
     for (auto& ev : e->ev)
@@ -1610,6 +1680,9 @@ void rl_engine_destroy(rl_engine* e) {
     if (e->h_tiny) (void)hipHostFree(e->h_tiny);
     if (e->h_total) (void)hipHostFree(e->h_total);
     if (e->h_m_total) (void)hipHostFree(e->h_m_total);
+    if (e->h_m_word) (void)hipHostFree(e->h_m_word);
+    if (e->h_gen_word) (void)hipHostFree(e->h_gen_word);
+    if (e->d_m_scan1) (void)hipFree(e->d_m_scan1);
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& f : e->inflight) {
@@ -2463,6 +2536,31 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
                                       uint8_t* d_verdict, int32_t* d_limited, u32* n_hits_out) {
     if (!e->d_match_limits) return fail(e, RL_ERR_INVALID, "rl_match_table_set was not called");
     const u32 g = cdiv(n_req, 256);
+    if (e->match_fast && e->match_one) {
+        // count pass -> one-workgroup scan, which hands {total, error bits} to the host through a host-mapped word ->
+        // fill pass, enqueued right away: the host's poll and the launches of the resolver run under it
+        const u32 call = ++e->m_call ? e->m_call : ++e->m_call;
+        const MatchTables T{e->d_match_flimits, e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_fconds,
+                            e->n_match_conds, e->match_slots};
+        k_match_count2<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, n_req, T, e->d_m_mask, e->d_m_scan1);
+        k_match_scan2<<<1, 1024, 0, e->stream>>>(e->d_m_scan1, g, e->d_req_off + n_req, e->h_m_word, call);
+        k_match_fill2<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, T, e->d_m_mask,
+                                                e->d_m_scan1, e->d_req_off, e->d_hits, e->d_hit_req, e->max_batch);
+        HIP_TRY(e, hipGetLastError());
+        int wrc = wait_word(e, e->h_m_word + 3, call, "the matcher's count pass");
+        if (wrc) return wrc;
+        const u32 n_hits = e->h_m_word[0], m_err = e->h_m_word[1];
+        if (n_hits_out) *n_hits_out = n_hits;
+        if (m_err || n_hits > e->max_batch) HIP_TRY(e, hipStreamSynchronize(e->stream));  // refused
+        if (m_err & ERRBIT_RESERVED_KEY)
+            return fail(e, RL_ERR_INVALID, "a value id does not fit %u bits: such dictionaries keep the host path", MATCH_VAL_BITS);
+        if (m_err) return status_to_error(e, m_err);
+        if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the requests expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
+        GenCall gc{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load, false, d_verdict, e->d_first, e->d_remaining, e->d_expires};
+        gc.d_limited = d_limited;
+        gc.hit_req_filled = n_hits > 0;
+        return run_check_general(e, gc);
+    }
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_m_count + n_req, 0, sizeof(u32), e->stream));
     const bool in_lds = e->n_match_limits <= MATCH_LDS_LIMITS && e->n_match_conds <= MATCH_LDS_CONDS &&
@@ -2645,6 +2743,29 @@ int32_t rl_engine_info(rl_engine* e, int32_t* device, uint32_t* max_batch_hits) 
     if (!e) return RL_ERR_INVALID;
     if (device) *device = e->device;
     if (max_batch_hits) *max_batch_hits = e->max_batch;
+    return RL_OK;
+}
+
+int32_t rl_host_register(rl_engine* e, void* ptr, uint64_t bytes) {
+    if (!e || !ptr || !bytes) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e, RL_ERR_INVALID, "hipHostRegister refused %llu bytes at %p", (unsigned long long)bytes, ptr);
+    }
+    return RL_OK;
+}
+
+int32_t rl_host_unregister(rl_engine* e, void* ptr) {
+    if (!e || !ptr) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    // (copies of host-buffer calls are complete when the call returns: nothing of ours still reads the range)
+    if (hipHostUnregister(ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e, RL_ERR_INVALID, "hipHostUnregister: %p is not a registered range", ptr);
+    }
     return RL_OK;
 }
 

@@ -303,6 +303,236 @@ __global__ __launch_bounds__(256) void k_match_fast(const u32* __restrict__ req_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The slot form without the library scan, the copy commands and the marker (count pass + rocPRIM scan + two copies + an
+// event + fill pass were 125 us of a 0.54 ms call):
+//   k_match_count2   evaluate; per request the bit mask of the limits that apply; per WORKGROUP the number of counters
+//   k_match_scan2    one workgroup: exclusive scan of the workgroups' totals; {total, error bits, call number} handed to
+//                    the host as ONE 16-byte store into host-mapped memory — the host polls that word while ...
+//   k_match_fill2    ... the records are written: a workgroup's base + a scan of its own requests' mask popcounts gives
+//                    every request its offset (the CSR offsets the resolver wants are written here too), in the order
+//                    the storage walks a request's counters (limits without variables first, in_memory.rs:105,121).
+// A batch that expands to more counters than the staging buffers hold writes nothing; the host sees the total and
+// refuses it.
+// (Tried first, measured, withdrawn: all of it in ONE kernel with ticketed workgroups and a decoupled look-back over
+// their totals — 128 us against 34 + 4 + 38: four thousand workgroups polling each other's state words across the
+// XCDs, whose L2s only meet in memory.)
+// ---------------------------------------------------------------------------------------------
+struct MatchScan {
+    Status st;       // the matcher's own error word (zero between calls: k_match_scan2 clears it)
+    u32 wg_tot[1];   // [workgroups]: counters of the workgroup's requests, then (in place) the counters before it
+};
+
+struct MatchTables {
+    const MatchLimitF* limits;
+    u32 n_limits;
+    const u32* ns_off;
+    u32 n_ns;
+    const MatchCondF* conds;
+    u32 n_conds;
+    MatchSlots slots;
+};
+
+struct MatchLdsTables {
+    MatchLimitF l[MATCH_LDS_LIMITS];
+    MatchCondF c[MATCH_LDS_CONDS];
+    u32 ns[MATCH_LDS_NS + 1];
+    u32 v[256][MATCH_SLOTS + 1];  // (+1: rows on different banks)
+    u32 w[4];
+};
+
+__device__ __forceinline__ void match_stage_tables(MatchLdsTables& S, const MatchTables& T) {
+    const u32 tid = threadIdx.x;
+    for (u32 q = tid; q < T.n_limits; q += 256) S.l[q] = T.limits[q];
+    for (u32 q = tid; q < T.n_conds; q += 256) S.c[q] = T.conds[q];
+    for (u32 q = tid; q <= T.n_ns; q += 256) S.ns[q] = T.ns_off[q];
+}
+
+// value of every slot of request r -> S.v[tid]: the FIRST entry with the slot's key wins, like the first insertion into
+// the reference's context map
+__device__ __forceinline__ void match_slot_values(MatchLdsTables& S, const MatchSlots& slots, const u32* __restrict__ ent_off,
+                                                  const u32* __restrict__ ent_key, const u32* __restrict__ ent_val, u32 r) {
+    const u32 tid = threadIdx.x;
+    const u32 b = ent_off[r], n = ent_off[r + 1] - b;
+    u32 v[MATCH_SLOTS];
+#pragma unroll
+    for (u32 sl = 0; sl < MATCH_SLOTS; ++sl) v[sl] = MATCH_NO_VALUE;
+#pragma unroll
+    for (u32 q = 0; q < MATCH_REG_ENTRIES; ++q) {
+        if (q < n) {
+            const u32 ek = ent_key[b + q], val = ent_val[b + q];
+#pragma unroll
+            for (u32 sl = 0; sl < MATCH_SLOTS; ++sl)
+                if (sl < slots.n && ek == slots.key[sl] && v[sl] == MATCH_NO_VALUE) v[sl] = val;
+        }
+    }
+    for (u32 q = MATCH_REG_ENTRIES; q < n; ++q) {
+        const u32 ek = ent_key[b + q], val = ent_val[b + q];
+#pragma unroll
+        for (u32 sl = 0; sl < MATCH_SLOTS; ++sl)
+            if (sl < slots.n && ek == slots.key[sl] && v[sl] == MATCH_NO_VALUE) v[sl] = val;
+    }
+#pragma unroll
+    for (u32 sl = 0; sl < MATCH_SLOTS; ++sl) S.v[tid][sl] = v[sl];
+}
+
+// exclusive offset of this thread's k among the workgroup's 256, and the workgroup's total (all threads; one barrier)
+__device__ __forceinline__ u32 match_block_scan(u32 k, u32* s_w, u32& total) {
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 inc = k;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 o = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += o;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+#pragma unroll
+    for (u32 ww = 0; ww < 4; ++ww) {
+        const u32 x = s_w[ww];
+        if (ww < w) woff += x;
+        tot += x;
+    }
+    total = tot;
+    return woff + inc - k;
+}
+
+__global__ __launch_bounds__(256) void k_match_count2(const u32* __restrict__ req_ns, const u32* __restrict__ ent_off,
+                                                      const u32* __restrict__ ent_key, const u32* __restrict__ ent_val,
+                                                      u32 n_req, MatchTables T, unsigned long long* __restrict__ mask,
+                                                      MatchScan* ms) {
+    __shared__ MatchLdsTables S;
+    const u32 tid = threadIdx.x;
+    match_stage_tables(S, T);
+    __syncthreads();
+    const u32 r = blockIdx.x * 256 + tid;
+    u32 err = 0, k = 0;
+    unsigned long long m = 0ull;
+    if (r < n_req) {
+        const u32 ns = req_ns[r];
+        match_slot_values(S, T.slots, ent_off, ent_key, ent_val, r);
+        if (ns >= T.n_ns) {
+            err |= ERRBIT_BAD_LIMIT;  // unknown namespace id
+        } else {
+            const u32 l0 = S.ns[ns], l1 = S.ns[ns + 1];
+            for (u32 li = l0; li < l1; ++li) {
+                const MatchLimitF L = S.l[li];
+                const u32 nc = L.shape & 0xFFu, nv = (L.shape >> 8) & 0xFFu;
+                bool ok = true;
+                for (u32 c = 0; c < nc; ++c) {
+                    const MatchCondF cd = S.c[L.cond_off + c];
+                    const u32 val = S.v[tid][cd.slot_op & 0xFFu];
+                    // NoSuchKey -> false, whatever the operator (limit/cel.rs:321-338)
+                    ok = ok && val != MATCH_NO_VALUE && ((val == cd.value) == ((cd.slot_op >> 8) == 0u));
+                }
+                if (nv > 0) ok = ok && S.v[tid][(L.shape >> 16) & 0xFFu] != MATCH_NO_VALUE;  // limit/cel.rs:176-191
+                if (nv > 1) ok = ok && S.v[tid][(L.shape >> 24) & 0xFFu] != MATCH_NO_VALUE;
+                if (ok) {
+                    // a value id that does not fit the packed key keeps the host path: said here, the fill pass has
+                    // nothing left to refuse
+                    if ((nv > 0 && S.v[tid][(L.shape >> 16) & 0xFFu] >> MATCH_VAL_BITS) ||
+                        (nv > 1 && S.v[tid][(L.shape >> 24) & 0xFFu] >> MATCH_VAL_BITS))
+                        err |= ERRBIT_RESERVED_KEY;
+                    m |= 1ull << (li - l0);
+                    ++k;
+                }
+            }
+        }
+        mask[r] = m;
+    }
+    if (err) atomicOr(&ms->st.err, err);
+    u32 total;
+    (void)match_block_scan(k, S.w, total);
+    if (tid == 0) ms->wg_tot[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_match_scan2(MatchScan* ms, u32 g, u32* __restrict__ req_off_end, u32* host_word,
+                                                      u32 call) {
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < g; base += 1024) {  // (block-uniform)
+        const u32 i = base + tid;
+        const u32 x = i < g ? ms->wg_tot[i] : 0u;
+        u32 inc = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 o = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += o;
+        }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        u32 woff = 0, tot = 0;
+#pragma unroll
+        for (u32 ww = 0; ww < 16; ++ww) {
+            const u32 y = s_w[ww];
+            if (ww < w) woff += y;
+            tot += y;
+        }
+        const u32 carry = s_carry;
+        if (i < g) ms->wg_tot[i] = carry + woff + inc - x;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const u32 total = s_carry, err = ms->st.err;
+        *req_off_end = total;
+        ms->st.err = 0;
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{total, err, 0u, call}, reinterpret_cast<u32x4*>(host_word));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_match_fill2(const u32* __restrict__ req_ns, const u32* __restrict__ ent_off,
+                                                     const u32* __restrict__ ent_key, const u32* __restrict__ ent_val,
+                                                     const u32* __restrict__ req_delta, u32 n_req, MatchTables T,
+                                                     const unsigned long long* __restrict__ mask, const MatchScan* ms,
+                                                     u32* __restrict__ req_off, Hit* __restrict__ hits,
+                                                     u32* __restrict__ hit_req, u32 max_hits) {
+    __shared__ MatchLdsTables S;
+    const u32 tid = threadIdx.x;
+    // enqueued before the host has seen the total (its round trip runs under this kernel)
+    const bool fits = req_off[n_req] <= max_hits;
+    match_stage_tables(S, T);
+    __syncthreads();
+    const u32 r = blockIdx.x * 256 + tid;
+    const bool active = r < n_req;
+    const unsigned long long m = active ? mask[r] : 0ull;
+    if (active && m) match_slot_values(S, T.slots, ent_off, ent_key, ent_val, r);
+    u32 total;
+    const u32 k = (u32)__popcll(m);
+    const u32 out = ms->wg_tot[blockIdx.x] + match_block_scan(k, S.w, total);
+    if (!active) return;
+    req_off[r] = out;
+    if (!m || !fits) return;
+    const u32 l0 = S.ns[req_ns[r]];  // (a request of an unknown namespace has no mask bits)
+    const u32 delta = req_delta[r];
+    u32 kk = 0;
+    for (int pass = 0; pass < 2; ++pass) {  // limits without variables first (in_memory.rs:105,121)
+        unsigned long long mm = m;
+        while (mm) {
+            const u32 i = (u32)__builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            const MatchLimitF L = S.l[l0 + i];
+            const u32 nv = (L.shape >> 8) & 0xFFu;
+            if ((nv != 0u) != (pass == 1)) continue;
+            const u32 v0 = nv > 0 ? S.v[tid][(L.shape >> 16) & 0xFFu] : 0u;
+            const u32 v1 = nv > 1 ? S.v[tid][(L.shape >> 24) & 0xFFu] : 0u;
+            Hit h;
+            h.key = match_key(L.limit & ~SIMPLE_FLAG, nv, v0, v1);
+            h.limit = L.limit;
+            h.delta = delta;
+            hits[out + kk] = h;
+            if (hit_req) hit_req[out + kk] = r;
+            ++kk;
+        }
+    }
+}
+
 // first_limited (index into hits) -> the limit id whose name the reference reports
 // (Authorization::Limited(name), in_memory.rs:91-93,97-99), -1 when the request is not limited.
 __global__ __launch_bounds__(256) void k_match_limited_limit(const int32_t* __restrict__ first_limited,

@@ -104,8 +104,16 @@ class Engine:
         self._check(self._lib.rl_add_counter(self._h, int(limit), int(key)))
 
     # -- hot path ----------------------------------------------------------------------------
+    def host_register(self, array):
+        """Pin a numpy array the caller reuses for host-buffer calls (rl_host_register); undo with host_unregister
+        before the array is freed."""
+        self._check(self._lib.rl_host_register(self._h, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array):
+        self._check(self._lib.rl_host_unregister(self._h, array.ctypes.data))
+
     def check_and_update(self, hits, now_us, req_off=None, load_counters=False, want_first_limited=True,
-                         req_delta=None, req_now_us=None):
+                         req_delta=None, req_now_us=None, verdict_out=None):
         """CounterStorage::check_and_update for a batch.  Returns (verdict u8[n_req],
         first_limited i32[n_req] | None, remaining u64[n_hits] | None, expires_in_us | None).
         req_delta: per-request u64 deltas (the trait's `delta: u64`); req_now_us: per-request clock values."""
@@ -122,7 +130,11 @@ class Engine:
         if req_now_us is not None:
             req_now_us = np.ascontiguousarray(req_now_us, dtype=np.uint64)
             assert req_now_us.shape[0] == n_req
-        verdict = np.empty(n_req, dtype=np.uint8)
+        if verdict_out is not None:  # (a caller-owned, possibly registered, result array)
+            assert verdict_out.dtype == np.uint8 and verdict_out.flags.c_contiguous and verdict_out.shape[0] >= n_req
+            verdict = verdict_out[:n_req]
+        else:
+            verdict = np.empty(n_req, dtype=np.uint8)
         first = np.empty(n_req, dtype=np.int32) if want_first_limited else None
         remaining = np.zeros(n_hits, dtype=np.uint64) if load_counters else None
         expires = np.zeros(n_hits, dtype=np.uint64) if load_counters else None

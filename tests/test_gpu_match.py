@@ -55,12 +55,17 @@ def expected_counters(limits, ns, ctx):
     return [c for c in out if not c[1].is_qualified()] + [c for c in out if c[1].is_qualified()]
 
 
-@pytest.mark.parametrize("generic", [False, True])
+MATCHERS = {"own_scan": {}, "two_pass": {"RL_MATCH_ONE": "0", "RL_GEN_POST": "0"}, "generic": {"RL_MATCH_GENERIC": "1"}}
+
+
+@pytest.mark.parametrize("matcher", list(MATCHERS))
 @pytest.mark.parametrize("seed,load", [(1, False), (2, True), (3, False)])
-def test_match_table_against_counters_that_apply(make_engine, seed, load, generic, monkeypatch):
-    # the slot form of the table (k_match_fast: what limit files compile to) and the generic kernel (k_match)
-    if generic:
-        monkeypatch.setenv("RL_MATCH_GENERIC", "1")
+def test_match_table_against_counters_that_apply(make_engine, seed, load, matcher, monkeypatch):
+    # the slot form of the table (what limit files compile to) with its own scan and a host-mapped status word
+    # (k_match_count2 / _scan2 / _fill2) or as count pass + library scan + fill pass (k_match_fast, status through copy
+    # commands), and the generic kernel (k_match)
+    for k, v in MATCHERS[matcher].items():
+        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(seed)
     methods, paths = ["GET", "POST", "PUT"], ["/a", "/b", "/json"]
     limits = []
@@ -163,11 +168,11 @@ def test_slot_form_and_generic_matcher_agree_on_long_and_repeated_entries(make_e
         ent_off.append(len(ent_key))
         delta.append(1)
     results = []
-    for generic in (True, False):
-        if generic:
-            monkeypatch.setenv("RL_MATCH_GENERIC", "1")
-        else:
-            monkeypatch.delenv("RL_MATCH_GENERIC")
+    for matcher in ("generic", "two_pass", "own_scan"):
+        for k in ("RL_MATCH_GENERIC", "RL_MATCH_ONE", "RL_GEN_POST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in MATCHERS[matcher].items():
+            monkeypatch.setenv(k, v)
         eng = make_engine(capacity_cells=1 << 16, max_batch_hits=1 << 16)
         kid, vid = Dictionary(), Dictionary()
         kid.ids, vid.ids = dict(key_id.ids), dict(val_id.ids)
@@ -180,10 +185,76 @@ def test_slot_form_and_generic_matcher_agree_on_long_and_repeated_entries(make_e
         results.append(got)
         with pytest.raises(Exception):
             eng.match_and_check([5], [0, 0], [], [], [1], NOW)  # unknown namespace id
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert len(a["hits"]) > n_req
+            for field in ("req_off", "hits", "verdict", "limited_limit"):
+                assert np.array_equal(a[field], b[field]), field
+
+
+def test_matcher_offsets_over_hundreds_of_workgroups(make_engine, monkeypatch):
+    """300 000 requests = 1172 workgroups: the scan of the workgroups' totals takes two trips of k_match_scan2's loop,
+    workgroups with no counters at all sit between busy ones, and a request's offset is its workgroup's base + a scan of
+    mask popcounts.  Differential against the library-scan form on the same arrays, every output array."""
+    rng = np.random.default_rng(78)
+    limits = []
+    for ns in ("a", "b", "c"):
+        for j in range(8):
+            conds = [f"m == 'v{int(rng.integers(0, 3))}'"] if j % 3 == 1 else ([f"p != 'v{int(rng.integers(0, 3))}'"] if j % 3 == 2 else [])
+            variables = [(), ("u",), ("a", "u")][j % 3] if j else ()
+            lim = Limit(ns, int(rng.integers(1, 2000)), 60, conds, variables, name=None)
+            if lim not in limits:
+                limits.append(lim)
+    limits.append(Limit("d", 5, 60, ["m == 'nothing-sends-this'"], (), name=None))  # namespace d: no counters ever
+    limits.sort(key=lambda l: l.namespace)
+    n_req = 300_000
+    key_id, val_id = Dictionary(), Dictionary()
+    for k in ("m", "p", "u", "a"):
+        key_id(k)
+    for v in range(4000):
+        val_id(f"v{v}")
+    val_id("nothing-sends-this")
+    # long stretches of namespace d (whole workgroups with a total of 0), the rest mixed
+    ns = rng.integers(0, 3, size=n_req)
+    ns[40_000:90_000] = 3
+    ns[200_000:200_300] = 3
+    n_ent = rng.integers(0, 5, size=n_req)
+    ent_off = np.concatenate([[0], np.cumsum(n_ent)]).astype(np.uint32)
+    ent_key = np.concatenate([rng.permutation(4)[:k] for k in n_ent]).astype(np.uint32)
+    ent_val = np.where(ent_key < 2, rng.integers(0, 3, size=len(ent_key)), (rng.zipf(1.3, size=len(ent_key)) % 4000)).astype(np.uint32)
+    delta = rng.integers(0, 3, size=n_req).astype(np.uint32)
+    results = []
+    for matcher in ("two_pass", "own_scan"):
+        for k in ("RL_MATCH_ONE", "RL_GEN_POST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in MATCHERS[matcher].items():
+            monkeypatch.setenv(k, v)
+        eng = make_engine(capacity_cells=1 << 21, max_batch_hits=1 << 21)
+        kid, vid = Dictionary(), Dictionary()
+        kid.ids, vid.ids = dict(key_id.ids), dict(val_id.ids)
+        compile_table(eng, limits, kid, vid)
+        for i, l in enumerate(limits):
+            if not l.variables:
+                eng.add_counter(i | RL_SIMPLE, eng.match_key(i))
+        results.append([eng.match_and_check(ns.astype(np.uint32), ent_off, ent_key, ent_val, delta, NOW + q * SEC, load_counters=(q == 1))
+                        for q in range(3)])
+        # a batch that expands to more counters than the engine stages is refused, and the next call is served
+        small = make_engine(capacity_cells=1 << 16, max_batch_hits=4096)
+        three = [Limit("a", 5, sec, [], (), name=None) for sec in (1, 10, 60)]
+        compile_table(small, three, Dictionary(), Dictionary())
+        for i in range(3):
+            small.add_counter(i | RL_SIMPLE, small.match_key(i))
+        zeros = np.zeros(4001, dtype=np.uint32)
+        with pytest.raises(Exception):  # 4000 requests x 3 counters
+            small.match_and_check(zeros[:4000], zeros, [], [], np.ones(4000, dtype=np.uint32), NOW)
+        ok = small.match_and_check(zeros[:1000], zeros[:1001], [], [], np.ones(1000, dtype=np.uint32), NOW)
+        assert len(ok["hits"]) == 3000 and int(ok["verdict"].sum()) == 1000 - 5
     for a, b in zip(*results):
         assert len(a["hits"]) > n_req
         for field in ("req_off", "hits", "verdict", "limited_limit"):
             assert np.array_equal(a[field], b[field]), field
+    assert np.array_equal(results[0][1]["remaining"], results[1][1]["remaining"])
+    assert np.array_equal(results[0][1]["expires_in_us"], results[1][1]["expires_in_us"])
 
 
 def test_match_table_rejects_what_must_stay_on_the_host(make_engine):

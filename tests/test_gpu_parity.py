@@ -111,6 +111,51 @@ def test_random_single_counter_batches(make_engine, seed):
     assert_same_state(eng, orc, n_simple_expected=2)
 
 
+def test_registered_host_arrays_give_the_same_answers(make_engine):
+    """rl_host_register pins the caller's staging arrays in place (what a binding does with the buffers it reuses): the
+    same calls, the same bytes — single-counter batches, a tiny call, a multi-counter call with load_counters — with the
+    hits read from and the verdicts written into registered memory."""
+    from limitador_amd.engine import EngineError
+
+    rng = np.random.default_rng(41)
+    rows = [(5, 1), (50, 10), (1000, 60)]
+    eng, orc = pair(make_engine, rows, [(0, 9_000_001)])
+    cap = 20_000
+    hits_buf = np.zeros(cap, dtype=HIT_DTYPE)
+    vout = np.full(cap, 0xEE, dtype=np.uint8)
+    eng.host_register(hits_buf)
+    eng.host_register(vout)
+    now = NOW
+    for n in (20_000, 1, 7, 12_345, 0, 3000):
+        idx = rng.integers(0, 400, size=n)
+        hits = hits_buf[:n]
+        hits["key"] = W.splitmix64(idx.astype(np.uint64))
+        hits["limit"] = idx % 3
+        hits["delta"] = rng.integers(0, 3, size=n)
+        req_off = None
+        kw = {}
+        if n == 3000:  # requests of 1..3 counters, values loaded
+            cuts = np.unique(np.concatenate([[0, n], rng.integers(0, n, size=1500)])).astype(np.uint32)
+            kw = {"req_off": cuts, "load_counters": True}
+            # (one delta per request: in_memory.rs:75 — every hit carries its request's)
+            hits["delta"] = np.repeat(rng.integers(0, 3, size=len(cuts) - 1), np.diff(cuts))
+        vout[:] = 0xEE
+        v1, f1, r1, e1 = eng.check_and_update(hits, now, verdict_out=vout, **kw)
+        v2, f2, r2, e2 = orc.check_and_update(hits, now, **kw)
+        assert v1.ctypes.data == vout.ctypes.data or n == 0
+        assert np.array_equal(v1, v2) and np.array_equal(f1, f2)
+        assert np.all(vout[len(v2):] == 0xEE), "nothing past the batch's verdicts is written"
+        if kw:
+            assert np.array_equal(r1, r2) and np.array_equal(e1, e2)
+        now += SEC // 2
+    eng.host_unregister(hits_buf)
+    eng.host_unregister(vout)
+    with pytest.raises(EngineError):
+        eng.host_unregister(np.zeros(16, dtype=np.uint8))  # never registered
+    run_both(eng, orc, hits_buf[:500].copy(), now)  # and pageable again
+    assert_same_state(eng, orc, n_simple_expected=1)
+
+
 def test_one_hot_key_nonuniform_deltas(make_engine):
     """Every hit on one cell, mixed deltas: the one-lane replay of the round (mixed deltas)."""
     rng = np.random.default_rng(7)
