@@ -379,6 +379,30 @@ int32_t rl_route_partition_stream(rl_engine *e, void *stream, const rl_hit *d_hi
 int32_t rl_unpermute_u8_stream(rl_engine *e, void *stream, const uint8_t *d_src, const uint32_t *d_perm,
                                uint32_t n, uint8_t *d_dst);
 
+/* Ingress side of the key-sharded MULTI-counter step (include/rl_sharded.h: rl_sharded_check_requests_device).  A
+ * request's counters live on several owners; the all-or-nothing rule (in_memory.rs:141-153) is the AND of its hits'
+ * pass flags, taken on the rank the request entered.  Hits travel in ROUTED order (rl_route_partition_stream: d_perm[j] =
+ * ingress index of routed hit j).  All enqueue on the caller's stream and return.
+ *   ids      d_req_of_hit[i] = request of ingress hit i (from the CSR offsets); d_req_id_sorted[j] = base + request of
+ *            routed hit j — the id rl_gen_begin_device wants beside every hit (base: requests of the ranks before)
+ *   round    pass flags back from the owners, routed order -> ingress order (d_pass_home, scratch) -> per request
+ *            d_adm (in/out), d_first (first failing hit, ingress index, or -1: in_memory.rs:90-99), d_verdict;
+ *            *d_changed |= 1 if the admitted set differs from the previous round's (first_round: from "all admitted");
+ *            d_adm_sorted[j] = admission of routed hit j's request, for the owners' next round
+ *   reached  d_reached_sorted[j] = the request's walk got to routed hit j (it stops at its first limited counter unless
+ *            the values are loaded: in_memory.rs:109-113,129-133) */
+int32_t rl_req_ids_stream(rl_engine *e, void *stream, const uint32_t *d_req_off, uint32_t n_req, uint32_t n_hits,
+                          uint32_t base, const uint32_t *d_perm, uint32_t *d_req_of_hit, uint32_t *d_req_id_sorted);
+int32_t rl_req_round_stream(rl_engine *e, void *stream, const uint8_t *d_pass_sorted, const uint32_t *d_perm,
+                            const uint32_t *d_req_off, const uint32_t *d_req_of_hit, uint32_t n_req, uint32_t n_hits,
+                            int32_t first_round, uint8_t *d_pass_home, uint8_t *d_adm, int32_t *d_first,
+                            uint8_t *d_verdict, uint32_t *d_changed, uint8_t *d_adm_sorted);
+int32_t rl_req_reached_stream(rl_engine *e, void *stream, const int32_t *d_first, const uint32_t *d_req_of_hit,
+                              const uint32_t *d_perm, uint32_t n_hits, uint8_t *d_reached_sorted);
+/* d_dst[d_perm[j]] = d_src[j], 8-byte elements (remaining / expires_in back to ingress order). */
+int32_t rl_unpermute_u64_stream(rl_engine *e, void *stream, const uint64_t *d_src, const uint32_t *d_perm, uint32_t n,
+                                uint64_t *d_dst);
+
 /* The HIP stream (hipStream_t) the engine launches on, for callers that order their own work
  * against it, and a per-kernel timing hook used by bench.py (HIP events on that stream). */
 void *rl_engine_stream(rl_engine *e);

@@ -95,6 +95,27 @@ int32_t rl_sharded_collect(rl_sharded *s, uint32_t *n_applied);
 /* submit + collect + synchronise on an empty pipeline. */
 int32_t rl_sharded_check_and_update_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
                                            uint8_t *d_verdict, uint32_t *n_applied);
+/* Requests with SEVERAL counters each, the counters sharded by key like everything else: a request's counters live on
+ * several GPUs and the all-or-nothing rule of check_and_update (in_memory.rs:141-153) spans them (SURVEY.md §8e "k > 1").
+ *     hits -> owners (stable partition by owner; the id of its request travels with every hit)
+ *     owners: sort by cell, read the cells                                            (rl_gen_begin_device)
+ *     repeat  owners: per hit "fits on top of the admitted hits before it"            (rl_gen_round_device)
+ *             flags back to the ingress ranks; per request AND; admitted bits out to the owners again
+ *     until no rank saw the admitted set change (Jacobi rounds from "all admitted": the unique fixpoint)
+ *     the walks' ends -> owners; cells to create against room: all ranks fit or none does   (rl_gen_count_device)
+ *     owners commit                                                                   (rl_gen_commit_device)
+ * Global trace order per call is "rank 0's requests, then rank 1's, ...", so verdicts, first_limited, remaining /
+ * expires_in and the union of the tables equal ONE sequential storage fed the concatenated slices.
+ * d_hits: the slice's counters, request after request (CSR d_req_off[n_req + 1]; simple counters first inside a request,
+ * every hit carrying its request's delta); d_first_limited[r] = index into d_hits of the request's first limited counter
+ * or -1 (may be NULL); d_remaining / d_expires_in_us per hit with load_counters (else may be NULL).  n_hits and n_req
+ * <= max_slice_hits.  BLOCKING, on an empty pipeline, called by EVERY rank for every step (it contains collectives: two
+ * exchanges of one byte per hit and one word per rank each round).  A step one rank cannot take — a malformed hit, a full
+ * table — is refused on every rank with nothing applied anywhere; the rank at fault gets the reason. */
+int32_t rl_sharded_check_requests_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n_hits, const uint32_t *d_req_off,
+                                         uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t *d_verdict,
+                                         int32_t *d_first_limited, uint64_t *d_remaining, uint64_t *d_expires_in_us,
+                                         uint32_t *rounds);
 /* The stream the verdicts are ordered on (hipStream_t), and a host wait on it. */
 void *rl_sharded_stream(rl_sharded *s);
 int32_t rl_sharded_sync(rl_sharded *s);

@@ -171,6 +171,15 @@ struct rl_sharded {
     std::vector<uint64_t> send_off[SLOTS], send_cnt[SLOTS], recv_off[SLOTS], recv_cnt[SLOTS];
     // byte-scaled copies handed to the transport (must outlive the call only)
     std::vector<uint64_t> b_so, b_sc, b_ro, b_rc, v_so[2], v_sc[2], v_ro[2], v_rc[2], c_off, c_cnt;
+    // rl_sharded_check_requests_device (multi-counter requests): allocated at the first call
+    struct ReqBufs {
+        bool ready = false;
+        uint32_t *req_of_hit = nullptr, *req_id_sorted = nullptr, *r_req = nullptr, *d_words = nullptr, *h_words = nullptr;
+        uint8_t *pass_recv = nullptr, *pass_sorted = nullptr, *pass_home = nullptr, *adm = nullptr, *adm_sorted = nullptr,
+                *adm_recv = nullptr;
+        int32_t* first = nullptr;
+        uint64_t *rem_recv = nullptr, *exp_recv = nullptr, *rem_sorted = nullptr, *exp_sorted = nullptr;
+    } rq;
     std::deque<Slice> pending;
     uint64_t seq = 0;
     uint64_t last_engine_slice = ~0ull;  // the slice whose local batch was submitted to the engine last (its replay may be held back)
@@ -499,6 +508,12 @@ void rl_sharded_destroy(rl_sharded* s) {
         if (s->ev_exchanged[q]) (void)hipEventDestroy(s->ev_exchanged[q]);
         if (s->ev_applied[q]) (void)hipEventDestroy(s->ev_applied[q]);
     }
+    for (void* q : {(void*)s->rq.req_of_hit, (void*)s->rq.req_id_sorted, (void*)s->rq.r_req, (void*)s->rq.d_words,
+                    (void*)s->rq.pass_recv, (void*)s->rq.pass_sorted, (void*)s->rq.pass_home, (void*)s->rq.adm,
+                    (void*)s->rq.adm_sorted, (void*)s->rq.adm_recv, (void*)s->rq.first, (void*)s->rq.rem_recv,
+                    (void*)s->rq.exp_recv, (void*)s->rq.rem_sorted, (void*)s->rq.exp_sorted})
+        if (q) (void)hipFree(q);
+    if (s->rq.h_words) (void)hipHostFree(s->rq.h_words);
     if (s->cs) (void)hipStreamDestroy(s->cs);
     if (s->as && engine_released) (void)hipStreamDestroy(s->as);  // (never destroy a stream the engine still references)
     delete s;
@@ -556,6 +571,258 @@ int32_t rl_sharded_check_and_update_device(rl_sharded* s, const rl_hit* d_hits, 
     rc = rl_sharded_collect(s, n_applied);
     const int32_t rs = rl_sharded_sync(s);
     return rc != RL_OK ? rc : rs;
+}
+
+// ---- multi-counter requests, counters sharded by key (SURVEY.md §8e "k > 1") --------------------------------------
+namespace {
+
+constexpr uint32_t RQ_GATHER = 16;   // d_words[RQ_GATHER + p]: rank p's word of the last gather
+constexpr uint32_t RQ_CHANGED = 64;  // d_words[RQ_CHANGED]: k_req_and raises it
+constexpr uint32_t RQ_WORDS = 128;
+
+int32_t req_bufs(rl_sharded* s) {
+    if (s->rq.ready) return RL_OK;
+    const size_t ms = s->max_slice ? s->max_slice : 1;
+    const size_t mr = std::max<size_t>(s->max_recv ? s->max_recv : 1, (size_t)s->world * ms);
+    auto& q = s->rq;
+    HIP_S(s, hipMalloc(&q.req_of_hit, ms * 4));
+    HIP_S(s, hipMalloc(&q.req_id_sorted, ms * 4));
+    HIP_S(s, hipMalloc(&q.r_req, mr * 4));
+    HIP_S(s, hipMalloc(&q.d_words, RQ_WORDS * 4));
+    HIP_S(s, hipHostMalloc(reinterpret_cast<void**>(&q.h_words), RQ_WORDS * 4, hipHostMallocDefault));
+    HIP_S(s, hipMalloc(&q.pass_recv, mr));
+    HIP_S(s, hipMalloc(&q.pass_sorted, ms));
+    HIP_S(s, hipMalloc(&q.pass_home, ms));
+    HIP_S(s, hipMalloc(&q.adm, ms));
+    HIP_S(s, hipMalloc(&q.adm_sorted, ms));
+    HIP_S(s, hipMalloc(&q.adm_recv, mr));
+    HIP_S(s, hipMalloc(&q.first, ms * 4));
+    HIP_S(s, hipMalloc(&q.rem_recv, mr * 8));
+    HIP_S(s, hipMalloc(&q.exp_recv, mr * 8));
+    HIP_S(s, hipMalloc(&q.rem_sorted, ms * 8));
+    HIP_S(s, hipMalloc(&q.exp_sorted, ms * 8));
+    q.ready = true;
+    return RL_OK;
+}
+
+// One 32-bit word of every rank to every rank (d_send: this rank's, on the device); out[p] = rank p's.  A collective.
+int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out) {
+    const uint32_t W = s->world;
+    std::vector<uint64_t> zero(W, 0), four(W, 4), ro(W);
+    for (uint32_t p = 0; p < W; ++p) ro[p] = 4ull * p;
+    rl_xfer x;
+    x.send = d_send;
+    x.recv = s->rq.d_words + RQ_GATHER;
+    x.send_off = zero.data();
+    x.send_cnt = four.data();
+    x.recv_off = ro.data();
+    x.recv_cnt = four.data();
+    const int32_t rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
+    if (rc != RL_OK) return fail(s, rc, "exchange (one word per rank) failed");
+    HIP_S(s, hipMemcpyAsync(s->rq.h_words, s->rq.d_words + RQ_GATHER, W * 4, hipMemcpyDeviceToHost, s->cs));
+    HIP_S(s, hipStreamSynchronize(s->cs));
+    for (uint32_t p = 0; p < W; ++p) out[p] = s->rq.h_words[p];
+    return RL_OK;
+}
+int32_t gather_host_word(rl_sharded* s, uint32_t mine, uint32_t* out) {
+    s->rq.h_words[RQ_WORDS - 1] = mine;
+    HIP_S(s, hipMemcpyAsync(s->rq.d_words, s->rq.h_words + RQ_WORDS - 1, 4, hipMemcpyHostToDevice, s->cs));
+    return gather_words(s, s->rq.d_words, out);
+}
+uint32_t max_of(const uint32_t* w, uint32_t n) {
+    uint32_t m = 0;
+    for (uint32_t p = 0; p < n; ++p) m = std::max(m, w[p]);
+    return m;
+}
+
+// bytes of one element per routed hit, ingress -> owners (fwd) or owners -> ingress (!fwd), as ONE grouped exchange of
+// up to two arrays
+int32_t exchange_per_hit(rl_sharded* s, bool fwd, uint32_t elem, const void* a_send, void* a_recv, const void* b_send = nullptr,
+                         void* b_recv = nullptr) {
+    const uint32_t W = s->world;
+    std::vector<uint64_t> so(W), sc(W), ro(W), rc(W);
+    for (uint32_t p = 0; p < W; ++p) {
+        const uint64_t ho = s->send_off[0][p], hc = s->send_cnt[0][p], oo = s->recv_off[0][p], oc = s->recv_cnt[0][p];
+        so[p] = (fwd ? ho : oo) * elem;
+        sc[p] = (fwd ? hc : oc) * elem;
+        ro[p] = (fwd ? oo : ho) * elem;
+        rc[p] = (fwd ? oc : hc) * elem;
+    }
+    rl_xfer xs[2];
+    uint32_t n = 0;
+    for (int k = 0; k < 2; ++k) {
+        const void* sp = k ? b_send : a_send;
+        void* rp = k ? b_recv : a_recv;
+        if (!sp) continue;
+        xs[n].send = sp;
+        xs[n].recv = rp;
+        xs[n].send_off = so.data();
+        xs[n].send_cnt = sc.data();
+        xs[n].recv_off = ro.data();
+        xs[n].recv_cnt = rc.data();
+        ++n;
+    }
+    const int32_t r = s->t.exchange(s->t.ctx, xs, n, s->cs);
+    if (r != RL_OK) return fail(s, r, "exchange (%u bytes per hit, %s) failed", elem, fwd ? "to the owners" : "back to the ingress ranks");
+    return RL_OK;
+}
+
+}  // namespace
+
+int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, uint32_t n_hits, const uint32_t* d_req_off,
+                                         uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t* d_verdict,
+                                         int32_t* d_first_limited, uint64_t* d_remaining, uint64_t* d_expires_in_us,
+                                         uint32_t* rounds_out) {
+    if (!s) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->mu);
+    HIP_S(s, hipSetDevice(s->device));
+    int32_t rc = req_bufs(s);
+    if (rc != RL_OK) return rc;  // (out of memory before the first exchange: nothing a peer could be told through)
+    const uint32_t W = s->world;
+    auto& q = s->rq;
+    uint32_t words[MAX_WORLD];
+    // ---- 0. every rank's request count (the ids of the ranks behind me start after mine); a rank whose arguments are
+    //         unusable says so HERE, so that all ranks leave together
+    int32_t bad = RL_OK;
+    if (!s->pending.empty()) bad = RL_ERR_BUSY;
+    else if ((n_hits && !d_hits) || !d_req_off || (n_req && !d_verdict) || (load_counters && n_hits && (!d_remaining || !d_expires_in_us)))
+        bad = RL_ERR_INVALID;
+    else if (n_hits > s->max_slice || n_req > s->max_slice) bad = RL_ERR_BATCH_TOO_LARGE;
+    rc = gather_host_word(s, bad ? 0xFFFFFFFFu : n_req, words);
+    if (rc != RL_OK) return rc;
+    if (max_of(words, W) == 0xFFFFFFFFu) {
+        if (bad == RL_ERR_BUSY) return fail(s, bad, "slices are in flight: collect them first");
+        if (bad == RL_ERR_BATCH_TOO_LARGE) return fail(s, bad, "%u hits / %u requests, communicator sized for %u", n_hits, n_req, s->max_slice);
+        if (bad) return fail(s, bad, "null argument");
+        return fail(s, RL_ERR_INVALID, "another rank refused the step (its arguments): nothing was applied anywhere");
+    }
+    uint64_t base = 0, total_req = 0;
+    for (uint32_t p = 0; p < W; ++p) {
+        if (p < s->rank) base += words[p];
+        total_req += words[p];
+    }
+    const bool too_many = total_req >= (1ull << 32);  // (request ids are 32 bits; every rank computes the same sum)
+    if (too_many) return fail(s, RL_ERR_BATCH_TOO_LARGE, "more than 2^32 requests in one step");
+    int32_t* d_first = d_first_limited ? d_first_limited : q.first;
+    // ---- 1. route: stable partition by owner, the request id of every routed hit, the counts, the records -------------
+    ENG_S(s, rl_route_partition_stream(s->e, s->cs, d_hits, n_hits, W, s->sorted[0], s->perm[0], s->d_counts[0]));
+    ENG_S(s, rl_req_ids_stream(s->e, s->cs, d_req_off, n_req, n_hits, (uint32_t)base, s->perm[0], q.req_of_hit, q.req_id_sorted));
+    {
+        rl_xfer x;
+        x.send = s->d_counts[0];
+        x.recv = s->d_counts[0] + W;
+        x.send_off = x.recv_off = s->c_off.data();
+        x.send_cnt = x.recv_cnt = s->c_cnt.data();
+        rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
+        if (rc != RL_OK) return fail(s, rc, "exchange (counts) failed");
+    }
+    HIP_S(s, hipMemcpyAsync(s->h_counts[0], s->d_counts[0], 2 * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s->cs));
+    HIP_S(s, hipStreamSynchronize(s->cs));
+    uint64_t so = 0, ro = 0;
+    for (uint32_t p = 0; p < W; ++p) {
+        s->send_off[0][p] = so;
+        s->send_cnt[0][p] = s->h_counts[0][p];
+        so += s->h_counts[0][p];
+        s->recv_off[0][p] = ro;
+        s->recv_cnt[0][p] = s->h_counts[0][W + p];
+        ro += s->h_counts[0][W + p];
+    }
+    if (so != n_hits) return fail(s, RL_ERR_DEVICE, "router counted %llu of %u hits", (unsigned long long)so, n_hits);
+    const uint32_t n_recv = (uint32_t)ro;
+    {   // records and ids in one group (16 + 4 bytes per hit)
+        const uint32_t Wn = W;
+        std::vector<uint64_t> hso(Wn), hsc(Wn), hro(Wn), hrc(Wn), iso(Wn), isc(Wn), iro(Wn), irc(Wn);
+        for (uint32_t p = 0; p < Wn; ++p) {
+            hso[p] = s->send_off[0][p] * sizeof(rl_hit);
+            hsc[p] = s->send_cnt[0][p] * sizeof(rl_hit);
+            hro[p] = s->recv_off[0][p] * sizeof(rl_hit);
+            hrc[p] = s->recv_cnt[0][p] * sizeof(rl_hit);
+            iso[p] = s->send_off[0][p] * 4;
+            isc[p] = s->send_cnt[0][p] * 4;
+            iro[p] = s->recv_off[0][p] * 4;
+            irc[p] = s->recv_cnt[0][p] * 4;
+        }
+        rl_xfer xs[2];
+        xs[0] = {s->sorted[0], s->recv_hits[0], hso.data(), hsc.data(), hro.data(), hrc.data()};
+        xs[1] = {q.req_id_sorted, q.r_req, iso.data(), isc.data(), iro.data(), irc.data()};
+        rc = s->t.exchange(s->t.ctx, xs, 2, s->cs);
+        if (rc != RL_OK) return fail(s, rc, "exchange (hits + request ids) failed");
+    }
+    HIP_S(s, hipStreamSynchronize(s->cs));
+    // ---- 2. owners: sort by cell, read the cells.  A slice one owner refuses is refused everywhere ---------------------
+    const int32_t brc = rl_gen_begin_device(s->e, s->recv_hits[0], q.r_req, n_recv, now_us, load_counters);
+    char bmsg[200] = {0};
+    if (brc != RL_OK) std::snprintf(bmsg, sizeof(bmsg), "%s", rl_last_error(s->e));
+    rc = gather_host_word(s, brc != RL_OK ? 1u : 0u, words);
+    if (rc != RL_OK) return rc;
+    if (max_of(words, W)) {
+        if (brc == RL_OK) {
+            (void)rl_gen_abort(s->e);
+            return fail(s, RL_ERR_INVALID, "another rank refused the step: nothing was applied anywhere");
+        }
+        return fail(s, brc, "rank %u: %s (refused on every rank, nothing applied)", s->rank, bmsg);
+    }
+    // ---- 3. Jacobi rounds: owners -> pass flags -> ingress AND per request -> admitted bits -> owners, until no rank
+    //         saw the admitted set change: the unique fixpoint -----------------------------------------
+    uint32_t rounds = 0;
+    for (bool first_round = true;; first_round = false) {
+        const int32_t rrc = rl_gen_round_device(s->e, first_round ? nullptr : q.adm_recv, q.pass_recv, q.rem_recv, q.exp_recv);
+        if (rrc != RL_OK) {  // (misuse or a device error: not an outcome of the input)
+            (void)rl_gen_abort(s->e);
+            return fail(s, rrc, "rl_gen_round_device: %s", rl_last_error(s->e));
+        }
+        ++rounds;
+        rc = exchange_per_hit(s, false, 1, q.pass_recv, q.pass_sorted);
+        if (rc != RL_OK) return rc;
+        HIP_S(s, hipMemsetAsync(q.d_words + RQ_CHANGED, 0, 4, s->cs));
+        ENG_S(s, rl_req_round_stream(s->e, s->cs, q.pass_sorted, s->perm[0], d_req_off, q.req_of_hit, n_req, n_hits, first_round ? 1 : 0,
+                                     q.pass_home, q.adm, d_first, d_verdict, q.d_words + RQ_CHANGED, q.adm_sorted));
+        rc = gather_words(s, q.d_words + RQ_CHANGED, words);
+        if (rc != RL_OK) return rc;
+        if (!max_of(words, W)) break;  // the admitted set of this round is the one the flags were computed with
+        rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
+        if (rc != RL_OK) return rc;
+        HIP_S(s, hipStreamSynchronize(s->cs));
+        if (rounds > total_req + 2) {
+            (void)rl_gen_abort(s->e);
+            return fail(s, RL_ERR_DEVICE, "the rounds did not converge (bug)");
+        }
+    }
+    if (rounds_out) *rounds_out = rounds;
+    // ---- 4. the walks' ends -> owners; cells to create, room: all ranks fit or none does -------------------------------
+    uint32_t n_new = 0;
+    uint64_t room = 0;
+    int32_t crc;
+    if (!load_counters) {
+        ENG_S(s, rl_req_reached_stream(s->e, s->cs, d_first, q.req_of_hit, s->perm[0], n_hits, q.adm_sorted));
+        rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
+        if (rc != RL_OK) return rc;
+        HIP_S(s, hipStreamSynchronize(s->cs));
+        crc = rl_gen_count_device(s->e, q.adm_recv, &n_new, &room);
+    } else {
+        crc = rl_gen_count_device(s->e, nullptr, &n_new, &room);
+    }
+    char cmsg[200] = {0};
+    if (crc != RL_OK) std::snprintf(cmsg, sizeof(cmsg), "%s", rl_last_error(s->e));
+    rc = gather_host_word(s, crc != RL_OK ? 2u : (n_new > room ? 1u : 0u), words);
+    if (rc != RL_OK) return rc;
+    if (const uint32_t worst = max_of(words, W)) {
+        (void)rl_gen_abort(s->e);
+        if (crc != RL_OK) return fail(s, crc, "rank %u: %s", s->rank, cmsg);
+        if (worst == 2u) return fail(s, RL_ERR_DEVICE, "another rank failed while counting: nothing was applied anywhere");
+        return fail(s, RL_ERR_TABLE_FULL, "refused, nothing applied on any rank: a shard cannot take the cells the step creates (here: %u new, room %llu)",
+                    n_new, (unsigned long long)room);
+    }
+    ENG_S(s, rl_gen_commit_device(s->e));
+    // ---- 5. values read before the update, back to the ingress ranks (in_memory.rs:114-116,134-136) -------------------
+    if (load_counters) {
+        rc = exchange_per_hit(s, false, 8, q.rem_recv, q.rem_sorted, q.exp_recv, q.exp_sorted);
+        if (rc != RL_OK) return rc;
+        ENG_S(s, rl_unpermute_u64_stream(s->e, s->cs, q.rem_sorted, s->perm[0], n_hits, d_remaining));
+        ENG_S(s, rl_unpermute_u64_stream(s->e, s->cs, q.exp_sorted, s->perm[0], n_hits, d_expires_in_us));
+    }
+    HIP_S(s, hipStreamSynchronize(s->cs));
+    return RL_OK;
 }
 
 void* rl_sharded_stream(rl_sharded* s) { return s ? s->cs : nullptr; }

@@ -2746,6 +2746,62 @@ int32_t rl_engine_info(rl_engine* e, int32_t* device, uint32_t* max_batch_hits) 
     return RL_OK;
 }
 
+// ---- ingress side of the key-sharded multi-counter step (rl_route.hpp): enqueue on the caller's stream and return -----
+int32_t rl_req_ids_stream(rl_engine* e, void* stream, const uint32_t* d_req_off, uint32_t n_req, uint32_t n_hits,
+                          uint32_t base, const uint32_t* d_perm, uint32_t* d_req_of_hit, uint32_t* d_req_id_sorted) {
+    if (!e || !d_req_off || (n_hits && (!d_perm || !d_req_of_hit || !d_req_id_sorted))) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n_req && n_hits) k_req_of_hit<<<cdiv(n_req, 256), 256, 0, st>>>(d_req_off, n_req, d_req_of_hit);
+    if (n_hits) k_req_id_sorted<<<cdiv(n_hits, 256), 256, 0, st>>>(d_req_of_hit, d_perm, n_hits, base, d_req_id_sorted);
+    HIP_TRY(e, hipGetLastError());
+    return RL_OK;
+}
+
+int32_t rl_req_round_stream(rl_engine* e, void* stream, const uint8_t* d_pass_sorted, const uint32_t* d_perm,
+                            const uint32_t* d_req_off, const uint32_t* d_req_of_hit, uint32_t n_req, uint32_t n_hits,
+                            int32_t first_round, uint8_t* d_pass_home, uint8_t* d_adm, int32_t* d_first, uint8_t* d_verdict,
+                            uint32_t* d_changed, uint8_t* d_adm_sorted) {
+    if (!e || !d_changed || (n_req && (!d_req_off || !d_adm || !d_first || !d_verdict)) ||
+        (n_hits && (!d_pass_sorted || !d_perm || !d_req_of_hit || !d_pass_home || !d_adm_sorted)))
+        return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n_hits) k_unpermute_u8<<<cdiv(n_hits, 256), 256, 0, st>>>(d_pass_sorted, d_perm, n_hits, d_pass_home);
+    if (n_req)
+        k_req_and<<<cdiv(n_req, 256), 256, 0, st>>>(d_pass_home, d_req_off, n_req, first_round ? 1u : 0u, d_adm, d_first, d_verdict,
+                                                    d_changed);
+    if (n_hits) k_req_spread<<<cdiv(n_hits, 256), 256, 0, st>>>(d_adm, d_req_of_hit, d_perm, n_hits, d_adm_sorted);
+    HIP_TRY(e, hipGetLastError());
+    return RL_OK;
+}
+
+int32_t rl_req_reached_stream(rl_engine* e, void* stream, const int32_t* d_first, const uint32_t* d_req_of_hit,
+                              const uint32_t* d_perm, uint32_t n_hits, uint8_t* d_reached_sorted) {
+    if (!e || (n_hits && (!d_first || !d_req_of_hit || !d_perm || !d_reached_sorted))) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (n_hits)
+        k_req_reached<<<cdiv(n_hits, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(d_first, d_req_of_hit, d_perm, n_hits,
+                                                                                             d_reached_sorted);
+    HIP_TRY(e, hipGetLastError());
+    return RL_OK;
+}
+
+int32_t rl_unpermute_u64_stream(rl_engine* e, void* stream, const uint64_t* d_src, const uint32_t* d_perm, uint32_t n,
+                                uint64_t* d_dst) {
+    if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (n)
+        k_unpermute_u64<<<cdiv(n, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(reinterpret_cast<const u64*>(d_src), d_perm, n,
+                                                                                          reinterpret_cast<u64*>(d_dst));
+    HIP_TRY(e, hipGetLastError());
+    return RL_OK;
+}
+
 int32_t rl_host_register(rl_engine* e, void* ptr, uint64_t bytes) {
     if (!e || !ptr || !bytes) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(e->mu);

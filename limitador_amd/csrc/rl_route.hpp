@@ -153,4 +153,71 @@ __global__ __launch_bounds__(256) void k_unpermute_u8(const uint8_t* __restrict_
     if (j < n) dst[perm[j]] = src[j];
 }
 
+__global__ __launch_bounds__(256) void k_unpermute_u64(const u64* __restrict__ src, const u32* __restrict__ perm, u32 n,
+                                                       u64* __restrict__ dst) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) dst[perm[j]] = src[j];
+}
+
+// ---- the ingress side of the key-sharded MULTI-counter step (include/rl_sharded.h, rl_sharded_check_requests_device) ----
+// A request's counters live on several owners; the all-or-nothing rule (in_memory.rs:141-153) is the AND of its hits'
+// pass flags, taken where the request entered.  Hits travel in ROUTED order (stable partition by owner, perm[j] = the
+// ingress index of routed hit j); everything per request happens in ingress order.
+
+// request of every hit (ingress order), and the id that travels with routed hit j: base + its request
+__global__ __launch_bounds__(256) void k_req_of_hit(const u32* __restrict__ req_off, u32 n_req, u32* __restrict__ req_of_hit) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_req) return;
+    for (u32 q = req_off[r]; q < req_off[r + 1]; ++q) req_of_hit[q] = r;
+}
+__global__ __launch_bounds__(256) void k_req_id_sorted(const u32* __restrict__ req_of_hit, const u32* __restrict__ perm, u32 n,
+                                                       u32 base, u32* __restrict__ req_id_sorted) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) req_id_sorted[j] = base + req_of_hit[perm[j]];
+}
+
+// One round, ingress side: a request is admitted iff every one of its hits passed on its owner (pass_home: the flags
+// back in ingress order); first[r] = its first failing hit (the counter the reference reports: in_memory.rs:90-99,
+// 141-143) or -1; *changed is raised if the admitted set differs from the previous round's (first round: from
+// "everything admitted", which is what the owners assumed).
+__global__ __launch_bounds__(256) void k_req_and(const uint8_t* __restrict__ pass_home, const u32* __restrict__ req_off, u32 n_req,
+                                                 u32 first_round, uint8_t* __restrict__ adm, int32_t* __restrict__ first,
+                                                 uint8_t* __restrict__ verdict, u32* __restrict__ changed) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    bool ch = false;
+    if (r < n_req) {
+        int32_t f = -1;
+        const u32 e = req_off[r + 1];
+        for (u32 q = req_off[r]; q < e; ++q)
+            if (pass_home[q] == 0) {
+                f = (int32_t)q;
+                break;
+            }
+        const uint8_t a = f < 0 ? 1 : 0;
+        ch = first_round ? a == 0 : adm[r] != a;
+        adm[r] = a;
+        first[r] = f;
+        verdict[r] = a ? 0 : 1;
+    }
+    if (__syncthreads_or(ch ? 1 : 0) && threadIdx.x == 0) atomicOr(changed, 1u);
+}
+
+// per routed hit: a byte of its request (the admission for the owners' next round)
+__global__ __launch_bounds__(256) void k_req_spread(const uint8_t* __restrict__ req_byte, const u32* __restrict__ req_of_hit,
+                                                    const u32* __restrict__ perm, u32 n, uint8_t* __restrict__ out_sorted) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) out_sorted[j] = req_byte[req_of_hit[perm[j]]];
+}
+
+// per routed hit: did its request's walk get to it — it stops at the first limited counter unless the values are loaded
+// (in_memory.rs:109-113,129-133)
+__global__ __launch_bounds__(256) void k_req_reached(const int32_t* __restrict__ first, const u32* __restrict__ req_of_hit,
+                                                     const u32* __restrict__ perm, u32 n, uint8_t* __restrict__ out_sorted) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const u32 pos = perm[j];
+    const int32_t f = first[req_of_hit[pos]];
+    out_sorted[j] = (f < 0 || pos <= (u32)f) ? 1 : 0;
+}
+
 }  // namespace rl

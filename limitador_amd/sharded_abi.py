@@ -35,6 +35,7 @@ def load():
         "rl_sharded_submit_device": (i32, [p, p, u32, u64, p]),
         "rl_sharded_collect": (i32, [p, C.POINTER(u32)]),
         "rl_sharded_check_and_update_device": (i32, [p, p, u32, u64, p, C.POINTER(u32)]),
+        "rl_sharded_check_requests_device": (i32, [p, p, u32, p, u32, u64, i32, p, p, p, p, C.POINTER(u32)]),
         "rl_sharded_stream": (p, [p]),
         "rl_sharded_sync": (i32, [p]),
         "rl_sharded_in_flight": (u32, [p]),
@@ -129,6 +130,16 @@ class Sharded:
         n = C.c_uint32()
         self._check(SYMBOLS["rl_sharded_check_and_update_device"](self._h, d_hits, n_hits, int(now_us), d_verdict, C.byref(n)))
         return n.value
+
+    def check_requests(self, d_hits, n_hits, d_req_off, n_req, now_us, d_verdict, load_counters=False, d_first_limited=None,
+                       d_remaining=None, d_expires=None):
+        """Multi-counter requests, counters sharded by key (rl_sharded_check_requests_device): raw device pointers, blocking,
+        every rank calls it for every step.  -> rounds the fixpoint took."""
+        rounds = C.c_uint32()
+        self._check(SYMBOLS["rl_sharded_check_requests_device"](self._h, d_hits, n_hits, d_req_off, n_req, int(now_us),
+                                                                int(bool(load_counters)), d_verdict, d_first_limited, d_remaining,
+                                                                d_expires, C.byref(rounds)))
+        return rounds.value
 
     def sync(self):
         self._check(SYMBOLS["rl_sharded_sync"](self._h))

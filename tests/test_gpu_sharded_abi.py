@@ -1,6 +1,7 @@
 """include/rl_sharded.h on one MI355X: the routed step behind the C ABI, (a) over the library's own RCCL
 communicator with world 1, (b) with world 2 and 3 — ranks as threads of this process, each with its own engine,
-exchanging through the in-process transport — against the sequential oracle on the concatenated slices."""
+exchanging through the in-process transport — against the sequential oracle on the concatenated slices.  Single-counter
+slices (pipelined) and multi-counter requests whose counters live on several ranks (rl_sharded_check_requests_device)."""
 import threading
 
 import numpy as np
@@ -216,6 +217,161 @@ def test_a_slice_that_fails_on_one_rank_is_a_collective_outcome_not_a_hang():
     for s in range(steps):
         for r in range(world):
             assert np.array_equal(dev_out[s][r].cpu().numpy(), want[(s, r)]), f"slice {s} rank {r}"
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        e.close()
+    group.close()
+
+
+# ---- multi-counter requests, counters sharded by key: rl_sharded_check_requests_device --------------------------------
+class _RequestsOverTheAbi:
+    """What tests/test_sharded_multi_gloo.py's run_rank drives: check(hits [n, 2] int64, req_off int64) -> verdict,
+    first_limited, remaining, expires_in (torch tensors) and .rounds — here through the C ABI."""
+
+    def __init__(self, sh, dev):
+        self.sh, self.dev, self.rounds = sh, dev, 0
+
+    def check(self, hits, req_off, now_us, load_counters=False):
+        n, n_req = int(hits.shape[0]), int(req_off.shape[0]) - 1
+        off = req_off.to(torch.int32).contiguous()  # (bit pattern of the u32 offsets)
+        v = torch.full((max(n_req, 1),), 9, dtype=torch.uint8, device=self.dev)
+        f = torch.full((max(n_req, 1),), -7, dtype=torch.int32, device=self.dev)
+        rem = torch.zeros(max(n, 1), dtype=torch.int64, device=self.dev) if load_counters else None
+        exp = torch.zeros(max(n, 1), dtype=torch.int64, device=self.dev) if load_counters else None
+        torch.cuda.synchronize()
+        self.rounds = self.sh.check_requests(hits.data_ptr() if n else None, n, off.data_ptr(), n_req, now_us, v.data_ptr(),
+                                             load_counters, f.data_ptr(), rem.data_ptr() if load_counters else None,
+                                             exp.data_ptr() if load_counters else None)
+        return v[:n_req], f[:n_req].to(torch.int64), None if rem is None else rem[:n], None if exp is None else exp[:n]
+
+
+def _multi_engine(world, rank, seed, **kw):
+    from limitador_amd.sharded import owner_of_tensor
+    from limitador_amd.wire import RL_SIMPLE
+    from test_sharded_multi_gloo import ROWS as MROWS, SIMPLE
+
+    eng = Engine(capacity_cells=kw.pop("capacity_cells", 1 << 16), max_batch_hits=kw.pop("max_batch_hits", 1 << 16), **kw)
+    eng.set_limits(MROWS)
+    for limit, key in SIMPLE:
+        if int(owner_of_tensor(torch.tensor([key]), seed, world)[0]) == rank:
+            eng.add_counter(limit | RL_SIMPLE, key)
+    return eng
+
+
+def _check_union_of_tables(engines, orc):
+    from limitador_amd.wire import RL_SIMPLE
+
+    rows = np.concatenate([e.dump_cells() for e in engines])
+    assert len(np.unique(rows["key"])) == len(rows)
+    qual = rows[(rows["limit"] & RL_SIMPLE) == 0]
+    assert len(qual) == orc.num_qualified()
+    for r in qual:
+        assert (int(r["value"]), int(r["expiry_us"]), int(r["limit"])) == orc.peek(int(r["key"]))
+    for r in rows[(rows["limit"] & RL_SIMPLE) != 0]:
+        assert (int(r["value"]), int(r["expiry_us"])) == orc.peek_simple(int(r["limit"]))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_key_sharded_multi_counter_requests_behind_the_c_abi(world):
+    """in_memory.rs:141-153 across GPUs: a request is admitted iff all its counters — on whatever rank their keys hash
+    to — take it.  World 1 over the library's own RCCL communicator; world 2 and 3 as threads with the in-process
+    transport.  Against ONE sequential oracle on the concatenated slices: verdicts, first_limited, remaining /
+    expires_in, the union of the tables; at least one step needs three rounds."""
+    from test_sharded_multi_gloo import compare, expected, make_slices, run_rank
+
+    dev = torch.device("cuda", 0)
+    steps, n_req, load_steps = 6, 900, {1, 4}
+    probe = Engine(capacity_cells=1 << 10, max_batch_hits=1 << 10)
+    seed = probe.hash_seed
+    probe.close()
+    engines = [_multi_engine(world, r, seed) for r in range(world)]
+    group = sharded_abi.LocalGroup(world) if world > 1 else None
+    uid = sharded_abi.unique_id() if world == 1 else None
+    ranks = [sharded_abi.Sharded(engines[r], world, r, 8192, unique_id=uid, transport=group.transport(r) if group else None)
+             for r in range(world)]
+    data = make_slices(world, steps, n_req)
+    got, errors = {}, []
+
+    def run(r):
+        try:
+            got[r] = run_rank(_RequestsOverTheAbi(ranks[r], dev), data, r, steps, load_steps, device=dev)
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck at an exchange"
+    want, orc = expected(world, steps, n_req, load_steps)
+    assert compare(got, want, world, steps) >= 3
+    _check_union_of_tables(engines, orc)
+    # single-counter slices still go through the same communicator afterwards
+    rng = np.random.default_rng(3)
+    for r in range(world if world == 1 else 0):
+        hits = W.zipf_batch(500, 2000, rng)
+        hits["limit"] = 2
+        t, out = _to_dev(hits, dev), torch.empty(2000, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        assert ranks[r].check_and_update(t.data_ptr(), 2000, W.NOW0_US + 10**9, out.data_ptr()) == 2000
+        assert np.array_equal(out.cpu().numpy(), orc.check_and_update(hits, W.NOW0_US + 10**9)[0])
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        assert e.stats()["live_cells"] > 0  # the engines are their own again
+        e.close()
+    if group:
+        group.close()
+
+
+def test_a_multi_counter_step_one_shard_cannot_take_is_refused_on_every_rank():
+    from test_sharded_multi_gloo import SIMPLE
+
+    dev = torch.device("cuda", 0)
+    world = 2
+    probe = Engine(capacity_cells=1 << 10, max_batch_hits=1 << 10)
+    seed = probe.hash_seed
+    probe.close()
+    engines = [_multi_engine(world, 0, seed, capacity_cells=1 << 16), _multi_engine(world, 1, seed, capacity_cells=1 << 9)]
+    group = sharded_abi.LocalGroup(world)
+    ranks = [sharded_abi.Sharded(engines[r], world, r, 4096, transport=group.transport(r)) for r in range(world)]
+    rng = np.random.default_rng(4)
+    keys = rng.integers(1, 2**62, size=3000, dtype=np.int64)  # far more new cells than the small shard takes
+    hits = np.zeros((3000, 2), dtype=np.int64)
+    hits[:, 0] = keys
+    hits[:, 1] = 4 | (1 << 32)  # limit 4, delta 1
+    off = np.arange(0, 3001, 3, dtype=np.int64)
+    results, errors = {}, []
+
+    def run(r):
+        try:
+            sh = _RequestsOverTheAbi(ranks[r], dev)
+            t = torch.from_numpy(hits if r == 0 else hits[:0]).to(dev)
+            o = torch.from_numpy(off if r == 0 else off[:1]).to(dev)
+            try:
+                sh.check(t, o, W.NOW0_US)
+                results[r] = "applied"
+            except sharded_abi.ShardedError as ex:
+                results[r] = ex.code
+            small = torch.from_numpy(hits[:30] if r == 0 else hits[:0]).to(dev)  # a step that fits still works afterwards
+            so = torch.from_numpy(off[:11] if r == 0 else off[:1]).to(dev)
+            v, _f, _r, _e = sh.check(small, so, W.NOW0_US + 1)
+            results[(r, "after")] = int(v.sum().item())
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert results[0] == results[1] == -4  # RL_ERR_TABLE_FULL on both ranks, nothing applied on either
+    assert results[(0, "after")] == 0
+    assert sum(e.stats()["live_cells"] for e in engines) == 30 + len(SIMPLE)
     for sh in ranks:
         sh.close()
     for e in engines:
