@@ -286,7 +286,12 @@ def secondary(args, eng, dev, gen):
 
         hs = HostStorage(capacity_cells=1 << 12, max_batch_hits=1 << 10, device=eng.device)
         hs.set_clock(W.NOW0_US)
-        lims = [("ns", 10, 60, (), (), None), ("ns", 5, 60, (), (), None), ("ns", 50000, 10, (), (), None)]  # sandbox/limits.yaml
+        # limitador-server/sandbox/limits.yaml: 10/60 s, 5/60 s, 50000/10 s in one namespace.  The conditions are part of
+        # a limit's identity (max_value is not): without them the first two are ONE limit whose max_value flips with
+        # every counter the caller hands over — two rl_limits_set calls per request (what this leg measured before).
+        lims = [("ns", 10, 60, ("descriptors[0]['req.method'] == 'GET'",), (), None),
+                ("ns", 5, 60, ("descriptors[0]['req.method'] == 'POST'",), (), None),
+                ("ns", 50000, 10, ("descriptors[0]['req.path'] == '/json'",), (), None)]
         for la in lims:
             hs.add_counter(la)
         ctrs = [(la, ()) for la in lims]
@@ -307,8 +312,9 @@ def secondary(args, eng, dev, gen):
         out["configs0_3_limits_10k_sequential_calls"] = {
             "gpu_calls_per_s": 10_000 / sec, "gpu_us_per_call": sec / 10_000 * 1e6, "gpu_limited": int(limited),
             "cpu_oracle_calls_per_s": 10_000 / osec, "cpu_limited": int(v.sum()),
-            "note": "one request (3 counters) per call: the GPU path is launch-latency-bound, the reason the transport "
-                    "has to micro-batch"}
+            "note": "one request (3 counters) per call through the C++ mirror of the trait (rls_check_and_update); the calls "
+                    "are answered by a lingering k_gen_serve through a host-mapped mailbox, no kernel launch per call "
+                    "(RL_SERVE=0: one launch per call)"}
     except Exception as ex:  # the host mirror is optional plumbing for this leg
         out["configs0_3_limits_10k_sequential_calls"] = {"error": str(ex)[:200]}
     # -- BASELINE.json configs[4] shape on one GPU: 4 namespaces x 8 limits, 1 M requests -> ~3.1 M counters per call,

@@ -247,6 +247,13 @@ struct rl_engine {
     u32 m_call = 0;
     bool match_one = true;      // RL_MATCH_ONE=0: count pass + library scan + two copies + an event + fill pass
     // end of a general pass: {error bits, cells created, flags, sequence number} as one 16-byte store (k_gen_post)
+    // k_gen_serve (rl_general.hpp): per-request calls without a launch per call
+    ServeBox* h_serve = nullptr;  // host-mapped mailbox
+    bool serve_enabled = true;    // RL_SERVE=0: every per-request call is a launch of its own
+    bool serve_live = false;      // a server may be running (it leaves by itself after `serve_linger_us` without a request)
+    u32 serve_linger_us = 200;    // RL_SERVE_LINGER_US
+    u32 serve_timeout_ms = 60000; // RL_SERVE_TIMEOUT_MS
+    u64 n_serve_calls = 0, n_serve_launches = 0;
     bool gen_clean = false;     // d_bs[0..BS_ROT) and d_gst are zero (the last stream command was a general pass's clean-up)
     u32* h_gen_word = nullptr;
     u32 gen_post_seq = 0;
@@ -458,6 +465,29 @@ int wait_word(rl_engine* e, const u32* word, u32 seq, const char* what) {
     }
     return RL_OK;
 }
+
+// Tell a lingering k_gen_serve to leave and wait until it has: from here on the stream and the table are the caller's.
+// (The command carries the next sequence number, so the answer is "gone, waiting for exactly that one" whether the server
+// saw the command or had just left by itself.)
+void serve_stop(rl_engine* e) {
+    if (!e->serve_live) return;
+    ServeBox* b = e->h_serve;
+    const u32 seq = ++e->gen_seq ? e->gen_seq : ++e->gen_seq;
+    b->cmd[1] = 0;
+    b->cmd[2] = SRV_QUIT;
+    __atomic_store_n(&b->cmd[0], seq, __ATOMIC_RELEASE);
+    (void)wait_word(e, &b->gone[3], seq, "k_gen_serve (asked to leave)");
+    e->serve_live = false;
+}
+
+// The engine's mutex, and the device to ourselves: every entry point but the per-request host-buffer call sends a
+// lingering server away before it touches the stream or the table.
+struct EngineLock {
+    std::lock_guard<std::mutex> g;
+    explicit EngineLock(rl_engine* e, bool keep_server = false) : g(e->mu) {
+        if (!keep_server) serve_stop(e);
+    }
+};
 
 // the partition kernels' wave-private counters (dynamic LDS): PT_WAVES x (hash buckets + hot buckets) x 2 bytes
 inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof(unsigned short); }
@@ -1636,6 +1666,11 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     };
     if (!host_block((void**)&e->h_status, sizeof(Status))) return bail(RL_ERR_NOMEM);
     if (!host_block((void**)&e->h_tiny, TIO_BYTES)) return bail(RL_ERR_NOMEM);
+    if (!host_block((void**)&e->h_serve, sizeof(ServeBox))) return bail(RL_ERR_NOMEM);
+    memset(e->h_serve, 0, sizeof(ServeBox));
+    if (const char* v = getenv("RL_SERVE")) e->serve_enabled = atoi(v) != 0;
+    if (const char* v = getenv("RL_SERVE_TIMEOUT_MS")) e->serve_timeout_ms = (u32)std::max(1, atoi(v));
+    if (const char* v = getenv("RL_SERVE_LINGER_US")) e->serve_linger_us = (u32)std::max(1, atoi(v));
     if (!host_block((void**)&e->h_m_word, 64)) return bail(RL_ERR_NOMEM);
     if (!host_block((void**)&e->h_gen_word, 64)) return bail(RL_ERR_NOMEM);
     memset(e->h_m_word, 0, 64);
@@ -1662,6 +1697,10 @@ void rl_engine_destroy(rl_engine* e) {
         std::fprintf(stderr, "[engine] %llu partitioned batches; wait commands enqueued: %llu for a partition, %llu for an apply\n",
                      (unsigned long long)e->n_part_batches, (unsigned long long)e->n_wait_parted, (unsigned long long)e->n_wait_applied);
     (void)hipSetDevice(e->device);
+    if (e->h_serve) serve_stop(e);
+    if (e->apply_trace && e->n_serve_calls)
+        std::fprintf(stderr, "[engine] %llu per-request calls served by %llu launches of k_gen_serve\n",
+                     (unsigned long long)e->n_serve_calls, (unsigned long long)e->n_serve_launches);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->own_pstream) (void)hipStreamSynchronize(e->own_pstream);
     for (auto& pt : e->peer_tables)
@@ -1681,6 +1720,7 @@ void rl_engine_destroy(rl_engine* e) {
     if (e->h_total) (void)hipHostFree(e->h_total);
     if (e->h_m_total) (void)hipHostFree(e->h_m_total);
     if (e->h_m_word) (void)hipHostFree(e->h_m_word);
+    if (e->h_serve) (void)hipHostFree(e->h_serve);
     if (e->h_gen_word) (void)hipHostFree(e->h_gen_word);
     if (e->d_m_scan1) (void)hipFree(e->d_m_scan1);
     for (auto& ev : e->ev)
@@ -1706,7 +1746,7 @@ int32_t rl_status_is_transient(int32_t status) { return (status == RL_ERR_DEVICE
 
 int32_t rl_stats(rl_engine* e, rl_stats_t* out) {
     if (!e || !out) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     e->stats.capacity_cells = e->cap;
     e->stats.live_cells = e->live;
     e->stats.tombstones = e->tombs;
@@ -1718,7 +1758,7 @@ void* rl_engine_stream(rl_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -1732,7 +1772,7 @@ int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
 
 int32_t rl_engine_wait_event(rl_engine* e, void* event) {
     if (!e || !event) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     if (e->pstream != e->stream) {
         // Two streams: the event gates the NEXT batch's inputs, and the first kernel that reads them is its partition
@@ -1751,7 +1791,7 @@ int32_t rl_engine_wait_event(rl_engine* e, void* event) {
 
 int32_t rl_engine_record_event(rl_engine* e, void* event) {
     if (!e || !event) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     const int rc = flush_pending_apply(e);  // "everything submitted so far" includes a replay that was waiting for the next submit
     if (rc) return rc;
@@ -1761,7 +1801,7 @@ int32_t rl_engine_record_event(rl_engine* e, void* event) {
 
 int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n && !rows) return fail(e, RL_ERR_INVALID, "rows is null");
     if ((u64)first + n > e->max_limits) return fail(e, RL_ERR_INVALID, "limit rows [%u,%u) exceed max_limits %u", first, first + n, e->max_limits);
@@ -1783,7 +1823,7 @@ int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, ui
 
 int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (!(limit & RL_SIMPLE)) return RL_OK;  // in_memory.rs:39: only limits without variables
     if (RL_LIMIT_ID(limit) >= e->h_limits.size()) return fail(e, RL_ERR_INVALID, "unknown limit id %u", RL_LIMIT_ID(limit));
@@ -1801,7 +1841,7 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
                                          uint64_t* d_expires_in_us) {
     int rc = validate_batch(e, d_hits, n_hits, d_req_off, n_req, d_verdict);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
@@ -1832,6 +1872,77 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
         const bool general = req_off || load_counters || req_delta;
         const bool one_launch = general ? (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ)
                                         : (n_hits && n_hits <= e->tiny_max);
+        // ONE request of a few counters — the trait's per-request call: no launch at all when a server is lingering
+        // (k_gen_serve).  Only while the table has room to spare: growing or refusing is the ordinary path's business.
+        if (e->serve_enabled && e->h_tiny_coherent && !e->external_stream && general && n_req == 1 && n_hits >= 1 &&
+            n_hits <= SRV_MAX_HITS && n_hits <= e->gen_tiny_max && e->live + e->tombs + n_hits <= e->cap - e->cap / 4) {
+            ServeBox* b = e->h_serve;
+            Hit* t_hits = reinterpret_cast<Hit*>(e->h_tiny + TIO_OFF_HITS);
+            memcpy(t_hits, hits, (size_t)n_hits * sizeof(Hit));
+            const u32 seq = ++e->gen_seq ? e->gen_seq : ++e->gen_seq;
+            b->now = now_us;
+            b->delta = req_delta ? req_delta[0] : 0ull;
+            b->cmd[1] = n_hits;
+            b->cmd[2] = (load_counters ? SRV_LOAD : 0u) | (req_delta ? SRV_DELTA : 0u);
+            __atomic_store_n(&b->cmd[0], seq, __ATOMIC_RELEASE);
+            const volatile u32* done = &e->h_status->n_removed;
+            const auto t_start = std::chrono::steady_clock::now();
+            bool launched = false;  // (at most one launch per request: a server started FOR this command takes it at once,
+                                    // and the `gone` word that sent us here still says this request's number)
+            for (u64 spins = 0;; ++spins) {
+                if (!e->serve_live) {  // nobody is there (yet, or any more): a server that starts at this very command
+                    k_gen_serve<<<1, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_limits, (u32)e->h_limits.size(), t_hits, b,
+                                                          e->h_status, seq, e->serve_linger_us * 100u);  // (100 MHz clock)
+                    HIP_TRY(e, hipGetLastError());
+                    e->serve_live = true;
+                    launched = true;
+                    e->n_serve_launches++;
+                }
+                if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == seq) break;
+                if (!launched && __atomic_load_n(&b->gone[3], __ATOMIC_ACQUIRE) == seq) {  // it left without taking this one
+                    e->serve_live = false;
+                    continue;
+                }
+                __builtin_ia32_pause();
+                if ((spins & 0xFFFFu) == 0xFFFFu) {
+                    if (std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(e->serve_timeout_ms)) {
+                        e->serve_live = false;  // (whatever is there is no server of ours any more)
+                        return fail(e, RL_ERR_DEVICE, "k_gen_serve did not answer request %u within %u ms (cmd %u/%u/%u, done %u, gone %u, %llu calls, %llu launches, stream %s)",
+                                    seq, e->serve_timeout_ms, b->cmd[0], b->cmd[1], b->cmd[2], e->h_status->n_removed, b->gone[3],
+                                    (unsigned long long)e->n_serve_calls, (unsigned long long)e->n_serve_launches,
+                                    hipStreamQuery(e->stream) == hipSuccess ? "idle" : "busy");
+                    }
+                    std::this_thread::yield();
+                }
+            }
+            e->n_serve_calls++;
+            const u32 w0 = e->h_status->err, dropped = e->h_status->n_ord, created = e->h_status->n_inserted;
+            e->live += created;
+            if (w0 & 0xFFu) return status_to_error(e, w0 & 0xFFu);
+            e->live -= dropped;
+            e->tombs += dropped;
+            e->stats.batches++;
+            e->stats.hits += n_hits;
+            e->stats.ordered_hits += n_hits;
+            e->stats.ordered_batches++;
+            verdict[0] = (uint8_t)((w0 >> 8) & 1u);
+            if (first_limited) first_limited[0] = (int32_t)((w0 >> 16) & 0xFFFFu) - 1;
+            if (load_counters) {
+                for (u32 j = 0; j < 2 * n_hits; ++j) {  // every slot says itself which request it answers
+                    const volatile u32* sl = b->slot[j];
+                    for (u64 spins = 0; __atomic_load_n(&sl[2], __ATOMIC_ACQUIRE) != seq || sl[3] != j; ++spins) {
+                        __builtin_ia32_pause();
+                        if ((spins & 0xFFFFFu) == 0xFFFFFu && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                            return fail(e, RL_ERR_DEVICE, "k_gen_serve: a result slot did not arrive within 60 s");
+                    }
+                    const u64 val = ((u64)sl[1] << 32) | sl[0];
+                    if (j & 1u) expires_in_us[j >> 1] = val;
+                    else remaining[j >> 1] = val;
+                }
+            }
+            return RL_OK;
+        }
+        serve_stop(e);
         if (one_launch && n_hits <= TIO_HITS && n_req <= TIO_HITS) {
             Hit* t_hits = reinterpret_cast<Hit*>(e->h_tiny + TIO_OFF_HITS);
             u32* t_off = reinterpret_cast<u32*>(e->h_tiny + TIO_OFF_REQ);
@@ -1901,7 +2012,7 @@ int32_t rl_check_and_update_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t 
                                      uint64_t* expires_in_us) {
     int rc = validate_batch(e, hits, n_hits, req_off, n_req, verdict);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e, /*keep_server=*/true);  // (check_batch_locked sends the server away unless the call is one for it)
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
@@ -1953,7 +2064,7 @@ int32_t rl_check_and_update_submit_device_ev(rl_engine* e, const rl_hit* d_hits,
                                              uint8_t* d_verdict, int32_t* d_first_limited, void* done_event) {
     int rc = validate_batch(e, d_hits, n_hits, nullptr, n_hits, d_verdict);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (n_hits == 0) return fail(e, RL_ERR_INVALID, "empty batch");
     if (e->ph_open) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
@@ -1970,14 +2081,14 @@ int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, ui
 
 int32_t rl_engine_flush(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     return flush_pending_apply(e);
 }
 
 int32_t rl_check_and_update_collect(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     return collect_k1_bucketed(e);
 }
@@ -1986,7 +2097,7 @@ int32_t rl_is_within_limits_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t 
                                      uint64_t now_us, uint8_t* within) {
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, within);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy_for_reads(e)) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
@@ -2015,7 +2126,7 @@ int32_t rl_update_counter_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_
     uint8_t dummy = 0;
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, &dummy);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_hits == 0) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
@@ -2033,7 +2144,7 @@ int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hit
 int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_row* out, uint64_t cap,
                         uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy_for_reads(e)) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     const int rc = flush_pending_apply(e);  // behind every batch submitted so far
     if (rc) return rc;
@@ -2042,28 +2153,28 @@ int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_r
 
 int32_t rl_dump_cells(rl_engine* e, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_DUMP>(e, 0, 0, out, cap, n_out);
 }
 
 int32_t rl_delete_counters(rl_engine* e, uint32_t limit) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_DELETE_LIMIT>(e, limit, 0, nullptr, 0, nullptr);
 }
 
 int32_t rl_clear(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_CLEAR_SIMPLE>(e, 0, 0, nullptr, 0, nullptr);
 }
 
 int32_t rl_sweep_expired_rows(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_removed) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     const u64 before = e->live;
     int rc = scan_locked<SCAN_SWEEP>(e, 0, now_us, out, cap, nullptr);
@@ -2079,7 +2190,7 @@ int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
 
 int32_t rl_sweep_expired_submit(rl_engine* e, uint64_t now_us) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (e->ph_open) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (e->sub_seq - e->col_seq >= 3) return fail(e, RL_ERR_BUSY, "three commands are already in flight: collect one first");
     HIP_TRY(e, hipSetDevice(e->device));
@@ -2105,7 +2216,7 @@ int32_t rl_sweep_expired_submit(rl_engine* e, uint64_t now_us) {
 
 int32_t rl_sweep_expired_collect(rl_engine* e, uint64_t* n_removed) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "nothing in flight");
     if (e->inflight[e->col_seq & 3u].kind != 1) return fail(e, RL_ERR_INVALID, "the oldest command in flight is a batch: rl_check_and_update_collect");
     HIP_TRY(e, hipSetDevice(e->device));
@@ -2116,7 +2227,7 @@ int32_t rl_sweep_expired_collect(rl_engine* e, uint64_t* n_removed) {
 
 int32_t rl_compact(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     return do_compact(e, 0);
@@ -2124,7 +2235,7 @@ int32_t rl_compact(rl_engine* e) {
 
 int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     const u32 lg = ceil_log2(capacity_cells < 1024 ? 1024 : capacity_cells);
@@ -2137,7 +2248,7 @@ int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {
 
 int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n) {
     if (!e || (n && !d_rows)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     if (n == 0) return RL_OK;
@@ -2146,7 +2257,7 @@ int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n
 
 int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
     if (!e || (n && !rows)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     if (n == 0) return RL_OK;
@@ -2178,7 +2289,7 @@ int32_t rl_snapshot_save(rl_engine* e, const char* path) {
         if (rc) return rc;
         rows.resize(n);
     }
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     FILE* f = fopen(path, "wb");
     if (!f) return fail(e, RL_ERR_INVALID, "cannot open %s for writing", path);
     SnapshotHeader h{};
@@ -2231,7 +2342,7 @@ static PeerTables peer_tables_of(rl_engine* e) {
 
 int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const rl_cell_row* rows, uint64_t n, uint64_t now_us) {
     if (!e || (n && !rows)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (actor >= (u32)MERGE_MAX_ACTORS || self_actor >= (u32)MERGE_MAX_ACTORS)
         return fail(e, RL_ERR_INVALID, "actor ids are 0..%d", MERGE_MAX_ACTORS - 1);
@@ -2263,7 +2374,7 @@ int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const 
 
 int32_t rl_export_local(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     CellRow* d_out = nullptr;
@@ -2305,7 +2416,7 @@ static int32_t gen_phase_close(rl_engine* e) {
 int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* d_req_id, uint32_t n_hits, uint64_t now_us,
                             int32_t load_counters) {
     if (!e || (n_hits && (!d_hits || !d_req_id))) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight or a phased pass is open");
     if (n_hits > e->gen_cap) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u > %u: split the slice", n_hits, e->gen_cap);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -2357,7 +2468,7 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
 int32_t rl_gen_round_device(rl_engine* e, const uint8_t* d_admitted, uint8_t* d_pass, uint64_t* d_remaining,
                             uint64_t* d_expires_in_us) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
     if (e->ph_n == 0) return RL_OK;
     if (!d_pass) return fail(e, RL_ERR_INVALID, "d_pass is null");
@@ -2381,7 +2492,7 @@ int32_t rl_gen_round_device(rl_engine* e, const uint8_t* d_admitted, uint8_t* d_
 
 int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_new, uint64_t* room) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
     const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
     if (room) *room = used < bound ? bound - used : 0;
@@ -2412,7 +2523,7 @@ int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_
 
 int32_t rl_gen_commit_device(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
     if (e->ph_n == 0) return gen_phase_close(e);
     if (!e->ph_counted) return fail(e, RL_ERR_INVALID, "rl_gen_count_device must follow the last round");
@@ -2441,7 +2552,7 @@ int32_t rl_gen_commit_device(rl_engine* e) {
 
 int32_t rl_gen_abort(rl_engine* e) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (!e->ph_open) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     return gen_phase_close(e);
@@ -2450,7 +2561,7 @@ int32_t rl_gen_abort(rl_engine* e) {
 int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t n_limits, const rl_match_cond* conds,
                            uint32_t n_conds, uint32_t n_namespaces) {
     if (!e || (n_limits && !limits) || (n_conds && !conds)) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     std::vector<u32> ns_off(n_namespaces + 1, 0);
@@ -2632,7 +2743,7 @@ int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, 
                                         int32_t load_counters, uint8_t* d_verdict, int32_t* d_limited_limit,
                                         uint32_t* n_hits_out) {
     if (!e || !n_req || !d_req_ns || !d_ent_off || !d_req_delta || !d_verdict) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -2646,7 +2757,7 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
                                  rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out, uint64_t* remaining,
                                  uint64_t* expires_in_us) {
     if (!e || !n_req || !req_ns || !ent_off || !req_delta || !verdict) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
     const u32 n_ent = ent_off[n_req];
@@ -2687,7 +2798,7 @@ uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world) { return 
 static int32_t route_partition_on(rl_engine* e, hipStream_t st, bool block, const rl_hit* d_hits, uint32_t n_hits,
                                   uint32_t world, rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
     if (!e || !d_counts || (n_hits && (!d_hits || !d_out || !d_perm))) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (world == 0 || world > ROUTE_MAX_WORLD) return fail(e, RL_ERR_INVALID, "world %u not in [1,%d]", world, ROUTE_MAX_WORLD);
     HIP_TRY(e, hipSetDevice(e->device));
     const u32 nblk = n_hits ? cdiv(n_hits, ROUTE_TILE) : 0;
@@ -2719,7 +2830,7 @@ int32_t rl_route_partition_stream(rl_engine* e, void* stream, const rl_hit* d_hi
 static int32_t unpermute_on(rl_engine* e, hipStream_t st, bool block, const uint8_t* d_src, const uint32_t* d_perm,
                             uint32_t n, uint8_t* d_dst) {
     if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     if (n) k_unpermute_u8<<<cdiv(n, 256), 256, 0, st>>>(d_src, d_perm, n, d_dst);
     HIP_TRY(e, hipGetLastError());
@@ -2750,7 +2861,7 @@ int32_t rl_engine_info(rl_engine* e, int32_t* device, uint32_t* max_batch_hits) 
 int32_t rl_req_ids_stream(rl_engine* e, void* stream, const uint32_t* d_req_off, uint32_t n_req, uint32_t n_hits,
                           uint32_t base, const uint32_t* d_perm, uint32_t* d_req_of_hit, uint32_t* d_req_id_sorted) {
     if (!e || !d_req_off || (n_hits && (!d_perm || !d_req_of_hit || !d_req_id_sorted))) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n_req && n_hits) k_req_of_hit<<<cdiv(n_req, 256), 256, 0, st>>>(d_req_off, n_req, d_req_of_hit);
@@ -2766,7 +2877,7 @@ int32_t rl_req_round_stream(rl_engine* e, void* stream, const uint8_t* d_pass_so
     if (!e || !d_changed || (n_req && (!d_req_off || !d_adm || !d_first || !d_verdict)) ||
         (n_hits && (!d_pass_sorted || !d_perm || !d_req_of_hit || !d_pass_home || !d_adm_sorted)))
         return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n_hits) k_unpermute_u8<<<cdiv(n_hits, 256), 256, 0, st>>>(d_pass_sorted, d_perm, n_hits, d_pass_home);
@@ -2781,7 +2892,7 @@ int32_t rl_req_round_stream(rl_engine* e, void* stream, const uint8_t* d_pass_so
 int32_t rl_req_reached_stream(rl_engine* e, void* stream, const int32_t* d_first, const uint32_t* d_req_of_hit,
                               const uint32_t* d_perm, uint32_t n_hits, uint8_t* d_reached_sorted) {
     if (!e || (n_hits && (!d_first || !d_req_of_hit || !d_perm || !d_reached_sorted))) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     if (n_hits)
         k_req_reached<<<cdiv(n_hits, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(d_first, d_req_of_hit, d_perm, n_hits,
@@ -2793,7 +2904,7 @@ int32_t rl_req_reached_stream(rl_engine* e, void* stream, const int32_t* d_first
 int32_t rl_unpermute_u64_stream(rl_engine* e, void* stream, const uint64_t* d_src, const uint32_t* d_perm, uint32_t n,
                                 uint64_t* d_dst) {
     if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     if (n)
         k_unpermute_u64<<<cdiv(n, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(reinterpret_cast<const u64*>(d_src), d_perm, n,
@@ -2804,7 +2915,7 @@ int32_t rl_unpermute_u64_stream(rl_engine* e, void* stream, const uint64_t* d_sr
 
 int32_t rl_host_register(rl_engine* e, void* ptr, uint64_t bytes) {
     if (!e || !ptr || !bytes) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
@@ -2815,7 +2926,7 @@ int32_t rl_host_register(rl_engine* e, void* ptr, uint64_t bytes) {
 
 int32_t rl_host_unregister(rl_engine* e, void* ptr) {
     if (!e || !ptr) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     // (copies of host-buffer calls are complete when the call returns: nothing of ours still reads the range)
     if (hipHostUnregister(ptr) != hipSuccess) {
@@ -2827,7 +2938,7 @@ int32_t rl_host_unregister(rl_engine* e, void* ptr) {
 
 int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (enable < 0 || enable > 3) return fail(e, RL_ERR_INVALID, "timing mode %d", enable);
     e->timing = enable;
     return RL_OK;
@@ -2835,7 +2946,7 @@ int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
 
 int32_t rl_kernel_timing_read(rl_engine* e, double* ms, uint64_t* launches, int32_t reset) {
     if (!e) return RL_ERR_INVALID;
-    std::lock_guard<std::mutex> g(e->mu);
+    EngineLock g(e);
     if (ms)
         for (int q = 0; q < RL_TIMING_SLOTS; ++q) ms[q] = e->ms_slot[q];
     if (launches) *launches = e->timed_launches;

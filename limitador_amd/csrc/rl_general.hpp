@@ -995,13 +995,16 @@ constexpr u32 GT_MAX_REQ = 256;
 constexpr u32 GT_ENT = 512;  // LDS cells
 constexpr u32 GT_DIRTY = 1u, GT_CREATED = 2u, GT_REACHED = 4u;
 
-__global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 log2cap, u64 seed,
-                                                  const Hit* __restrict__ hits, u32 n_hits,
-                                                  const u32* __restrict__ req_off, u32 n_req,
-                                                  const LimitDev* __restrict__ limits, u32 n_limits, u64 now, int load,
-                                                  uint8_t* __restrict__ verdict, int32_t* __restrict__ first_limited,
-                                                  u64* __restrict__ remaining, u64* __restrict__ expires_in,
-                                                  const u64* __restrict__ req_delta, Status* host_status, u32 done_seq) {
+// The kernel's body (all 256 threads; ends with every thread past a barrier).  POST: the completion word goes to
+// host_status as k_gen_tiny's protocol wants it; else {error bits, cells dropped, cells created} are left in
+// out_counts[3] (workgroup memory) for the caller — k_gen_serve, which answers in its own format.  The output pointers
+// may be global or workgroup memory.
+template <bool POST>
+__device__ __forceinline__ void gen_tiny_body(Cell* __restrict__ table, u32 log2cap, u64 seed, const Hit* __restrict__ hits,
+                                              u32 n_hits, const u32* req_off, u32 n_req, const LimitDev* __restrict__ limits,
+                                              u32 n_limits, u64 now, int load, uint8_t* verdict, int32_t* first_limited,
+                                              u64* remaining, u64* expires_in, const u64* req_delta, Status* host_status,
+                                              u32 done_seq, u32* out_counts) {
     __shared__ u64 s_key[GT_ENT], s_value[GT_ENT], s_expiry[GT_ENT];
     __shared__ u32 s_slot[GT_ENT], s_limit[GT_ENT], s_flags[GT_ENT];
     __shared__ u64 h_max[GT_MAX], h_win[GT_MAX];
@@ -1141,11 +1144,136 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
     }
     __syncthreads();
     if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // completion word written last, with the counts, as ONE 16-byte store (see apply_finish)
-        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(u32x4{s_err, s_dropped, s_created, done_seq},
-                                    reinterpret_cast<u32x4*>(host_status));
+        if (POST) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // completion word written last, with the counts, as ONE 16-byte store (see apply_finish)
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4{s_err, s_dropped, s_created, done_seq},
+                                        reinterpret_cast<u32x4*>(host_status));
+        } else {
+            out_counts[0] = s_err;
+            out_counts[1] = s_dropped;
+            out_counts[2] = s_created;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 log2cap, u64 seed,
+                                                  const Hit* __restrict__ hits, u32 n_hits,
+                                                  const u32* __restrict__ req_off, u32 n_req,
+                                                  const LimitDev* __restrict__ limits, u32 n_limits, u64 now, int load,
+                                                  uint8_t* __restrict__ verdict, int32_t* __restrict__ first_limited,
+                                                  u64* __restrict__ remaining, u64* __restrict__ expires_in,
+                                                  const u64* __restrict__ req_delta, Status* host_status, u32 done_seq) {
+    gen_tiny_body<true>(table, log2cap, seed, hits, n_hits, req_off, n_req, limits, n_limits, now, load, verdict, first_limited,
+                        remaining, expires_in, req_delta, host_status, done_seq, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gen_serve: per-request calls WITHOUT a launch per call.  One request with 1..SRV_MAX_HITS counters (the trait's
+// check_and_update called request by request: BASELINE.json configs[0]) is launch-latency-bound as a kernel of its own:
+// ~10 us from the enqueue to the first wave, ~10 us for the stream to be seen idle again — 47 us per call for 10 us of
+// work.  This kernel stays: one workgroup polls a MAILBOX in host-mapped memory, serves request after request with
+// k_gen_tiny's body (same semantics, same code), and leaves by itself `linger` after the last one — so that nothing
+// ever waits for it longer than that (a device-wide synchronise, the next kernel on the stream) — or at once when
+// the host says so (any other engine call does, before it touches the device).
+//   host -> device   the hits (the engine's host-mapped staging), now, the request's u64 delta; then cmd = {seq, hits,
+//                    flags, 0}, seq LAST: a command is the one the server expects or it is not there yet
+//   device -> host   done = {error bits | verdict << 8 | (first_limited + 1) << 16, cells dropped, cells created, seq},
+//                    seq in a system-scope RELEASE store behind the rest (the kernel does not end behind a request:
+//                    only write-through stores ever leave the L2); with load_counters two 16-byte slots per hit in front
+//                    of it, each tagged with seq and its index
+//   leaving          gone = {0, 0, 0, the seq it was waiting for}: the host then knows that command was NOT taken (it
+//                    launches a new server for it) — the decision is one read of cmd, so "taken" and "gone" exclude
+//                    each other.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 SRV_MAX_HITS = 16;
+constexpr u32 SRV_LOAD = 1u, SRV_DELTA = 2u, SRV_QUIT = 4u;
+struct ServeBox {
+    u32 cmd[4];
+    u64 now, delta;
+    u32 pad0[8];
+    u32 gone[4];
+    u32 pad1[12];
+    u32 slot[2 * SRV_MAX_HITS][4];  // {lo, hi, seq, index}: remaining of hit j at [2 j], expires_in at [2 j + 1]
+};
+static_assert(sizeof(ServeBox) == 128 + 32 * SRV_MAX_HITS, "ServeBox layout");
+
+// 16 bytes to the host from a kernel that does not end: two 8-byte system-scope stores, the one with the sequence
+// number (upper half of `second`) a RELEASE behind the other — whoever reads the number with acquire finds the rest.
+__device__ __forceinline__ void srv_post(u64* dst, u64 first, u64 second) {
+    __hip_atomic_store(dst, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, second, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32 log2cap, u64 seed,
+                                                   const LimitDev* __restrict__ limits, u32 n_limits,
+                                                   const Hit* __restrict__ hits, ServeBox* box, Status* host_status,
+                                                   u32 first_seq, u32 linger_ticks) {
+    __shared__ u32 s_c[4];
+    __shared__ u64 s_now, s_delta;
+    __shared__ u32 s_off[2], s_counts[3];
+    __shared__ uint8_t o_verdict[4];
+    __shared__ int32_t o_first[1];
+    __shared__ u64 o_rem[SRV_MAX_HITS], o_exp[SRV_MAX_HITS];
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32 tid = threadIdx.x;
+    u32 expect = first_seq;
+    for (;;) {
+        if (tid == 0) {
+            const u64 t0 = wall_clock64();
+            bool leave = false;
+            for (;;) {
+                if (__hip_atomic_load(&box->cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == expect) break;
+                if (wall_clock64() - t0 > (u64)linger_ticks) {
+                    leave = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            u32 nh = 0, flags = 0;
+            if (!leave) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                nh = __hip_atomic_load(&box->cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                flags = __hip_atomic_load(&box->cmd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_now = __hip_atomic_load(&box->now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_delta = __hip_atomic_load(&box->delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((flags & SRV_QUIT) || nh == 0 || nh > SRV_MAX_HITS) leave = true;
+            }
+            s_c[0] = leave ? 1u : 0u;
+            s_c[1] = nh;
+            s_c[2] = flags;
+            s_off[0] = 0;
+            s_off[1] = nh;
+        }
+        __syncthreads();
+        if (s_c[0]) {
+            if (tid == 0) srv_post(reinterpret_cast<u64*>(box->gone), 0ull, (u64)expect << 32);
+            return;
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the staging area was rewritten by the host: no line of it from the last request)
+        const u32 n_hits = s_c[1], flags = s_c[2];
+        const int load = (flags & SRV_LOAD) ? 1 : 0;
+        gen_tiny_body<false>(table, log2cap, seed, hits, n_hits, s_off, 1u, limits, n_limits, s_now, load, o_verdict, o_first, o_rem,
+                             o_exp, (flags & SRV_DELTA) ? &s_delta : nullptr, nullptr, 0u, s_counts);
+        if (load && tid < n_hits && !s_counts[0]) {
+            // written THROUGH to the host (system scope) and acknowledged before the barrier: the kernel does not end
+            // behind a request, so nothing else would ever push these lines out of the L2
+            u64* sl = reinterpret_cast<u64*>(box->slot[2 * tid]);
+            __hip_atomic_store(sl + 0, o_rem[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(sl + 1, (u64)expect | ((u64)(2u * tid) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(sl + 2, o_exp[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(sl + 3, (u64)expect | ((u64)(2u * tid + 1u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const u32 w0 = s_counts[0] ? s_counts[0] : (((u32)o_verdict[0] << 8) | ((u32)(o_first[0] + 1) << 16));
+            srv_post(reinterpret_cast<u64*>(host_status), (u64)w0 | ((u64)s_counts[1] << 32), (u64)s_counts[2] | ((u64)expect << 32));
+        }
+        expect = expect + 1u ? expect + 1u : 1u;
+        __syncthreads();
     }
 }
 

@@ -73,14 +73,63 @@ def run_both(eng, orc, hits, now, **kw):
 
 
 # ---- the reference's own scenarios, through the engine ---------------------------------------
-@pytest.mark.parametrize("one_launch", [True, False], ids=["tiny_path_on", "partitioned_only"])
+@pytest.mark.parametrize("mode", ["served", "one_launch_per_call", "partitioned_only"])
 @pytest.mark.parametrize("scenario", scenarios.ALL, ids=lambda f: f.__name__)
-def test_reference_scenarios_on_engine(make_engine, monkeypatch, scenario, one_launch):
-    """Per-request calls (1..k hits) take the one-launch path (k_bkt_tiny) by default; RL_TINY_MAX=0
-    runs the same scenarios through the four partitioned kernels."""
-    if not one_launch:
+def test_reference_scenarios_on_engine(make_engine, monkeypatch, scenario, mode):
+    """Per-request calls (one request, 1..k counters) are answered by a lingering k_gen_serve without a launch per call
+    (the default); RL_SERVE=0: one launch per call (k_gen_tiny / k_bkt_tiny); RL_TINY_MAX=0: the same scenarios through
+    the partitioned kernels."""
+    if mode != "served":
+        monkeypatch.setenv("RL_SERVE", "0")
+    if mode == "partitioned_only":
         monkeypatch.setenv("RL_TINY_MAX", "0")
     scenario(TestsLimiter(make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)))
+
+
+def test_per_request_calls_between_everything_else(make_engine):
+    """The server (k_gen_serve) lingers on the engine's stream: every other call — batches, reads, sweeps, limits —
+    must send it away first, and a per-request call after a pause longer than its linger finds it gone and starts
+    another.  One request at a time against the oracle, with u64 deltas and load_counters, interleaved with the rest of
+    the surface."""
+    import time
+
+    rng = np.random.default_rng(77)
+    rows = [(9, 1), (40, 10), (300, 60)]
+    eng, orc = pair(make_engine, rows, [(2, 9_000_009)])
+    keys = W.splitmix64(np.arange(1, 60, dtype=np.uint64))
+    now = NOW
+
+    def one_request(load, big_delta=False):
+        k = int(rng.integers(1, 5))
+        idx = rng.integers(0, len(keys), size=k)
+        hits = np.zeros(k + 1, dtype=HIT_DTYPE)
+        hits[0] = (9_000_009, 2 | RL_SIMPLE, 1)  # simple counters first
+        hits["key"][1:] = keys[idx]
+        hits["limit"][1:] = idx % 2
+        d = int(rng.integers(0, 3))
+        hits["delta"] = d
+        kw = {"req_off": np.array([0, k + 1], dtype=np.uint32), "load_counters": load}
+        if big_delta:
+            kw["req_delta"] = np.array([2**40 + d], dtype=np.uint64)
+        run_both(eng, orc, hits, now, **kw)
+
+    for step in range(300):
+        one_request(load=bool(step % 3 == 0), big_delta=(step % 50 == 49))
+        now += int(rng.integers(0, SEC // 3))
+        if step % 40 == 7:  # a batch in between
+            idx = rng.integers(0, len(keys), size=5000)
+            hits = np.zeros(5000, dtype=HIT_DTYPE)
+            hits["key"], hits["limit"], hits["delta"] = keys[idx], idx % 2, 1
+            run_both(eng, orc, hits, now)
+        if step % 40 == 17:
+            assert eng.sweep_expired(now) == orc.sweep_expired(now)
+        if step % 40 == 27:
+            probe = np.zeros(3, dtype=HIT_DTYPE)
+            probe["key"], probe["limit"], probe["delta"] = keys[:3], np.arange(3) % 2, 1
+            assert np.array_equal(eng.is_within_limits(probe, now), orc.is_within_limits(probe, now))
+        if step % 40 == 37:
+            time.sleep(0.002)  # ten lingers: the server has left by itself
+    assert_same_state(eng, orc, n_simple_expected=1)
 
 
 # ---- seeded random traces, single-counter requests -------------------------------------------
