@@ -1874,7 +1874,8 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
                                         : (n_hits && n_hits <= e->tiny_max);
         // ONE request of a few counters — the trait's per-request call: no launch at all when a server is lingering
         // (k_gen_serve).  Only while the table has room to spare: growing or refusing is the ordinary path's business.
-        if (e->serve_enabled && e->h_tiny_coherent && !e->external_stream && general && n_req == 1 && n_hits >= 1 &&
+        // (a single-counter request is a request of one counter: the general body is exact for it too)
+        if (e->serve_enabled && e->h_tiny_coherent && !e->external_stream && n_req == 1 && n_hits >= 1 &&
             n_hits <= SRV_MAX_HITS && n_hits <= e->gen_tiny_max && e->live + e->tombs + n_hits <= e->cap - e->cap / 4) {
             ServeBox* b = e->h_serve;
             Hit* t_hits = reinterpret_cast<Hit*>(e->h_tiny + TIO_OFF_HITS);
