@@ -19,7 +19,10 @@ for pmc in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum T
   timeout 600 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out/pmc_$name" -o p -- $BENCH > /dev/null 2> "$out/pmc_$name.err"
   timeout 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out/calib_$name" -o c -- $OLDPWD/scripts/microbench/bin/pmc_calib > /dev/null 2> "$out/calib_$name.err"
 done
+# 2b. the general resolver (match + multi-counter check_and_update): kernel trace of scripts/bench_match.py
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/gen" -o g -- python $OLDPWD/scripts/bench_match.py --steps 6 > "$out/gen_bench_under_trace.json" 2> "$out/gen.err"
 cd "$OLDPWD"
+timeout 200 python scripts/bench_match.py --steps 20 > "$out/gen_bench.json" 2>> "$out/gen.err"
 # keep the merged-back output small: per-dispatch CSVs of the engine's kernels only
 find "$out" -type f -size +8M -delete
 find "$out" -type f | head -50 > "$out/files.txt"

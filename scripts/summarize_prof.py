@@ -159,3 +159,29 @@ for name in ("bench.json", "bench_under_trace.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         open(out + "_" + name, "w").write(open(p).read())
+
+
+# ---- the general resolver's timeline (scripts/bench_match.py under rocprofv3 --kernel-trace) --------------------------
+gen_trace = os.path.join(src, "gen", "g_kernel_trace.csv")
+if os.path.exists(gen_trace):
+    rows = sorted(csv.DictReader(open(gen_trace)), key=lambda r: int(r["Start_Timestamp"]))
+    first = [i for i, r in enumerate(rows) if "k_match_count2" in r["Kernel_Name"] or "k_match_fast<false>" in r["Kernel_Name"]]
+    with open(out + "_general_timeline.md", "w") as f:
+        f.write(f"rocprofv3 --kernel-trace of `python scripts/bench_match.py --steps 6` ({tag}): one steady-state call of "
+                "rl_match_and_check_batch_device (1 M requests -> 3.1 M counters), kernel by kernel.\n\n")
+        try:
+            line = [l for l in open(os.path.join(src, "gen_bench.json")).read().splitlines() if l.startswith("{")][-1]
+            f.write(f"Without the profiler: `{line}`\n\n")
+        except Exception:
+            pass
+        if len(first) >= 2:
+            a, b = first[-2], first[-1]
+            t0 = int(rows[a]["Start_Timestamp"])
+            prev = t0
+            f.write("| start us | duration us | idle before us | kernel |\n|---|---|---|---|\n")
+            for r in rows[a:b]:
+                st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                f.write(f"| {(st - t0) / 1e3:.1f} | {(en - st) / 1e3:.1f} | {(st - prev) / 1e3:.1f} | `{short(r['Kernel_Name'])}` |\n")
+                prev = en
+            f.write(f"\nDevice span of the call: {(prev - t0) / 1e3:.1f} us.\n")
+    print("wrote", out + "_general_timeline.md")
