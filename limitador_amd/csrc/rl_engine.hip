@@ -173,7 +173,8 @@ struct rl_engine {
     bool apply_events = true;
     bool part_compact = true;       // RL_PART_COMPACT=0: k_bkt_part (1024 threads, ~78 KB of LDS) for 4096-hit tiles too instead of
                                     // k_bkt_part_c (512 threads, ~41 KB: resident beside the replay's workgroups; 1.7 us per step)
-    bool fuse = false;              // RL_FUSE=1: one stream, the partition of batch j + 1 as a role of the launch that replays batch j
+    bool fuse = false;              // one stream, the partition of batch j + 1 as a role of the launch that replays batch j: the default of
+                                    // engines with max_batch_hits <= 256 k (RL_FUSE=0 / 1 overrides)
                                     // (k_bkt_step; parity-green, but the role's 4-wave workgroups walk a tile in 2 x 16 dependent steps:
                                     // 57 us alone against 24 us for k_bkt_part's 16 waves — measured slower, kept for the record)
     bool defer_apply = true;        // RL_DEFER_APPLY=0: enqueue k_bkt_apply at submit (see PendingApply)
@@ -1482,6 +1483,9 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
     if (const char* v = getenv("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
     if (const char* v = getenv("RL_APPLY_EVENTS")) e->apply_events = atoi(v) != 0;
+    // Engines for small batches run the fused form (one stream, one launch per step): a step of <= 256 k hits is bound by
+    // launches, not by kernels (64 k hits: 16.4 us per batch fused, 19.4 on two streams; 1 M hits: 65-75 against 47).
+    e->fuse = e->max_batch <= (1u << 18);
     if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
     if (const char* v = getenv("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0;
     if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch

@@ -11,6 +11,14 @@ from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["engine_default", "two_streams"])
+def pipeline_form(request, monkeypatch):
+    """Engines as small as these tests' run the fused form by default (one stream, one launch per step); every test here
+    also runs on the two-stream pipeline that engines for large batches use."""
+    if request.param == "two_streams":
+        monkeypatch.setenv("RL_FUSE", "0")
+
 SEED = 0x9E3779B97F4A7C15  # Engine's default hash_seed
 M64 = (1 << 64) - 1
 

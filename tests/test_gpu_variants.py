@@ -1,8 +1,9 @@
 """The build variants of the bucketed hot path, each bit-exact against the CPU oracle on a trace that takes every
 branch of the hot-key code (promotion, decided by position, replayed, created by the hot path, demoted):
 
-  default            two streams: k_bkt_part (1024-thread workgroups) on a stream of its own, the replay (k_bkt_step) enqueued
-                     one submit late (PendingApply); 16-bit limit ids in LDS, default verdicts written by the partition
+  default            an engine for batches of <= 256 k hits: RL_FUSE=1 below (larger engines: RL_FUSE=0)
+  RL_FUSE=0          two streams: k_bkt_part on a stream of its own, the replay (k_bkt_step) enqueued one submit late
+                     (PendingApply); 16-bit limit ids in LDS, default verdicts written by the partition
   RL_DEFER_APPLY=0   the replay enqueued at submit, behind a wait for its partition
   RL_PIPE_DEPTH=2    the partition of batch p waits for the replay of batch p - 2
   RL_APPLY2_CFG=1    32-bit limit ids in LDS (what an engine with more than 32768 limit rows takes by itself)
@@ -24,8 +25,11 @@ from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [{}, {"RL_DEFER_APPLY": "0"}, {"RL_APPLY2_CFG": "1"}, {"RL_FUSE": "1"}, {"RL_OVERLAP": "0"},
-            {"RL_FUSE": "1", "RL_DEFER_APPLY": "0"}, {"RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"}, {"RL_APPLY_EVENTS": "0"}, {"RL_PART_COMPACT": "0"}]
+# (an engine this small is fused by default: the two-stream variants say RL_FUSE=0)
+TWO = {"RL_FUSE": "0"}
+VARIANTS = [{}, TWO, {**TWO, "RL_DEFER_APPLY": "0"}, {**TWO, "RL_APPLY2_CFG": "1"}, {"RL_FUSE": "1"}, {**TWO, "RL_OVERLAP": "0"},
+            {"RL_FUSE": "1", "RL_DEFER_APPLY": "0"}, {**TWO, "RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"},
+            {**TWO, "RL_APPLY_EVENTS": "0"}, {**TWO, "RL_PART_COMPACT": "0"}]
 
 
 def hot_trace(eng, orc, rng, n=60_000):
