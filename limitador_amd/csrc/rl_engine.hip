@@ -876,6 +876,16 @@ int collect_k1_bucketed(rl_engine* e) {
     if (e->pend.valid && e->pend.slot == (u32)(e->col_seq & 3u)) {  // nothing was submitted behind it: its k_bkt_apply goes out now
         const int prc = flush_pending_apply(e);
         if (prc) return prc;
+    } else if (e->pend.valid && e->pstream != e->stream) {
+        // The replay of a LATER batch is still held back (the pipeline is draining: no submit came to send it out).  If
+        // its partition has finished, it goes out now, behind the replay this collect waits for — not after it, when the
+        // stream would sit idle for a launch latency.  (Not finished yet: it stays held back, no wait command.)
+        if (hipEventQuery(e->ev_parted[e->pend.p & 3u]) == hipSuccess) {
+            const int prc = flush_pending_apply(e);
+            if (prc) return prc;
+        } else {
+            (void)hipGetLastError();
+        }
     }
     if (!f.settled) {
         const int wrc = wait_done(e, f);
