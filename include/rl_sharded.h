@@ -111,7 +111,9 @@ int32_t rl_sharded_check_and_update_device(rl_sharded *s, const rl_hit *d_hits, 
  * or -1 (may be NULL); d_remaining / d_expires_in_us per hit with load_counters (else may be NULL).  n_hits and n_req
  * <= max_slice_hits.  BLOCKING, on an empty pipeline, called by EVERY rank for every step (it contains collectives: two
  * exchanges of one byte per hit and one word per rank each round).  A step one rank cannot take — a malformed hit, a full
- * table — is refused on every rank with nothing applied anywhere; the rank at fault gets the reason. */
+ * table, no memory for the step's arrays — is refused on every rank with nothing applied anywhere; the rank at fault gets
+ * the reason.  (A HIP or transport error in the MIDDLE of a step is not an outcome of the input: the ranks are no longer
+ * in step and the communicator is to be destroyed.) */
 int32_t rl_sharded_check_requests_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n_hits, const uint32_t *d_req_off,
                                          uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t *d_verdict,
                                          int32_t *d_first_limited, uint64_t *d_remaining, uint64_t *d_expires_in_us,

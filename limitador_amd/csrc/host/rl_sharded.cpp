@@ -23,6 +23,9 @@
 
 namespace {
 
+constexpr uint32_t RQ_GATHER = 16;   // rq.d_words[RQ_GATHER + p]: rank p's word of the last gather (multi-counter step)
+constexpr uint32_t RQ_CHANGED = 64;  // rq.d_words[RQ_CHANGED]: k_req_and raises it
+constexpr uint32_t RQ_WORDS = 128;
 constexpr int SLOTS = 3;          // slices in flight: routed / applied / returned
 constexpr uint32_t MAX_WORLD = 16; // the router's limit (rl_route.hpp)
 enum Stage { ROUTED = 1, APPLIED = 2, RETURNED = 3 };
@@ -404,6 +407,8 @@ int32_t create_common(rl_engine* e, uint32_t world, uint32_t rank, uint32_t max_
     for (auto* v : {&s->b_so, &s->b_sc, &s->b_ro, &s->b_rc, &s->v_so[0], &s->v_sc[0], &s->v_ro[0], &s->v_rc[0], &s->v_so[1],
                     &s->v_sc[1], &s->v_ro[1], &s->v_rc[1]})
         v->assign(world, 0);
+    HIP_S(s, hipMalloc(&s->rq.d_words, RQ_WORDS * 4));
+    HIP_S(s, hipHostMalloc(reinterpret_cast<void**>(&s->rq.h_words), RQ_WORDS * 4, hipHostMallocDefault));
     s->c_off.resize(world);
     s->c_cnt.assign(world, sizeof(uint32_t));
     for (uint32_t q = 0; q < world; ++q) s->c_off[q] = q * sizeof(uint32_t);
@@ -576,10 +581,8 @@ int32_t rl_sharded_check_and_update_device(rl_sharded* s, const rl_hit* d_hits, 
 // ---- multi-counter requests, counters sharded by key (SURVEY.md §8e "k > 1") --------------------------------------
 namespace {
 
-constexpr uint32_t RQ_GATHER = 16;   // d_words[RQ_GATHER + p]: rank p's word of the last gather
-constexpr uint32_t RQ_CHANGED = 64;  // d_words[RQ_CHANGED]: k_req_and raises it
-constexpr uint32_t RQ_WORDS = 128;
-
+// The arrays of the multi-counter step, allocated at its first call.  (The words every collective decision travels in are
+// allocated with the communicator: a rank that runs out of memory HERE can still tell its peers.)
 int32_t req_bufs(rl_sharded* s) {
     if (s->rq.ready) return RL_OK;
     const size_t ms = s->max_slice ? s->max_slice : 1;
@@ -588,8 +591,6 @@ int32_t req_bufs(rl_sharded* s) {
     HIP_S(s, hipMalloc(&q.req_of_hit, ms * 4));
     HIP_S(s, hipMalloc(&q.req_id_sorted, ms * 4));
     HIP_S(s, hipMalloc(&q.r_req, mr * 4));
-    HIP_S(s, hipMalloc(&q.d_words, RQ_WORDS * 4));
-    HIP_S(s, hipHostMalloc(reinterpret_cast<void**>(&q.h_words), RQ_WORDS * 4, hipHostMallocDefault));
     HIP_S(s, hipMalloc(&q.pass_recv, mr));
     HIP_S(s, hipMalloc(&q.pass_sorted, ms));
     HIP_S(s, hipMalloc(&q.pass_home, ms));
@@ -676,21 +677,23 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
     if (!s) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(s->mu);
     HIP_S(s, hipSetDevice(s->device));
-    int32_t rc = req_bufs(s);
-    if (rc != RL_OK) return rc;  // (out of memory before the first exchange: nothing a peer could be told through)
+    int32_t rc = RL_OK;
+    const int32_t mem_rc = req_bufs(s);  // (a rank that cannot allocate says so in the first exchange, like any other refusal)
     const uint32_t W = s->world;
     auto& q = s->rq;
     uint32_t words[MAX_WORLD];
     // ---- 0. every rank's request count (the ids of the ranks behind me start after mine); a rank whose arguments are
     //         unusable says so HERE, so that all ranks leave together
     int32_t bad = RL_OK;
-    if (!s->pending.empty()) bad = RL_ERR_BUSY;
+    if (mem_rc != RL_OK) bad = RL_ERR_NOMEM;
+    else if (!s->pending.empty()) bad = RL_ERR_BUSY;
     else if ((n_hits && !d_hits) || !d_req_off || (n_req && !d_verdict) || (load_counters && n_hits && (!d_remaining || !d_expires_in_us)))
         bad = RL_ERR_INVALID;
     else if (n_hits > s->max_slice || n_req > s->max_slice) bad = RL_ERR_BATCH_TOO_LARGE;
     rc = gather_host_word(s, bad ? 0xFFFFFFFFu : n_req, words);
     if (rc != RL_OK) return rc;
     if (max_of(words, W) == 0xFFFFFFFFu) {
+        if (bad == RL_ERR_NOMEM) return fail(s, bad, "out of device memory for the step's arrays");
         if (bad == RL_ERR_BUSY) return fail(s, bad, "slices are in flight: collect them first");
         if (bad == RL_ERR_BATCH_TOO_LARGE) return fail(s, bad, "%u hits / %u requests, communicator sized for %u", n_hits, n_req, s->max_slice);
         if (bad) return fail(s, bad, "null argument");

@@ -1684,7 +1684,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     memset(e->h_serve, 0, sizeof(ServeBox));
     if (const char* v = getenv("RL_SERVE")) e->serve_enabled = atoi(v) != 0;
     if (const char* v = getenv("RL_SERVE_TIMEOUT_MS")) e->serve_timeout_ms = (u32)std::max(1, atoi(v));
-    if (const char* v = getenv("RL_SERVE_LINGER_US")) e->serve_linger_us = (u32)std::max(1, atoi(v));
+    if (const char* v = getenv("RL_SERVE_LINGER_US")) e->serve_linger_us = (u32)std::min(std::max(1, atoi(v)), 1000000);
     if (!host_block((void**)&e->h_m_word, 64)) return bail(RL_ERR_NOMEM);
     if (!host_block((void**)&e->h_gen_word, 64)) return bail(RL_ERR_NOMEM);
     memset(e->h_m_word, 0, 64);
