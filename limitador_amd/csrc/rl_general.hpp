@@ -1116,6 +1116,22 @@ __device__ __forceinline__ void gen_tiny_body(Cell* __restrict__ table, u32 log2
         u32 c_flg = 0;
         u64 o_rem = 0, o_exp = 0;  // lane j: what hit j loaded
         u32 o_res = 0;             // lane r: verdict | (first + 1) << 1
+        // Requests that list their simple counters first (the mirror and the matcher do) need ONE walk in index order, not
+        // two filtered ones: no hit of a request may be a simple counter right behind a qualified one of the same request.
+        u32 my_req = 0;
+        if (lane < n_hits) {
+            u32 a = 0, bnd = n_req;  // the request r with s_req_off[r] <= lane < s_req_off[r + 1]
+            while (bnd - a > 1) {
+                const u32 m = (a + bnd) >> 1;
+                if (s_req_off[m] <= lane) a = m;
+                else bnd = m;
+            }
+            my_req = a;
+        }
+        const u32 prev_lim = (u32)__shfl_up((int)r_lim, 1), prev_req = (u32)__shfl_up((int)my_req, 1);
+        const bool bad_pair = lane > 0 && lane < n_hits && prev_req == my_req && (prev_lim & SIMPLE_FLAG) == 0u &&
+                              (r_lim & SIMPLE_FLAG) != 0u;
+        const int n_pass = __ballot(bad_pair) == 0ull ? 1 : 2;
 #define RL_RD32(v, l) gt_readlane((u32)(v), (u32)(l))
 #define RL_RD64(v, l) (((u64)RL_RD32((u32)((v) >> 32), l) << 32) | (u64)RL_RD32((u32)(v), l))
 #define RL_WR32(v, x, l) v = gt_writelane((v), (u32)(x), (u32)(l))
@@ -1130,10 +1146,9 @@ __device__ __forceinline__ void gen_tiny_body(Cell* __restrict__ table, u32 log2
             const u32 b = s_req_off[r], e_ = s_req_off[r + 1];
             int32_t first = -1;
             bool stopped = false;
-            for (int pass = 0; pass < 2 && !stopped; ++pass) {  // simple counters (:105-118), then qualified (:121-139)
+            for (int pass = 0; pass < n_pass && !stopped; ++pass) {  // simple counters (:105-118), then qualified (:121-139)
                 for (u32 j = b; j < e_; ++j) {
-                    const u32 lim = RL_RD32(r_lim, j);
-                    if (((lim & SIMPLE_FLAG) == 0u) != (pass == 1)) continue;
+                    if (n_pass == 2 && ((RL_RD32(r_lim, j) & SIMPLE_FLAG) == 0u) != (pass == 1)) continue;
                     const u32 c = RL_RD32(r_own, j);
                     RL_WR32(c_flg, RL_RD32(c_flg, c) | GT_REACHED, c);
                     const u64 exp = RL_RD64(c_exp, c), val = RL_RD64(c_val, c), mx = RL_RD64(r_max, j);
@@ -1152,10 +1167,9 @@ __device__ __forceinline__ void gen_tiny_body(Cell* __restrict__ table, u32 log2
                 }
             }
             if (first < 0) {  // :146-153: update every counter, simple ones first
-                for (int pass = 0; pass < 2; ++pass)
+                for (int pass = 0; pass < n_pass; ++pass)
                     for (u32 j = b; j < e_; ++j) {
-                        const u32 lim = RL_RD32(r_lim, j);
-                        if (((lim & SIMPLE_FLAG) == 0u) != (pass == 1)) continue;
+                        if (n_pass == 2 && ((RL_RD32(r_lim, j) & SIMPLE_FLAG) == 0u) != (pass == 1)) continue;
                         const u32 c = RL_RD32(r_own, j);
                         const u64 exp = RL_RD64(c_exp, c), d = RL_RD64(r_delta, j);
                         if (exp <= now) {  // atomic_expiring_value.rs:36-42,87-99

@@ -86,6 +86,36 @@ def test_reference_scenarios_on_engine(make_engine, monkeypatch, scenario, mode)
     scenario(TestsLimiter(make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)))
 
 
+@pytest.mark.parametrize("load", [False, True])
+def test_requests_that_list_qualified_counters_first(make_engine, load):
+    """The storage walks a request's simple counters first whatever order the caller lists them in (in_memory.rs:105,121:
+    two filtered loops).  Micro-batches whose requests list a qualified counter in front of a simple one — the one-launch
+    kernel's wave-resident replay then takes its two-pass form, ordered batches the single walk — and one request at a
+    time through the server."""
+    rng = np.random.default_rng(91)
+    rows = [(6, 1), (25, 10), (40, 60), (3, 60)]
+    eng, orc = pair(make_engine, rows, [(2, 9_000_002), (3, 9_000_003)])
+    keys = W.splitmix64(np.arange(1, 40, dtype=np.uint64))
+    now = NOW
+    for step in range(60):
+        n_req = int(rng.integers(1, 20)) if step % 3 else 1
+        hits, off = [], [0]
+        for _ in range(n_req):
+            d = int(rng.integers(0, 3))
+            req = [(int(keys[i]), int(i % 2), d) for i in rng.integers(0, len(keys), size=int(rng.integers(0, 3)))]
+            simple = [(9_000_002, 2 | RL_SIMPLE, d), (9_000_003, 3 | RL_SIMPLE, d)][: int(rng.integers(0, 3))]
+            order = rng.integers(0, 3)  # qualified first / simple first / interleaved
+            req = req + simple if order == 0 else simple + req if order == 1 else [x for p in zip(req, simple) for x in p] + req[len(simple):] + simple[len(req):]
+            hits += req
+            off.append(len(hits))
+        arr = np.zeros(len(hits), dtype=HIT_DTYPE)
+        for i, h in enumerate(hits):
+            arr[i] = h
+        run_both(eng, orc, arr, now, req_off=np.array(off, dtype=np.uint32), load_counters=load)
+        now += int(rng.integers(0, SEC // 2))
+    assert_same_state(eng, orc, n_simple_expected=2)
+
+
 def test_per_request_calls_between_everything_else(make_engine):
     """The server (k_gen_serve) lingers on the engine's stream: every other call — batches, reads, sweeps, limits —
     must send it away first, and a per-request call after a pause longer than its linger finds it gone and starts
