@@ -153,8 +153,8 @@ int32_t rl_add_counter(rl_engine *e, uint32_t limit, uint64_t key);
  *   remaining[n_hits], expires_in_us[n_hits] (may be NULL unless load_counters): the values
  *                       set_remaining / set_expires_in receive (counter.rs:96-106).
  * Host pointers; the call copies in, runs the kernels, copies out and returns when done.
- * A call with ONE request of up to 16 counters — the trait's check_and_update called request by request — launches
- * nothing when a server kernel is lingering on the engine's stream (k_gen_serve: a host-mapped mailbox in, tagged
+ * A call with ONE request of a few counters — the trait's check_and_update called request by request — or a micro-batch
+ * of up to 64 counters / 64 requests launches nothing when a server kernel is lingering on the engine's stream (k_gen_serve: a host-mapped mailbox in, tagged
  * write-through stores out; ~10 us per call instead of ~30).  The server leaves by itself RL_SERVE_LINGER_US (200) after
  * the last request and every other entry point sends it away before touching the device, so nothing waits for it longer
  * than that; RL_SERVE=0 turns it off (one launch per call).  Same kernel body as the one-launch path, same results. */

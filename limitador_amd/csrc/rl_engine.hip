@@ -1889,16 +1889,28 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
         // ONE request of a few counters — the trait's per-request call: no launch at all when a server is lingering
         // (k_gen_serve).  Only while the table has room to spare: growing or refusing is the ordinary path's business.
         // (a single-counter request is a request of one counter: the general body is exact for it too)
-        if (e->serve_enabled && e->h_tiny_coherent && !e->external_stream && n_req == 1 && n_hits >= 1 &&
-            n_hits <= SRV_MAX_HITS && n_hits <= e->gen_tiny_max && e->live + e->tombs + n_hits <= e->cap - e->cap / 4) {
+        // Micro-batches of up to 64 hits / 64 requests ride the same way (verdict and first_limited then come back in one
+        // tagged 8-byte slot per request).
+        if (e->serve_enabled && e->h_tiny_coherent && !e->external_stream && n_req >= 1 && n_req <= SRV_MAX_HITS && n_hits >= 1 &&
+            n_hits <= SRV_MAX_HITS && n_hits <= e->gen_tiny_max && (n_req == 1 || general) &&
+            e->live + e->tombs + n_hits <= e->cap - e->cap / 4) {
             ServeBox* b = e->h_serve;
             Hit* t_hits = reinterpret_cast<Hit*>(e->h_tiny + TIO_OFF_HITS);
+            u32* t_off = reinterpret_cast<u32*>(e->h_tiny + TIO_OFF_REQ);
+            u64* t_delta = reinterpret_cast<u64*>(e->h_tiny + TIO_OFF_DELTA);
             memcpy(t_hits, hits, (size_t)n_hits * sizeof(Hit));
+            if (n_req > 1) {
+                if (req_off) memcpy(t_off, req_off, ((size_t)n_req + 1) * sizeof(u32));
+                else
+                    for (u32 r = 0; r <= n_req; ++r) t_off[r] = r;
+                if (req_delta) memcpy(t_delta, req_delta, (size_t)n_req * sizeof(u64));
+            }
             const u32 seq = ++e->gen_seq ? e->gen_seq : ++e->gen_seq;
             b->now = now_us;
             b->delta = req_delta ? req_delta[0] : 0ull;
             b->cmd[1] = n_hits;
             b->cmd[2] = (load_counters ? SRV_LOAD : 0u) | (req_delta ? SRV_DELTA : 0u);
+            b->cmd[3] = n_req;
             __atomic_store_n(&b->cmd[0], seq, __ATOMIC_RELEASE);
             const volatile u32* done = &e->h_status->n_removed;
             const auto t_start = std::chrono::steady_clock::now();
@@ -1906,8 +1918,9 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
                                     // and the `gone` word that sent us here still says this request's number)
             for (u64 spins = 0;; ++spins) {
                 if (!e->serve_live) {  // nobody is there (yet, or any more): a server that starts at this very command
-                    k_gen_serve<<<1, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_limits, (u32)e->h_limits.size(), t_hits, b,
-                                                          e->h_status, seq, e->serve_linger_us * 100u);  // (100 MHz clock)
+                    k_gen_serve<<<1, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_limits, (u32)e->h_limits.size(), t_hits,
+                                                          t_off, t_delta, b, e->h_status, seq,
+                                                          e->serve_linger_us * 100u);  // (100 MHz clock)
                     HIP_TRY(e, hipGetLastError());
                     e->serve_live = true;
                     launched = true;
@@ -1940,8 +1953,22 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
             e->stats.hits += n_hits;
             e->stats.ordered_hits += n_hits;
             e->stats.ordered_batches++;
-            verdict[0] = (uint8_t)((w0 >> 8) & 1u);
-            if (first_limited) first_limited[0] = (int32_t)((w0 >> 16) & 0xFFFFu) - 1;
+            if (n_req == 1) {
+                verdict[0] = (uint8_t)((w0 >> 8) & 1u);
+                if (first_limited) first_limited[0] = (int32_t)((w0 >> 16) & 0xFFFFu) - 1;
+            } else {
+                for (u32 r = 0; r < n_req; ++r) {  // every slot says itself which command it answers
+                    const volatile u32* sl = b->rslot[r];
+                    for (u64 spins = 0; __atomic_load_n(&sl[1], __ATOMIC_ACQUIRE) != seq; ++spins) {
+                        __builtin_ia32_pause();
+                        if ((spins & 0xFFFFFu) == 0xFFFFFu && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                            return fail(e, RL_ERR_DEVICE, "k_gen_serve: a request's slot did not arrive within 60 s");
+                    }
+                    const u32 w = sl[0];
+                    verdict[r] = (uint8_t)(w & 1u);
+                    if (first_limited) first_limited[r] = (int32_t)(w >> 1) - 1;
+                }
+            }
             if (load_counters) {
                 for (u32 j = 0; j < 2 * n_hits; ++j) {  // every slot says itself which request it answers
                     const volatile u32* sl = b->slot[j];

@@ -1289,8 +1289,9 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gen_serve: per-request calls WITHOUT a launch per call.  One request with 1..SRV_MAX_HITS counters (the trait's
-// check_and_update called request by request: BASELINE.json configs[0]) is launch-latency-bound as a kernel of its own:
+// k_gen_serve: per-request calls — and micro-batches of up to SRV_MAX_HITS hits / requests — WITHOUT a launch per call.
+// One request with a few counters (the trait's check_and_update called request by request: BASELINE.json configs[0]) is
+// launch-latency-bound as a kernel of its own:
 // ~10 us from the enqueue to the first wave, ~10 us for the stream to be seen idle again — 47 us per call for 10 us of
 // work.  This kernel stays: one workgroup polls a MAILBOX in host-mapped memory, serves request after request with
 // k_gen_tiny's body (same semantics, same code), and leaves by itself `linger` after the last one — so that nothing
@@ -1306,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_gen_tiny(Cell* __restrict__ table, u32 
 //                    launches a new server for it) — the decision is one read of cmd, so "taken" and "gone" exclude
 //                    each other.
 // ---------------------------------------------------------------------------------------------
-constexpr u32 SRV_MAX_HITS = 16;
+constexpr u32 SRV_MAX_HITS = 64;  // hits and requests of one command (the wave-resident replay's reach)
 constexpr u32 SRV_LOAD = 1u, SRV_DELTA = 2u, SRV_QUIT = 4u;
 struct ServeBox {
     u32 cmd[4];
@@ -1315,8 +1316,9 @@ struct ServeBox {
     u32 gone[4];
     u32 pad1[12];
     u32 slot[2 * SRV_MAX_HITS][4];  // {lo, hi, seq, index}: remaining of hit j at [2 j], expires_in at [2 j + 1]
+    u32 rslot[SRV_MAX_HITS][2];     // commands of several requests: {verdict | (first_limited + 1) << 1, seq} of request r
 };
-static_assert(sizeof(ServeBox) == 128 + 32 * SRV_MAX_HITS, "ServeBox layout");
+static_assert(sizeof(ServeBox) == 128 + 40 * SRV_MAX_HITS, "ServeBox layout");
 
 // 16 bytes to the host from a kernel that does not end: two 8-byte system-scope stores, the one with the sequence
 // number (upper half of `second`) a RELEASE behind the other — whoever reads the number with acquire finds the rest.
@@ -1327,13 +1329,14 @@ __device__ __forceinline__ void srv_post(u64* dst, u64 first, u64 second) {
 
 __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32 log2cap, u64 seed,
                                                    const LimitDev* __restrict__ limits, u32 n_limits,
-                                                   const Hit* __restrict__ hits, ServeBox* box, Status* host_status,
-                                                   u32 first_seq, u32 linger_ticks) {
+                                                   const Hit* __restrict__ hits, const u32* __restrict__ req_off_many,
+                                                   const u64* __restrict__ req_delta_many, ServeBox* box,
+                                                   Status* host_status, u32 first_seq, u32 linger_ticks) {
     __shared__ u32 s_c[4];
     __shared__ u64 s_now, s_delta;
     __shared__ u32 s_off[2], s_counts[3];
-    __shared__ uint8_t o_verdict[4];
-    __shared__ int32_t o_first[1];
+    __shared__ uint8_t o_verdict[SRV_MAX_HITS];
+    __shared__ int32_t o_first[SRV_MAX_HITS];
     __shared__ u64 o_rem[SRV_MAX_HITS], o_exp[SRV_MAX_HITS];
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     const u32 tid = threadIdx.x;
@@ -1350,18 +1353,20 @@ __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32
                 }
                 __builtin_amdgcn_s_sleep(4);
             }
-            u32 nh = 0, flags = 0;
+            u32 nh = 0, flags = 0, nr = 0;
             if (!leave) {
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 nh = __hip_atomic_load(&box->cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 flags = __hip_atomic_load(&box->cmd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                nr = __hip_atomic_load(&box->cmd[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 s_now = __hip_atomic_load(&box->now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 s_delta = __hip_atomic_load(&box->delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((flags & SRV_QUIT) || nh == 0 || nh > SRV_MAX_HITS) leave = true;
+                if ((flags & SRV_QUIT) || nh == 0 || nh > SRV_MAX_HITS || nr == 0 || nr > SRV_MAX_HITS) leave = true;
             }
             s_c[0] = leave ? 1u : 0u;
             s_c[1] = nh;
             s_c[2] = flags;
+            s_c[3] = nr;
             s_off[0] = 0;
             s_off[1] = nh;
         }
@@ -1371,10 +1376,13 @@ __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32
             return;
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the staging area was rewritten by the host: no line of it from the last request)
-        const u32 n_hits = s_c[1], flags = s_c[2];
+        const u32 n_hits = s_c[1], flags = s_c[2], n_req = s_c[3];
         const int load = (flags & SRV_LOAD) ? 1 : 0;
-        gen_tiny_body<false>(table, log2cap, seed, hits, n_hits, s_off, 1u, limits, n_limits, s_now, load, o_verdict, o_first, o_rem,
-                             o_exp, (flags & SRV_DELTA) ? &s_delta : nullptr, nullptr, 0u, s_counts);
+        // one request: its offsets and its delta came with the command; several: the CSR offsets / the deltas are in the staging
+        const bool many = n_req > 1u;
+        gen_tiny_body<false>(table, log2cap, seed, hits, n_hits, many ? req_off_many : s_off, n_req, limits, n_limits, s_now, load,
+                             o_verdict, o_first, o_rem, o_exp,
+                             (flags & SRV_DELTA) ? (many ? req_delta_many : &s_delta) : nullptr, nullptr, 0u, s_counts);
         if (load && tid < n_hits && !s_counts[0]) {
             // written THROUGH to the host (system scope) and acknowledged before the barrier: the kernel does not end
             // behind a request, so nothing else would ever push these lines out of the L2
@@ -1383,6 +1391,12 @@ __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32
             __hip_atomic_store(sl + 1, (u64)expect | ((u64)(2u * tid) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(sl + 2, o_exp[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(sl + 3, (u64)expect | ((u64)(2u * tid + 1u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (many && tid < n_req && !s_counts[0]) {
+            __hip_atomic_store(reinterpret_cast<u64*>(box->rslot[tid]),
+                               (u64)((u32)o_verdict[tid] | ((u32)(o_first[tid] + 1) << 1)) | ((u64)expect << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
