@@ -204,6 +204,7 @@ struct rl_engine {
     u32 hot_floor = HOT_PROMOTE;      // RL_HOT_PROMOTE: the floor of hot_threshold
     u32 hot_long_cfg = HOT_LONG_BUCKET;  // RL_HOT_LONG: a hash bucket of this many hits has its middling keys promoted too
     u32 hot_seen = 0;                 // keys that qualified for a hot bucket in the batch collected last
+    bool hot_report = false;          // RL_HOT_REPORT=1: one stderr line per eighth batch (qualified keys, threshold)
     HotParam* d_hot_param = nullptr;  // [PB_SETS][HOT_MAX + 1]
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
@@ -916,7 +917,11 @@ int collect_k1_bucketed(rl_engine* e) {
         HIP_TRY(e, hipMemcpy(t.data(), e->d_apply_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         bool has_part = false;  // (a launch that only replays — the last batch of a burst — does not overwrite a full one)
         for (size_t r = f.n_wg; r < (size_t)(BK_MAX + 1024) && !has_part; ++r) has_part = t[r * 8] != 0;
-        if (const char* path = getenv("RL_APPLY_TRACE_FILE"); path && (has_part || e->stats.batches < 2)) {  // raw stamps, for offline analysis
+        // raw stamps, for offline analysis: of the first batches, or of batch RL_APPLY_TRACE_AT (a steady-state one; it must
+        // be a blocking call — with batches in flight the stamp buffer already belongs to the newest launch)
+        const char* at = getenv("RL_APPLY_TRACE_AT");
+        if (const char* path = getenv("RL_APPLY_TRACE_FILE");
+            path && (at ? e->stats.batches == strtoull(at, nullptr, 10) : (has_part || e->stats.batches < 2))) {
             if (FILE* fp = std::fopen(path, "wb")) {
                 const unsigned long long hdr[8] = {f.n_wg, e->hot_wgs, 0, 0, 0, 0, 0, 0};
                 std::fwrite(hdr, sizeof(unsigned long long), 8, fp);
@@ -960,14 +965,22 @@ int collect_k1_bucketed(rl_engine* e) {
         }
         if (live)
             std::fprintf(stderr, "[apply] %u workgroups, span %.1f us (first one out after %.1f); mean per workgroup: view %.2f, bucket %.2f "
-                         "(%.0f hits), hot items %.2f, drain %.2f, finish %.2f us; longest workgroup %.1f us\n", live,
+                         "(%.0f hits), hot items %.2f, drain %.2f, finish %.2f us; longest workgroup %.1f us; %u keys qualified as hot at "
+                         "threshold %u\n", live,
                          (double)(t_max - t_min) / 100.0, (double)(first_end - t_min) / 100.0, ph[0] / live, ph[1] / live, hits / live,
-                         ph[2] / live, ph[3] / live, ph[4] / live, longest);
+                         ph[2] / live, ph[3] / live, ph[4] / live, longest, f.h_st->pad[2], e->hot_threshold);
     }
     // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
     if (f.n_wg > 1) e->hot_seen = f.h_st->pad[2];  // (a partitioned batch: k_bkt_tiny leaves the hot sets alone)
+    // (A threshold that moves in steps of 1/16 towards a nearly full set — 430-520 hot keys instead of ~375 — and long
+    // buckets handed to the hot set from 896 / 768 / 640 hits on were measured, scripts/exp/r5a.sh, r5b.sh: the step
+    // stays within 0.3 us or gets longer.  Coarse steps with hysteresis never overflow the set, and an overflow drops
+    // whichever keys come last — possibly the hottest.)
     if (f.h_st->pad[2] > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
     else if (f.h_st->pad[2] < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
+    if (e->hot_report && f.n_wg > 1 && (e->stats.batches & 7u) == 0)  // RL_HOT_REPORT=1 (diagnostics)
+        std::fprintf(stderr, "[hot] batch %llu: %u keys qualified, threshold now %u\n", (unsigned long long)e->stats.batches,
+                     f.h_st->pad[2], e->hot_threshold);
     e->stats.batches++;
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
@@ -1510,6 +1523,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 16 && b <= (1 << 20)) e->hot_floor = e->hot_threshold = (u32)b;
     }
+    if (const char* v = getenv("RL_HOT_REPORT")) e->hot_report = atoi(v) != 0;
     if (const char* v = getenv("RL_HOT_LONG")) e->hot_long_cfg = (u32)std::max<unsigned long>(1ul, strtoul(v, nullptr, 10));
     if (const char* v = getenv("RL_GEN_TRACE")) e->gen_trace = atoi(v);
     if (const char* v = getenv("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
