@@ -1,0 +1,17 @@
+#!/bin/bash
+# r6b (prepared in round 3, not yet run): what a 256-hit round of the replay is made of — stamps inside the first two
+# rounds of every bucket workgroup (requests / phase A / phase B = the cells arrive / C / D / rebuild / second round), alone
+# and beside the partition.
+# Here, before the visit:  scripts/exp/build_variant.sh apply_round_stamps
+# then:                    gpurun --timeout 60 -- 'bash scripts/exp/r6b.sh'
+set -u
+out=$PWD/gpurun_out/r6b; rm -rf "$out"; mkdir -p "$out"
+export TMPDIR=/tmp
+cp limitador_amd/lib/variants/librl_engine_apply_round_stamps.so limitador_amd/lib/librl_engine.so || exit 1   # (the box's copy of the tree)
+RL_APPLY_TRACE=1 timeout 60 python bench.py --cpu-seconds 0 --secondary 0 --steps 20 --warmup 5 --depth 1 > "$out/alone.json" 2> "$out/alone.err"
+grep "^\[round\]" "$out/alone.err" | tail -4
+grep "^\[apply\]" "$out/alone.err" | tail -2
+# (with batches in flight the stamp buffer belongs to the newest launch: the lines of a pipelined run mix batches and are
+# only good for the means)
+RL_APPLY_TRACE=1 timeout 60 python bench.py --cpu-seconds 0 --secondary 0 --steps 20 --warmup 5 > "$out/pipe.json" 2> "$out/pipe.err"
+grep "^\[round\]" "$out/pipe.err" | tail -4
