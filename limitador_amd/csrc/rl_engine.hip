@@ -582,9 +582,11 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
         P.sparse_out = 1u;
         P.hot_long = q.hot_long;
         if (e->apply_trace) {
-            if (!e->d_apply_trace) HIP_TRY(e, hipMalloc((void**)&e->d_apply_trace, (size_t)(BK_MAX + 1024) * 8 * sizeof(unsigned long long)));
-            HIP_TRY(e, hipMemsetAsync(e->d_apply_trace, 0, (size_t)(BK_MAX + 1024) * 8 * sizeof(unsigned long long), e->stream));
-            P.trace = e->d_apply_trace;
+            // one stamp buffer per batch in flight (indexed like e->inflight): the stamps a collect reads are its own batch's
+            constexpr size_t TR = (size_t)(BK_MAX + 1024) * 8;
+            if (!e->d_apply_trace) HIP_TRY(e, hipMalloc((void**)&e->d_apply_trace, 4 * TR * sizeof(unsigned long long)));
+            HIP_TRY(e, hipMemsetAsync(e->d_apply_trace + (size_t)q.slot * TR, 0, TR * sizeof(unsigned long long), e->stream));
+            P.trace = e->d_apply_trace + (size_t)q.slot * TR;
         }
         S.n_apply_wgs = q.n_wg;
         // "applied" for the partition stream (two-stream engines): the stop event of the launch itself where possible
@@ -911,17 +913,21 @@ int collect_k1_bucketed(rl_engine* e) {
         if (f.h_st->err) return status_to_error(e, f.h_st->err);
         return RL_OK;
     }
-    if (e->apply_trace && f.n_wg > 1 && e->d_apply_trace) {
+    // RL_APPLY_TRACE_AT=<batch>: only that batch is looked at (a copy per collect holds the host back: with it the pipeline
+    // of a three-deep feeder runs 20 % slower; one copy in a run does not show)
+    const char* trace_at = e->apply_trace ? getenv("RL_APPLY_TRACE_AT") : nullptr;
+    if (e->apply_trace && f.n_wg > 1 && e->d_apply_trace && (!trace_at || e->stats.batches == strtoull(trace_at, nullptr, 10))) {
         // diagnostics: where the workgroups of k_bkt_apply spent their time (wall clock, 100 MHz)
-        std::vector<unsigned long long> t((size_t)(BK_MAX + 1024) * 8);  // (the rows behind the replay's: the partition role's)
-        HIP_TRY(e, hipMemcpy(t.data(), e->d_apply_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        constexpr size_t TR = (size_t)(BK_MAX + 1024) * 8;
+        std::vector<unsigned long long> t(TR);  // (the rows behind the replay's: the partition role's)
+        // (the batch has completed — its status word was seen — so its own buffer is final; the streams are non-blocking,
+        // the copy does not wait for the batches behind it)
+        HIP_TRY(e, hipMemcpy(t.data(), e->d_apply_trace + (size_t)((e->col_seq - 1) & 3u) * TR, t.size() * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost));
         bool has_part = false;  // (a launch that only replays — the last batch of a burst — does not overwrite a full one)
         for (size_t r = f.n_wg; r < (size_t)(BK_MAX + 1024) && !has_part; ++r) has_part = t[r * 8] != 0;
-        // raw stamps, for offline analysis: of the first batches, or of batch RL_APPLY_TRACE_AT (a steady-state one; it must
-        // be a blocking call — with batches in flight the stamp buffer already belongs to the newest launch)
-        const char* at = getenv("RL_APPLY_TRACE_AT");
-        if (const char* path = getenv("RL_APPLY_TRACE_FILE");
-            path && (at ? e->stats.batches == strtoull(at, nullptr, 10) : (has_part || e->stats.batches < 2))) {
+        // raw stamps, for offline analysis: of the first batches, or of batch RL_APPLY_TRACE_AT (a steady-state one)
+        if (const char* path = getenv("RL_APPLY_TRACE_FILE"); path && (trace_at || has_part || e->stats.batches < 2)) {
             if (FILE* fp = std::fopen(path, "wb")) {
                 const unsigned long long hdr[8] = {f.n_wg, e->hot_wgs, 0, 0, 0, 0, 0, 0};
                 std::fwrite(hdr, sizeof(unsigned long long), 8, fp);

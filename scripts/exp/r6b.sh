@@ -11,7 +11,9 @@ cp limitador_amd/lib/variants/librl_engine_apply_round_stamps.so limitador_amd/l
 RL_APPLY_TRACE=1 timeout 60 python bench.py --cpu-seconds 0 --secondary 0 --steps 20 --warmup 5 --depth 1 > "$out/alone.json" 2> "$out/alone.err"
 grep "^\[round\]" "$out/alone.err" | tail -4
 grep "^\[apply\]" "$out/alone.err" | tail -2
-# (with batches in flight the stamp buffer belongs to the newest launch: the lines of a pipelined run mix batches and are
-# only good for the means)
-RL_APPLY_TRACE=1 timeout 60 python bench.py --cpu-seconds 0 --secondary 0 --steps 20 --warmup 5 > "$out/pipe.json" 2> "$out/pipe.err"
-grep "^\[round\]" "$out/pipe.err" | tail -4
+# beside the partition: one steady-state batch of a three-deep pipeline (every batch in flight has its own stamp buffer;
+# RL_APPLY_TRACE_AT looks at one batch only, so the host is not held back by a copy per collect).  The raw dump answers
+# "which workgroups start late, which end last" (scripts/apply_trace.py).
+RL_APPLY_TRACE=1 RL_APPLY_TRACE_AT=60 RL_APPLY_TRACE_FILE=$out/pipe_trace.bin timeout 60 python bench.py --cpu-seconds 0 --secondary 0 --steps 100 --warmup 5 > "$out/pipe.json" 2> "$out/pipe.err"
+grep "^\[round\]\|^\[apply\]" "$out/pipe.err" | tail -4
+python scripts/apply_trace.py "$out/pipe_trace.bin" > "$out/pipe_trace.txt" 2>&1; head -30 "$out/pipe_trace.txt"
