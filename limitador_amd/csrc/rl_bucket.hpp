@@ -191,17 +191,21 @@ __device__ __forceinline__ int hot_lookup(const u64* s_key, const u32* s_idx, u6
 }
 
 // Lanes of the wave whose `d` equals mine (among `valid` lanes): one ballot per bucket-id bit.
+// All BK_LOG2_MAX + 1 bits are walked whatever `nbits` says: a bin id has no bit above nbits (d < 2^nbits), so those
+// ballots are empty and change nothing — and without a test per bit the twelve steps are straight-line code.  The
+// MISMATCHES are accumulated, z |= ballot(bit) ^ -(my bit): two xors and (pairwise) one three-input or per bit and
+// half, where "m &= bit ? bm : ~bm" compiled to ten vector instructions, two wait states and a scalar branch per bit.
 __device__ __forceinline__ u64 match_digit(u32 d, u32 nbits, u64 valid) {
-    u64 m = valid;
+    (void)nbits;
+    u32 zlo = 0, zhi = 0;
 #pragma unroll
     for (u32 b = 0; b < (u32)BK_LOG2_MAX + 1u; ++b) {
-        if (b < nbits) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bm = __ballot(bit);
-            m &= bit ? bm : ~bm;
-        }
+        const u32 sb = (u32)__builtin_amdgcn_sbfe((int)d, b, 1u);  // -(bit b of d)
+        const u64 bm = __ballot(sb != 0u);
+        zlo |= (u32)bm ^ sb;
+        zhi |= (u32)(bm >> 32) ^ sb;
     }
-    return m;
+    return valid & ~(((u64)zhi << 32) | zlo);
 }
 
 // ---------------------------------------------------------------------------------------------
