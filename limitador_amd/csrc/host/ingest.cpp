@@ -29,6 +29,13 @@
 #include <unordered_map>
 #include <vector>
 
+// experiment / diagnostics switches exist only in -DRL_EXPERIMENT builds (see rl_engine.hip)
+#ifdef RL_EXPERIMENT
+#define RL_EXP_ENV(name) getenv(name)
+#else
+#define RL_EXP_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace {
 
 struct Dictionary {  // exact string -> dense id
@@ -744,7 +751,7 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
     rli_batch_clear(g);
     if (n == 0) return RL_OK;
     const uint32_t threads = serve_threads(n);
-    const bool trace = getenv("RLI_TRACE") != nullptr;
+    const bool trace = RL_EXP_ENV("RLI_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (trace)

@@ -21,6 +21,13 @@
 #include <new>
 #include <vector>
 
+// experiment / diagnostics switches exist only in -DRL_EXPERIMENT builds (see rl_engine.hip)
+#ifdef RL_EXPERIMENT
+#define RL_EXP_ENV(name) getenv(name)
+#else
+#define RL_EXP_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace {
 
 constexpr uint32_t RQ_GATHER = 16;   // rq.d_words[RQ_GATHER + p]: rank p's word of the last gather (multi-counter step)
@@ -373,11 +380,11 @@ int32_t create_common(rl_engine* e, uint32_t world, uint32_t rank, uint32_t max_
         // round-robin, and a queue shared with the engine's decision stream serialises the two (seen in the trace)
         int lo = 0, hi = 0;
         HIP_S(s, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const char* pr = std::getenv("RL_SHARDED_STREAM_PRIO");
+        const char* pr = RL_EXP_ENV("RL_SHARDED_STREAM_PRIO");
         const int prio = (pr && pr[0] == '0') ? lo : hi;
         HIP_S(s, hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, prio));
     }
-    const char* es = std::getenv("RL_SHARDED_ENGINE_STREAMS");
+    const char* es = RL_EXP_ENV("RL_SHARDED_ENGINE_STREAMS");
     if (!es || std::strcmp(es, "own") != 0) {
         HIP_S(s, hipStreamCreateWithFlags(&s->as, hipStreamNonBlocking));
         ENG_S(s, rl_engine_set_stream(e, s->as, 1));

@@ -13,7 +13,6 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <rocprim/device/device_scan.hpp>
 #include <algorithm>
 #include <chrono>
 #include <thread>
@@ -31,6 +30,16 @@
 #include "rl_match.hpp"
 
 using namespace rl;
+
+// Switches.  A release build reads the documented handful (include/rl_engine.h: RL_FUSE, RL_SERVE, RL_TINY_MAX, RL_STREAM;
+// include/rl_ingest.h: RLI_THREADS).  Everything else — shapes, budgets, priorities, diagnostics that copy from the device
+// per batch — exists only in builds with -DRL_EXPERIMENT (scripts/exp/build_variant.sh, limitador_amd/build.py
+// build_engine_exp: the library tests/test_gpu_variants.py loads); in a release build the names are not even in the binary.
+#ifdef RL_EXPERIMENT
+#define RL_EXP_ENV(name) getenv(name)
+#else
+#define RL_EXP_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 
 static_assert(sizeof(rl_hit) == sizeof(Hit), "rl_hit layout");
 static_assert(sizeof(rl_cell_row) == sizeof(CellRow), "rl_cell_row layout");
@@ -915,7 +924,7 @@ int collect_k1_bucketed(rl_engine* e) {
     }
     // RL_APPLY_TRACE_AT=<batch>: only that batch is looked at (a copy per collect holds the host back: with it the pipeline
     // of a three-deep feeder runs 20 % slower; one copy in a run does not show)
-    const char* trace_at = e->apply_trace ? getenv("RL_APPLY_TRACE_AT") : nullptr;
+    const char* trace_at = e->apply_trace ? RL_EXP_ENV("RL_APPLY_TRACE_AT") : nullptr;
     if (e->apply_trace && f.n_wg > 1 && e->d_apply_trace && (!trace_at || e->stats.batches == strtoull(trace_at, nullptr, 10))) {
         // diagnostics: where the workgroups of k_bkt_apply spent their time (wall clock, 100 MHz)
         constexpr size_t TR = (size_t)(BK_MAX + 1024) * 8;
@@ -927,7 +936,7 @@ int collect_k1_bucketed(rl_engine* e) {
         bool has_part = false;  // (a launch that only replays — the last batch of a burst — does not overwrite a full one)
         for (size_t r = f.n_wg; r < (size_t)(BK_MAX + 1024) && !has_part; ++r) has_part = t[r * 8] != 0;
         // raw stamps, for offline analysis: of the first batches, or of batch RL_APPLY_TRACE_AT (a steady-state one)
-        if (const char* path = getenv("RL_APPLY_TRACE_FILE"); path && (trace_at || has_part || e->stats.batches < 2)) {
+        if (const char* path = RL_EXP_ENV("RL_APPLY_TRACE_FILE"); path && (trace_at || has_part || e->stats.batches < 2)) {
             if (FILE* fp = std::fopen(path, "wb")) {
                 const unsigned long long hdr[8] = {f.n_wg, e->hot_wgs, 0, 0, 0, 0, 0, 0};
                 std::fwrite(hdr, sizeof(unsigned long long), 8, fp);
@@ -1508,46 +1517,46 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->max_batch = cfg->max_batch_hits ? cfg->max_batch_hits : (1u << 20);
     if (e->max_batch > MAX_BATCH_HITS) e->max_batch = MAX_BATCH_HITS;
     e->max_limits = cfg->max_limits ? cfg->max_limits : 1024;
-    if (const char* v = getenv("RL_OVERLAP")) e->overlap = atoi(v) != 0;
-    if (const char* v = getenv("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
-    if (const char* v = getenv("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
-    if (const char* v = getenv("RL_APPLY_EVENTS")) e->apply_events = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_OVERLAP")) e->overlap = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_PIPE_DEPTH")) e->pipe_depth = atoi(v) == 2 ? 2u : 3u;
+    if (const char* v = RL_EXP_ENV("RL_DEFER_APPLY")) e->defer_apply = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_APPLY_EVENTS")) e->apply_events = atoi(v) != 0;
     // Engines for small batches run the fused form (one stream, one launch per step): a step of <= 256 k hits is bound by
     // launches, not by kernels (64 k hits: 16.4 us per batch fused, 19.4 on two streams; 1 M hits: 65-75 against 47).
     e->fuse = e->max_batch <= (1u << 18);
     if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
-    if (const char* v = getenv("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0;
     if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch
-    if (const char* v = getenv("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
-    if (const char* v = getenv("RL_HOT_WGS")) e->hot_wgs = (u32)std::min(std::max(atoi(v), 8), 1024);
-    if (const char* v = getenv("RL_PART_STEPS")) {
+    if (const char* v = RL_EXP_ENV("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
+    if (const char* v = RL_EXP_ENV("RL_HOT_WGS")) e->hot_wgs = (u32)std::min(std::max(atoi(v), 8), 1024);
+    if (const char* v = RL_EXP_ENV("RL_PART_STEPS")) {
         const int b = atoi(v);
         if (b == 4 || b == 8 || b == 16) e->part_steps_cfg = (u32)b;
     }
-    if (const char* v = getenv("RL_EXT_EVENTS")) e->ext_events = atoi(v) != 0;
-    if (const char* v = getenv("RL_HOT_PROMOTE")) {
+    if (const char* v = RL_EXP_ENV("RL_EXT_EVENTS")) e->ext_events = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_HOT_PROMOTE")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 16 && b <= (1 << 20)) e->hot_floor = e->hot_threshold = (u32)b;
     }
-    if (const char* v = getenv("RL_HOT_REPORT")) e->hot_report = atoi(v) != 0;
-    if (const char* v = getenv("RL_HOT_LONG")) e->hot_long_cfg = (u32)std::max<unsigned long>(1ul, strtoul(v, nullptr, 10));
-    if (const char* v = getenv("RL_GEN_TRACE")) e->gen_trace = atoi(v);
-    if (const char* v = getenv("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
-    if (const char* v = getenv("RL_GEN_SUB_MAX")) {
+    if (const char* v = RL_EXP_ENV("RL_HOT_REPORT")) e->hot_report = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_HOT_LONG")) e->hot_long_cfg = (u32)std::max<unsigned long>(1ul, strtoul(v, nullptr, 10));
+    if (const char* v = RL_EXP_ENV("RL_GEN_TRACE")) e->gen_trace = atoi(v);
+    if (const char* v = RL_EXP_ENV("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
+    if (const char* v = RL_EXP_ENV("RL_GEN_SUB_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 1024) e->gen_sub_max = (u32)std::min<long>(b, GEN_SUB_MAX);
     }
-    if (const char* v = getenv("RL_APPLY2_CFG")) e->apply2_cfg = atoi(v);
+    if (const char* v = RL_EXP_ENV("RL_APPLY2_CFG")) e->apply2_cfg = atoi(v);
     if (const char* v = getenv("RL_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= (long)TINY_MAX) e->tiny_max = (u32)b;
         if (b == 0) e->gen_tiny_max = 0;  // RL_TINY_MAX=0 switches both one-launch kernels off
     }
-    if (const char* v = getenv("RL_GEN_TINY_MAX")) {
+    if (const char* v = RL_EXP_ENV("RL_GEN_TINY_MAX")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= (long)GT_MAX) e->gen_tiny_max = (u32)b;
     }
-    if (const char* v = getenv("RL_BUCKET_LOG2")) {
+    if (const char* v = RL_EXP_ENV("RL_BUCKET_LOG2")) {
         const long b = strtol(v, nullptr, 10);
         if (b >= 0 && b <= BK_LOG2_MAX) e->bk_log2_cfg = (u32)b;
     }
@@ -1570,7 +1579,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (lo = least urgent, hi = most: numerically lower)
         int prio = prio_hi;
-        if (const char* v = getenv("RL_PSTREAM_PRIO")) prio = atoi(v) == 0 ? prio_lo : (atoi(v) == 2 ? 0 : prio_hi);
+        if (const char* v = RL_EXP_ENV("RL_PSTREAM_PRIO")) prio = atoi(v) == 0 ? prio_lo : (atoi(v) == 2 ? 0 : prio_hi);
         if (hipStreamCreateWithPriority(&e->own_pstream, hipStreamNonBlocking, prio) != hipSuccess) return bail(RL_ERR_DEVICE);
         e->pstream = e->own_pstream;
     } else {
@@ -1580,7 +1589,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     // WITHOUT the system-scope fence an event carries by default: they order two streams of one device, nothing the
     // host reads depends on them (the status block is fine-grained memory written with explicit stores).
     unsigned ev_flags = hipEventDisableSystemFence;
-    if (const char* v = getenv("RL_EVENT_FLAGS")) ev_flags = (unsigned)strtoul(v, nullptr, 0);
+    if (const char* v = RL_EXP_ENV("RL_EVENT_FLAGS")) ev_flags = (unsigned)strtoul(v, nullptr, 0);
     for (auto& ev : e->ev_parted)
         if (hipEventCreateWithFlags(&ev, ev_flags) != hipSuccess) return bail(RL_ERR_DEVICE);
     for (auto& ev : e->ev_applied)
@@ -1604,7 +1613,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0)
             e->n_cus = (u32)cus;
-        if (const char* v = getenv("RL_APPLY_WG_PER_CU")) {  // tuning knob
+        if (const char* v = RL_EXP_ENV("RL_APPLY_WG_PER_CU")) {  // tuning knob
             const long m = strtol(v, nullptr, 10);
             if (m >= 1 && m <= 8) e->n_cus = e->n_cus * (u32)m / 2;
         }
@@ -1672,22 +1681,16 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_m_limited, mb * sizeof(int32_t));
     ALLOC(e->d_m_mask, mb * sizeof(unsigned long long));
     ALLOC(e->d_m_flags, 16);
-    {
-        size_t mtmp = 0;
-        if (rocprim::exclusive_scan(nullptr, mtmp, e->d_m_count, e->d_req_off, 0u, mb + 1, rocprim::plus<u32>(),
-                                    e->stream) != hipSuccess)
-            return bail(RL_ERR_DEVICE);
-        e->m_scan_tmp_bytes = mtmp ? mtmp : 16;
-        ALLOC(e->d_m_scan_tmp, e->m_scan_tmp_bytes);
-    }
+    e->m_scan_tmp_bytes = ((size_t)cdiv(mb + 1, XSCAN_PER_WG) + 4) * sizeof(u32);  // the generic matcher's scan: workgroup totals
+    ALLOC(e->d_m_scan_tmp, e->m_scan_tmp_bytes);
     if (hipHostMalloc((void**)&e->h_m_total, 16) != hipSuccess) return bail(RL_ERR_NOMEM);
     {
         const size_t bytes = sizeof(MatchScan) + (size_t)cdiv(mb, 256) * sizeof(u32);
         ALLOC(e->d_m_scan1, bytes);
         if (hipMemsetAsync(e->d_m_scan1, 0, bytes, e->stream) != hipSuccess) return bail(RL_ERR_DEVICE);
     }
-    if (const char* v = getenv("RL_MATCH_ONE")) e->match_one = atoi(v) != 0;
-    if (const char* v = getenv("RL_GEN_POST")) e->gen_post = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_MATCH_ONE")) e->match_one = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_GEN_POST")) e->gen_post = atoi(v) != 0;
 #undef ALLOC
     // Host-mapped blocks the device writes while the host polls them: fine-grained (coherent) memory, so a
     // device store is on its way to the host when the wave's vmcnt says so, not when the kernel ends.
@@ -1703,8 +1706,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (!host_block((void**)&e->h_serve, sizeof(ServeBox))) return bail(RL_ERR_NOMEM);
     memset(e->h_serve, 0, sizeof(ServeBox));
     if (const char* v = getenv("RL_SERVE")) e->serve_enabled = atoi(v) != 0;
-    if (const char* v = getenv("RL_SERVE_TIMEOUT_MS")) e->serve_timeout_ms = (u32)std::max(1, atoi(v));
-    if (const char* v = getenv("RL_SERVE_LINGER_US")) e->serve_linger_us = (u32)std::min(std::max(1, atoi(v)), 1000000);
+    if (const char* v = RL_EXP_ENV("RL_SERVE_TIMEOUT_MS")) e->serve_timeout_ms = (u32)std::max(1, atoi(v));
+    if (const char* v = RL_EXP_ENV("RL_SERVE_LINGER_US")) e->serve_linger_us = (u32)std::min(std::max(1, atoi(v)), 1000000);
     if (!host_block((void**)&e->h_m_word, 64)) return bail(RL_ERR_NOMEM);
     if (!host_block((void**)&e->h_gen_word, 64)) return bail(RL_ERR_NOMEM);
     memset(e->h_m_word, 0, 64);
@@ -2697,7 +2700,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
         HIP_TRY(e, hipMemcpy(e->d_match_flimits, fl.data(), n_limits * sizeof(MatchLimitF), hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_match_fconds, fc.data(), fc.size() * sizeof(MatchCondF), hipMemcpyHostToDevice));
         e->match_slots = slots;
-        e->match_fast = getenv("RL_MATCH_GENERIC") == nullptr;
+        e->match_fast = RL_EXP_ENV("RL_MATCH_GENERIC") == nullptr;
     }
     return RL_OK;
 }
@@ -2749,9 +2752,13 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
         k_count<<<g, 256, 0, e->stream>>>(d_ns, d_ent_off, d_ent_key, d_ent_val, d_delta, n_req, e->d_match_limits,
                                           e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_conds,
                                           e->n_match_conds, e->d_m_count, nullptr, nullptr, e->d_status);
-    size_t stmp = e->m_scan_tmp_bytes;
-    HIP_TRY(e, rocprim::exclusive_scan(e->d_m_scan_tmp, stmp, e->d_m_count, e->d_req_off, 0u, (size_t)n_req + 1,
-                                       rocprim::plus<u32>(), e->stream));
+    {
+        const u32 ns = n_req + 1, gs = cdiv(ns, XSCAN_PER_WG);
+        u32* tot = static_cast<u32*>(e->d_m_scan_tmp);
+        k_xscan_sums<<<gs, 256, 0, e->stream>>>(e->d_m_count, ns, tot);
+        k_xscan_tot<<<1, 1024, 0, e->stream>>>(tot, gs);
+        k_xscan_apply<<<gs, 256, 0, e->stream>>>(e->d_m_count, ns, tot, e->d_req_off);
+    }
     HIP_TRY(e, hipMemcpyAsync(e->h_m_total, e->d_req_off + n_req, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     int rc = RL_OK;
     bool filled = false;

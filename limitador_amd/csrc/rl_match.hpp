@@ -544,4 +544,75 @@ __global__ __launch_bounds__(256) void k_match_limited_limit(const int32_t* __re
     out[r] = f < 0 ? -1 : (int32_t)(hits[f].limit & ~SIMPLE_FLAG);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan of the per-request counter counts for the GENERIC matcher (tables that do not take the slot form),
+// without a library: k_xscan_sums (1024 counts per workgroup -> its total) -> k_xscan_tot (one workgroup: the totals
+// in place -> what lies before each workgroup) -> k_xscan_apply (every workgroup scans its own 1024 counts on top of
+// its base).  out[i] = sum of in[0 .. i), i < n.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 XSCAN_PER_WG = 1024;
+
+__global__ __launch_bounds__(256) void k_xscan_sums(const u32* __restrict__ in, u32 n, u32* __restrict__ wg_tot) {
+    __shared__ u32 s_w[4];
+    const u32 i0 = blockIdx.x * XSCAN_PER_WG + threadIdx.x * 4;
+    u32 k = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q)
+        if (i0 + q < n) k += in[i0 + q];
+    u32 total;
+    (void)match_block_scan(k, s_w, total);
+    if (threadIdx.x == 0) wg_tot[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_xscan_tot(u32* __restrict__ wg_tot, u32 g) {
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < g; base += 1024) {  // (block-uniform)
+        const u32 i = base + tid;
+        const u32 x = i < g ? wg_tot[i] : 0u;
+        u32 inc = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 o = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += o;
+        }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        u32 woff = 0, tot = 0;
+#pragma unroll
+        for (u32 ww = 0; ww < 16; ++ww) {
+            const u32 y = s_w[ww];
+            if (ww < w) woff += y;
+            tot += y;
+        }
+        const u32 carry = s_carry;
+        if (i < g) wg_tot[i] = carry + woff + inc - x;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xscan_apply(const u32* __restrict__ in, u32 n, const u32* __restrict__ wg_tot,
+                                                     u32* __restrict__ out) {
+    __shared__ u32 s_w[4];
+    const u32 i0 = blockIdx.x * XSCAN_PER_WG + threadIdx.x * 4;
+    u32 c[4], k = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        c[q] = i0 + q < n ? in[i0 + q] : 0u;
+        k += c[q];
+    }
+    u32 total;
+    u32 ex = wg_tot[blockIdx.x] + match_block_scan(k, s_w, total);
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        if (i0 + q < n) out[i0 + q] = ex;
+        ex += c[q];
+    }
+}
+
 }  // namespace rl

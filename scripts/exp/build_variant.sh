@@ -12,7 +12,7 @@ mkdir -p "$tmp/limitador_amd" "$root/limitador_amd/lib/variants"
 cp -r "$root/include" "$tmp/include"
 cp -r "$root/limitador_amd/csrc" "$tmp/limitador_amd/csrc"
 (cd "$tmp" && patch -p1 < "$root/scripts/exp/patches/$name.patch")
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -I"$tmp/include" "$tmp/limitador_amd/csrc/rl_engine.hip" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DRL_EXPERIMENT -I"$tmp/include" "$tmp/limitador_amd/csrc/rl_engine.hip" \
     -o "$root/limitador_amd/lib/variants/librl_engine_$name.so"
 rm -rf "$tmp"
 ls -la "$root/limitador_amd/lib/variants/librl_engine_$name.so"

@@ -4,6 +4,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The test-suite walks every engine mode (stream forms, kernel shapes, pipeline depths) by environment switches that only
+# the -DRL_EXPERIMENT build of the libraries reads (limitador_amd/lib/exp/, limitador_amd/build.py); the release
+# build — what bench.py, smoke() and a host link — is run by tests/test_gpu_release_lib.py in a process of its own
+# (LIMITADOR_AMD_LIB=release there).  Must be set before limitador_amd is imported.
+os.environ.setdefault("LIMITADOR_AMD_LIB", "exp")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

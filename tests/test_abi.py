@@ -112,3 +112,30 @@ def test_sharded_library_exports_every_symbol_of_rl_sharded_h():
     with pytest.raises(sharded_abi.ShardedError):
         g.transport(2)
     g.close()
+
+
+DOCUMENTED_SWITCHES = {"RL_FUSE", "RL_SERVE", "RL_TINY_MAX", "RL_STREAM", "RLI_THREADS"}
+
+
+def _switch_names(path):
+    blob = open(path, "rb").read()
+    return {m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])(RLI?_[A-Z][A-Z0-9_]+)\x00", blob)}
+
+
+def test_release_libraries_read_only_the_documented_switches():
+    """shapes, budgets, priorities and diagnostics are compiled behind -DRL_EXPERIMENT; the libraries a
+    host links against name at most the documented handful of environment variables (include/rl_engine.h,
+    include/rl_ingest.h) — the experiment build (limitador_amd/lib/exp/, what this suite loads) names the rest."""
+    from limitador_amd import build as b
+
+    seen = set()
+    for so in ("librl_engine.so", "librl_storage.so", "librl_sharded.so"):
+        path = os.path.join(b.RELEASE_LIBDIR, so)
+        assert os.path.exists(path), f"{path}: run __graft_entry__.build()"
+        names = _switch_names(path)
+        assert names <= DOCUMENTED_SWITCHES, f"{so} names undocumented switches: {sorted(names - DOCUMENTED_SWITCHES)}"
+        seen |= names
+    assert len(seen) <= 6
+    exp = _switch_names(os.path.join(b.EXP_LIBDIR, "librl_engine.so"))
+    assert "RL_PIPE_DEPTH" in exp and "RL_APPLY_TRACE" in exp, "the experiment build lost its switches"
+    assert b.EXPERIMENT, "tests/conftest.py selects the experiment build for the suite"
