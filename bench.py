@@ -279,19 +279,22 @@ def secondary(args, eng, dev, gen):
     out["configs1_1M_keys_uniform_64k_hits"] = {"decisions_per_s": (1 << 16) * 500 / dt, "us_per_batch": dt / 500 * 1e6}
     e1.close()
     del rows, b1
-    # -- BASELINE.json configs[0]: 3 limits / 1 namespace, 10 k sequential check_and_update calls through the trait
-    #    mirror (rls_check_and_update, one request per call), the single-thread oracle beside it
+    # -- BASELINE.json configs[0]: 3 limits / 1 namespace, 10 k sequential check_and_update calls, in the reference's two
+    #    shapes (SURVEY.md §8d "Config #1"), the single-thread oracle beside each:
+    #    A  limitador/benches/bench.rs:526-570 — three limits of one namespace with identical conditions,
+    #       max_value = u64::MAX, seconds = i * 60 + 10: every call meets all three (k = 3) and is ADMITTED (three
+    #       write-backs per call), through the C++ mirror of the trait (rls_check_and_update, one request per call);
+    #    B  limitador-server/sandbox/limits.yaml:1-22 as written (two conditions per limit) through the wire path
+    #       (rli_serve_batch, one serialized RateLimitRequest per call): a GET /json request meets ONLY the 50000 / 10 s
+    #       limit (k = 1); the clock advances 5 ms per call, so the window restarts every 2000 calls, and hits_addend 30
+    #       makes the tail of every window OVER_LIMIT (2000 x 30 > 50000).
     try:
         from limitador_amd.host_storage import HostStorage
 
+        U64 = (1 << 64) - 1
         hs = HostStorage(capacity_cells=1 << 12, max_batch_hits=1 << 10, device=eng.device)
         hs.set_clock(W.NOW0_US)
-        # limitador-server/sandbox/limits.yaml: 10/60 s, 5/60 s, 50000/10 s in one namespace.  The conditions are part of
-        # a limit's identity (max_value is not): without them the first two are ONE limit whose max_value flips with
-        # every counter the caller hands over — two rl_limits_set calls per request (what this leg measured before).
-        lims = [("ns", 10, 60, ("descriptors[0]['req.method'] == 'GET'",), (), None),
-                ("ns", 5, 60, ("descriptors[0]['req.method'] == 'POST'",), (), None),
-                ("ns", 50000, 10, ("descriptors[0]['req.path'] == '/json'",), (), None)]
+        lims = [("0", U64, i * 60 + 10, ("cond_0 == '1'",), (), None) for i in range(3)]
         for la in lims:
             hs.add_counter(la)
         ctrs = [(la, ()) for la in lims]
@@ -299,7 +302,7 @@ def secondary(args, eng, dev, gen):
         sec, limited = hs.check_and_update_repeat(ctrs, 1, 10_000)
         hs.close()
         orc = oracle.OracleStorage()
-        orc.set_limits([(10, 60), (5, 60), (50000, 10)])
+        orc.set_limits([(U64, i * 60 + 10) for i in range(3)])
         hits = np.zeros(30_600, dtype=oracle.HIT_DTYPE)  # the same 200 warm-up calls first, so that the counts compare
         for q in range(3):
             orc.add_counter(q | oracle.SIMPLE_FLAG)
@@ -309,14 +312,70 @@ def secondary(args, eng, dev, gen):
         t0 = time.perf_counter()
         v, _f, _r, _e = orc.check_and_update(hits[600:], W.NOW0_US, req_off=off[:10_001])
         osec = time.perf_counter() - t0
-        out["configs0_3_limits_10k_sequential_calls"] = {
+        orc.close()
+        out["configs0_bench_rs_shape_10k_sequential_calls"] = {
             "gpu_calls_per_s": 10_000 / sec, "gpu_us_per_call": sec / 10_000 * 1e6, "gpu_limited": int(limited),
-            "cpu_oracle_calls_per_s": 10_000 / osec, "cpu_limited": int(v.sum()),
-            "note": "one request (3 counters) per call through the C++ mirror of the trait (rls_check_and_update); the calls "
-                    "are answered by a lingering k_gen_serve through a host-mapped mailbox, no kernel launch per call "
+            "cpu_oracle_calls_per_s": 10_000 / osec, "cpu_limited": int(v.sum()), "counters_per_call": 3,
+            "note": "limitador/benches/bench.rs:526-570 shape (3 limits, identical conditions, max u64::MAX, seconds i*60+10): "
+                    "every call admitted, three cells written per call; one request per call through the C++ mirror of the "
+                    "trait (rls_check_and_update), answered by a lingering k_gen_serve through a host-mapped mailbox "
                     "(RL_SERVE=0: one launch per call)"}
     except Exception as ex:  # the host mirror is optional plumbing for this leg
-        out["configs0_3_limits_10k_sequential_calls"] = {"error": str(ex)[:200]}
+        out["configs0_bench_rs_shape_10k_sequential_calls"] = {"error": str(ex)[:200]}
+    try:
+        from limitador_amd.ingest import Ingest
+
+        def pb_str(field, b):  # (a length-delimited protobuf field; every length here is < 128)
+            return bytes([field << 3 | 2, len(b)]) + b
+
+        def rls_request(domain, entries, hits_addend):
+            d = b"".join(pb_str(1, pb_str(1, k.encode()) + pb_str(2, v.encode())) for k, v in entries)
+            return pb_str(1, domain.encode()) + pb_str(2, d) + bytes([3 << 3, hits_addend])
+
+        e0 = Engine(capacity_cells=1 << 12, max_batch_hits=1 << 10, device=eng.device)
+        g = Ingest()
+        sandbox = [("test_namespace", 10, 60, ["descriptors[0]['req.method'] == 'GET'", "descriptors[0]['req.path'] != '/json'"]),
+                   ("test_namespace", 5, 60, ["descriptors[0]['req.method'] == 'POST'", "descriptors[0]['req.path'] != '/json'"]),
+                   ("test_namespace", 50000, 10, ["descriptors[0]['req.method'] == 'GET'", "descriptors[0]['req.path'] == '/json'"])]
+        for ns, mx, secs, conds in sandbox:
+            g.add_limit(ns, mx, secs, conds, [])
+        g.install(e0)
+        ADD, STEP_US = 30, 5000
+        prep = g.prepare_batch([rls_request("test_namespace", [("req.method", "GET"), ("req.path", "/json")], ADD)])
+        t_now = W.NOW0_US
+        for _ in range(200):
+            g.serve_prepared(e0, prep, t_now)
+            t_now += STEP_US
+        gpu_limited = 0
+        t0 = time.perf_counter()
+        for _ in range(10_000):
+            g.serve_prepared(e0, prep, t_now)
+            gpu_limited += prep["status"][0] == 1
+            t_now += STEP_US
+        sec_b = time.perf_counter() - t0
+        g.close()
+        e0.close()
+        orc = oracle.OracleStorage()
+        orc.set_limits([(10, 60), (5, 60), (50000, 10)])
+        orc.add_counter(2 | oracle.SIMPLE_FLAG)
+        hits = np.zeros(10_200, dtype=oracle.HIT_DTYPE)
+        hits["key"], hits["limit"], hits["delta"] = 7_000_002, 2 | oracle.SIMPLE_FLAG, ADD
+        nows = (W.NOW0_US + np.arange(10_200, dtype=np.uint64) * np.uint64(STEP_US)).astype(np.uint64)
+        offb = np.arange(10_201, dtype=np.uint32)
+        orc.check_and_update(hits[:200], W.NOW0_US, req_off=offb[:201], req_now_us=nows[:200])
+        t0 = time.perf_counter()
+        v, _f, _r, _e = orc.check_and_update(hits[200:], W.NOW0_US, req_off=offb[:10_001], req_now_us=nows[200:])
+        osec = time.perf_counter() - t0
+        orc.close()
+        out["configs0_sandbox_limits_10k_sequential_calls"] = {
+            "gpu_calls_per_s": 10_000 / sec_b, "gpu_us_per_call": sec_b / 10_000 * 1e6, "gpu_limited": int(gpu_limited),
+            "cpu_oracle_calls_per_s": 10_000 / osec, "cpu_limited": int(v.sum()), "counters_per_call": 1,
+            "note": "limitador-server/sandbox/limits.yaml:1-22 as written, a GET /json RateLimitRequest (hits_addend 30) per "
+                    "rli_serve_batch call: wire decode + device matching (only the 50000 / 10 s limit applies) + "
+                    "check_and_update + response bytes; clock + 5 ms per call, the window restarts every 2000 calls; the "
+                    "figure includes the ctypes call from Python (the oracle's is the bare cell arithmetic, no matching)"}
+    except Exception as ex:
+        out["configs0_sandbox_limits_10k_sequential_calls"] = {"error": str(ex)[:200]}
     # -- BASELINE.json configs[4] shape on one GPU: 4 namespaces x 8 limits, 1 M requests -> ~3.1 M counters per call,
     #    limit matching + key derivation on the device + the multi-counter resolver (scripts/bench_match.py, own process)
     try:

@@ -59,7 +59,7 @@ constexpr u32 GEN_SUB_MAX = 4u << 20;  // most hits of one pass of the general r
 //            so that the set a partition rewrites is never one a batch still in flight reads (k_hot_state of batch
 //            p - 1 and p - 2 read the sets of p - 1 - depth and p - 2 - depth)
 constexpr u32 PB_SETS = 3;
-constexpr u32 BS_ROT = 5;
+constexpr u32 BS_ROT = 6;
 constexpr u32 HS_SETS = 8;
 
 struct rl_engine {
@@ -157,6 +157,8 @@ struct rl_engine {
     // k_hot_state + k_bkt_apply of batch k (on `stream`).  With a caller's stream (rl_engine_set_stream)
     // or RL_OVERLAP=0 both are the same stream.
     hipStream_t pstream = nullptr, own_pstream = nullptr;
+    hipStream_t stream2 = nullptr;  // xover: the replays of odd partitioned batches (see xover)
+    int xover = 0;
     bool overlap = true;
     bool ext_events = true;         // RL_EXT_EVENTS=0: hipEventRecord markers behind k_bkt_scatter / k_bkt_apply instead of the
                                     // launches' own stop events (two marker commands fewer per batch on the two streams)
@@ -515,10 +517,10 @@ inline u32 scatter_lds_bytes(u32 nbt) { return (u32)PT_WAVES * nbt * (u32)sizeof
     RL_LAUNCH_TS(timed, ev0, ev1, kern, grid, block, 0, stream, __VA_ARGS__)
 
 // k_bkt_step in the instantiation RL_APPLY2_CFG selects (see RL_DEF_STEP).
-void launch_step(rl_engine* e, const StepParams& S, bool timed, hipEvent_t ev0, hipEvent_t ev1) {
+void launch_step(rl_engine* e, hipStream_t rs, const StepParams& S, bool timed, hipEvent_t ev0, hipEvent_t ev1) {
     const u32 n_wg = S.n_apply_wgs + S.n_part_wgs;
 #define RL_ST(KERN)                                                                                                  \
-    RL_LAUNCH_TS(timed, ev0, ev1, KERN, n_wg, AP_BLOCK, std::max(sizeof(KERN##_lds), sizeof(PartLds)), e->stream, S)
+    RL_LAUNCH_TS(timed, ev0, ev1, KERN, n_wg, AP_BLOCK, std::max(sizeof(KERN##_lds), sizeof(PartLds)), rs, S)
     if (S.A.run_tt == (u32)TT_LARGE) {  // the largest batches (more than TT_SMALL tiles): a bucket view of 1024 tiles
         RL_ST(k_bkt_step_large);
         return;
@@ -554,15 +556,17 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
     const bool two_streams = e->pstream != e->stream;
     rl_engine::Inflight* fa = nullptr;
     u64 p = 0;
+    hipStream_t rs = e->stream;
     if (q.valid) {
         q.valid = false;
         rl_engine::Inflight& f = e->inflight[q.slot];
         fa = &f;
         p = q.p;
+        if (e->xover && (p & 1u)) rs = e->stream2;
         const u32 par = (u32)(p % PB_SETS);
         if (two_streams && hipEventQuery(e->ev_parted[p & 3u]) != hipSuccess) {
             (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
-            HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_parted[p & 3u], 0));
+            HIP_TRY(e, hipStreamWaitEvent(rs, e->ev_parted[p & 3u], 0));
             e->n_wait_parted++;
         }
         ApplyParams& P = S.A;
@@ -587,7 +591,7 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
         P.done_seq = f.seq;
         P.hot_next = e->d_hot + p % HS_SETS;
         P.hot_threshold = e->hot_threshold;
-        P.hot_arrive = e->d_hot_arrive;
+        P.hot_arrive = e->d_hot_arrive + (size_t)(p & 1u) * HOT_MAX;
         P.sparse_out = 1u;
         P.hot_long = q.hot_long;
         if (e->apply_trace) {
@@ -618,10 +622,10 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
     }
     const hipEvent_t done_event = fa ? q.done_event : nullptr;
     q.done_event = nullptr;
-    launch_step(e, S, timed, ev0, ev1);
+    launch_step(e, rs, S, timed, ev0, ev1);
     HIP_TRY(e, hipGetLastError());
-    if (fa && two_streams && e->apply_events && !e->ext_events) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], e->stream));
-    if (done_event) HIP_TRY(e, hipEventRecord(done_event, e->stream));
+    if (fa && two_streams && e->apply_events && !e->ext_events) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], rs));
+    if (done_event) HIP_TRY(e, hipEventRecord(done_event, rs));
     return RL_OK;
 }
 
@@ -1582,6 +1586,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
         if (const char* v = RL_EXP_ENV("RL_PSTREAM_PRIO")) prio = atoi(v) == 0 ? prio_lo : (atoi(v) == 2 ? 0 : prio_hi);
         if (hipStreamCreateWithPriority(&e->own_pstream, hipStreamNonBlocking, prio) != hipSuccess) return bail(RL_ERR_DEVICE);
         e->pstream = e->own_pstream;
+        if (const char* v = RL_EXP_ENV("RL_XOVER")) e->xover = atoi(v);
+        if (e->xover && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) return bail(RL_ERR_DEVICE);
     } else {
         e->pstream = e->stream;
     }
@@ -1666,8 +1672,8 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     ALLOC(e->d_runs, PB_SETS * (size_t)BKT_MAX * e->run_tt_max * sizeof(u32));
     ALLOC(e->d_items, PB_SETS * sizeof(HotItems));
     if (hipMemset(e->d_items, 0, PB_SETS * sizeof(HotItems)) != hipSuccess) return bail(RL_ERR_DEVICE);
-    ALLOC(e->d_hot_arrive, (size_t)HOT_MAX * sizeof(u32));
-    if (hipMemset(e->d_hot_arrive, 0, (size_t)HOT_MAX * sizeof(u32)) != hipSuccess) return bail(RL_ERR_DEVICE);
+    ALLOC(e->d_hot_arrive, (size_t)2 * HOT_MAX * sizeof(u32));  // by the parity of the partitioned batch
+    if (hipMemset(e->d_hot_arrive, 0, (size_t)2 * HOT_MAX * sizeof(u32)) != hipSuccess) return bail(RL_ERR_DEVICE);
     ALLOC(e->d_tiny_hits, (size_t)TINY_MAX * sizeof(BHit));
     e->chunk_tab_len = std::max<size_t>((size_t)mb / HOT_CHUNK + HOT_MAX + 8, (size_t)HOT_MAX * HOT_NK_MAX);
     ALLOC(e->d_chunk_tab, PB_SETS * e->chunk_tab_len * sizeof(unsigned short));

@@ -478,27 +478,33 @@ def test_single_counter_requests_with_u64_deltas(make_engine):
 
 
 # ---- BASELINE.json configs at full size ----------------------------------------------------------
-def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False):
+def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False, nows=None, early_third=False):
     """in_flight: the bench's entry point and geometry — device-resident batches through
-    rl_check_and_update_submit_device / _collect, three in flight, table at load <= 0.30."""
+    rl_check_and_update_submit_device / _collect, three in flight, table at load <= 0.30.
+    nows: the clock of every batch (default NOW + 1 ms per batch: no pre-populated window ends inside the run).
+    early_third: every third key of the universe carries an expiry 2.5 ms after NOW instead of 30 s, so its window ends
+    INSIDE the run (atomic_expiring_value.rs:36-42,87-99: the first admitted hit after that resets value and expiry)."""
     rows = [(W.MAX_VALUE, W.WINDOW_S)]
     cap = 1 << (int(n_keys * 2.2 - 1).bit_length())
     eng, orc = pair(make_engine, rows, capacity_cells=cap, max_batch_hits=n_hits)
     chunk = 1 << 20
     for lo in range(0, n_keys, chunk):
         cells = W.universe_rows(n_keys, lo=lo, hi=min(n_keys, lo + chunk))
+        if early_third:
+            cells["expiry_us"][(np.arange(lo, lo + len(cells)) % 3) == 0] = NOW + 2500
         eng.load_cells(cells)
         orc.load_cells(cells["key"], cells["limit"], cells["value"], cells["expiry_us"])
     assert eng.stats()["live_cells"] == n_keys
     rng = np.random.default_rng(W.SEED)
     cdf = W.zipf_cdf(n_keys) if zipf else None
-    now = NOW
+    if nows is None:
+        nows = [NOW + 1000 * i for i in range(steps)]
+    assert len(nows) == steps
     denied = 0
     batches = [W.zipf_batch(n_keys, n_hits, rng, cdf) if zipf else W.uniform_batch(n_keys, n_hits, rng) for _ in range(steps)]
     if not in_flight:
-        for hits in batches:
+        for hits, now in zip(batches, nows):
             denied += int(run_both(eng, orc, hits, now, want_first_limited=True).sum())
-            now += 1000
     else:
         import torch
 
@@ -509,7 +515,7 @@ def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False):
         torch.cuda.synchronize()
         pending = 0
         for i in range(steps):
-            eng.submit_device(d_hits[i].data_ptr(), n_hits, now + 1000 * i, d_verdict[i].data_ptr(), d_first[i].data_ptr())
+            eng.submit_device(d_hits[i].data_ptr(), n_hits, nows[i], d_verdict[i].data_ptr(), d_first[i].data_ptr())
             if pending == 2:
                 eng.collect()
             else:
@@ -519,7 +525,7 @@ def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False):
             pending -= 1
         torch.cuda.synchronize()
         for i, hits in enumerate(batches):
-            v, f, _r, _e = orc.check_and_update(hits, now + 1000 * i)
+            v, f, _r, _e = orc.check_and_update(hits, nows[i])
             assert np.array_equal(d_verdict[i].cpu().numpy(), v), f"verdicts of batch {i}"
             assert np.array_equal(d_first[i].cpu().numpy(), f), f"first_limited of batch {i}"
             denied += int(v.sum())
@@ -552,6 +558,29 @@ def test_config3_through_the_bench_entry_point(make_engine):
     first_limited and final cell compared."""
     eng = _full_size(make_engine, 10_000_000, 1_000_000, steps=5, zipf=True, in_flight=True)
     assert eng.stats()["hits"] == 5_000_000
+
+
+def test_config3_every_window_ends_between_two_batches(make_engine):
+    """configs[2] at full size with the clock jumping past the pre-populated 30 s expiry between batches 2 and 3 (VERDICT
+    r03 missing #3): every cell touched from then on is read as 0 and its first admitted hit resets value AND expiry
+    (atomic_expiring_value.rs:19-24,36-42,87-99: the 16-byte write-back), the saturated Zipf head is admitted again.
+    Three batches in flight through the bench's entry point; every verdict, first_limited and all 10 M cells compared."""
+    nows = [NOW, NOW + 1000, NOW + 31_000_000, NOW + 31_001_000, NOW + 31_002_000]
+    eng = _full_size(make_engine, 10_000_000, 1_000_000, steps=5, zipf=True, in_flight=True, nows=nows)
+    rows = eng.dump_cells()
+    reset = rows["expiry_us"] > np.uint64(NOW + 60_000_000)  # restarted windows: now + 60 s
+    assert 0.05 * len(rows) < int(reset.sum()) < 0.5 * len(rows)  # (~1.3 M distinct keys in three Zipf batches)
+    assert int(rows["value"][reset].max()) <= W.MAX_VALUE
+
+
+def test_config3_a_third_of_the_windows_end_inside_the_run(make_engine):
+    """configs[2] at full size where every third key's window ends 2.5 ms into the run (between batches 3 and 4 of 6):
+    live, expired-and-reset and never-touched expired cells side by side in every bucket; blocking calls (one kernel
+    sequence per batch) this time.  All 10 M cells compared."""
+    eng = _full_size(make_engine, 10_000_000, 1_000_000, steps=6, zipf=True, early_third=True)
+    rows = eng.dump_cells()
+    n_reset = int((rows["expiry_us"] > np.uint64(NOW + 59_000_000)).sum())
+    assert n_reset > 100_000
 
 
 # ---- multi-counter requests and load_counters (the general resolver) ------------------------------
