@@ -204,14 +204,14 @@ def secondary(args, eng, dev, gen):
     out = {}
     now = [W.NOW0_US + 10_000_000]
 
-    def run_device(e, batches, n, steps, depth=3):
+    def run_device(e, batches, n, steps, depth=3, jump_every=0, jump_us=0):
         v = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(4)]
         torch.cuda.synchronize()
         pending = 0
         t0 = time.perf_counter()
         for i in range(steps):
             e.submit_device(batches[i % len(batches)].data_ptr(), n, now[0], v[i & 3].data_ptr())
-            now[0] += 1000
+            now[0] += jump_us if jump_every and i % jump_every == jump_every - 1 else 1000
             if pending == depth - 1:
                 e.collect()
             else:
@@ -228,6 +228,17 @@ def secondary(args, eng, dev, gen):
     run_device(eng, many, args.batch, 20)
     dt = run_device(eng, many, args.batch, 1000)
     out["headline_1000_steps"] = {"decisions_per_s": args.batch * 1000 / dt, "ms_per_step": dt}
+    # -- the same workload with the windows ENDING inside the run: the clock jumps 40 s behind every 8th batch (windows
+    #    of 60 s, pre-populated expiries 30-60 s ahead), so every touched cell is reset again and again
+    #    (atomic_expiring_value.rs:36-42,87-99: value = delta, expiry = now + ttl — a 16-byte write-back instead of 8)
+    #    and the hot keys leave saturation; the denials of the last batch say where the run ended
+    run_device(eng, many, args.batch, 16, jump_every=8, jump_us=40_000_000)
+    vlast = torch.empty(args.batch, dtype=torch.uint8, device=dev)
+    dt = run_device(eng, many, args.batch, 200, jump_every=8, jump_us=40_000_000)
+    eng.check_and_update_device(many[0].data_ptr(), args.batch, now[0], vlast.data_ptr())
+    out["headline_with_expiry"] = {"decisions_per_s": args.batch * 200 / dt, "ms_per_step": dt / 200 * 1e3,
+                                   "clock": "+1 ms per batch, +40 s behind every 8th (windows of 60 s)",
+                                   "denied_in_a_batch_after_the_run": int(vlast.sum().item())}
     del many
     # -- uniform keys, same table and batch size (no hot keys: every hit reads and writes a cell)
     uni = [W.torch_batch(args.keys, args.batch, dev, gen, None) for _ in range(10)]
@@ -418,12 +429,35 @@ def secondary(args, eng, dev, gen):
         t0 = time.perf_counter()
         eng.compact()
         dt_c = time.perf_counter() - t0
+        # a sweep that FINDS something: the clock jumps 100 s (every window of the table is over), seven uniform batches
+        # restart the windows of the ~half of the cells they touch, and the sweep right behind them removes the other
+        # half; then compact the table the tombstones are in (in place: k_compact_mark / k_compact_shift)
+        now[0] += 100_000_000
+        b7 = [W.torch_batch(args.keys, args.batch, dev, gen, None) for _ in range(7)]
+        run_device(eng, b7, args.batch, 7)
+        live0 = eng.stats()["live_cells"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        removed = eng.sweep_expired(now[0])
+        dt_x = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng.compact()
+        dt_xc = time.perf_counter() - t0
+        live1 = eng.stats()["live_cells"]
+        slots = table_bytes // 32
         out["sweep_and_compact_10M_keys"] = {
             "sweep_ms": dt * 1e3, "sweep_GBps": table_bytes / dt / 1e9, "sweep_frac_of_8TBps": table_bytes / dt / 1e9 / HBM_PEAK_GBPS,
+            "sweep_GBps_24B_per_slot": slots * 24 / dt / 1e9,
             "batch_sweep_batch_in_flight_ms": dt_mix * 1e3, "swept_between_batches": int(swept),
             "compact_ms": dt_c * 1e3, "table_bytes": table_bytes,
-            "note": "rl_sweep_expired (host call incl. its status read-back) over the 32-byte cells; rl_sweep_expired_submit "
-                    "between two 1 M-hit batches in flight; rl_compact"}
+            "expired_sweep": {"live_before": int(live0), "removed": int(removed), "removed_frac": removed / max(live0, 1),
+                              "live_after_compact": int(live1), "sweep_ms": dt_x * 1e3,
+                              "sweep_GBps_24B_per_slot": slots * 24 / dt_x / 1e9, "sweep_GBps_32B_cells": table_bytes / dt_x / 1e9,
+                              "compact_ms": dt_xc * 1e3},
+            "note": "rl_sweep_expired (host call incl. its status read-back) over the 32-byte cells (SURVEY.md 8d counts 24 B "
+                    "per slot: both rates given); rl_sweep_expired_submit between two 1 M-hit batches in flight; rl_compact of a "
+                    "table without tombstones; expired_sweep: clock + 100 s, seven uniform 1 M-hit batches restart the windows of the "
+                    "cells they touch, the sweep removes every other cell (expiry <= now), rl_compact closes the gaps in place"}
     except Exception as ex:
         out["sweep_and_compact_10M_keys"] = {"error": str(ex)[:200]}
     return out

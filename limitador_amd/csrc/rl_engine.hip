@@ -52,9 +52,10 @@ constexpr u32 GEN_SUB_MAX = 4u << 20;  // most hits of one pass of the general r
 // batch may run as soon as the batch `pipe_depth` (2 or 3) before it has been applied:
 //   PB_SETS  partitioned records / ranges / hot-bucket table / chunk table: batch p writes set p % 3, last read by
 //            k_bkt_apply of batch p - 3
-//   BS_ROT   scratch blocks: batch p uses [p % 5]; its replay zeroes [(p + 4) % 5] (= batch p - 1's, done) for batch
-//            p + 4 — FOUR ahead, so that the partition of a batch only ever depends on a replay kernel that has ENDED
-//            (see apply_events); one more block ([BS_ROT]) belongs to k_bkt_tiny
+//   BS_ROT   scratch blocks: batch p uses [p % 6]; its replay zeroes [(p + 4) % 6] (= batch p - 2's, whose replay ENDED
+//            before this one started — also when the replays of p - 1 and p overlap, RL_XOVER) for batch p + 4 — FOUR
+//            ahead, so that the partition of a batch only ever depends on a replay kernel that has ENDED (see
+//            apply_events); one more block ([BS_ROT]) belongs to k_bkt_tiny
 //   HS_SETS  hot sets: batch p picks set p % 8 and is partitioned with the one batch p - pipe_depth picked; eight,
 //            so that the set a partition rewrites is never one a batch still in flight reads (k_hot_state of batch
 //            p - 1 and p - 2 read the sets of p - 1 - depth and p - 2 - depth)
@@ -157,12 +158,17 @@ struct rl_engine {
     // k_hot_state + k_bkt_apply of batch k (on `stream`).  With a caller's stream (rl_engine_set_stream)
     // or RL_OVERLAP=0 both are the same stream.
     hipStream_t pstream = nullptr, own_pstream = nullptr;
-    hipStream_t stream2 = nullptr;  // xover: the replays of odd partitioned batches (see xover)
+    // RL_XOVER=2 (experiment builds; a MEASUREMENT device, the results are wrong): the replays of odd partitioned batches go to
+    // `stream2` and nothing orders two consecutive replays — the ceiling of what a per-bucket hand-over between overlapped
+    // replays could reach.  Measured: the step does not move (profiles/r04b_overlap_bound.md), so the hand-over is not built.
+    hipStream_t stream2 = nullptr;
     int xover = 0;
     bool overlap = true;
     bool ext_events = true;         // RL_EXT_EVENTS=0: hipEventRecord markers behind k_bkt_scatter / k_bkt_apply instead of the
                                     // launches' own stop events (two marker commands fewer per batch on the two streams)
-    u32* d_hot_arrive = nullptr;    // [HOT_MAX] (apply2_hot_item)
+    u32* d_hot_arrive = nullptr;    // [2][HOT_MAX] (apply2_hot_item), by the parity of the partitioned batch
+    u64* d_cmark = nullptr;         // do_compact in place: one bit per slot (cluster starts), allocated at the first compaction
+    u64 cmark_words = 0;
     // the single-pass partition (rl_part.hpp): per set, the tiles' runs and the hot buckets' work items
     u32* d_runs = nullptr;          // [PB_SETS][BKT_MAX * run_tt_max]
     u32 run_tt_max = TT_SMALL;      // TT_SMALL, or TT_LARGE for engines whose largest batch has more than TT_SMALL tiles
@@ -396,6 +402,35 @@ int check_room(rl_engine* e, u64 incoming, bool* need_count = nullptr) {
 // capacity and the counters are committed together — a failure half-way frees the new ones and leaves the engine as it was.
 int do_compact(rl_engine* e, u32 new_log2cap) {
     if (!new_log2cap) new_log2cap = e->log2cap;
+    if (new_log2cap == e->log2cap && e->log2cap >= 6) {
+        // Same geometry: IN PLACE (k_compact_mark / k_compact_shift, rl_kernels.hpp) — no second table, nothing that can
+        // fail half-way; the peer tables (same geometry) the same way, behind the main table.
+        const u64 words = e->cap >> 6;
+        if (e->cmark_words < words) {
+            if (e->d_cmark) (void)hipFree(e->d_cmark);
+            e->d_cmark = nullptr;
+            e->cmark_words = 0;
+            if (hipMalloc((void**)&e->d_cmark, words * sizeof(u64)) != hipSuccess)
+                return fail(e, RL_ERR_NOMEM, "hipMalloc of the compaction's %llu-word cluster map failed", (unsigned long long)words);
+            e->cmark_words = words;
+        }
+        HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+        const u32 grid = (u32)std::min<u64>(std::max<u64>(e->cap >> 10, 64), 8192);
+        k_compact_mark<<<grid, 256, 0, e->stream>>>(e->table, e->cap, e->d_cmark);
+        k_compact_shift<<<grid, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_cmark, e->d_status, 1u);
+        for (u32 a = 0; a < (u32)MERGE_MAX_ACTORS; ++a)
+            if (e->peer_tables[a]) {
+                k_compact_mark<<<grid, 256, 0, e->stream>>>(e->peer_tables[a], e->cap, e->d_cmark);
+                k_compact_shift<<<grid, 256, 0, e->stream>>>(e->peer_tables[a], e->log2cap, e->seed, e->d_cmark, e->d_status, 0u);
+            }
+        HIP_TRY(e, hipGetLastError());
+        int rc = read_status(e);
+        if (rc) return rc;
+        e->live = e->h_status->n_inserted;
+        e->tombs = 0;
+        e->stats.rebuilds++;
+        return RL_OK;
+    }
     Cell* fresh = nullptr;
     Cell* fresh_peer[MERGE_MAX_ACTORS] = {};
     auto undo = [&]() {
@@ -416,11 +451,12 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
         // like any other, its expiry is checked where it is read)
         for (u32 a = 0; a < (u32)MERGE_MAX_ACTORS; ++a)
             if (e->peer_tables[a])
-                k_rehash<<<2048, 256, 0, e->stream>>>(e->peer_tables[a], e->cap, fresh_peer[a], new_log2cap, e->seed, e->d_status);
-        r = hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream);  // (n_inserted below counts the MAIN table's cells only)
+                k_rehash<<<2048, 256, 0, e->stream>>>(e->peer_tables[a], e->cap, fresh_peer[a], new_log2cap, e->seed, e->d_status, 0u);
+        // (one status block for all of them: a peer table's cell that found no room raises the same error bit as the main
+        // table's and refuses the whole resize; n_inserted counts the MAIN table's cells only)
     }
     if (r == hipSuccess) {
-        k_rehash<<<2048, 256, 0, e->stream>>>(e->table, e->cap, fresh, new_log2cap, e->seed, e->d_status);
+        k_rehash<<<2048, 256, 0, e->stream>>>(e->table, e->cap, fresh, new_log2cap, e->seed, e->d_status, 1u);
         r = hipGetLastError();
     }
     if (r != hipSuccess) {
@@ -429,6 +465,7 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
         return fail(e, RL_ERR_DEVICE, "rehash failed: %s", hipGetErrorString(r));
     }
     rc = read_status(e);
+    if (!rc && e->h_status->err) rc = status_to_error(e, e->h_status->err);  // (a live cell found no room in a smaller table)
     if (rc) {
         undo();
         return rc;
@@ -1753,7 +1790,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_cmark, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)

@@ -251,10 +251,143 @@ __global__ __launch_bounds__(256) void k_scan(Cell* __restrict__ table, u64 cap,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compaction IN PLACE (same capacity, same seed): drop the tombstones and close the gaps they leave.
+//
+// With linear probing and tombstones (never EMPTY again), every slot between a key's home and its cell is non-empty,
+// so a key's home lies in the same CLUSTER (maximal run of non-empty slots) as its cell and clusters never interact:
+// one thread REBUILDS one cluster inside its own slots.  It walks the cluster left to right and re-inserts every live
+// cell the way an insert would — into the first free slot at or after its home, where "free" = a slot of the cluster
+// before the walk's position that holds nothing final (a tombstone, or a cell that has moved on) or the cell's own
+// slot.  Linear-probing insertion of the cluster's cells into its emptied range, in slot order: every cell lands at or
+// before the slot it came from (the cells placed inside [home, d) come from slots inside [home, d), so one of
+// [home, d] is free), nothing unread is overwritten, and what is left free at the end becomes EMPTY.  (Packing the
+// cells with pos = max(home, previous pos + 1) in SLOT order is wrong: a later cell with an earlier home then sits
+// behind a gap that was emptied — that formula needs the cells sorted by home.)
+// No second table, no atomics, no failure mode: a streaming read of the table + a write per moved cell / dropped
+// tombstone (the rebuild into a fresh table, k_rehash, is a 1 GB fill + 10 M random compare-and-swaps + 1 GB of
+// hipMalloc / hipFree for the bench's table: 1.7 ms).
+//   k_compact_mark   cluster starts from the UNMODIFIED table (slot non-empty, slot before it EMPTY), one bit per slot:
+//                    decided while the walks run, a slot a walk has just emptied would make a second start of a
+//                    cluster that is being walked
+//   k_compact_shift  one thread per start bit; the free slots of a cluster's first 64 slots are a bit mask in a
+//                    register, a longer cluster continues with the table itself as the state (free = EMPTY)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact_mark(const Cell* __restrict__ table, u64 cap, u64* __restrict__ starts) {
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 words = cap >> 6;  // (cap is a power of two >= 64)
+    for (u64 w = wave; w < words; w += n_waves) {
+        const u64 slot = (w << 6) + lane;
+        const u64 tag = table[slot].tag;
+        const u64 prev = table[((w << 6) + cap - 1) & (cap - 1)].tag;  // (every lane the same address)
+        const u64 empty = __ballot(tag == TAG_EMPTY);
+        const u64 st = ~empty & ((empty << 1) | (prev == TAG_EMPTY ? 1ull : 0ull));
+        if (lane == 0) starts[w] = st;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_shift(Cell* table, u32 log2cap, u64 seed,
+                                                       const u64* __restrict__ starts, Status* st, u32 count) {
+    const u64 cap = 1ull << log2cap;
+    const u32 mask = (u32)(cap - 1);
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 live = 0;
+    const uint4 e0 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u), z0 = make_uint4(0u, 0u, 0u, 0u);
+    auto cell = [&](u32 rel_slot) { return reinterpret_cast<uint4*>(&table[rel_slot & mask]); };
+    for (u64 s = gid; s < cap; s += stride) {
+        if (!((starts[s >> 6] >> (s & 63u)) & 1ull)) continue;
+        const u32 a = (u32)s;
+        u64 freem = 0;  // bit q: slot a + q (q < 64) holds nothing final
+        u32 d = 0;
+        bool ended = false;
+        // the first 64 slots, four at a time (the slots ahead of the walk are never written by it, so they may be read early;
+        // what lies behind the cluster's EMPTY slot is read and ignored)
+        while (d < 64 && !ended) {
+            uint4 ca[4], cb[4];
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                const uint4* p = cell(a + d + j);
+                ca[j] = p[0];
+                cb[j] = p[1];
+            }
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                if (ended) break;
+                const u64 tag = ((u64)ca[j].y << 32) | ca[j].x;
+                if (tag == TAG_EMPTY) {
+                    ended = true;
+                    break;
+                }
+                const u32 dd = d + j;
+                if (tag == TAG_TOMB) {
+                    freem |= 1ull << dd;
+                    continue;
+                }
+                u32 hd = (slot_of(tag, seed, log2cap) - a) & mask;  // the home's distance from the cluster's start
+                if (hd > dd) hd = dd;  // (cannot happen in a well-formed table: never move a cell away from its home)
+                const u64 cand = (freem >> hd) << hd;
+                if (cand) {
+                    const u32 q = (u32)__builtin_ctzll(cand);
+                    uint4* t = cell(a + q);
+                    t[0] = ca[j];
+                    t[1] = cb[j];
+                    freem = (freem & ~(1ull << q)) | (1ull << dd);
+                }
+                ++live;
+            }
+            if (!ended) d += 4;
+        }
+        for (u64 f = freem; f; f &= f - 1) {
+            uint4* z = cell(a + (u32)__builtin_ctzll(f));
+            z[0] = e0;
+            z[1] = z0;
+        }
+        if (ended) continue;
+        // a cluster of more than 64 slots: the table is the state from here on (free = EMPTY; this thread reads its own stores)
+        for (d = 64; d <= mask; ++d) {
+            uint4* p = cell(a + d);
+            const uint4 c0 = p[0];
+            const u64 tag = ((u64)c0.y << 32) | c0.x;
+            if (tag == TAG_EMPTY) break;
+            if (tag == TAG_TOMB) {
+                p[0] = e0;
+                p[1] = z0;
+                continue;
+            }
+            const uint4 c1 = p[1];
+            u32 q = (slot_of(tag, seed, log2cap) - a) & mask;
+            if (q > d) q = d;
+            for (; q < d; ++q) {
+                const uint4 t0 = *cell(a + q);
+                if ((((u64)t0.y << 32) | t0.x) == TAG_EMPTY) break;
+            }
+            if (q < d) {
+                uint4* t = cell(a + q);
+                t[0] = c0;
+                t[1] = c1;
+                p[0] = e0;
+                p[1] = z0;
+            }
+            ++live;
+        }
+    }
+    if (!count) return;
+    __shared__ u32 s_live;
+    if (threadIdx.x == 0) s_live = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) live += __shfl_down(live, off);
+    if ((threadIdx.x & 63u) == 0 && live) atomicAdd(&s_live, live);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_live) atomicAdd(&st->n_inserted, s_live);
+}
+
 // Compaction: re-insert every live cell of `src` into the (initialised, empty) `dst`.
 __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u64 src_cap,
                                                 Cell* __restrict__ dst, u32 dst_log2cap, u64 seed,
-                                                Status* st) {
+                                                Status* st, u32 count) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u32 mask = (1u << dst_log2cap) - 1u;
@@ -266,6 +399,7 @@ __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u6
         if (tag >= TAG_TOMB) continue;
         const uint4 b = p[1];  // expiry, limit, cnt
         u32 slot = slot_of(tag, seed, dst_log2cap);
+        bool placed = false;
         for (u32 step = 0; step <= mask; ++step) {
             const u64 old = atomicCAS(&dst[slot].tag, TAG_EMPTY, tag);
             if (old == TAG_EMPTY) {
@@ -273,11 +407,14 @@ __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u6
                 dst[slot].expiry = ((u64)b.y << 32) | b.x;
                 dst[slot].limit = b.z;
                 ++moved;
+                placed = true;
                 break;
             }
             slot = (slot + 1) & mask;
         }
+        if (!placed) atomicOr(&st->err, ERRBIT_TABLE_FULL);  // (a smaller table that cannot hold the live cells)
     }
+    if (!count) return;  // (peer tables: only the error bit)
     // one atomic per workgroup (same-address atomics serialise at ~30 ns each)
     __shared__ u32 s_moved;
     if (threadIdx.x == 0) s_moved = 0;

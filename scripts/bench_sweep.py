@@ -54,5 +54,18 @@ dt = sum(times[:1]) / 1  # the first call is a pure sweep (tombstones below cap/
 out["sweep_expired"] = {"calls_ms": [t * 1e3 for t in times], "removed": removed, "rebuilds_after": st["rebuilds"],
                         "first_call": {"ms": dt * 1e3, "GBps": (table_bytes + 8 * removed[0]) / dt / 1e9,
                                        "frac_of_8TBps": (table_bytes + 8 * removed[0]) / dt / 8e12}}
+# compaction in place (k_compact_mark + k_compact_shift) of the table the three sweeps left: 30 % of the cells are tombstones
+# (unless the sweeps' own threshold — tombstones > capacity / 8 — has compacted already: rebuilds_after says)
+t0 = time.perf_counter()
+eng.compact()
+dt = time.perf_counter() - t0
+st = eng.stats()
+out["compact_after_sweeps"] = {"ms": dt * 1e3, "live_after": st["live_cells"], "tombstones_after": st["tombstones"]}
+# and with 4 more tenths gone in one sweep (the threshold compaction runs inside the call: sweep + compaction)
+t0 = time.perf_counter()
+rem = eng.sweep_expired(W.NOW0_US + 7_000_000)
+dt = time.perf_counter() - t0
+st = eng.stats()
+out["sweep_40pct_incl_threshold_compaction"] = {"ms": dt * 1e3, "removed": int(rem), "rebuilds_after": st["rebuilds"], "live_after": st["live_cells"]}
 print(json.dumps(out))
 eng.close()

@@ -43,7 +43,14 @@
 //!   * orders a request's counters like `in_memory.rs:105,121` (counters of limits without variables first);
 //!   * aggregates concurrent `check_and_update` callers into one device batch (`max_batch` requests or
 //!     `max_delay`, whichever comes first): a batch is applied exactly like the reference applied to its
-//!     requests one after another, with one clock value for the batch.
+//!     requests one after another, with ONE clock value for the batch — read by the batch leader when the batch
+//!     runs; a caller's own reading would be at most `max_delay` earlier.  (Per-request clocks make the engine
+//!     commit the batch run by run of equal clocks: microsecond stamps turn a batch into single requests, and a
+//!     run that fails leaves the runs before it applied — ADVICE r03);
+//!   * resolves identities to keys INSIDE the leader's critical section, after the sweep that may have forgotten
+//!     them, so that no queued request carries a key whose cell was just dropped;
+//!   * stages every batch in arrays allocated once and pinned in place (`rl_host_register`): no allocation and no
+//!     pageable copy per batch.
 
 use crate::counter::Counter;
 use crate::limit::Limit;
@@ -104,6 +111,8 @@ extern "C" {
     fn rl_engine_destroy(e: *mut RlEngine);
     fn rl_last_error(e: *const RlEngine) -> *const c_char;
     fn rl_status_is_transient(status: i32) -> i32;
+    fn rl_host_register(e: *mut RlEngine, ptr: *mut std::ffi::c_void, bytes: u64) -> i32;
+    fn rl_host_unregister(e: *mut RlEngine, ptr: *mut std::ffi::c_void) -> i32;
     fn rl_limits_set(e: *mut RlEngine, first: u32, rows: *const RlLimitRow, n: u32) -> i32;
     fn rl_add_counter(e: *mut RlEngine, limit: u32, key: u64) -> i32;
     #[allow(clippy::too_many_arguments)]
@@ -141,6 +150,7 @@ extern "C" {
 const RL_ERR_INVALID: i32 = -1;
 const RL_ERR_MISSING_SIMPLE: i32 = -5;
 const RL_ERR_KEY_LIMIT: i32 = -6;
+const RL_ERR_BATCH_TOO_LARGE: i32 = -7;
 
 // ---- errors ---------------------------------------------------------------------------------------
 /// An `rl_status` with the engine's message; becomes a `StorageErr` (`storage/mod.rs:312-339`).
@@ -267,14 +277,67 @@ impl Interner {
 
 // ---- micro-batching of check_and_update -----------------------------------------------------------------
 struct Pending {
+    /// the request's counters in processing order (identities only: limit + set_variables); the batch LEADER turns
+    /// them into wire records, under the interner lock it holds from the sweep to the end of the batch
+    counters: Vec<Counter>,
+    /// filled by the leader
     hits: Vec<RlHit>,
     /// position in the caller's Vec<Counter> of every hit (counters are reordered: simple first)
     order: Vec<usize>,
     delta: u64,
     load_counters: bool,
-    /// the clock when the caller arrived (in_memory.rs:83 reads it per call): travels as the request's `req_now_us`
-    arrived_us: u64,
     result: Option<Result<Answer, GpuEngineError>>,
+}
+
+/// The arrays one device batch travels in: allocated once for the largest batch, pinned in place with
+/// `rl_host_register` (the engine's copies are then DMA from / into these pages), reused by every leader.
+struct Staging {
+    hits: Vec<RlHit>,
+    off: Vec<u32>,
+    deltas: Vec<u64>,
+    verdict: Vec<u8>,
+    first: Vec<i32>,
+    rem: Vec<u64>,
+    exp: Vec<u64>,
+    registered: Vec<*mut std::ffi::c_void>,
+}
+
+impl Staging {
+    fn new(engine: *mut RlEngine, max_batch: usize, max_batch_hits: usize) -> Self {
+        let mut st = Self {
+            hits: vec![RlHit { key: 0, limit: 0, delta: 0 }; max_batch_hits],
+            off: vec![0u32; max_batch + 1],
+            deltas: vec![0u64; max_batch],
+            verdict: vec![0u8; max_batch],
+            first: vec![-1i32; max_batch],
+            rem: vec![0u64; max_batch_hits],
+            exp: vec![0u64; max_batch_hits],
+            registered: Vec::new(),
+        };
+        // the Vecs are never resized, so the ranges stay where they are until drop (unregistered there); a range the
+        // runtime refuses simply stays pageable
+        let ranges: [(*mut std::ffi::c_void, usize); 7] = [
+            (st.hits.as_mut_ptr() as *mut _, st.hits.len() * std::mem::size_of::<RlHit>()),
+            (st.off.as_mut_ptr() as *mut _, st.off.len() * 4),
+            (st.deltas.as_mut_ptr() as *mut _, st.deltas.len() * 8),
+            (st.verdict.as_mut_ptr() as *mut _, st.verdict.len()),
+            (st.first.as_mut_ptr() as *mut _, st.first.len() * 4),
+            (st.rem.as_mut_ptr() as *mut _, st.rem.len() * 8),
+            (st.exp.as_mut_ptr() as *mut _, st.exp.len() * 8),
+        ];
+        for (ptr, bytes) in ranges {
+            if bytes > 0 && unsafe { rl_host_register(engine, ptr, bytes as u64) } == RL_OK {
+                st.registered.push(ptr);
+            }
+        }
+        st
+    }
+
+    fn release(&mut self, engine: *mut RlEngine) {
+        for ptr in self.registered.drain(..) {
+            unsafe { rl_host_unregister(engine, ptr) };
+        }
+    }
 }
 
 struct Answer {
@@ -302,6 +365,8 @@ pub struct GpuStorage {
     /// serialises engine calls that are not batched (the engine has its own mutex too; this one keeps the
     /// interner and the engine's limit table in step)
     call: Mutex<()>,
+    /// the batch leader's arrays (one leader at a time: `leader_active`)
+    staging: Mutex<Staging>,
     max_batch: usize,
     /// hits one engine batch may carry (the engine's max_batch_hits)
     max_batch_hits: usize,
@@ -367,6 +432,7 @@ impl GpuStorage {
             }),
             queue_cv: Condvar::new(),
             call: Mutex::new(()),
+            staging: Mutex::new(Staging::new(engine, max_batch.max(1), max_batch_hits)),
             max_batch: max_batch.max(1),
             max_batch_hits,
             max_delay,
@@ -421,55 +487,49 @@ impl GpuStorage {
 
     /// One device batch for `batch` (all with the same load_counters flag), results stored in place.  A batch the
     /// engine REFUSES for what one request carries (a simple counter that was never add_counter'ed, a malformed hit:
-    /// validation errors, nothing applied) is re-run request by request, so that only the offending caller gets the
-    /// error — the reference fails that caller alone.
-    fn run_batch(&self, batch: &mut [(u64, Pending)]) {
-        let rc = self.run_batch_once(batch);
+    /// validation errors, decided before anything is applied — the batch has ONE clock, so it is one all-or-nothing
+    /// engine command) is re-run request by request, so that only the offending caller gets the error — the reference
+    /// fails that caller alone.
+    fn run_batch(&self, st: &mut Staging, batch: &mut [(u64, Pending)]) {
+        let rc = self.run_batch_once(st, batch);
         if batch.len() > 1 && matches!(rc, RL_ERR_INVALID | RL_ERR_MISSING_SIMPLE | RL_ERR_KEY_LIMIT) {
             for q in 0..batch.len() {
-                self.run_batch_once(&mut batch[q..q + 1]);
+                self.run_batch_once(st, &mut batch[q..q + 1]);
             }
         }
     }
 
     /// -> the engine's status (every request of `batch` has its `result` set)
-    fn run_batch_once(&self, batch: &mut [(u64, Pending)]) -> i32 {
+    fn run_batch_once(&self, st: &mut Staging, batch: &mut [(u64, Pending)]) -> i32 {
         let load = batch[0].1.load_counters;
-        let mut hits: Vec<RlHit> = Vec::new();
-        let mut off: Vec<u32> = vec![0];
-        let mut deltas: Vec<u64> = Vec::new();
-        let mut clocks: Vec<u64> = Vec::new();
-        for (_, p) in batch.iter() {
-            hits.extend_from_slice(&p.hits);
-            off.push(hits.len() as u32);
-            deltas.push(p.delta);
-            // one clock value per request, as each caller would have read it; the engine wants them non-decreasing
-            let t = p.arrived_us.max(clocks.last().copied().unwrap_or(0));
-            clocks.push(t);
-        }
         let n_req = batch.len();
-        let mut verdict = vec![0u8; n_req];
-        let mut first = vec![-1i32; n_req];
-        let mut rem = vec![0u64; if load { hits.len() } else { 0 }];
-        let mut exp = vec![0u64; if load { hits.len() } else { 0 }];
-        let big_delta = deltas.iter().any(|&d| d > u32::MAX as u64);
+        let mut n_hits = 0usize;
+        let mut big_delta = false;
+        st.off[0] = 0;
+        for (q, (_, p)) in batch.iter().enumerate() {
+            st.hits[n_hits..n_hits + p.hits.len()].copy_from_slice(&p.hits);
+            n_hits += p.hits.len();
+            st.off[q + 1] = n_hits as u32;
+            st.deltas[q] = p.delta;
+            big_delta |= p.delta > u32::MAX as u64;
+        }
         let rc = {
             let _g = self.call.lock().unwrap();
             unsafe {
                 rl_check_and_update_batch_ex(
                     self.engine,
-                    hits.as_ptr(),
-                    hits.len() as u32,
-                    off.as_ptr(),
+                    st.hits.as_ptr(),
+                    n_hits as u32,
+                    st.off.as_ptr(),
                     n_req as u32,
-                    if big_delta { deltas.as_ptr() } else { std::ptr::null() },
-                    clocks.as_ptr(),
-                    *clocks.last().unwrap(),
+                    if big_delta { st.deltas.as_ptr() } else { std::ptr::null() },
+                    std::ptr::null(), // one clock for the whole batch
+                    now_us(),         // read here, under the lock: clocks of consecutive batches never go backwards
                     load as c_int,
-                    verdict.as_mut_ptr(),
-                    first.as_mut_ptr(),
-                    if load { rem.as_mut_ptr() } else { std::ptr::null_mut() },
-                    if load { exp.as_mut_ptr() } else { std::ptr::null_mut() },
+                    st.verdict.as_mut_ptr(),
+                    st.first.as_mut_ptr(),
+                    if load { st.rem.as_mut_ptr() } else { std::ptr::null_mut() },
+                    if load { st.exp.as_mut_ptr() } else { std::ptr::null_mut() },
                 )
             }
         };
@@ -481,16 +541,16 @@ impl GpuStorage {
                     message: e.message.clone(),
                 }),
                 Ok(()) => {
-                    let base = off[q] as usize;
+                    let base = st.off[q] as usize;
                     Ok(Answer {
-                        limited: verdict[q] != 0,
-                        first_limited: if verdict[q] != 0 {
-                            Some(p.order[first[q] as usize - base])
+                        limited: st.verdict[q] != 0,
+                        first_limited: if st.verdict[q] != 0 {
+                            Some(p.order[st.first[q] as usize - base])
                         } else {
                             None
                         },
                         loaded: if load {
-                            (0..p.hits.len()).map(|j| (rem[base + j], exp[base + j])).collect()
+                            (0..p.hits.len()).map(|j| (st.rem[base + j], st.exp[base + j])).collect()
                         } else {
                             Vec::new()
                         },
@@ -532,33 +592,68 @@ impl GpuStorage {
                 let mut batch: Vec<(u64, Pending)> = std::mem::take(&mut q.pending);
                 q.first_arrival = None;
                 drop(q);
-                // the bound moka's cache_size gives the reference: past it, the expired cells go first
-                if self.sweep_after > 0 {
-                    let mut interner = self.interner.lock().unwrap();
-                    if interner.by_key.len() > self.sweep_after {
-                        let _g = self.call.lock().unwrap();
-                        let _ = self.sweep_locked(&mut interner);
-                    }
+                // From here to the end of the batch the leader holds the interner: the sweep (the bound moka's cache_size
+                // gives the reference: past it, the expired cells go first) forgets identities, delete_counters does too,
+                // and both must happen-before or happen-after "identity -> key -> cell" of a whole batch, never in between
+                // (a request carrying the key of a cell that was just dropped would re-create the cell under a key no
+                // later request of the same counter resolves to: its hits would be lost to the limit).
+                let mut interner = self.interner.lock().unwrap();
+                if self.sweep_after > 0 && interner.by_key.len() > self.sweep_after {
+                    let _g = self.call.lock().unwrap();
+                    let _ = self.sweep_locked(&mut interner);
                 }
+                for (_, p) in batch.iter_mut() {
+                    let mut hits = Vec::with_capacity(p.counters.len());
+                    for c in &p.counters {
+                        match self.hit_of(&mut interner, c, p.delta) {
+                            Ok(h) => hits.push(h),
+                            Err(e) => {
+                                p.result = Some(Err(e)); // (the limit table refused the row: this caller alone fails)
+                                break;
+                            }
+                        }
+                    }
+                    p.hits = hits;
+                }
+                let mut st = self.staging.lock().unwrap();
                 // runs of equal load_counters (a property of the whole engine call), at most max_batch requests and
-                // max_batch_hits counters each (a request with more counters than that is a batch by itself and the
-                // engine answers RL_ERR_BATCH_TOO_LARGE for it alone)
+                // max_batch_hits counters each; a request with more counters than the engine's batch can carry is
+                // answered here (the staging arrays are sized for max_batch_hits)
                 let mut start = 0;
                 while start < batch.len() {
+                    if batch[start].1.result.is_some() {
+                        start += 1;
+                        continue;
+                    }
+                    if batch[start].1.hits.len() > self.max_batch_hits {
+                        batch[start].1.result = Some(Err(GpuEngineError {
+                            status: RL_ERR_BATCH_TOO_LARGE,
+                            message: format!(
+                                "a request of {} counters exceeds the engine's batch of {} hits",
+                                batch[start].1.hits.len(),
+                                self.max_batch_hits
+                            ),
+                        }));
+                        start += 1;
+                        continue;
+                    }
                     let load = batch[start].1.load_counters;
                     let mut end = start + 1;
                     let mut n_hits = batch[start].1.hits.len();
                     while end < batch.len()
                         && end - start < self.max_batch
+                        && batch[end].1.result.is_none()
                         && batch[end].1.load_counters == load
                         && n_hits + batch[end].1.hits.len() <= self.max_batch_hits
                     {
                         n_hits += batch[end].1.hits.len();
                         end += 1;
                     }
-                    self.run_batch(&mut batch[start..end]);
+                    self.run_batch(&mut st, &mut batch[start..end]);
                     start = end;
                 }
+                drop(st);
+                drop(interner);
                 q = self.queue.lock().unwrap();
                 for (t, p) in batch {
                     q.done.insert(t, p);
@@ -574,6 +669,9 @@ impl GpuStorage {
 
 impl Drop for GpuStorage {
     fn drop(&mut self) {
+        if let Ok(mut st) = self.staging.lock() {
+            st.release(self.engine);
+        }
         unsafe { rl_engine_destroy(self.engine) };
     }
 }
@@ -655,20 +753,13 @@ impl CounterStorage for GpuStorage {
         // (in_memory.rs:105,121)
         let mut order: Vec<usize> = (0..counters.len()).filter(|&i| !counters[i].is_qualified()).collect();
         order.extend((0..counters.len()).filter(|&i| counters[i].is_qualified()));
-        let hits = {
-            let mut interner = self.interner.lock().unwrap();
-            let mut hits = Vec::with_capacity(order.len());
-            for &i in &order {
-                hits.push(self.hit_of(&mut interner, &counters[i], delta)?);
-            }
-            hits
-        };
+        // identities only: the batch leader resolves them to keys inside its critical section (see submit)
         let answer = self.submit(Pending {
-            hits,
+            counters: order.iter().map(|&i| counters[i].clone()).collect(),
+            hits: Vec::new(),
             order: order.clone(),
             delta,
             load_counters,
-            arrived_us: now_us(),
             result: None,
         })?;
         if load_counters {
@@ -707,11 +798,13 @@ impl CounterStorage for GpuStorage {
                 rows.truncate(n as usize);
             }
             for row in rows {
-                let vars: HashMap<String, String> = interner
-                    .by_key
-                    .get(&row.key)
-                    .map(|(_, m)| m.iter().map(|(k, v)| (k.clone(), v.clone())).collect())
-                    .unwrap_or_default();
+                // a row whose key the interner does not know (it cannot happen while identities are resolved and
+                // forgotten under the leader's lock; a cell loaded behind the binding's back could) has no identity
+                // to report: skipped, not rebuilt with empty variables
+                let Some((_, known)) = interner.by_key.get(&row.key) else {
+                    continue;
+                };
+                let vars: HashMap<String, String> = known.iter().map(|(k, v)| (k.clone(), v.clone())).collect();
                 let mut counter = Counter::resolved_vars(Arc::clone(limit), vars).map_err(|e| GpuEngineError {
                     status: -1,
                     message: format!("cannot rebuild counter: {e}"),

@@ -796,6 +796,45 @@ def test_resize_answers_table_full_without_losing_a_counter(make_engine):
     assert_same_state(eng, orc, n_simple_expected=1)
 
 
+@pytest.mark.parametrize("cap,n_keys", [(4096, 2900), (1 << 16, 44_000), (1024, 740)])
+def test_compaction_in_place_keeps_every_counter_reachable(make_engine, cap, n_keys):
+    """rl_compact at the same capacity closes the gaps in place (k_compact_mark / k_compact_shift): dense tables
+    (long probe clusters, clusters that wrap around the end of the table), three rounds of sweep -> compact -> refill;
+    after each, every live counter is found again with its value and window and the dropped ones start fresh
+    (in_memory.rs:122-127), exactly as in the oracle."""
+    rng = np.random.default_rng(cap)
+    eng, orc = pair(make_engine, [(9, 60), (4, 2)], simple_keys=[(1, 9_000_001)], capacity_cells=cap,
+                    max_batch_hits=max(n_keys, 64))
+    keys = W.splitmix64(np.arange(1, n_keys + 1, dtype=np.uint64))
+
+    def batch(idx):
+        h = np.empty(len(idx), dtype=HIT_DTYPE)
+        h["key"], h["limit"], h["delta"] = keys[idx], (idx % 2).astype(np.uint32), rng.integers(1, 3, size=len(idx))
+        return h
+
+    now = NOW
+    for _ in range(3):
+        # windows of 60 s on even keys, 2 s on odd ones: 3 s on, the odd ones are swept (half of the table -> tombstones)
+        run_both(eng, orc, batch(rng.permutation(n_keys)), now)
+        now += 3 * SEC
+        assert eng.sweep_expired(now) == orc.sweep_expired(now)
+        before = np.sort(eng.dump_cells(), order="key")
+        st0 = eng.stats()
+        eng.compact()
+        st = eng.stats()
+        assert st["tombstones"] == 0 and st["live_cells"] == len(before) and st["capacity_cells"] == cap
+        assert st["rebuilds"] == st0["rebuilds"] + 1
+        assert np.array_equal(before, np.sort(eng.dump_cells(), order="key"))
+        assert_same_state(eng, orc, n_simple_expected=1)
+        # every key again: the kept ones continue their window, the swept ones are created anew
+        run_both(eng, orc, batch(rng.permutation(n_keys)), now + 1)
+        assert_same_state(eng, orc, n_simple_expected=1)
+        now += 58 * SEC  # the rest of the 60-second windows ends too
+        assert eng.sweep_expired(now) == orc.sweep_expired(now)
+        eng.compact()
+        assert_same_state(eng, orc, n_simple_expected=1)
+
+
 def test_auto_grow_doubles_the_table_instead_of_refusing(make_engine):
     rng = np.random.default_rng(29)
     eng, orc = pair(make_engine, [(5, 60), (2, 1)], capacity_cells=1024, max_batch_hits=4096, auto_grow=True)
