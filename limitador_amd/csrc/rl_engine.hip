@@ -167,7 +167,7 @@ struct rl_engine {
     bool ext_events = true;         // RL_EXT_EVENTS=0: hipEventRecord markers behind k_bkt_scatter / k_bkt_apply instead of the
                                     // launches' own stop events (two marker commands fewer per batch on the two streams)
     u32* d_hot_arrive = nullptr;    // [2][HOT_MAX] (apply2_hot_item), by the parity of the partitioned batch
-    u64* d_cmark = nullptr;         // do_compact in place: one bit per slot (cluster starts), allocated at the first compaction
+    u64* d_cmark = nullptr;         // do_compact in place: the segments' bounds (k_compact_bounds), allocated at the first compaction
     u64 cmark_words = 0;
     // the single-pass partition (rl_part.hpp): per set, the tiles' runs and the hot buckets' work items
     u32* d_runs = nullptr;          // [PB_SETS][BKT_MAX * run_tt_max]
@@ -403,25 +403,24 @@ int check_room(rl_engine* e, u64 incoming, bool* need_count = nullptr) {
 int do_compact(rl_engine* e, u32 new_log2cap) {
     if (!new_log2cap) new_log2cap = e->log2cap;
     if (new_log2cap == e->log2cap && e->log2cap >= 6) {
-        // Same geometry: IN PLACE (k_compact_mark / k_compact_shift, rl_kernels.hpp) — no second table, nothing that can
+        // Same geometry: IN PLACE (k_compact_bounds / k_compact_seg, rl_kernels.hpp) — no second table, nothing that can
         // fail half-way; the peer tables (same geometry) the same way, behind the main table.
-        const u64 words = e->cap >> 6;
-        if (e->cmark_words < words) {
+        const u32 n_seg = (u32)std::max<u64>(e->cap >> CSEG_LOG2, 1);
+        if (e->cmark_words < n_seg) {
             if (e->d_cmark) (void)hipFree(e->d_cmark);
             e->d_cmark = nullptr;
             e->cmark_words = 0;
-            if (hipMalloc((void**)&e->d_cmark, words * sizeof(u64)) != hipSuccess)
-                return fail(e, RL_ERR_NOMEM, "hipMalloc of the compaction's %llu-word cluster map failed", (unsigned long long)words);
-            e->cmark_words = words;
+            if (hipMalloc((void**)&e->d_cmark, (size_t)n_seg * sizeof(u64)) != hipSuccess)
+                return fail(e, RL_ERR_NOMEM, "hipMalloc of the compaction's %u segment bounds failed", n_seg);
+            e->cmark_words = n_seg;
         }
         HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
-        const u32 grid = (u32)std::min<u64>(std::max<u64>(e->cap >> 10, 64), 8192);
-        k_compact_mark<<<grid, 256, 0, e->stream>>>(e->table, e->cap, e->d_cmark);
-        k_compact_shift<<<grid, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_cmark, e->d_status, 1u);
+        k_compact_bounds<<<(n_seg + 255) / 256, 256, 0, e->stream>>>(e->table, e->cap, e->d_cmark, n_seg);
+        k_compact_seg<<<(n_seg + 3) / 4, 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_cmark, n_seg, e->d_status, 1u);
         for (u32 a = 0; a < (u32)MERGE_MAX_ACTORS; ++a)
             if (e->peer_tables[a]) {
-                k_compact_mark<<<grid, 256, 0, e->stream>>>(e->peer_tables[a], e->cap, e->d_cmark);
-                k_compact_shift<<<grid, 256, 0, e->stream>>>(e->peer_tables[a], e->log2cap, e->seed, e->d_cmark, e->d_status, 0u);
+                k_compact_bounds<<<(n_seg + 255) / 256, 256, 0, e->stream>>>(e->peer_tables[a], e->cap, e->d_cmark, n_seg);
+                k_compact_seg<<<(n_seg + 3) / 4, 256, 0, e->stream>>>(e->peer_tables[a], e->log2cap, e->seed, e->d_cmark, n_seg, e->d_status, 0u);
             }
         HIP_TRY(e, hipGetLastError());
         int rc = read_status(e);

@@ -1320,11 +1320,18 @@ struct ServeBox {
 };
 static_assert(sizeof(ServeBox) == 128 + 40 * SRV_MAX_HITS, "ServeBox layout");
 
-// 16 bytes to the host from a kernel that does not end: two 8-byte system-scope stores, the one with the sequence
-// number (upper half of `second`) a RELEASE behind the other — whoever reads the number with acquire finds the rest.
+// What the lingering server tells the host travels as SELF-VALIDATING 16-byte units: value and tag {sequence number, index}
+// leave in ONE store (system scope, written through), so the host can never see a tag whose value is not there yet — two
+// 8-byte stores, even with the second a release, are two arrivals at the host (the withdrawn synchronise-free
+// tiny path: acknowledged stores are not ordered arrivals), and a release per request is an L2 write-back per request.
+__device__ __forceinline__ void srv_store16(void* dst, u32 a, u32 b, u32 c, u32 d) {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v{a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+}
 __device__ __forceinline__ void srv_post(u64* dst, u64 first, u64 second) {
-    __hip_atomic_store(dst, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(dst + 1, second, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    srv_store16(dst, (u32)first, (u32)(first >> 32), (u32)second, (u32)(second >> 32));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32 log2cap, u64 seed,
@@ -1386,11 +1393,9 @@ __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32
         if (load && tid < n_hits && !s_counts[0]) {
             // written THROUGH to the host (system scope) and acknowledged before the barrier: the kernel does not end
             // behind a request, so nothing else would ever push these lines out of the L2
-            u64* sl = reinterpret_cast<u64*>(box->slot[2 * tid]);
-            __hip_atomic_store(sl + 0, o_rem[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(sl + 1, (u64)expect | ((u64)(2u * tid) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(sl + 2, o_exp[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(sl + 3, (u64)expect | ((u64)(2u * tid + 1u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const u64 rem = o_rem[tid], exp = o_exp[tid];
+            srv_store16(box->slot[2 * tid], (u32)rem, (u32)(rem >> 32), expect, 2u * tid);
+            srv_store16(box->slot[2 * tid + 1], (u32)exp, (u32)(exp >> 32), expect, 2u * tid + 1u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (many && tid < n_req && !s_counts[0]) {

@@ -256,122 +256,208 @@ __global__ __launch_bounds__(256) void k_scan(Cell* __restrict__ table, u64 cap,
 //
 // With linear probing and tombstones (never EMPTY again), every slot between a key's home and its cell is non-empty,
 // so a key's home lies in the same CLUSTER (maximal run of non-empty slots) as its cell and clusters never interact:
-// one thread REBUILDS one cluster inside its own slots.  It walks the cluster left to right and re-inserts every live
-// cell the way an insert would — into the first free slot at or after its home, where "free" = a slot of the cluster
-// before the walk's position that holds nothing final (a tombstone, or a cell that has moved on) or the cell's own
-// slot.  Linear-probing insertion of the cluster's cells into its emptied range, in slot order: every cell lands at or
+// a cluster is REBUILT inside its own slots.  One lane walks it left to right and re-inserts every live cell the way
+// an insert would — into the first free slot at or after its home, where "free" = a slot of the cluster before the
+// walk's position that holds nothing final (a tombstone, or a cell that has moved on) or the cell's own slot.
+// Linear-probing insertion of the cluster's cells into its emptied range, in slot order: every cell lands at or
 // before the slot it came from (the cells placed inside [home, d) come from slots inside [home, d), so one of
 // [home, d] is free), nothing unread is overwritten, and what is left free at the end becomes EMPTY.  (Packing the
 // cells with pos = max(home, previous pos + 1) in SLOT order is wrong: a later cell with an earlier home then sits
 // behind a gap that was emptied — that formula needs the cells sorted by home.)
-// No second table, no atomics, no failure mode: a streaming read of the table + a write per moved cell / dropped
-// tombstone (the rebuild into a fresh table, k_rehash, is a 1 GB fill + 10 M random compare-and-swaps + 1 GB of
-// hipMalloc / hipFree for the bench's table: 1.7 ms).
-//   k_compact_mark   cluster starts from the UNMODIFIED table (slot non-empty, slot before it EMPTY), one bit per slot:
-//                    decided while the walks run, a slot a walk has just emptied would make a second start of a
-//                    cluster that is being walked
-//   k_compact_shift  one thread per start bit; the free slots of a cluster's first 64 slots are a bit mask in a
-//                    register, a longer cluster continues with the table itself as the state (free = EMPTY)
+// No second table, no atomics, no failure mode (the rebuild into a fresh table, k_rehash, is a 1 GB fill + 10 M random
+// compare-and-swaps + 1 GB of hipMalloc / hipFree for the bench's table: 1.7 ms).
+//
+// The table is read ONCE, as coalesced 2 KB loads: a wave owns a SEGMENT — the slots between two EMPTY slots of the
+// unmodified table, `bounds[w]` = the first EMPTY slot at or after w * 4096 (k_compact_bounds: a launch of its own,
+// ~1.4 cells read per segment, so that nobody decides a boundary from a table that is being rewritten) — and no
+// cluster crosses a segment's end.  It walks the segment in steps of 64 slots: every lane loads its slot's cell
+// (+ 16 slots of look-ahead) into a per-wave LDS window, the next step's loads are in flight meanwhile; a lane whose
+// slot STARTS a cluster (non-empty, the slot before it EMPTY) rebuilds that cluster, reading from the window (from
+// the table where the cluster runs past it).  What a cluster's walk has touched lies before its end, `carry_end`:
+// later steps ignore what they loaded up to there (it may have been rewritten) and take slot carry_end as EMPTY.
+// The free slots of a cluster's first 64 slots are a bit mask in a register; a longer cluster continues with the
+// table itself as the state (free = EMPTY; the lane reads its own stores).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact_mark(const Cell* __restrict__ table, u64 cap, u64* __restrict__ starts) {
-    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
-    const u32 lane = threadIdx.x & 63u;
-    const u64 words = cap >> 6;  // (cap is a power of two >= 64)
-    for (u64 w = wave; w < words; w += n_waves) {
-        const u64 slot = (w << 6) + lane;
-        const u64 tag = table[slot].tag;
-        const u64 prev = table[((w << 6) + cap - 1) & (cap - 1)].tag;  // (every lane the same address)
-        const u64 empty = __ballot(tag == TAG_EMPTY);
-        const u64 st = ~empty & ((empty << 1) | (prev == TAG_EMPTY ? 1ull : 0ull));
-        if (lane == 0) starts[w] = st;
-    }
+constexpr u32 CSEG_LOG2 = 12;   // slots per segment (one wave)
+constexpr u32 CWIN_EXTRA = 16;  // look-ahead slots of the LDS window
+
+__global__ __launch_bounds__(256) void k_compact_bounds(const Cell* __restrict__ table, u64 cap, u64* __restrict__ bounds,
+                                                        u32 n_seg) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_seg) return;
+    u64 s = (u64)w << CSEG_LOG2;  // (absolute: may run past the segment, past the table's end for the last ones)
+    for (u64 k = 0; k < cap && table[s & (cap - 1)].tag != TAG_EMPTY; ++k) ++s;
+    bounds[w] = s;
 }
 
-__global__ __launch_bounds__(256) void k_compact_shift(Cell* table, u32 log2cap, u64 seed,
-                                                       const u64* __restrict__ starts, Status* st, u32 count) {
+// What a slot holds, as the walks need it: EMPTY, a tombstone, or a live cell's distance from its home — computed by
+// all 64 lanes at once (the hash of the key is most of a walk's arithmetic, and a walk runs on the few lanes whose slot
+// starts a cluster).
+constexpr u32 CCODE_EMPTY = 0xFFFFFFFFu, CCODE_TOMB = 0xFFFFFFFEu;
+__device__ __forceinline__ u32 compact_code(u64 tag, u64 slot, u64 seed, u32 log2cap, u32 mask) {
+    return tag == TAG_EMPTY ? CCODE_EMPTY : tag == TAG_TOMB ? CCODE_TOMB : (((u32)slot - slot_of(tag, seed, log2cap)) & mask);
+}
+
+__global__ __launch_bounds__(256) void k_compact_seg(Cell* table, u32 log2cap, u64 seed, const u64* __restrict__ bounds,
+                                                     u32 n_seg, Status* st, u32 count) {
+    __shared__ uint4 s_win[4][(64 + CWIN_EXTRA) * 2];
+    __shared__ u32 s_code[4][64 + CWIN_EXTRA];
     const u64 cap = 1ull << log2cap;
     const u32 mask = (u32)(cap - 1);
-    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    u32 live = 0;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 gw = blockIdx.x * 4u + wv;
     const uint4 e0 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u), z0 = make_uint4(0u, 0u, 0u, 0u);
-    auto cell = [&](u32 rel_slot) { return reinterpret_cast<uint4*>(&table[rel_slot & mask]); };
-    for (u64 s = gid; s < cap; s += stride) {
-        if (!((starts[s >> 6] >> (s & 63u)) & 1ull)) continue;
-        const u32 a = (u32)s;
-        u64 freem = 0;  // bit q: slot a + q (q < 64) holds nothing final
-        u32 d = 0;
-        bool ended = false;
-        // the first 64 slots, four at a time (the slots ahead of the walk are never written by it, so they may be read early;
-        // what lies behind the cluster's EMPTY slot is read and ignored)
-        while (d < 64 && !ended) {
-            uint4 ca[4], cb[4];
-#pragma unroll
-            for (u32 j = 0; j < 4; ++j) {
-                const uint4* p = cell(a + d + j);
-                ca[j] = p[0];
-                cb[j] = p[1];
+    auto cell = [&](u64 slot) { return reinterpret_cast<uint4*>(&table[(u32)slot & mask]); };
+    u32 live = 0;
+    if (gw < n_seg) {
+        const u64 lo = bounds[gw], hi = gw + 1 < n_seg ? bounds[gw + 1] : bounds[0] + cap;
+        uint4* win = s_win[wv];
+        u32* code = s_code[wv];
+        u64 carry_end = lo;   // everything up to here is final (slot carry_end itself is an EMPTY slot of the unmodified table)
+        bool prev_ne = false;  // the slot before this step's first one was non-empty when it was loaded
+        uint4 a0 = z0, a1 = z0, x0 = z0, x1 = z0;
+        if (lo + 1 < hi) {
+            const uint4* p = cell(lo + 1 + lane);
+            a0 = p[0];
+            a1 = p[1];
+            if (lane < CWIN_EXTRA) {
+                const uint4* px = cell(lo + 1 + 64 + lane);
+                x0 = px[0];
+                x1 = px[1];
             }
-#pragma unroll
-            for (u32 j = 0; j < 4; ++j) {
-                if (ended) break;
-                const u64 tag = ((u64)ca[j].y << 32) | ca[j].x;
-                if (tag == TAG_EMPTY) {
-                    ended = true;
-                    break;
-                }
-                const u32 dd = d + j;
-                if (tag == TAG_TOMB) {
-                    freem |= 1ull << dd;
-                    continue;
-                }
-                u32 hd = (slot_of(tag, seed, log2cap) - a) & mask;  // the home's distance from the cluster's start
-                if (hd > dd) hd = dd;  // (cannot happen in a well-formed table: never move a cell away from its home)
-                const u64 cand = (freem >> hd) << hd;
-                if (cand) {
-                    const u32 q = (u32)__builtin_ctzll(cand);
-                    uint4* t = cell(a + q);
-                    t[0] = ca[j];
-                    t[1] = cb[j];
-                    freem = (freem & ~(1ull << q)) | (1ull << dd);
-                }
-                ++live;
-            }
-            if (!ended) d += 4;
         }
-        for (u64 f = freem; f; f &= f - 1) {
-            uint4* z = cell(a + (u32)__builtin_ctzll(f));
-            z[0] = e0;
-            z[1] = z0;
-        }
-        if (ended) continue;
-        // a cluster of more than 64 slots: the table is the state from here on (free = EMPTY; this thread reads its own stores)
-        for (d = 64; d <= mask; ++d) {
-            uint4* p = cell(a + d);
-            const uint4 c0 = p[0];
-            const u64 tag = ((u64)c0.y << 32) | c0.x;
-            if (tag == TAG_EMPTY) break;
-            if (tag == TAG_TOMB) {
-                p[0] = e0;
-                p[1] = z0;
-                continue;
+        for (u64 base = lo + 1; base < hi; base += 64) {
+            __builtin_amdgcn_wave_barrier();  // (the walks of the step before have read the window)
+            const u64 slot = base + lane;
+            const u64 own_tag = ((u64)a0.y << 32) | a0.x;
+            win[2 * lane] = a0;
+            win[2 * lane + 1] = a1;
+            code[lane] = compact_code(own_tag, slot, seed, log2cap, mask);
+            if (lane < CWIN_EXTRA) {
+                win[2 * (64 + lane)] = x0;
+                win[2 * (64 + lane) + 1] = x1;
+                code[64 + lane] = compact_code(((u64)x0.y << 32) | x0.x, slot + 64, seed, log2cap, mask);
             }
-            const uint4 c1 = p[1];
-            u32 q = (slot_of(tag, seed, log2cap) - a) & mask;
-            if (q > d) q = d;
-            for (; q < d; ++q) {
-                const uint4 t0 = *cell(a + q);
-                if ((((u64)t0.y << 32) | t0.x) == TAG_EMPTY) break;
+            if (base + 64 < hi) {  // the next step's cells, in flight while this step's clusters are rebuilt
+                const uint4* p = cell(base + 64 + lane);
+                a0 = p[0];
+                a1 = p[1];
+                if (lane < CWIN_EXTRA) {
+                    const uint4* px = cell(base + 128 + lane);
+                    x0 = px[0];
+                    x1 = px[1];
+                }
             }
-            if (q < d) {
-                uint4* t = cell(a + q);
-                t[0] = c0;
-                t[1] = c1;
-                p[0] = e0;
-                p[1] = z0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool ne = own_tag != TAG_EMPTY;
+            const u64 ne_mask = __ballot(ne);
+            const u64 tomb_mask = __ballot(own_tag == TAG_TOMB);
+            bool before_ne = lane ? ((ne_mask >> (lane - 1)) & 1ull) != 0 : prev_ne;
+            if (slot - 1 == carry_end) before_ne = false;
+            const bool start = ne && !before_ne && slot > carry_end && slot < hi;
+            u64 end = 0;
+            bool walk = start;
+            if (start) {
+                // a cluster that ends inside these 64 slots and holds no tombstone stays as it is
+                const u64 rest = ~ne_mask >> lane;
+                if (rest) {
+                    const u32 len = (u32)__builtin_ctzll(rest);
+                    if (!((tomb_mask >> lane) & ((1ull << len) - 1ull))) {
+                        live += len;
+                        end = slot + len;
+                        walk = false;
+                    }
+                }
             }
-            ++live;
+            if (walk) {
+                auto rd_code = [&](u64 sl) {
+                    const u64 r = sl - base;
+                    if (r < 64 + CWIN_EXTRA) return code[r];
+                    const uint4 c0 = *cell(sl);
+                    return compact_code(((u64)c0.y << 32) | c0.x, sl, seed, log2cap, mask);
+                };
+                auto rd = [&](u64 sl, uint4& c0, uint4& c1) {
+                    const u64 r = sl - base;
+                    if (r < 64 + CWIN_EXTRA) {
+                        c0 = win[2 * r];
+                        c1 = win[2 * r + 1];
+                    } else {
+                        const uint4* p = cell(sl);
+                        c0 = p[0];
+                        c1 = p[1];
+                    }
+                };
+                const u64 a = slot;
+                u64 freem = 0;  // bit q: slot a + q (q < 64) holds nothing final
+                u32 d = 0;
+                bool ended = false;
+                for (; d < 64; ++d) {
+                    const u32 cd = rd_code(a + d);
+                    if (cd == CCODE_EMPTY) {
+                        ended = true;
+                        break;
+                    }
+                    if (cd == CCODE_TOMB) {
+                        freem |= 1ull << d;
+                        continue;
+                    }
+                    const u32 hd = cd > d ? 0u : d - cd;  // the home's distance from the cluster's start (cd > d cannot happen
+                                                          // in a well-formed table: the home lies inside the cluster)
+                    const u64 cand = (freem >> hd) << hd;
+                    if (cand) {
+                        const u32 q = (u32)__builtin_ctzll(cand);
+                        uint4 c0, c1;
+                        rd(a + d, c0, c1);
+                        uint4* t = cell(a + q);
+                        t[0] = c0;
+                        t[1] = c1;
+                        freem = (freem & ~(1ull << q)) | (1ull << d);
+                    }
+                    ++live;
+                }
+                for (u64 f = freem; f; f &= f - 1) {
+                    uint4* z = cell(a + (u32)__builtin_ctzll(f));
+                    z[0] = e0;
+                    z[1] = z0;
+                }
+                if (!ended) {
+                    // a cluster of more than 64 slots: the table is the state from here on
+                    for (; d <= mask; ++d) {
+                        const u32 cd = rd_code(a + d);
+                        if (cd == CCODE_EMPTY) break;
+                        uint4* p = cell(a + d);
+                        if (cd == CCODE_TOMB) {
+                            p[0] = e0;
+                            p[1] = z0;
+                            continue;
+                        }
+                        u32 q = cd > d ? 0u : d - cd;
+                        for (; q < d; ++q) {
+                            const uint4 t0 = *cell(a + q);
+                            if ((((u64)t0.y << 32) | t0.x) == TAG_EMPTY) break;
+                        }
+                        if (q < d) {
+                            uint4 c0, c1;
+                            rd(a + d, c0, c1);
+                            uint4* t = cell(a + q);
+                            t[0] = c0;
+                            t[1] = c1;
+                            p[0] = e0;
+                            p[1] = z0;
+                        }
+                        ++live;
+                    }
+                }
+                end = a + d;
+            }
+            const u64 smask = __ballot(start);
+            if (smask) {
+                const int top = 63 - __builtin_clzll(smask);  // clusters are disjoint and in order: the last start ends last
+                const u32 elo = __shfl((u32)end, top), ehi = __shfl((u32)(end >> 32), top);
+                carry_end = ((u64)ehi << 32) | elo;
+            }
+            prev_ne = (ne_mask >> 63) & 1ull;
         }
     }
     if (!count) return;
@@ -379,7 +465,7 @@ __global__ __launch_bounds__(256) void k_compact_shift(Cell* table, u32 log2cap,
     if (threadIdx.x == 0) s_live = 0;
     __syncthreads();
     for (int off = 32; off > 0; off >>= 1) live += __shfl_down(live, off);
-    if ((threadIdx.x & 63u) == 0 && live) atomicAdd(&s_live, live);
+    if (lane == 0 && live) atomicAdd(&s_live, live);
     __syncthreads();
     if (threadIdx.x == 0 && s_live) atomicAdd(&st->n_inserted, s_live);
 }
