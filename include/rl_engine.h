@@ -49,7 +49,8 @@ typedef enum {
     RL_ERR_KEY_LIMIT = -6,      /* a hit's limit id differs from the one stored with its key */
     RL_ERR_BATCH_TOO_LARGE = -7,
     RL_ERR_NOMEM = -8,
-    RL_ERR_BUSY = -9            /* batches are in flight (rl_check_and_update_submit_device): collect them first */
+    RL_ERR_BUSY = -9,           /* batches are in flight (rl_check_and_update_submit_device): collect them first */
+    RL_ERR_KEY_COLLISION = -10  /* hashed keys (rl_wire_*): two counters share a 64-bit key; nothing was applied */
 } rl_status;
 
 /* bit 31 of a limit id marks a counter of a limit WITHOUT variables ("simple", the
@@ -339,6 +340,40 @@ int32_t rl_match_and_check_batch_device(rl_engine *e, const uint32_t *d_req_ns, 
                                         const uint32_t *d_req_delta, uint32_t n_req, uint64_t now_us,
                                         int32_t load_counters, uint8_t *d_verdict, int32_t *d_limited_limit,
                                         uint32_t *n_hits_out);
+
+/* ---- the wire path without host dictionaries (limitador_amd/csrc/rl_wire.hpp; row f1 of SURVEY.md 8) ------------------
+ * Serialized envoy.service.ratelimit.v3.RateLimitRequest messages are decoded ON THE DEVICE (what ShouldRateLimit does
+ * per call, envoy_rls/server.rs:97-137), matched against the table of rl_match_table_set (lib.rs:507-522), and every
+ * counter is keyed by a hash of its CANONICAL KEY BYTES (storage/keys.rs:220-248) — include/rl_keyhash.h says which
+ * bytes, which hash, and how a collision of two 64-bit keys is detected (the cell's 32-bit check word) instead of
+ * merged.  Strings the TABLE names are compared byte by byte on the device; the host keeps no per-request state.
+ *
+ * rl_wire_table_set: the strings behind the ids of the installed match table (call after rl_match_table_set; the table
+ * must have the slot form: at most 8 distinct descriptor keys, 64 limits per namespace) — all inside `blob`
+ * (<= 8192 bytes): ns[namespace id] (ns[0] is the namespace without limits), keys[key id], vals[value id] for every id
+ * the conditions use (<= 512), and limit_prefix[2 * limit id ..] = rl_kh_bytes of the limit's canonical prefix. */
+typedef struct {
+    uint32_t off, len; /* a string: blob[off .. off + len) */
+} rl_wire_str;
+int32_t rl_wire_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, const rl_wire_str *ns, uint32_t n_ns,
+                          const rl_wire_str *keys, uint32_t n_keys, const rl_wire_str *vals, uint32_t n_vals,
+                          const uint64_t *limit_prefix, uint32_t n_limits);
+/* counters_that_apply + check_and_update for n messages, applied in index order with one clock value: message i is
+ * wire[msg_off[i] .. msg_off[i + 1]) (host pointers; msg_off[0] = 0).  Out, per message: status[i] = 0, or
+ * -101 (no domain: Code::Unknown, envoy_rls/server.rs:105-115; the message derives no counter) or RL_ERR_INVALID
+ * (malformed: no counter); verdict[i]; limited_limit[i] (may be NULL); the derived counters as in
+ * rl_match_and_check_batch.  Returns RL_ERR_KEY_COLLISION when two counters of the batch, or a counter of the batch and
+ * a stored one, share a 64-bit key with different check words: NOTHING was applied and *collided_message is the index
+ * of a message that derives one of them — the caller answers that message on its exact path (or drops it) and calls
+ * again without it. */
+/* A pinned host buffer of at least `bytes` bytes that belongs to the engine (grown on demand, freed with it; a later call
+ * may move it): where a caller builds `wire` / `msg_off` so that the copies to the device are plain DMA. */
+int32_t rl_wire_staging(rl_engine *e, uint64_t bytes, void **out);
+int32_t rl_wire_match_and_check_batch(rl_engine *e, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
+                                      uint64_t now_us, int32_t load_counters, uint8_t *verdict, int32_t *limited_limit,
+                                      int32_t *status, uint32_t *req_off_out, rl_hit *hits_out, uint32_t hits_cap,
+                                      uint32_t *n_hits_out, uint64_t *remaining, uint64_t *expires_in_us,
+                                      int64_t *collided_message);
 
 /* ---- the general resolver in phases: admission decided by the host ----------------------- */
 /* For requests whose counters live on SEVERAL engines (key-sharded multi-counter requests): the per-request AND

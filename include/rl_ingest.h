@@ -84,6 +84,25 @@ int32_t rli_batch_add_rls(rli_ingest *g, const uint8_t *msg, uint32_t len);
 #define RLI_BIND_DESCRIPTORS 0
 #define RLI_BIND_ROOT 1
 int32_t rli_set_binding(rli_ingest *g, int32_t binding);
+/* How counters are keyed, before the first request (default RLI_KEYS_EXACT):
+ *   RLI_KEYS_EXACT   the host interns every namespace / key / value string (exact dictionaries under a reader-writer
+ *                    lock) and the device packs ids into an injective 64-bit key (rl_match_key);
+ *   RLI_KEYS_HASHED  the host keeps NO per-request state: rli_serve_batch hands the serialized messages to the device,
+ *                    which decodes them, compares the strings the limits name byte by byte, and keys every counter by
+ *                    a hash of its canonical key bytes (storage/keys.rs:220-248; include/rl_keyhash.h says which bytes,
+ *                    which hash, and the odds).  The 64-bit key addresses the cell, a 32-bit check word stored with the
+ *                    cell is compared on every touch: two counters that share a key are never merged — the message
+ *                    that derives the second one is answered RLI_HOST_ONLY (nothing of it is applied; the other messages
+ *                    of the batch are).  Needs the slot form of the match table (<= 8 distinct descriptor keys, <= 64
+ *                    limits per namespace, <= 512 condition literals, <= 8 KB of table strings): rli_install answers
+ *                    RLI_HOST_ONLY otherwise.  rli_batch_add* / rli_check stay dictionary calls (RLI_KEYS_EXACT only). */
+#define RLI_KEYS_EXACT 0
+#define RLI_KEYS_HASHED 1
+int32_t rli_set_key_mode(rli_ingest *g, int32_t mode);
+/* The key (and check word) RLI_KEYS_HASHED gives the counter of `limit_id` with these variable values (in variable-name
+ * order; n_values = the limit's number of variables): what rl_get_counters / rl_dump_cells rows of that mode carry. */
+int32_t rli_counter_key(rli_ingest *g, uint32_t limit_id, const char *const *values, const uint32_t *value_lens,
+                        uint32_t n_values, uint64_t *key, uint32_t *check);
 /* Most distinct descriptor values the dictionary may hold (default 2^24, at most 2^26: value ids travel in 26
  * bits).  At the cap a request that carries a value never seen before answers RLI_HOST_ONLY (nothing is added;
  * requests made of known values go on): descriptor values are caller-controlled and must not grow host state

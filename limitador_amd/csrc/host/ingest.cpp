@@ -8,6 +8,7 @@
 // The predicate shapes are the ones rl_match.hpp evaluates; anything else is CEL and stays with the
 // caller (RLI_HOST_ONLY).
 #include "../../../include/rl_ingest.h"
+#include "../../../include/rl_keyhash.h"
 
 #include <algorithm>
 #include <atomic>
@@ -243,6 +244,10 @@ struct rli_ingest {
     int binding = RLI_BIND_DESCRIPTORS;  // rli_set_binding
     uint32_t n_ns_installed = 0;     // namespaces the installed match table knows (ids beyond it: no limits)
     uint32_t value_cap = 1u << 24;   // most distinct descriptor values the dictionary takes (rli_set_value_cap)
+    // RLI_KEYS_HASHED (rli_set_key_mode): no request ever touches the dictionaries — the device decodes the messages,
+    // compares the table's strings as bytes and keys every counter by a hash of its canonical key bytes (rl_keyhash.h)
+    int key_mode = RLI_KEYS_EXACT;
+    std::vector<rl_h128> prefix;     // [limit id]: hash of the limit's canonical prefix (compiled)
     // batch
     std::vector<uint32_t> req_ns, req_delta, ent_off{0}, ent_key, ent_val;
     std::string err;
@@ -435,13 +440,41 @@ int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_
     return (int32_t)id;
 }
 
+
+// The canonical key bytes of a counter WITHOUT its variables' values (include/rl_keyhash.h; storage/keys.rs:220-248:
+// version byte 1 + postcard of CounterKey { ns, seconds, conditions (sorted), variables (sorted by name) }).
+static void pc_varint(std::string& o, uint64_t v) {
+    while (v >= 0x80) {
+        o.push_back((char)(v | 0x80));
+        v >>= 7;
+    }
+    o.push_back((char)v);
+}
+static void pc_str(std::string& o, const std::string& s) {
+    pc_varint(o, s.size());
+    o += s;
+}
+static rl_h128 canonical_prefix_hash(const LimitSpec& L) {
+    std::string o;
+    o.push_back((char)1);
+    pc_str(o, L.ns);
+    pc_varint(o, L.seconds);
+    pc_varint(o, L.cond_src.size());
+    for (const std::string& c : L.cond_src) pc_str(o, c);  // (std::set order = Vec<String>::sort: bytewise)
+    pc_varint(o, L.var_src.size());
+    for (const std::string& v : L.var_src) pc_str(o, v);
+    return rl_kh_bytes(reinterpret_cast<const uint8_t*>(o.data()), (uint32_t)o.size(), 0ull);
+}
+
 int32_t rli_compile(rli_ingest* g) {
     if (!g) return RL_ERR_INVALID;
     const uint32_t n = (uint32_t)g->limits.size();
     g->rows.assign(n, rl_limit_row{0, 0});
+    g->prefix.assign(n, rl_h128{0, 0});
     std::vector<uint32_t> order(n), ns_of(n);
     for (uint32_t i = 0; i < n; ++i) {
         g->rows[i] = rl_limit_row{g->limits[i].max_value, g->limits[i].seconds};
+        g->prefix[i] = canonical_prefix_hash(g->limits[i]);
         ns_of[i] = g->ns_ids.intern(g->limits[i].ns);
         order[i] = i;
     }
@@ -487,11 +520,59 @@ int32_t rli_install(rli_ingest* g, rl_engine* e) {
                             (uint32_t)g->ns_ids.ids.size());
     if (rc) return gfail(g, rc, "rl_match_table_set: %s", rl_last_error(e));
     g->n_ns_installed = (uint32_t)g->ns_ids.ids.size();
+    if (g->key_mode == RLI_KEYS_HASHED) {
+        // the strings behind the table's ids, for the device to compare bytes against (rl_wire_table_set)
+        std::vector<uint8_t> blob;
+        auto strs_of = [&](const Dictionary& d) {
+            std::vector<rl_wire_str> v(d.ids.size(), rl_wire_str{0, 0});
+            for (const auto& kv : d.ids) {
+                v[kv.second] = rl_wire_str{(uint32_t)blob.size(), (uint32_t)kv.first.size()};
+                blob.insert(blob.end(), kv.first.begin(), kv.first.end());
+            }
+            return v;
+        };
+        const std::vector<rl_wire_str> ns = strs_of(g->ns_ids), keys = strs_of(g->key_ids), vals = strs_of(g->val_ids);
+        std::vector<uint64_t> pre(2 * g->prefix.size() + 2, 0);
+        for (size_t i = 0; i < g->prefix.size(); ++i) {
+            pre[2 * i] = g->prefix[i].h1;
+            pre[2 * i + 1] = g->prefix[i].h2;
+        }
+        rc = rl_wire_table_set(e, blob.data(), (uint32_t)blob.size(), ns.data(), (uint32_t)ns.size(), keys.data(), (uint32_t)keys.size(),
+                               vals.data(), (uint32_t)vals.size(), pre.data(), (uint32_t)g->prefix.size());
+        if (rc) return gfail(g, rc == RL_ERR_INVALID ? RLI_HOST_ONLY : rc, "rl_wire_table_set: %s", rl_last_error(e));
+    }
     for (uint32_t id = 0; id < g->limits.size(); ++id)
         if (g->limits[id].vars.empty()) {  // add_counter, in_memory.rs:38-44: limits without variables only
-            rc = rl_add_counter(e, id | RL_SIMPLE, rl_match_key(id, 0, 0, 0));
+            uint64_t key = rl_match_key(id, 0, 0, 0);
+            uint32_t chk = 0;
+            if (g->key_mode == RLI_KEYS_HASHED) rl_counter_key(g->prefix[id], nullptr, 0, &key, &chk);
+            rc = rl_add_counter(e, id | RL_SIMPLE, key);
             if (rc) return gfail(g, rc, "rl_add_counter: %s", rl_last_error(e));
         }
+    return RL_OK;
+}
+
+int32_t rli_set_key_mode(rli_ingest* g, int32_t mode) {
+    if (!g || (mode != RLI_KEYS_EXACT && mode != RLI_KEYS_HASHED)) return RL_ERR_INVALID;
+    if (!g->req_ns.empty()) return gfail(g, RL_ERR_INVALID, "the key mode is chosen before the first request is added");
+    g->key_mode = mode;
+    return RL_OK;
+}
+
+int32_t rli_counter_key(rli_ingest* g, uint32_t limit_id, const char* const* values, const uint32_t* value_lens,
+                        uint32_t n_values, uint64_t* key, uint32_t* check) {
+    if (!g || !key || limit_id >= g->limits.size() || (n_values && (!values || !value_lens))) return RL_ERR_INVALID;
+    if (!g->compiled) {
+        const int32_t rc = rli_compile(g);
+        if (rc) return rc;
+    }
+    if (n_values != g->limits[limit_id].vars.size() || n_values > 2)
+        return gfail(g, RL_ERR_INVALID, "limit %u has %zu variables", limit_id, g->limits[limit_id].vars.size());
+    rl_h128 v[2];
+    for (uint32_t q = 0; q < n_values; ++q) v[q] = rl_kh_bytes(reinterpret_cast<const uint8_t*>(values[q]), value_lens[q], 0ull);
+    uint32_t chk = 0;
+    rl_counter_key(g->prefix[limit_id], v, n_values, key, &chk);
+    if (check) *check = chk;
     return RL_OK;
 }
 
@@ -586,6 +667,8 @@ static int32_t batch_append(rli_ingest* g, const EncReq& r) {
 
 static int32_t batch_add_sv(rli_ingest* g, const std::string& ns, const std::vector<std::pair<std::string, std::string>>& entries,
                             uint32_t delta) {
+    if (g->key_mode == RLI_KEYS_HASHED)
+        return gfail(g, RL_ERR_INVALID, "rli_batch_add* builds dictionary-encoded requests: RLI_KEYS_EXACT only (RLI_KEYS_HASHED: rli_serve_batch)");
     EncReq r;
     const int32_t rc = encode_request(g, ns, entries, delta, &r);
     if (rc == RLI_HOST_ONLY)
@@ -758,104 +841,171 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
             std::fprintf(stderr, "[rli] %-10s at %8.1f us\n", what,
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    // ---- decode + dictionary encoding: every message on its own, many at a time.  A thread keeps the encoded entries
-    //      of its share of the messages in ONE flat list (no allocation per request) ------------------------------
-    struct EncSlot {
-        uint32_t ns, delta, kv_off, kv_cnt;
-    };
-    std::vector<EncSlot> enc(n);
-    const uint32_t per = threads > 1 ? (n + threads - 1) / threads : n;
-    const uint32_t n_chunks = per ? (n + per - 1) / per : 0;
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> chunk_kv(n_chunks ? n_chunks : 1);
-    std::vector<uint32_t> chunk_req(n_chunks + 1, 0), chunk_ent(n_chunks + 1, 0);
-    parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
-        std::string domain;
-        std::vector<std::pair<std::string, std::string>> entries;
-        EncReq tmp;
-        auto& flat = chunk_kv[lo / per];
-        flat.reserve((size_t)(hi - lo) * 4);
-        uint32_t n_ok = 0;
-        std::shared_lock<std::shared_mutex> rd(g->dict_mu);
-        for (uint32_t i = lo; i < hi; ++i) {
-            if (((i - lo) & 255u) == 255u) {  // let a thread that has a new value to intern get its turn
-                rd.unlock();
-                rd.lock();
-            }
-            domain.clear();
-            entries.clear();
-            uint32_t delta = 1;
-            const char* what = "";
-            int32_t rc = (lens[i] && !msgs[i]) ? (int32_t)RL_ERR_INVALID : decode_rls(msgs[i], lens[i], &domain, &entries, &delta, &what);
-            if (rc == 0) rc = encode_request(g, domain, entries, delta, &tmp, &rd);
-            if (rc == 0) {
-                enc[i] = EncSlot{tmp.ns, tmp.delta, (uint32_t)flat.size(), (uint32_t)tmp.kv.size()};
-                flat.insert(flat.end(), tmp.kv.begin(), tmp.kv.end());
-                ++n_ok;
-            }
-            status[i] = rc;  // 0, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY, < 0
-            out_len[i] = 0;
-        }
-        chunk_req[lo / per + 1] = n_ok;
-        chunk_ent[lo / per + 1] = (uint32_t)flat.size();
-    });
-    lap("decoded");
-    // ---- the batch, in message order: every thread's share lands at its offset --------------------------------
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-        chunk_req[c + 1] += chunk_req[c];
-        chunk_ent[c + 1] += chunk_ent[c];
-    }
     std::vector<int32_t> req_of(n, -1);
-    g->req_ns.resize(chunk_req[n_chunks]);
-    g->req_delta.resize(chunk_req[n_chunks]);
-    g->ent_off.resize((size_t)chunk_req[n_chunks] + 1);
-    g->ent_key.resize(chunk_ent[n_chunks]);
-    g->ent_val.resize(chunk_ent[n_chunks]);
-    g->ent_off[0] = 0;
-    parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
-        const uint32_t c = lo / per;
-        const auto& flat = chunk_kv[c];
-        uint32_t r = chunk_req[c];
-        const uint32_t e0 = chunk_ent[c];
-        for (uint32_t i = lo; i < hi; ++i) {
-            if (status[i] != 0) continue;
-            const EncSlot& q = enc[i];
-            g->req_ns[r] = q.ns;
-            g->req_delta[r] = q.delta;
-            for (uint32_t k = 0; k < q.kv_cnt; ++k) {
-                g->ent_key[e0 + q.kv_off + k] = flat[q.kv_off + k].first;
-                g->ent_val[e0 + q.kv_off + k] = flat[q.kv_off + k].second;
-            }
-            g->ent_off[r + 1] = e0 + q.kv_off + q.kv_cnt;
-            req_of[i] = (int32_t)r++;
-        }
-    });
-    const uint32_t n_req = (uint32_t)g->req_ns.size();
-    lap("appended");
-    std::vector<uint8_t> verdict(n_req ? n_req : 1);
-    std::vector<int32_t> limited(n_req ? n_req : 1);
-    std::vector<uint32_t> req_off(n_req + 1, 0);
+    std::vector<uint8_t> verdict;
+    std::vector<int32_t> limited;
+    std::vector<uint32_t> req_off;
     std::unique_ptr<rl_hit[]> hits;  // (new T[n]: no zero fill — tens of megabytes per call otherwise)
     std::unique_ptr<uint64_t[]> rem, exp;
-    if (n_req) {
-        uint32_t n_hits = 0;
-        // every request derives at most one counter per limit of its namespace
-        size_t per_ns = 1;
-        {
-            std::map<std::string, size_t> cnt;
-            for (const auto& L : g->limits) per_ns = std::max(per_ns, ++cnt[L.ns]);
-        }
-        const size_t cap = with_headers ? (size_t)n_req * per_ns : 0;
+    uint32_t n_req = 0;
+    // every request derives at most one counter per limit of its namespace
+    size_t per_ns = 1;
+    {
+        std::map<std::string, size_t> cnt;
+        for (const auto& L : g->limits) per_ns = std::max(per_ns, ++cnt[L.ns]);
+    }
+    if (g->key_mode == RLI_KEYS_HASHED) {
+        // ---- no decoding, no dictionaries: the messages are concatenated (into a buffer pinned in place once) and the
+        //      device does the rest — protobuf walk, byte comparison with the table's strings, hashed counter keys
+        //      (rl_wire.hpp).  Message i IS request i; a message the device finds malformed / without a domain derives no
+        //      counter and carries its status.
+        std::vector<uint8_t> skip(n, 0);  // messages taken out after a key collision: answered RLI_HOST_ONLY
+        n_req = n;
+        verdict.resize(n);
+        limited.resize(n);
+        req_off.assign((size_t)n + 1, 0);
+        std::vector<int32_t> dev_status(n);
+        const size_t cap = with_headers ? (size_t)n * per_ns : 0;
         if (with_headers) {
             hits.reset(new rl_hit[cap]);
             rem.reset(new uint64_t[cap]);
             exp.reset(new uint64_t[cap]);
         }
-        const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
-                                                    g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict.data(),
-                                                    limited.data(), with_headers ? req_off.data() : nullptr,
-                                                    with_headers ? hits.get() : nullptr, (uint32_t)cap, &n_hits,
-                                                    with_headers ? rem.get() : nullptr, with_headers ? exp.get() : nullptr);
-        if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
+        uint64_t sum = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (lens[i] && !msgs[i]) return gfail(g, RL_ERR_INVALID, "message %u: null pointer with length %u", i, lens[i]);
+            sum += lens[i];
+        }
+        if (sum > 0xFFFFFFFFull - 64) return gfail(g, RL_ERR_BATCH_TOO_LARGE, "the messages take %llu bytes", (unsigned long long)sum);
+        // offsets and bytes live in the ENGINE's pinned staging (rl_wire_staging: the copies to the device are plain DMA)
+        const size_t off_bytes = (((size_t)n + 1) * sizeof(uint32_t) + 63) & ~(size_t)63;
+        void* stage = nullptr;
+        int32_t src = rl_wire_staging(e, off_bytes + sum + 64, &stage);
+        if (src) return gfail(g, src, "rl_wire_staging: %s", rl_last_error(e));
+        uint32_t* w_off = static_cast<uint32_t*>(stage);
+        uint8_t* w_bytes = static_cast<uint8_t*>(stage) + off_bytes;
+        for (int attempt = 0;; ++attempt) {
+            uint64_t total = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                w_off[i] = (uint32_t)total;
+                total += skip[i] ? 0u : lens[i];
+            }
+            w_off[n] = (uint32_t)total;
+            parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
+                for (uint32_t i = lo; i < hi; ++i)
+                    if (!skip[i] && lens[i]) memcpy(w_bytes + w_off[i], msgs[i], lens[i]);
+            });
+            if (attempt == 0) lap("packed");
+            uint32_t n_hits = 0;
+            int64_t collided = -1;
+            const int32_t rc = rl_wire_match_and_check_batch(e, w_bytes, w_off, n, now_us, with_headers ? 1 : 0,
+                                                             verdict.data(), limited.data(), dev_status.data(),
+                                                             with_headers ? req_off.data() : nullptr, with_headers ? hits.get() : nullptr,
+                                                             (uint32_t)cap, &n_hits, with_headers ? rem.get() : nullptr,
+                                                             with_headers ? exp.get() : nullptr, &collided);
+            if (rc == RL_ERR_KEY_COLLISION && collided >= 0 && (uint64_t)collided < n && !skip[collided] && attempt < 64) {
+                skip[collided] = 1;  // its counter shares a 64-bit key with another one: never merged — the caller's exact path
+                continue;
+            }
+            if (rc) return gfail(g, rc, "rl_wire_match_and_check_batch: %s", rl_last_error(e));
+            break;
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            status[i] = skip[i] ? (int32_t)RLI_HOST_ONLY : dev_status[i];
+            out_len[i] = 0;
+            req_of[i] = status[i] == 0 ? (int32_t)i : -1;
+        }
+    } else {
+        // ---- decode + dictionary encoding: every message on its own, many at a time.  A thread keeps the encoded entries
+        //      of its share of the messages in ONE flat list (no allocation per request) ------------------------------
+        struct EncSlot {
+            uint32_t ns, delta, kv_off, kv_cnt;
+        };
+        std::vector<EncSlot> enc(n);
+        const uint32_t per = threads > 1 ? (n + threads - 1) / threads : n;
+        const uint32_t n_chunks = per ? (n + per - 1) / per : 0;
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> chunk_kv(n_chunks ? n_chunks : 1);
+        std::vector<uint32_t> chunk_req(n_chunks + 1, 0), chunk_ent(n_chunks + 1, 0);
+        parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
+            std::string domain;
+            std::vector<std::pair<std::string, std::string>> entries;
+            EncReq tmp;
+            auto& flat = chunk_kv[lo / per];
+            flat.reserve((size_t)(hi - lo) * 4);
+            uint32_t n_ok = 0;
+            std::shared_lock<std::shared_mutex> rd(g->dict_mu);
+            for (uint32_t i = lo; i < hi; ++i) {
+                if (((i - lo) & 255u) == 255u) {  // let a thread that has a new value to intern get its turn
+                    rd.unlock();
+                    rd.lock();
+                }
+                domain.clear();
+                entries.clear();
+                uint32_t delta = 1;
+                const char* what = "";
+                int32_t rc = (lens[i] && !msgs[i]) ? (int32_t)RL_ERR_INVALID : decode_rls(msgs[i], lens[i], &domain, &entries, &delta, &what);
+                if (rc == 0) rc = encode_request(g, domain, entries, delta, &tmp, &rd);
+                if (rc == 0) {
+                    enc[i] = EncSlot{tmp.ns, tmp.delta, (uint32_t)flat.size(), (uint32_t)tmp.kv.size()};
+                    flat.insert(flat.end(), tmp.kv.begin(), tmp.kv.end());
+                    ++n_ok;
+                }
+                status[i] = rc;  // 0, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY, < 0
+                out_len[i] = 0;
+            }
+            chunk_req[lo / per + 1] = n_ok;
+            chunk_ent[lo / per + 1] = (uint32_t)flat.size();
+        });
+        lap("decoded");
+        // ---- the batch, in message order: every thread's share lands at its offset --------------------------------
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            chunk_req[c + 1] += chunk_req[c];
+            chunk_ent[c + 1] += chunk_ent[c];
+        }
+        g->req_ns.resize(chunk_req[n_chunks]);
+        g->req_delta.resize(chunk_req[n_chunks]);
+        g->ent_off.resize((size_t)chunk_req[n_chunks] + 1);
+        g->ent_key.resize(chunk_ent[n_chunks]);
+        g->ent_val.resize(chunk_ent[n_chunks]);
+        g->ent_off[0] = 0;
+        parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
+            const uint32_t c = lo / per;
+            const auto& flat = chunk_kv[c];
+            uint32_t r = chunk_req[c];
+            const uint32_t e0 = chunk_ent[c];
+            for (uint32_t i = lo; i < hi; ++i) {
+                if (status[i] != 0) continue;
+                const EncSlot& q = enc[i];
+                g->req_ns[r] = q.ns;
+                g->req_delta[r] = q.delta;
+                for (uint32_t k = 0; k < q.kv_cnt; ++k) {
+                    g->ent_key[e0 + q.kv_off + k] = flat[q.kv_off + k].first;
+                    g->ent_val[e0 + q.kv_off + k] = flat[q.kv_off + k].second;
+                }
+                g->ent_off[r + 1] = e0 + q.kv_off + q.kv_cnt;
+                req_of[i] = (int32_t)r++;
+            }
+        });
+        n_req = (uint32_t)g->req_ns.size();
+        lap("appended");
+        verdict.resize(n_req ? n_req : 1);
+        limited.resize(n_req ? n_req : 1);
+        req_off.assign(n_req + 1, 0);
+        if (n_req) {
+            uint32_t n_hits = 0;
+            const size_t cap = with_headers ? (size_t)n_req * per_ns : 0;
+            if (with_headers) {
+                hits.reset(new rl_hit[cap]);
+                rem.reset(new uint64_t[cap]);
+                exp.reset(new uint64_t[cap]);
+            }
+            const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
+                                                        g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict.data(),
+                                                        limited.data(), with_headers ? req_off.data() : nullptr,
+                                                        with_headers ? hits.get() : nullptr, (uint32_t)cap, &n_hits,
+                                                        with_headers ? rem.get() : nullptr, with_headers ? exp.get() : nullptr);
+            if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
+        }
     }
     lap("device");
     // ---- the responses: independent of one another ----------------------------------------------------------

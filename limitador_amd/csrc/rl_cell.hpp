@@ -24,7 +24,7 @@ struct alignas(32) Cell {
     u64 value;   //  8  AtomicExpiringValue.value                        }
     u64 expiry;  // 16  AtomicExpiringValue.expiry (us since epoch)      } one dwordx4
     u32 limit;   // 24  limit id | SIMPLE_FLAG (attribute of the cell)   }
-    u32 pad;     // 28  reserved (0)                                     }
+    u32 pad;     // 28  check word of a hashed key (rl_keyhash.h), 0 = none      }
 };
 static_assert(sizeof(Cell) == 32, "one cell = one 32-byte sector");
 
@@ -50,6 +50,7 @@ constexpr u32 ERRBIT_MISSING_SIMPLE = 2u;
 constexpr u32 ERRBIT_TABLE_FULL = 4u;
 constexpr u32 ERRBIT_KEY_LIMIT = 8u;
 constexpr u32 ERRBIT_RESERVED_KEY = 16u;
+constexpr u32 ERRBIT_KEY_COLLISION = 32u;  // two counters share a 64-bit key (hashed keys, include/rl_keyhash.h): their check words differ
 
 constexpr u32 MAX_BATCH_HITS = (1u << 24) - 1u;  // hit indices travel in 24 bits (BHit.idx_tag)
 

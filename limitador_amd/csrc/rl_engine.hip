@@ -28,6 +28,7 @@
 #include "rl_general.hpp"
 #include "rl_route.hpp"
 #include "rl_match.hpp"
+#include "rl_wire.hpp"
 
 using namespace rl;
 
@@ -247,6 +248,24 @@ struct rl_engine {
     MatchLimitF* d_match_flimits = nullptr;
     MatchCondF* d_match_fconds = nullptr;
     MatchSlots match_slots{};
+    u32 match_var_slots = 0;        // slots some limit of the fast table reads as a variable
+    u32 match_max_limit_id = 0;
+    // the wire path without host dictionaries (rl_wire.hpp): tables of rl_wire_table_set, staging of a batch of messages
+    bool wire_ready = false;
+    WireTables wire_t{};
+    uint8_t* d_w_blob = nullptr;
+    WireStr* d_w_ns = nullptr;
+    WireLit* d_w_lit = nullptr;
+    u64* d_w_prefix = nullptr;
+    uint8_t* d_w_bytes = nullptr;   // the messages of one batch, concatenated
+    u64 w_bytes_cap = 0;
+    u32* d_w_off = nullptr;         // [max_batch + 1]
+    int32_t* d_w_status = nullptr;  // [max_batch]
+    uint4* d_w_slot_h = nullptr;    // [max_batch][MATCH_SLOTS]: hashes of the values the variables read
+    u32* d_hit_check = nullptr;     // [max_batch]: the check word of every derived counter (rl_keyhash.h)
+    u32 collide_hit = 0;            // RL_ERR_KEY_COLLISION: a hit (index in the call) of the colliding pair
+    void* h_w_stage = nullptr;      // rl_wire_staging
+    u64 h_w_stage_cap = 0;
     unsigned long long* d_m_mask = nullptr;  // [max_batch] limits of its namespace that apply to a request
     u32* d_m_ns = nullptr;      // staging for host-pointer calls: per request namespace, delta
     u32* d_m_delta = nullptr;
@@ -334,6 +353,8 @@ int status_to_error(rl_engine* e, u32 bits) {
                     "simple counter without a pre-created cell (reference: in_memory.rs:107 unwrap panics)");
     if (bits & ERRBIT_TABLE_FULL) return fail(e, RL_ERR_TABLE_FULL, "counter table is full");
     if (bits & ERRBIT_KEY_LIMIT) return fail(e, RL_ERR_KEY_LIMIT, "a key was used with two different limit ids");
+    if (bits & ERRBIT_KEY_COLLISION)
+        return fail(e, RL_ERR_KEY_COLLISION, "two counters share a 64-bit key (their check words differ): nothing was applied");
     return fail(e, RL_ERR_DEVICE, "unknown device status 0x%x", bits);
 }
 
@@ -1099,6 +1120,7 @@ struct GenCall {
     const u32* d_hit_req_ext = nullptr;  // phased form: the caller's request id of every hit (any u32, equal = same request)
     bool hit_req_filled = false;         // e->d_hit_req already holds the request of every hit (k_match_fast wrote it)
     bool host_mapped_results = false;    // every result pointer is fine-grained host-mapped memory (rl_engine::h_tiny)
+    const u32* d_hit_check = nullptr;    // hashed keys: the check word of every hit (rl_keyhash.h), verified before the commit
 };
 
 // Partition of the pass's hits + k_gen_sort: everything up to the first fixpoint round.  A is filled for the kernels
@@ -1152,6 +1174,7 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     A.hit_req = c.d_hit_req_ext ? c.d_hit_req_ext : (c.d_req_off ? e->d_hit_req : nullptr);
     A.req_off = c.d_req_off;
     A.req_delta = c.d_req_delta;
+    A.hit_check = c.d_hit_check ? c.d_hit_check + hit0 : nullptr;
     A.hit0 = hit0;
     A.req0 = req0;
     A.n_hits = n;
@@ -1243,6 +1266,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     BatchScratch* bs = nullptr;
     rc = gen_setup_and_sort(e, c, req0, n_req, hit0, n, mark, A, &bs);
     if (rc) return rc;
+    if (A.hit_check) k_gen_check_keys<<<cdiv(n, 256), 256, 0, st>>>(A);  // (a collision refuses the pass: k_gen_commit reads gst->err)
     const u64 p = e->part_seq;
     // ---- fixpoint rounds: a few at a time, each returning at once if the one before changed nothing; then
     //      k_gen_commit, which applies the pass only if the status block says it is final and fits -------------
@@ -1325,6 +1349,11 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         if (mark) HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, st));
     }
     if (h_bst.err | h_gst.err) {
+        if (h_gst.err & ERRBIT_KEY_COLLISION) {  // which hit: the caller takes its request out and calls again
+            u32 cw = 0;
+            HIP_TRY(e, hipMemcpy(&cw, &e->d_gst->collide, sizeof(u32), hipMemcpyDeviceToHost));
+            e->collide_hit = hit0 + ~cw;
+        }
         rc = cleanup();
         return rc ? rc : status_to_error(e, h_bst.err | h_gst.err);  // nothing was applied
     }
@@ -1365,7 +1394,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
 }
 
 int run_check_general(rl_engine* e, const GenCall& c) {
-    if (c.n_hits && c.n_hits <= e->gen_tiny_max && c.n_req <= GT_MAX_REQ && !c.update_mode) {
+    if (c.n_hits && c.n_hits <= e->gen_tiny_max && c.n_req <= GT_MAX_REQ && !c.update_mode && !c.d_hit_check) {
         // A few requests (the per-request calls of the trait): one workgroup, one launch (k_gen_tiny),
         // completion through a sequence word in the host-mapped status block.
         int rc = check_room(e, c.n_hits);
@@ -1789,7 +1818,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_cmark, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_cmark, e->d_w_blob, e->d_w_ns, e->d_w_lit, e->d_w_prefix, e->d_w_bytes, e->d_w_off, e->d_w_status, e->d_w_slot_h, e->d_hit_check, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)
@@ -1799,6 +1828,7 @@ void rl_engine_destroy(rl_engine* e) {
     if (e->h_total) (void)hipHostFree(e->h_total);
     if (e->h_m_total) (void)hipHostFree(e->h_m_total);
     if (e->h_m_word) (void)hipHostFree(e->h_m_word);
+    if (e->h_w_stage) (void)hipHostFree(e->h_w_stage);
     if (e->h_serve) (void)hipHostFree(e->h_serve);
     if (e->h_gen_word) (void)hipHostFree(e->h_gen_word);
     if (e->d_m_scan1) (void)hipFree(e->d_m_scan1);
@@ -2672,6 +2702,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     std::vector<u32> ns_off(n_namespaces + 1, 0);
+    u32 max_id = 0;
     for (u32 i = 0; i < n_limits; ++i) {
         const rl_match_limit& L = limits[i];
         if (L.ns >= n_namespaces) return fail(e, RL_ERR_INVALID, "match limit %u: namespace id %u out of range", i, L.ns);
@@ -2681,7 +2712,9 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
         if (RL_LIMIT_ID(L.limit) >= e->h_limits.size() || RL_LIMIT_ID(L.limit) >= 4095u) return fail(e, RL_ERR_INVALID, "match limit %u: unknown limit id", i);
         if ((u64)L.cond_off + L.n_cond > n_conds) return fail(e, RL_ERR_INVALID, "match limit %u: conditions out of range", i);
         ns_off[L.ns + 1]++;
+        max_id = std::max<u32>(max_id, RL_LIMIT_ID(L.limit));
     }
+    e->match_max_limit_id = max_id;
     for (u32 n = 0; n < n_namespaces; ++n) ns_off[n + 1] += ns_off[n];
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->d_match_limits) (void)hipFree(e->d_match_limits);
@@ -2702,6 +2735,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
     e->n_match_conds = n_conds;
     // ---- the slot form, when the table has it (k_match_fast) ---------------------------------------------
     e->match_fast = false;
+    e->wire_ready = false;  // (the strings of rl_wire_table_set belong to the table that is being replaced)
     if (e->d_match_flimits) (void)hipFree(e->d_match_flimits);
     if (e->d_match_fconds) (void)hipFree(e->d_match_fconds);
     e->d_match_flimits = nullptr;
@@ -2709,6 +2743,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
     bool fast = n_limits && n_limits <= MATCH_LDS_LIMITS && n_conds <= MATCH_LDS_CONDS && n_namespaces <= MATCH_LDS_NS;
     for (u32 n = 0; fast && n < n_namespaces; ++n) fast = ns_off[n + 1] - ns_off[n] <= 64u;
     MatchSlots slots{};
+    u32 var_slots = 0;
     auto slot_of = [&](u32 key) -> int {
         for (u32 q = 0; q < slots.n; ++q)
             if (slots.key[q] == key) return (int)q;
@@ -2725,7 +2760,10 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
         for (u32 q = 0; fast && q < L.n_vars; ++q) {
             const int sl = slot_of(L.var_key[q]);
             if (sl < 0) fast = false;
-            else vs[q] = (u32)sl;
+            else {
+                vs[q] = (u32)sl;
+                var_slots |= 1u << sl;
+            }
         }
         for (u32 c = 0; fast && c < L.n_cond; ++c) {
             const rl_match_cond& cd = conds[L.cond_off + c];
@@ -2742,6 +2780,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
         HIP_TRY(e, hipMemcpy(e->d_match_flimits, fl.data(), n_limits * sizeof(MatchLimitF), hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_match_fconds, fc.data(), fc.size() * sizeof(MatchCondF), hipMemcpyHostToDevice));
         e->match_slots = slots;
+        e->match_var_slots = var_slots;
         e->match_fast = RL_EXP_ENV("RL_MATCH_GENERIC") == nullptr;
     }
     return RL_OK;
@@ -2896,6 +2935,149 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
     const u32 n_copy = n_hits < hits_cap ? n_hits : hits_cap;
     if (hits_out && n_copy)
         HIP_TRY(e, hipMemcpyAsync(hits_out, e->d_hits, (size_t)n_copy * sizeof(Hit), hipMemcpyDeviceToHost, e->stream));
+    if (load_counters && n_copy && remaining && expires_in_us) {
+        HIP_TRY(e, hipMemcpyAsync(remaining, e->d_remaining, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(expires_in_us, e->d_expires, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return RL_OK;
+}
+
+int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, const rl_wire_str* ns, uint32_t n_ns,
+                          const rl_wire_str* keys, uint32_t n_keys, const rl_wire_str* vals, uint32_t n_vals,
+                          const uint64_t* limit_prefix, uint32_t n_limits) {
+    if (!e || (blob_len && !blob) || !ns || (n_keys && !keys) || (n_vals && !vals) || (n_limits && !limit_prefix)) return RL_ERR_INVALID;
+    EngineLock g(e);
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    if (!e->d_match_limits || !e->match_fast || !e->match_one)
+        return fail(e, RL_ERR_INVALID, "rl_wire_table_set needs the slot form of the match table (rl_match_table_set first: at most %u descriptor keys, 64 limits per namespace)", MATCH_SLOTS);
+    if (blob_len > WIRE_BLOB_MAX) return fail(e, RL_ERR_INVALID, "the table's strings take %u bytes > %u", blob_len, WIRE_BLOB_MAX);
+    if (n_ns != e->n_match_ns) return fail(e, RL_ERR_INVALID, "%u namespace strings for a match table of %u namespaces", n_ns, e->n_match_ns);
+    if (n_vals > WIRE_LIT_TAB / 2) return fail(e, RL_ERR_INVALID, "%u condition literals > %u", n_vals, WIRE_LIT_TAB / 2);
+    if (n_limits <= e->match_max_limit_id)
+        return fail(e, RL_ERR_INVALID, "limit_prefix has %u rows, the match table names limit id %u", n_limits, e->match_max_limit_id);
+    auto inside = [&](const rl_wire_str& s) { return (u64)s.off + s.len <= blob_len && s.len <= 0xFFFFu; };
+    for (u32 i = 0; i < n_ns; ++i)
+        if (!inside(ns[i])) return fail(e, RL_ERR_INVALID, "namespace string %u lies outside the blob", i);
+    for (u32 i = 0; i < n_keys; ++i)
+        if (!inside(keys[i])) return fail(e, RL_ERR_INVALID, "key string %u lies outside the blob", i);
+    for (u32 i = 0; i < n_vals; ++i)
+        if (!inside(vals[i])) return fail(e, RL_ERR_INVALID, "value string %u lies outside the blob", i);
+    HIP_TRY(e, hipSetDevice(e->device));
+    WireTables W{};
+    for (u32 sl = 0; sl < e->match_slots.n; ++sl) {
+        const u32 kid = e->match_slots.key[sl];
+        if (kid >= n_keys) return fail(e, RL_ERR_INVALID, "the match table reads key id %u, %u key strings were given", kid, n_keys);
+        W.slot_key[sl] = WireStr{keys[kid].off, keys[kid].len};
+    }
+    std::vector<WireLit> lit(WIRE_LIT_TAB, WireLit{0ull, 0u, 0, 0xFFFFu});
+    for (u32 id = 0; id < n_vals; ++id) {
+        const rl_h128 h = rl_kh_bytes(blob + vals[id].off, vals[id].len, 0ull);
+        u32 q = (u32)h.h1 & (WIRE_LIT_TAB - 1u);
+        while (lit[q].id != 0xFFFFu) q = (q + 1u) & (WIRE_LIT_TAB - 1u);
+        lit[q] = WireLit{h.h1, vals[id].off, (unsigned short)vals[id].len, (unsigned short)id};
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const size_t mb = e->max_batch;
+    auto need = [&](void** p, size_t bytes) { return *p || hipMalloc(p, bytes ? bytes : 16) == hipSuccess; };
+    if (!need((void**)&e->d_w_blob, WIRE_BLOB_MAX) || !need((void**)&e->d_w_ns, MATCH_LDS_NS * sizeof(WireStr)) ||
+        !need((void**)&e->d_w_lit, WIRE_LIT_TAB * sizeof(WireLit)) || !need((void**)&e->d_w_prefix, 4096 * 2 * sizeof(u64)) ||
+        !need((void**)&e->d_w_off, (mb + 1) * sizeof(u32)) || !need((void**)&e->d_w_status, mb * sizeof(int32_t)) ||
+        !need((void**)&e->d_w_slot_h, mb * MATCH_SLOTS * sizeof(uint4)) || !need((void**)&e->d_hit_check, mb * sizeof(u32)))
+        return fail(e, RL_ERR_NOMEM, "hipMalloc of the wire path's tables / staging failed");
+    if (blob_len) HIP_TRY(e, hipMemcpy(e->d_w_blob, blob, blob_len, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->d_w_ns, ns, n_ns * sizeof(WireStr), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->d_w_lit, lit.data(), lit.size() * sizeof(WireLit), hipMemcpyHostToDevice));
+    if (n_limits) HIP_TRY(e, hipMemcpy(e->d_w_prefix, limit_prefix, (size_t)std::min(n_limits, 4096u) * 2 * sizeof(u64), hipMemcpyHostToDevice));
+    W.blob = e->d_w_blob;
+    W.blob_len = blob_len;
+    W.ns = e->d_w_ns;
+    W.n_ns = n_ns;
+    W.lit = e->d_w_lit;
+    W.prefix = e->d_w_prefix;
+    W.var_slot_mask = e->match_var_slots;
+    e->wire_t = W;
+    e->wire_ready = true;
+    return RL_OK;
+}
+
+int32_t rl_wire_staging(rl_engine* e, uint64_t bytes, void** out) {
+    if (!e || !out) return RL_ERR_INVALID;
+    EngineLock g(e);
+    if (bytes > e->h_w_stage_cap) {
+        HIP_TRY(e, hipSetDevice(e->device));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (e->h_w_stage) (void)hipHostFree(e->h_w_stage);
+        e->h_w_stage = nullptr;
+        e->h_w_stage_cap = 0;
+        u64 cap = 1u << 20;
+        while (cap < bytes) cap <<= 1;
+        if (hipHostMalloc(&e->h_w_stage, cap, hipHostMallocDefault) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipHostMalloc of %llu bytes of message staging failed", (unsigned long long)cap);
+        e->h_w_stage_cap = cap;
+    }
+    *out = e->h_w_stage;
+    return RL_OK;
+}
+
+int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
+                                      int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, int32_t* status,
+                                      uint32_t* req_off_out, rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out,
+                                      uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) {
+    if (!e || !n || !msg_off || !verdict || !status) return RL_ERR_INVALID;
+    if (collided_message) *collided_message = -1;
+    EngineLock g(e);
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    if (!e->wire_ready) return fail(e, RL_ERR_INVALID, "rl_wire_table_set was not called for the installed match table");
+    if (n > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n %u > max_batch_hits %u", n, e->max_batch);
+    const u64 bytes = msg_off[n];
+    if (msg_off[0] != 0 || (bytes && !wire)) return fail(e, RL_ERR_INVALID, "msg_off[0] must be 0 and wire non-null");
+    if (bytes > 0xFFFFFFFFull - 64) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the messages take %llu bytes", (unsigned long long)bytes);
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (bytes > e->w_bytes_cap) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (e->d_w_bytes) (void)hipFree(e->d_w_bytes);
+        e->d_w_bytes = nullptr;
+        e->w_bytes_cap = 0;
+        u64 cap = 1u << 16;
+        while (cap < bytes) cap <<= 1;
+        if (hipMalloc((void**)&e->d_w_bytes, cap) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc of %llu bytes of message staging failed", (unsigned long long)cap);
+        e->w_bytes_cap = cap;
+    }
+    if (bytes) HIP_TRY(e, hipMemcpyAsync(e->d_w_bytes, wire, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_w_off, msg_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, e->stream));
+    const u32 gq = cdiv(n, 256);
+    const u32 call = ++e->m_call ? e->m_call : ++e->m_call;
+    const MatchTables T{e->d_match_flimits, e->n_match_limits, e->d_match_ns_off, e->n_match_ns, e->d_match_fconds,
+                        e->n_match_conds, e->match_slots};
+    k_wire_count<<<gq, 256, 0, e->stream>>>(e->d_w_bytes, e->d_w_off, n, e->wire_t, T, e->d_m_ns, e->d_m_delta, e->d_w_status,
+                                            e->d_m_mask, e->d_w_slot_h, e->d_m_scan1);
+    k_match_scan2<<<1, 1024, 0, e->stream>>>(e->d_m_scan1, gq, e->d_req_off + n, e->h_m_word, call);
+    k_wire_fill<<<gq, 256, 0, e->stream>>>(e->d_m_ns, e->d_m_delta, n, T, e->d_w_prefix, e->d_m_mask, e->d_w_slot_h, e->d_m_scan1,
+                                           e->d_req_off, e->d_hits, e->d_hit_check, e->d_hit_req, e->max_batch);
+    HIP_TRY(e, hipGetLastError());
+    int rc = wait_word(e, e->h_m_word + 3, call, "the wire path's count pass");
+    if (rc) return rc;
+    const u32 n_hits = e->h_m_word[0], m_err = e->h_m_word[1];
+    if (n_hits_out) *n_hits_out = n_hits;
+    if (m_err || n_hits > e->max_batch) HIP_TRY(e, hipStreamSynchronize(e->stream));  // refused
+    if (m_err) return status_to_error(e, m_err);
+    if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the messages expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
+    GenCall gc{e->d_hits, n_hits, e->d_req_off, n, nullptr, now_us, load_counters != 0, false, e->d_verdict, e->d_first, e->d_remaining, e->d_expires};
+    gc.d_limited = limited_limit ? e->d_m_limited : nullptr;
+    gc.hit_req_filled = n_hits > 0;
+    gc.d_hit_check = e->d_hit_check;
+    rc = run_check_general(e, gc);
+    if (rc == RL_ERR_KEY_COLLISION && collided_message && e->collide_hit < n_hits) {
+        u32 req = 0;
+        if (hipMemcpy(&req, e->d_hit_req + e->collide_hit, sizeof(u32), hipMemcpyDeviceToHost) == hipSuccess) *collided_message = req;
+    }
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (limited_limit) HIP_TRY(e, hipMemcpyAsync(limited_limit, e->d_m_limited, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (req_off_out) HIP_TRY(e, hipMemcpyAsync(req_off_out, e->d_req_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, e->stream));
+    const u32 n_copy = n_hits < hits_cap ? n_hits : hits_cap;
+    if (hits_out && n_copy) HIP_TRY(e, hipMemcpyAsync(hits_out, e->d_hits, (size_t)n_copy * sizeof(Hit), hipMemcpyDeviceToHost, e->stream));
     if (load_counters && n_copy && remaining && expires_in_us) {
         HIP_TRY(e, hipMemcpyAsync(remaining, e->d_remaining, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(expires_in_us, e->d_expires, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));

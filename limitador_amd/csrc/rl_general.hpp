@@ -96,7 +96,8 @@ struct GenStatus {
     u32 rounds_run;
     u32 hot_n;       // keys that qualified for the next hot set (the host adapts the threshold)
     u32 committed;   // k_gen_commit applied the pass (converged, no error, the new cells fit)
-    u32 pad2[3];
+    u32 collide;     // ERRBIT_KEY_COLLISION: ~(the smallest hit index, relative to the pass, whose check word disagrees); 0 = none
+    u32 pad2[2];
     u32 changed[GEN_ROUNDS_MAX + 2];  // [slot]: that round changed a pass flag
 };
 
@@ -110,6 +111,7 @@ struct GenArgs {
     const u32* hit_req;      // absolute request of every hit of the caller's batch (null: hit i is request i)
     const u32* req_off;      // absolute CSR offsets (null: every hit its own request)
     const u64* req_delta;    // per-request u64 deltas of the caller's batch (null: the wire field)
+    const u32* hit_check;    // hashed keys (rl_keyhash.h): the check word of every hit of the pass, else null
     u32 hit0, req0;          // the pass starts at this hit / request of the caller's batch
     u32 n_hits, n_req;       // size of the pass
     const BHit* b_hits;
@@ -891,6 +893,31 @@ __global__ __launch_bounds__(256) void k_gen_count(GenArgs A) {
     if (threadIdx.x == 0 && s_n) atomicAdd(&A.gst->n_new, s_n);
 }
 
+// Hashed keys (include/rl_keyhash.h): every hit carries the 32-bit check word of its counter's identity.  Two hits of one
+// segment (= one 64-bit key) with different words, or a hit whose word differs from the one stored in its key's cell, are
+// two counters that share a key: the pass is REFUSED (ERRBIT_KEY_COLLISION, nothing is applied, `collide` names the hit)
+// and the caller takes that request out — never a silent merge.  Launched between k_gen_sort and the commit.
+__global__ __launch_bounds__(256) void k_gen_check_keys(GenArgs A) {
+    if (A.pst->err || A.gst->overflow) return;
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= A.n_hits) return;
+    const SHit h = A.s_hits[j];
+    const u32 chk = A.hit_check[h.idx];
+    u32 other;
+    if (h.seg == j) {
+        const u32 slot = A.seg_info[j].slot;
+        other = slot == SLOT_INVALID ? chk : A.table[slot].pad;
+        if (other == 0u) other = chk;  // a cell that was not created through hashed keys (add_counter, a loaded row)
+    } else {
+        other = A.hit_check[A.s_hits[h.seg].idx];
+    }
+    if (other != chk) {
+        atomicOr(&A.gst->err, ERRBIT_KEY_COLLISION);
+        atomicMax(&A.gst->collide, ~h.idx);
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // k_gen_commit: per cell
 // ---------------------------------------------------------------------------------------------
@@ -942,6 +969,7 @@ __global__ __launch_bounds__(256) void k_gen_commit(GenArgs A, u32 room) {
             }
             Cell* c = &A.table[slot];
             c->limit = si.limit;
+            c->pad = A.hit_check ? A.hit_check[A.s_hits[j].idx] : 0u;  // the key's check word travels with the cell
             c->value = 0;
             c->expiry = A.now + Lm.window_us;
             ++created;

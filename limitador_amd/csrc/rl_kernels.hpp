@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void k_insert_rows(Cell* __restrict__ table, u
                 table[slot].value = r.value;
                 table[slot].expiry = r.expiry;
                 table[slot].limit = r.limit;
+                table[slot].pad = r.reserved;  // (the check word of a hashed key, 0 otherwise)
                 atomicAdd(&st->n_inserted, 1u);
                 return;
             }
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void k_scan(Cell* __restrict__ table, u64 cap,
                         CellRow r;
                         r.key = tag;
                         r.limit = limit;
-                        r.reserved = 0;
+                        r.reserved = MODE == SCAN_DUMP ? b.w : 0u;  // (a dump carries the check word of a hashed key: rl_keyhash.h)
                         r.value = value;  // SCAN_GET: not expired here, so value_at(now) == value
                         r.expiry = MODE == SCAN_GET ? expiry - now : expiry;
                         out[pos] = r;
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(256) void k_rehash(const Cell* __restrict__ src, u6
                 dst[slot].value = ((u64)a.w << 32) | a.z;
                 dst[slot].expiry = ((u64)b.y << 32) | b.x;
                 dst[slot].limit = b.z;
+                dst[slot].pad = b.w;
                 ++moved;
                 placed = true;
                 break;

@@ -45,6 +45,8 @@ def _lib():
         "rli_frontend_should_rate_limit": (i32, [p, C.c_char_p, u32, C.POINTER(C.c_uint8), u32, C.POINTER(u32)]),
         "rli_frontend_stats": (None, [p, C.POINTER(u64), C.POINTER(u64)]),
         "rli_set_value_cap": (i32, [p, u32]),
+        "rli_set_key_mode": (i32, [p, i32]),
+        "rli_counter_key": (i32, [p, u32, strs, C.POINTER(u32), u32, C.POINTER(u64), C.POINTER(u32)]),
         "rli_batch_n_requests": (u32, [p]),
         "rli_batch_n_entries": (u32, [p]),
         "rli_batch_req_ns": (p, [p]),
@@ -86,9 +88,11 @@ class IngestError(RuntimeError):
 
 
 class Ingest:
-    def __init__(self, binding="descriptors", value_cap=None):
+    def __init__(self, binding="descriptors", value_cap=None, keys="exact"):
         """binding: what the caller's Context binds — "descriptors" (the transports: only the list `descriptors`)
-        or "root" (library callers, Context::from(HashMap): every key a root variable)."""
+        or "root" (library callers, Context::from(HashMap): every key a root variable).
+        keys: "exact" (host dictionaries, packed ids) or "hashed" (rli_set_key_mode RLI_KEYS_HASHED: the device decodes
+        the messages and keys counters by a hash of their canonical key bytes; serve_batch only)."""
         self._so = _lib()
         h = C.c_void_p()
         rc = SYMBOLS["rli_create"](C.byref(h))
@@ -98,6 +102,8 @@ class Ingest:
         self._check(SYMBOLS["rli_set_binding"](self._h, {"descriptors": 0, "root": 1}[binding]))
         if value_cap is not None:
             self._check(SYMBOLS["rli_set_value_cap"](self._h, int(value_cap)))
+        self.keys = keys
+        self._check(SYMBOLS["rli_set_key_mode"](self._h, {"exact": 0, "hashed": 1}[keys]))
 
     def close(self):
         if self._h:
@@ -122,6 +128,16 @@ class Ingest:
         if rc == HOST_ONLY:
             return HOST_ONLY
         return self._check(rc)
+
+    def counter_key(self, limit_id, values=()):
+        """(key, check word) the hashed mode gives the counter of `limit_id` with these variable values (bytes or str,
+        in variable-name order)."""
+        vals = [v.encode() if isinstance(v, str) else bytes(v) for v in values]
+        arr = (C.c_char_p * max(1, len(vals)))(*vals) if vals else (C.c_char_p * 1)()
+        lens = (C.c_uint32 * max(1, len(vals)))(*[len(v) for v in vals])
+        key, chk = C.c_uint64(0), C.c_uint32(0)
+        self._check(SYMBOLS["rli_counter_key"](self._h, int(limit_id), arr, lens, len(vals), C.byref(key), C.byref(chk)))
+        return key.value, chk.value
 
     def set_limit_name(self, limit_id, name):
         self._check(SYMBOLS["rli_set_limit_name"](self._h, int(limit_id), None if name is None else name.encode()))

@@ -3,7 +3,9 @@
 RateLimitRequests + limit matching + check_and_update on the device + the serialized RateLimitResponses, for a
 batch of N requests (4 namespaces x 8 limits, Zipf users).  A request that waits for a batch of N pays at most
 max_delay (the batcher's budget) + this.  Prints one JSON line: per N the p50 / p99 of the call and requests/s,
-without and with the draft-03 headers (load_counters)."""
+without and with the draft-03 headers (load_counters).
+usage: python scripts/bench_rls.py [exact|hashed]   exact: host dictionaries + packed ids; hashed: the messages decoded on
+the device, counters keyed by a hash of their canonical key bytes (rli_set_key_mode, rl_wire.hpp)."""
 import json
 import os
 import sys
@@ -20,7 +22,8 @@ from test_ingest_cpu import rls_request  # noqa: E402  (the hand-written wire en
 
 rng = np.random.default_rng(5)
 eng = Engine(capacity_cells=1 << 22, max_batch_hits=1 << 21, max_limits=64)
-g = Ingest()
+KEYS = sys.argv[1] if len(sys.argv) > 1 else "exact"
+g = Ingest(keys=KEYS)
 methods = ["GET", "POST", "PUT"]
 for n in range(4):
     for j in range(8):
@@ -42,7 +45,7 @@ def messages(n):
 
 
 now = 1_700_000_000_000_000
-out = {"what": "rli_serve_batch: wire bytes -> verdicts + RateLimitResponse bytes", "sizes": {}}
+out = {"what": "rli_serve_batch: wire bytes -> verdicts + RateLimitResponse bytes", "keys": KEYS, "sizes": {}}
 for n in (1, 16, 256, 4096, 32768, 262144):
     prep = g.prepare_batch(messages(n))  # (the ctypes marshalling of the Python harness is not what is measured)
     row = {}

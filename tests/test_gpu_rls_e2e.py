@@ -54,9 +54,11 @@ def _limits():
     return out
 
 
-def _install(make_engine):
-    eng = make_engine(capacity_cells=1 << 16, max_batch_hits=1 << 15)
-    g = Ingest()  # the transports' binding: descriptors[0][...]
+def _install(make_engine, keys="exact", **engine_kw):
+    engine_kw.setdefault("capacity_cells", 1 << 16)
+    engine_kw.setdefault("max_batch_hits", 1 << 15)
+    eng = make_engine(**engine_kw)
+    g = Ingest(keys=keys)  # the transports' binding: descriptors[0][...]
     model = TestsLimiter(oracle.OracleStorage(), now_us=NOW)
     for ns, mx, secs, conds, variables, name in _limits():
         lid = g.add_limit(ns, mx, secs, [f"descriptors[0]['{k}'] {op} '{v}'" for k, op, v in conds],
@@ -68,10 +70,13 @@ def _install(make_engine):
     return eng, g, model
 
 
-def test_rate_limit_requests_from_the_wire_to_the_wire(make_engine):
+# keys: "exact" = host dictionaries + packed ids; "hashed" = the messages decoded on the device, counters keyed by a hash
+# of their canonical key bytes (rl_wire.hpp, include/rl_keyhash.h) — same statuses, same response bytes.
+@pytest.mark.parametrize("keys", ["exact", "hashed"])
+def test_rate_limit_requests_from_the_wire_to_the_wire(make_engine, keys):
     rng = np.random.default_rng(77)
     Resp = _response_class()
-    eng, g, model = _install(make_engine)
+    eng, g, model = _install(make_engine, keys)
     methods, paths = ["GET", "POST", "PUT"], ["/", "/admin", "/json"]
     n_ok = n_over = n_unknown = 0
     for batch in range(20):
@@ -118,12 +123,13 @@ def test_rate_limit_requests_from_the_wire_to_the_wire(make_engine):
     assert n_ok > 500 and n_over > 500 and n_unknown > 20
 
 
-def test_micro_batcher_in_front_of_the_wire_path(make_engine):
+@pytest.mark.parametrize("keys", ["exact", "hashed"])
+def test_micro_batcher_in_front_of_the_wire_path(make_engine, keys):
     """64 threads x 40 ShouldRateLimit calls on one tight limit: the batches are aggregated (fewer device batches
     than requests), every request gets its own answer, and exactly max_value of them are OK."""
     Resp = _response_class()
     eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
-    g = Ingest()
+    g = Ingest(keys=keys)
     assert g.add_limit("shop", 1000, 60, ["descriptors[0]['method'] == 'GET'"], []) == 0
     assert g.add_limit("shop", 10**6, 60, [], ["descriptors[0]['user']"]) == 1
     g.install(eng)
@@ -173,17 +179,20 @@ def test_large_batches_are_decoded_and_answered_by_several_threads(make_engine, 
             msgs.append(m)
         batches.append(msgs)
     results = []
-    for threads in ("1", "7"):
+    for threads, keys in (("1", "exact"), ("7", "exact"), ("7", "hashed")):
         monkeypatch.setenv("RLI_THREADS", threads)
-        eng, g, _model = _install(make_engine)
+        eng, g, _model = _install(make_engine, keys)
         out = []
         for b, msgs in enumerate(batches):
             out.append(g.serve_batch(eng, msgs, NOW + b * 700_000, with_headers=bool(b % 2)))
         results.append(out)
     for b in range(3):
-        (s1, r1), (s7, r7) = results[0][b], results[1][b]
+        (s1, r1), (s7, r7), (sh, rh) = results[0][b], results[1][b], results[2][b]
         assert s1 == s7, f"batch {b}: statuses"
         assert r1 == r7, f"batch {b}: response bytes"
+        # the device's decoder agrees with the host's on every message, malformed ones included
+        assert s1 == sh, f"batch {b}: statuses, hashed keys: {[(i, a, c) for i, (a, c) in enumerate(zip(s1, sh)) if a != c][:10]}"
+        assert r1 == rh, f"batch {b}: response bytes, hashed keys"
         assert sum(1 for s in s1 if s == 1) > 100 and sum(1 for s in s1 if s == 0) > 100 and any(s < -1 for s in s1)
 
 
@@ -198,7 +207,8 @@ SANDBOX_LIMITS = [
 SANDBOX_REQUEST = ("test_namespace", [[("req.method", "GET"), ("req.path", "/json")]], 1)
 
 
-def test_the_reference_sandbox_fixture_through_the_wire_path(make_engine):
+@pytest.mark.parametrize("keys", ["exact", "hashed"])
+def test_the_reference_sandbox_fixture_through_the_wire_path(make_engine, keys):
     """BASELINE.json configs[0]'s shape as the reference ships it: the limits FILE text through rli_add_limit, the load
     test's request as wire bytes.  GET /json only meets the 50000 / 10 s limit: exactly 50 000 of 50 400 requests inside
     one window are OK, the rest OVER_LIMIT, the headers count down; after the window everything is OK again.  Beside it
@@ -207,7 +217,7 @@ def test_the_reference_sandbox_fixture_through_the_wire_path(make_engine):
 
     Resp = _response_class()
     eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 15)
-    g = Ingest()
+    g = Ingest(keys=keys)
     model = TestsLimiter(oracle.OracleStorage(), now_us=NOW)
     for ns, mx, secs, conds, variables in SANDBOX_LIMITS:
         assert g.add_limit(ns, mx, secs, conds, variables) >= 0
@@ -249,3 +259,187 @@ def test_the_reference_sandbox_fixture_through_the_wire_path(make_engine):
     status, _ = g.serve_batch(eng, [load] * 10, model.now_us, with_headers=False)
     assert status == [0] * 10
     g.close()
+
+
+# ---- hashed keys: what only that mode has -----------------------------------------------------------------------------
+def _b(x):
+    return x if isinstance(x, bytes) else x.encode()
+
+
+def rls_request_b(domain, entries, hits_addend=None):
+    """rls_request for keys / values given as bytes (any bytes: protobuf strings may hold them)."""
+    from test_ingest_cpu import _ld
+
+    msg = _ld(1, _b(domain)) + _ld(2, b"".join(_ld(1, _ld(1, _b(k)) + _ld(2, _b(v))) for k, v in entries))
+    if hits_addend is not None:
+        msg += _varint((3 << 3) | 0) + _varint(hits_addend)
+    return msg
+
+
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def test_hashed_keys_are_the_hash_of_the_canonical_key_bytes(make_engine):
+    """The cells the device creates carry exactly the (key, check word) include/rl_keyhash.h defines over the counter's
+    canonical key bytes (storage/keys.rs:220-248): recomputed here from the strings alone — MurmurHash3_x64_128 of the
+    prefix (version, namespace, seconds, sorted conditions, sorted variable names in postcard), one block step per value
+    hash, the finalisation — and compared with the table's dump."""
+    M = (1 << 64) - 1
+
+    def rotl(x, r):
+        return ((x << r) | (x >> (64 - r))) & M
+
+    def fmix(k):
+        k ^= k >> 33
+        k = (k * 0xff51afd7ed558ccd) & M
+        k ^= k >> 33
+        k = (k * 0xc4ceb9fe1a85ec53) & M
+        return k ^ (k >> 33)
+
+    c1, c2 = 0x87c37b91114253d5, 0x4cf5ad432745937f
+
+    def mix1(k):
+        return (rotl((k * c1) & M, 31) * c2) & M
+
+    def mix2(k):
+        return (rotl((k * c2) & M, 33) * c1) & M
+
+    def block(h1, h2, k1, k2):
+        h1 = ((rotl(h1 ^ mix1(k1), 27) + h2) & M) * 5 + 0x52dce729 & M
+        h2 = ((rotl(h2 ^ mix2(k2), 31) + h1) & M) * 5 + 0x38495ab5 & M
+        return h1, h2
+
+    def finish(h1, h2, n):
+        h1 ^= n
+        h2 ^= n
+        h1 = (h1 + h2) & M
+        h2 = (h2 + h1) & M
+        h1, h2 = fmix(h1), fmix(h2)
+        h1 = (h1 + h2) & M
+        return h1, (h2 + h1) & M
+
+    def murmur(b):
+        h1 = h2 = 0
+        i = 0
+        while i + 16 <= len(b):
+            h1, h2 = block(h1, h2, int.from_bytes(b[i:i + 8], "little"), int.from_bytes(b[i + 8:i + 16], "little"))
+            i += 16
+        t = b[i:]
+        if len(t) > 8:
+            h2 ^= mix2(int.from_bytes(t[8:], "little"))
+        if t:
+            h1 ^= mix1(int.from_bytes(t[:8], "little"))
+        return finish(h1, h2, len(b))
+
+    assert murmur(b"The quick brown fox jumps over the lazy dog") == (0xe34bbc7bbc071b6c, 0x7a433ca9c49a9347)  # the published vector
+
+    def pstr(x):
+        return _varint(len(x)) + x
+
+    def key_of(ns, seconds, conds, var_names, values):
+        prefix = b"\x01" + pstr(ns.encode()) + _varint(seconds) + _varint(len(conds)) + b"".join(pstr(c.encode()) for c in sorted(conds))
+        prefix += _varint(len(var_names)) + b"".join(pstr(v.encode()) for v in sorted(var_names))
+        h1, h2 = murmur(prefix)
+        for v in values:
+            h1, h2 = block(h1, h2, *murmur(v))
+        h1, h2 = finish(h1, h2, 16 * len(values) + 1)
+        return (h1 - 2 if h1 >= M - 1 else h1), ((h2 >> 32) or 1)
+
+    eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
+    g = Ingest(keys="hashed")
+    conds = ["descriptors[0]['method'] == 'GET'", "descriptors[0]['path'] != '/admin'"]
+    v2 = ["descriptors[0]['user']", "descriptors[0]['app']"]
+    l0 = g.add_limit("shop", 100, 60, conds, [])
+    l1 = g.add_limit("shop", 100, 3600, conds[:1], v2[:1])
+    l2 = g.add_limit("shop", 100, 7, [], v2)
+    g.install(eng)
+    users = [b"alice", b"", b"a-user-name-of-more-than-sixteen-bytes", bytes(range(1, 40))]
+    msgs = [rls_request_b("shop", [("method", "GET"), ("path", "/"), ("user", u), ("app", b"app%d" % (i % 2))]) for i, u in enumerate(users)]
+    status, _ = g.serve_batch(eng, msgs, NOW)
+    assert status == [0] * len(users)
+    want = {key_of("shop", 60, conds, [], []): l0 | 0x80000000}
+    for i, u in enumerate(users):
+        want[key_of("shop", 3600, conds[:1], v2[:1], [u])] = l1
+        want[key_of("shop", 7, [], v2, [b"app%d" % (i % 2), u])] = l2  # (variables in NAME order: ...['app'] < ...['user'])
+    rows = eng.dump_cells()
+    got = {(int(r["key"]), int(r["reserved"])): int(r["limit"]) for r in rows}
+    assert {k: v for k, v in got.items() if v & 0x80000000} == {(k[0], 0): v for k, v in want.items() if v & 0x80000000}  # add_counter: no check word
+    assert {k: v for k, v in got.items() if not v & 0x80000000} == {k: v for k, v in want.items() if not v & 0x80000000}
+    assert g.counter_key(l1, [users[2]]) == key_of("shop", 3600, conds[:1], v2[:1], [users[2]])
+    assert g.counter_key(l0) [0] == key_of("shop", 60, conds, [], [])[0]
+    g.close()
+
+
+def test_two_counters_that_share_a_key_are_never_merged(make_engine):
+    """A cell that already holds ANOTHER counter's check word under the key a message derives (forged here by loading
+    such a row: finding a real 64-bit collision is not an option): the message is answered HOST_ONLY, nothing of it is
+    applied, the forged cell is untouched, and the other messages of the batch are applied as if it had not been there."""
+    from limitador_amd.ingest import HOST_ONLY
+    from limitador_amd.wire import CELL_ROW_DTYPE
+
+    eng, g, model = _install(make_engine, "hashed")
+    lims = _limits()
+    j = next(i for i, L in enumerate(lims) if L[0] == "ns1" and L[4] == ["user"])
+    key, chk = g.counter_key(j, ["mallory"])
+    row = np.zeros(1, dtype=CELL_ROW_DTYPE)
+    row[0] = (key, j, chk ^ 0x5A5A, 3, NOW + 50_000_000)
+    eng.load_cells(row)
+    ctxs = [("ns1", {"method": m, "path": "/", "user": u, "app": "app0"}) for u in ("bob", "mallory", "carol", "bob") for m in ("PUT", "GET")]
+    msgs = [rls_request(d, [list(c.items())]) for d, c in ctxs]
+    status, _ = g.serve_batch(eng, msgs, NOW, with_headers=True)
+    # every message of mallory that meets limit j is taken out (one per retry), the rest is answered like the model does
+    applies = [any(L[0] == d and L[4] == ["user"] and li == j and model_applies(L, c) for li, L in enumerate(lims)) for d, c in ctxs]
+    for i, (d, c) in enumerate(ctxs):
+        if c["user"] == "mallory" and applies[i]:
+            assert status[i] == HOST_ONLY, i
+        else:
+            want = model.check_rate_limited_and_update(d, c, 1, True)
+            assert status[i] == (1 if want.limited else 0), i
+    assert sum(s == HOST_ONLY for s in status) == 1 and any(applies)
+    after = eng.dump_cells()
+    forged = after[after["key"] == key]
+    assert len(forged) == 1 and int(forged[0]["value"]) == 3 and int(forged[0]["reserved"]) == chk ^ 0x5A5A
+    g.close()
+
+
+def model_applies(L, ctx):
+    for k, op, v in L[3]:
+        if k not in ctx or (ctx[k] == v) != (op == "=="):
+            return False
+    return all(k in ctx for k in L[4])
+
+
+def test_both_key_modes_on_one_million_messages(make_engine):
+    """The same trace of 2^20 serialized requests (8 batches of 131 072, Zipf users, four namespaces x 8 limits) through
+    the dictionary path and through the device decoder with hashed keys: identical statuses, and the two tables hold the
+    same counters — the same multiset of (limit, value, expiry); only the keys' spelling differs."""
+    rng = np.random.default_rng(2024)
+    methods, paths = [b"GET", b"POST", b"PUT"], [b"/", b"/admin", b"/json"]
+    n_per, n_batches = 1 << 17, 8
+    users = [b"user-%d" % i for i in range(200_000)]
+    engines = {k: _install(make_engine, k, capacity_cells=1 << 22, max_batch_hits=1 << 20)[:2] for k in ("exact", "hashed")}
+    for b in range(n_batches):
+        ns = rng.integers(0, 4, size=n_per)
+        me = rng.integers(0, 3, size=n_per)
+        pa = rng.integers(0, 3, size=n_per)
+        us = rng.zipf(1.2, size=n_per) % len(users)
+        ap = rng.integers(0, 3, size=n_per)
+        msgs = [rls_request_b(b"ns%d" % ns[i], [(b"method", methods[me[i]]), (b"path", paths[pa[i]]), (b"user", users[us[i]]), (b"app", b"app%d" % ap[i])])
+                for i in range(n_per)]
+        out = {k: g.serve_batch(eng, msgs, NOW + b * 400_000)[0] for k, (eng, g) in engines.items()}
+        assert out["exact"] == out["hashed"], f"batch {b}: {[(i, a, c) for i, (a, c) in enumerate(zip(out['exact'], out['hashed'])) if a != c][:10]}"
+        assert 0 in out["exact"] and 1 in out["exact"]
+    tables = {}
+    for k, (eng, g) in engines.items():
+        rows = eng.dump_cells()
+        t = np.stack([rows["limit"].astype(np.uint64), rows["value"], rows["expiry_us"]], axis=1)
+        tables[k] = t[np.lexsort(t.T[::-1])]
+        g.close()
+    assert tables["exact"].shape == tables["hashed"].shape and np.array_equal(tables["exact"], tables["hashed"])
+    assert len(tables["exact"]) > 100_000
