@@ -252,11 +252,15 @@ int32_t rl_sweep_expired_rows(rl_engine *e, uint64_t now_us, rl_cell_row *out, u
  * enqueued behind every batch submitted so far and in front of every later one, without draining the pipeline — it
  * takes one of the three in-flight slots, like a batch of rl_check_and_update_submit_device, and is collected in
  * submission order: rl_sweep_expired_collect (or rl_check_and_update_collect, which drops the count) when it is the
- * oldest command in flight.  The result is the same as a blocking rl_sweep_expired called at that point of the
- * sequence; the table is not compacted by it (tombstones are counted, the next blocking sweep / rl_compact compacts). */
+ * oldest command in flight.  For the counter table the result is the same as a blocking rl_sweep_expired called at that
+ * point of the sequence; the table is not compacted by it (tombstones are counted, the next blocking sweep / rl_compact
+ * compacts), and the PEER tables of rl_merge_cells are left alone (the blocking sweep also drops their entries of windows
+ * that are over; a peer entry's expiry is checked wherever it is read, so a stale one changes no answer — it only keeps
+ * its slot until the next blocking sweep). */
 int32_t rl_sweep_expired_submit(rl_engine *e, uint64_t now_us);
 int32_t rl_sweep_expired_collect(rl_engine *e, uint64_t *n_removed);
-/* Force a compaction (rehash of live cells into a fresh table). */
+/* Force a compaction: the tombstones go and the gaps they leave are closed IN PLACE (every probe cluster rebuilt inside
+ * its own slots, the table read once: k_compact_bounds / k_compact_seg) — no second table, nothing that can fail half-way. */
 int32_t rl_compact(rl_engine *e);
 /* Rehash the live cells into a table of capacity_cells (rounded up to a power of two, >= 1024): how a
  * caller answers RL_ERR_TABLE_FULL — or shrinks after a sweep — without losing a counter.  Refused

@@ -1308,7 +1308,8 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
             // command, no stream synchronise (the pass's results are complete when the word is there: k_gen_post runs
             // behind the kernels that wrote them)
             const u32 seq = ++e->gen_post_seq ? e->gen_post_seq : ++e->gen_post_seq;
-            k_gen_post<<<1, 64, 0, st>>>(e->d_gst, &bs->st, e->h_gen_word, seq);
+            k_gen_post<<<1, 256, 0, st>>>(e->d_gst, &bs->st, e->h_gen_word, seq, reinterpret_cast<u32*>(e->d_bs),
+                                          (u32)(BS_ROT * sizeof(BatchScratch) / sizeof(u32)));
             HIP_TRY(e, hipGetLastError());
             const int wrc = wait_word(e, e->h_gen_word + 3, seq, "the general resolver's pass");
             if (wrc) return wrc;
@@ -1384,8 +1385,8 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     }
     e->live += h_gst.n_inserted;  // (== n_new when k_gen_count ran)
     e->part_seq++;
-    rc = cleanup();
-    if (rc) return rc;
+    if (e->gen_post) e->gen_clean = true;  // (k_gen_post zeroed the status block and the scratch blocks behind the commit)
+    else if ((rc = cleanup()) != RL_OK) return rc;
     e->stats.batches++;
     e->stats.hits += n;
     e->stats.ordered_hits += n;

@@ -1445,15 +1445,27 @@ __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32
 // End of a pass: what the host decides on — error bits of the pass and of its partition, cells created, overflow /
 // committed / "the last round still changed something", rounds run, size of the next hot set — as ONE 16-byte store
 // into host-mapped memory, sequence number last.  Launched behind k_gen_commit: everything it reads is final.
-__global__ void k_gen_post(const GenStatus* __restrict__ gst, const Status* __restrict__ pst, u32* host_word, u32 seq) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const u32 err = gst->err | pst->err;
-    const u32 hot = gst->hot_n > 0xFFFEu ? 0xFFFFu : gst->hot_n;
-    const u32 rr = gst->rounds_run > 0xFFu ? 0xFFu : gst->rounds_run;
-    const u32 changed = gst->changed[gst->last_slot] ? 1u : 0u;
-    const u32 flags = (gst->overflow ? 1u : 0u) | (gst->committed ? 2u : 0u) | (changed << 2) | (rr << 8) | (hot << 16);
-    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    __builtin_nontemporal_store(u32x4{err, gst->n_inserted, flags, seq}, reinterpret_cast<u32x4*>(host_word));
+__global__ __launch_bounds__(256) void k_gen_post(GenStatus* gst, const Status* __restrict__ pst, u32* host_word, u32 seq,
+                                                  u32* __restrict__ scratch_words, u32 n_scratch_words) {
+    __shared__ u32 s_clean;
+    if (threadIdx.x == 0) {
+        const u32 err = gst->err | pst->err;
+        const u32 hot = gst->hot_n > 0xFFFEu ? 0xFFFFu : gst->hot_n;
+        const u32 rr = gst->rounds_run > 0xFFu ? 0xFFu : gst->rounds_run;
+        const u32 changed = gst->changed[gst->last_slot] ? 1u : 0u;
+        const u32 flags = (gst->overflow ? 1u : 0u) | (gst->committed ? 2u : 0u) | (changed << 2) | (rr << 8) | (hot << 16);
+        // a pass that was applied leaves nothing the host still wants from the device: the status block and the rotating
+        // scratch blocks are zeroed HERE for whatever batch comes next (two fill commands the host used to enqueue once it
+        // had seen the word: 15-25 us between two calls); every other outcome keeps them for the host to look at
+        s_clean = (!err && !gst->overflow && gst->committed) ? 1u : 0u;
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(u32x4{err, gst->n_inserted, flags, seq}, reinterpret_cast<u32x4*>(host_word));
+    }
+    __syncthreads();
+    if (!s_clean) return;
+    for (u32 q = threadIdx.x; q < n_scratch_words; q += 256) scratch_words[q] = 0u;
+    u32* g = reinterpret_cast<u32*>(gst);
+    for (u32 q = threadIdx.x; q < (u32)(sizeof(GenStatus) / sizeof(u32)); q += 256) g[q] = 0u;
 }
 
 }  // namespace rl
