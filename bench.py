@@ -457,7 +457,9 @@ def secondary(args, eng, dev, gen):
             "note": "rl_sweep_expired (host call incl. its status read-back) over the 32-byte cells (SURVEY.md 8d counts 24 B "
                     "per slot: both rates given); rl_sweep_expired_submit between two 1 M-hit batches in flight; rl_compact of a "
                     "table without tombstones; expired_sweep: clock + 100 s, seven uniform 1 M-hit batches restart the windows of the "
-                    "cells they touch, the sweep removes every other cell (expiry <= now), rl_compact closes the gaps in place"}
+                    "cells they touch, the sweep removes every other cell (expiry <= now) and — tombstones now exceed capacity / 8 — compacts "
+                    "the table in place inside the same call (expired_sweep.sweep_ms = scan + 5 M tombstone stores + compaction); "
+                    "expired_sweep.compact_ms: rl_compact of the already compact table"}
     except Exception as ex:
         out["sweep_and_compact_10M_keys"] = {"error": str(ex)[:200]}
     return out
