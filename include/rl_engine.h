@@ -370,9 +370,11 @@ int32_t rl_wire_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, 
  * a stored one, share a 64-bit key with different check words: NOTHING was applied and *collided_message is the index
  * of a message that derives one of them — the caller answers that message on its exact path (or drops it) and calls
  * again without it. */
-/* A pinned host buffer of at least `bytes` bytes that belongs to the engine (grown on demand, freed with it; a later call
- * may move it): where a caller builds `wire` / `msg_off` so that the copies to the device are plain DMA. */
-int32_t rl_wire_staging(rl_engine *e, uint64_t bytes, void **out);
+/* Pinned host buffers that belong to the engine, by slot (0..3; grown on demand — a later call for the same slot may move
+ * it — and freed with the engine): where a host layer builds the arrays it hands to the host-pointer entry points and
+ * receives their results, so that every copy is plain DMA instead of the runtime's pageable path (a fresh 60 MB result
+ * array per call cost the wire path 20 ms of page faults and staged copies).  No reference analogue. */
+int32_t rl_host_staging(rl_engine *e, uint32_t slot, uint64_t bytes, void **out);
 int32_t rl_wire_match_and_check_batch(rl_engine *e, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
                                       uint64_t now_us, int32_t load_counters, uint8_t *verdict, int32_t *limited_limit,
                                       int32_t *status, uint32_t *req_off_out, rl_hit *hits_out, uint32_t hits_cap,

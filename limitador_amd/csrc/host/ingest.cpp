@@ -798,33 +798,6 @@ void put_string_field(std::string& o, uint32_t field, const std::string& v) {
     o += v;
 }
 
-// CheckResult::response_header (limitador/src/lib.rs:235-275) + RateLimitHeaders::headers
-// (envoy_rls/server.rs:44-57: sorted by key) for one request's counters, given in the order the storage saw them.
-struct LoadedCounter {
-    uint64_t max_value, seconds, remaining, expires_in_us;
-    const LimitSpec* limit;
-};
-void response_headers(std::vector<LoadedCounter> cs, std::vector<std::pair<std::string, std::string>>* out) {
-    out->clear();
-    if (cs.empty()) return;
-    // "sort by the limit remaining" (a stable sort: ties keep the storage's order)
-    std::stable_sort(cs.begin(), cs.end(), [](const LoadedCounter& a, const LoadedCounter& b) { return a.remaining < b.remaining; });
-    std::string all;
-    for (const auto& c : cs) {
-        all += ", " + std::to_string(c.max_value) + ";w=" + std::to_string(c.seconds);
-        if (c.limit && c.limit->has_name) {
-            std::string n = c.limit->name;
-            std::replace(n.begin(), n.end(), '"', '\'');
-            all += ";name=\"" + n + "\"";
-        }
-    }
-    const LoadedCounter& f = cs.front();
-    out->emplace_back("X-RateLimit-Limit", std::to_string(f.max_value) + all);
-    out->emplace_back("X-RateLimit-Remaining", std::to_string(f.remaining));
-    out->emplace_back("X-RateLimit-Reset", std::to_string(f.expires_in_us / 1000000ull));  // Duration::as_secs
-    std::sort(out->begin(), out->end());
-}
-
 }  // namespace
 
 int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
@@ -842,11 +815,35 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
     std::vector<int32_t> req_of(n, -1);
-    std::vector<uint8_t> verdict;
-    std::vector<int32_t> limited;
-    std::vector<uint32_t> req_off;
-    std::unique_ptr<rl_hit[]> hits;  // (new T[n]: no zero fill — tens of megabytes per call otherwise)
-    std::unique_ptr<uint64_t[]> rem, exp;
+    // The results of the device call live in the ENGINE's pinned staging (rl_host_staging slot 1): fresh pageable arrays —
+    // 60 MB of them for 262 144 requests with headers — cost the call 20 ms of page faults and staged copies.
+    uint8_t* verdict = nullptr;
+    int32_t *limited = nullptr, *dev_status = nullptr;
+    uint32_t* req_off = nullptr;
+    rl_hit* hits = nullptr;
+    uint64_t *rem = nullptr, *exp = nullptr;
+    auto result_arrays = [&](uint32_t n_r, size_t cap) -> int32_t {
+        auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+        const size_t total = up(n_r + 1) + 2 * up(((size_t)n_r + 1) * 4) + up(((size_t)n_r + 2) * 4) + up(cap * sizeof(rl_hit)) + 2 * up(cap * 8) + 64;
+        void* base = nullptr;
+        const int32_t rc = rl_host_staging(e, 1, total, &base);
+        if (rc) return gfail(g, rc, "rl_host_staging: %s", rl_last_error(e));
+        uint8_t* p = static_cast<uint8_t*>(base);
+        verdict = p;
+        p += up(n_r + 1);
+        limited = reinterpret_cast<int32_t*>(p);
+        p += up(((size_t)n_r + 1) * 4);
+        dev_status = reinterpret_cast<int32_t*>(p);
+        p += up(((size_t)n_r + 1) * 4);
+        req_off = reinterpret_cast<uint32_t*>(p);
+        p += up(((size_t)n_r + 2) * 4);
+        hits = reinterpret_cast<rl_hit*>(p);
+        p += up(cap * sizeof(rl_hit));
+        rem = reinterpret_cast<uint64_t*>(p);
+        p += up(cap * 8);
+        exp = reinterpret_cast<uint64_t*>(p);
+        return RL_OK;
+    };
     uint32_t n_req = 0;
     // every request derives at most one counter per limit of its namespace
     size_t per_ns = 1;
@@ -861,27 +858,19 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
         //      counter and carries its status.
         std::vector<uint8_t> skip(n, 0);  // messages taken out after a key collision: answered RLI_HOST_ONLY
         n_req = n;
-        verdict.resize(n);
-        limited.resize(n);
-        req_off.assign((size_t)n + 1, 0);
-        std::vector<int32_t> dev_status(n);
         const size_t cap = with_headers ? (size_t)n * per_ns : 0;
-        if (with_headers) {
-            hits.reset(new rl_hit[cap]);
-            rem.reset(new uint64_t[cap]);
-            exp.reset(new uint64_t[cap]);
-        }
+        if (const int32_t brc = result_arrays(n, cap)) return brc;
         uint64_t sum = 0;
         for (uint32_t i = 0; i < n; ++i) {
             if (lens[i] && !msgs[i]) return gfail(g, RL_ERR_INVALID, "message %u: null pointer with length %u", i, lens[i]);
             sum += lens[i];
         }
         if (sum > 0xFFFFFFFFull - 64) return gfail(g, RL_ERR_BATCH_TOO_LARGE, "the messages take %llu bytes", (unsigned long long)sum);
-        // offsets and bytes live in the ENGINE's pinned staging (rl_wire_staging: the copies to the device are plain DMA)
+        // offsets and bytes live in the ENGINE's pinned staging (rl_host_staging slot 0: the copies to the device are plain DMA)
         const size_t off_bytes = (((size_t)n + 1) * sizeof(uint32_t) + 63) & ~(size_t)63;
         void* stage = nullptr;
-        int32_t src = rl_wire_staging(e, off_bytes + sum + 64, &stage);
-        if (src) return gfail(g, src, "rl_wire_staging: %s", rl_last_error(e));
+        int32_t src = rl_host_staging(e, 0, off_bytes + sum + 64, &stage);
+        if (src) return gfail(g, src, "rl_host_staging: %s", rl_last_error(e));
         uint32_t* w_off = static_cast<uint32_t*>(stage);
         uint8_t* w_bytes = static_cast<uint8_t*>(stage) + off_bytes;
         for (int attempt = 0;; ++attempt) {
@@ -899,10 +888,10 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
             uint32_t n_hits = 0;
             int64_t collided = -1;
             const int32_t rc = rl_wire_match_and_check_batch(e, w_bytes, w_off, n, now_us, with_headers ? 1 : 0,
-                                                             verdict.data(), limited.data(), dev_status.data(),
-                                                             with_headers ? req_off.data() : nullptr, with_headers ? hits.get() : nullptr,
-                                                             (uint32_t)cap, &n_hits, with_headers ? rem.get() : nullptr,
-                                                             with_headers ? exp.get() : nullptr, &collided);
+                                                             verdict, limited, dev_status,
+                                                             with_headers ? req_off : nullptr, with_headers ? hits : nullptr,
+                                                             (uint32_t)cap, &n_hits, with_headers ? rem : nullptr,
+                                                             with_headers ? exp : nullptr, &collided);
             if (rc == RL_ERR_KEY_COLLISION && collided >= 0 && (uint64_t)collided < n && !skip[collided] && attempt < 64) {
                 skip[collided] = 1;  // its counter shares a 64-bit key with another one: never merged — the caller's exact path
                 continue;
@@ -988,31 +977,49 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
         });
         n_req = (uint32_t)g->req_ns.size();
         lap("appended");
-        verdict.resize(n_req ? n_req : 1);
-        limited.resize(n_req ? n_req : 1);
-        req_off.assign(n_req + 1, 0);
+        const size_t cap = with_headers ? (size_t)n_req * per_ns : 0;
+        if (const int32_t brc = result_arrays(n_req, cap)) return brc;
         if (n_req) {
             uint32_t n_hits = 0;
-            const size_t cap = with_headers ? (size_t)n_req * per_ns : 0;
-            if (with_headers) {
-                hits.reset(new rl_hit[cap]);
-                rem.reset(new uint64_t[cap]);
-                exp.reset(new uint64_t[cap]);
-            }
             const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
-                                                        g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict.data(),
-                                                        limited.data(), with_headers ? req_off.data() : nullptr,
-                                                        with_headers ? hits.get() : nullptr, (uint32_t)cap, &n_hits,
-                                                        with_headers ? rem.get() : nullptr, with_headers ? exp.get() : nullptr);
+                                                        g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict,
+                                                        limited, with_headers ? req_off : nullptr,
+                                                        with_headers ? hits : nullptr, (uint32_t)cap, &n_hits,
+                                                        with_headers ? rem : nullptr, with_headers ? exp : nullptr);
             if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
         }
     }
     lap("device");
     // ---- the responses: independent of one another ----------------------------------------------------------
     std::atomic<uint32_t> too_long{0};
+    // what a limit contributes to X-RateLimit-Limit — `, {max};w={secs}[;name="{name}"]` — is the same for every request:
+    // built once per call, not once per counter (lib.rs:246-262)
+    std::vector<std::string> frag(g->limits.size() + 1);
+    if (with_headers)
+        for (size_t l = 0; l <= g->limits.size(); ++l) {
+            const LimitSpec* L = l < g->limits.size() ? &g->limits[l] : nullptr;  // (the last one: a limit id this ingest does not know)
+            std::string& f = frag[l];
+            f = ", " + std::to_string(L ? L->max_value : 0) + ";w=" + std::to_string(L ? L->seconds : 0);
+            if (L && L->has_name) {
+                std::string nm = L->name;
+                std::replace(nm.begin(), nm.end(), '"', '\'');
+                f += ";name=\"" + nm + "\"";
+            }
+        }
+    auto put_u64 = [](std::string& o, uint64_t v) {
+        char buf[24];
+        int k = 24;
+        do {
+            buf[--k] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        o.append(buf + k, (size_t)(24 - k));
+    };
     parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
-        std::vector<std::pair<std::string, std::string>> hdrs;
-        std::string o, hv;
+        // (strings that keep their capacity from one request to the next: no allocation per request)
+        std::string o, hv, val;
+        std::vector<uint32_t> order;
+        static const std::string k_limit = "X-RateLimit-Limit", k_rem = "X-RateLimit-Remaining", k_reset = "X-RateLimit-Reset";
         for (uint32_t i = lo; i < hi; ++i) {
             o.clear();
             if (status[i] == RLI_UNKNOWN_DOMAIN) {
@@ -1021,20 +1028,41 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
                 const uint32_t r = (uint32_t)req_of[i];
                 put_varint(o, (1u << 3) | 0u);
                 put_varint(o, verdict[r] ? 2u : 1u);  // OVER_LIMIT : OK
-                if (with_headers) {
-                    std::vector<LoadedCounter> cs;
+                if (with_headers && req_off[r + 1] > req_off[r]) {
+                    // CheckResult::response_header (lib.rs:235-275): the request's counters sorted by remaining (stable: ties
+                    // keep the storage's order), the most restrictive one first; RateLimitHeaders::headers sorts the three
+                    // headers by key (envoy_rls/server.rs:44-57) — Limit < Remaining < Reset.
+                    order.clear();
                     for (uint32_t q = req_off[r]; q < req_off[r + 1]; ++q) {
-                        const uint32_t lid = RL_LIMIT_ID(hits[q].limit);
-                        const LimitSpec* L = lid < g->limits.size() ? &g->limits[lid] : nullptr;
-                        cs.push_back(LoadedCounter{L ? L->max_value : 0, L ? L->seconds : 0, rem[q], exp[q], L});
+                        size_t at = order.size();
+                        order.push_back(q);
+                        while (at > 0 && rem[order[at - 1]] > rem[q]) {  // (insertion: a handful of counters)
+                            order[at] = order[at - 1];
+                            --at;
+                        }
+                        order[at] = q;
                     }
-                    response_headers(std::move(cs), &hdrs);
-                    for (const auto& kv : hdrs) {  // response_headers_to_add = 3: HeaderValue { key = 1; value = 2 }
+                    auto lid_of = [&](uint32_t q) {
+                        const uint32_t l = RL_LIMIT_ID(hits[q].limit);
+                        return l < g->limits.size() ? (size_t)l : g->limits.size();
+                    };
+                    const uint32_t f = order[0];
+                    auto header = [&](const std::string& key) {  // response_headers_to_add = 3: HeaderValue { key = 1; value = 2 }
                         hv.clear();
-                        put_string_field(hv, 1, kv.first);
-                        put_string_field(hv, 2, kv.second);
+                        put_string_field(hv, 1, key);
+                        put_string_field(hv, 2, val);
                         put_string_field(o, 3, hv);
-                    }
+                    };
+                    val.clear();
+                    put_u64(val, lid_of(f) < g->limits.size() ? g->limits[lid_of(f)].max_value : 0);
+                    for (uint32_t q : order) val += frag[lid_of(q)];
+                    header(k_limit);
+                    val.clear();
+                    put_u64(val, rem[f]);
+                    header(k_rem);
+                    val.clear();
+                    put_u64(val, exp[f] / 1000000ull);  // Duration::as_secs
+                    header(k_reset);
                 }
                 status[i] = verdict[r] ? 1 : 0;
             } else {

@@ -264,8 +264,8 @@ struct rl_engine {
     uint4* d_w_slot_h = nullptr;    // [max_batch][MATCH_SLOTS]: hashes of the values the variables read
     u32* d_hit_check = nullptr;     // [max_batch]: the check word of every derived counter (rl_keyhash.h)
     u32 collide_hit = 0;            // RL_ERR_KEY_COLLISION: a hit (index in the call) of the colliding pair
-    void* h_w_stage = nullptr;      // rl_wire_staging
-    u64 h_w_stage_cap = 0;
+    void* h_stage[4] = {};          // rl_host_staging: pinned buffers the engine lends to a host layer, by slot
+    u64 h_stage_cap[4] = {};
     unsigned long long* d_m_mask = nullptr;  // [max_batch] limits of its namespace that apply to a request
     u32* d_m_ns = nullptr;      // staging for host-pointer calls: per request namespace, delta
     u32* d_m_delta = nullptr;
@@ -1829,7 +1829,8 @@ void rl_engine_destroy(rl_engine* e) {
     if (e->h_total) (void)hipHostFree(e->h_total);
     if (e->h_m_total) (void)hipHostFree(e->h_m_total);
     if (e->h_m_word) (void)hipHostFree(e->h_m_word);
-    if (e->h_w_stage) (void)hipHostFree(e->h_w_stage);
+    for (void* hs : e->h_stage)
+        if (hs) (void)hipHostFree(hs);
     if (e->h_serve) (void)hipHostFree(e->h_serve);
     if (e->h_gen_word) (void)hipHostFree(e->h_gen_word);
     if (e->d_m_scan1) (void)hipFree(e->d_m_scan1);
@@ -3002,21 +3003,22 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     return RL_OK;
 }
 
-int32_t rl_wire_staging(rl_engine* e, uint64_t bytes, void** out) {
-    if (!e || !out) return RL_ERR_INVALID;
+int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out) {
+    if (!e || !out || slot >= 4u) return RL_ERR_INVALID;
     EngineLock g(e);
-    if (bytes > e->h_w_stage_cap) {
+    if (bytes > e->h_stage_cap[slot]) {
         HIP_TRY(e, hipSetDevice(e->device));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
-        if (e->h_w_stage) (void)hipHostFree(e->h_w_stage);
-        e->h_w_stage = nullptr;
-        e->h_w_stage_cap = 0;
+        if (e->h_stage[slot]) (void)hipHostFree(e->h_stage[slot]);
+        e->h_stage[slot] = nullptr;
+        e->h_stage_cap[slot] = 0;
         u64 cap = 1u << 20;
         while (cap < bytes) cap <<= 1;
-        if (hipHostMalloc(&e->h_w_stage, cap, hipHostMallocDefault) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipHostMalloc of %llu bytes of message staging failed", (unsigned long long)cap);
-        e->h_w_stage_cap = cap;
+        if (hipHostMalloc(&e->h_stage[slot], cap, hipHostMallocDefault) != hipSuccess)
+            return fail(e, RL_ERR_NOMEM, "hipHostMalloc of %llu bytes of host staging failed", (unsigned long long)cap);
+        e->h_stage_cap[slot] = cap;
     }
-    *out = e->h_w_stage;
+    *out = e->h_stage[slot];
     return RL_OK;
 }
 
