@@ -443,3 +443,61 @@ def test_both_key_modes_on_one_million_messages(make_engine):
         g.close()
     assert tables["exact"].shape == tables["hashed"].shape and np.array_equal(tables["exact"], tables["hashed"])
     assert len(tables["exact"]) > 100_000
+
+
+def test_the_device_decoder_agrees_with_the_host_decoder_on_mangled_messages(make_engine):
+    """Differential fuzz of the two protobuf readers (csrc/host/ingest.cpp decode_rls; rl_wire.hpp k_wire_count): valid
+    messages with junk fields, repeated keys / fields, empty strings, oversized varints, then byte flips, truncations and
+    insertions.  Both key modes must give every message the same status (0 / 1 / UNKNOWN_DOMAIN / malformed) — and, since
+    statuses include the verdicts, the same counters behind them."""
+    rng = np.random.default_rng(31337)
+    from test_ingest_cpu import _ld
+
+    def valid():
+        entries = [("method", ["GET", "POST", "PUT", ""][int(rng.integers(0, 4))]), ("path", ["/", "/admin"][int(rng.integers(0, 2))]),
+                   ("user", "u%d" % int(rng.integers(0, 50))), ("app", "app%d" % int(rng.integers(0, 3)))]
+        rng.shuffle(entries)
+        if rng.random() < 0.3:
+            entries.append(entries[int(rng.integers(0, len(entries)))])  # a repeated key
+        m = rls_request("ns%d" % int(rng.integers(0, 5)), [entries, [("method", "PUT")]][: int(rng.integers(1, 3))],
+                        hits_addend=[None, 0, 1, 3, 2**32 + 5][int(rng.integers(0, 5))], junk=rng.random() < 0.3)
+        if rng.random() < 0.1:
+            m = _ld(1, b"ns0") + m  # the domain twice: the last one counts
+        if rng.random() < 0.1:
+            m += _varint((7 << 3) | 1) + bytes(8) + _varint((8 << 3) | 5) + bytes(4) + _varint((9 << 3) | 0) + _varint(2**63)
+        return m
+
+    def mangle(m):
+        b = bytearray(m)
+        r = rng.random()
+        if r < 0.35 and b:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif r < 0.6 and b:
+            del b[int(rng.integers(0, len(b))):]
+        elif r < 0.8:
+            at = int(rng.integers(0, len(b) + 1))
+            b[at:at] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 6))).astype(np.uint8))
+        elif r < 0.9:
+            b = bytearray(b"\xff" * int(rng.integers(1, 12)))  # a varint that never ends
+        return bytes(b)
+
+    msgs = [valid() if rng.random() < 0.4 else mangle(valid()) for _ in range(20_000)]
+    msgs[0] = b""
+    out = {}
+    for keys in ("exact", "hashed"):
+        eng, g, _model = _install(make_engine, keys)
+        res = []
+        for b in range(4):
+            st, resp = g.serve_batch(eng, msgs[b * 5000:(b + 1) * 5000], NOW + b * 300_000, with_headers=bool(b & 1))
+            res.append((st, resp))
+        out[keys] = res
+        g.close()
+    for b in range(4):
+        (se, re_), (sh, rh) = out["exact"][b], out["hashed"][b]
+        bad = [(i, a, c, msgs[b * 5000 + i].hex()) for i, (a, c) in enumerate(zip(se, sh)) if a != c]
+        assert not bad, bad[:5]
+        assert re_ == rh, f"batch {b}: response bytes"
+    flat = [s for st, _ in out["exact"] for s in st]
+    assert sum(1 for s in flat if s == 0) > 2000 and sum(1 for s in flat if s == 1) > 500
+    assert sum(1 for s in flat if s == UNKNOWN_DOMAIN) > 20 and sum(1 for s in flat if s not in (0, 1, UNKNOWN_DOMAIN)) > 1000
