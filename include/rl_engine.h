@@ -422,6 +422,14 @@ int32_t rl_unpermute_u8_device(rl_engine *e, const uint8_t *d_src, const uint32_
  * (include/rl_sharded.h puts them on its exchange stream, beside the engine's batches on another). */
 int32_t rl_route_partition_stream(rl_engine *e, void *stream, const rl_hit *d_hits, uint32_t n_hits,
                                   uint32_t world, rl_hit *d_out, uint32_t *d_perm, uint32_t *d_counts);
+/* Up to four device-to-device copies as ONE kernel launch on `stream` (a router's own segments of an exchange).  Device
+ * pointers; host-mapped pinned memory counts as device memory. */
+typedef struct {
+    void *dst;
+    const void *src;
+    uint64_t bytes;
+} rl_copy_seg;
+int32_t rl_copy_segments_stream(rl_engine *e, void *stream, const rl_copy_seg *segs, uint32_t n);
 int32_t rl_unpermute_u8_stream(rl_engine *e, void *stream, const uint8_t *d_src, const uint32_t *d_perm,
                                uint32_t n, uint8_t *d_dst);
 

@@ -124,6 +124,7 @@ def _declare(lib):
     _sig(lib, "rl_req_round_stream", C.c_int32, [p, p, p, p, p, p, C.c_uint32, C.c_uint32, C.c_int32, p, p, p, p, p, p])
     _sig(lib, "rl_req_reached_stream", C.c_int32, [p, p, p, p, p, C.c_uint32, p])
     _sig(lib, "rl_unpermute_u64_stream", C.c_int32, [p, p, p, p, C.c_uint32, p])
+    _sig(lib, "rl_copy_segments_stream", C.c_int32, [p, p, p, C.c_uint32])
     _sig(lib, "rl_host_register", C.c_int32, [p, C.c_void_p, C.c_uint64])
     _sig(lib, "rl_host_unregister", C.c_int32, [p, C.c_void_p])
     _sig(lib, "rl_kernel_timing", C.c_int32, [p, C.c_int32])

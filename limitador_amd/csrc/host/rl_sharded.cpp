@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +135,7 @@ struct RcclTransport {
     RcclApi* api = nullptr;
     ncclComm_t comm = nullptr;
     uint32_t world = 0, rank = 0;
+    rl_engine* e = nullptr;  // launches the copy of the rank's own segments
 };
 
 int32_t rccl_exchange(void* ctx, const rl_xfer* xs, uint32_t n, void* stream) {
@@ -142,12 +144,20 @@ int32_t rccl_exchange(void* ctx, const rl_xfer* xs, uint32_t n, void* stream) {
     // What a rank sends to ITSELF never meets the communicator: a device-to-device copy on the same stream (an RCCL launch
     // costs 17-20 us even when all it moves is the local segment — at world 1 that was two such launches per slice, 36 of
     // the routed step's 98 us; at any world it is 1 / world of the traffic that stays off the links).
+    rl_copy_seg own[4];
+    uint32_t n_own = 0;
     for (uint32_t k = 0; k < n; ++k)
         if (xs[k].send_cnt[t->rank] && xs[k].send_cnt[t->rank] == xs[k].recv_cnt[t->rank]) {
             const void* src = static_cast<const char*>(xs[k].send) + xs[k].send_off[t->rank];
             void* dst = static_cast<char*>(xs[k].recv) + xs[k].recv_off[t->rank];
-            if (src != dst && hipMemcpyAsync(dst, src, xs[k].send_cnt[t->rank], hipMemcpyDeviceToDevice, st) != hipSuccess) return RL_ERR_DEVICE;
+            if (src == dst) continue;
+            if (n_own == 4) {  // (an exchange has at most 1 + SLOTS segments: flush)
+                if (rl_copy_segments_stream(t->e, st, own, n_own) != RL_OK) return RL_ERR_DEVICE;
+                n_own = 0;
+            }
+            own[n_own++] = rl_copy_seg{dst, src, xs[k].send_cnt[t->rank]};
         }
+    if (n_own && rl_copy_segments_stream(t->e, st, own, n_own) != RL_OK) return RL_ERR_DEVICE;
     if (t->world == 1) return RL_OK;
     // one group = one launch: every segment's sends and receives to all peers travel concurrently over the
     // point-to-point xGMI links (RCCL's all-to-all-v as grouped ncclSend / ncclRecv)
@@ -210,6 +220,17 @@ struct rl_sharded {
 
 namespace {
 
+// RL_SHARDED_TRACE=1 (experiment builds): host timestamps of the router's calls, one stderr line each
+static bool g_trace = RL_EXP_ENV("RL_SHARDED_TRACE") != nullptr;
+static double t_us() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+#define SH_TRACE(...)                                  \
+    do {                                               \
+        if (g_trace) std::fprintf(stderr, __VA_ARGS__); \
+    } while (0)
+
 int32_t fail(rl_sharded* s, int32_t code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -247,18 +268,48 @@ void verdict_xfer(rl_sharded* s, const Slice& p, int which, rl_xfer* x) {
 
 int32_t applied_event(rl_sharded* s, Slice& p);
 
-// ROUTED: partition by owner + GROUP A (counts of this slice, verdicts of the slices in `returned`)
-int32_t route(rl_sharded* s, const rl_hit* d_hits, uint32_t n, uint64_t now, uint8_t* out, const std::vector<Slice*>& returned) {
+// One submit on the exchange stream (what waits for what decides the order):
+//   1. the hit records of the slice routed by the submit BEFORE (its sizes are on the host) to their owners, and that slice's
+//      batch to the engine: nothing in front of them waits for anything, so the engine has the next batch queued while it
+//      still replays the one before;
+//   2. the owner partition of slice i and its SIZES, by themselves, then their copy to the host: the next submit needs them
+//      and must not find them behind a wait for a batch (riding in the verdicts' group — one group fewer, the first cut —
+//      they sat behind the replay of slice i - 2, the host's hipEventSynchronize on them blocked 16-35 us, and the engine got
+//      the batch of slice i - 1 only once that replay had ended; riding in the hit records' group they put the route kernels
+//      of slice i — 35 us beside a replay — in front of the records the engine was waiting for);
+//   3. the verdicts of the slices whose batches an earlier submit enqueued (this one waits for their replays), un-permuted.
+int32_t apply_prepare(rl_sharded* s, Slice& p, rl_xfer* x);
+int32_t apply_finish(rl_sharded* s, Slice& p);
+
+int32_t route(rl_sharded* s, const rl_hit* d_hits, uint32_t n, uint64_t now, uint8_t* out, const std::vector<Slice*>& returned,
+              Slice* to_apply) {
     const int slot = (int)(s->seq % SLOTS);
     const uint32_t W = s->world;
+    int32_t rc;
+    if (to_apply) {
+        rl_xfer xh;
+        rc = apply_prepare(s, *to_apply, &xh);
+        if (rc != RL_OK) return rc;
+        rc = s->t.exchange(s->t.ctx, &xh, 1, s->cs);
+        if (rc != RL_OK) return fail(s, rc, "exchange (hits) failed");  // (the transport itself is gone: nothing to keep in step with)
+        rc = apply_finish(s, *to_apply);
+        if (rc != RL_OK) return rc;
+        SH_TRACE("[sh] %9.1f  hits exchanged, engine half handed over\n", t_us());
+    }
     ENG_S(s, rl_route_partition_stream(s->e, s->cs, d_hits, n, W, s->sorted[slot], s->perm[slot], s->d_counts[slot]));
-    rl_xfer xs[1 + SLOTS];
+    SH_TRACE("[sh] %9.1f  route kernels enqueued\n", t_us());
+    rl_xfer xc;
+    xc.send = s->d_counts[slot];
+    xc.recv = s->d_counts[slot] + W;
+    xc.send_off = xc.recv_off = s->c_off.data();
+    xc.send_cnt = xc.recv_cnt = s->c_cnt.data();
+    rc = s->t.exchange(s->t.ctx, &xc, 1, s->cs);
+    if (rc != RL_OK) return fail(s, rc, "exchange (counts) failed");
+    HIP_S(s, hipMemcpyAsync(s->h_counts[slot], s->d_counts[slot], 2 * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s->cs));
+    HIP_S(s, hipEventRecord(s->ev_counts[slot], s->cs));
+    SH_TRACE("[sh] %9.1f  counts exchanged + copy + event\n", t_us());
+    rl_xfer xs[SLOTS];
     uint32_t nx = 0;
-    xs[nx].send = s->d_counts[slot];
-    xs[nx].recv = s->d_counts[slot] + W;
-    xs[nx].send_off = xs[nx].recv_off = s->c_off.data();
-    xs[nx].send_cnt = xs[nx].recv_cnt = s->c_cnt.data();
-    ++nx;
     int which = 0;
     for (Slice* p : returned) {
         const int32_t erc = applied_event(s, *p);
@@ -266,10 +317,11 @@ int32_t route(rl_sharded* s, const rl_hit* d_hits, uint32_t n, uint64_t now, uin
         HIP_S(s, hipStreamWaitEvent(s->cs, s->ev_applied[p->slot], 0));
         verdict_xfer(s, *p, which++, &xs[nx++]);
     }
-    const int32_t rc = s->t.exchange(s->t.ctx, xs, nx, s->cs);
-    if (rc != RL_OK) return fail(s, rc, "exchange (counts%s) failed", which ? " + verdicts" : "");
-    HIP_S(s, hipMemcpyAsync(s->h_counts[slot], s->d_counts[slot], 2 * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s->cs));
-    HIP_S(s, hipEventRecord(s->ev_counts[slot], s->cs));
+    if (nx) {
+        rc = s->t.exchange(s->t.ctx, xs, nx, s->cs);
+        if (rc != RL_OK) return fail(s, rc, "exchange (verdicts) failed");
+    }
+    SH_TRACE("[sh] %9.1f  group 2 enqueued\n", t_us());
     for (Slice* p : returned) {
         ENG_S(s, rl_unpermute_u8_stream(s->e, s->cs, s->sorted_verdict[p->slot], s->perm[p->slot], p->n, p->out));
         p->stage = RETURNED;
@@ -285,11 +337,15 @@ int32_t route(rl_sharded* s, const rl_hit* d_hits, uint32_t n, uint64_t now, uin
     return RL_OK;
 }
 
-// APPLIED: GROUP B (hit records to their owners; the sizes were exchanged at least one submit ago) + local batch
-int32_t apply(rl_sharded* s, Slice& p) {
+// APPLIED, in two halves around the exchange that carries the slice's hit records to their owners (the sizes reached the
+// host at least one submit ago): apply_prepare describes the transfer, apply_finish — behind the exchange on the stream —
+// hands the received records to the engine.
+int32_t apply_prepare(rl_sharded* s, Slice& p, rl_xfer* x) {
     const int slot = p.slot;
     const uint32_t W = s->world;
+    SH_TRACE("[sh] %9.1f apply(%llu) begin\n", t_us(), (unsigned long long)p.id);
     HIP_S(s, hipEventSynchronize(s->ev_counts[slot]));
+    SH_TRACE("[sh] %9.1f apply(%llu) counts seen\n", t_us(), (unsigned long long)p.id);
     uint64_t so = 0, ro = 0;
     for (uint32_t q = 0; q < W; ++q) {
         s->send_off[slot][q] = so;
@@ -307,20 +363,26 @@ int32_t apply(rl_sharded* s, Slice& p) {
         s->b_ro[q] = s->recv_off[slot][q] * sizeof(rl_hit);
         s->b_rc[q] = s->recv_cnt[slot][q] * sizeof(rl_hit);
     }
-    rl_xfer x;
-    x.send = s->sorted[slot];
-    x.recv = s->recv_hits[slot];
-    x.send_off = s->b_so.data();
-    x.send_cnt = s->b_sc.data();
-    x.recv_off = s->b_ro.data();
-    x.recv_cnt = s->b_rc.data();
-    const int32_t rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
-    if (rc != RL_OK) return fail(s, rc, "exchange (hits) failed");  // (the transport itself is gone: nothing to keep in step with)
-    HIP_S(s, hipEventRecord(s->ev_exchanged[slot], s->cs));
-    if (s->as)
-        HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[slot], 0));
-    else
+    x->send = s->sorted[slot];
+    x->recv = s->recv_hits[slot];
+    x->send_off = s->b_so.data();
+    x->send_cnt = s->b_sc.data();
+    x->recv_off = s->b_ro.data();
+    x->recv_cnt = s->b_rc.data();
+    return RL_OK;
+}
+
+// (the second half of apply_finish: everything that goes to the APPLY stream / the engine)
+int32_t apply_engine_half(rl_sharded* s, Slice& p) {
+    const int slot = p.slot;
+    const uint64_t ro = p.n_recv;
+    if (s->as) {
+        // a wait command costs its stream ~9 us even when its event completed long ago: where the HOST can see the exchange
+        // complete (the usual case: a 6 us copy enqueued 20 us ago) the apply stream is not made to wait for it
+        if (hipEventQuery(s->ev_exchanged[slot]) != hipSuccess) HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[slot], 0));
+    } else {
         ENG_S(s, rl_engine_wait_event(s->e, s->ev_exchanged[slot]));
+    }
     if (ro > s->max_recv) {
         p.err = RL_ERR_BATCH_TOO_LARGE;
         std::snprintf(p.errmsg, sizeof(p.errmsg), "rank %u: %llu routed hits exceed the engine's max_batch_hits (%u)", s->rank,
@@ -350,6 +412,21 @@ int32_t apply(rl_sharded* s, Slice& p) {
     }
     p.stage = APPLIED;
     return RL_OK;
+}
+
+int32_t apply_finish(rl_sharded* s, Slice& p) {
+    HIP_S(s, hipEventRecord(s->ev_exchanged[p.slot], s->cs));
+    return apply_engine_half(s, p);
+}
+
+// the two halves around an exchange of its own (the pipeline drains: rl_sharded_collect of a slice that is still ROUTED)
+int32_t apply(rl_sharded* s, Slice& p) {
+    rl_xfer x;
+    int32_t rc = apply_prepare(s, p, &x);
+    if (rc != RL_OK) return rc;
+    rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
+    if (rc != RL_OK) return fail(s, rc, "exchange (hits) failed");  // (the transport itself is gone: nothing to keep in step with)
+    return apply_finish(s, p);
 }
 
 // ev_applied[slot] of an APPLIED slice, recorded by now
@@ -485,6 +562,7 @@ int32_t rl_sharded_create_rccl(rl_engine* e, uint32_t world, uint32_t rank, cons
     r->api = api;
     r->world = world;
     r->rank = rank;
+    r->e = e;
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
     if (api->CommInitRank(&r->comm, (int)world, u, (int)rank) != ncclSuccess) {
@@ -548,22 +626,24 @@ const char* rl_sharded_last_error(const rl_sharded* s) { return s ? s->err : "nu
 int32_t rl_sharded_submit_device(rl_sharded* s, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us, uint8_t* d_verdict) {
     if (!s || (n_hits && (!d_hits || !d_verdict))) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(s->mu);
+    SH_TRACE("[sh] %9.1f submit(%llu) begin, %zu pending\n", t_us(), (unsigned long long)s->seq, s->pending.size());
     if (n_hits > s->max_slice) return fail(s, RL_ERR_BATCH_TOO_LARGE, "slice of %u hits, communicator sized for %u", n_hits, s->max_slice);
     if (s->pending.size() >= (size_t)SLOTS) return fail(s, RL_ERR_BUSY, "%d slices are in flight: collect first", SLOTS);
     HIP_S(s, hipSetDevice(s->device));
-    // Order on the exchange stream: hits(i-1) FIRST, so that the local batch of slice i-1 starts as soon as the
-    // engine is free; then route(i) + counts(i) with the verdicts of slice i-2 riding along.  (The other order
-    // chains everything: the verdict segment waits for batch i-2, and hits(i-1) — behind it on the stream —
-    // would hold back batch i-1 until then; measured: 191 us per routed step, all kernels back to back.)
-    // The sizes of slice i-1 reached pinned memory a whole submit ago, so the host never drains the device to
-    // read 2 x world integers.
+    // (the order of things on the exchange stream: see route())
     int32_t rc;
     std::vector<Slice*> to_return;  // the slices whose batch was enqueued by an EARLIER submit (at most two)
     for (auto& p : s->pending)
         if (p.stage == APPLIED && to_return.size() < 2) to_return.push_back(&p);
+    Slice* to_apply = nullptr;      // the slice the submit before routed (at most one: every submit applies what it finds)
     for (auto& p : s->pending)
-        if (p.stage == ROUTED && (rc = apply(s, p)) != RL_OK) return rc;
-    return route(s, d_hits, n_hits, now_us, d_verdict, to_return);
+        if (p.stage == ROUTED) {
+            if (!to_apply) to_apply = &p;
+            else if ((rc = apply(s, p)) != RL_OK) return rc;
+        }
+    rc = route(s, d_hits, n_hits, now_us, d_verdict, to_return, to_apply);
+    SH_TRACE("[sh] %9.1f submit end (returned %zu)\n", t_us(), to_return.size());
+    return rc;
 }
 
 int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) {
@@ -573,13 +653,16 @@ int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) {
     HIP_S(s, hipSetDevice(s->device));
     Slice& p = s->pending.front();
     int32_t rc;
+    SH_TRACE("[sh] %9.1f collect(%llu) begin stage %d\n", t_us(), (unsigned long long)p.id, (int)p.stage);
     if (p.stage == ROUTED && (rc = apply(s, p)) != RL_OK) return rc;
     if (p.stage == APPLIED && (rc = give_back(s, p)) != RL_OK) return rc;
     const Slice done = p;
     s->pending.pop_front();
     if (n_applied) *n_applied = done.err ? 0u : done.n_recv;
     if (done.waits) {
+        SH_TRACE("[sh] %9.1f collect(%llu) engine collect\n", t_us(), (unsigned long long)done.id);
         rc = rl_check_and_update_collect(s->e);  // the status of the local batch this rank applied for the slice
+        SH_TRACE("[sh] %9.1f collect(%llu) done\n", t_us(), (unsigned long long)done.id);
         if (rc != RL_OK) return fail(s, rc, "local batch: %s", rl_last_error(s->e));
     }
     if (done.err) return fail(s, done.err, "%s (every exchange of the slice was issued; the hits this rank owns were answered 0xFF)", done.errmsg);

@@ -3094,9 +3094,16 @@ uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world) { return 
 static int32_t route_partition_on(rl_engine* e, hipStream_t st, bool block, const rl_hit* d_hits, uint32_t n_hits,
                                   uint32_t world, rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
     if (!e || !d_counts || (n_hits && (!d_hits || !d_out || !d_perm))) return RL_ERR_INVALID;
-    EngineLock g(e);
+    // The caller's-stream form takes no engine lock and does not switch devices: it reads two immutable fields and a scratch
+    // that stream order protects (every routed step of a communicator goes through ONE stream), and a router calls it while
+    // its helper thread hands a batch to the same engine — behind the engine's mutex each launch here waited for that.
+    std::unique_lock<std::mutex> g(e->mu, std::defer_lock);
+    if (block) {
+        g.lock();
+        serve_stop(e);
+    }
     if (world == 0 || world > ROUTE_MAX_WORLD) return fail(e, RL_ERR_INVALID, "world %u not in [1,%d]", world, ROUTE_MAX_WORLD);
-    HIP_TRY(e, hipSetDevice(e->device));
+    if (block) HIP_TRY(e, hipSetDevice(e->device));
     const u32 nblk = n_hits ? cdiv(n_hits, ROUTE_TILE) : 0;
     if (nblk > ROUTE_MAX_BLOCKS) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u too large for the router", n_hits);
     if (nblk)
@@ -3126,8 +3133,12 @@ int32_t rl_route_partition_stream(rl_engine* e, void* stream, const rl_hit* d_hi
 static int32_t unpermute_on(rl_engine* e, hipStream_t st, bool block, const uint8_t* d_src, const uint32_t* d_perm,
                             uint32_t n, uint8_t* d_dst) {
     if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
-    EngineLock g(e);
-    HIP_TRY(e, hipSetDevice(e->device));
+    std::unique_lock<std::mutex> g(e->mu, std::defer_lock);  // (the caller's-stream form: no lock, see route_partition_on)
+    if (block) {
+        g.lock();
+        serve_stop(e);
+        HIP_TRY(e, hipSetDevice(e->device));
+    }
     if (n) k_unpermute_u8<<<cdiv(n, 256), 256, 0, st>>>(d_src, d_perm, n, d_dst);
     HIP_TRY(e, hipGetLastError());
     if (block) HIP_TRY(e, hipStreamSynchronize(st));
@@ -3144,6 +3155,25 @@ int32_t rl_unpermute_u8_stream(rl_engine* e, void* stream, const uint8_t* d_src,
                                uint8_t* d_dst) {
     if (!e) return RL_ERR_INVALID;
     return unpermute_on(e, reinterpret_cast<hipStream_t>(stream), false, d_src, d_perm, n, d_dst);
+}
+
+int32_t rl_copy_segments_stream(rl_engine* e, void* stream, const rl_copy_seg* segs, uint32_t n) {
+    if (!e || (n && !segs) || n > COPY_SEGS_MAX) return RL_ERR_INVALID;
+    if (!n) return RL_OK;
+    CopySegs S{};
+    u64 most = 0;
+    for (u32 k = 0; k < n; ++k) {
+        S.dst[k] = segs[k].dst;
+        S.src[k] = segs[k].src;
+        S.bytes[k] = segs[k].bytes;
+        most = std::max<u64>(most, segs[k].bytes);
+    }
+    S.n = n;
+    if (!most) return RL_OK;
+    const u32 grid = (u32)std::min<u64>(std::max<u64>(most >> 14, 1), 2048);
+    // (no engine lock: the launch touches nothing of the engine's but its device)
+    k_copy_segs<<<grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(S);
+    return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_DEVICE;
 }
 
 int32_t rl_engine_info(rl_engine* e, int32_t* device, uint32_t* max_batch_hits) {

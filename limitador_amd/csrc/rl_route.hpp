@@ -220,4 +220,29 @@ __global__ __launch_bounds__(256) void k_req_reached(const int32_t* __restrict__
     out_sorted[j] = (f < 0 || pos <= (u32)f) ? 1 : 0;
 }
 
+// Up to four device-to-device copies in ONE launch (the router's own segments of an exchange: what a rank sends to
+// itself).  hipMemcpyAsync costs the host 8-10 us per call whatever it moves; a kernel launch ~3.
+constexpr u32 COPY_SEGS_MAX = 4;
+struct CopySegs {
+    void* dst[COPY_SEGS_MAX];
+    const void* src[COPY_SEGS_MAX];
+    u64 bytes[COPY_SEGS_MAX];
+    u32 n;
+};
+__global__ __launch_bounds__(256) void k_copy_segs(const CopySegs S) {
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x, stride = (u64)gridDim.x * 256;
+    for (u32 k = 0; k < S.n; ++k) {
+        const u64 b = S.bytes[k];
+        if ((((u64)S.dst[k] | (u64)S.src[k] | b) & 15ull) == 0ull) {
+            const uint4* s4 = static_cast<const uint4*>(S.src[k]);
+            uint4* d4 = static_cast<uint4*>(S.dst[k]);
+            for (u64 i = gid; i < (b >> 4); i += stride) d4[i] = s4[i];
+        } else {
+            const uint8_t* s1 = static_cast<const uint8_t*>(S.src[k]);
+            uint8_t* d1 = static_cast<uint8_t*>(S.dst[k]);
+            for (u64 i = gid; i < b; i += stride) d1[i] = s1[i];
+        }
+    }
+}
+
 }  // namespace rl
