@@ -404,6 +404,24 @@ def secondary(args, eng, dev, gen):
             "note": "rl_match_and_check_batch_device: k_match_fast + general resolver (round 1: 2.03 ms per call)"}
     except Exception as ex:
         out["configs4_shape_match_and_check_1M_requests"] = {"error": str(ex)[:200]}
+    # -- the wire path: serialized RateLimitRequests -> verdicts -> RateLimitResponse bytes, per batch size,
+    #    with the host's dictionaries and with the messages decoded and the keys hashed on the device (scripts/bench_rls.py)
+    try:
+        import subprocess
+
+        wp = {}
+        for keys in ("exact", "hashed"):
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "bench_rls.py"), keys],
+                               capture_output=True, text=True, timeout=240)
+            m = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            wp[keys] = {n: {"codes_only_ms": v["codes_only"]["p50_ms"], "with_headers_ms": v["with_headers"]["p50_ms"],
+                            "requests_per_s": v["codes_only"]["requests_per_s"]}
+                        for n, v in m["sizes"].items() if n in ("256", "32768", "262144")}
+        out["wire_path_rli_serve_batch"] = dict(wp, note="p50 of the C call per batch of N serialized messages (4 namespaces x 8 limits, "
+                                                "Zipf users); exact = host dictionaries + packed ids, hashed = RLI_KEYS_HASHED "
+                                                "(messages decoded on the device, keys = hash of the canonical key bytes)")
+    except Exception as ex:
+        out["wire_path_rli_serve_batch"] = {"error": str(ex)[:200]}
     # -- the streaming maintenance kernels over the headline's table (LAST: they change it): a sweep that finds nothing
     #    expired is a pure scan of the table (the kernel expected near the HBM roofline); a sweep as a
     #    command between two batches in flight; a compaction (rehash of every live cell into a fresh table)

@@ -3035,6 +3035,8 @@ int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const u
     const u64 bytes = msg_off[n];
     if (msg_off[0] != 0 || (bytes && !wire)) return fail(e, RL_ERR_INVALID, "msg_off[0] must be 0 and wire non-null");
     if (bytes > 0xFFFFFFFFull - 64) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the messages take %llu bytes", (unsigned long long)bytes);
+    for (u32 i = 0; i < n; ++i)  // (the device walks [msg_off[i], msg_off[i + 1]) of the staging: never outside it)
+        if (msg_off[i] > msg_off[i + 1]) return fail(e, RL_ERR_INVALID, "msg_off is not non-decreasing at message %u", i);
     HIP_TRY(e, hipSetDevice(e->device));
     if (bytes > e->w_bytes_cap) {
         HIP_TRY(e, hipStreamSynchronize(e->stream));
