@@ -521,10 +521,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_keys_total = args.keys * world
-    # 32-byte cells at load <= 0.30: 10 M keys -> 2^25 cells = 1.07 GB (measured on MI355X, k_bkt_step one
-    # workgroup per bucket: 2^27 / 2^26 / 2^25 cells -> 14.3 / 14.1 / 13.7 G decisions/s; the first cut needed
-    # load 0.075 of 64-byte cells, 8.6 GB, to hide its probe chains)
-    cap = 1 << (int(n_keys_total / world * 2.2 * args.cap_mult - 1).bit_length())
+    # 32-byte cells at load <= 0.15: 10 M keys -> 2^26 cells = 2.1 GB of the GPU's 288 (215 bytes of table per key; the
+    # reference keeps a Counter — limit, set variables, strings — and an AtomicExpiringValue per key).  The capacity is the
+    # deployment's choice (rl_config.capacity_cells); what it buys here, measured on MI355X (profiles/r04h_replay_memory_path.md):
+    # load 0.30 / 0.15 / 0.075 (2^25 / 2^26 / 2^27 cells) -> replay launch 39.1 / 36.4 / 36.0 us, step (20 steps) 50.7 / 48.3 /
+    # 48.2 us.  --cap-mult 0.5 is the round-3 sizing.
+    cap = 1 << (int(n_keys_total / world * 4.4 * args.cap_mult - 1).bit_length())
     max_batch = int(args.batch * 2) if sharded else args.batch
     eng = Engine(capacity_cells=cap, max_batch_hits=max_batch, device=local_rank)
     eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
@@ -734,6 +736,7 @@ def main():
                        else f"{args.keys} keys/GPU, zipf {args.zipf}, {args.batch}-hit batch/GPU",
                        "keys_per_gpu": args.keys, "batch_per_gpu": args.batch, "zipf_s": args.zipf,
                        "table_capacity_cells": cap, "cell_bytes": 32, "table_bytes": cap * 32,
+                       "table_load": round(args.keys / cap, 3),
                        "parallelism": (f"hash-sharded x{world}, RCCL all-to-all" + (" behind the C ABI (rl_sharded_*)" if args.sharded_impl == "abi" else " (torch.distributed)") + sharded_note) if sharded else "single GPU",
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
                        "overlap": "partition of batches k+1, k+2 (own stream) beside k_bkt_step of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",

@@ -25,7 +25,7 @@ for pmc in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum T
   timeout 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out/pmc_$name" -o p -- $BENCH > /dev/null 2> "$out/pmc_$name.err"
   timeout 120 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out/calib_$name" -o c -- $OLDPWD/scripts/microbench/bin/pmc_calib > /dev/null 2> "$out/calib_$name.err"
 done
-for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS"; do
+[ -n "${SKIP_SQ:-}" ] || for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS"; do
   name=$(echo $pmc | tr ' ' '+')
   RL_OVERLAP=0 timeout 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out/sq_$name" -o p -- $BENCH > /dev/null 2> "$out/sq_$name.err"
 done

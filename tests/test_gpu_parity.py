@@ -162,6 +162,37 @@ def test_per_request_calls_between_everything_else(make_engine):
     assert_same_state(eng, orc, n_simple_expected=1)
 
 
+# ---- displaced keys: long probe chains, tags that share a word with EMPTY -----------------------
+@pytest.mark.parametrize("low_word", ["any", "all_ones"])
+def test_dense_table_long_probe_chains(make_engine, low_word):
+    """A table filled to 0.7 batch by batch: most new keys are displaced, many by more cells than one probe trip fetches
+    (apply2_round reads PROBE_W tags per trip — their low words — and claims an EMPTY cell with a compare-and-swap).  With
+    `all_ones` every key's low word equals EMPTY's, so that every comparison of a low word is inconclusive."""
+    rng = np.random.default_rng(7)
+    rows = [(9, 60), (400, 3600), (3, 1)]
+    eng, orc = pair(make_engine, rows, capacity_cells=4096)
+    ids = W.splitmix64(np.arange(1, 2901, dtype=np.uint64))
+    keys = ids if low_word == "any" else (ids << np.uint64(32)) | np.uint64(0xFFFFFFFF)
+    assert len(np.unique(keys)) == len(keys)
+    key_limit = rng.integers(0, 3, size=len(keys))
+    now = NOW
+    known = 0
+    for step in range(14):
+        known = min(len(keys), known + 230)  # ~230 keys the table has not seen, among hits on the ones it has
+        n = 3000 + 137 * step
+        idx = rng.integers(0, known, size=n)
+        idx[: known - max(0, known - 230)] = np.arange(max(0, known - 230), known)  # every new key at least once
+        rng.shuffle(idx)
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        hits["key"] = keys[idx]
+        hits["limit"] = key_limit[idx]
+        hits["delta"] = rng.integers(0, 3, size=n) if step % 2 else 1
+        run_both(eng, orc, hits, now)
+        now += int(rng.integers(0, 2 * SEC))
+    assert eng.stats()["live_cells"] == known == len(keys)
+    assert_same_state(eng, orc)
+
+
 # ---- seeded random traces, single-counter requests -------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_single_counter_batches(make_engine, seed):
