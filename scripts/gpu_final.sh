@@ -10,8 +10,7 @@ rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
 nproc > gpurun_out/host.txt; lscpu | grep -E 'Model name|^CPU\(s\)|Thread|Socket' >> gpurun_out/host.txt
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/pytest_gpu.log
-echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/pytest_gpu.log
+timeout 600 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_full.log 2>&1; rc=$?; tail -40 gpurun_out/pytest_gpu_full.log > gpurun_out/pytest_gpu.log; echo "pytest exit: $rc" >> gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 echo "smoke exit: $?" >> gpurun_out/smoke.log
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
