@@ -213,6 +213,17 @@ struct rl_engine {
         u32 hot_long = 0;
         hipEvent_t done_event = nullptr;  // the caller's, recorded behind the replay when it goes out (rl_check_and_update_submit_device_ev)
     } pend;
+    // RL_DEFER2=1 (experiment builds; prepared in round 4, not yet run on a GPU): the replay of the batch BEFORE `pend`, held
+    // back across one more submit.  With today's kernel times the partition of batch p ends ~25 us after the submit of batch
+    // p + 1 — while the replay of batch p - 1 is running and the host is spinning in its collect — so four replays out of five
+    // go out behind a wait command (n_wait_parted), and a wait on an event that is not complete when it is enqueued costs the
+    // stream 5.4 us at the boundary however long ago the event completed by then (scripts/microbench/kernel_gap2.hip:
+    // 3.6 -> 9.0 us between two kernels).  Held back, the replay goes out from the collect's spin the moment the host sees its
+    // partition's event complete — no wait command, still 25 us before the stream needs it.  Order among replays, the
+    // partition -> replay dependency (the host has SEEN the event, or the wait command goes in as before) and everything
+    // the in-flight limit guarantees (batch p - 3 collected before batch p is submitted) are unchanged.
+    PendingApply pend_old;
+    bool defer2 = false;
     hipEvent_t submit_done_event = nullptr;  // (argument of the submit being processed)
     hipEvent_t input_event = nullptr;        // rl_engine_wait_event on a two-stream engine: gates the next batch's inputs
     u32 pipe_depth = 3;             // RL_PIPE_DEPTH (2 or 3): the partition of batch p waits for k_bkt_apply of batch p - depth
@@ -508,11 +519,18 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
 
 
 // Spin until the batch's last workgroup has stored its sequence number (see apply_finish).
-int wait_done(rl_engine* e, rl_engine::Inflight& f) {
+int poll_pending_apply(rl_engine* e);
+
+// `poll` (RL_DEFER2): while the host waits, replays that are held back go out as soon as their partitions are seen complete.
+int wait_done(rl_engine* e, rl_engine::Inflight& f, bool poll = false) {
     const volatile u32* done = &f.h_st->n_removed;
     const auto t_start = std::chrono::steady_clock::now();
     for (u64 spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != f.seq; ++spins) {
         __builtin_ia32_pause();
+        if (poll && (spins & 63u) == 63u && (e->pend_old.valid || e->pend.valid)) {
+            const int prc = poll_pending_apply(e);
+            if (prc) return prc;
+        }
         if ((spins & 0xFFFFu) == 0xFFFFu) {
             if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
                 return fail(e, RL_ERR_DEVICE, "batch %u did not complete within 60 s", f.seq);
@@ -604,8 +622,7 @@ struct PartLaunch {
 
 // One k_bkt_step launch: the replay that submit_k1_bucketed left pending (rl_engine::PendingApply), if any, and —
 // `part`, engines in the fused mode — the partition of the batch being submitted.
-int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
-    rl_engine::PendingApply& q = e->pend;
+int flush_one(rl_engine* e, rl_engine::PendingApply& q, const PartLaunch* part) {
     if (!q.valid && !part) return RL_OK;
     StepParams S{};
     bool timed = false;
@@ -683,6 +700,36 @@ int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
     HIP_TRY(e, hipGetLastError());
     if (fa && two_streams && e->apply_events && !e->ext_events) HIP_TRY(e, hipEventRecord(e->ev_applied[p & 3u], rs));
     if (done_event) HIP_TRY(e, hipEventRecord(done_event, rs));
+    return RL_OK;
+}
+
+// Everything held back goes out now, oldest first (and, fused engines, the partition of the batch being submitted).
+int flush_pending_apply(rl_engine* e, const PartLaunch* part = nullptr) {
+    if (e->pend_old.valid) {
+        const int rc = flush_one(e, e->pend_old, nullptr);
+        if (rc) return rc;
+    }
+    return flush_one(e, e->pend, part);
+}
+
+// Replays that are held back go out, oldest first, as far as the host sees their partitions complete: no wait command.
+int poll_pending_apply(rl_engine* e) {
+    if (e->pstream == e->stream) return RL_OK;
+    if (e->pend_old.valid) {
+        if (hipEventQuery(e->ev_parted[e->pend_old.p & 3u]) != hipSuccess) {
+            (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
+            return RL_OK;
+        }
+        const int rc = flush_one(e, e->pend_old, nullptr);
+        if (rc) return rc;
+    }
+    if (e->pend.valid) {
+        if (hipEventQuery(e->ev_parted[e->pend.p & 3u]) != hipSuccess) {
+            (void)hipGetLastError();
+            return RL_OK;
+        }
+        return flush_one(e, e->pend, nullptr);
+    }
     return RL_OK;
 }
 
@@ -893,10 +940,21 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     }
     if (two_streams && !chain_p) HIP_TRY(e, hipEventRecord(e->ev_parted[p & 3u], ps));
     // ---- apply --------------------------------------------------------------------------------------
-    // the batch before this one first (its partition is usually complete by now: no wait command), then this one —
+    // the batch before this one first (if its partition is complete by now: no wait command), then this one —
     // now, or when the next batch is submitted / this one collected
-    rc = flush_pending_apply(e);
-    if (rc) return rc;
+    if (e->pend_old.valid) {
+        rc = flush_one(e, e->pend_old, nullptr);
+        if (rc) return rc;
+    }
+    if (e->pend.valid && e->defer2 && e->defer_apply && two_streams && e->pipe_depth >= 3u && !e->external_stream && !e->pend.done_event &&
+        !e->submit_done_event && hipEventQuery(e->ev_parted[e->pend.p & 3u]) != hipSuccess) {
+        (void)hipGetLastError();  // its partition is still running: held back once more (see pend_old)
+        e->pend_old = e->pend;
+        e->pend.valid = false;
+    } else {
+        rc = flush_one(e, e->pend, nullptr);
+        if (rc) return rc;
+    }
     }
     rl_engine::PendingApply& q = e->pend;
     q.valid = true;
@@ -946,22 +1004,22 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 int collect_k1_bucketed(rl_engine* e) {
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
     rl_engine::Inflight& f = e->inflight[e->col_seq & 3u];
+    if (e->pend_old.valid && e->pend_old.slot == (u32)(e->col_seq & 3u)) {  // the batch being collected is itself held back
+        const int prc = flush_one(e, e->pend_old, nullptr);
+        if (prc) return prc;
+    }
     if (e->pend.valid && e->pend.slot == (u32)(e->col_seq & 3u)) {  // nothing was submitted behind it: its k_bkt_apply goes out now
         const int prc = flush_pending_apply(e);
         if (prc) return prc;
-    } else if (e->pend.valid && e->pstream != e->stream) {
-        // The replay of a LATER batch is still held back (the pipeline is draining: no submit came to send it out).  If
-        // its partition has finished, it goes out now, behind the replay this collect waits for — not after it, when the
-        // stream would sit idle for a launch latency.  (Not finished yet: it stays held back, no wait command.)
-        if (hipEventQuery(e->ev_parted[e->pend.p & 3u]) == hipSuccess) {
-            const int prc = flush_pending_apply(e);
-            if (prc) return prc;
-        } else {
-            (void)hipGetLastError();
-        }
+    } else if (e->pend.valid || e->pend_old.valid) {
+        // The replay of a LATER batch is still held back (the pipeline is draining: no submit came to send it out — or
+        // RL_DEFER2).  If its partition has finished, it goes out now, behind the replay this collect waits for — not after
+        // it, when the stream would sit idle for a launch latency.  (Not finished yet: it stays held back, no wait command.)
+        const int prc = poll_pending_apply(e);
+        if (prc) return prc;
     }
     if (!f.settled) {
-        const int wrc = wait_done(e, f);
+        const int wrc = wait_done(e, f, e->defer2);
         if (wrc) {
             // give the slot up (a stuck batch must not leave the engine RL_ERR_BUSY for ever); the table's
             // state is unknown from here on, which is what the device error tells the caller
@@ -1599,6 +1657,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->fuse = e->max_batch <= (1u << 18);
     if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_DEFER2")) e->defer2 = atoi(v) != 0;
     if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch
     if (const char* v = RL_EXP_ENV("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
     if (const char* v = RL_EXP_ENV("RL_HOT_WGS")) e->hot_wgs = (u32)std::min(std::max(atoi(v), 8), 1024);

@@ -2,6 +2,8 @@
 long hash buckets (window pass, deferred ring, LDS rebuilds), hot-key buckets (decided from their
 position; replayed when they do not fit that form), hot-set promotion / demotion, and the fallbacks.
 Every case is bit-exact against the CPU oracle.  Needs a MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,12 +14,20 @@ from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["engine_default", "two_streams"])
+# RL_DEFER2 was written without a GPU at hand (end of round 4): its runs join the suite with RL_TEST_DEFER2=1 until a visit
+# has seen them green (then: drop the switch and make it the default if it is faster).
+_FORMS = ["engine_default", "two_streams"] + (["two_streams_replays_held_back"] if os.environ.get("RL_TEST_DEFER2") == "1" else [])
+
+
+@pytest.fixture(autouse=True, params=_FORMS)
 def pipeline_form(request, monkeypatch):
     """Engines as small as these tests' run the fused form by default (one stream, one launch per step); every test here
-    also runs on the two-stream pipeline that engines for large batches use."""
-    if request.param == "two_streams":
+    also runs on the two-stream pipeline that engines for large batches use, and on that pipeline with a replay held back
+    across one more submit until the host sees its partition complete (RL_DEFER2, rl_engine::pend_old)."""
+    if request.param != "engine_default":
         monkeypatch.setenv("RL_FUSE", "0")
+    if request.param == "two_streams_replays_held_back":
+        monkeypatch.setenv("RL_DEFER2", "1")
 
 SEED = 0x9E3779B97F4A7C15  # Engine's default hash_seed
 M64 = (1 << 64) - 1
