@@ -1,3 +1,9 @@
+"""Model of the in-place compaction (limitador_amd/csrc/rl_kernels.hpp: k_compact_bounds + k_compact_seg) — the same walk, slot
+for slot: segment bounds = the first EMPTY slot at or after every SEG-th slot of the UNMODIFIED table; a wave owns the clusters
+that start inside its segment and walks them in 64-slot steps through a window (64 + EXTRA slots read ahead); a cluster without
+room in its first 64 slots for what lies behind them takes the slow path (the table itself as state).  Checked: no tombstone is
+left, exactly the live keys remain, every one is reachable from its home slot by linear probing.  tests/test_compact_algorithm_cpu.py
+runs it; `python scripts/model/compact_in_place.py` runs 400 cases."""
 import random
 EMPTY, TOMB = -1, -2
 SEG=256; EXTRA=16
@@ -79,8 +85,10 @@ def run(cap,nkeys,ndel,seed):
         s=home[k]
         while t[s]!=k:
             assert t[s]!=EMPTY,("unreachable",k); s=(s+1)%cap
-for seed in range(400):
+def case(seed):
     cap=random.Random(seed).choice([64,128,256,1024,2048])
     load=random.Random(seed+1).uniform(0.2,0.85)
     n=int(cap*load); run(cap,n,random.Random(seed+2).randrange(0,n+1),seed)
-print("ok")
+if __name__ == "__main__":
+    for seed in range(400): case(seed)
+    print("ok")
