@@ -311,6 +311,13 @@ struct rl_engine {
     rl_stats_t stats{};
 
     int timing = 0;  // 0 off, 1 every kernel of the hot path, 2 k_bkt_apply only, 3 k_bkt_apply of every 4th batch
+    // RL_TIMING_LAZY=1 (experiment builds; prepared in round 4, not yet run on a GPU): a timed batch's events are not read in its
+    // own collect — two hipEventSynchronize and up to four hipEventElapsedTime between that collect and the next submit, which
+    // is what every fourth gap of the replay stream carries on top (profiles/r04f_kernel_stats.csv) — but at the start of the
+    // NEXT collect, in front of its wait for a batch the device is still busy with (the events of an in-flight slot live
+    // until the slot is reused four batches on; "applied" of the batch before until the replay three batches on goes out).
+    bool timing_lazy = false;
+    int timing_todo = -1;  // in-flight slot whose timed events are still to be read
     hipEvent_t ev[8]{};
     double ms_slot[RL_TIMING_SLOTS]{};
     u64 timed_launches = 0;
@@ -520,6 +527,8 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
 
 // Spin until the batch's last workgroup has stored its sequence number (see apply_finish).
 int poll_pending_apply(rl_engine* e);
+int read_timing(rl_engine* e, rl_engine::Inflight& f);
+int read_timing_todo(rl_engine* e);
 
 // `poll` (RL_DEFER2): while the host waits, replays that are held back go out as soon as their partitions are seen complete.
 int wait_done(rl_engine* e, rl_engine::Inflight& f, bool poll = false) {
@@ -778,6 +787,10 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         if (rc) return rc;
     }
     e->gen_clean = false;  // (this batch's scratch block is not the general resolver's to find clean)
+    if (e->timing_todo == (int)(e->sub_seq & 3u)) {  // (RL_TIMING_LAZY: the slot's events are about to be recorded again)
+        rc = read_timing_todo(e);
+        if (rc) return rc;
+    }
     rl_engine::Inflight& f = e->inflight[e->sub_seq & 3u];
     // timing: 1 both kernels of every batch, 2 k_bkt_apply of every batch, 3 both kernels of every fourth batch
     const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
@@ -1004,6 +1017,12 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 int collect_k1_bucketed(rl_engine* e) {
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
     rl_engine::Inflight& f = e->inflight[e->col_seq & 3u];
+    if (e->timing_todo >= 0) {
+        // RL_TIMING_LAZY: the timed events of the batch collected before this one — read here, in front of the wait for this
+        // batch (the device is busy with it), and before anything below sends out a replay that takes over one of those events
+        const int trc = read_timing_todo(e);
+        if (trc) return trc;
+    }
     if (e->pend_old.valid && e->pend_old.slot == (u32)(e->col_seq & 3u)) {  // the batch being collected is itself held back
         const int prc = flush_one(e, e->pend_old, nullptr);
         if (prc) return prc;
@@ -1118,6 +1137,17 @@ int collect_k1_bucketed(rl_engine* e) {
     e->stats.batches++;
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
+    if (f.timed && e->timing_lazy) {
+        const int trc = read_timing_todo(e);  // (a batch timed before this one whose events nobody has read yet)
+        if (trc) return trc;
+        e->timing_todo = (int)((e->col_seq - 1) & 3u);
+        return RL_OK;
+    }
+    return read_timing(e, f);
+}
+
+// The timed launches' events of one collected batch -> the engine's timing sums (rl_kernel_timing_read).
+int read_timing(rl_engine* e, rl_engine::Inflight& f) {
     if (f.timed) {
         // start events: k_bkt_part tev[0], k_bkt_apply / k_bkt_tiny tev[4]; the stop events are the ones the streams
         // hand to each other anyway ("partitioned" / "applied") or tev[1] / tev[5]
@@ -1143,6 +1173,13 @@ int collect_k1_bucketed(rl_engine* e) {
         if (f.timed & 2) e->timed_launches++;
     }
     return RL_OK;
+}
+
+int read_timing_todo(rl_engine* e) {
+    if (e->timing_todo < 0) return RL_OK;
+    rl_engine::Inflight& f = e->inflight[e->timing_todo];
+    e->timing_todo = -1;
+    return read_timing(e, f);
 }
 
 // check_and_update for single-counter requests, all pointers on the device: the bucketed
@@ -1658,6 +1695,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_DEFER2")) e->defer2 = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_TIMING_LAZY")) e->timing_lazy = atoi(v) != 0;
     if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch
     if (const char* v = RL_EXP_ENV("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
     if (const char* v = RL_EXP_ENV("RL_HOT_WGS")) e->hot_wgs = (u32)std::min(std::max(atoi(v), 8), 1024);
@@ -3337,6 +3375,7 @@ int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
 int32_t rl_kernel_timing_read(rl_engine* e, double* ms, uint64_t* launches, int32_t reset) {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
+    (void)read_timing_todo(e);
     if (ms)
         for (int q = 0; q < RL_TIMING_SLOTS; ++q) ms[q] = e->ms_slot[q];
     if (launches) *launches = e->timed_launches;

@@ -25,5 +25,21 @@ except Exception as ex: print(sys.argv[2], "FAILED", ex)
 PY
   done
 done
+# RL_TIMING_LAZY=1 (also prepared without a GPU): a timed batch's events are read at the start of the NEXT collect instead of
+# between its own collect and the next submit (the 4-5 us every fourth gap carries on top).  Parity is not involved (host-side
+# reads of events); what to check: roofline.avg_launch_ms / pipeline.kernel_ms_per_batch are still filled and agree with rocprofv3.
+for cfg in "0 0" "0 1" "1 1"; do
+  set -- $cfg
+  for steps in 20 200; do
+    RL_DEFER2=$1 RL_TIMING_LAZY=$2 bench --steps $steps --warmup 6 > "$out/d$1_l$2_s$steps.json" 2> "$out/d$1_l$2_s$steps.err"
+    python - "$out/d$1_l$2_s$steps.json" "defer2=$1 timing_lazy=$2 steps=$steps" <<'PY'
+import json,sys
+try:
+    d=[json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")][-1]; p=d["pipeline"]
+    print(sys.argv[2], round(d["value"]/1e9,2),"G/s", round(d["ms_per_step"]*1e3,1),"us/step launch", round(d["roofline"]["avg_launch_ms"]*1e3,1), "part", round(p["kernel_ms_per_batch_in_pipeline"]["part"]*1e3,1), "replay stream idle", round(p["apply_stream_idle_ms_per_batch"]*1e3,1))
+except Exception as ex: print(sys.argv[2], "FAILED", ex)
+PY
+  done
+done
 # how many wait commands went in (printed when the engine is destroyed; the trace mode itself slows the host down)
 for d2 in 0 1; do RL_DEFER2=$d2 RL_APPLY_TRACE=1 RL_APPLY_TRACE_AT=999999 bench --steps 100 --warmup 5 2>&1 >/dev/null | grep "wait commands" | sed "s/^/defer2=$d2 /"; done
