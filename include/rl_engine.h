@@ -50,7 +50,8 @@ typedef enum {
     RL_ERR_BATCH_TOO_LARGE = -7,
     RL_ERR_NOMEM = -8,
     RL_ERR_BUSY = -9,           /* batches are in flight (rl_check_and_update_submit_device): collect them first */
-    RL_ERR_KEY_COLLISION = -10  /* hashed keys (rl_wire_*): two counters share a 64-bit key; nothing was applied */
+    RL_ERR_KEY_COLLISION = -10, /* hashed keys (rl_wire_*): two counters share a 64-bit key; nothing was applied */
+    RL_ERR_INTERNAL = -11       /* a C++ exception was stopped at the boundary (rl_last_internal_error); see below */
 } rl_status;
 
 /* bit 31 of a limit id marks a counter of a limit WITHOUT variables ("simple", the
@@ -489,6 +490,19 @@ enum {
 };
 int32_t rl_kernel_timing(rl_engine *e, int32_t enable);
 int32_t rl_kernel_timing_read(rl_engine *e, double *ms, uint64_t *launches, int32_t reset);
+
+/* No C++ exception crosses this boundary (the reference's errors are values, storage/mod.rs:312-339, and its in-memory
+ * path never fails, in_memory.rs:72-156): every entry point of librl_engine.so, librl_storage.so and librl_sharded.so
+ * that can allocate behind the call ends in the same barrier (limitador_amd/csrc/rl_abi_guard.h).  std::bad_alloc comes
+ * back as RL_ERR_NOMEM, anything else as RL_ERR_INTERNAL; rl_last_internal_error() is the calling thread's last such
+ * message ("entry point: what()").  The device table is only written by kernels of a batch the call had already
+ * validated, so the counters are as the call found them or as the batch made them.
+ * rl_abi_selftest throws behind the barrier — kind 1 std::bad_alloc, 2 std::length_error, 3 an object that is no
+ * std::exception, 4 a vector resized to 2^58 elements (a real failed allocation), 5 a reserve beyond max_size — and
+ * returns what the barrier made of it; it touches no engine and needs no device (tests/test_abi_barrier.py). */
+const char *rl_last_internal_error(void);
+int32_t rl_abi_selftest(int32_t kind);
+int32_t rl_abi_caught(const char *fn, const char *what, int32_t status); /* (the barrier's landing pad; not for callers) */
 
 #ifdef __cplusplus
 }

@@ -155,6 +155,8 @@ void rli_frontend_set_clock(rli_frontend *f, uint64_t now_us); /* tests: a fixed
 int32_t rli_frontend_should_rate_limit(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp,
                                        uint32_t resp_cap, uint32_t *resp_len);
 void rli_frontend_stats(rli_frontend *f, uint64_t *batches, uint64_t *requests);
+/* exception barrier self-test of THIS library (rl_engine.h: rl_abi_selftest; kinds 1-4) */
+int32_t rli_abi_selftest(int32_t kind);
 
 /* Dictionary look-ups (tests, diagnostics): id of a string, -1 if it was never interned. */
 int64_t rli_key_id(const rli_ingest *g, const char *key);

@@ -122,6 +122,8 @@ int32_t rl_sharded_check_requests_device(rl_sharded *s, const rl_hit *d_hits, ui
 void *rl_sharded_stream(rl_sharded *s);
 int32_t rl_sharded_sync(rl_sharded *s);
 uint32_t rl_sharded_in_flight(const rl_sharded *s);
+/* exception barrier self-test of THIS library (rl_engine.h: rl_abi_selftest; kinds 1-4) */
+int32_t rl_sharded_abi_selftest(int32_t kind);
 
 /* In-process transport: `world` ranks in one process (one thread per rank; any mix of devices with peer
  * access, or all on one device).  exchange() is a rendezvous: it waits for every rank's send buffers,

@@ -81,6 +81,8 @@ int32_t rls_clear(rls_storage *s);
  * under caller-controlled descriptor values).  It runs by itself once `n_new_counters` new counters have been
  * interned since the last sweep (default 2^20; 0 = never). */
 int32_t rls_sweep_expired(rls_storage *s, uint64_t *n_removed);
+/* exception barrier self-test of THIS library (rl_engine.h: rl_abi_selftest; kinds 1-4) */
+int32_t rls_abi_selftest(int32_t kind);
 void rls_set_sweep_after(rls_storage *s, uint64_t n_new_counters);
 uint64_t rls_interned_counters(const rls_storage *s);
 

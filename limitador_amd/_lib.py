@@ -129,4 +129,7 @@ def _declare(lib):
     _sig(lib, "rl_host_unregister", C.c_int32, [p, C.c_void_p])
     _sig(lib, "rl_kernel_timing", C.c_int32, [p, C.c_int32])
     _sig(lib, "rl_kernel_timing_read", C.c_int32, [p, C.POINTER(C.c_double), u64p, C.c_int32])
+    _sig(lib, "rl_last_internal_error", C.c_char_p, [])
+    _sig(lib, "rl_abi_selftest", C.c_int32, [C.c_int32])
+    _sig(lib, "rl_abi_caught", C.c_int32, [C.c_char_p, C.c_char_p, C.c_int32])
     del u8p, u32p, i32p

@@ -6,6 +6,9 @@
 #include <cstring>
 
 #include "../../../include/rl_storage.h"
+#include "../rl_abi_guard.h"
+#include <stdexcept>
+#include <vector>
 
 namespace rls {
 
@@ -349,10 +352,17 @@ void MicroBatcher::run() {
         std::vector<Slot*> batch;
         batch.swap(queue_);
         lk.unlock();
-        std::vector<GpuCounterStorage::Request*> reqs;
-        reqs.reserve(batch.size());
-        for (Slot* s : batch) reqs.push_back(&s->req);
-        const int rc = s_->check_and_update_many(reqs);
+        int rc;
+        try {  // (no entry point's barrier above this thread: the callers get the status, the worker lives on)
+            std::vector<GpuCounterStorage::Request*> reqs;
+            reqs.reserve(batch.size());
+            for (Slot* s : batch) reqs.push_back(&s->req);
+            rc = s_->check_and_update_many(reqs);
+        } catch (const std::bad_alloc&) {
+            rc = rl_abi_caught("MicroBatcher worker", "std::bad_alloc (host memory exhausted)", RL_ERR_NOMEM);
+        } catch (...) {
+            rc = rl_abi_caught("MicroBatcher worker", "C++ exception", RL_ERR_INTERNAL);
+        }
         lk.lock();
         ++n_batches_;
         n_requests_ += batch.size();
@@ -417,7 +427,24 @@ void copy_back(const rls::Counter& src, rls_counter* dst) {
 
 extern "C" {
 
-int32_t rls_storage_create(uint64_t capacity_cells, uint32_t max_batch_hits, int32_t device, rls_storage** out) {
+// behind the same barrier as every entry point of this library (../rl_abi_guard.h): proves THIS library was built
+// with it (tests/test_abi_barrier.py, no GPU needed)
+int32_t rls_abi_selftest(int32_t kind) try {
+    std::vector<uint64_t> unwound(16, 1ull);
+    switch (kind) {
+        case 1: throw std::bad_alloc();
+        case 2: throw std::length_error("rls_abi_selftest: std::length_error");
+        case 3: throw 42;
+        case 4: {
+            std::vector<uint64_t> v;
+            v.resize((size_t)1 << 58);
+            return (int32_t)v.size();
+        }
+        default: return RL_OK;
+    }
+} RL_ABI_CATCH
+
+int32_t rls_storage_create(uint64_t capacity_cells, uint32_t max_batch_hits, int32_t device, rls_storage** out) try {
     if (!out) return RL_ERR_INVALID;
     *out = nullptr;
     rls::GpuCounterStorage* s = nullptr;
@@ -425,7 +452,7 @@ int32_t rls_storage_create(uint64_t capacity_cells, uint32_t max_batch_hits, int
     if (rc) return rc;
     *out = new rls_storage{s, {}};
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rls_storage_destroy(rls_storage* s) {
     if (!s) return;
@@ -439,26 +466,26 @@ void rls_set_clock(rls_storage* s, uint64_t now_us) {
     if (s) s->s->set_clock(now_us);
 }
 
-int32_t rls_is_within_limits(rls_storage* s, const rls_counter* counter, uint64_t delta, int32_t* within) {
+int32_t rls_is_within_limits(rls_storage* s, const rls_counter* counter, uint64_t delta, int32_t* within) try {
     if (!s || !counter || !within) return RL_ERR_INVALID;
     bool w = false;
     const int rc = s->s->is_within_limits(to_counter(counter), delta, &w);
     *within = w ? 1 : 0;
     return rc;
-}
+} RL_ABI_CATCH
 
-int32_t rls_add_counter(rls_storage* s, const rls_limit* limit) {
+int32_t rls_add_counter(rls_storage* s, const rls_limit* limit) try {
     if (!s || !limit) return RL_ERR_INVALID;
     return s->s->add_counter(to_limit(limit));
-}
+} RL_ABI_CATCH
 
-int32_t rls_update_counter(rls_storage* s, const rls_counter* counter, uint64_t delta) {
+int32_t rls_update_counter(rls_storage* s, const rls_counter* counter, uint64_t delta) try {
     if (!s || !counter) return RL_ERR_INVALID;
     return s->s->update_counter(to_counter(counter), delta);
-}
+} RL_ABI_CATCH
 
 int32_t rls_check_and_update(rls_storage* s, rls_counter* counters, uint32_t n, uint64_t delta, int32_t load_counters,
-                             int32_t* limited, int32_t* limited_idx) {
+                             int32_t* limited, int32_t* limited_idx) try {
     if (!s || (n && !counters) || !limited) return RL_ERR_INVALID;
     std::vector<rls::Counter> cs;
     for (uint32_t i = 0; i < n; ++i) cs.push_back(to_counter(&counters[i]));
@@ -469,9 +496,9 @@ int32_t rls_check_and_update(rls_storage* s, rls_counter* counters, uint32_t n, 
     *limited = a.limited ? 1 : 0;
     if (limited_idx) *limited_idx = a.limited_idx;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rls_get_counters(rls_storage* s, const rls_limit* limits, uint32_t n_limits, rls_emit_fn emit, void* user) {
+int32_t rls_get_counters(rls_storage* s, const rls_limit* limits, uint32_t n_limits, rls_emit_fn emit, void* user) try {
     if (!s || (n_limits && !limits) || !emit) return RL_ERR_INVALID;
     std::vector<rls::Limit> ls;
     for (uint32_t i = 0; i < n_limits; ++i) ls.push_back(to_limit(&limits[i]));
@@ -488,18 +515,22 @@ int32_t rls_get_counters(rls_storage* s, const rls_limit* limits, uint32_t n_lim
              pc.second.expires_in_us);
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rls_delete_counters(rls_storage* s, const rls_limit* limits, uint32_t n_limits) {
+int32_t rls_delete_counters(rls_storage* s, const rls_limit* limits, uint32_t n_limits) try {
     if (!s || (n_limits && !limits)) return RL_ERR_INVALID;
     std::vector<rls::Limit> ls;
     for (uint32_t i = 0; i < n_limits; ++i) ls.push_back(to_limit(&limits[i]));
     return s->s->delete_counters(ls);
-}
+} RL_ABI_CATCH
 
-int32_t rls_clear(rls_storage* s) { return s ? s->s->clear() : RL_ERR_INVALID; }
+int32_t rls_clear(rls_storage* s) try {
+    return s ? s->s->clear() : RL_ERR_INVALID;
+} RL_ABI_CATCH
 
-int32_t rls_sweep_expired(rls_storage* s, uint64_t* n_removed) { return s ? s->s->sweep_expired(n_removed) : RL_ERR_INVALID; }
+int32_t rls_sweep_expired(rls_storage* s, uint64_t* n_removed) try {
+    return s ? s->s->sweep_expired(n_removed) : RL_ERR_INVALID;
+} RL_ABI_CATCH
 
 void rls_set_sweep_after(rls_storage* s, uint64_t n_new_counters) {
     if (s) s->s->set_sweep_after(n_new_counters);
@@ -507,11 +538,11 @@ void rls_set_sweep_after(rls_storage* s, uint64_t n_new_counters) {
 
 uint64_t rls_interned_counters(const rls_storage* s) { return s ? (uint64_t)s->s->interned_counters() : 0; }
 
-int32_t rls_batcher_create(rls_storage* s, uint32_t max_batch, uint32_t max_delay_us, rls_batcher** out) {
+int32_t rls_batcher_create(rls_storage* s, uint32_t max_batch, uint32_t max_delay_us, rls_batcher** out) try {
     if (!s || !out) return RL_ERR_INVALID;
     *out = new rls_batcher{new rls::MicroBatcher(s->s, max_batch, max_delay_us), s};
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rls_batcher_destroy(rls_batcher* b) {
     if (!b) return;
@@ -520,7 +551,7 @@ void rls_batcher_destroy(rls_batcher* b) {
 }
 
 int32_t rls_batcher_check_and_update(rls_batcher* b, rls_counter* counters, uint32_t n, uint64_t delta,
-                                     int32_t load_counters, int32_t* limited, int32_t* limited_idx) {
+                                     int32_t load_counters, int32_t* limited, int32_t* limited_idx) try {
     if (!b || (n && !counters) || !limited) return RL_ERR_INVALID;
     std::vector<rls::Counter> cs;
     for (uint32_t i = 0; i < n; ++i) cs.push_back(to_counter(&counters[i]));
@@ -531,10 +562,10 @@ int32_t rls_batcher_check_and_update(rls_batcher* b, rls_counter* counters, uint
     *limited = a.limited ? 1 : 0;
     if (limited_idx) *limited_idx = a.limited_idx;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rls_check_and_update_repeat(rls_storage* s, rls_counter* counters, uint32_t n, uint64_t delta, uint32_t iterations,
-                                    uint64_t* elapsed_ns, uint32_t* n_limited) {
+                                    uint64_t* elapsed_ns, uint32_t* n_limited) try {
     if (!s || (n && !counters) || !elapsed_ns) return RL_ERR_INVALID;
     std::vector<rls::Counter> cs;
     for (uint32_t i = 0; i < n; ++i) cs.push_back(to_counter(&counters[i]));
@@ -549,7 +580,7 @@ int32_t rls_check_and_update_repeat(rls_storage* s, rls_counter* counters, uint3
     *elapsed_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     if (n_limited) *n_limited = limited;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rls_batcher_stats(rls_batcher* b, uint64_t* batches, uint64_t* requests) {
     uint64_t nb = 0, nr = 0;

@@ -9,6 +9,8 @@
 // caller (RLI_HOST_ONLY).
 #include "../../../include/rl_ingest.h"
 #include "../../../include/rl_keyhash.h"
+#include "../rl_abi_guard.h"
+#include <stdexcept>
 
 #include <algorithm>
 #include <atomic>
@@ -287,6 +289,11 @@ class ChunkPool {
         const std::function<void(uint32_t)>* f;
         uint32_t total;
         std::atomic<uint32_t> next{0};
+        // An exception in a chunk (std::bad_alloc while a helper encodes its share) must not end a helper thread —
+        // that is std::terminate for the whole host.  The first one is kept and rethrown by run() on the CALLER's
+        // thread, where the entry point's barrier (rl_abi_guard.h) turns it into a status.
+        std::mutex err_mu;
+        std::exception_ptr err;
     };
 
 public:
@@ -315,6 +322,8 @@ public:
         std::unique_lock<std::mutex> l(mu);
         job = nullptr;  // (a helper that wakes up late finds no job)
         cv_done.wait(l, [&] { return active == 0; });
+        l.unlock();
+        if (j.err) std::rethrow_exception(j.err);
     }
 
 private:
@@ -335,7 +344,13 @@ private:
         for (;;) {
             const uint32_t c = j.next.fetch_add(1, std::memory_order_relaxed);
             if (c >= j.total) break;
-            (*j.f)(c);
+            try {
+                (*j.f)(c);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(j.err_mu);
+                if (!j.err) j.err = std::current_exception();
+                j.next.store(j.total, std::memory_order_relaxed);  // (nobody starts another chunk of a failed job)
+            }
         }
     }
     void loop() {
@@ -379,14 +394,31 @@ static void parallel_chunks(uint32_t n, uint32_t threads, F f) {  // f(lo, hi)
 
 extern "C" {
 
-int32_t rli_create(rli_ingest** out) {
+// behind the same barrier as every entry point of this library (../rl_abi_guard.h): proves THIS library was built
+// with it (tests/test_abi_barrier.py, no GPU needed)
+int32_t rli_abi_selftest(int32_t kind) try {
+    std::vector<uint64_t> unwound(16, 1ull);
+    switch (kind) {
+        case 1: throw std::bad_alloc();
+        case 2: throw std::length_error("rli_abi_selftest: std::length_error");
+        case 3: throw 42;
+        case 4: {
+            std::vector<uint64_t> v;
+            v.resize((size_t)1 << 58);
+            return (int32_t)v.size();
+        }
+        default: return RL_OK;
+    }
+} RL_ABI_CATCH
+
+int32_t rli_create(rli_ingest** out) try {
     if (!out) return RL_ERR_INVALID;
     rli_ingest* g = new (std::nothrow) rli_ingest();
     if (!g) return RL_ERR_NOMEM;
     g->ns_ids.intern("");  // namespace id 0: the namespace without limits
     *out = g;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rli_destroy(rli_ingest* g) { delete g; }
 
@@ -394,7 +426,7 @@ const char* rli_last_error(const rli_ingest* g) { return g ? g->err.c_str() : "n
 
 int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_t seconds,
                       const char* const* conditions, uint32_t n_conditions, const char* const* variables,
-                      uint32_t n_variables) {
+                      uint32_t n_variables) try {
     if (!g || !ns || (n_conditions && !conditions) || (n_variables && !variables)) return RL_ERR_INVALID;
     if (!*ns) return gfail(g, RL_ERR_INVALID, "empty namespace");
     LimitSpec L;
@@ -438,7 +470,7 @@ int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_
     g->limits.push_back(std::move(L));
     g->compiled = false;
     return (int32_t)id;
-}
+} RL_ABI_CATCH
 
 
 // The canonical key bytes of a counter WITHOUT its variables' values (include/rl_keyhash.h; storage/keys.rs:220-248:
@@ -466,7 +498,7 @@ static rl_h128 canonical_prefix_hash(const LimitSpec& L) {
     return rl_kh_bytes(reinterpret_cast<const uint8_t*>(o.data()), (uint32_t)o.size(), 0ull);
 }
 
-int32_t rli_compile(rli_ingest* g) {
+int32_t rli_compile(rli_ingest* g) try {
     if (!g) return RL_ERR_INVALID;
     const uint32_t n = (uint32_t)g->limits.size();
     g->rows.assign(n, rl_limit_row{0, 0});
@@ -499,7 +531,7 @@ int32_t rli_compile(rli_ingest* g) {
     }
     g->compiled = true;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 uint32_t rli_n_limits(const rli_ingest* g) { return g ? (uint32_t)g->limits.size() : 0; }
 uint32_t rli_n_conds(const rli_ingest* g) { return g ? (uint32_t)g->conds.size() : 0; }
@@ -508,7 +540,7 @@ const rl_limit_row* rli_limit_rows(const rli_ingest* g) { return g && g->compile
 const rl_match_limit* rli_match_limits(const rli_ingest* g) { return g && g->compiled ? g->table.data() : nullptr; }
 const rl_match_cond* rli_match_conds(const rli_ingest* g) { return g && g->compiled ? g->conds.data() : nullptr; }
 
-int32_t rli_install(rli_ingest* g, rl_engine* e) {
+int32_t rli_install(rli_ingest* g, rl_engine* e) try {
     if (!g || !e) return RL_ERR_INVALID;
     if (!g->compiled) {
         const int32_t rc = rli_compile(g);
@@ -550,17 +582,17 @@ int32_t rli_install(rli_ingest* g, rl_engine* e) {
             if (rc) return gfail(g, rc, "rl_add_counter: %s", rl_last_error(e));
         }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rli_set_key_mode(rli_ingest* g, int32_t mode) {
+int32_t rli_set_key_mode(rli_ingest* g, int32_t mode) try {
     if (!g || (mode != RLI_KEYS_EXACT && mode != RLI_KEYS_HASHED)) return RL_ERR_INVALID;
     if (!g->req_ns.empty()) return gfail(g, RL_ERR_INVALID, "the key mode is chosen before the first request is added");
     g->key_mode = mode;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rli_counter_key(rli_ingest* g, uint32_t limit_id, const char* const* values, const uint32_t* value_lens,
-                        uint32_t n_values, uint64_t* key, uint32_t* check) {
+                        uint32_t n_values, uint64_t* key, uint32_t* check) try {
     if (!g || !key || limit_id >= g->limits.size() || (n_values && (!values || !value_lens))) return RL_ERR_INVALID;
     if (!g->compiled) {
         const int32_t rc = rli_compile(g);
@@ -574,7 +606,7 @@ int32_t rli_counter_key(rli_ingest* g, uint32_t limit_id, const char* const* val
     rl_counter_key(g->prefix[limit_id], v, n_values, key, &chk);
     if (check) *check = chk;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rli_batch_clear(rli_ingest* g) {
     if (!g) return;
@@ -679,7 +711,7 @@ static int32_t batch_add_sv(rli_ingest* g, const std::string& ns, const std::vec
 }
 
 int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, const char* const* values,
-                      uint32_t n_entries, uint32_t delta) {
+                      uint32_t n_entries, uint32_t delta) try {
     if (!g || !ns || (n_entries && (!keys || !values))) return RL_ERR_INVALID;
     std::vector<std::pair<std::string, std::string>> entries;
     for (uint32_t q = 0; q < n_entries; ++q) {
@@ -687,20 +719,20 @@ int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, co
         entries.emplace_back(keys[q], values[q]);
     }
     return batch_add_sv(g, ns, entries, delta);
-}
+} RL_ABI_CATCH
 
-int32_t rli_set_binding(rli_ingest* g, int32_t binding) {
+int32_t rli_set_binding(rli_ingest* g, int32_t binding) try {
     if (!g || (binding != RLI_BIND_DESCRIPTORS && binding != RLI_BIND_ROOT)) return RL_ERR_INVALID;
     if (!g->limits.empty()) return gfail(g, RL_ERR_INVALID, "the binding is chosen before the first limit is added");
     g->binding = binding;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rli_set_value_cap(rli_ingest* g, uint32_t cap) {
+int32_t rli_set_value_cap(rli_ingest* g, uint32_t cap) try {
     if (!g || cap == 0 || cap > (1u << 26)) return RL_ERR_INVALID;  // value ids travel in 26 bits (rl_match_key)
     g->value_cap = cap;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 // A serialized RateLimitRequest -> (domain, entries of descriptors[0], delta).  Pure: no ingest state.
 // 0, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID with *what = the part that is malformed.
@@ -735,7 +767,7 @@ static int32_t decode_rls(const uint8_t* msg, uint32_t len, std::string* domain,
     return 0;
 }
 
-int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) {
+int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) try {
     if (!g || (len && !msg)) return RL_ERR_INVALID;
     std::string domain;
     std::vector<std::pair<std::string, std::string>> entries;
@@ -745,7 +777,7 @@ int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) {
     if (rc == RLI_UNKNOWN_DOMAIN) return rc;
     if (rc) return gfail(g, rc, "malformed RateLimitRequest (%s)", what);
     return batch_add_sv(g, domain, entries, delta);
-}
+} RL_ABI_CATCH
 
 uint32_t rli_batch_n_requests(const rli_ingest* g) { return g ? (uint32_t)g->req_ns.size() : 0; }
 uint32_t rli_batch_n_entries(const rli_ingest* g) { return g ? (uint32_t)g->ent_key.size() : 0; }
@@ -755,7 +787,7 @@ const uint32_t* rli_batch_ent_off(const rli_ingest* g) { return g ? g->ent_off.d
 const uint32_t* rli_batch_ent_key(const rli_ingest* g) { return g ? g->ent_key.data() : nullptr; }
 const uint32_t* rli_batch_ent_val(const rli_ingest* g) { return g ? g->ent_val.data() : nullptr; }
 
-int32_t rli_check(rli_ingest* g, rl_engine* e, uint64_t now_us, uint8_t* verdict, int32_t* limited_limit) {
+int32_t rli_check(rli_ingest* g, rl_engine* e, uint64_t now_us, uint8_t* verdict, int32_t* limited_limit) try {
     if (!g || !e || !verdict) return RL_ERR_INVALID;
     const uint32_t n = (uint32_t)g->req_ns.size();
     if (!n) return RL_OK;
@@ -765,7 +797,7 @@ int32_t rli_check(rli_ingest* g, rl_engine* e, uint64_t now_us, uint8_t* verdict
                                                 nullptr, 0, &n_hits, nullptr, nullptr);
     if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 uint32_t rli_rls_response(int32_t verdict, uint8_t out[2]) {
     // RateLimitResponse { Code overall_code = 1 }: UNKNOWN = 0 is the default and is not put on the wire
@@ -775,12 +807,12 @@ uint32_t rli_rls_response(int32_t verdict, uint8_t out[2]) {
     return 2;
 }
 
-int32_t rli_set_limit_name(rli_ingest* g, uint32_t limit_id, const char* name) {
+int32_t rli_set_limit_name(rli_ingest* g, uint32_t limit_id, const char* name) try {
     if (!g || limit_id >= g->limits.size()) return RL_ERR_INVALID;
     g->limits[limit_id].has_name = name != nullptr;
     g->limits[limit_id].name = name ? name : "";
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 // ---- serving: RateLimitRequest bytes in, RateLimitResponse bytes out -----------------------------------------
 namespace {
@@ -802,7 +834,7 @@ void put_string_field(std::string& o, uint32_t field, const std::string& v) {
 
 int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
                         uint64_t now_us, int32_t with_headers, uint8_t* out, uint32_t out_stride, uint32_t* out_len,
-                        int32_t* status) {
+                        int32_t* status) try {
     if (!g || !e || (n && (!msgs || !lens || !out || !out_len || !status)) || out_stride < 2) return RL_ERR_INVALID;
     rli_batch_clear(g);
     if (n == 0) return RL_OK;
@@ -1084,7 +1116,7 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
     if (too_long.load())  // (not an error of the call: the message names the size a retry needs)
         (void)gfail(g, RL_OK, "a response of %u bytes does not fit the stride %u: status RLI_RESPONSE_TOO_LARGE for it", too_long.load(), out_stride);
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 // The micro-batcher of the wire path: concurrent ShouldRateLimit callers are aggregated into one device batch,
 // closed at max_batch requests or max_delay_us after its first request arrived, stamped with ONE clock value
@@ -1126,21 +1158,33 @@ struct rli_frontend {
             }
             lk.unlock();
             const uint32_t n = (uint32_t)batch.size();
-            std::vector<const uint8_t*> msgs(n);
-            std::vector<uint32_t> lens(n), out_len(n);
-            std::vector<int32_t> status(n);
-            std::vector<uint8_t> out((size_t)n * stride);
-            for (uint32_t i = 0; i < n; ++i) {
-                msgs[i] = batch[i]->msg;
-                lens[i] = batch[i]->len;
+            std::vector<const uint8_t*> msgs;
+            std::vector<uint32_t> lens, out_len;
+            std::vector<int32_t> status;
+            std::vector<uint8_t> out;
+            int32_t rc;
+            try {  // (this thread has no entry point's barrier above it: its callers get the status, the thread lives on)
+                msgs.resize(n);
+                lens.resize(n);
+                out_len.resize(n);
+                status.resize(n);
+                out.resize((size_t)n * stride);
+                for (uint32_t i = 0; i < n; ++i) {
+                    msgs[i] = batch[i]->msg;
+                    lens[i] = batch[i]->len;
+                }
+                uint64_t now = fixed_now_us;
+                if (!now) {
+                    using namespace std::chrono;
+                    now = (uint64_t)duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
+                }
+                rc = rli_serve_batch(g, e, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride, out_len.data(),
+                                     status.data());
+            } catch (const std::bad_alloc&) {
+                rc = rl_abi_caught("rli_frontend worker", "std::bad_alloc (host memory exhausted)", RL_ERR_NOMEM);
+            } catch (...) {
+                rc = rl_abi_caught("rli_frontend worker", "C++ exception", RL_ERR_INTERNAL);
             }
-            uint64_t now = fixed_now_us;
-            if (!now) {
-                using namespace std::chrono;
-                now = (uint64_t)duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
-            }
-            const int32_t rc = rli_serve_batch(g, e, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride,
-                                               out_len.data(), status.data());
             lk.lock();
             ++n_batches;
             n_requests += n;
@@ -1161,7 +1205,7 @@ struct rli_frontend {
 };
 
 int32_t rli_frontend_create(rli_ingest* g, rl_engine* e, uint32_t max_batch, uint32_t max_delay_us, int32_t with_headers,
-                            rli_frontend** out) {
+                            rli_frontend** out) try {
     if (!g || !e || !out) return RL_ERR_INVALID;
     rli_frontend* f = new (std::nothrow) rli_frontend();
     if (!f) return RL_ERR_NOMEM;
@@ -1174,7 +1218,7 @@ int32_t rli_frontend_create(rli_ingest* g, rl_engine* e, uint32_t max_batch, uin
     f->worker = std::thread([f] { f->run(); });
     *out = f;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rli_frontend_destroy(rli_frontend* f) {
     if (!f) return;
@@ -1192,7 +1236,7 @@ void rli_frontend_set_clock(rli_frontend* f, uint64_t now_us) {
 }
 
 int32_t rli_frontend_should_rate_limit(rli_frontend* f, const uint8_t* msg, uint32_t len, uint8_t* resp, uint32_t resp_cap,
-                                       uint32_t* resp_len) {
+                                       uint32_t* resp_len) try {
     if (!f || (len && !msg) || !resp || !resp_len) return RL_ERR_INVALID;
     rli_frontend::Slot slot;
     slot.msg = msg;
@@ -1205,7 +1249,7 @@ int32_t rli_frontend_should_rate_limit(rli_frontend* f, const uint8_t* msg, uint
     f->cv_done.wait(lk, [&] { return slot.done; });
     *resp_len = slot.resp_len;
     return slot.status;
-}
+} RL_ABI_CATCH
 
 void rli_frontend_stats(rli_frontend* f, uint64_t* batches, uint64_t* requests) {
     if (!f) return;

@@ -4,6 +4,8 @@
 // reference — its in-memory storage is one process (limitador/src/storage/in_memory.rs) — the semantics it
 // must preserve are the sequential ones of check_and_update (in_memory.rs:72-156) on the concatenated slices.
 #include "rl_sharded.h"
+#include "../rl_abi_guard.h"
+#include <stdexcept>
 
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
@@ -379,7 +381,10 @@ int32_t apply_engine_half(rl_sharded* s, Slice& p) {
     if (s->as) {
         // a wait command costs its stream ~9 us even when its event completed long ago: where the HOST can see the exchange
         // complete (the usual case: a 6 us copy enqueued 20 us ago) the apply stream is not made to wait for it
-        if (hipEventQuery(s->ev_exchanged[slot]) != hipSuccess) HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[slot], 0));
+        if (hipEventQuery(s->ev_exchanged[slot]) != hipSuccess) {
+            (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error: do not leave it for the engine's next HIP_TRY)
+            HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[slot], 0));
+        }
     } else {
         ENG_S(s, rl_engine_wait_event(s->e, s->ev_exchanged[slot]));
     }
@@ -514,7 +519,24 @@ int32_t create_common(rl_engine* e, uint32_t world, uint32_t rank, uint32_t max_
 
 extern "C" {
 
-int32_t rl_sharded_unique_id(uint8_t id[RL_UNIQUE_ID_BYTES]) {
+// behind the same barrier as every entry point of this library (../rl_abi_guard.h): proves THIS library was built
+// with it (tests/test_abi_barrier.py, no GPU needed)
+int32_t rl_sharded_abi_selftest(int32_t kind) try {
+    std::vector<uint64_t> unwound(16, 1ull);
+    switch (kind) {
+        case 1: throw std::bad_alloc();
+        case 2: throw std::length_error("rl_sharded_abi_selftest: std::length_error");
+        case 3: throw 42;
+        case 4: {
+            std::vector<uint64_t> v;
+            v.resize((size_t)1 << 58);
+            return (int32_t)v.size();
+        }
+        default: return RL_OK;
+    }
+} RL_ABI_CATCH
+
+int32_t rl_sharded_unique_id(uint8_t id[RL_UNIQUE_ID_BYTES]) try {
     static_assert(sizeof(ncclUniqueId) == RL_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
     if (!id) return RL_ERR_INVALID;
     char why[600];
@@ -527,10 +549,10 @@ int32_t rl_sharded_unique_id(uint8_t id[RL_UNIQUE_ID_BYTES]) {
     if (api->GetUniqueId(&u) != ncclSuccess) return RL_ERR_DEVICE;
     std::memcpy(id, &u, sizeof(u));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_sharded_create(rl_engine* e, uint32_t world, uint32_t rank, const rl_transport* t, uint32_t max_slice_hits,
-                          rl_sharded** out) {
+                          rl_sharded** out) try {
     if (!e || !out || !t || !t->exchange || world == 0 || world > MAX_WORLD || rank >= world) return RL_ERR_INVALID;
     rl_sharded* s = new (std::nothrow) rl_sharded();
     if (!s) return RL_ERR_NOMEM;
@@ -543,10 +565,10 @@ int32_t rl_sharded_create(rl_engine* e, uint32_t world, uint32_t rank, const rl_
     }
     *out = s;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_sharded_create_rccl(rl_engine* e, uint32_t world, uint32_t rank, const uint8_t id[RL_UNIQUE_ID_BYTES],
-                               uint32_t max_slice_hits, rl_sharded** out) {
+                               uint32_t max_slice_hits, rl_sharded** out) try {
     if (!e || !out || !id || world == 0 || world > MAX_WORLD || rank >= world) return RL_ERR_INVALID;
     int32_t dev = 0;
     if (rl_engine_info(e, &dev, nullptr) != RL_OK) return RL_ERR_INVALID;
@@ -580,7 +602,7 @@ int32_t rl_sharded_create_rccl(rl_engine* e, uint32_t world, uint32_t rank, cons
     }
     (*out)->rccl = r;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rl_sharded_destroy(rl_sharded* s) {
     if (!s) return;
@@ -623,7 +645,7 @@ void rl_sharded_destroy(rl_sharded* s) {
 
 const char* rl_sharded_last_error(const rl_sharded* s) { return s ? s->err : "null communicator"; }
 
-int32_t rl_sharded_submit_device(rl_sharded* s, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us, uint8_t* d_verdict) {
+int32_t rl_sharded_submit_device(rl_sharded* s, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us, uint8_t* d_verdict) try {
     if (!s || (n_hits && (!d_hits || !d_verdict))) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(s->mu);
     SH_TRACE("[sh] %9.1f submit(%llu) begin, %zu pending\n", t_us(), (unsigned long long)s->seq, s->pending.size());
@@ -644,9 +666,9 @@ int32_t rl_sharded_submit_device(rl_sharded* s, const rl_hit* d_hits, uint32_t n
     rc = route(s, d_hits, n_hits, now_us, d_verdict, to_return, to_apply);
     SH_TRACE("[sh] %9.1f submit end (returned %zu)\n", t_us(), to_return.size());
     return rc;
-}
+} RL_ABI_CATCH
 
-int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) {
+int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) try {
     if (!s) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(s->mu);
     if (s->pending.empty()) return fail(s, RL_ERR_INVALID, "nothing in flight");
@@ -667,10 +689,10 @@ int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) {
     }
     if (done.err) return fail(s, done.err, "%s (every exchange of the slice was issued; the hits this rank owns were answered 0xFF)", done.errmsg);
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_sharded_check_and_update_device(rl_sharded* s, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
-                                           uint8_t* d_verdict, uint32_t* n_applied) {
+                                           uint8_t* d_verdict, uint32_t* n_applied) try {
     if (!s) return RL_ERR_INVALID;
     if (rl_sharded_in_flight(s)) return RL_ERR_BUSY;
     int32_t rc = rl_sharded_submit_device(s, d_hits, n_hits, now_us, d_verdict);
@@ -678,14 +700,14 @@ int32_t rl_sharded_check_and_update_device(rl_sharded* s, const rl_hit* d_hits, 
     rc = rl_sharded_collect(s, n_applied);
     const int32_t rs = rl_sharded_sync(s);
     return rc != RL_OK ? rc : rs;
-}
+} RL_ABI_CATCH
 
 // ---- multi-counter requests, counters sharded by key (SURVEY.md §8e "k > 1") --------------------------------------
 namespace {
 
 // The arrays of the multi-counter step, allocated at its first call.  (The words every collective decision travels in are
 // allocated with the communicator: a rank that runs out of memory HERE can still tell its peers.)
-int32_t req_bufs(rl_sharded* s) {
+int32_t req_bufs(rl_sharded* s) try {
     if (s->rq.ready) return RL_OK;
     const size_t ms = s->max_slice ? s->max_slice : 1;
     const size_t mr = std::max<size_t>(s->max_recv ? s->max_recv : 1, (size_t)s->world * ms);
@@ -706,7 +728,7 @@ int32_t req_bufs(rl_sharded* s) {
     HIP_S(s, hipMalloc(&q.exp_sorted, ms * 8));
     q.ready = true;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 // One 32-bit word of every rank to every rank (d_send: this rank's, on the device); out[p] = rank p's.  A collective.
 int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out) {
@@ -775,7 +797,7 @@ int32_t exchange_per_hit(rl_sharded* s, bool fwd, uint32_t elem, const void* a_s
 int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, uint32_t n_hits, const uint32_t* d_req_off,
                                          uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t* d_verdict,
                                          int32_t* d_first_limited, uint64_t* d_remaining, uint64_t* d_expires_in_us,
-                                         uint32_t* rounds_out) {
+                                         uint32_t* rounds_out) try {
     if (!s) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(s->mu);
     HIP_S(s, hipSetDevice(s->device));
@@ -928,17 +950,17 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
     }
     HIP_S(s, hipStreamSynchronize(s->cs));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void* rl_sharded_stream(rl_sharded* s) { return s ? s->cs : nullptr; }
 
-int32_t rl_sharded_sync(rl_sharded* s) {
+int32_t rl_sharded_sync(rl_sharded* s) try {
     if (!s) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(s->mu);
     HIP_S(s, hipSetDevice(s->device));
     HIP_S(s, hipStreamSynchronize(s->cs));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 uint32_t rl_sharded_in_flight(const rl_sharded* s) {
     if (!s) return 0;
@@ -1006,7 +1028,7 @@ static int32_t local_exchange(void* c, const rl_xfer* xs, uint32_t n, void* stre
     return rc;
 }
 
-int32_t rl_local_group_create(uint32_t world, rl_local_group** out) {
+int32_t rl_local_group_create(uint32_t world, rl_local_group** out) try {
     if (!out || world == 0 || world > MAX_WORLD) return RL_ERR_INVALID;
     auto* g = new (std::nothrow) rl_local_group();
     if (!g) return RL_ERR_NOMEM;
@@ -1017,15 +1039,15 @@ int32_t rl_local_group_create(uint32_t world, rl_local_group** out) {
     for (uint32_t r = 0; r < world; ++r) g->ctx[r] = {g, r};
     *out = g;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rl_local_group_destroy(rl_local_group* g) { delete g; }
 
-int32_t rl_local_group_transport(rl_local_group* g, uint32_t rank, rl_transport* out) {
+int32_t rl_local_group_transport(rl_local_group* g, uint32_t rank, rl_transport* out) try {
     if (!g || !out || rank >= g->world) return RL_ERR_INVALID;
     out->ctx = &g->ctx[rank];
     out->exchange = local_exchange;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 }  // extern "C"

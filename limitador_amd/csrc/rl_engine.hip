@@ -18,9 +18,11 @@
 #include <thread>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "rl_abi_guard.h"
 #include "rl_cell.hpp"
 #include "rl_kernels.hpp"
 #include "rl_bucket.hpp"
@@ -1671,7 +1673,41 @@ static int32_t scan_locked(rl_engine* e, u32 limit, u64 now, rl_cell_row* out, u
 
 extern "C" {
 
-int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
+// ---- the exception barrier of the C ABI (rl_abi_guard.h) ------------------------------------------------------------
+namespace {
+thread_local char g_abi_msg[320] = "";
+}
+int32_t rl_abi_caught(const char* fn, const char* what, int32_t status) {
+    std::snprintf(g_abi_msg, sizeof g_abi_msg, "%s: %s", fn ? fn : "?", what ? what : "?");
+    return status;
+}
+const char* rl_last_internal_error(void) { return g_abi_msg; }
+namespace {
+struct NotAStdException {
+    int why;
+};
+}
+int32_t rl_abi_selftest(int32_t kind) try {
+    std::vector<u64> guard_is_unwound(16, 1ull);  // (RAII behind the barrier unwinds like anywhere else)
+    switch (kind) {
+        case 1: throw std::bad_alloc();
+        case 2: throw std::length_error("rl_abi_selftest: std::length_error");
+        case 3: throw NotAStdException{3};
+        case 4: {  // a REAL failed allocation, the way a bogus size reaches operator new behind an entry point
+            std::vector<u64> v;
+            v.resize((size_t)1 << 58);
+            return (int32_t)v.size();
+        }
+        case 5: {
+            std::vector<u64> v;
+            v.reserve(v.max_size() + 1);  // std::length_error from the library itself
+            return (int32_t)v.capacity();
+        }
+        default: return RL_OK;
+    }
+} RL_ABI_CATCH
+
+int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (!cfg || !out) return RL_ERR_INVALID;
     *out = nullptr;
     int ndev = 0;
@@ -1793,8 +1829,13 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     int rc = alloc_table(e, e->cap, &e->table);
     if (rc) return bail(rc);
     const size_t mb = e->max_batch;
-#define ALLOC(ptr, bytes)                                                    \
-    if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) return bail(RL_ERR_NOMEM)
+    // RL_LOG_ALLOCS=1 (experiment builds): every device buffer's address range on stderr — a "Memory access fault by GPU ... on
+    // address X" of a later kernel can then be attributed to the buffer it ran off (scripts/exp/r13_abort_hunt.sh)
+    const bool log_allocs = RL_EXP_ENV("RL_LOG_ALLOCS") != nullptr;
+    if (log_allocs) std::fprintf(stderr, "[alloc] %-18s %p %zu\n", "e->table", (void*)e->table, (size_t)e->cap * sizeof(Cell));
+#define ALLOC(ptr, bytes)                                                                                       \
+    if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) return bail(RL_ERR_NOMEM);                               \
+    else if (log_allocs) std::fprintf(stderr, "[alloc] %-18s %p %zu\n", #ptr, (void*)(ptr), (size_t)(bytes))
     ALLOC(e->d_limits, e->max_limits * sizeof(LimitDev));
     ALLOC(e->d_hits, mb * sizeof(Hit));
     ALLOC(e->d_req_off, (mb + 1) * sizeof(u32));
@@ -1898,7 +1939,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) {
     e->stats.capacity_cells = e->cap;
     *out = e;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void rl_engine_destroy(rl_engine* e) {
     if (!e) return;
@@ -1955,7 +1996,7 @@ const char* rl_last_error(const rl_engine* e) { return e ? e->err.c_str() : "nul
 
 int32_t rl_status_is_transient(int32_t status) { return (status == RL_ERR_DEVICE || status == RL_ERR_BUSY) ? 1 : 0; }
 
-int32_t rl_stats(rl_engine* e, rl_stats_t* out) {
+int32_t rl_stats(rl_engine* e, rl_stats_t* out) try {
     if (!e || !out) return RL_ERR_INVALID;
     EngineLock g(e);
     e->stats.capacity_cells = e->cap;
@@ -1963,11 +2004,11 @@ int32_t rl_stats(rl_engine* e, rl_stats_t* out) {
     e->stats.tombstones = e->tombs;
     *out = e->stats;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 void* rl_engine_stream(rl_engine* e) { return e ? (void*)e->stream : nullptr; }
 
-int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
+int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -1979,9 +2020,9 @@ int32_t rl_engine_set_stream(rl_engine* e, void* stream, int32_t external) {
     // with a caller's stream everything is enqueued there, in order (no overlap of consecutive batches)
     e->pstream = (external || !e->own_pstream) ? e->stream : e->own_pstream;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_engine_wait_event(rl_engine* e, void* event) {
+int32_t rl_engine_wait_event(rl_engine* e, void* event) try {
     if (!e || !event) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -1998,9 +2039,9 @@ int32_t rl_engine_wait_event(rl_engine* e, void* event) {
     }
     HIP_TRY(e, hipStreamWaitEvent(e->stream, (hipEvent_t)event, 0));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_engine_record_event(rl_engine* e, void* event) {
+int32_t rl_engine_record_event(rl_engine* e, void* event) try {
     if (!e || !event) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -2008,9 +2049,9 @@ int32_t rl_engine_record_event(rl_engine* e, void* event) {
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord((hipEvent_t)event, e->stream));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) {
+int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, uint32_t n) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2030,9 +2071,9 @@ int32_t rl_limits_set(rl_engine* e, uint32_t first, const rl_limit_row* rows, ui
         HIP_TRY(e, hipStreamSynchronize(e->stream));
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) {
+int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2043,13 +2084,13 @@ int32_t rl_add_counter(rl_engine* e, uint32_t limit, uint64_t key) {
     CellRow* d_row = e->d_row1;
     HIP_TRY(e, hipMemcpyAsync(d_row, &row, sizeof(row), hipMemcpyHostToDevice, e->stream));
     return insert_rows_locked(e, d_row, 1, 0);
-}
+} RL_ABI_CATCH
 
 int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits,
                                          const uint32_t* d_req_off, uint32_t n_req, uint64_t now_us,
                                          int32_t load_counters, uint8_t* d_verdict,
                                          int32_t* d_first_limited, uint64_t* d_remaining,
-                                         uint64_t* d_expires_in_us) {
+                                         uint64_t* d_expires_in_us) try {
     int rc = validate_batch(e, d_hits, n_hits, d_req_off, n_req, d_verdict);
     if (rc) return rc;
     EngineLock g(e);
@@ -2068,7 +2109,7 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
     // caller's own stream set, stream order is the caller's synchronisation, as documented).
     if (!rc && !e->external_stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
     return rc;
-}
+} RL_ABI_CATCH
 
 // Host-buffer form of check_and_update for one clock value (the caller holds the engine's mutex).
 static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
@@ -2248,7 +2289,7 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
 int32_t rl_check_and_update_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
                                      uint32_t n_req, const uint64_t* req_delta, const uint64_t* req_now_us, uint64_t now_us,
                                      int32_t load_counters, uint8_t* verdict, int32_t* first_limited, uint64_t* remaining,
-                                     uint64_t* expires_in_us) {
+                                     uint64_t* expires_in_us) try {
     int rc = validate_batch(e, hits, n_hits, req_off, n_req, verdict);
     if (rc) return rc;
     EngineLock g(e, /*keep_server=*/true);  // (check_batch_locked sends the server away unless the call is one for it)
@@ -2290,17 +2331,17 @@ int32_t rl_check_and_update_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t 
         r0 = r1;
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_check_and_update_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint32_t* req_off,
                                   uint32_t n_req, uint64_t now_us, int32_t load_counters, uint8_t* verdict,
-                                  int32_t* first_limited, uint64_t* remaining, uint64_t* expires_in_us) {
+                                  int32_t* first_limited, uint64_t* remaining, uint64_t* expires_in_us) try {
     return rl_check_and_update_batch_ex(e, hits, n_hits, req_off, n_req, nullptr, nullptr, now_us, load_counters, verdict,
                                         first_limited, remaining, expires_in_us);
-}
+} RL_ABI_CATCH
 
 int32_t rl_check_and_update_submit_device_ev(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
-                                             uint8_t* d_verdict, int32_t* d_first_limited, void* done_event) {
+                                             uint8_t* d_verdict, int32_t* d_first_limited, void* done_event) try {
     int rc = validate_batch(e, d_hits, n_hits, nullptr, n_hits, d_verdict);
     if (rc) return rc;
     EngineLock g(e);
@@ -2311,29 +2352,29 @@ int32_t rl_check_and_update_submit_device_ev(rl_engine* e, const rl_hit* d_hits,
     rc = submit_k1_bucketed(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);
     e->submit_done_event = nullptr;
     return rc;
-}
+} RL_ABI_CATCH
 
 int32_t rl_check_and_update_submit_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint64_t now_us,
-                                          uint8_t* d_verdict, int32_t* d_first_limited) {
+                                          uint8_t* d_verdict, int32_t* d_first_limited) try {
     return rl_check_and_update_submit_device_ev(e, d_hits, n_hits, now_us, d_verdict, d_first_limited, nullptr);
-}
+} RL_ABI_CATCH
 
-int32_t rl_engine_flush(rl_engine* e) {
+int32_t rl_engine_flush(rl_engine* e) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     return flush_pending_apply(e);
-}
+} RL_ABI_CATCH
 
-int32_t rl_check_and_update_collect(rl_engine* e) {
+int32_t rl_check_and_update_collect(rl_engine* e) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
     return collect_k1_bucketed(e);
-}
+} RL_ABI_CATCH
 
 int32_t rl_is_within_limits_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint64_t* delta,
-                                     uint64_t now_us, uint8_t* within) {
+                                     uint64_t now_us, uint8_t* within) try {
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, within);
     if (rc) return rc;
     EngineLock g(e);
@@ -2354,14 +2395,14 @@ int32_t rl_is_within_limits_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t 
     if (rc) return rc;
     if (e->h_status->err) return status_to_error(e, e->h_status->err);
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us, uint8_t* within) {
+int32_t rl_is_within_limits_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us, uint8_t* within) try {
     return rl_is_within_limits_batch_ex(e, hits, n_hits, nullptr, now_us, within);
-}
+} RL_ABI_CATCH
 
 int32_t rl_update_counter_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_hits, const uint64_t* delta,
-                                   uint64_t now_us) {
+                                   uint64_t now_us) try {
     uint8_t dummy = 0;
     int rc = validate_batch(e, hits, n_hits, nullptr, n_hits, &dummy);
     if (rc) return rc;
@@ -2374,44 +2415,44 @@ int32_t rl_update_counter_batch_ex(rl_engine* e, const rl_hit* hits, uint32_t n_
     if (delta) HIP_TRY(e, hipMemcpyAsync(e->d_req_delta, delta, (size_t)n_hits * sizeof(u64), hipMemcpyHostToDevice, e->stream));
     return run_check_general(e, GenCall{e->d_hits, n_hits, nullptr, n_hits, delta ? e->d_req_delta : nullptr, now_us, false, true,
                                         e->d_verdict, nullptr, nullptr, nullptr});
-}
+} RL_ABI_CATCH
 
-int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us) {
+int32_t rl_update_counter_batch(rl_engine* e, const rl_hit* hits, uint32_t n_hits, uint64_t now_us) try {
     return rl_update_counter_batch_ex(e, hits, n_hits, nullptr, now_us);
-}
+} RL_ABI_CATCH
 
 int32_t rl_get_counters(rl_engine* e, uint32_t limit, uint64_t now_us, rl_cell_row* out, uint64_t cap,
-                        uint64_t* n_out) {
+                        uint64_t* n_out) try {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy_for_reads(e)) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     const int rc = flush_pending_apply(e);  // behind every batch submitted so far
     if (rc) return rc;
     return scan_locked<SCAN_GET>(e, limit, now_us, out, cap, n_out);
-}
+} RL_ABI_CATCH
 
-int32_t rl_dump_cells(rl_engine* e, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
+int32_t rl_dump_cells(rl_engine* e, rl_cell_row* out, uint64_t cap, uint64_t* n_out) try {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_DUMP>(e, 0, 0, out, cap, n_out);
-}
+} RL_ABI_CATCH
 
-int32_t rl_delete_counters(rl_engine* e, uint32_t limit) {
+int32_t rl_delete_counters(rl_engine* e, uint32_t limit) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_DELETE_LIMIT>(e, limit, 0, nullptr, 0, nullptr);
-}
+} RL_ABI_CATCH
 
-int32_t rl_clear(rl_engine* e) {
+int32_t rl_clear(rl_engine* e) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     return scan_locked<SCAN_CLEAR_SIMPLE>(e, 0, 0, nullptr, 0, nullptr);
-}
+} RL_ABI_CATCH
 
-int32_t rl_sweep_expired_rows(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_removed) {
+int32_t rl_sweep_expired_rows(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_removed) try {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2421,13 +2462,13 @@ int32_t rl_sweep_expired_rows(rl_engine* e, uint64_t now_us, rl_cell_row* out, u
     if (n_removed) *n_removed = before - e->live;
     if (e->tombs > e->cap / 8) return do_compact(e, 0);
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) {
+int32_t rl_sweep_expired(rl_engine* e, uint64_t now_us, uint64_t* n_removed) try {
     return rl_sweep_expired_rows(e, now_us, nullptr, 0, n_removed);
-}
+} RL_ABI_CATCH
 
-int32_t rl_sweep_expired_submit(rl_engine* e, uint64_t now_us) {
+int32_t rl_sweep_expired_submit(rl_engine* e, uint64_t now_us) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (e->ph_open) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2451,9 +2492,9 @@ int32_t rl_sweep_expired_submit(rl_engine* e, uint64_t now_us) {
     e->last_k1_was_part = false;
     e->sub_seq++;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_sweep_expired_collect(rl_engine* e, uint64_t* n_removed) {
+int32_t rl_sweep_expired_collect(rl_engine* e, uint64_t* n_removed) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "nothing in flight");
@@ -2462,17 +2503,17 @@ int32_t rl_sweep_expired_collect(rl_engine* e, uint64_t* n_removed) {
     const int rc = collect_k1_bucketed(e);
     if (n_removed) *n_removed = e->last_sweep_removed;
     return rc;
-}
+} RL_ABI_CATCH
 
-int32_t rl_compact(rl_engine* e) {
+int32_t rl_compact(rl_engine* e) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     return do_compact(e, 0);
-}
+} RL_ABI_CATCH
 
-int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {
+int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2483,18 +2524,18 @@ int32_t rl_resize(rl_engine* e, uint64_t capacity_cells) {
         return fail(e, RL_ERR_INVALID, "%llu live cells would fill a %llu-cell table beyond one half",
                     (unsigned long long)e->live, (unsigned long long)(1ull << lg));
     return do_compact(e, lg);
-}
+} RL_ABI_CATCH
 
-int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n) {
+int32_t rl_load_cells_device(rl_engine* e, const rl_cell_row* d_rows, uint64_t n) try {
     if (!e || (n && !d_rows)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     if (n == 0) return RL_OK;
     return insert_rows_locked(e, reinterpret_cast<const CellRow*>(d_rows), n, 1);
-}
+} RL_ABI_CATCH
 
-int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
+int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) try {
     if (!e || (n && !rows)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2507,7 +2548,7 @@ int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) {
                              : fail(e, RL_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(r));
     (void)hipFree(d_rows);
     return rc;
-}
+} RL_ABI_CATCH
 
 // ---- snapshot files, cross-node merge -----------------------------------------
 namespace {
@@ -2517,7 +2558,7 @@ struct SnapshotHeader {
 };
 }  // namespace
 
-int32_t rl_snapshot_save(rl_engine* e, const char* path) {
+int32_t rl_snapshot_save(rl_engine* e, const char* path) try {
     if (!e || !path) return RL_ERR_INVALID;
     uint64_t n = 0;
     int rc = rl_dump_cells(e, nullptr, 0, &n);
@@ -2542,9 +2583,9 @@ int32_t rl_snapshot_save(rl_engine* e, const char* path) {
               (rows.empty() || fwrite(rows.data(), sizeof(rl_cell_row), rows.size(), f) == rows.size());
     ok = fclose(f) == 0 && ok;
     return ok ? RL_OK : fail(e, RL_ERR_INVALID, "short write to %s", path);
-}
+} RL_ABI_CATCH
 
-int32_t rl_snapshot_load(rl_engine* e, const char* path) {
+int32_t rl_snapshot_load(rl_engine* e, const char* path) try {
     if (!e || !path) return RL_ERR_INVALID;
     FILE* f = fopen(path, "rb");
     if (!f) return fail(e, RL_ERR_INVALID, "cannot open %s", path);
@@ -2570,7 +2611,7 @@ int32_t rl_snapshot_load(rl_engine* e, const char* path) {
         if (rc) return rc;
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 static PeerTables peer_tables_of(rl_engine* e) {
     PeerTables p{};
@@ -2579,7 +2620,7 @@ static PeerTables peer_tables_of(rl_engine* e) {
     return p;
 }
 
-int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const rl_cell_row* rows, uint64_t n, uint64_t now_us) {
+int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const rl_cell_row* rows, uint64_t n, uint64_t now_us) try {
     if (!e || (n && !rows)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2609,9 +2650,9 @@ int32_t rl_merge_cells(rl_engine* e, uint32_t self_actor, uint32_t actor, const 
     e->live += e->h_status->n_inserted;
     if (e->h_status->err) return status_to_error(e, e->h_status->err);
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_export_local(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_out) {
+int32_t rl_export_local(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_t cap, uint64_t* n_out) try {
     if (!e || (cap && !out)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2633,7 +2674,7 @@ int32_t rl_export_local(rl_engine* e, uint64_t now_us, rl_cell_row* out, uint64_
     if (r != hipSuccess) return fail(e, RL_ERR_DEVICE, "export failed: %s", hipGetErrorString(r));
     if (n_out) *n_out = *e->h_total;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 // ---- on-device limit matching (rl_match.hpp) -------------------------------------------------------
 uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t v1) {
@@ -2653,7 +2694,7 @@ static int32_t gen_phase_close(rl_engine* e) {
 }
 
 int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* d_req_id, uint32_t n_hits, uint64_t now_us,
-                            int32_t load_counters) {
+                            int32_t load_counters) try {
     if (!e || (n_hits && (!d_hits || !d_req_id))) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight or a phased pass is open");
@@ -2702,10 +2743,10 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
     }
     e->ph_open = true;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_gen_round_device(rl_engine* e, const uint8_t* d_admitted, uint8_t* d_pass, uint64_t* d_remaining,
-                            uint64_t* d_expires_in_us) {
+                            uint64_t* d_expires_in_us) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
@@ -2727,9 +2768,9 @@ int32_t rl_gen_round_device(rl_engine* e, const uint8_t* d_admitted, uint8_t* d_
     e->ph_rounds++;
     e->ph_counted = false;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_new, uint64_t* room) {
+int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_new, uint64_t* room) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
@@ -2758,9 +2799,9 @@ int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_
     else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
     if (n_new) *n_new = h_gst.n_new;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_gen_commit_device(rl_engine* e) {
+int32_t rl_gen_commit_device(rl_engine* e) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
@@ -2787,18 +2828,18 @@ int32_t rl_gen_commit_device(rl_engine* e) {
     e->stats.ordered_hits += n;
     e->stats.ordered_batches++;
     return gen_phase_close(e);
-}
+} RL_ABI_CATCH
 
-int32_t rl_gen_abort(rl_engine* e) {
+int32_t rl_gen_abort(rl_engine* e) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (!e->ph_open) return RL_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     return gen_phase_close(e);
-}
+} RL_ABI_CATCH
 
 int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t n_limits, const rl_match_cond* conds,
-                           uint32_t n_conds, uint32_t n_namespaces) {
+                           uint32_t n_conds, uint32_t n_namespaces) try {
     if (!e || (n_limits && !limits) || (n_conds && !conds)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -2886,7 +2927,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
         e->match_fast = RL_EXP_ENV("RL_MATCH_GENERIC") == nullptr;
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 // device pointers for the request arrays and for verdict / limited_limit; derived hits stay in the
 // engine's staging buffers (e->d_hits, e->d_req_off)
@@ -2993,7 +3034,7 @@ int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, 
                                         const uint32_t* d_ent_key, const uint32_t* d_ent_val,
                                         const uint32_t* d_req_delta, uint32_t n_req, uint64_t now_us,
                                         int32_t load_counters, uint8_t* d_verdict, int32_t* d_limited_limit,
-                                        uint32_t* n_hits_out) {
+                                        uint32_t* n_hits_out) try {
     if (!e || !n_req || !d_req_ns || !d_ent_off || !d_req_delta || !d_verdict) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -3001,13 +3042,13 @@ int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, 
     HIP_TRY(e, hipSetDevice(e->device));
     return match_and_check_locked(e, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, n_req, now_us,
                                   load_counters != 0, d_verdict, d_limited_limit, n_hits_out);
-}
+} RL_ABI_CATCH
 
 int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
                                  const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
                                  int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, uint32_t* req_off_out,
                                  rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out, uint64_t* remaining,
-                                 uint64_t* expires_in_us) {
+                                 uint64_t* expires_in_us) try {
     if (!e || !n_req || !req_ns || !ent_off || !req_delta || !verdict) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -3043,11 +3084,11 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
     }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, const rl_wire_str* ns, uint32_t n_ns,
                           const rl_wire_str* keys, uint32_t n_keys, const rl_wire_str* vals, uint32_t n_vals,
-                          const uint64_t* limit_prefix, uint32_t n_limits) {
+                          const uint64_t* limit_prefix, uint32_t n_limits) try {
     if (!e || (blob_len && !blob) || !ns || (n_keys && !keys) || (n_vals && !vals) || (n_limits && !limit_prefix)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -3101,9 +3142,9 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     e->wire_t = W;
     e->wire_ready = true;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out) {
+int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out) try {
     if (!e || !out || slot >= 4u) return RL_ERR_INVALID;
     EngineLock g(e);
     if (bytes > e->h_stage_cap[slot]) {
@@ -3120,12 +3161,12 @@ int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out)
     }
     *out = e->h_stage[slot];
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
                                       int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, int32_t* status,
                                       uint32_t* req_off_out, rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out,
-                                      uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) {
+                                      uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) try {
     if (!e || !n || !msg_off || !verdict || !status) return RL_ERR_INVALID;
     if (collided_message) *collided_message = -1;
     EngineLock g(e);
@@ -3189,7 +3230,7 @@ int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const u
     }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world) { return owner_of(key, hash_seed, world); }
 
@@ -3221,16 +3262,16 @@ static int32_t route_partition_on(rl_engine* e, hipStream_t st, bool block, cons
 }
 
 int32_t rl_route_partition_device(rl_engine* e, const rl_hit* d_hits, uint32_t n_hits, uint32_t world,
-                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
+                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) try {
     if (!e) return RL_ERR_INVALID;
     return route_partition_on(e, e->stream, !e->external_stream, d_hits, n_hits, world, d_out, d_perm, d_counts);
-}
+} RL_ABI_CATCH
 
 int32_t rl_route_partition_stream(rl_engine* e, void* stream, const rl_hit* d_hits, uint32_t n_hits, uint32_t world,
-                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) {
+                                  rl_hit* d_out, uint32_t* d_perm, uint32_t* d_counts) try {
     if (!e) return RL_ERR_INVALID;
     return route_partition_on(e, reinterpret_cast<hipStream_t>(stream), false, d_hits, n_hits, world, d_out, d_perm, d_counts);
-}
+} RL_ABI_CATCH
 
 static int32_t unpermute_on(rl_engine* e, hipStream_t st, bool block, const uint8_t* d_src, const uint32_t* d_perm,
                             uint32_t n, uint8_t* d_dst) {
@@ -3248,18 +3289,18 @@ static int32_t unpermute_on(rl_engine* e, hipStream_t st, bool block, const uint
 }
 
 int32_t rl_unpermute_u8_device(rl_engine* e, const uint8_t* d_src, const uint32_t* d_perm, uint32_t n,
-                               uint8_t* d_dst) {
+                               uint8_t* d_dst) try {
     if (!e) return RL_ERR_INVALID;
     return unpermute_on(e, e->stream, !e->external_stream, d_src, d_perm, n, d_dst);
-}
+} RL_ABI_CATCH
 
 int32_t rl_unpermute_u8_stream(rl_engine* e, void* stream, const uint8_t* d_src, const uint32_t* d_perm, uint32_t n,
-                               uint8_t* d_dst) {
+                               uint8_t* d_dst) try {
     if (!e) return RL_ERR_INVALID;
     return unpermute_on(e, reinterpret_cast<hipStream_t>(stream), false, d_src, d_perm, n, d_dst);
-}
+} RL_ABI_CATCH
 
-int32_t rl_copy_segments_stream(rl_engine* e, void* stream, const rl_copy_seg* segs, uint32_t n) {
+int32_t rl_copy_segments_stream(rl_engine* e, void* stream, const rl_copy_seg* segs, uint32_t n) try {
     if (!e || (n && !segs) || n > COPY_SEGS_MAX) return RL_ERR_INVALID;
     if (!n) return RL_OK;
     CopySegs S{};
@@ -3276,18 +3317,18 @@ int32_t rl_copy_segments_stream(rl_engine* e, void* stream, const rl_copy_seg* s
     // (no engine lock: the launch touches nothing of the engine's but its device)
     k_copy_segs<<<grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(S);
     return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_DEVICE;
-}
+} RL_ABI_CATCH
 
-int32_t rl_engine_info(rl_engine* e, int32_t* device, uint32_t* max_batch_hits) {
+int32_t rl_engine_info(rl_engine* e, int32_t* device, uint32_t* max_batch_hits) try {
     if (!e) return RL_ERR_INVALID;
     if (device) *device = e->device;
     if (max_batch_hits) *max_batch_hits = e->max_batch;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 // ---- ingress side of the key-sharded multi-counter step (rl_route.hpp): enqueue on the caller's stream and return -----
 int32_t rl_req_ids_stream(rl_engine* e, void* stream, const uint32_t* d_req_off, uint32_t n_req, uint32_t n_hits,
-                          uint32_t base, const uint32_t* d_perm, uint32_t* d_req_of_hit, uint32_t* d_req_id_sorted) {
+                          uint32_t base, const uint32_t* d_perm, uint32_t* d_req_of_hit, uint32_t* d_req_id_sorted) try {
     if (!e || !d_req_off || (n_hits && (!d_perm || !d_req_of_hit || !d_req_id_sorted))) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -3296,12 +3337,12 @@ int32_t rl_req_ids_stream(rl_engine* e, void* stream, const uint32_t* d_req_off,
     if (n_hits) k_req_id_sorted<<<cdiv(n_hits, 256), 256, 0, st>>>(d_req_of_hit, d_perm, n_hits, base, d_req_id_sorted);
     HIP_TRY(e, hipGetLastError());
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_req_round_stream(rl_engine* e, void* stream, const uint8_t* d_pass_sorted, const uint32_t* d_perm,
                             const uint32_t* d_req_off, const uint32_t* d_req_of_hit, uint32_t n_req, uint32_t n_hits,
                             int32_t first_round, uint8_t* d_pass_home, uint8_t* d_adm, int32_t* d_first, uint8_t* d_verdict,
-                            uint32_t* d_changed, uint8_t* d_adm_sorted) {
+                            uint32_t* d_changed, uint8_t* d_adm_sorted) try {
     if (!e || !d_changed || (n_req && (!d_req_off || !d_adm || !d_first || !d_verdict)) ||
         (n_hits && (!d_pass_sorted || !d_perm || !d_req_of_hit || !d_pass_home || !d_adm_sorted)))
         return RL_ERR_INVALID;
@@ -3315,10 +3356,10 @@ int32_t rl_req_round_stream(rl_engine* e, void* stream, const uint8_t* d_pass_so
     if (n_hits) k_req_spread<<<cdiv(n_hits, 256), 256, 0, st>>>(d_adm, d_req_of_hit, d_perm, n_hits, d_adm_sorted);
     HIP_TRY(e, hipGetLastError());
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_req_reached_stream(rl_engine* e, void* stream, const int32_t* d_first, const uint32_t* d_req_of_hit,
-                              const uint32_t* d_perm, uint32_t n_hits, uint8_t* d_reached_sorted) {
+                              const uint32_t* d_perm, uint32_t n_hits, uint8_t* d_reached_sorted) try {
     if (!e || (n_hits && (!d_first || !d_req_of_hit || !d_perm || !d_reached_sorted))) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -3327,10 +3368,10 @@ int32_t rl_req_reached_stream(rl_engine* e, void* stream, const int32_t* d_first
                                                                                              d_reached_sorted);
     HIP_TRY(e, hipGetLastError());
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 int32_t rl_unpermute_u64_stream(rl_engine* e, void* stream, const uint64_t* d_src, const uint32_t* d_perm, uint32_t n,
-                                uint64_t* d_dst) {
+                                uint64_t* d_dst) try {
     if (!e || (n && (!d_src || !d_perm || !d_dst))) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -3339,9 +3380,9 @@ int32_t rl_unpermute_u64_stream(rl_engine* e, void* stream, const uint64_t* d_sr
                                                                                           reinterpret_cast<u64*>(d_dst));
     HIP_TRY(e, hipGetLastError());
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_host_register(rl_engine* e, void* ptr, uint64_t bytes) {
+int32_t rl_host_register(rl_engine* e, void* ptr, uint64_t bytes) try {
     if (!e || !ptr || !bytes) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -3350,9 +3391,9 @@ int32_t rl_host_register(rl_engine* e, void* ptr, uint64_t bytes) {
         return fail(e, RL_ERR_INVALID, "hipHostRegister refused %llu bytes at %p", (unsigned long long)bytes, ptr);
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_host_unregister(rl_engine* e, void* ptr) {
+int32_t rl_host_unregister(rl_engine* e, void* ptr) try {
     if (!e || !ptr) return RL_ERR_INVALID;
     EngineLock g(e);
     HIP_TRY(e, hipSetDevice(e->device));
@@ -3362,17 +3403,17 @@ int32_t rl_host_unregister(rl_engine* e, void* ptr) {
         return fail(e, RL_ERR_INVALID, "hipHostUnregister: %p is not a registered range", ptr);
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_kernel_timing(rl_engine* e, int32_t enable) {
+int32_t rl_kernel_timing(rl_engine* e, int32_t enable) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     if (enable < 0 || enable > 3) return fail(e, RL_ERR_INVALID, "timing mode %d", enable);
     e->timing = enable;
     return RL_OK;
-}
+} RL_ABI_CATCH
 
-int32_t rl_kernel_timing_read(rl_engine* e, double* ms, uint64_t* launches, int32_t reset) {
+int32_t rl_kernel_timing_read(rl_engine* e, double* ms, uint64_t* launches, int32_t reset) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
     (void)read_timing_todo(e);
@@ -3384,6 +3425,6 @@ int32_t rl_kernel_timing_read(rl_engine* e, double* ms, uint64_t* launches, int3
         e->timed_launches = 0;
     }
     return RL_OK;
-}
+} RL_ABI_CATCH
 
 }  // extern "C"

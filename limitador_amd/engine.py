@@ -14,7 +14,7 @@ RL_OK = 0
 ERR_NAMES = {
     -1: "RL_ERR_INVALID", -2: "RL_ERR_DEVICE", -3: "RL_ERR_NO_DEVICE", -4: "RL_ERR_TABLE_FULL",
     -5: "RL_ERR_MISSING_SIMPLE", -6: "RL_ERR_KEY_LIMIT", -7: "RL_ERR_BATCH_TOO_LARGE", -8: "RL_ERR_NOMEM",
-    -9: "RL_ERR_BUSY",
+    -9: "RL_ERR_BUSY", -10: "RL_ERR_KEY_COLLISION", -11: "RL_ERR_INTERNAL",
 }
 
 

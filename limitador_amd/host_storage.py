@@ -58,6 +58,7 @@ def load():
     sig("rls_delete_counters", C.c_int32, [p, C.POINTER(RlsLimit), C.c_uint32])
     sig("rls_clear", C.c_int32, [p])
     sig("rls_sweep_expired", C.c_int32, [p, C.POINTER(C.c_uint64)])
+    sig("rls_abi_selftest", C.c_int32, [C.c_int32])
     sig("rls_set_sweep_after", None, [p, C.c_uint64])
     sig("rls_interned_counters", C.c_uint64, [p])
     sig("rls_check_and_update_repeat", C.c_int32, [p, C.POINTER(RlsCounter), C.c_uint32, C.c_uint64, C.c_uint32,

@@ -44,6 +44,7 @@ def _lib():
         "rli_frontend_set_clock": (None, [p, u64]),
         "rli_frontend_should_rate_limit": (i32, [p, C.c_char_p, u32, C.POINTER(C.c_uint8), u32, C.POINTER(u32)]),
         "rli_frontend_stats": (None, [p, C.POINTER(u64), C.POINTER(u64)]),
+        "rli_abi_selftest": (C.c_int32, [C.c_int32]),
         "rli_set_value_cap": (i32, [p, u32]),
         "rli_set_key_mode": (i32, [p, i32]),
         "rli_counter_key": (i32, [p, u32, strs, C.POINTER(u32), u32, C.POINTER(u64), C.POINTER(u32)]),

@@ -39,6 +39,7 @@ def load():
         "rl_sharded_stream": (p, [p]),
         "rl_sharded_sync": (i32, [p]),
         "rl_sharded_in_flight": (u32, [p]),
+        "rl_sharded_abi_selftest": (C.c_int32, [C.c_int32]),
         "rl_local_group_create": (i32, [u32, C.POINTER(p)]),
         "rl_local_group_destroy": (None, [p]),
         "rl_local_group_transport": (i32, [p, u32, C.POINTER(RlTransport)]),

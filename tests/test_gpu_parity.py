@@ -509,14 +509,15 @@ def test_single_counter_requests_with_u64_deltas(make_engine):
 
 
 # ---- BASELINE.json configs at full size ----------------------------------------------------------
-def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False, nows=None, early_third=False):
+def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False, nows=None, early_third=False, capacity_cells=None, timing_mode=0):
     """in_flight: the bench's entry point and geometry — device-resident batches through
     rl_check_and_update_submit_device / _collect, three in flight, table at load <= 0.30.
     nows: the clock of every batch (default NOW + 1 ms per batch: no pre-populated window ends inside the run).
     early_third: every third key of the universe carries an expiry 2.5 ms after NOW instead of 30 s, so its window ends
-    INSIDE the run (atomic_expiring_value.rs:36-42,87-99: the first admitted hit after that resets value and expiry)."""
+    INSIDE the run (atomic_expiring_value.rs:36-42,87-99: the first admitted hit after that resets value and expiry).
+    capacity_cells: the table's size (default: load <= 0.30; tests/test_gpu_bench_config.py passes bench.py's 2^26)."""
     rows = [(W.MAX_VALUE, W.WINDOW_S)]
-    cap = 1 << (int(n_keys * 2.2 - 1).bit_length())
+    cap = capacity_cells or 1 << (int(n_keys * 2.2 - 1).bit_length())
     eng, orc = pair(make_engine, rows, capacity_cells=cap, max_batch_hits=n_hits)
     chunk = 1 << 20
     for lo in range(0, n_keys, chunk):
@@ -544,6 +545,8 @@ def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False, nows=N
         d_verdict = [torch.empty(n_hits, dtype=torch.uint8, device=dev) for _ in batches]
         d_first = [torch.empty(n_hits, dtype=torch.int32, device=dev) for _ in batches]
         torch.cuda.synchronize()
+        if timing_mode:  # bench.py's timed region: some launches carry their own start / stop events (rl_kernel_timing)
+            eng.kernel_timing(timing_mode)
         pending = 0
         for i in range(steps):
             eng.submit_device(d_hits[i].data_ptr(), n_hits, nows[i], d_verdict[i].data_ptr(), d_first[i].data_ptr())
@@ -555,6 +558,10 @@ def _full_size(make_engine, n_keys, n_hits, steps, zipf, in_flight=False, nows=N
             eng.collect()
             pending -= 1
         torch.cuda.synchronize()
+        if timing_mode:
+            kt = eng.kernel_timing_read(reset=True)
+            eng.kernel_timing(0)
+            assert kt["launches"] >= 1
         for i, hits in enumerate(batches):
             v, f, _r, _e = orc.check_and_update(hits, nows[i])
             assert np.array_equal(d_verdict[i].cpu().numpy(), v), f"verdicts of batch {i}"

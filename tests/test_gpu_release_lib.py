@@ -32,3 +32,10 @@ def test_reference_scenarios_and_the_pipelined_hot_path_on_the_release_build():
     out = _run(["-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_parity.py", "tests/test_gpu_bucketed.py", "-k",
                 "served or three_batches_in_flight or config2 or sweeps_between"], 600)
     assert " passed" in out and "lib/exp" not in out
+
+
+def test_the_bench_configuration_at_full_size_on_the_release_build():
+    """bench.py's headline geometry — 10 M keys in a 2^26-cell table, 1 M-hit Zipf batches, three in flight, timed
+    launches — plain and with both window-expiry variants, all 10 M cells compared (tests/test_gpu_bench_config.py)."""
+    out = _run(["-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_bench_config.py"], 900)
+    assert "3 passed" in out and "skipped" not in out.split("\n")[-2]
