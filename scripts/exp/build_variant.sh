@@ -5,14 +5,15 @@
 # before it runs bench.py; the product library in this tree is never replaced.  Variants are not committed (lib/ is
 # git-ignored) and should be deleted after the visit.
 set -eu
-name=$1
+name=$1; shift
 root=$(cd "$(dirname "$0")/../.." && pwd)
 tmp=$(mktemp -d)
 mkdir -p "$tmp/limitador_amd" "$root/limitador_amd/lib/variants"
 cp -r "$root/include" "$tmp/include"
 cp -r "$root/limitador_amd/csrc" "$tmp/limitador_amd/csrc"
-(cd "$tmp" && patch -p1 < "$root/scripts/exp/patches/$name.patch")
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DRL_EXPERIMENT -I"$tmp/include" "$tmp/limitador_amd/csrc/rl_engine.hip" \
+# (a variant that is only a set of -D flags has no patch file:  build_variant.sh partl_wpe4 -DRL_PARTL_WPE=4)
+[ -f "$root/scripts/exp/patches/$name.patch" ] && (cd "$tmp" && patch -p1 < "$root/scripts/exp/patches/$name.patch")
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DRL_EXPERIMENT "$@" -I"$tmp/include" "$tmp/limitador_amd/csrc/rl_engine.hip" \
     -o "$root/limitador_amd/lib/variants/librl_engine_$name.so"
 rm -rf "$tmp"
 ls -la "$root/limitador_amd/lib/variants/librl_engine_$name.so"

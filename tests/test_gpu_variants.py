@@ -129,10 +129,10 @@ def test_every_output_of_a_batch_is_defined_whatever_the_buffers_held(make_engin
     assert_same_state(eng, orc)
 
 
-@pytest.mark.parametrize("compact", ["1", "0"])
+@pytest.mark.parametrize("compact", ["1", "0", "2"])
 def test_both_shapes_of_the_partition_on_4096_hit_tiles(make_engine, monkeypatch, compact):
-    """Batches of more than 256 x 1024 hits take 4096-hit tiles: k_bkt_part_c (512 threads, the default) or k_bkt_part
-    (1024 threads, RL_PART_COMPACT=0).  300 000 Zipf hits per batch (74 tiles, the last one ragged), hot keys with mixed
+    """Batches of more than 256 x 1024 hits take 4096-hit tiles: k_bkt_part_c (512 threads), k_bkt_part (1024 threads,
+    RL_PART_COMPACT=0) or k_bkt_part_l (RL_PART_COMPACT=2: the compact shape with the per-hit work cut down).  300 000 Zipf hits per batch (74 tiles, the last one ragged), hot keys with mixed
     limits, four batches so that the hot set is in use: every verdict and the final table against the oracle."""
     monkeypatch.setenv("RL_PART_COMPACT", compact)
     rng = np.random.default_rng(41)
@@ -145,3 +145,58 @@ def test_both_shapes_of_the_partition_on_4096_hit_tiles(make_engine, monkeypatch
         run_both(eng, orc, h, now)
         now += 1000
     assert_same_state(eng, orc)
+
+
+@pytest.mark.parametrize("compact", ["1", "2"])
+def test_the_partition_kernels_agree_on_crowded_hot_sets_simple_counters_and_refusals(make_engine, monkeypatch, compact):
+    """What k_bkt_part_l does differently from k_bkt_part_c, each against the oracle (and therefore against each other):
+    a FULL hot set (500+ keys over the threshold: groups of its slot table overflow into their neighbours, fingerprint
+    matches that are another key — the slot-by-slot path), simple counters in the batch (the cell must pre-exist,
+    in_memory.rs:106-107: one wave-uniform branch in the lean kernel), hot keys whose hits stop matching the set's
+    predicted delta / limit, a ragged last tile, and the three refusals of the validation pass — unknown limit id, reserved
+    key, missing simple cell — which must leave the table untouched and name the same error."""
+    from limitador_amd.engine import EngineError
+
+    monkeypatch.setenv("RL_PART_COMPACT", compact)
+    rng = np.random.default_rng(77)
+    n = 330_001  # 81 tiles of 4096, the last one ragged
+    rows = [(700, 60), (30, 60), (10**7, 60), (5, 1), (10**9, 60)]
+    eng, orc = pair(make_engine, rows, simple_keys=[(4, 9_100_004)], max_batch_hits=n, capacity_cells=1 << 20)
+    hot_keys = W.splitmix64(np.arange(50_000, 50_560, dtype=np.uint64))  # 560 keys x ~330 hits: more than fit the set
+    cold = W.splitmix64(np.arange(100_000, 400_000, dtype=np.uint64))
+    now = NOW
+
+    def batch(step):
+        r = rng.random(n)
+        hk = rng.integers(0, len(hot_keys), size=n)
+        ck = rng.integers(0, len(cold), size=n)
+        is_hot = r < 0.55
+        is_simple = (~is_hot) & (r < 0.60)
+        keys = np.where(is_hot, hot_keys[hk], np.where(is_simple, 9_100_004, cold[ck]))
+        limits = np.where(is_hot, hk % 3, np.where(is_simple, 4 | RL_SIMPLE, 2 + ck % 2)).astype(np.uint32)  # (one id per key)
+        delta = np.ones(n, dtype=np.uint32)
+        if step >= 4:  # some hot keys now arrive with another delta than the set predicts: their buckets are replayed
+            delta[is_hot & (hk % 7 == 0)] = 2
+        return make_hits(keys, limits, delta)
+
+    for step in range(7):
+        run_both(eng, orc, batch(step), now)
+        now += 400_000 if step == 5 else 1000  # (limit 3's one-second windows run out along the way)
+    assert_same_state(eng, orc, n_simple_expected=1)
+    before = np.sort(eng.dump_cells(), order="key")
+    good = batch(0)
+    for what, code in (("limit", -1), ("reserved", -1), ("missing_simple", -5)):
+        bad = good.copy()
+        at = int(rng.integers(0, n))
+        if what == "limit":
+            bad["limit"][at] = 77
+        elif what == "reserved":
+            bad["key"][at] = 2**64 - 1
+        else:
+            bad["key"][at], bad["limit"][at] = 9_100_099, 2 | RL_SIMPLE
+        with pytest.raises(EngineError) as e:
+            eng.check_and_update(bad, now)
+        assert e.value.code == code, what
+        assert np.array_equal(np.sort(eng.dump_cells(), order="key"), before), f"a refused batch ({what}) touched the table"
+    run_both(eng, orc, good, now)
+    assert_same_state(eng, orc, n_simple_expected=1)
