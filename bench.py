@@ -30,6 +30,9 @@ ALGO_BYTES = {"apply": 49, "part": 0}
 NOT_KERNELS = ("apply_gap", "part_slack")  # timing slots that are intervals between kernels
 ALGO_BYTES_TOTAL = 49
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# roofline.random_line_frac: what the replay is actually bound by
+RANDOM_TRANSACTIONS_PER_1M_ZIPF = 1.45e6  # profiles/r04h_replay_memory_path.md (configs[2], 1 M-hit Zipf-0.99 batch)
+RANDOM_LINE_RATE = 57e9                   # random 32-byte cell reads per second, chip-wide: profiles/r04a_random_slope.txt
 
 
 def parse():
@@ -239,6 +242,32 @@ def secondary(args, eng, dev, gen):
     out["headline_with_expiry"] = {"decisions_per_s": args.batch * 200 / dt, "ms_per_step": dt / 200 * 1e3,
                                    "clock": "+1 ms per batch, +40 s behind every 8th (windows of 60 s)",
                                    "denied_in_a_batch_after_the_run": int(vlast.sum().item())}
+    # -- the headline at the OTHER table sizing (ADVICE r04 / VERDICT r04 #9): rounds 1-3 sized the table at load 0.30
+    #    (2^25 cells, 1.07 GB for 10 M keys), round 4 on at 0.15 (2^26 cells, 2.1 GB: shorter probe chains).  Both belong in
+    #    the record: same keys, same batches, same 20-step window as the driver's line, on a second engine of half the
+    #    capacity (`--cap-mult 0.5`, run as the headline, gives the same figure)
+    try:
+        cap2 = eng.stats()["capacity_cells"] // 2
+        e2 = Engine(capacity_cells=cap2, max_batch_hits=args.batch, device=eng.device)
+        e2.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+        rows = W.torch_universe_rows(args.keys, dev)
+        torch.cuda.synchronize()
+        for lo in range(0, rows.shape[0], 1 << 20):
+            part = rows[lo:lo + (1 << 20)].contiguous()
+            e2.load_cells_device(part.data_ptr(), part.shape[0])
+        del rows
+        torch.cuda.synchronize()
+        run_device(e2, many, args.batch, 12)
+        dt20 = run_device(e2, many[12:], args.batch, 20)
+        dt200 = run_device(e2, many, args.batch, 200)
+        out["headline_load_0.30"] = {"table_capacity_cells": cap2, "table_bytes": cap2 * 32, "table_load": round(args.keys / cap2, 3),
+                                     "decisions_per_s_20_steps": args.batch * 20 / dt20, "ms_per_step_20_steps": dt20 / 20 * 1e3,
+                                     "decisions_per_s_200_steps": args.batch * 200 / dt200, "ms_per_step_200_steps": dt200 / 200 * 1e3,
+                                     "note": "the round-1..3 sizing of the same workload; the headline line is at "
+                                             f"load {round(args.keys / (2 * cap2), 3)}"}
+        e2.close()
+    except Exception as ex:  # noqa: BLE001
+        out["headline_load_0.30"] = {"error": str(ex)[:200]}
     del many
     # -- uniform keys, same table and batch size (no hot keys: every hit reads and writes a cell)
     uni = [W.torch_batch(args.keys, args.batch, dev, gen, None) for _ in range(10)]
@@ -757,6 +786,19 @@ def main():
                          "algorithmic_bytes_per_hit": ALGO_BYTES[dom], "hits_per_launch": hits_per_launch,
                          "avg_launch_ms": per.get(dom, 0.0),
                          "avg_launch_ms_alone": per_alone.get(dom),
+                         # The honest end-to-end: the same algorithmic bytes over the STEP (partition, gaps and pipeline fill
+                         # included), not over the dominant kernel's own launch.
+                         "step_frac": (ALGO_BYTES_TOTAL * args.batch / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if world == 1 else None,
+                         # ... and the reachable ceiling: the replay is bound by random TRANSACTIONS, not bytes.  Per 1 M-hit
+                         # Zipf-0.99 batch it issues ~1.45 M of them (record-gather lines ~350 k, cell reads ~500 k, write-backs
+                         # ~400 k, one-byte verdict stores ~200 k: profiles/r04h_replay_memory_path.md, from the TCP / TCC
+                         # counters); the chip's measured random-line rate is 57 G/s (profiles/r04a_random_slope.txt).
+                         # random_line_frac = (transactions / 57 G/s) / the kernel's launch time: 1.0 = at the fabric's line rate.
+                         "random_line_frac": ((RANDOM_TRANSACTIONS_PER_1M_ZIPF / RANDOM_LINE_RATE) / (per[dom] * 1e-3))
+                         if (default_workload and per.get(dom, 0) > 0) else None,
+                         "random_line_model": {"transactions_per_launch": RANDOM_TRANSACTIONS_PER_1M_ZIPF, "lines_per_s": RANDOM_LINE_RATE,
+                                               "source": "profiles/r04h_replay_memory_path.md, profiles/r04a_random_slope.txt"}
+                         if default_workload else None,
                          "timed_with": (f"HIP events on {kt['launches']} of the {args.steps} launches of the timed region: "
                                         "the launch carries its own start / stop events (hipExtLaunchKernelGGL), no marker "
                                         "commands around the kernel; the partition of the next batches runs beside it on a "

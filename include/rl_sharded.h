@@ -92,6 +92,14 @@ int32_t rl_sharded_submit_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n
  * synchronised (rl_sharded_stream) — or use rl_sharded_sync.  -> the status of the local batch this
  * rank applied for that slice; *n_applied = hits it applied. */
 int32_t rl_sharded_collect(rl_sharded *s, uint32_t *n_applied);
+/* A sweep of expired counters as a command of the routed pipeline: every rank calls it at the same point of its sequence of
+ * submits; its shard is swept behind every slice submitted so far and in front of every later one — the point a sequential
+ * storage would be swept at — without draining the slices in flight (it takes one of the three in-flight places and is
+ * collected in order with rl_sharded_sweep_collect; *n_removed = cells THIS rank's shard dropped).  The sweep itself is
+ * rl_sweep_expired_submit of rl_engine.h (qualified cells with expiry <= now_us; no reference analogue: an explicit eviction
+ * event, replayed into the oracle by the tests). */
+int32_t rl_sharded_sweep_submit(rl_sharded *s, uint64_t now_us);
+int32_t rl_sharded_sweep_collect(rl_sharded *s, uint64_t *n_removed);
 /* submit + collect + synchronise on an empty pipeline. */
 int32_t rl_sharded_check_and_update_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
                                            uint8_t *d_verdict, uint32_t *n_applied);

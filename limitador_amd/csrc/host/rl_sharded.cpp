@@ -56,6 +56,8 @@ struct Slice {
     char errmsg[200] = {0};
     bool applied_recorded = false;  // ev_applied[slot] has been recorded behind the slice's local batch
     uint64_t id = 0;                // the slice's sequence number
+    bool sweep = false;             // not a slice: this rank's share of a routed sweep (rl_sharded_sweep_submit) — one engine
+                                    // command, nothing to route or to return (stage RETURNED from the start)
 };
 
 // RCCL is bound at RUN time, to the copy the process has already mapped if there is one: a host that also uses
@@ -612,8 +614,10 @@ void rl_sharded_destroy(rl_sharded* s) {
     // the local batches of slices nobody collected are still in flight on the engine: it would refuse to change streams
     // (RL_ERR_BUSY) and keep pointing at the stream destroyed below
     if (s->e)
-        for (const Slice& p : s->pending)
-            if (p.waits) (void)rl_check_and_update_collect(s->e);
+        for (const Slice& p : s->pending) {
+            if (p.sweep) (void)rl_sweep_expired_collect(s->e, nullptr);
+            else if (p.waits) (void)rl_check_and_update_collect(s->e);
+        }
     bool engine_released = true;
     if (s->e && s->as) engine_released = rl_engine_set_stream(s->e, nullptr, 0) == RL_OK;  // back to the engine's own streams
     if (s->rccl) {
@@ -674,6 +678,7 @@ int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) try {
     if (s->pending.empty()) return fail(s, RL_ERR_INVALID, "nothing in flight");
     HIP_S(s, hipSetDevice(s->device));
     Slice& p = s->pending.front();
+    if (p.sweep) return fail(s, RL_ERR_INVALID, "the oldest command in flight is a sweep: rl_sharded_sweep_collect");
     int32_t rc;
     SH_TRACE("[sh] %9.1f collect(%llu) begin stage %d\n", t_us(), (unsigned long long)p.id, (int)p.stage);
     if (p.stage == ROUTED && (rc = apply(s, p)) != RL_OK) return rc;
@@ -688,6 +693,48 @@ int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) try {
         if (rc != RL_OK) return fail(s, rc, "local batch: %s", rl_last_error(s->e));
     }
     if (done.err) return fail(s, done.err, "%s (every exchange of the slice was issued; the hits this rank owns were answered 0xFF)", done.errmsg);
+    return RL_OK;
+} RL_ABI_CATCH
+
+// A sweep as a COMMAND of the routed pipeline (BASELINE.json configs[4]: "mixed TTLs with concurrent expiry sweep"): every
+// rank sweeps its own shard at the same point of the global sequence — behind every slice submitted so far, in front of every
+// later one — which is the point a sequential storage would be swept at.  The slices this rank has routed but not yet handed
+// to their owners go out first (that exchange is collective: every rank calls the sweep at the same point of its sequence of
+// calls, like every other entry of this header); then the engine's own stream-ordered sweep (rl_sweep_expired_submit) takes
+// one of the three in-flight places.  No drain: slices in front of it and behind it stay in flight.
+int32_t rl_sharded_sweep_submit(rl_sharded* s, uint64_t now_us) try {
+    if (!s) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->pending.size() >= (size_t)SLOTS) return fail(s, RL_ERR_BUSY, "%d commands are in flight: collect first", SLOTS);
+    HIP_S(s, hipSetDevice(s->device));
+    int32_t rc;
+    for (auto& p : s->pending)
+        if (!p.sweep && p.stage == ROUTED && (rc = apply(s, p)) != RL_OK) return rc;
+    ENG_S(s, rl_sweep_expired_submit(s->e, now_us));
+    Slice sl;
+    sl.sweep = true;
+    sl.stage = RETURNED;
+    sl.now = now_us;
+    sl.id = s->seq;
+    sl.slot = (int)(s->seq % SLOTS);  // (its buffers stay unused: a slot is just a place in the window of three)
+    s->pending.push_back(sl);
+    ++s->seq;
+    return RL_OK;
+} RL_ABI_CATCH
+
+// Finish the OLDEST command, which must be a sweep: *n_removed = cells THIS rank's shard dropped (the global figure is the
+// sum over the ranks — the host's to add up if it wants it).
+int32_t rl_sharded_sweep_collect(rl_sharded* s, uint64_t* n_removed) try {
+    if (!s) return RL_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->pending.empty()) return fail(s, RL_ERR_INVALID, "nothing in flight");
+    if (!s->pending.front().sweep) return fail(s, RL_ERR_INVALID, "the oldest command in flight is a slice: rl_sharded_collect");
+    HIP_S(s, hipSetDevice(s->device));
+    s->pending.pop_front();
+    uint64_t n = 0;
+    const int32_t rc = rl_sweep_expired_collect(s->e, &n);
+    if (n_removed) *n_removed = n;
+    if (rc != RL_OK) return fail(s, rc, "sweep: %s", rl_last_error(s->e));
     return RL_OK;
 } RL_ABI_CATCH
 

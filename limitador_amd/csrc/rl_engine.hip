@@ -216,8 +216,10 @@ struct rl_engine {
         u32 hot_long = 0;
         hipEvent_t done_event = nullptr;  // the caller's, recorded behind the replay when it goes out (rl_check_and_update_submit_device_ev)
     } pend;
-    // RL_DEFER2=1 (experiment builds; prepared in round 4, not yet run on a GPU): the replay of the batch BEFORE `pend`, held
-    // back across one more submit.  With today's kernel times the partition of batch p ends ~25 us after the submit of batch
+    // The replay of the batch BEFORE `pend`, held back across one more submit (the default since round 5: parity-green on the
+    // pipeline suites and at full size, 49.1 -> 46.0 us per step over the driver's 20 steps, 45.5 -> 42.9 over 200, the replay
+    // stream's idle time 9.8 -> 4.4 us, 111 -> 14 wait commands per 117 batches: gpurun_out/r13a, profiles/r05a_defer2.md;
+    // RL_DEFER2=0 in experiment builds is the form before).  With today's kernel times the partition of batch p ends ~25 us after the submit of batch
     // p + 1 — while the replay of batch p - 1 is running and the host is spinning in its collect — so four replays out of five
     // go out behind a wait command (n_wait_parted), and a wait on an event that is not complete when it is enqueued costs the
     // stream 5.4 us at the boundary however long ago the event completed by then (scripts/microbench/kernel_gap2.hip:
@@ -226,7 +228,7 @@ struct rl_engine {
     // partition -> replay dependency (the host has SEEN the event, or the wait command goes in as before) and everything
     // the in-flight limit guarantees (batch p - 3 collected before batch p is submitted) are unchanged.
     PendingApply pend_old;
-    bool defer2 = false;
+    bool defer2 = true;
     hipEvent_t submit_done_event = nullptr;  // (argument of the submit being processed)
     hipEvent_t input_event = nullptr;        // rl_engine_wait_event on a two-stream engine: gates the next batch's inputs
     u32 pipe_depth = 3;             // RL_PIPE_DEPTH (2 or 3): the partition of batch p waits for k_bkt_apply of batch p - depth

@@ -35,6 +35,8 @@ def load():
         "rl_sharded_submit_device": (i32, [p, p, u32, u64, p]),
         "rl_sharded_collect": (i32, [p, C.POINTER(u32)]),
         "rl_sharded_check_and_update_device": (i32, [p, p, u32, u64, p, C.POINTER(u32)]),
+        "rl_sharded_sweep_submit": (i32, [p, u64]),
+        "rl_sharded_sweep_collect": (i32, [p, C.POINTER(u64)]),
         "rl_sharded_check_requests_device": (i32, [p, p, u32, p, u32, u64, i32, p, p, p, p, C.POINTER(u32)]),
         "rl_sharded_stream": (p, [p]),
         "rl_sharded_sync": (i32, [p]),
@@ -125,6 +127,16 @@ class Sharded:
         """-> hits this rank applied for the oldest slice (its verdicts are ordered on stream(); sync() waits)."""
         n = C.c_uint32()
         self._check(SYMBOLS["rl_sharded_collect"](self._h, C.byref(n)))
+        return n.value
+
+    def sweep_submit(self, now_us):
+        """This rank's share of a routed sweep, behind every slice submitted so far (every rank calls it at the same point)."""
+        self._check(SYMBOLS["rl_sharded_sweep_submit"](self._h, int(now_us)))
+
+    def sweep_collect(self):
+        """-> cells this rank's shard dropped (the oldest command in flight must be the sweep)."""
+        n = C.c_uint64()
+        self._check(SYMBOLS["rl_sharded_sweep_collect"](self._h, C.byref(n)))
         return n.value
 
     def check_and_update(self, d_hits, n_hits, now_us, d_verdict):

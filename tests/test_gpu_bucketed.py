@@ -14,20 +14,21 @@ from test_gpu_parity import NOW, SEC, assert_same_state, make_engine, pair, run_
 pytestmark = pytest.mark.gpu
 
 
-# RL_DEFER2 was written without a GPU at hand (end of round 4): its runs join the suite with RL_TEST_DEFER2=1 until a visit
-# has seen them green (then: drop the switch and make it the default if it is faster).
-_FORMS = ["engine_default", "two_streams"] + (["two_streams_replays_held_back"] if os.environ.get("RL_TEST_DEFER2") == "1" else [])
+# (the two-stream pipeline holds a replay back across one more submit by default since round 5 — RL_DEFER2, first run and seen
+# green in gpurun_out/r13a; the form before it stays in the suite as "two_streams_replays_not_held_back")
+_FORMS = ["engine_default", "two_streams", "two_streams_replays_not_held_back"]
 
 
 @pytest.fixture(autouse=True, params=_FORMS)
 def pipeline_form(request, monkeypatch):
     """Engines as small as these tests' run the fused form by default (one stream, one launch per step); every test here
-    also runs on the two-stream pipeline that engines for large batches use, and on that pipeline with a replay held back
-    across one more submit until the host sees its partition complete (RL_DEFER2, rl_engine::pend_old)."""
+    also runs on the two-stream pipeline that engines for large batches use — where a replay whose partition is still running
+    is held back across one more submit until the host sees the partition complete (rl_engine::pend_old, the default) — and
+    on that pipeline without the second hold (RL_DEFER2=0)."""
     if request.param != "engine_default":
         monkeypatch.setenv("RL_FUSE", "0")
-    if request.param == "two_streams_replays_held_back":
-        monkeypatch.setenv("RL_DEFER2", "1")
+    if request.param == "two_streams_replays_not_held_back":
+        monkeypatch.setenv("RL_DEFER2", "0")
 
 SEED = 0x9E3779B97F4A7C15  # Engine's default hash_seed
 M64 = (1 << 64) - 1

@@ -46,7 +46,7 @@ def test_route_partition_is_a_stable_partition_by_owner(world, n):
     eng.close()
 
 
-def test_sharded_engine_over_rccl_world_1():
+def test_sharded_engine_over_rccl_world_1(rccl_ready):
     import torch.distributed as dist
     from limitador_amd.engine import Engine
 
@@ -99,7 +99,7 @@ def test_sharded_engine_over_rccl_world_1():
         dist.destroy_process_group()
 
 
-def test_namespace_sharded_requests_over_rccl_world_1():
+def test_namespace_sharded_requests_over_rccl_world_1(rccl_ready):
     """ShardedRequestEngine on the HIP engine (device matcher + general resolver behind RCCL with one
     rank) against the id-level CPU matcher + the oracle, multi-counter requests included."""
     import torch.distributed as dist

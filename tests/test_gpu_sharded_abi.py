@@ -30,7 +30,7 @@ def _slice(rng, n, n_keys):
 
 
 @pytest.mark.parametrize("engine_streams", ["external", "own"])
-def test_routed_step_over_the_library_owned_rccl_communicator_world_1(engine_streams, monkeypatch):
+def test_routed_step_over_the_library_owned_rccl_communicator_world_1(engine_streams, monkeypatch, rccl_ready):
     # "own": the engine keeps its two streams and is ordered by rl_engine_wait_event / rl_engine_record_event
     monkeypatch.setenv("RL_SHARDED_ENGINE_STREAMS", engine_streams)
     dev = torch.device("cuda", 0)
@@ -75,12 +75,15 @@ def test_routed_step_over_the_library_owned_rccl_communicator_world_1(engine_str
     eng.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_routed_step_world_n_with_the_in_process_transport(world):
     """Every rank a thread with its own engine (all on this GPU).  The owners' tables are disjoint, the
-    verdicts must equal ONE sequential storage fed rank 0's slice, then rank 1's, ... per step."""
+    verdicts must equal ONE sequential storage fed rank 0's slice, then rank 1's, ... per step.
+    World 8 is bench.py --gpus 8's shape scaled down (8 engines, 16 k keys each, 16 k-hit ingress slices, three slices in
+    flight) with two skewed steps: every rank's slice made of keys ONE rank owns, so that rank receives 8 x its own slice
+    (the receive buffers and the engine's max_batch_hits are sized for exactly that) while seven ranks apply nothing."""
     dev = torch.device("cuda", 0)
-    n, steps, n_keys = 30_000, 7, 5000
+    n, steps, n_keys = (30_000, 7, 5000) if world < 8 else (16_000, 8, 128_000)
     group = sharded_abi.LocalGroup(world)
     engines = [Engine(capacity_cells=1 << 16, max_batch_hits=world * n) for _ in range(world)]
     for e in engines:
@@ -92,6 +95,15 @@ def test_routed_step_world_n_with_the_in_process_transport(world):
     slices = [[_slice(rng, n - 97 * s - 13 * r, n_keys) for r in range(world)] for s in range(steps)]
     if world == 3:
         slices[2][1] = slices[2][1][:0]  # an empty ingress slice on one rank
+    if world == 8:
+        pool = W.splitmix64(np.arange(1, 200_000, dtype=np.uint64))
+        for s_skew, owner in ((3, 5), (4, 0)):  # (two skewed slices in flight at once, different owners)
+            own = np.array([k for k in pool[:40_000] if engines[0].owner_of(int(k), world) == owner][:2500], dtype=np.uint64)
+            for r in range(world):
+                h = slices[s_skew][r]
+                h["key"] = own[rng.integers(0, len(own), size=len(h))]
+                h["limit"] = (h["key"] % 2).astype(np.uint32)
+                h["delta"] = 1 + (h["key"] % 3 == 0)
     now0 = W.NOW0_US
     want = []
     for s in range(steps):
@@ -131,6 +143,9 @@ def test_routed_step_world_n_with_the_in_process_transport(world):
             assert np.array_equal(dev_out[s][r].cpu().numpy(), want[s * world + r]), f"step {s} rank {r}"
         # every hit of the step was applied by exactly one owner
         assert sum(applied[r][s] for r in range(world)) == sum(len(slices[s][r]) for r in range(world))
+    if world == 8:  # the skewed steps: ONE rank applied all eight slices, the others nothing
+        assert applied[5][3] == sum(len(slices[3][r]) for r in range(world)) and applied[0][3] == 0
+        assert applied[0][4] == sum(len(slices[4][r]) for r in range(world)) and applied[5][4] == 0
     # the owners' tables are a partition of the oracle's cells
     rows = np.concatenate([e.dump_cells() for e in engines])
     assert len(rows) == orc.num_qualified()
@@ -273,13 +288,15 @@ def _check_union_of_tables(engines, orc):
 
 
 @pytest.mark.parametrize("world", [1, 2, 3])
-def test_key_sharded_multi_counter_requests_behind_the_c_abi(world):
+def test_key_sharded_multi_counter_requests_behind_the_c_abi(world, request):
     """in_memory.rs:141-153 across GPUs: a request is admitted iff all its counters — on whatever rank their keys hash
     to — take it.  World 1 over the library's own RCCL communicator; world 2 and 3 as threads with the in-process
     transport.  Against ONE sequential oracle on the concatenated slices: verdicts, first_limited, remaining /
     expires_in, the union of the tables; at least one step needs three rounds."""
     from test_sharded_multi_gloo import compare, expected, make_slices, run_rank
 
+    if world == 1:
+        request.getfixturevalue("rccl_ready")  # (world 1 runs over the library's own RCCL communicator)
     dev = torch.device("cuda", 0)
     steps, n_req, load_steps = 6, 900, {1, 4}
     probe = Engine(capacity_cells=1 << 10, max_batch_hits=1 << 10)
@@ -372,6 +389,224 @@ def test_a_multi_counter_step_one_shard_cannot_take_is_refused_on_every_rank():
     assert results[0] == results[1] == -4  # RL_ERR_TABLE_FULL on both ranks, nothing applied on either
     assert results[(0, "after")] == 0
     assert sum(e.stats()["live_cells"] for e in engines) == 30 + len(SIMPLE)
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        e.close()
+    group.close()
+
+
+# ---- a sweep as a command of the routed pipeline: rl_sharded_sweep_submit / _collect ------------------------------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_routed_sweeps_between_slices_in_flight(world):
+    """BASELINE.json configs[4] "concurrent expiry sweep", routed: every rank sweeps its shard at the same point of the
+    sequence — behind every slice submitted so far, in front of every later one — with slices in flight on both sides of it
+    (three commands deep).  Against ONE sequential oracle that is swept at those points: verdicts of every slice, the sum of
+    the ranks' removed cells per sweep, and the union of the tables (a swept cell that a later slice touches is created anew:
+    value 0, expiry now + window, in_memory.rs:122-127)."""
+    dev = torch.device("cuda", 0)
+    n, steps, n_keys = 20_000, 10, 6000
+    sweep_after = {1, 2, 5, 8}  # (two sweeps back to back in the window of three, too)
+    group = sharded_abi.LocalGroup(world)
+    engines = [Engine(capacity_cells=1 << 16, max_batch_hits=world * n) for _ in range(world)]
+    for e in engines:
+        e.set_limits(ROWS)
+    ranks = [sharded_abi.Sharded(engines[r], world, r, n, transport=group.transport(r)) for r in range(world)]
+    orc = oracle.OracleStorage()
+    orc.set_limits(ROWS)
+    rng = np.random.default_rng(70 + world)
+    slices = [[_slice(rng, n - 53 * s - 11 * r, n_keys) for r in range(world)] for s in range(steps)]
+    now_of = [W.NOW0_US + 450_000 * s for s in range(steps)]   # limit 1's one-second windows run out every other slice
+    want, want_removed = [], []
+    for s in range(steps):
+        for r in range(world):
+            want.append(orc.check_and_update(slices[s][r], now_of[s])[0])
+        if s in sweep_after:
+            want_removed.append(orc.sweep_expired(now_of[s] + 200_000))
+    assert sum(want_removed) > 1000
+    dev_in = [[_to_dev(slices[s][r], dev) for r in range(world)] for s in range(steps)]
+    dev_out = [[torch.full((len(slices[s][r]),), 7, dtype=torch.uint8, device=dev) for r in range(world)] for s in range(steps)]
+    torch.cuda.synchronize()
+    removed = [[] for _ in range(world)]
+    errors = []
+
+    def run(r):
+        try:
+            sh, kinds = ranks[r], []
+
+            def collect_one():
+                if kinds.pop(0) == "sweep":
+                    removed[r].append(sh.sweep_collect())
+                else:
+                    sh.collect()
+
+            for s in range(steps):
+                while sh.in_flight == 3:
+                    collect_one()
+                sh.submit(dev_in[s][r].data_ptr(), len(slices[s][r]), now_of[s], dev_out[s][r].data_ptr())
+                kinds.append("slice")
+                if s in sweep_after:
+                    while sh.in_flight == 3:
+                        collect_one()
+                    sh.sweep_submit(now_of[s] + 200_000)
+                    kinds.append("sweep")
+                    if s == 5:  # the wrong collect for the oldest command is refused, and nothing is lost
+                        if kinds[0] == "sweep":
+                            with pytest.raises(sharded_abi.ShardedError):
+                                sh.collect()
+                        else:
+                            with pytest.raises(sharded_abi.ShardedError):
+                                sh.sweep_collect()
+            while sh.in_flight:
+                collect_one()
+            sh.sync()
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck at the rendezvous"
+    torch.cuda.synchronize()
+    for s in range(steps):
+        for r in range(world):
+            assert np.array_equal(dev_out[s][r].cpu().numpy(), want[s * world + r]), f"step {s} rank {r}"
+    assert [sum(removed[r][i] for r in range(world)) for i in range(len(want_removed))] == want_removed
+    rows = np.concatenate([e.dump_cells() for e in engines])
+    assert len(rows) == orc.num_qualified() and len(np.unique(rows["key"])) == len(rows)
+    for row in rows[::29]:
+        assert (int(row["value"]), int(row["expiry_us"]), int(row["limit"])) == orc.peek(int(row["key"]))
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        e.close()
+    group.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config5_trace_routed_by_key_with_sweeps_between_the_steps(world):
+    """BASELINE.json configs[4] / SURVEY.md §8(d) config #5 as a ROUTED run (VERDICT r04 missing #2): 4 namespaces x 8 limits
+    (2 simple + 6 qualified on 1-2 variables), windows {1, 10, 60, 3600} s, k in [1, 8] counters per request with the
+    conditions as per-request applicability, 16 steps with an advancing clock that crosses the 1 s and 10 s windows — every
+    request's counters spread over the ranks by key hash, the all-or-nothing rule spanning them (in_memory.rs:141-153) through
+    rl_sharded_check_requests_device, and a routed sweep (rl_sharded_sweep_submit / _collect) between the steps.  Against ONE
+    sequential oracle on the concatenated slices, swept at the same points: verdicts, first_limited, remaining / expires_in
+    on the load_counters steps, the sweeps' removed counts, the union of the shards' tables."""
+    from limitador_amd.sharded import owner_of_tensor
+    from limitador_amd.wire import HIT_DTYPE, RL_SIMPLE
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(550 + world)
+    windows = [1, 10, 60, 3600]
+    rows, simple, limit_of = [], [], {}
+    for ns in range(4):
+        for j in range(8):
+            lid = len(rows)
+            rows.append((int(rng.integers(20, 2000)) if j == 0 else int(rng.integers(2, 60)), windows[(ns + j) % 4]))
+            limit_of[(ns, j)] = lid
+            if j < 2:
+                simple.append((lid, 20_000_000 + lid))
+    probe = Engine(capacity_cells=1 << 10, max_batch_hits=1 << 10)
+    seed = probe.hash_seed
+    probe.close()
+    engines = []
+    for r in range(world):
+        e = Engine(capacity_cells=1 << 16, max_batch_hits=1 << 15)
+        e.set_limits(rows)
+        for lid, key in simple:  # a simple counter's cell lives on the rank its key hashes to (in_memory.rs:38-44)
+            if int(owner_of_tensor(torch.tensor([key]), seed, world)[0]) == r:
+                e.add_counter(lid | RL_SIMPLE, key)
+        engines.append(e)
+    orc = oracle.OracleStorage()
+    orc.set_limits(rows)
+    for lid, key in simple:
+        orc.add_counter(lid | RL_SIMPLE, key)
+    group = sharded_abi.LocalGroup(world)
+    ranks = [sharded_abi.Sharded(engines[r], world, r, 1 << 13, transport=group.transport(r)) for r in range(world)]
+    steps = 16
+
+    def make(n_req):
+        hits, off = [], [0]
+        for _ in range(n_req):
+            ns, user, path = int(rng.integers(0, 4)), int(rng.zipf(1.4) - 1) % 300, int(rng.integers(0, 6))
+            delta = 1 if rng.random() < 0.8 else int(rng.integers(0, 5))
+            applies = [j for j in range(8) if rng.random() < (0.9 if j < 2 else 0.45)] or [0]
+            for j in sorted(applies, key=lambda x: (x >= 2,)):  # simple first (in_memory.rs:105,121)
+                lid = limit_of[(ns, j)]
+                if j < 2:
+                    hits.append((20_000_000 + lid, lid | RL_SIMPLE, delta))
+                else:
+                    material = lid * 1_000_003 + user * 7 + (path if j % 2 else 0)
+                    hits.append((int(W.splitmix64(np.array([material], dtype=np.uint64))[0]), lid, delta))
+            off.append(len(hits))
+        arr = np.zeros(len(hits), dtype=HIT_DTYPE)
+        for i, h in enumerate(hits):
+            arr[i] = h
+        return arr, np.array(off, dtype=np.int64)
+
+    data = [[make(int(rng.integers(150, 700))) for _ in range(world)] for _ in range(steps)]
+    nows, sweeps, now = [], [], W.NOW0_US
+    for s in range(steps):
+        nows.append(now)
+        now += int(rng.integers(250_000, 3_000_000))
+        sweeps.append(now if s % 2 else None)
+    want, want_removed = [], []
+    for s in range(steps):
+        hits = np.concatenate([data[s][r][0] for r in range(world)])
+        off = [0]
+        for r in range(world):
+            off.extend((data[s][r][1][1:] + off[-1]).tolist())
+        load = s % 3 == 2
+        v, f, rem, exp = orc.check_and_update(hits, nows[s], req_off=np.array(off, dtype=np.uint32), load_counters=load)
+        per_rank, lo_r, lo_h = [], 0, 0
+        for r in range(world):
+            nr, nh = len(data[s][r][1]) - 1, len(data[s][r][0])
+            fr = f[lo_r:lo_r + nr].astype(np.int64)
+            per_rank.append((v[lo_r:lo_r + nr], np.where(fr >= 0, fr - lo_h, -1), rem[lo_h:lo_h + nh] if load else None,
+                             exp[lo_h:lo_h + nh] if load else None))
+            lo_r, lo_h = lo_r + nr, lo_h + nh
+        want.append(per_rank)
+        if sweeps[s] is not None:
+            want_removed.append(orc.sweep_expired(sweeps[s]))
+    assert sum(want_removed) > 50
+    got, removed, errors = {r: [] for r in range(world)}, {r: [] for r in range(world)}, []
+
+    def run(r):
+        try:
+            sh = _RequestsOverTheAbi(ranks[r], dev)
+            for s in range(steps):
+                h, off = data[s][r]
+                t = torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev)
+                load = s % 3 == 2
+                v, f, rem, exp = sh.check(t, torch.from_numpy(off).to(dev), nows[s], load_counters=load)
+                got[r].append((v.cpu().numpy(), f.cpu().numpy(), None if rem is None else rem.cpu().numpy().view(np.uint64),
+                               None if exp is None else exp.cpu().numpy().view(np.uint64)))
+                if sweeps[s] is not None:
+                    ranks[r].sweep_submit(sweeps[s])
+                    removed[r].append(ranks[r].sweep_collect())
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck at an exchange"
+    for s in range(steps):
+        for r in range(world):
+            v, f, rem, exp = got[r][s]
+            wv, wf, wrem, wexp = want[s][r]
+            assert np.array_equal(v, wv), f"step {s} rank {r}: verdicts"
+            assert np.array_equal(f, wf), f"step {s} rank {r}: first_limited"
+            if wrem is not None:
+                assert np.array_equal(rem, wrem) and np.array_equal(exp, wexp), f"step {s} rank {r}: remaining / expires_in"
+    assert [sum(removed[r][i] for r in range(world)) for i in range(len(want_removed))] == want_removed
+    _check_union_of_tables(engines, orc)
     for sh in ranks:
         sh.close()
     for e in engines:

@@ -77,7 +77,7 @@ def test_key_sharded_multi_counter_requests_on_the_hip_engine(world):
         e.close()
 
 
-def test_the_driver_over_rccl_world_1():
+def test_the_driver_over_rccl_world_1(rccl_ready):
     import torch.distributed as dist
 
     with socket.socket() as s:

@@ -10,8 +10,8 @@ branch of the hot-key code (promotion, decided by position, replayed, created by
   RL_OVERLAP=0       k_bkt_part and the replay on one stream
   RL_PART_COMPACT=0  k_bkt_part (1024 threads) for 4096-hit tiles instead of k_bkt_part_c (512 threads, half the LDS)
   RL_APPLY_EVENTS=0  the replay as a plain launch; the partition stream ordered by what the host has collected
-  RL_DEFER2=1        a replay whose partition is still running when the next batch is submitted is held back across that submit
-                     and goes out from the collect's spin, without a wait command (prepared in round 4)
+  RL_DEFER2=0        the default (1) holds a replay whose partition is still running when the next batch is submitted back across
+                     that submit and sends it out from the collect's spin, without a wait command; 0 = the form before
   RL_FUSE=1          one stream, one k_bkt_step launch per step: the replay of batch j and, beside it, the partition of batch
                      j + 1 as a role of 256-thread workgroups
 
@@ -34,8 +34,7 @@ TWO = {"RL_FUSE": "0"}
 VARIANTS = [{}, TWO, {**TWO, "RL_DEFER_APPLY": "0"}, {**TWO, "RL_APPLY2_CFG": "1"}, {"RL_FUSE": "1"}, {**TWO, "RL_OVERLAP": "0"},
             {"RL_FUSE": "1", "RL_DEFER_APPLY": "0"}, {**TWO, "RL_DEFER_APPLY": "0", "RL_PIPE_DEPTH": "2", "RL_APPLY2_CFG": "2"},
             {**TWO, "RL_APPLY_EVENTS": "0"}, {**TWO, "RL_PART_COMPACT": "0"}]
-if os.environ.get("RL_TEST_DEFER2") == "1":  # (written without a GPU at hand: opt-in until a visit has seen it green)
-    VARIANTS.append({**TWO, "RL_DEFER2": "1"})
+VARIANTS.append({**TWO, "RL_DEFER2": "0"})  # (the default since round 5 is 1: gpurun_out/r13a)
 
 
 def hot_trace(eng, orc, rng, n=60_000):
