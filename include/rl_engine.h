@@ -368,9 +368,11 @@ int32_t rl_wire_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, 
  * -101 (no domain: Code::Unknown, envoy_rls/server.rs:105-115; the message derives no counter) or RL_ERR_INVALID
  * (malformed: no counter); verdict[i]; limited_limit[i] (may be NULL); the derived counters as in
  * rl_match_and_check_batch.  Returns RL_ERR_KEY_COLLISION when two counters of the batch, or a counter of the batch and
- * a stored one, share a 64-bit key with different check words: NOTHING was applied and *collided_message is the index
- * of a message that derives one of them — the caller answers that message on its exact path (or drops it) and calls
- * again without it. */
+ * a stored one, share a 64-bit key with different check words (a limit id that differs under one key is the same thing:
+ * hashed keys carry the limit in the key): NOTHING was applied, status[i] = -103 for EVERY message that derives a
+ * counter which is not the one its key belongs to (the word stored in the key's cell decides; without a cell, the
+ * batch's first counter of that key) and *collided_message is the index of one of them — the caller answers those
+ * messages on its exact path (or drops them) and calls again without them: one re-run, however many collide. */
 /* Pinned host buffers that belong to the engine, by slot (0..3; grown on demand — a later call for the same slot may move
  * it — and freed with the engine): where a host layer builds the arrays it hands to the host-pointer entry points and
  * receives their results, so that every copy is plain DMA instead of the runtime's pageable path (a fresh 60 MB result

@@ -924,9 +924,22 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
                                                              with_headers ? req_off : nullptr, with_headers ? hits : nullptr,
                                                              (uint32_t)cap, &n_hits, with_headers ? rem : nullptr,
                                                              with_headers ? exp : nullptr, &collided);
-            if (rc == RL_ERR_KEY_COLLISION && collided >= 0 && (uint64_t)collided < n && !skip[collided] && attempt < 64) {
-                skip[collided] = 1;  // its counter shares a 64-bit key with another one: never merged — the caller's exact path
-                continue;
+            if (rc == RL_ERR_KEY_COLLISION && attempt < 8) {
+                // Counters that share a 64-bit key with another counter are never merged: their messages are taken out — ALL
+                // of them at once, the device names every one in dev_status (-103) — and answered RLI_HOST_ONLY (the caller's
+                // exact path); the rest of the batch is applied.  One re-run is the rule; a second only when a message that
+                // was taken out had been hiding another collision behind it.
+                uint32_t taken = 0;
+                for (uint32_t i = 0; i < n; ++i)
+                    if (dev_status[i] == -103 && !skip[i]) {
+                        skip[i] = 1;
+                        ++taken;
+                    }
+                if (!taken && collided >= 0 && (uint64_t)collided < n && !skip[collided]) {
+                    skip[collided] = 1;
+                    ++taken;
+                }
+                if (taken) continue;
             }
             if (rc) return gfail(g, rc, "rl_wire_match_and_check_batch: %s", rl_last_error(e));
             break;

@@ -375,9 +375,11 @@ int status_to_error(rl_engine* e, u32 bits) {
         return fail(e, RL_ERR_MISSING_SIMPLE,
                     "simple counter without a pre-created cell (reference: in_memory.rs:107 unwrap panics)");
     if (bits & ERRBIT_TABLE_FULL) return fail(e, RL_ERR_TABLE_FULL, "counter table is full");
-    if (bits & ERRBIT_KEY_LIMIT) return fail(e, RL_ERR_KEY_LIMIT, "a key was used with two different limit ids");
+    // (hashed keys carry the limit IN the key: two limit ids under one key are two counters that share it, and the check
+    // words — which k_gen_check_keys compares whatever k_gen_sort said about the limit ids — name the hits)
     if (bits & ERRBIT_KEY_COLLISION)
         return fail(e, RL_ERR_KEY_COLLISION, "two counters share a 64-bit key (their check words differ): nothing was applied");
+    if (bits & ERRBIT_KEY_LIMIT) return fail(e, RL_ERR_KEY_LIMIT, "a key was used with two different limit ids");
     return fail(e, RL_ERR_DEVICE, "unknown device status 0x%x", bits);
 }
 
@@ -1230,6 +1232,7 @@ struct GenCall {
     bool hit_req_filled = false;         // e->d_hit_req already holds the request of every hit (k_match_fast wrote it)
     bool host_mapped_results = false;    // every result pointer is fine-grained host-mapped memory (rl_engine::h_tiny)
     const u32* d_hit_check = nullptr;    // hashed keys: the check word of every hit (rl_keyhash.h), verified before the commit
+    int32_t* d_msg_status = nullptr;     // hashed keys: per-request status words; a colliding request is marked there (k_gen_check_keys)
 };
 
 // Partition of the pass's hits + k_gen_sort: everything up to the first fixpoint round.  A is filled for the kernels
@@ -1287,6 +1290,7 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     A.req_off = c.d_req_off;
     A.req_delta = c.d_req_delta;
     A.hit_check = c.d_hit_check ? c.d_hit_check + hit0 : nullptr;
+    A.msg_status = c.d_hit_check ? c.d_msg_status : nullptr;
     A.hit0 = hit0;
     A.req0 = req0;
     A.n_hits = n;
@@ -3224,10 +3228,15 @@ int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const u
     gc.d_limited = limited_limit ? e->d_m_limited : nullptr;
     gc.hit_req_filled = n_hits > 0;
     gc.d_hit_check = e->d_hit_check;
+    gc.d_msg_status = e->d_w_status;
     rc = run_check_general(e, gc);
-    if (rc == RL_ERR_KEY_COLLISION && collided_message && e->collide_hit < n_hits) {
-        u32 req = 0;
-        if (hipMemcpy(&req, e->d_hit_req + e->collide_hit, sizeof(u32), hipMemcpyDeviceToHost) == hipSuccess) *collided_message = req;
+    if (rc == RL_ERR_KEY_COLLISION) {
+        // status[] names EVERY message that carries a colliding counter (-103); *collided_message is one of them
+        if (collided_message && e->collide_hit < n_hits) {
+            u32 req = 0;
+            if (hipMemcpy(&req, e->d_hit_req + e->collide_hit, sizeof(u32), hipMemcpyDeviceToHost) == hipSuccess) *collided_message = req;
+        }
+        (void)hipMemcpy(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost);
     }
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n, hipMemcpyDeviceToHost, e->stream));

@@ -112,6 +112,8 @@ struct GenArgs {
     const u32* req_off;      // absolute CSR offsets (null: every hit its own request)
     const u64* req_delta;    // per-request u64 deltas of the caller's batch (null: the wire field)
     const u32* hit_check;    // hashed keys (rl_keyhash.h): the check word of every hit of the pass, else null
+    int32_t* msg_status;     // hashed keys: per REQUEST of the caller's batch; k_gen_check_keys stores WIRE_ST_KEY_COLLISION for
+                             // every request that carries a colliding hit (the caller takes them all out at once), else null
     u32 hit0, req0;          // the pass starts at this hit / request of the caller's batch
     u32 n_hits, n_req;       // size of the pass
     const BHit* b_hits;
@@ -897,23 +899,24 @@ __global__ __launch_bounds__(256) void k_gen_count(GenArgs A) {
 // segment (= one 64-bit key) with different words, or a hit whose word differs from the one stored in its key's cell, are
 // two counters that share a key: the pass is REFUSED (ERRBIT_KEY_COLLISION, nothing is applied, `collide` names the hit)
 // and the caller takes that request out — never a silent merge.  Launched between k_gen_sort and the commit.
+// Every hit of a segment is compared with ONE reference — the word stored in the key's cell if the cell exists (and was
+// created through hashed keys), else the word of the segment's first hit — so that one pass names EVERY hit that is not
+// the counter the key belongs to: the caller takes all their requests out and runs the batch again once (one
+// re-run per colliding message, capped at 64, turned 65 crafted messages into a failed batch of 262 144).
+constexpr int32_t WIRE_ST_KEY_COLLISION = -103;  // msg_status[]: the request carries a counter whose 64-bit key is another counter's
 __global__ __launch_bounds__(256) void k_gen_check_keys(GenArgs A) {
     if (A.pst->err || A.gst->overflow) return;
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= A.n_hits) return;
     const SHit h = A.s_hits[j];
     const u32 chk = A.hit_check[h.idx];
-    u32 other;
-    if (h.seg == j) {
-        const u32 slot = A.seg_info[j].slot;
-        other = slot == SLOT_INVALID ? chk : A.table[slot].pad;
-        if (other == 0u) other = chk;  // a cell that was not created through hashed keys (add_counter, a loaded row)
-    } else {
-        other = A.hit_check[A.s_hits[h.seg].idx];
-    }
-    if (other != chk) {
+    const u32 slot = A.seg_info[h.seg].slot;
+    u32 ref = slot == SLOT_INVALID ? 0u : A.table[slot].pad;  // 0: no cell yet, or one not created through hashed keys
+    if (ref == 0u) ref = A.hit_check[A.s_hits[h.seg].idx];
+    if (ref != chk) {
         atomicOr(&A.gst->err, ERRBIT_KEY_COLLISION);
         atomicMax(&A.gst->collide, ~h.idx);
+        if (A.msg_status) A.msg_status[A.hit_req ? A.hit_req[A.hit0 + h.idx] : A.req0 + h.idx] = WIRE_ST_KEY_COLLISION;
     }
 }
 

@@ -408,6 +408,53 @@ def test_two_counters_that_share_a_key_are_never_merged(make_engine):
     g.close()
 
 
+def test_many_colliding_messages_take_one_rerun_and_a_limit_mismatch_is_a_collision(make_engine):
+    """(a) 150 messages of one batch whose counters' keys are held by OTHER counters — one re-run per
+    colliding message, capped at 64, used to turn that into a failed batch of up to 262 144 requests; the device now names every
+    colliding message in one pass and the batch is served with ONE re-run.  (b) A stored cell that shares a message's key
+    under another LIMIT id (hashed keys carry the limit in the key, so that is two counters sharing a key) used to come back
+    as RL_ERR_KEY_LIMIT and fail the whole batch, again on every later batch carrying that message; it is a collision like
+    any other: that message HOST_ONLY, the rest applied.  Both forged by loading rows (a real 64-bit collision is a
+    2^32-hash birthday search, cheap for an attacker but not for a test: include/rl_keyhash.h)."""
+    from limitador_amd.ingest import HOST_ONLY
+    from limitador_amd.wire import CELL_ROW_DTYPE
+
+    eng, g, model = _install(make_engine, "hashed")
+    lims = _limits()
+    j = next(i for i, L in enumerate(lims) if L[0] == "ns1" and L[4] == ["user"])
+    other = next(i for i, L in enumerate(lims) if i != j and L[0] == "ns1")
+    victims = [f"victim-{i}" for i in range(150)]
+    rows = np.zeros(len(victims) + 1, dtype=CELL_ROW_DTYPE)
+    for i, u in enumerate(victims):
+        key, chk = g.counter_key(j, [u])
+        rows[i] = (key, j, chk ^ (0x1000 + i), 2, NOW + 50_000_000)          # another counter's check word under the key
+    key_lm, chk_lm = g.counter_key(j, ["limit-mismatch"])
+    rows[-1] = (key_lm, other, chk_lm ^ 0x77, 5, NOW + 50_000_000)            # ... and under ANOTHER limit id
+    eng.load_cells(rows)
+    before = np.sort(eng.dump_cells(), order="key")
+    users = victims + ["limit-mismatch"] + [f"honest-{i}" for i in range(300)]
+    rng = np.random.default_rng(9)
+    order = rng.permutation(len(users))
+    ctxs = [("ns1", {"method": "GET", "path": "/", "user": users[i], "app": "app0"}) for i in order]
+    msgs = [rls_request(d, [list(c.items())]) for d, c in ctxs]
+    for rerun in range(2):  # the second batch meets the same cells again: still served, still without them
+        status, _ = g.serve_batch(eng, msgs, NOW + rerun, with_headers=bool(rerun))
+        n_host = 0
+        for i, (d, c) in enumerate(ctxs):
+            applies_j = model_applies(lims[j], c)
+            if applies_j and (c["user"].startswith("victim-") or c["user"] == "limit-mismatch"):
+                assert status[i] == HOST_ONLY, (i, c["user"], status[i])
+                n_host += 1
+            else:
+                want = model.check_rate_limited_and_update(d, c, 1, bool(rerun))
+                assert status[i] == (1 if want.limited else 0), (i, c["user"])
+        assert n_host == 151
+    after = np.sort(eng.dump_cells(), order="key")
+    forged = after[np.isin(after["key"], before["key"])]
+    assert np.array_equal(forged, before), "a forged cell was touched"
+    g.close()
+
+
 def model_applies(L, ctx):
     for k, op, v in L[3]:
         if k not in ctx or (ctx[k] == v) != (op == "=="):
