@@ -356,13 +356,15 @@ int32_t rl_match_and_check_batch_device(rl_engine *e, const uint32_t *d_req_ns, 
  * rl_wire_table_set: the strings behind the ids of the installed match table (call after rl_match_table_set; the table
  * must have the slot form: at most 8 distinct descriptor keys, 64 limits per namespace) — all inside `blob`
  * (<= 8192 bytes): ns[namespace id] (ns[0] is the namespace without limits), keys[key id], vals[value id] for every id
- * the conditions use (<= 512), and limit_prefix[2 * limit id ..] = rl_kh_bytes of the limit's canonical prefix. */
+ * the conditions use (<= 512), limit_prefix[2 * limit id ..] = rl_kh_bytes of the limit's canonical prefix, and
+ * hash_key[2] = the 128-bit secret every hash of this path is keyed with (include/rl_keyhash.h: the prefixes must have
+ * been hashed under the same key; whoever else derives keys for this table — another front-end, a restart — needs it). */
 typedef struct {
     uint32_t off, len; /* a string: blob[off .. off + len) */
 } rl_wire_str;
 int32_t rl_wire_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, const rl_wire_str *ns, uint32_t n_ns,
                           const rl_wire_str *keys, uint32_t n_keys, const rl_wire_str *vals, uint32_t n_vals,
-                          const uint64_t *limit_prefix, uint32_t n_limits);
+                          const uint64_t *limit_prefix, uint32_t n_limits, const uint64_t *hash_key);
 /* counters_that_apply + check_and_update for n messages, applied in index order with one clock value: message i is
  * wire[msg_off[i] .. msg_off[i + 1]) (host pointers; msg_off[0] = 0).  Out, per message: status[i] = 0, or
  * -101 (no domain: Code::Unknown, envoy_rls/server.rs:105-115; the message derives no counter) or RL_ERR_INVALID

@@ -99,6 +99,13 @@ int32_t rli_set_binding(rli_ingest *g, int32_t binding);
 #define RLI_KEYS_EXACT 0
 #define RLI_KEYS_HASHED 1
 int32_t rli_set_key_mode(rli_ingest *g, int32_t mode);
+/* The 128-bit secret RLI_KEYS_HASHED keys its hash with (SipHash-2-4-128, include/rl_keyhash.h: without it a caller who
+ * chooses descriptor values cannot aim at another counter's key).  rli_create draws it from the OS; a host whose table
+ * outlives the ingest or is fed by several ingests — a restart that reloads a snapshot, several front-ends in front of one
+ * engine, the ranks of a sharded deployment — reads it once (rli_hash_key) and gives it to the others (rli_set_hash_key,
+ * before the limits are compiled): it names the cells.  Keep it as secret as the table's contents. */
+int32_t rli_set_hash_key(rli_ingest *g, uint64_t k0, uint64_t k1);
+int32_t rli_hash_key(const rli_ingest *g, uint64_t out[2]);
 /* The key (and check word) RLI_KEYS_HASHED gives the counter of `limit_id` with these variable values (in variable-name
  * order; n_values = the limit's number of variables): what rl_get_counters / rl_dump_cells rows of that mode carry. */
 int32_t rli_counter_key(rli_ingest *g, uint32_t limit_id, const char *const *values, const uint32_t *value_lens,

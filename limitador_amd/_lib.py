@@ -101,7 +101,7 @@ def _declare(lib):
          [p, p, p, p, p, p, C.c_uint32, C.c_uint64, C.c_int32, p, p, p, p, C.c_uint32, u32p, p, p])
     _sig(lib, "rl_match_and_check_batch_device", C.c_int32,
          [p, p, p, p, p, p, C.c_uint32, C.c_uint64, C.c_int32, p, p, u32p])
-    _sig(lib, "rl_wire_table_set", C.c_int32, [p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32])
+    _sig(lib, "rl_wire_table_set", C.c_int32, [p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p])
     _sig(lib, "rl_host_staging", C.c_int32, [p, C.c_uint32, C.c_uint64, C.POINTER(p)])
     _sig(lib, "rl_wire_match_and_check_batch", C.c_int32,
          [p, p, p, C.c_uint32, C.c_uint64, C.c_int32, p, p, p, p, p, C.c_uint32, p, p, p, p])

@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <random>
 #include <shared_mutex>
 #include <thread>
 #include <cstdarg>
@@ -250,6 +251,8 @@ struct rli_ingest {
     // compares the table's strings as bytes and keys every counter by a hash of its canonical key bytes (rl_keyhash.h)
     int key_mode = RLI_KEYS_EXACT;
     std::vector<rl_h128> prefix;     // [limit id]: hash of the limit's canonical prefix (compiled)
+    rl_hkey hash_key{0, 0};          // the secret every hash of this mode is keyed with (rl_keyhash.h): random at rli_create,
+                                     // rli_set_hash_key to share it between front-ends / bring it back with a snapshot
     // batch
     std::vector<uint32_t> req_ns, req_delta, ent_off{0}, ent_key, ent_val;
     std::string err;
@@ -416,6 +419,11 @@ int32_t rli_create(rli_ingest** out) try {
     rli_ingest* g = new (std::nothrow) rli_ingest();
     if (!g) return RL_ERR_NOMEM;
     g->ns_ids.intern("");  // namespace id 0: the namespace without limits
+    {   // 128 bits from the OS: the key of RLI_KEYS_HASHED's SipHash (std::random_device reads /dev/urandom / getrandom here)
+        std::random_device rd;
+        g->hash_key.k0 = ((uint64_t)rd() << 32) | rd();
+        g->hash_key.k1 = ((uint64_t)rd() << 32) | rd();
+    }
     *out = g;
     return RL_OK;
 } RL_ABI_CATCH
@@ -486,7 +494,7 @@ static void pc_str(std::string& o, const std::string& s) {
     pc_varint(o, s.size());
     o += s;
 }
-static rl_h128 canonical_prefix_hash(const LimitSpec& L) {
+static rl_h128 canonical_prefix_hash(const LimitSpec& L, rl_hkey key) {
     std::string o;
     o.push_back((char)1);
     pc_str(o, L.ns);
@@ -495,7 +503,7 @@ static rl_h128 canonical_prefix_hash(const LimitSpec& L) {
     for (const std::string& c : L.cond_src) pc_str(o, c);  // (std::set order = Vec<String>::sort: bytewise)
     pc_varint(o, L.var_src.size());
     for (const std::string& v : L.var_src) pc_str(o, v);
-    return rl_kh_bytes(reinterpret_cast<const uint8_t*>(o.data()), (uint32_t)o.size(), 0ull);
+    return rl_kh_bytes(reinterpret_cast<const uint8_t*>(o.data()), (uint32_t)o.size(), key);
 }
 
 int32_t rli_compile(rli_ingest* g) try {
@@ -506,7 +514,7 @@ int32_t rli_compile(rli_ingest* g) try {
     std::vector<uint32_t> order(n), ns_of(n);
     for (uint32_t i = 0; i < n; ++i) {
         g->rows[i] = rl_limit_row{g->limits[i].max_value, g->limits[i].seconds};
-        g->prefix[i] = canonical_prefix_hash(g->limits[i]);
+        g->prefix[i] = canonical_prefix_hash(g->limits[i], g->hash_key);
         ns_of[i] = g->ns_ids.intern(g->limits[i].ns);
         order[i] = i;
     }
@@ -570,14 +578,14 @@ int32_t rli_install(rli_ingest* g, rl_engine* e) try {
             pre[2 * i + 1] = g->prefix[i].h2;
         }
         rc = rl_wire_table_set(e, blob.data(), (uint32_t)blob.size(), ns.data(), (uint32_t)ns.size(), keys.data(), (uint32_t)keys.size(),
-                               vals.data(), (uint32_t)vals.size(), pre.data(), (uint32_t)g->prefix.size());
+                               vals.data(), (uint32_t)vals.size(), pre.data(), (uint32_t)g->prefix.size(), &g->hash_key.k0);
         if (rc) return gfail(g, rc == RL_ERR_INVALID ? RLI_HOST_ONLY : rc, "rl_wire_table_set: %s", rl_last_error(e));
     }
     for (uint32_t id = 0; id < g->limits.size(); ++id)
         if (g->limits[id].vars.empty()) {  // add_counter, in_memory.rs:38-44: limits without variables only
             uint64_t key = rl_match_key(id, 0, 0, 0);
             uint32_t chk = 0;
-            if (g->key_mode == RLI_KEYS_HASHED) rl_counter_key(g->prefix[id], nullptr, 0, &key, &chk);
+            if (g->key_mode == RLI_KEYS_HASHED) rl_counter_key(g->prefix[id], nullptr, 0, g->hash_key, &key, &chk);
             rc = rl_add_counter(e, id | RL_SIMPLE, key);
             if (rc) return gfail(g, rc, "rl_add_counter: %s", rl_last_error(e));
         }
@@ -591,6 +599,21 @@ int32_t rli_set_key_mode(rli_ingest* g, int32_t mode) try {
     return RL_OK;
 } RL_ABI_CATCH
 
+int32_t rli_set_hash_key(rli_ingest* g, uint64_t k0, uint64_t k1) try {
+    if (!g) return RL_ERR_INVALID;
+    // (the prefix hashes of the compiled limits and everything installed from them carry the old key)
+    if (g->compiled) return gfail(g, RL_ERR_INVALID, "the hash key is set before the limits are compiled / installed");
+    g->hash_key = rl_hkey{k0, k1};
+    return RL_OK;
+} RL_ABI_CATCH
+
+int32_t rli_hash_key(const rli_ingest* g, uint64_t out[2]) try {
+    if (!g || !out) return RL_ERR_INVALID;
+    out[0] = g->hash_key.k0;
+    out[1] = g->hash_key.k1;
+    return RL_OK;
+} RL_ABI_CATCH
+
 int32_t rli_counter_key(rli_ingest* g, uint32_t limit_id, const char* const* values, const uint32_t* value_lens,
                         uint32_t n_values, uint64_t* key, uint32_t* check) try {
     if (!g || !key || limit_id >= g->limits.size() || (n_values && (!values || !value_lens))) return RL_ERR_INVALID;
@@ -601,9 +624,9 @@ int32_t rli_counter_key(rli_ingest* g, uint32_t limit_id, const char* const* val
     if (n_values != g->limits[limit_id].vars.size() || n_values > 2)
         return gfail(g, RL_ERR_INVALID, "limit %u has %zu variables", limit_id, g->limits[limit_id].vars.size());
     rl_h128 v[2];
-    for (uint32_t q = 0; q < n_values; ++q) v[q] = rl_kh_bytes(reinterpret_cast<const uint8_t*>(values[q]), value_lens[q], 0ull);
+    for (uint32_t q = 0; q < n_values; ++q) v[q] = rl_kh_bytes(reinterpret_cast<const uint8_t*>(values[q]), value_lens[q], g->hash_key);
     uint32_t chk = 0;
-    rl_counter_key(g->prefix[limit_id], v, n_values, key, &chk);
+    rl_counter_key(g->prefix[limit_id], v, n_values, g->hash_key, key, &chk);
     if (check) *check = chk;
     return RL_OK;
 } RL_ABI_CATCH

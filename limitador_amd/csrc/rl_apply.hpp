@@ -26,6 +26,30 @@
 
 namespace rl {
 
+// RL_STEP_WT (experiment variants, scripts/exp/build_variant.sh ... -DRL_STEP_WT=1|2): the replay's scattered stores written
+// THROUGH (sc1: they do not stay dirty in the L2).  Why it is worth a measurement now: with the cross-stream wait gone
+// (RL_DEFER2) the 4.4 us between two replays are the boundary of two dependent kernels, and behind a kernel that leaves 16 MB
+// dirty that boundary is 3.4-4.7 us against 1.1-2.0 behind write-through stores (profiles/r04h_kernel_gap.txt).  1: the cells'
+// 8-byte write-backs; 2: the one-byte verdicts too.
+#ifndef RL_STEP_WT
+#define RL_STEP_WT 0
+#endif
+__device__ __forceinline__ void store_cell_value(u64* p, u64 v) {
+#if RL_STEP_WT >= 1
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_verdict(uint8_t* p, u32 v) {
+#if RL_STEP_WT >= 2
+    asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = (uint8_t)v;
+#endif
+}
+
+
 constexpr u32 AP2_BIG_DELTA = 1u << 23;  // 512 hits x (2^23 - 1) < 2^32: the round's sum fits 32 bits
 
 // NARROW: the cell's limit attribute in 16 bits (id < 2^15 | simple flag).  With it the workgroup's LDS is 19.5 KB and
@@ -140,7 +164,7 @@ __device__ __forceinline__ void apply2_commit(LDS& S, const Apply2Args& A, bool 
         }
         if (f & EF_DIRTY) {
             Cell* c = &A.table[S.slot[e]];
-            c->value = S.run[e];
+            store_cell_value(&c->value, S.run[e]);
             if (f & EF_EXPIRED) {  // (the limit row is only read when the window is reset: no dependent load in front of
                                    // the usual write-back)
                 const LimitDev L = limit_row2(A, unpack_limit<NARROW>(S.limit[e]));
@@ -471,7 +495,7 @@ __device__ __forceinline__ void apply2_round(LDS& S, const Apply2Args& A, u32 fi
         if (!ok[u]) continue;
         const u32 i = idx[u];
         if (!slow[u] && (v[u] || !A.sparse_out)) {  // (a slow hit's verdict was stored by the replay above)
-            A.verdict[i] = v[u];
+            store_verdict(&A.verdict[i], v[u]);
             if (A.first_limited) A.first_limited[i] = v[u] ? (int32_t)i : -1;
         }
         if (!leader[u]) continue;
@@ -631,7 +655,7 @@ __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32
                 const u32 j = cb + u * AP_BLOCK + tid;
                 if (j < dlo || j >= dhi) continue;
                 const u32 i = h_tag[u] & 0xFFFFFFu;
-                A.verdict[i] = dv ? 0 : 1;
+                store_verdict(&A.verdict[i], dv ? 0u : 1u);
                 if (A.first_limited) A.first_limited[i] = dv ? -1 : (int32_t)i;
             }
         }
@@ -681,7 +705,7 @@ __device__ __forceinline__ void apply2_hot_item(LDS& S, const Apply2Args& A, u32
         }
         if (n_adm && wslot != SLOT_INVALID) {
             Cell* cell = &A.table[wslot];
-            cell->value = s + (u64)n_adm * d_pred;
+            store_cell_value(&cell->value, s + (u64)n_adm * d_pred);
             if (reset) cell->expiry = A.now + L.window_us;
         }
     }

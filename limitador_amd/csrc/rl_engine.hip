@@ -3104,8 +3104,8 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
 
 int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, const rl_wire_str* ns, uint32_t n_ns,
                           const rl_wire_str* keys, uint32_t n_keys, const rl_wire_str* vals, uint32_t n_vals,
-                          const uint64_t* limit_prefix, uint32_t n_limits) try {
-    if (!e || (blob_len && !blob) || !ns || (n_keys && !keys) || (n_vals && !vals) || (n_limits && !limit_prefix)) return RL_ERR_INVALID;
+                          const uint64_t* limit_prefix, uint32_t n_limits, const uint64_t* hash_key) try {
+    if (!e || (blob_len && !blob) || !ns || (n_keys && !keys) || (n_vals && !vals) || (n_limits && !limit_prefix) || !hash_key) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (!e->d_match_limits || !e->match_fast || !e->match_one)
@@ -3131,7 +3131,7 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     }
     std::vector<WireLit> lit(WIRE_LIT_TAB, WireLit{0ull, 0u, 0, 0xFFFFu});
     for (u32 id = 0; id < n_vals; ++id) {
-        const rl_h128 h = rl_kh_bytes(blob + vals[id].off, vals[id].len, 0ull);
+        const rl_h128 h = rl_kh_bytes(blob + vals[id].off, vals[id].len, rl_hkey{hash_key[0], hash_key[1]});
         u32 q = (u32)h.h1 & (WIRE_LIT_TAB - 1u);
         while (lit[q].id != 0xFFFFu) q = (q + 1u) & (WIRE_LIT_TAB - 1u);
         lit[q] = WireLit{h.h1, vals[id].off, (unsigned short)vals[id].len, (unsigned short)id};
@@ -3155,6 +3155,7 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     W.lit = e->d_w_lit;
     W.prefix = e->d_w_prefix;
     W.var_slot_mask = e->match_var_slots;
+    W.hkey = rl_hkey{hash_key[0], hash_key[1]};
     e->wire_t = W;
     e->wire_ready = true;
     return RL_OK;
@@ -3214,7 +3215,7 @@ int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const u
     k_wire_count<<<gq, 256, 0, e->stream>>>(e->d_w_bytes, e->d_w_off, n, e->wire_t, T, e->d_m_ns, e->d_m_delta, e->d_w_status,
                                             e->d_m_mask, e->d_w_slot_h, e->d_m_scan1);
     k_match_scan2<<<1, 1024, 0, e->stream>>>(e->d_m_scan1, gq, e->d_req_off + n, e->h_m_word, call);
-    k_wire_fill<<<gq, 256, 0, e->stream>>>(e->d_m_ns, e->d_m_delta, n, T, e->d_w_prefix, e->d_m_mask, e->d_w_slot_h, e->d_m_scan1,
+    k_wire_fill<<<gq, 256, 0, e->stream>>>(e->d_m_ns, e->d_m_delta, n, T, e->d_w_prefix, e->wire_t.hkey, e->d_m_mask, e->d_w_slot_h, e->d_m_scan1,
                                            e->d_req_off, e->d_hits, e->d_hit_check, e->d_hit_req, e->max_batch);
     HIP_TRY(e, hipGetLastError());
     int rc = wait_word(e, e->h_m_word + 3, call, "the wire path's count pass");

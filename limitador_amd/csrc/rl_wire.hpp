@@ -44,6 +44,7 @@ struct WireTables {
     WireStr slot_key[MATCH_SLOTS];
     const WireLit* lit;    // [WIRE_LIT_TAB]
     const u64* prefix;     // [limit id][2]: rl_kh_bytes of the limit's canonical prefix
+    rl_hkey hkey;          // the ingest's secret: every hash of this path is SipHash-2-4-128 under it (include/rl_keyhash.h)
     u32 var_slot_mask;     // slots some limit reads as a variable (their values' hashes are kept for k_wire_fill)
 };
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* __restrict__ 
                                 if (sl < T.slots.n && W.slot_key[sl].len == kl && wire_bytes_eq(wire + ko, kl, L.blob + W.slot_key[sl].off))
                                     sl_hit = sl;
                             if (sl_hit < MATCH_SLOTS) {
-                                const rl_h128 h = rl_kh_bytes(wire + vo, vl, 0ull);
+                                const rl_h128 h = rl_kh_bytes(wire + vo, vl, W.hkey);
                                 u32 v = WIRE_NON_LITERAL;
                                 for (u32 q = (u32)h.h1 & (WIRE_LIT_TAB - 1u);; q = (q + 1u) & (WIRE_LIT_TAB - 1u)) {
                                     const WireLit e = L.lit[q];
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_wire_fill(const u32* __restrict__ req_ns, const u32* __restrict__ req_delta, u32 n_req,
-                                                   MatchTables T, const u64* __restrict__ prefix,
+                                                   MatchTables T, const u64* __restrict__ prefix, rl_hkey hkey,
                                                    const unsigned long long* __restrict__ mask, const uint4* __restrict__ slot_h,
                                                    const MatchScan* ms, u32* __restrict__ req_off, Hit* __restrict__ hits,
                                                    u32* __restrict__ hit_check, u32* __restrict__ hit_req, u32 max_hits) {
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void k_wire_fill(const u32* __restrict__ req_n
             }
             uint64_t key;
             uint32_t chk;
-            rl_counter_key(P, vals, nv, &key, &chk);
+            rl_counter_key(P, vals, nv, hkey, &key, &chk);
             Hit h;
             h.key = key;
             h.limit = Lm.limit;

@@ -47,6 +47,8 @@ def _lib():
         "rli_abi_selftest": (C.c_int32, [C.c_int32]),
         "rli_set_value_cap": (i32, [p, u32]),
         "rli_set_key_mode": (i32, [p, i32]),
+        "rli_set_hash_key": (i32, [p, u64, u64]),
+        "rli_hash_key": (i32, [p, C.POINTER(u64)]),
         "rli_counter_key": (i32, [p, u32, strs, C.POINTER(u32), u32, C.POINTER(u64), C.POINTER(u32)]),
         "rli_batch_n_requests": (u32, [p]),
         "rli_batch_n_entries": (u32, [p]),
@@ -89,11 +91,12 @@ class IngestError(RuntimeError):
 
 
 class Ingest:
-    def __init__(self, binding="descriptors", value_cap=None, keys="exact"):
+    def __init__(self, binding="descriptors", value_cap=None, keys="exact", hash_key=None):
         """binding: what the caller's Context binds — "descriptors" (the transports: only the list `descriptors`)
         or "root" (library callers, Context::from(HashMap): every key a root variable).
         keys: "exact" (host dictionaries, packed ids) or "hashed" (rli_set_key_mode RLI_KEYS_HASHED: the device decodes
-        the messages and keys counters by a hash of their canonical key bytes; serve_batch only)."""
+        the messages and keys counters by a hash of their canonical key bytes; serve_batch only).
+        hash_key: (k0, k1), the 128-bit secret of the hashed mode (include/rl_keyhash.h); default: drawn by rli_create."""
         self._so = _lib()
         h = C.c_void_p()
         rc = SYMBOLS["rli_create"](C.byref(h))
@@ -105,6 +108,15 @@ class Ingest:
             self._check(SYMBOLS["rli_set_value_cap"](self._h, int(value_cap)))
         self.keys = keys
         self._check(SYMBOLS["rli_set_key_mode"](self._h, {"exact": 0, "hashed": 1}[keys]))
+        if hash_key is not None:
+            self._check(SYMBOLS["rli_set_hash_key"](self._h, int(hash_key[0]), int(hash_key[1])))
+
+    @property
+    def hash_key(self):
+        """(k0, k1): what another ingest in front of the same table must be given (rli_hash_key)."""
+        out = (C.c_uint64 * 2)()
+        self._check(SYMBOLS["rli_hash_key"](self._h, out))
+        return int(out[0]), int(out[1])
 
     def close(self):
         if self._h:

@@ -1,58 +1,72 @@
-"""Pure-Python restatement of include/rl_keyhash.h for the tests: MurmurHash3_x64_128 (Austin Appleby's published
-function: block step, tail, fmix64) and the counter key the hashed mode derives from a counter's canonical key bytes
-(reference: limitador/src/storage/keys.rs:209-248, key_for_counter_v2 = version byte 1 + postcard of CounterKey)."""
+"""Pure-Python restatement of include/rl_keyhash.h for the tests: SipHash-2-4 with 128-bit output (Aumasson & Bernstein's
+published function; pinned by the paper's 64-bit vector and the reference implementation's first 128-bit vectors in
+tests/test_keyhash_cpu.py) and the counter key the hashed mode derives from a counter's canonical key bytes (reference:
+limitador/src/storage/keys.rs:209-248, key_for_counter_v2 = version byte 1 + postcard of CounterKey)."""
 M = (1 << 64) - 1
-C1, C2 = 0x87C37B91114253D5, 0x4CF5AD432745937F
 
 
 def _rotl(x, r):
     return ((x << r) | (x >> (64 - r))) & M
 
 
-def fmix(k):
-    k ^= k >> 33
-    k = (k * 0xFF51AFD7ED558CCD) & M
-    k ^= k >> 33
-    k = (k * 0xC4CEB9FE1A85EC53) & M
-    return k ^ (k >> 33)
+def _round(v):
+    v0, v1, v2, v3 = v
+    v0 = (v0 + v1) & M
+    v1 = _rotl(v1, 13) ^ v0
+    v0 = _rotl(v0, 32)
+    v2 = (v2 + v3) & M
+    v3 = _rotl(v3, 16) ^ v2
+    v0 = (v0 + v3) & M
+    v3 = _rotl(v3, 21) ^ v0
+    v2 = (v2 + v1) & M
+    v1 = _rotl(v1, 17) ^ v2
+    v2 = _rotl(v2, 32)
+    return [v0, v1, v2, v3]
 
 
-def _mix1(k):
-    return (_rotl((k * C1) & M, 31) * C2) & M
+def _init(key, wide=True):
+    k0, k1 = key
+    v = [k0 ^ 0x736F6D6570736575, k1 ^ 0x646F72616E646F6D, k0 ^ 0x6C7967656E657261, k1 ^ 0x7465646279746573]
+    if wide:
+        v[1] ^= 0xEE
+    return v
 
 
-def _mix2(k):
-    return (_rotl((k * C2) & M, 33) * C1) & M
+def _word(v, m):
+    v[3] ^= m
+    v = _round(_round(v))
+    v[0] ^= m
+    return v
 
 
-def block(h1, h2, k1, k2):
-    h1 = (((_rotl(h1 ^ _mix1(k1), 27) + h2) & M) * 5 + 0x52DCE729) & M
-    h2 = (((_rotl(h2 ^ _mix2(k2), 31) + h1) & M) * 5 + 0x38495AB5) & M
-    return h1, h2
+def _finish(v, last, wide=True):
+    v = _word(v, last)
+    v[2] ^= 0xEE if wide else 0xFF
+    v = _round(_round(_round(_round(v))))
+    h1 = v[0] ^ v[1] ^ v[2] ^ v[3]
+    if not wide:
+        return h1
+    v[1] ^= 0xDD
+    v = _round(_round(_round(_round(v))))
+    return h1, v[0] ^ v[1] ^ v[2] ^ v[3]
 
 
-def finish(h1, h2, n):
-    h1 ^= n
-    h2 ^= n
-    h1 = (h1 + h2) & M
-    h2 = (h2 + h1) & M
-    h1, h2 = fmix(h1), fmix(h2)
-    h1 = (h1 + h2) & M
-    return h1, (h2 + h1) & M
-
-
-def murmur3_x64_128(b, seed=0):
-    h1 = h2 = seed
+def siphash24(b, key, wide=True):
+    """SipHash-2-4 of bytes `b` under key (k0, k1): the 64-bit value, or (h1, h2) of the 128-bit output."""
+    v = _init(key, wide)
     i = 0
-    while i + 16 <= len(b):
-        h1, h2 = block(h1, h2, int.from_bytes(b[i:i + 8], "little"), int.from_bytes(b[i + 8:i + 16], "little"))
-        i += 16
-    t = b[i:]
-    if len(t) > 8:
-        h2 ^= _mix2(int.from_bytes(t[8:], "little"))
-    if t:
-        h1 ^= _mix1(int.from_bytes(t[:8], "little"))
-    return finish(h1, h2, len(b))
+    while i + 8 <= len(b):
+        v = _word(v, int.from_bytes(b[i:i + 8], "little"))
+        i += 8
+    return _finish(v, ((len(b) & 0xFF) << 56) | int.from_bytes(b[i:], "little"), wide)
+
+
+def siphash24_words(words, key):
+    """rl_kh_words: the 128-bit output over 8-byte little-endian words."""
+    v = _init(key)
+    for w in words:
+        v = _word(v, w)
+    return _finish(v, ((8 * len(words)) & 0xFF) << 56)
 
 
 def varint(v):
@@ -87,11 +101,11 @@ def key_prefix_bytes(ns, seconds, conditions, var_names):
             + varint(len(enc)) + b"".join(pstr(v) for v in sorted(enc)))
 
 
-def counter_key(ns, seconds, conditions, var_names, values):
-    """(key, check word) of include/rl_keyhash.h; `values` in variable-NAME order."""
-    h1, h2 = murmur3_x64_128(key_prefix_bytes(ns, seconds, conditions, var_names))
+def counter_key(ns, seconds, conditions, var_names, values, key):
+    """(key, check word) of include/rl_keyhash.h under the ingest's secret `key` = (k0, k1); `values` in variable-NAME order."""
+    words = list(siphash24(key_prefix_bytes(ns, seconds, conditions, var_names), key))
     for v in values:
         v = v.encode() if isinstance(v, str) else bytes(v)
-        h1, h2 = block(h1, h2, *murmur3_x64_128(v))
-    h1, h2 = finish(h1, h2, 16 * len(values) + 1)
+        words += list(siphash24(v, key))
+    h1, h2 = siphash24_words(words, key)
     return (h1 - 2 if h1 >= M - 1 else h1), ((h2 >> 32) or 1)

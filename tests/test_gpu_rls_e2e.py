@@ -287,69 +287,15 @@ def _varint(v):
 
 def test_hashed_keys_are_the_hash_of_the_canonical_key_bytes(make_engine):
     """The cells the device creates carry exactly the (key, check word) include/rl_keyhash.h defines over the counter's
-    canonical key bytes (storage/keys.rs:220-248): recomputed here from the strings alone — MurmurHash3_x64_128 of the
-    prefix (version, namespace, seconds, sorted conditions, sorted variable names in postcard), one block step per value
-    hash, the finalisation — and compared with the table's dump."""
-    M = (1 << 64) - 1
+    canonical key bytes (storage/keys.rs:220-248): recomputed here from the strings and the ingest's secret alone —
+    SipHash-2-4-128 of the prefix (version, namespace, seconds, sorted conditions, sorted variable names in postcard) and of
+    every value, then of those digests as 8-byte words (tests/helpers/keyhash_ref.py, pinned by the published vectors in
+    tests/test_keyhash_cpu.py) — and compared with the table's dump.  A second engine fed the same messages through an
+    ingest with ANOTHER secret holds the same counters under unrelated keys."""
+    from helpers import keyhash_ref as kh
 
-    def rotl(x, r):
-        return ((x << r) | (x >> (64 - r))) & M
-
-    def fmix(k):
-        k ^= k >> 33
-        k = (k * 0xff51afd7ed558ccd) & M
-        k ^= k >> 33
-        k = (k * 0xc4ceb9fe1a85ec53) & M
-        return k ^ (k >> 33)
-
-    c1, c2 = 0x87c37b91114253d5, 0x4cf5ad432745937f
-
-    def mix1(k):
-        return (rotl((k * c1) & M, 31) * c2) & M
-
-    def mix2(k):
-        return (rotl((k * c2) & M, 33) * c1) & M
-
-    def block(h1, h2, k1, k2):
-        h1 = ((rotl(h1 ^ mix1(k1), 27) + h2) & M) * 5 + 0x52dce729 & M
-        h2 = ((rotl(h2 ^ mix2(k2), 31) + h1) & M) * 5 + 0x38495ab5 & M
-        return h1, h2
-
-    def finish(h1, h2, n):
-        h1 ^= n
-        h2 ^= n
-        h1 = (h1 + h2) & M
-        h2 = (h2 + h1) & M
-        h1, h2 = fmix(h1), fmix(h2)
-        h1 = (h1 + h2) & M
-        return h1, (h2 + h1) & M
-
-    def murmur(b):
-        h1 = h2 = 0
-        i = 0
-        while i + 16 <= len(b):
-            h1, h2 = block(h1, h2, int.from_bytes(b[i:i + 8], "little"), int.from_bytes(b[i + 8:i + 16], "little"))
-            i += 16
-        t = b[i:]
-        if len(t) > 8:
-            h2 ^= mix2(int.from_bytes(t[8:], "little"))
-        if t:
-            h1 ^= mix1(int.from_bytes(t[:8], "little"))
-        return finish(h1, h2, len(b))
-
-    assert murmur(b"The quick brown fox jumps over the lazy dog") == (0xe34bbc7bbc071b6c, 0x7a433ca9c49a9347)  # the published vector
-
-    def pstr(x):
-        return _varint(len(x)) + x
-
-    def key_of(ns, seconds, conds, var_names, values):
-        prefix = b"\x01" + pstr(ns.encode()) + _varint(seconds) + _varint(len(conds)) + b"".join(pstr(c.encode()) for c in sorted(conds))
-        prefix += _varint(len(var_names)) + b"".join(pstr(v.encode()) for v in sorted(var_names))
-        h1, h2 = murmur(prefix)
-        for v in values:
-            h1, h2 = block(h1, h2, *murmur(v))
-        h1, h2 = finish(h1, h2, 16 * len(values) + 1)
-        return (h1 - 2 if h1 >= M - 1 else h1), ((h2 >> 32) or 1)
+    def key_of(ns, seconds, conds, var_names, values, hkey=None):
+        return kh.counter_key(ns, seconds, conds, var_names, values, hkey or g.hash_key)
 
     eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
     g = Ingest(keys="hashed")
@@ -373,6 +319,18 @@ def test_hashed_keys_are_the_hash_of_the_canonical_key_bytes(make_engine):
     assert {k: v for k, v in got.items() if not v & 0x80000000} == {k: v for k, v in want.items() if not v & 0x80000000}
     assert g.counter_key(l1, [users[2]]) == key_of("shop", 3600, conds[:1], v2[:1], [users[2]])
     assert g.counter_key(l0) [0] == key_of("shop", 60, conds, [], [])[0]
+    # another secret: the same counters (limit, value, expiry), not one key in common
+    eng2 = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
+    g2 = Ingest(keys="hashed", hash_key=(g.hash_key[0] ^ 1, g.hash_key[1]))
+    for args in (("shop", 100, 60, conds, []), ("shop", 100, 3600, conds[:1], v2[:1]), ("shop", 100, 7, [], v2)):
+        g2.add_limit(*args)
+    g2.install(eng2)
+    assert g2.serve_batch(eng2, msgs, NOW)[0] == status
+    rows2 = eng2.dump_cells()
+    assert sorted((int(r["limit"]), int(r["value"]), int(r["expiry_us"])) for r in rows) == \
+        sorted((int(r["limit"]), int(r["value"]), int(r["expiry_us"])) for r in rows2)
+    assert not set(int(k) for k in rows["key"]) & set(int(k) for k in rows2["key"])
+    g2.close()
     g.close()
 
 
