@@ -285,14 +285,13 @@ int32_t rl_snapshot_load(rl_engine *e, const char *path);
  * earliest future expiry wins (:84); a cell that is expired at now restarts from the row (:85-87).  actor ==
  * self_actor: another replica's memory of OUR value, which only counts if it is larger (:91-95).  Actor ids are
  * 0..7; a key must not appear twice in one call.
- * DEVIATION (pinned by tests/test_gpu_merge.py::test_a_local_window_restart_drops_the_stale_peer_part_the_reference_keeps
- * and exercised, not avoided, by ::test_merge_cells_matches_cr_counter_value): a window restarted by a LOCAL update.
- * check_and_update / update_counter follow InMemoryStorage (atomic_expiring_value.rs:36-42: value = delta, expiry = now +
- * window) and a peer's entry belongs to the window it was reported for, so the restarted cell reads `delta` and the
- * peer's next report counts in full; CrCounterValue::inc_at (cr_counter_value.rs:53-59) resets only its own value and
- * keeps the `others` of the expired window until a merge resets them (:85-87,144-149), so it reads delta + the stale
- * part, and a later report of that peer only counts if it exceeds the stale figure (:96-110).  What a node exports as
- * its own part (rl_export_local) is the same on both sides. */
+ * A window restarted by a LOCAL update follows CrCounterValue::inc_at (cr_counter_value.rs:53-59): our own value becomes
+ * the increment, the peers' contributions to the window that ended stay (`others` is only cleared by a merge's reset,
+ * :85-87,144-149) — the first hit after the expiry reads 0, every later one increment + that stale part, and a later report
+ * of a peer only counts if it exceeds its stale figure (:96-110).  That rule lives in the general resolver: from the first
+ * rl_merge_cells on, every check_and_update / update_counter of this engine takes it (exact, slower), and the pipelined
+ * single-counter entry (rl_check_and_update_submit_device) answers RL_ERR_INVALID — an engine without peer state is not
+ * affected.  tests/test_gpu_merge.py walks the restart number by number against the oracle's CrCounterValue. */
 int32_t rl_merge_cells(rl_engine *e, uint32_t self_actor, uint32_t actor, const rl_cell_row *rows, uint64_t n,
                        uint64_t now_us);
 /* local_values() of every live, unexpired cell: (key, limit, OUR part of the value, expiry) — what a node

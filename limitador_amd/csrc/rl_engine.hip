@@ -362,6 +362,17 @@ int fail(rl_engine* e, int code, const char* fmt, ...) {
 
 inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
+// An engine that holds PEER state (rl_merge_cells has created a per-actor table): its cells are CrCounterValues, not plain
+// AtomicExpiringValues — a window restarted by a local update keeps the peers' part of the window that ended
+// (cr_counter_value.rs:53-59) — and every check_and_update / update_counter of it goes through the general resolver, whose
+// per-cell resolve and commit know about the peer tables (rl_general.hpp).  The single-counter hot path (k_bkt_*), the
+// one-launch kernels and the lingering server do not, and are not taken: the CRDT rule is exact, off the hot path.
+inline bool engine_has_peers(const rl_engine* e) {
+    for (const Cell* t : e->peer_tables)
+        if (t) return true;
+    return false;
+}
+
 u32 ceil_log2(u64 x) {
     u32 l = 0;
     while ((1ull << l) < x) ++l;
@@ -1291,6 +1302,9 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     A.req_delta = c.d_req_delta;
     A.hit_check = c.d_hit_check ? c.d_hit_check + hit0 : nullptr;
     A.msg_status = c.d_hit_check ? c.d_msg_status : nullptr;
+    A.has_peers = engine_has_peers(e) ? 1u : 0u;
+    for (int a = 0; a < MERGE_MAX_ACTORS; ++a) A.peers.t[a] = e->peer_tables[a];
+    A.peers.log2cap = e->log2cap;
     A.hit0 = hit0;
     A.req0 = req0;
     A.n_hits = n;
@@ -1511,7 +1525,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
 }
 
 int run_check_general(rl_engine* e, const GenCall& c) {
-    if (c.n_hits && c.n_hits <= e->gen_tiny_max && c.n_req <= GT_MAX_REQ && !c.update_mode && !c.d_hit_check) {
+    if (c.n_hits && c.n_hits <= e->gen_tiny_max && c.n_req <= GT_MAX_REQ && !c.update_mode && !c.d_hit_check && !engine_has_peers(e)) {
         // A few requests (the per-request calls of the trait): one workgroup, one launch (k_gen_tiny),
         // completion through a sequence word in the host-mapped status block.
         int rc = check_room(e, c.n_hits);
@@ -2115,7 +2129,7 @@ int32_t rl_check_and_update_batch_device(rl_engine* e, const rl_hit* d_hits, uin
     HIP_TRY(e, hipSetDevice(e->device));
     if (load_counters && (!d_remaining || !d_expires_in_us))
         return fail(e, RL_ERR_INVALID, "load_counters needs remaining and expires_in_us buffers");
-    if (d_req_off || load_counters)
+    if (d_req_off || load_counters || engine_has_peers(e))
         return run_check_general(e, GenCall{reinterpret_cast<const Hit*>(d_hits), n_hits, d_req_off, n_req, nullptr, now_us,
                                             load_counters != 0, false, d_verdict, d_first_limited,
                                             reinterpret_cast<u64*>(d_remaining), reinterpret_cast<u64*>(d_expires_in_us)});
@@ -2137,15 +2151,16 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
         // A call the one-launch kernels take (k_bkt_tiny / k_gen_tiny): no copy commands at all.  The
         // request is staged in host-mapped memory the kernel reads directly, the results land there too
         // and are complete when the kernel's completion word is (both kernels are waited for by polling).
-        const bool general = req_off || load_counters || req_delta;
-        const bool one_launch = general ? (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ)
-                                        : (n_hits && n_hits <= e->tiny_max);
+        const bool cr = engine_has_peers(e);  // (cells with peer parts: the general resolver only, see engine_has_peers)
+        const bool general = req_off || load_counters || req_delta || cr;
+        const bool one_launch = !cr && (general ? (n_hits && n_hits <= e->gen_tiny_max && n_req <= GT_MAX_REQ)
+                                                : (n_hits && n_hits <= e->tiny_max));
         // ONE request of a few counters — the trait's per-request call: no launch at all when a server is lingering
         // (k_gen_serve).  Only while the table has room to spare: growing or refusing is the ordinary path's business.
         // (a single-counter request is a request of one counter: the general body is exact for it too)
         // Micro-batches of up to 64 hits / 64 requests ride the same way (verdict and first_limited then come back in one
         // tagged 8-byte slot per request).
-        if (e->serve_enabled && e->h_tiny_coherent && !e->external_stream && n_req >= 1 && n_req <= SRV_MAX_HITS && n_hits >= 1 &&
+        if (!cr && e->serve_enabled && e->h_tiny_coherent && !e->external_stream && n_req >= 1 && n_req <= SRV_MAX_HITS && n_hits >= 1 &&
             n_hits <= SRV_MAX_HITS && n_hits <= e->gen_tiny_max && (n_req == 1 || general) &&
             e->live + e->tombs + n_hits <= e->cap - e->cap / 4) {
             ServeBox* b = e->h_serve;
@@ -2271,10 +2286,11 @@ static int32_t check_batch_locked(rl_engine* e, const rl_hit* hits, uint32_t n_h
             return RL_OK;
         }
     }
+    const bool general_path = req_off || load_counters || req_delta || engine_has_peers(e);
     if (n_hits)  // (the single-counter path reads the batch on the partition stream first)
         HIP_TRY(e, hipMemcpyAsync(e->d_hits, hits, (size_t)n_hits * sizeof(Hit), hipMemcpyHostToDevice,
-                                  (req_off || load_counters || req_delta) ? e->stream : e->pstream));
-    if (req_off || load_counters || req_delta) {
+                                  general_path ? e->stream : e->pstream));
+    if (general_path) {
         if (req_delta)
             HIP_TRY(e, hipMemcpyAsync(e->d_req_delta, req_delta, (size_t)n_req * sizeof(u64), hipMemcpyHostToDevice, e->stream));
         if (req_off) {
@@ -2363,6 +2379,9 @@ int32_t rl_check_and_update_submit_device_ev(rl_engine* e, const rl_hit* d_hits,
     EngineLock g(e);
     if (n_hits == 0) return fail(e, RL_ERR_INVALID, "empty batch");
     if (e->ph_open) return fail(e, RL_ERR_BUSY, "a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    if (engine_has_peers(e))
+        return fail(e, RL_ERR_INVALID, "this engine holds peer state (rl_merge_cells): its counters follow CrCounterValue and are "
+                                       "served by the blocking entries (rl_check_and_update_batch*), not by the pipelined hot path");
     HIP_TRY(e, hipSetDevice(e->device));
     e->submit_done_event = (hipEvent_t)done_event;
     rc = submit_k1_bucketed(e, reinterpret_cast<const Hit*>(d_hits), n_hits, now_us, d_verdict, d_first_limited);

@@ -112,6 +112,8 @@ struct GenArgs {
     const u32* req_off;      // absolute CSR offsets (null: every hit its own request)
     const u64* req_delta;    // per-request u64 deltas of the caller's batch (null: the wire field)
     const u32* hit_check;    // hashed keys (rl_keyhash.h): the check word of every hit of the pass, else null
+    PeerTables peers;        // engines that hold peer state (rl_merge_cells): the per-actor tables; has_peers says whether any exists
+    u32 has_peers;
     int32_t* msg_status;     // hashed keys: per REQUEST of the caller's batch; k_gen_check_keys stores WIRE_ST_KEY_COLLISION for
                              // every request that carries a colliding hit (the caller takes them all out at once), else null
     u32 hit0, req0;          // the pass starts at this hit / request of the caller's batch
@@ -170,8 +172,15 @@ __device__ __forceinline__ SegInfo gen_resolve_from(const GenArgs& A, u64 key, u
             const u64 expiry = ((u64)b.y << 32) | b.x;
             si.slot = slot;
             si.limit = b.z;
-            if (expiry <= A.now) si.flags |= SF_EXPIRED0;
-            else {
+            if (expiry <= A.now) {
+                si.flags |= SF_EXPIRED0;
+                // An engine that holds PEER state (rl_merge_cells): the first admitted hit restarts the window the way
+                // CrCounterValue::inc_at does (cr_counter_value.rs:53-59) — our own value becomes the increment, the
+                // peers' contributions to the window that just ended STAY (`others` is only cleared by a merge's reset,
+                // :85-87,144-149) — so from the second hit on the cell reads increment + that stale part.  For an
+                // expired cell value_at(now) is 0 by definition, so `s` is free to carry the stale part.
+                if (A.has_peers) si.s = peers_window_sum(A.peers, A.seed, key, expiry, 0ull);
+            } else {
                 si.s = ((u64)a.w << 32) | a.z;  // value_at(now), atomic_expiring_value.rs:19-24
                 si.ttl0 = expiry - A.now;       // ttl, atomic_expiring_value.rs:68-74
             }
@@ -749,7 +758,10 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
         Lm.max_value = ((u64)lim[i].y << 32) | lim[i].x;
         Lm.window_us = ((u64)lim[i].w << 32) | lim[i].z;
         const bool zw = (si.flags & SF_ZEROWIN) != 0;
-        const u64 v = zw ? 0ull : si.s + (pr.sum - dup_sum);
+        // (an expired cell reads 0 until an admitted hit of an EARLIER request has restarted it; from then on `s` — the
+        // peers' stale part, 0 in an engine without peers — counts again: see k_gen_sort's resolve)
+        const u64 base = (si.flags & SF_EXPIRED0) && (pr.cnt - dup_cnt) == 0u ? 0ull : si.s;
+        const u64 v = zw ? 0ull : base + (pr.sum - dup_sum);
         const u64 sum = v + d[i];  // wraps like the reference's release build (in_memory.rs:88)
         const bool pass = A.update_mode ? true : sum <= Lm.max_value;
         pass_cur[h[i].idx] = pass ? 1 : 0;
@@ -983,7 +995,10 @@ __global__ __launch_bounds__(256) void k_gen_commit(GenArgs A, u32 room) {
             c->value = t.last;
             c->expiry = A.now;
         } else if (si.flags & SF_EXPIRED0) {  // update_if_expired: the first admitted hit stores, the rest add (:36-42,87-99)
-            c->value = t.sum;
+            // (+ s: the peers' part of the window that ended, which a local restart keeps — 0 without peers — and their
+            // entries move on to the new window, so that merges, exports and sweeps go on finding them)
+            if (A.has_peers) (void)peers_window_sum(A.peers, A.seed, c->tag, c->expiry, A.now + Lm.window_us);
+            c->value = si.s + t.sum;
             c->expiry = A.now + Lm.window_us;
         } else {
             c->value = si.s + t.sum;  // fetch_add, wrapping

@@ -548,6 +548,22 @@ __device__ __forceinline__ Cell* peer_find(Cell* table, u32 log2cap, u64 seed, u
     return nullptr;
 }
 
+// What the peers contributed to the window that ends at `window` (their entries carry the window they belong to): the
+// `others` of CrCounterValue for that window.  `restamp` != 0: the entries move on to that window (a LOCAL restart keeps
+// them: CrCounterValue::inc_at, cr_counter_value.rs:53-59, resets only our own value).
+__device__ __forceinline__ u64 peers_window_sum(const PeerTables& peers, u64 seed, u64 key, u64 window, u64 restamp) {
+    u64 sum = 0;
+    for (int a = 0; a < MERGE_MAX_ACTORS; ++a)
+        if (peers.t[a]) {
+            Cell* p = peer_find(peers.t[a], peers.log2cap, seed, key, false);
+            if (p && p->expiry == window) {
+                sum += p->value;
+                if (restamp) p->expiry = restamp;
+            }
+        }
+    return sum;
+}
+
 __global__ __launch_bounds__(256) void k_merge_rows(Cell* __restrict__ table, u32 log2cap, u64 seed, PeerTables peers,
                                                     u32 actor, u32 self_actor, const CellRow* __restrict__ rows, u64 n,
                                                     u64 now, Status* st) {
