@@ -78,7 +78,13 @@ int32_t rli_batch_add(rli_ingest *g, const char *namespace_, const char *const *
  * domain, the context of descriptors[0] is its entries with the LAST value of a repeated key
  * (HashMap::insert), hits_addend 0 means 1.  Further descriptors are not looked at (limits that read
  * them are RLI_HOST_ONLY).  -> request index, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID for a malformed
- * message (nothing is added). */
+ * message (nothing is added).  Malformed is what prost — the reference's decoder — answers a decode error for: truncated
+ * or overlong fields, a KNOWN field (domain, descriptors, hits_addend, entries, Entry.key, Entry.value) that arrives with
+ * another wire type than its declared one, a `string` (domain, key, value) that is not UTF-8.  Unknown fields are skipped
+ * by wire type like prost does.  Still more lenient than prost, on purpose: descriptors behind the first one and the nested
+ * messages this path never reads (RateLimitOverride, HitsAddend) are skipped by wire type without being validated — a
+ * message that is malformed only THERE is served where the reference would have refused it.  The device reader
+ * (limitador_amd/csrc/rl_wire.hpp, RLI_KEYS_HASHED) has the same rules. */
 int32_t rli_batch_add_rls(rli_ingest *g, const uint8_t *msg, uint32_t len);
 /* What the caller's Context binds (see the header comment); before the first rli_add_limit. */
 #define RLI_BIND_DESCRIPTORS 0

@@ -191,6 +191,37 @@ struct Wire {
     bool done() const { return p >= end; }
 };
 
+// What prost — the reference's decoder (envoy_rls/server.rs, tonic + prost) — rejects and a lenient reader would not
+// (ADVICE r04): a KNOWN field with another wire type than its declared one is a DecodeError ("invalid wire type"), and a
+// `string` field must be valid UTF-8 (Rust's str::from_utf8: no overlong forms, no surrogates, nothing above U+10FFFF).
+// A message the reference would have answered with a gRPC decode error must not create a counter here.  (What stays more
+// lenient than prost, documented in rl_ingest.h: descriptors behind the first one and the nested messages this path does
+// not read — RateLimitOverride, HitsAddend — are skipped by wire type without being validated.)
+bool utf8_ok(const uint8_t* p, const uint8_t* end) {
+    while (p < end) {
+        const uint8_t b = *p++;
+        if (b < 0x80) continue;
+        uint32_t need;
+        uint8_t lo = 0x80, hi = 0xBF;
+        if (b >= 0xC2 && b <= 0xDF) need = 1;
+        else if (b >= 0xE0 && b <= 0xEF) {
+            need = 2;
+            if (b == 0xE0) lo = 0xA0;
+            if (b == 0xED) hi = 0x9F;
+        } else if (b >= 0xF0 && b <= 0xF4) {
+            need = 3;
+            if (b == 0xF0) lo = 0x90;
+            if (b == 0xF4) hi = 0x8F;
+        } else return false;
+        if ((uint32_t)(end - p) < need) return false;
+        if (*p < lo || *p > hi) return false;
+        ++p;
+        for (uint32_t q = 1; q < need; ++q, ++p)
+            if ((*p & 0xC0) != 0x80) return false;
+    }
+    return true;
+}
+
 // RateLimitDescriptor.Entry { key = 1; value = 2 }
 bool parse_entry(Wire w, std::string* key, std::string* value) {
     while (!w.done()) {
@@ -198,8 +229,8 @@ bool parse_entry(Wire w, std::string* key, std::string* value) {
         if (!w.varint(&tag)) return false;
         const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
         Wire sub;
-        if ((field == 1 || field == 2) && wt == 2) {
-            if (!w.bytes(&sub)) return false;
+        if (field == 1 || field == 2) {
+            if (wt != 2 || !w.bytes(&sub) || !utf8_ok(sub.p, sub.end)) return false;
             (field == 1 ? key : value)->assign(reinterpret_cast<const char*>(sub.p), (size_t)(sub.end - sub.p));
         } else if (!w.skip(wt)) {
             return false;
@@ -215,8 +246,8 @@ bool parse_descriptor(Wire w, std::vector<std::pair<std::string, std::string>>* 
         if (!w.varint(&tag)) return false;
         const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
         Wire sub;
-        if (field == 1 && wt == 2) {
-            if (!w.bytes(&sub)) return false;
+        if (field == 1) {
+            if (wt != 2 || !w.bytes(&sub)) return false;
             std::string k, v;
             if (!parse_entry(sub, &k, &v)) return false;
             bool replaced = false;  // HashMap::insert: a repeated key keeps its LAST value
@@ -770,14 +801,14 @@ static int32_t decode_rls(const uint8_t* msg, uint32_t len, std::string* domain,
         if (!w.varint(&tag)) return *what = "tag", RL_ERR_INVALID;
         const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
         Wire sub;
-        if (field == 1 && wt == 2) {
-            if (!w.bytes(&sub)) return *what = "domain", RL_ERR_INVALID;
+        if (field == 1) {
+            if (wt != 2 || !w.bytes(&sub) || !utf8_ok(sub.p, sub.end)) return *what = "domain", RL_ERR_INVALID;
             domain->assign(reinterpret_cast<const char*>(sub.p), (size_t)(sub.end - sub.p));
-        } else if (field == 2 && wt == 2) {
-            if (!w.bytes(&sub)) return *what = "descriptor", RL_ERR_INVALID;
+        } else if (field == 2) {
+            if (wt != 2 || !w.bytes(&sub)) return *what = "descriptor", RL_ERR_INVALID;
             if (n_descriptors++ == 0 && !parse_descriptor(sub, entries)) return *what = "RateLimitDescriptor", RL_ERR_INVALID;
-        } else if (field == 3 && wt == 0) {
-            if (!w.varint(&hits_addend)) return *what = "hits_addend", RL_ERR_INVALID;
+        } else if (field == 3) {
+            if (wt != 0 || !w.varint(&hits_addend)) return *what = "hits_addend", RL_ERR_INVALID;
         } else if (!w.skip(wt)) {
             return *what = "unknown field", RL_ERR_INVALID;
         }

@@ -91,6 +91,32 @@ struct DWire {
     }
 };
 
+// str::from_utf8 (what prost demands of a `string` field): no overlong forms, no surrogates, nothing above U+10FFFF.
+__device__ __forceinline__ bool wire_utf8_ok(const uint8_t* p, const uint8_t* end) {
+    while (p < end) {
+        const uint8_t b = *p++;
+        if (b < 0x80) continue;
+        u32 need;
+        uint8_t lo = 0x80, hi = 0xBF;
+        if (b >= 0xC2 && b <= 0xDF) need = 1;
+        else if (b >= 0xE0 && b <= 0xEF) {
+            need = 2;
+            if (b == 0xE0) lo = 0xA0;
+            if (b == 0xED) hi = 0x9F;
+        } else if (b >= 0xF0 && b <= 0xF4) {
+            need = 3;
+            if (b == 0xF0) lo = 0x90;
+            if (b == 0xF4) hi = 0x8F;
+        } else return false;
+        if ((u32)(end - p) < need) return false;
+        if (*p < lo || *p > hi) return false;
+        ++p;
+        for (u32 q = 1; q < need; ++q, ++p)
+            if ((*p & 0xC0) != 0x80) return false;
+    }
+    return true;
+}
+
 struct WireLds {
     uint8_t blob[WIRE_BLOB_MAX];
     WireLit lit[WIRE_LIT_TAB];
@@ -135,14 +161,16 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* __restrict__ 
             }
             const u32 field = (u32)(tag >> 3), wt = (u32)(tag & 7);
             DWire sub;
-            if (field == 1 && wt == 2) {
-                if (!w.bytes(sub)) ok = false;
+            // (a KNOWN field with another wire type than its declared one is a decode error for prost, and so are strings
+            // that are not UTF-8: such a message derives nothing — csrc/host/ingest.cpp's reader has the same rules)
+            if (field == 1) {
+                if (wt != 2 || !w.bytes(sub) || !wire_utf8_ok(sub.p, sub.end)) ok = false;
                 else {
                     dom_off = (u32)(sub.p - wire);
                     dom_len = (u32)(sub.end - sub.p);
                 }
-            } else if (field == 2 && wt == 2) {
-                if (!w.bytes(sub)) ok = false;
+            } else if (field == 2) {
+                if (wt != 2 || !w.bytes(sub)) ok = false;
                 else if (n_desc++ == 0) {
                     // ---- RateLimitDescriptor { repeated Entry entries = 1; ... }: the first descriptor is the context ----
                     while (ok && !sub.done()) {
@@ -153,8 +181,8 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* __restrict__ 
                         }
                         const u32 f2 = (u32)(t2 >> 3), w2 = (u32)(t2 & 7);
                         DWire ent;
-                        if (f2 == 1 && w2 == 2) {
-                            if (!sub.bytes(ent)) {
+                        if (f2 == 1) {
+                            if (w2 != 2 || !sub.bytes(ent)) {
                                 ok = false;
                                 break;
                             }
@@ -168,8 +196,8 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* __restrict__ 
                                 }
                                 const u32 f3 = (u32)(t3 >> 3), w3 = (u32)(t3 & 7);
                                 DWire str;
-                                if ((f3 == 1 || f3 == 2) && w3 == 2) {
-                                    if (!ent.bytes(str)) ok = false;
+                                if (f3 == 1 || f3 == 2) {
+                                    if (w3 != 2 || !ent.bytes(str) || !wire_utf8_ok(str.p, str.end)) ok = false;
                                     else if (f3 == 1) {
                                         ko = (u32)(str.p - wire);
                                         kl = (u32)(str.end - str.p);
@@ -209,8 +237,8 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* __restrict__ 
                         }
                     }
                 }
-            } else if (field == 3 && wt == 0) {
-                if (!w.varint(hits_addend)) ok = false;
+            } else if (field == 3) {
+                if (wt != 0 || !w.varint(hits_addend)) ok = false;
             } else if (!w.skip(wt)) {
                 ok = false;
             }

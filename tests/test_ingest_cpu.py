@@ -249,6 +249,64 @@ def test_rate_limit_requests_from_the_wire(ingest):
     assert b["ent_val"][:2].tolist() == b["ent_val"][2:].tolist() == [g.value_id("GET"), g.value_id("zoe")]
 
 
+def test_what_the_reference_decoder_rejects_is_rejected(ingest):
+    """prost (the reference's decoder: envoy_rls/server.rs via tonic) answers a gRPC decode error — no counter is ever
+    touched — for (a) a KNOWN field that arrives with another wire type than its declared one ("invalid wire type") and
+    (b) a `string` field that is not UTF-8 (str::from_utf8: no overlong forms, no surrogates, nothing above U+10FFFF); a
+    reader that skipped (a) as an unknown field or took (b) as bytes would create counters the reference can never hold
+    (ADVICE r04).  Hand-built vectors, each one mutation away from a message that decodes; the device reader has the same
+    rules (rl_wire.hpp) and is held to this one by the differential fuzz of tests/test_gpu_rls_e2e.py."""
+    from limitador_amd.ingest import IngestError
+
+    g = ingest
+    g.add_limit("ns", 10, 60, [], ["descriptors[0]['user_id']"])
+    g.compile()
+
+    def entry(k, v, kwt=2, vwt=2):
+        def f(field, wt, payload):
+            if wt == 2:
+                return _ld(field, payload)
+            if wt == 0:
+                return _varint((field << 3) | 0) + _varint(7)
+            return _varint((field << 3) | 5) + bytes(4)
+        return _ld(1, f(1, kwt, k) + f(2, vwt, v))
+
+    def req(domain=b"ns", dom_wt=2, desc=None, desc_wt=2, addend_wt=0):
+        m = _ld(1, domain) if dom_wt == 2 else _varint((1 << 3) | dom_wt) + (_varint(5) if dom_wt == 0 else bytes(4))
+        d = desc if desc is not None else entry(b"user_id", b"bob")
+        m += _ld(2, d) if desc_wt == 2 else _varint((2 << 3) | desc_wt) + (_varint(5) if desc_wt == 0 else bytes(8 if desc_wt == 1 else 4))
+        m += (_varint((3 << 3) | 0) + _varint(2)) if addend_wt == 0 else (_ld(3, b"\x02") if addend_wt == 2 else _varint((3 << 3) | 5) + bytes(4))
+        return m
+
+    assert g.batch_add_rls(req()) == 0                                   # the unmutated message decodes
+    assert g.batch_add_rls(req(domain="n\u00e9\u4e16\U0001F600".encode())) == 1   # 2-, 3- and 4-byte sequences are fine
+    bad = {
+        "domain as a varint": req(dom_wt=0),
+        "domain as a fixed32": req(dom_wt=5),
+        "descriptors as a varint": req(desc_wt=0),
+        "descriptors as a fixed64": req(desc_wt=1),
+        "hits_addend length-delimited": req(addend_wt=2),
+        "hits_addend as a fixed32": req(addend_wt=5),
+        "entries as a varint": req(desc=_varint((1 << 3) | 0) + _varint(3)),
+        "Entry.key as a varint": req(desc=entry(b"user_id", b"bob", kwt=0)),
+        "Entry.value as a fixed32": req(desc=entry(b"user_id", b"bob", vwt=5)),
+        "domain: a lone continuation byte": req(domain=b"n\x80s"),
+        "domain: overlong NUL (C0 80)": req(domain=b"n\xc0\x80"),
+        "domain: 0xFF": req(domain=b"\xffns"),
+        "key: a surrogate (ED A0 80)": req(desc=entry(b"user\xed\xa0\x80", b"bob")),
+        "value: truncated 3-byte sequence": req(desc=entry(b"user_id", b"bo\xe4\xb8")),
+        "value: above U+10FFFF (F4 90 80 80)": req(desc=entry(b"user_id", b"\xf4\x90\x80\x80")),
+        "value: overlong 3-byte (E0 80 80)": req(desc=entry(b"user_id", b"\xe0\x80\x80")),
+        "value: 5-byte lead (F8)": req(desc=entry(b"user_id", b"\xf8\x88\x80\x80\x80")),
+    }
+    for what, m in bad.items():
+        with pytest.raises(IngestError):
+            g.batch_add_rls(m)
+        assert g.batch()["req_ns"].tolist() == [g.namespace_id("ns"), 0], what  # nothing was added
+    # unknown fields of any wire type are still skipped (prost does the same)
+    assert g.batch_add_rls(req() + _varint((12 << 3) | 0) + _varint(9) + _ld(13, b"\xff\xfe") + _varint((14 << 3) | 5) + bytes(4)) == 2
+
+
 def test_rate_limit_response_on_the_wire(engine_lib):
     from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
     from limitador_amd.ingest import UNKNOWN_DOMAIN, Ingest
