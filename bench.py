@@ -362,6 +362,51 @@ def secondary(args, eng, dev, gen):
                     "(RL_SERVE=0: one launch per call)"}
     except Exception as ex:  # the host mirror is optional plumbing for this leg
         out["configs0_bench_rs_shape_10k_sequential_calls"] = {"error": str(ex)[:200]}
+    # -- where the device overtakes the CPU: ONE blocking call from host arrays (PCIe inclusive, the
+    #    boundary a binding that does not pipeline uses) against ONE thread of the C oracle on the same hits, batch size by
+    #    batch size; 1 M keys (Zipf-0.99), single-counter requests.  crossover_hits_per_call = the smallest size from which
+    #    the device call is never slower again.  (Pipelined, device-resident batches are the headline; per-request calls:
+    #    configs0_* above.)
+    try:
+        nk = 1 << 20
+        ex_ = Engine(capacity_cells=1 << 22, max_batch_hits=1 << 18, device=eng.device)
+        ox = oracle.OracleStorage()
+        ex_.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+        ox.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
+        cells = W.universe_rows(nk)
+        ex_.load_cells(cells)
+        ox.load_cells(cells["key"], cells["limit"], cells["value"], cells["expiry_us"])
+        cdf_x = W.zipf_cdf(nk, args.zipf if args.zipf > 0 else 0.99)
+        rng_x = np.random.default_rng(W.SEED + 5)
+        rows, t_now = [], W.NOW0_US
+        for n in (16, 64, 256, 1024, 4096, 16384, 65536, 262144):
+            hx = [W.zipf_batch(nk, n, rng_x, cdf_x) for _ in range(4)]
+            reps = max(4, min(200, 400_000 // n))
+            ex_.check_and_update(hx[0], t_now, want_first_limited=False)
+            t0 = time.perf_counter()
+            for i in range(reps):
+                ex_.check_and_update(hx[i & 3], t_now + 1 + i, want_first_limited=False)
+            g_us = (time.perf_counter() - t0) / reps * 1e6
+            ox.check_and_update(hx[0], t_now)
+            t0 = time.perf_counter()
+            for i in range(reps):
+                ox.check_and_update(hx[i & 3], t_now + 1 + i)
+            c_us = (time.perf_counter() - t0) / reps * 1e6
+            t_now += 1000
+            rows.append({"hits_per_call": n, "gpu_us_per_call": round(g_us, 2), "cpu_1_thread_us_per_call": round(c_us, 2)})
+        ex_.close()
+        ox.close()
+        cross = None
+        for i, r in enumerate(rows):
+            if all(q["gpu_us_per_call"] <= q["cpu_1_thread_us_per_call"] for q in rows[i:]):
+                cross = r["hits_per_call"]
+                break
+        out["crossover_blocking_host_calls_vs_one_cpu_thread"] = {
+            "rows": rows, "crossover_hits_per_call": cross,
+            "note": "rl_check_and_update_batch from pageable host arrays, one call at a time (no pipelining), against "
+                    "lo_check_and_update_batch on one host thread; below the crossover the CPU answers sooner"}
+    except Exception as ex:  # noqa: BLE001
+        out["crossover_blocking_host_calls_vs_one_cpu_thread"] = {"error": str(ex)[:200]}
     try:
         from limitador_amd.ingest import Ingest
 

@@ -1,24 +1,27 @@
-// rl_apply.hpp — k_bkt_apply: the bucket replay of the single-counter hot path (see rl_bucket.hpp for
-// the partition that feeds it and for the algorithm: reference limitador/src/storage/in_memory.rs:72-156
-// applied hit by hit in trace order, one read and one write per touched counter cell).
+// rl_apply.hpp — k_bkt_step: the bucket replay of the single-counter hot path (rl_part.hpp: the single-pass partition
+// that feeds it, k_bkt_part / _c / _l, and the bucket view through which a workgroup finds its hits; rl_bucket.hpp: the
+// shared record / hot-set types).  The algorithm: reference limitador/src/storage/in_memory.rs:72-156 applied hit by hit
+// in trace order, one read and one write per touched counter cell.
 //
-// Machine mapping:
-//   * ONE workgroup per hash bucket, not persistent: the dependent chain of a bucket (hits -> home
-//     cells -> LDS aggregation -> probes -> verdicts -> write-back, ~6 us) is hidden by OTHER
-//     workgroups — 22 KB of LDS and 58 VGPRs keep 6 of them resident per CU.  (The first cut was
-//     persistent with a software pipeline of three register buffers: 251 VGPRs + 77 KB of LDS = two
-//     workgroups per CU, 48 us; this one 36-38 us on the same batch.)
-//   * the limit table and the hot-bucket table are read from global memory (L2-resident, a few
-//     hundred bytes): no LDS copies, no row limit on the limit table.
-//   * one 64-bit LDS atomic per hit carries the round's delta sum AND the per-wave hit counts;
-//     deltas >= 2^23 cannot share the 32-bit sum field and send their key through the sequential
-//     replay, which is exact for everything.
-//   * hot-key chunks are found through a chunk table prepared by k_bkt_scatter.
-//   * completion: the last workgroup out (ticket, sharded per XCD: one ticket word taken by 2048
-//     workgroups was 9 us of serialised atomics) stores the batch's sequence number into host-mapped
-//     memory (apply_finish, rl_bucket.hpp).
+// Machine mapping (as measured on MI355X, rounds 3-5):
+//   * ONE workgroup per hash bucket (1024 for a 1 M-hit batch) + 256 workgroups that walk the hot keys' work items, not
+//     persistent: a bucket's dependent chain (runs row -> view -> records -> home cells -> LDS aggregation -> verdicts
+//     -> write-back: 6.5 us + 5.3 us per 256-hit round) is hidden by OTHER workgroups — 80 VGPRs (no scratch) and
+//     21.5 KB of DYNAMIC LDS keep five of them resident per CU, so all 1280 of a launch are resident at once and the
+//     launch's span is its slowest workgroup (four beside a partition workgroup of the next batch: 82-96 VGPRs x two
+//     waves per SIMD).
+//   * the limit table and the hot work items are read from global memory (L2-resident, a few hundred bytes): no LDS
+//     copies, no row limit on the limit table (16-bit limit ids in LDS; engines with more than 32768 rows take the
+//     32-bit instantiation).
+//   * one 64-bit LDS atomic per hit carries the round's delta sum AND the per-wave hit counts; deltas >= 2^23 cannot
+//     share the 32-bit sum field and send their key through the sequential replay, which is exact for everything.
+//   * default verdicts are written by the partition as coalesced stores; the replay only stores the answers that differ.
+//   * completion: the last workgroup out (tickets sharded per XCD: one ticket word taken by 2048 workgroups was 9 us of
+//     serialised atomics) stores the batch's sequence number + status as ONE 16-byte store into host-mapped memory.
+//   * k_bkt_step can also carry the partition of the NEXT batch as a role of the same launch (RL_FUSE=1: one stream, one
+//     launch per step — the default for engines of <= 256 k hits per batch; rl_part.hpp part_role).
 //
-//   k_bkt_apply      the batch's hash buckets + hot buckets
+//   k_bkt_step       the batch's hash buckets + hot work items (+ the partition role)
 //   k_bkt_tiny       a batch of <= TINY_MAX hits is one bucket: validate + replay in ONE launch
 //   k_bkt_count_new  dry run: how many cells would the batch create (all-or-nothing under TABLE_FULL)
 #pragma once
