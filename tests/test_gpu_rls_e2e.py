@@ -393,7 +393,10 @@ def test_many_colliding_messages_take_one_rerun_and_a_limit_mismatch_is_a_collis
     users = victims + ["limit-mismatch"] + [f"honest-{i}" for i in range(300)]
     rng = np.random.default_rng(9)
     order = rng.permutation(len(users))
-    ctxs = [("ns1", {"method": "GET", "path": "/", "user": users[i], "app": "app0"}) for i in order]
+    # (a method / path under which limit j applies, whatever its conditions are in _limits())
+    base = next({"method": m, "path": pth, "app": "app0"} for m in ("GET", "POST", "PUT") for pth in ("/", "/admin")
+                if model_applies(lims[j], {"method": m, "path": pth, "app": "app0", "user": "x"}))
+    ctxs = [("ns1", dict(base, user=users[i])) for i in order]
     msgs = [rls_request(d, [list(c.items())]) for d, c in ctxs]
     for rerun in range(2):  # the second batch meets the same cells again: still served, still without them
         status, _ = g.serve_batch(eng, msgs, NOW + rerun, with_headers=bool(rerun))
