@@ -15,12 +15,19 @@ from limitador_amd.wire import HIT_DTYPE
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("form", ["one_launch", "three_kernels"])
 @pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
-@pytest.mark.parametrize("n", [1, 63, 2048, 100_003])
-def test_route_partition_is_a_stable_partition_by_owner(world, n):
+@pytest.mark.parametrize("n", [1, 63, 2048, 100_003, 1_000_001])
+def test_route_partition_is_a_stable_partition_by_owner(world, n, form, monkeypatch):
+    """k_route_one (one launch: count, the last workgroup in scans, scatter from registers — the default up to 3 M hits)
+    and the three-kernel form it replaced (RL_ROUTE_ONE=0; what larger batches take), both against numpy's stable argsort;
+    three calls in a row on one engine (the one-launch form leaves its three sync words zeroed for the next launch)."""
     from limitador_amd.engine import Engine
 
-    eng = Engine(capacity_cells=1 << 12, max_batch_hits=1 << 17)
+    if n > 200_000 and world not in (1, 8):
+        pytest.skip("the large batch on two world sizes only")
+    monkeypatch.setenv("RL_ROUTE_ONE", "1" if form == "one_launch" else "0")
+    eng = Engine(capacity_cells=1 << 12, max_batch_hits=max(1 << 17, n))
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(n * 31 + world)
     hits = W.uniform_batch(1 << 20, n, rng)
@@ -43,6 +50,14 @@ def test_route_partition_is_a_stable_partition_by_owner(world, n):
     want = np.zeros(n, dtype=np.uint8)
     want[want_perm] = (np.arange(n) % 256).astype(np.uint8)
     assert np.array_equal(dst.cpu().numpy(), want)
+    for again in range(2):  # the same engine again, other hits
+        hits2 = W.uniform_batch(1 << 20, n, rng)
+        t2 = torch.from_numpy(hits2.view(np.int64).reshape(-1, 2).copy()).to(dev)
+        out2, perm2 = loc.partition(t2, world, 0, counts)
+        torch.cuda.synchronize()
+        owners2 = owner_of_tensor(t2[:, 0].cpu(), eng.hash_seed, world).numpy()
+        assert np.array_equal(perm2.cpu().numpy(), np.argsort(owners2, kind="stable"))
+        assert np.array_equal(counts.cpu().numpy(), np.bincount(owners2, minlength=world))
     eng.close()
 
 
