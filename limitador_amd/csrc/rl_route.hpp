@@ -203,36 +203,35 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route_one(const Hit* __restrict
     if (tid == 0) s_last = atomicAdd(&sync[0], 1u) == nblk - 1 ? 1u : 0u;
     __syncthreads();
     if (s_last) {
-        // ---- 2. the last one in: exclusive scan of cnt[world][nblk] in place, the owners' totals --------------------
+        // ---- 2. the last one in: exclusive scan of cnt[world][nblk] in place, the owners' totals.  256 elements per step,
+        //         one per thread (coalesced device-scope loads), the next step's element requested before this step's scan:
+        //         the steps' memory round trips overlap (world 8 x 489 workgroups: 16 steps) ------------------------------
         const u32 total = nblk * world;
         if (tid < ROUTE_MAX_WORLD) s_owner_tot[tid] = 0;
         __syncthreads();
-        const u32 chunk = (total + ROUTE_BLOCK - 1) / ROUTE_BLOCK;
-        const u32 lo = tid * chunk < total ? tid * chunk : total;
-        const u32 hi = lo + chunk < total ? lo + chunk : total;
-        u32 sum = 0;
-        for (u32 q = lo; q < hi; ++q) {
-            const u32 v = __hip_atomic_load(&cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sum += v;
-            atomicAdd(&s_owner_tot[q / nblk], v);
-        }
-        s_part[tid] = sum;
-        __syncthreads();
-        if (tid == 0) {
-            u32 run = 0;
-            for (int t = 0; t < ROUTE_BLOCK; ++t) {
-                const u32 v = s_part[t];
-                s_part[t] = run;
-                run += v;
+        u32 carry = 0;
+        u32 nxt = tid < total ? __hip_atomic_load(&cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (u32 base = 0; base < total; base += ROUTE_BLOCK) {
+            const u32 q = base + tid;
+            const u32 v = nxt;
+            const u32 qn = q + ROUTE_BLOCK;
+            nxt = qn < total ? __hip_atomic_load(&cnt[qn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (q < total && v) atomicAdd(&s_owner_tot[q / nblk], v);
+            u32 inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 o2 = __shfl_up(inc, off);
+                if ((int)lane >= off) inc += o2;
             }
+            __syncthreads();  // (s_part of the step before has been read)
+            if (lane == 63) s_part[wave] = inc;
+            __syncthreads();
+            u32 ex = carry + inc - v;
+            for (u32 w2 = 0; w2 < wave; ++w2) ex += s_part[w2];
+            if (q < total) (void)__hip_atomic_exchange(&cnt[q], ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
         }
         __syncthreads();
-        u32 run = s_part[tid];
-        for (u32 q = lo; q < hi; ++q) {
-            const u32 v = __hip_atomic_load(&cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_exchange(&cnt[q], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            run += v;
-        }
         if (tid < world) counts[tid] = s_owner_tot[tid];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
