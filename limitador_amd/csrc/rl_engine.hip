@@ -133,7 +133,10 @@ struct rl_engine {
     unsigned long long* h_total = nullptr; // pinned
     // routing scratch
     u32* d_route_cnt = nullptr;
-    bool route_one = true;          // the router's partition by owner as one launch (k_route_one); RL_ROUTE_ONE=0: three kernels
+    bool route_one = false;         // RL_ROUTE_ONE=1 (experiment builds): the router's partition by owner as ONE launch with a
+                                    // ticket barrier (k_route_one).  Measured slower than the three kernels (gpurun_out/r13e, r13f:
+                                    // 33-50 us for the launch, the replay beside it 45-58 us, 97 against 82 us per routed slice):
+                                    // its workgroups hold their places while they wait for the last one to arrive
     // bucketed hot path (rl_bucket.hpp)
     // the phased form of the general resolver (rl_gen_begin_device .. rl_gen_commit_device / rl_gen_abort)
     bool ph_open = false;
@@ -3293,8 +3296,8 @@ static int32_t route_partition_on(rl_engine* e, hipStream_t st, bool block, cons
     if (block) HIP_TRY(e, hipSetDevice(e->device));
     const u32 nblk = n_hits ? cdiv(n_hits, ROUTE_TILE) : 0;
     if (nblk > ROUTE_MAX_BLOCKS) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u too large for the router", n_hits);
-    // one launch where every workgroup of it can be resident (rl_route.hpp: k_route_one; RL_ROUTE_ONE=0 in experiment builds:
-    // the three kernels), else count / scan / scatter
+    // count / scan / scatter; RL_ROUTE_ONE=1 (experiment builds): one launch with a ticket barrier (rl_route.hpp: k_route_one —
+    // parity-green, measured slower)
     if (nblk && nblk <= ROUTE_ONE_MAX_BLOCKS && e->route_one) {
         u32* sync = e->d_route_cnt + (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD;  // (the 64 words behind the matrix: zero between launches)
         k_route_one<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world, e->d_route_cnt, sync,

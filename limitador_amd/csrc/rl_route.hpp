@@ -30,10 +30,21 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route_count(const Hit* __restri
     const u32 tid = threadIdx.x;
     if (tid < ROUTE_MAX_WORLD) s_cnt[tid] = 0;
     __syncthreads();
+    // (per wave: one ballot per owner and round, one LDS atomic per owner — an LDS atomic per HIT put all 2048 of a
+    // workgroup's on ONE word at world 1: 15 us for the launch, gpurun_out/r13d)
     const u32 base = blockIdx.x * ROUTE_TILE;
+    const u32 lane = tid & 63u;
+    u32 own[ROUTE_TILE / ROUTE_BLOCK];
+#pragma unroll
     for (int r = 0; r < ROUTE_TILE / ROUTE_BLOCK; ++r) {
         const u32 i = base + r * ROUTE_BLOCK + tid;
-        if (i < n) atomicAdd(&s_cnt[owner_of(hits[i].key, seed, world)], 1u);
+        own[r] = i < n ? owner_of(hits[i].key, seed, world) : 0xFFFFFFFFu;
+    }
+    for (u32 o = 0; o < world; ++o) {
+        u32 c = 0;
+#pragma unroll
+        for (int r = 0; r < ROUTE_TILE / ROUTE_BLOCK; ++r) c += (u32)__popcll(__ballot(own[r] == o));
+        if (lane == 0 && c) atomicAdd(&s_cnt[o], c);
     }
     __syncthreads();
     if (tid < world) cnt[tid * gridDim.x + blockIdx.x] = s_cnt[tid];
@@ -42,39 +53,36 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route_count(const Hit* __restri
 // Single workgroup: exclusive scan of cnt[world * nblk] in place; counts[o] = group sizes.
 __global__ __launch_bounds__(256) void k_route_scan(u32* __restrict__ cnt, u32 nblk, u32 world,
                                                     u32* __restrict__ counts) {
-    __shared__ u32 s_part[256];
+    __shared__ u32 s_part[4];
     __shared__ u32 s_owner_tot[ROUTE_MAX_WORLD];
-    const u32 tid = threadIdx.x;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u32 total = nblk * world;
     if (tid < ROUTE_MAX_WORLD) s_owner_tot[tid] = 0;
     __syncthreads();
-    // each thread owns a contiguous chunk
-    const u32 chunk = (total + 255) / 256;
-    const u32 lo = tid * chunk;
-    const u32 hi = lo + chunk < total ? lo + chunk : total;
-    u32 sum = 0;
-    for (u32 q = lo; q < hi; ++q) {
-        const u32 v = cnt[q];
-        sum += v;
-        atomicAdd(&s_owner_tot[q / nblk], v);
-    }
-    s_part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        u32 run = 0;
-        for (int t = 0; t < 256; ++t) {
-            const u32 v = s_part[t];
-            s_part[t] = run;
-            run += v;
+    // 256 elements per step, one per thread (coalesced), the next step's element requested before this step's scan (one
+    // thread walking the 256 partial sums in a row was most of this kernel's 5-11 us: gpurun_out/r13d)
+    u32 carry = 0;
+    u32 nxt = tid < total ? cnt[tid] : 0u;
+    for (u32 base = 0; base < total; base += 256) {
+        const u32 q = base + tid;
+        const u32 v = nxt;
+        nxt = q + 256 < total ? cnt[q + 256] : 0u;
+        if (q < total && v) atomicAdd(&s_owner_tot[q / nblk], v);
+        u32 inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 o2 = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += o2;
         }
+        __syncthreads();  // (s_part of the step before has been read)
+        if (lane == 63) s_part[wave] = inc;
+        __syncthreads();
+        u32 ex = carry + inc - v;
+        for (u32 w2 = 0; w2 < wave; ++w2) ex += s_part[w2];
+        if (q < total) cnt[q] = ex;
+        carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
     }
     __syncthreads();
-    u32 run = s_part[tid];
-    for (u32 q = lo; q < hi; ++q) {
-        const u32 v = cnt[q];
-        cnt[q] = run;
-        run += v;
-    }
     if (tid < world) counts[tid] = s_owner_tot[tid];
 }
 
@@ -149,7 +157,11 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route_scatter(const Hit* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_route_one: the three kernels above as ONE launch (round 5).  The routed step at world 1 was HOST-bound — ~14 enqueues
+// k_route_one: the three kernels above as ONE launch (round 5) — BUILT, PARITY-GREEN, MEASURED SLOWER, NOT THE DEFAULT
+// (RL_ROUTE_ONE=1 in experiment builds; gpurun_out/r13e, r13f: the launch takes 33-50 us — its workgroups hold their places on
+// the CUs while they sleep until the last of them has been dispatched, which beside a replay is late — the replay next to it
+// 45-58 us, a routed slice 97 us against 82 with the three kernels).  What DID carry over: k_route_count without an LDS atomic
+// per hit and k_route_scan as a tiled, prefetching block scan.  The reasoning it was built on:  The routed step at world 1 was HOST-bound — ~14 enqueues
 // of 5-7 us each per slice, 85 us per slice against 43 for the local pipeline (gpurun_out/r13d: host trace + kernel
 // timeline) — and three of those enqueues were the router's own count / scan / scatter, whose device time (15 + 5-11 +
 // 13-31 us beside a replay; k_route_count's LDS atomics all hit ONE word at world 1) was another 35-55 us of machine

@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
 @pytest.mark.parametrize("n", [1, 63, 2048, 100_003, 1_000_001])
 def test_route_partition_is_a_stable_partition_by_owner(world, n, form, monkeypatch):
-    """k_route_one (one launch: count, the last workgroup in scans, scatter from registers — the default up to 3 M hits)
-    and the three-kernel form it replaced (RL_ROUTE_ONE=0; what larger batches take), both against numpy's stable argsort;
+    """The three kernels of the router's partition by owner (the default) and k_route_one (RL_ROUTE_ONE=1: one launch — count,
+    the last workgroup in scans, scatter from registers; parity-green, measured slower), both against numpy's stable argsort;
     three calls in a row on one engine (the one-launch form leaves its three sync words zeroed for the next launch)."""
     from limitador_amd.engine import Engine
 
