@@ -667,8 +667,8 @@ def main():
                 sh.check_and_update(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
         else:
             def step(i, now):
-                sh.submit(batches[i].data_ptr(), args.batch, now, verdicts[i % 3].data_ptr())
-                if sh.in_flight == 3:
+                sh.submit(batches[i].data_ptr(), args.batch, now, verdicts[i & 3].data_ptr())
+                if sh.in_flight == sharded_abi.MAX_IN_FLIGHT:  # (four: the host enqueues a slice ahead of the device)
                     sh.collect()
     elif sharded:
         from limitador_amd.sharded import ShardedEngine
@@ -760,7 +760,7 @@ def main():
     if args.depth == 1:
         last = verdict
     else:
-        last = verdicts[(total_steps - 1) % 3] if sharded else verdicts[(total_steps - 1) & 3]
+        last = (verdicts[(total_steps - 1) % 3] if (sharded and args.sharded_impl != "abi") else verdicts[(total_steps - 1) & 3])
     denied = int(last.sum().item())
     if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -812,7 +812,7 @@ def main():
                        "table_capacity_cells": cap, "cell_bytes": 32, "table_bytes": cap * 32,
                        "table_load": round(args.keys / cap, 3),
                        "parallelism": (f"hash-sharded x{world}, RCCL all-to-all" + (" behind the C ABI (rl_sharded_*)" if args.sharded_impl == "abi" else " (torch.distributed)") + sharded_note) if sharded else "single GPU",
-                       "batches_in_flight": args.depth if not sharded or args.depth == 1 else 3,
+                       "batches_in_flight": args.depth if not sharded or args.depth == 1 else (4 if args.sharded_impl == "abi" else 3),
                        "overlap": "partition of batches k+1, k+2 (own stream) beside k_bkt_step of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
                        "denied_in_last_batch": denied,
                        # every engine knob the process saw (rl_engine_create reads RL_*, the ingest layer RLI_*)

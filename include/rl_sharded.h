@@ -17,7 +17,9 @@
  *     apply     the local batch on the engine (rl_check_and_update_submit_device)
  *     return    verdict bytes back to the ingress ranks (rides in GROUP A of the slice two ahead, or
  *               alone when the pipeline drains), un-permute to ingress order
- * Up to three slices are in flight (routed / applied / returned); routing and exchanges run on one
+ * Up to four slices are in flight (RL_SHARDED_MAX_IN_FLIGHT: the newest one routed, up to three on the engine — applied /
+ * returned); a caller that keeps the window full (`submit(k); collect(k - 3)`) lets the host enqueue a slice ahead of the
+ * device.  Routing and exchanges run on one
  * stream, the engine's batches on another.  submit(i) enqueues
  * GROUP B of slice i-1 and its local batch, then route(i) and GROUP A(i): the engine never waits for an
  * exchange that is itself waiting for the engine.
@@ -85,7 +87,8 @@ void rl_sharded_destroy(rl_sharded *s);
 const char *rl_sharded_last_error(const rl_sharded *s);
 
 /* Enqueue one ingress slice (device pointers; d_hits and d_verdict stay untouched until the matching
- * collect).  RL_ERR_BUSY with three slices in flight. */
+ * collect).  RL_ERR_BUSY with RL_SHARDED_MAX_IN_FLIGHT slices in flight. */
+#define RL_SHARDED_MAX_IN_FLIGHT 4
 int32_t rl_sharded_submit_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n_hits, uint64_t now_us,
                                  uint8_t *d_verdict);
 /* Finish the OLDEST slice: its verdicts are in its d_verdict once the exchange stream has been
@@ -94,7 +97,7 @@ int32_t rl_sharded_submit_device(rl_sharded *s, const rl_hit *d_hits, uint32_t n
 int32_t rl_sharded_collect(rl_sharded *s, uint32_t *n_applied);
 /* A sweep of expired counters as a command of the routed pipeline: every rank calls it at the same point of its sequence of
  * submits; its shard is swept behind every slice submitted so far and in front of every later one — the point a sequential
- * storage would be swept at — without draining the slices in flight (it takes one of the three in-flight places and is
+ * storage would be swept at — without draining the slices in flight (it takes one of the engine's three in-flight places — RL_ERR_BUSY with more than two commands in flight — and is
  * collected in order with rl_sharded_sweep_collect; *n_removed = cells THIS rank's shard dropped).  The sweep itself is
  * rl_sweep_expired_submit of rl_engine.h (qualified cells with expiry <= now_us; no reference analogue: an explicit eviction
  * event, replayed into the oracle by the tests). */

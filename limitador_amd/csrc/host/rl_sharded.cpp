@@ -36,7 +36,11 @@ namespace {
 constexpr uint32_t RQ_GATHER = 16;   // rq.d_words[RQ_GATHER + p]: rank p's word of the last gather (multi-counter step)
 constexpr uint32_t RQ_CHANGED = 64;  // rq.d_words[RQ_CHANGED]: k_req_and raises it
 constexpr uint32_t RQ_WORDS = 128;
-constexpr int SLOTS = 3;          // slices in flight: routed / applied / returned
+constexpr int SLOTS = 4;          // slices in flight: one routed + up to three on the engine (applied / returned).  Three until
+                                  // round 5: with `submit(k); collect(k - 2)` the host's ~55 us of enqueues per slice only
+                                  // started once the replay of slice k - 2 had ENDED (the collect waits for it) — a bubble of
+                                  // 11-14 us per slice on the engine's stream (gpurun_out/r13g); one more slice in flight lets the
+                                  // host run a slice ahead of the device
 constexpr uint32_t MAX_WORLD = 16; // the router's limit (rl_route.hpp)
 enum Stage { ROUTED = 1, APPLIED = 2, RETURNED = 3 };
 
@@ -705,7 +709,9 @@ int32_t rl_sharded_collect(rl_sharded* s, uint32_t* n_applied) try {
 int32_t rl_sharded_sweep_submit(rl_sharded* s, uint64_t now_us) try {
     if (!s) return RL_ERR_INVALID;
     std::lock_guard<std::mutex> g(s->mu);
-    if (s->pending.size() >= (size_t)SLOTS) return fail(s, RL_ERR_BUSY, "%d commands are in flight: collect first", SLOTS);
+    // (everything in flight is on the engine once the routed slice has been handed over below, plus the sweep itself: the
+    // engine takes three commands — the same bound on every rank, whatever its share of the slices was)
+    if (s->pending.size() >= (size_t)SLOTS - 1) return fail(s, RL_ERR_BUSY, "%d commands are in flight: collect first", SLOTS - 1);
     HIP_S(s, hipSetDevice(s->device));
     int32_t rc;
     for (auto& p : s->pending)

@@ -8,6 +8,7 @@ from . import _lib
 from .build import SHARDED_SO
 
 UNIQUE_ID_BYTES = 128
+MAX_IN_FLIGHT = 4  # RL_SHARDED_MAX_IN_FLIGHT: slices a caller may keep in flight (submit(k); collect(k - 3))
 SYMBOLS = {}
 _so = None
 

@@ -143,7 +143,7 @@ def worker(rank, world, port, outdir):
     applied = []
     for s in range(STEPS):
         sh.submit(d_in[s].data_ptr(), len(slices[s][rank]), W.NOW0_US + 350_000 * s, d_out[s].data_ptr())
-        if sh.in_flight == 3:
+        if sh.in_flight == sharded_abi.MAX_IN_FLIGHT:
             applied.append(sh.collect())
     while sh.in_flight:
         applied.append(sh.collect())
