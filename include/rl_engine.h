@@ -345,6 +345,24 @@ int32_t rl_match_and_check_batch_device(rl_engine *e, const uint32_t *d_req_ns, 
                                         int32_t load_counters, uint8_t *d_verdict, int32_t *d_limited_limit,
                                         uint32_t *n_hits_out);
 
+/* The other two RateLimiter methods over the same matcher — what the Kuadrant RateLimitService splits ShouldRateLimit
+ * into (limitador-server/src/envoy_rls/kuadrant_service.rs:27-184: CheckRateLimit, then Report once the response is known):
+ *   RL_OP_CHECK_AND_UPDATE  check_rate_limited_and_update (lib.rs:425-464): rl_match_and_check_batch without load_counters;
+ *   RL_OP_CHECK             is_rate_limited (lib.rs:362-409): a request's counters in counters_that_apply's order, each
+ *                           through is_within_limits (in_memory.rs:20-35) with the request's delta; verdict[i] = 1 and
+ *                           limited_limit[i] = the limit of the FIRST counter that does not fit (find_first_limited_counter).
+ *                           Nothing is written: no cell is created, no value moves;
+ *   RL_OP_UPDATE            update_counters (lib.rs:411-423): every derived counter takes the request's delta through
+ *                           update_counter (in_memory.rs:47-69: no limit test, missing cells are created — simple ones too);
+ *                           verdict[i] = 0, limited_limit[i] = -1.
+ * Applied in index order with one clock value like every batch entry point; host pointers. */
+#define RL_OP_CHECK_AND_UPDATE 0
+#define RL_OP_CHECK 1
+#define RL_OP_UPDATE 2
+int32_t rl_match_batch_op(rl_engine *e, int32_t op, const uint32_t *req_ns, const uint32_t *ent_off,
+                          const uint32_t *ent_key, const uint32_t *ent_val, const uint32_t *req_delta, uint32_t n_req,
+                          uint64_t now_us, uint8_t *verdict, int32_t *limited_limit);
+
 /* ---- the wire path without host dictionaries (limitador_amd/csrc/rl_wire.hpp; row f1 of SURVEY.md 8) ------------------
  * Serialized envoy.service.ratelimit.v3.RateLimitRequest messages are decoded ON THE DEVICE (what ShouldRateLimit does
  * per call, envoy_rls/server.rs:97-137), matched against the table of rl_match_table_set (lib.rs:507-522), and every
@@ -384,6 +402,14 @@ int32_t rl_wire_match_and_check_batch(rl_engine *e, const uint8_t *wire, const u
                                       int32_t *status, uint32_t *req_off_out, rl_hit *hits_out, uint32_t hits_cap,
                                       uint32_t *n_hits_out, uint64_t *remaining, uint64_t *expires_in_us,
                                       int64_t *collided_message);
+/* rl_match_batch_op for serialized messages (RL_OP_* above).  RL_OP_CHECK is the Kuadrant CheckRateLimit: every counter is
+ * checked with delta 1 whatever the message's hits_addend says (kuadrant_service.rs:62-64); a message whose counter's key
+ * belongs to another counter gets status[i] = -103 and no verdict (nothing to re-run: the call wrote nothing).  RL_OP_UPDATE
+ * is Report: hits_addend (0 means 1, kuadrant_service.rs:139-145) is added to every derived counter; a key collision
+ * refuses the call like rl_wire_match_and_check_batch does (RL_ERR_KEY_COLLISION, nothing applied, -103 names the messages). */
+int32_t rl_wire_match_batch_op(rl_engine *e, int32_t op, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
+                               uint64_t now_us, uint8_t *verdict, int32_t *limited_limit, int32_t *status,
+                               int64_t *collided_message);
 
 /* ---- the general resolver in phases: admission decided by the host ----------------------- */
 /* For requests whose counters live on SEVERAL engines (key-sharded multi-counter requests): the per-request AND

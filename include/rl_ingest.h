@@ -157,6 +157,21 @@ int32_t rli_serve_batch(rli_ingest *g, rl_engine *e, const uint8_t *const *msgs,
                         uint64_t now_us, int32_t with_headers, uint8_t *out, uint32_t out_stride, uint32_t *out_len,
                         int32_t *status);
 
+/* The Kuadrant RateLimitService over the same messages (limitador-server/src/envoy_rls/kuadrant_service.rs:27-184), which
+ * splits ShouldRateLimit in two — op is one of rl_engine.h's RL_OP_*:
+ *   RL_OP_CHECK   CheckRateLimit (:27-106) = RateLimiter::is_rate_limited(namespace, ctx, 1) (lib.rs:362-409): every counter
+ *                 the message derives is checked with delta 1 WHATEVER hits_addend says (:62-64), in counters_that_apply's
+ *                 order, the first one that does not fit limits the request; nothing is written.  status 0 OK / 1 OVER_LIMIT;
+ *   RL_OP_UPDATE  Report (:108-184) = RateLimiter::update_counters(namespace, ctx, hits_addend or 1) (lib.rs:411-423): every
+ *                 derived counter takes the addend, no limit is tested; status 0, the response is always OK (:171-181);
+ *   RL_OP_CHECK_AND_UPDATE  rli_serve_batch without headers.
+ * Responses carry overall_code only (neither method adds headers); no domain -> RLI_UNKNOWN_DOMAIN and the empty message
+ * (:37-47, :118-128).  Everything else — index order, one clock value, the statuses of undecodable / RLI_HOST_ONLY messages,
+ * one call at a time per engine — as rli_serve_batch. */
+int32_t rli_serve_batch_op(rli_ingest *g, rl_engine *e, int32_t op, const uint8_t *const *msgs, const uint32_t *lens,
+                           uint32_t n, uint64_t now_us, uint8_t *out, uint32_t out_stride, uint32_t *out_len,
+                           int32_t *status);
+
 /* The micro-batcher of the wire path: thread-safe, blocking; concurrent callers are aggregated into one
  * rli_serve_batch, closed at max_batch requests or max_delay_us after its first request arrived (the latency
  * budget), stamped with one clock value.  -> the request's status (as rli_serve_batch), its response in resp. */
@@ -167,6 +182,13 @@ void rli_frontend_destroy(rli_frontend *f);
 void rli_frontend_set_clock(rli_frontend *f, uint64_t now_us); /* tests: a fixed clock instead of the system's */
 int32_t rli_frontend_should_rate_limit(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp,
                                        uint32_t resp_cap, uint32_t *resp_len);
+/* The Kuadrant methods through the same micro-batcher (rli_serve_batch_op).  A device batch is one method: the batcher cuts
+ * where the method changes and keeps arrival order across the cut, so a Report queued behind a CheckRateLimit is applied
+ * behind it. */
+int32_t rli_frontend_check_rate_limit(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp, uint32_t resp_cap,
+                                      uint32_t *resp_len);
+int32_t rli_frontend_report(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp, uint32_t resp_cap,
+                            uint32_t *resp_len);
 void rli_frontend_stats(rli_frontend *f, uint64_t *batches, uint64_t *requests);
 /* exception barrier self-test of THIS library (rl_engine.h: rl_abi_selftest; kinds 1-4) */
 int32_t rli_abi_selftest(int32_t kind);

@@ -886,10 +886,14 @@ void put_string_field(std::string& o, uint32_t field, const std::string& v) {
 
 }  // namespace
 
-int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
-                        uint64_t now_us, int32_t with_headers, uint8_t* out, uint32_t out_stride, uint32_t* out_len,
-                        int32_t* status) try {
+// op: RL_OP_CHECK_AND_UPDATE = ShouldRateLimit (envoy_rls/server.rs:91-208); RL_OP_CHECK / RL_OP_UPDATE = the Kuadrant service's
+// CheckRateLimit / Report (envoy_rls/kuadrant_service.rs:27-184), whose responses never carry rate-limit headers.
+static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
+                              uint64_t now_us, int32_t with_headers, uint8_t* out, uint32_t out_stride, uint32_t* out_len,
+                              int32_t* status) {
     if (!g || !e || (n && (!msgs || !lens || !out || !out_len || !status)) || out_stride < 2) return RL_ERR_INVALID;
+    if (op != RL_OP_CHECK_AND_UPDATE && op != RL_OP_CHECK && op != RL_OP_UPDATE) return RL_ERR_INVALID;
+    if (op != RL_OP_CHECK_AND_UPDATE) with_headers = 0;
     rli_batch_clear(g);
     if (n == 0) return RL_OK;
     const uint32_t threads = serve_threads(n);
@@ -973,11 +977,12 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
             if (attempt == 0) lap("packed");
             uint32_t n_hits = 0;
             int64_t collided = -1;
-            const int32_t rc = rl_wire_match_and_check_batch(e, w_bytes, w_off, n, now_us, with_headers ? 1 : 0,
-                                                             verdict, limited, dev_status,
-                                                             with_headers ? req_off : nullptr, with_headers ? hits : nullptr,
-                                                             (uint32_t)cap, &n_hits, with_headers ? rem : nullptr,
-                                                             with_headers ? exp : nullptr, &collided);
+            const int32_t rc =
+                op == RL_OP_CHECK_AND_UPDATE
+                    ? rl_wire_match_and_check_batch(e, w_bytes, w_off, n, now_us, with_headers ? 1 : 0, verdict, limited, dev_status,
+                                                    with_headers ? req_off : nullptr, with_headers ? hits : nullptr, (uint32_t)cap,
+                                                    &n_hits, with_headers ? rem : nullptr, with_headers ? exp : nullptr, &collided)
+                    : rl_wire_match_batch_op(e, op, w_bytes, w_off, n, now_us, verdict, limited, dev_status, &collided);
             if (rc == RL_ERR_KEY_COLLISION && attempt < 8) {
                 // Counters that share a 64-bit key with another counter are never merged: their messages are taken out — ALL
                 // of them at once, the device names every one in dev_status (-103) — and answered RLI_HOST_ONLY (the caller's
@@ -999,7 +1004,9 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
             break;
         }
         for (uint32_t i = 0; i < n; ++i) {
-            status[i] = skip[i] ? (int32_t)RLI_HOST_ONLY : dev_status[i];
+            // (-103 on a call that succeeded: RL_OP_CHECK met a cell that is another counter's — nothing was written, the
+            // message goes to the caller's exact path like the ones a counting call takes out)
+            status[i] = skip[i] || dev_status[i] == -103 ? (int32_t)RLI_HOST_ONLY : dev_status[i];
             out_len[i] = 0;
             req_of[i] = status[i] == 0 ? (int32_t)i : -1;
         }
@@ -1034,7 +1041,8 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
                 int32_t rc = (lens[i] && !msgs[i]) ? (int32_t)RL_ERR_INVALID : decode_rls(msgs[i], lens[i], &domain, &entries, &delta, &what);
                 if (rc == 0) rc = encode_request(g, domain, entries, delta, &tmp, &rd);
                 if (rc == 0) {
-                    enc[i] = EncSlot{tmp.ns, tmp.delta, (uint32_t)flat.size(), (uint32_t)tmp.kv.size()};
+                    // (CheckRateLimit checks with 1 whatever hits_addend says: kuadrant_service.rs:62-64)
+                    enc[i] = EncSlot{tmp.ns, op == RL_OP_CHECK ? 1u : tmp.delta, (uint32_t)flat.size(), (uint32_t)tmp.kv.size()};
                     flat.insert(flat.end(), tmp.kv.begin(), tmp.kv.end());
                     ++n_ok;
                 }
@@ -1080,11 +1088,14 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
         if (const int32_t brc = result_arrays(n_req, cap)) return brc;
         if (n_req) {
             uint32_t n_hits = 0;
-            const int32_t rc = rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
-                                                        g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict,
-                                                        limited, with_headers ? req_off : nullptr,
-                                                        with_headers ? hits : nullptr, (uint32_t)cap, &n_hits,
-                                                        with_headers ? rem : nullptr, with_headers ? exp : nullptr);
+            const int32_t rc =
+                op == RL_OP_CHECK_AND_UPDATE
+                    ? rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
+                                               g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict, limited,
+                                               with_headers ? req_off : nullptr, with_headers ? hits : nullptr, (uint32_t)cap, &n_hits,
+                                               with_headers ? rem : nullptr, with_headers ? exp : nullptr)
+                    : rl_match_batch_op(e, op, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
+                                        g->req_delta.data(), n_req, now_us, verdict, limited);
             if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
         }
     }
@@ -1183,6 +1194,17 @@ int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs,
     if (too_long.load())  // (not an error of the call: the message names the size a retry needs)
         (void)gfail(g, RL_OK, "a response of %u bytes does not fit the stride %u: status RLI_RESPONSE_TOO_LARGE for it", too_long.load(), out_stride);
     return RL_OK;
+}
+
+int32_t rli_serve_batch(rli_ingest* g, rl_engine* e, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
+                        uint64_t now_us, int32_t with_headers, uint8_t* out, uint32_t out_stride, uint32_t* out_len,
+                        int32_t* status) try {
+    return serve_batch_op(g, e, RL_OP_CHECK_AND_UPDATE, msgs, lens, n, now_us, with_headers, out, out_stride, out_len, status);
+} RL_ABI_CATCH
+
+int32_t rli_serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
+                           uint64_t now_us, uint8_t* out, uint32_t out_stride, uint32_t* out_len, int32_t* status) try {
+    return serve_batch_op(g, e, op, msgs, lens, n, now_us, 0, out, out_stride, out_len, status);
 } RL_ABI_CATCH
 
 // The micro-batcher of the wire path: concurrent ShouldRateLimit callers are aggregated into one device batch,
@@ -1200,6 +1222,7 @@ struct rli_frontend {
         uint8_t* resp;
         uint32_t resp_cap, resp_len = 0;
         int32_t status = 0;
+        int32_t op = RL_OP_CHECK_AND_UPDATE;  // which RPC the caller is in: ShouldRateLimit, or Kuadrant's CheckRateLimit / Report
         bool done = false;
     };
     std::mutex mu;
@@ -1216,10 +1239,15 @@ struct rli_frontend {
             if (stop && queue.empty()) return;
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_delay_us);
             cv_work.wait_until(lk, deadline, [&] { return stop || queue.size() >= max_batch; });
+            // One device call is one method: the batch is the longest run of requests of the queue's first method (arrival
+            // order is kept across methods — a Report that arrived behind a CheckRateLimit is applied behind it).
             std::vector<Slot*> batch;
-            if (queue.size() > max_batch) {
-                batch.assign(queue.begin(), queue.begin() + max_batch);
-                queue.erase(queue.begin(), queue.begin() + max_batch);
+            size_t take = 0;
+            while (take < queue.size() && take < max_batch && queue[take]->op == queue[0]->op) ++take;
+            const int32_t op = queue[0]->op;
+            if (take < queue.size()) {
+                batch.assign(queue.begin(), queue.begin() + take);
+                queue.erase(queue.begin(), queue.begin() + take);
             } else {
                 batch.swap(queue);
             }
@@ -1245,8 +1273,8 @@ struct rli_frontend {
                     using namespace std::chrono;
                     now = (uint64_t)duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
                 }
-                rc = rli_serve_batch(g, e, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride, out_len.data(),
-                                     status.data());
+                rc = serve_batch_op(g, e, op, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride, out_len.data(),
+                                    status.data());
             } catch (const std::bad_alloc&) {
                 rc = rl_abi_caught("rli_frontend worker", "std::bad_alloc (host memory exhausted)", RL_ERR_NOMEM);
             } catch (...) {
@@ -1302,20 +1330,36 @@ void rli_frontend_set_clock(rli_frontend* f, uint64_t now_us) {
     if (f) f->fixed_now_us = now_us;
 }
 
-int32_t rli_frontend_should_rate_limit(rli_frontend* f, const uint8_t* msg, uint32_t len, uint8_t* resp, uint32_t resp_cap,
-                                       uint32_t* resp_len) try {
+static int32_t frontend_call(rli_frontend* f, int32_t op, const uint8_t* msg, uint32_t len, uint8_t* resp, uint32_t resp_cap,
+                             uint32_t* resp_len) {
     if (!f || (len && !msg) || !resp || !resp_len) return RL_ERR_INVALID;
     rli_frontend::Slot slot;
     slot.msg = msg;
     slot.len = len;
     slot.resp = resp;
     slot.resp_cap = resp_cap;
+    slot.op = op;
     std::unique_lock<std::mutex> lk(f->mu);
     f->queue.push_back(&slot);
     if (f->queue.size() == 1 || f->queue.size() >= f->max_batch) f->cv_work.notify_one();
     f->cv_done.wait(lk, [&] { return slot.done; });
     *resp_len = slot.resp_len;
     return slot.status;
+}
+
+int32_t rli_frontend_should_rate_limit(rli_frontend* f, const uint8_t* msg, uint32_t len, uint8_t* resp, uint32_t resp_cap,
+                                       uint32_t* resp_len) try {
+    return frontend_call(f, RL_OP_CHECK_AND_UPDATE, msg, len, resp, resp_cap, resp_len);
+} RL_ABI_CATCH
+
+int32_t rli_frontend_check_rate_limit(rli_frontend* f, const uint8_t* msg, uint32_t len, uint8_t* resp, uint32_t resp_cap,
+                                      uint32_t* resp_len) try {
+    return frontend_call(f, RL_OP_CHECK, msg, len, resp, resp_cap, resp_len);
+} RL_ABI_CATCH
+
+int32_t rli_frontend_report(rli_frontend* f, const uint8_t* msg, uint32_t len, uint8_t* resp, uint32_t resp_cap,
+                            uint32_t* resp_len) try {
+    return frontend_call(f, RL_OP_UPDATE, msg, len, resp, resp_cap, resp_len);
 } RL_ABI_CATCH
 
 void rli_frontend_stats(rli_frontend* f, uint64_t* batches, uint64_t* requests) {

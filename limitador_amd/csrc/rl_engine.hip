@@ -2972,7 +2972,34 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
 
 // device pointers for the request arrays and for verdict / limited_limit; derived hits stay in the
 // engine's staging buffers (e->d_hits, e->d_req_off)
-static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* d_ent_off, const u32* d_ent_key,
+// What follows the matcher, by `op` (rl_engine.h RL_OP_*): the derived counters lie in e->d_hits / e->d_req_off / e->d_hit_req.
+//   RL_OP_CHECK_AND_UPDATE  check_rate_limited_and_update (lib.rs:425-464): the general resolver
+//   RL_OP_CHECK             is_rate_limited (lib.rs:362-409): k_req_within, nothing is written
+//   RL_OP_UPDATE            update_counters (lib.rs:411-423): the general resolver with every hit admitted (update_counter)
+static int32_t matched_op_locked(rl_engine* e, int op, u32 n_hits, u32 n_req, u64 now, bool load, uint8_t* d_verdict,
+                                 int32_t* d_limited, bool hit_req_filled, const u32* d_hit_check, int32_t* d_msg_status,
+                                 u32 force_delta) {
+    if (op == RL_OP_CHECK) {
+        HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
+        k_req_within<<<cdiv(n_req, 256), 256, 0, e->stream>>>(e->table, e->log2cap, e->seed, e->d_hits, e->d_req_off, n_req,
+                                                              d_hit_check, d_msg_status, e->d_limits, (u32)e->h_limits.size(),
+                                                              now, force_delta, d_verdict, d_limited, e->d_status);
+        HIP_TRY(e, hipGetLastError());
+        const int rc = read_status(e);
+        if (rc) return rc;
+        if (e->h_status->err) return status_to_error(e, e->h_status->err);
+        return RL_OK;
+    }
+    GenCall gc{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load && op == RL_OP_CHECK_AND_UPDATE, op == RL_OP_UPDATE,
+               d_verdict, e->d_first, e->d_remaining, e->d_expires};
+    gc.d_limited = d_limited;
+    gc.hit_req_filled = hit_req_filled && n_hits > 0;
+    gc.d_hit_check = d_hit_check;
+    gc.d_msg_status = d_msg_status;
+    return run_check_general(e, gc);
+}
+
+static int32_t match_and_check_locked(rl_engine* e, int op, const u32* d_ns, const u32* d_ent_off, const u32* d_ent_key,
                                       const u32* d_ent_val, const u32* d_delta, u32 n_req, u64 now, bool load,
                                       uint8_t* d_verdict, int32_t* d_limited, u32* n_hits_out) {
     if (!e->d_match_limits) return fail(e, RL_ERR_INVALID, "rl_match_table_set was not called");
@@ -2997,10 +3024,7 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
             return fail(e, RL_ERR_INVALID, "a value id does not fit %u bits: such dictionaries keep the host path", MATCH_VAL_BITS);
         if (m_err) return status_to_error(e, m_err);
         if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the requests expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
-        GenCall gc{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load, false, d_verdict, e->d_first, e->d_remaining, e->d_expires};
-        gc.d_limited = d_limited;
-        gc.hit_req_filled = n_hits > 0;
-        return run_check_general(e, gc);
+        return matched_op_locked(e, op, n_hits, n_req, now, load, d_verdict, d_limited, true, nullptr, nullptr, 0u);
     }
     HIP_TRY(e, hipMemsetAsync(e->d_status, 0, sizeof(Status), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_m_count + n_req, 0, sizeof(u32), e->stream));
@@ -3065,10 +3089,7 @@ static int32_t match_and_check_locked(rl_engine* e, const u32* d_ns, const u32* 
                                              e->n_match_conds, nullptr, e->d_req_off, e->d_hits, e->d_status);
         HIP_TRY(e, hipGetLastError());  // (the fill pass cannot fail: the count pass saw every value it writes)
     }
-    GenCall gc{e->d_hits, n_hits, e->d_req_off, n_req, nullptr, now, load, false, d_verdict, e->d_first, e->d_remaining, e->d_expires};
-    gc.d_limited = d_limited;
-    gc.hit_req_filled = e->match_fast && n_hits > 0;
-    return run_check_general(e, gc);
+    return matched_op_locked(e, op, n_hits, n_req, now, load, d_verdict, d_limited, e->match_fast, nullptr, nullptr, 0u);
 }
 
 int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, const uint32_t* d_ent_off,
@@ -3081,16 +3102,17 @@ int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, 
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
     HIP_TRY(e, hipSetDevice(e->device));
-    return match_and_check_locked(e, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, n_req, now_us,
+    return match_and_check_locked(e, RL_OP_CHECK_AND_UPDATE, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, n_req, now_us,
                                   load_counters != 0, d_verdict, d_limited_limit, n_hits_out);
 } RL_ABI_CATCH
 
-int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
-                                 const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
-                                 int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, uint32_t* req_off_out,
-                                 rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out, uint64_t* remaining,
-                                 uint64_t* expires_in_us) try {
+static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
+                                const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
+                                int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, uint32_t* req_off_out,
+                                rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out, uint64_t* remaining,
+                                uint64_t* expires_in_us) {
     if (!e || !n_req || !req_ns || !ent_off || !req_delta || !verdict) return RL_ERR_INVALID;
+    if (op != RL_OP_CHECK_AND_UPDATE && op != RL_OP_CHECK && op != RL_OP_UPDATE) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (n_req > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_req %u > max_batch_hits %u", n_req, e->max_batch);
@@ -3106,7 +3128,7 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
         HIP_TRY(e, hipMemcpyAsync(e->d_m_ent_val, ent_val, (size_t)n_ent * 4, hipMemcpyHostToDevice, e->stream));
     }
     u32 n_hits = 0;
-    int rc = match_and_check_locked(e, e->d_m_ns, e->d_m_ent_off, e->d_m_ent_key, e->d_m_ent_val, e->d_m_delta, n_req,
+    int rc = match_and_check_locked(e, op, e->d_m_ns, e->d_m_ent_off, e->d_m_ent_key, e->d_m_ent_val, e->d_m_delta, n_req,
                                     now_us, load_counters != 0, e->d_verdict, limited_limit ? e->d_m_limited : nullptr,
                                     &n_hits);
     if (n_hits_out) *n_hits_out = n_hits;
@@ -3125,6 +3147,22 @@ int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uin
     }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
+}
+
+int32_t rl_match_and_check_batch(rl_engine* e, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
+                                 const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
+                                 int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, uint32_t* req_off_out,
+                                 rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out, uint64_t* remaining,
+                                 uint64_t* expires_in_us) try {
+    return match_batch_host(e, RL_OP_CHECK_AND_UPDATE, req_ns, ent_off, ent_key, ent_val, req_delta, n_req, now_us, load_counters,
+                            verdict, limited_limit, req_off_out, hits_out, hits_cap, n_hits_out, remaining, expires_in_us);
+} RL_ABI_CATCH
+
+int32_t rl_match_batch_op(rl_engine* e, int32_t op, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
+                          const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us, uint8_t* verdict,
+                          int32_t* limited_limit) try {
+    return match_batch_host(e, op, req_ns, ent_off, ent_key, ent_val, req_delta, n_req, now_us, 0, verdict, limited_limit, nullptr,
+                            nullptr, 0u, nullptr, nullptr, nullptr);
 } RL_ABI_CATCH
 
 int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, const rl_wire_str* ns, uint32_t n_ns,
@@ -3205,11 +3243,12 @@ int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out)
     return RL_OK;
 } RL_ABI_CATCH
 
-int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
-                                      int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, int32_t* status,
-                                      uint32_t* req_off_out, rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out,
-                                      uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) try {
+static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
+                               int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, int32_t* status,
+                               uint32_t* req_off_out, rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out,
+                               uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) {
     if (!e || !n || !msg_off || !verdict || !status) return RL_ERR_INVALID;
+    if (op != RL_OP_CHECK_AND_UPDATE && op != RL_OP_CHECK && op != RL_OP_UPDATE) return RL_ERR_INVALID;
     if (collided_message) *collided_message = -1;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -3250,12 +3289,9 @@ int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const u
     if (m_err || n_hits > e->max_batch) HIP_TRY(e, hipStreamSynchronize(e->stream));  // refused
     if (m_err) return status_to_error(e, m_err);
     if (n_hits > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "the messages expand to %u counters > max_batch_hits %u", n_hits, e->max_batch);
-    GenCall gc{e->d_hits, n_hits, e->d_req_off, n, nullptr, now_us, load_counters != 0, false, e->d_verdict, e->d_first, e->d_remaining, e->d_expires};
-    gc.d_limited = limited_limit ? e->d_m_limited : nullptr;
-    gc.hit_req_filled = n_hits > 0;
-    gc.d_hit_check = e->d_hit_check;
-    gc.d_msg_status = e->d_w_status;
-    rc = run_check_general(e, gc);
+    // (CheckRateLimit over the wire checks with delta 1 whatever hits_addend says: kuadrant_service.rs:62-64)
+    rc = matched_op_locked(e, op, n_hits, n, now_us, load_counters != 0, e->d_verdict, limited_limit ? e->d_m_limited : nullptr,
+                           true, e->d_hit_check, e->d_w_status, op == RL_OP_CHECK ? 1u : 0u);
     if (rc == RL_ERR_KEY_COLLISION) {
         // status[] names EVERY message that carries a colliding counter (-103); *collided_message is one of them
         if (collided_message && e->collide_hit < n_hits) {
@@ -3277,6 +3313,20 @@ int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const u
     }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
+}
+
+int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
+                                      int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, int32_t* status,
+                                      uint32_t* req_off_out, rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out,
+                                      uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) try {
+    return wire_match_host(e, RL_OP_CHECK_AND_UPDATE, wire, msg_off, n, now_us, load_counters, verdict, limited_limit, status,
+                           req_off_out, hits_out, hits_cap, n_hits_out, remaining, expires_in_us, collided_message);
+} RL_ABI_CATCH
+
+int32_t rl_wire_match_batch_op(rl_engine* e, int32_t op, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
+                               uint8_t* verdict, int32_t* limited_limit, int32_t* status, int64_t* collided_message) try {
+    return wire_match_host(e, op, wire, msg_off, n, now_us, 0, verdict, limited_limit, status, nullptr, nullptr, 0u, nullptr,
+                           nullptr, nullptr, collided_message);
 } RL_ABI_CATCH
 
 uint32_t rl_owner_of(uint64_t key, uint64_t hash_seed, uint32_t world) { return owner_of(key, hash_seed, world); }

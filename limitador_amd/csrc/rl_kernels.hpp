@@ -96,6 +96,65 @@ __global__ __launch_bounds__(256) void k_within(Cell* __restrict__ table, u32 lo
     within[i] = (M >= (u64)(value + d)) ? 1 : 0;  // :34, wrapping add
 }
 
+// RateLimiter::is_rate_limited (lib.rs:362-409) for a batch of REQUESTS whose counters the matcher derived
+// (hits[req_off[r] .. req_off[r + 1]), in counters_that_apply's order): find_first_limited_counter walks a request's
+// counters with is_within_limits above and stops at the first one that does not fit — that counter's limit is the one
+// whose name the reference reports.  Read-only: nothing is created, nothing is counted.  One lane per request (a request
+// derives at most one counter per limit of its namespace: a handful).  `force_delta` != 0 replaces every hit's delta:
+// the Kuadrant CheckRateLimit method checks with 1 whatever hits_addend says (envoy_rls/kuadrant_service.rs:62-64).
+// Hashed keys (hit_check != null, include/rl_keyhash.h): a cell whose check word or limit id is another counter's is not
+// this counter's cell — the request is marked WIRE_ST_KEY_COLLISION (-103) in msg_status and answered by the caller's
+// exact path, like the counting entry points do; with exact keys a limit id that differs is RL_ERR_KEY_LIMIT.
+__global__ __launch_bounds__(256) void k_req_within(const Cell* __restrict__ table, u32 log2cap, u64 seed,
+                                                    const Hit* __restrict__ hits, const u32* __restrict__ req_off, u32 n_req,
+                                                    const u32* __restrict__ hit_check, int32_t* __restrict__ msg_status,
+                                                    const LimitDev* __restrict__ limits, u32 n_limits, u64 now,
+                                                    u32 force_delta, uint8_t* __restrict__ verdict,
+                                                    int32_t* __restrict__ limited_limit, Status* st) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_req) return;
+    const u32 q0 = req_off[r], q1 = req_off[r + 1];
+    const u32 mask = (1u << log2cap) - 1u;
+    uint8_t limited = 0;
+    int32_t which = -1;
+    for (u32 q = q0; q < q1; ++q) {
+        const Hit h = load_hit(hits, q);
+        const u32 lid = h.limit & ~SIMPLE_FLAG;
+        if (lid >= n_limits) {
+            atomicOr(&st->err, ERRBIT_BAD_LIMIT);
+            break;
+        }
+        u64 value = 0;
+        u32 slot = slot_of(h.key, seed, log2cap);
+        for (u32 step = 0; step <= mask; ++step, slot = (slot + 1) & mask) {
+            const uint4 a = *reinterpret_cast<const uint4*>(&table[slot]);
+            const u64 tag = ((u64)a.y << 32) | a.x;
+            if (tag == TAG_EMPTY) break;  // unwrap_or_default(): 0
+            if (tag != h.key) continue;
+            const uint4 b = reinterpret_cast<const uint4*>(&table[slot])[1];
+            const u64 expiry = ((u64)b.y << 32) | b.x;
+            const bool other = (b.z & ~SIMPLE_FLAG) != lid || (hit_check && b.w != 0u && b.w != hit_check[q]);
+            if (other) {
+                if (hit_check && msg_status) msg_status[r] = -103;
+                else atomicOr(&st->err, ERRBIT_KEY_LIMIT);
+                q = q1;  // (the request is not answered here)
+                break;
+            }
+            value = expiry <= now ? 0ull : (((u64)a.w << 32) | a.z);  // value_at(now), atomic_expiring_value.rs:19-24
+            break;
+        }
+        if (q >= q1) break;
+        const u64 d = force_delta ? (u64)force_delta : (u64)h.delta;
+        if (!(limits[lid].max_value >= (u64)(value + d))) {  // in_memory.rs:34, wrapping add
+            limited = 1;
+            which = (int32_t)lid;
+            break;
+        }
+    }
+    verdict[r] = limited;
+    if (limited_limit) limited_limit[r] = which;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Table maintenance: init, bulk insert, streaming scans, compaction
 // ---------------------------------------------------------------------------------------------

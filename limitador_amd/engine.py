@@ -282,6 +282,21 @@ class Engine:
         return {"verdict": verdict, "limited_limit": limited, "req_off": req_off, "hits": hits[:n],
                 "remaining": rem[:n] if load_counters else None, "expires_in_us": exp[:n] if load_counters else None}
 
+    def match_op(self, op, req_ns, ent_off, ent_key, ent_val, req_delta, now_us):
+        """rl_match_batch_op: op 0 check_rate_limited_and_update, 1 is_rate_limited (read-only), 2 update_counters — the
+        RateLimiter methods behind the matcher (lib.rs:362-464).  -> (verdict, limited_limit)"""
+        req_ns = np.ascontiguousarray(req_ns, dtype=np.uint32)
+        ent_off = np.ascontiguousarray(ent_off, dtype=np.uint32)
+        ent_key = np.ascontiguousarray(ent_key, dtype=np.uint32)
+        ent_val = np.ascontiguousarray(ent_val, dtype=np.uint32)
+        req_delta = np.ascontiguousarray(req_delta, dtype=np.uint32)
+        n_req = req_ns.shape[0]
+        verdict = np.empty(n_req, dtype=np.uint8)
+        limited = np.empty(n_req, dtype=np.int32)
+        self._check(self._lib.rl_match_batch_op(self._h, int(op), _ptr(req_ns), _ptr(ent_off), _ptr(ent_key), _ptr(ent_val),
+                                                _ptr(req_delta), n_req, int(now_us), _ptr(verdict), _ptr(limited)))
+        return verdict, limited
+
     def match_and_check_device(self, d_req_ns, d_ent_off, d_ent_key, d_ent_val, d_req_delta, n_req, now_us,
                                d_verdict, d_limited_limit, load_counters=False):
         """rl_match_and_check_batch_device: request arrays, verdict and limited_limit are device pointers.

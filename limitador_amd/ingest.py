@@ -10,6 +10,8 @@ from .wire import LIMIT_ROW_DTYPE, MATCH_COND_DTYPE, MATCH_LIMIT_DTYPE
 
 HOST_ONLY = -100
 UNKNOWN_DOMAIN = -101
+# rl_engine.h RL_OP_*: ShouldRateLimit; the Kuadrant service's CheckRateLimit / Report (envoy_rls/kuadrant_service.rs:27-184)
+OP_CHECK_AND_UPDATE, OP_CHECK, OP_UPDATE = 0, 1, 2
 SYMBOLS = {}
 
 
@@ -39,6 +41,10 @@ def _lib():
         "rli_set_limit_name": (i32, [p, u32, cp]),
         "rli_serve_batch": (i32, [p, p, C.POINTER(C.c_char_p), C.POINTER(u32), u32, u64, i32, C.POINTER(C.c_uint8), u32,
                                   C.POINTER(u32), C.POINTER(i32)]),
+        "rli_serve_batch_op": (i32, [p, p, i32, C.POINTER(C.c_char_p), C.POINTER(u32), u32, u64, C.POINTER(C.c_uint8), u32,
+                                     C.POINTER(u32), C.POINTER(i32)]),
+        "rli_frontend_check_rate_limit": (i32, [p, C.c_char_p, u32, C.POINTER(C.c_uint8), u32, C.POINTER(u32)]),
+        "rli_frontend_report": (i32, [p, C.c_char_p, u32, C.POINTER(C.c_uint8), u32, C.POINTER(u32)]),
         "rli_frontend_create": (i32, [p, p, u32, u32, i32, C.POINTER(p)]),
         "rli_frontend_destroy": (None, [p]),
         "rli_frontend_set_clock": (None, [p, u64]),
@@ -169,6 +175,21 @@ class Ingest:
         raw = bytes(out)
         return [status[i] for i in range(n)], [raw[i * stride:i * stride + out_len[i]] for i in range(n)]
 
+    def serve_batch_op(self, engine, op, messages, now_us, stride=64):
+        """rli_serve_batch_op: OP_CHECK = Kuadrant CheckRateLimit (is_rate_limited with delta 1, nothing written),
+        OP_UPDATE = Report (update_counters with hits_addend), OP_CHECK_AND_UPDATE = serve_batch without headers.
+        -> (status per request, response bytes per request)."""
+        n = len(messages)
+        msgs = (C.c_char_p * max(1, n))(*[bytes(m) for m in messages])
+        lens = (C.c_uint32 * max(1, n))(*[len(m) for m in messages])
+        out = (C.c_uint8 * (max(1, n) * stride))()
+        out_len = (C.c_uint32 * max(1, n))()
+        status = (C.c_int32 * max(1, n))()
+        self._check(SYMBOLS["rli_serve_batch_op"](self._h, engine._h, int(op), msgs, lens, n, int(now_us), out, stride, out_len,
+                                                  status))
+        raw = bytes(out)
+        return [status[i] for i in range(n)], [raw[i * stride:i * stride + out_len[i]] for i in range(n)]
+
     def prepare_batch(self, messages, stride=1024):
         """The ctypes arrays of serve_batch built once (benchmarks: what is timed afterwards is the C call alone)."""
         n = len(messages)
@@ -268,6 +289,20 @@ class Frontend:
         n = C.c_uint32()
         rc = SYMBOLS["rli_frontend_should_rate_limit"](self._h, bytes(message), len(message), out, 1024, C.byref(n))
         return rc, bytes(out[: n.value])
+
+    def _call(self, name, message):
+        out = (C.c_uint8 * 1024)()
+        n = C.c_uint32()
+        rc = SYMBOLS[name](self._h, bytes(message), len(message), out, 1024, C.byref(n))
+        return rc, bytes(out[: n.value])
+
+    def check_rate_limit(self, message):
+        """Kuadrant CheckRateLimit -> (status, response bytes)"""
+        return self._call("rli_frontend_check_rate_limit", message)
+
+    def report(self, message):
+        """Kuadrant Report -> (status, response bytes)"""
+        return self._call("rli_frontend_report", message)
 
     def stats(self):
         b, r = C.c_uint64(), C.c_uint64()
