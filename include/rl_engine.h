@@ -395,13 +395,37 @@ int32_t rl_wire_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, 
 /* Pinned host buffers that belong to the engine, by slot (0..3; grown on demand — a later call for the same slot may move
  * it — and freed with the engine): where a host layer builds the arrays it hands to the host-pointer entry points and
  * receives their results, so that every copy is plain DMA instead of the runtime's pageable path (a fresh 60 MB result
- * array per call cost the wire path 20 ms of page faults and staged copies).  No reference analogue. */
+ * array per call cost the wire path 20 ms of page faults and staged copies).  Slots 2 and 3 are also where
+ * rl_match_serve_batch / rl_wire_serve_batch leave their responses.  No reference analogue. */
 int32_t rl_host_staging(rl_engine *e, uint32_t slot, uint64_t bytes, void **out);
 int32_t rl_wire_match_and_check_batch(rl_engine *e, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
                                       uint64_t now_us, int32_t load_counters, uint8_t *verdict, int32_t *limited_limit,
                                       int32_t *status, uint32_t *req_off_out, rl_hit *hits_out, uint32_t hits_cap,
                                       uint32_t *n_hits_out, uint64_t *remaining, uint64_t *expires_in_us,
                                       int64_t *collided_message);
+/* ---- the answer as RateLimitResponse bytes, built on the device (limitador_amd/csrc/rl_resp.hpp) -------------------------
+ * ShouldRateLimit's reply (envoy_rls/server.rs:176-206) is a serialized RateLimitResponse per request: overall_code, and
+ * with RateLimitHeaders::DraftVersion03 the three headers of CheckResult::response_header (lib.rs:235-275) over the
+ * request's loaded counters.  These entries decide the batch like rl_match_and_check_batch / rl_wire_match_and_check_batch
+ * do (load_counters = with_headers) and hand back the responses — request i's bytes are resp[resp_off[i] .. resp_off[i + 1])
+ * — instead of the counters, their remaining / expires_in and the request offsets: what crosses PCIe is the answer.
+ *
+ * rl_resp_table_set: what limit `id` contributes to X-RateLimit-Limit, frag[id] inside blob — the text
+ * `, {max};w={seconds}[;name="{name}"]` (lib.rs:246-262), formatted once per limit by the host layer that knows the names;
+ * a limit id beyond n_limits contributes `, 0;w=0`.  Call after rl_limits_set, again whenever a limit's max / name changes.
+ *
+ * A request with status != 0 (rl_wire_serve_batch: no domain, malformed, -103) has an empty response: for -101 that IS the
+ * reply (Code::Unknown = 0 is the proto3 default, server.rs:105-115), the others have none.  *resp_off ([n + 1]) and *resp
+ * point into pinned memory of the ENGINE (rl_host_staging slots 2 and 3, sized by the batch's own total): valid until the
+ * next serving call on the engine or a rl_host_staging call for those slots.  The other pointers are host pointers. */
+int32_t rl_resp_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, const rl_wire_str *frag, uint32_t n_limits);
+int32_t rl_match_serve_batch(rl_engine *e, const uint32_t *req_ns, const uint32_t *ent_off, const uint32_t *ent_key,
+                             const uint32_t *ent_val, const uint32_t *req_delta, uint32_t n_req, uint64_t now_us,
+                             int32_t with_headers, uint8_t *verdict, const uint32_t **resp_off, const uint8_t **resp);
+int32_t rl_wire_serve_batch(rl_engine *e, const uint8_t *wire, const uint32_t *msg_off, uint32_t n, uint64_t now_us,
+                            int32_t with_headers, uint8_t *verdict, int32_t *status, const uint32_t **resp_off,
+                            const uint8_t **resp, int64_t *collided_message);
+
 /* rl_match_batch_op for serialized messages (RL_OP_* above).  RL_OP_CHECK is the Kuadrant CheckRateLimit: every counter is
  * checked with delta 1 whatever the message's hits_addend says (kuadrant_service.rs:62-64); a message whose counter's key
  * belongs to another counter gets status[i] = -103 and no verdict (nothing to re-run: the call wrote nothing).  RL_OP_UPDATE

@@ -287,6 +287,10 @@ struct rli_ingest {
     // batch
     std::vector<uint32_t> req_ns, req_delta, ent_off{0}, ent_key, ent_val;
     std::string err;
+    // What each limit contributes to X-RateLimit-Limit lives on the device (rl_resp_table_set): re-sent to an engine when a
+    // limit's max / name changed since the last time, or the engine is another one
+    uint64_t resp_version = 1, resp_sent = 0;
+    const rl_engine* resp_engine = nullptr;
     // The dictionaries are read by many decoding threads at once (rli_serve_batch splits a large batch over
     // threads) and written when a request brings a value never seen before: readers share, a writer excludes.
     mutable std::shared_mutex dict_mu;
@@ -501,6 +505,7 @@ int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_
     if (it != g->by_identity.end()) {  // same limit (limit.rs:177-214): max_value is not identity
         g->limits[it->second].max_value = max_value;
         g->compiled = false;
+        ++g->resp_version;
         return (int32_t)it->second;
     }
     if (g->limits.size() >= 4095) return gfail(g, RL_ERR_INVALID, "more than 4095 limits");
@@ -508,6 +513,7 @@ int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_
     g->by_identity.emplace(L.identity(), id);
     g->limits.push_back(std::move(L));
     g->compiled = false;
+    ++g->resp_version;
     return (int32_t)id;
 } RL_ABI_CATCH
 
@@ -865,6 +871,7 @@ int32_t rli_set_limit_name(rli_ingest* g, uint32_t limit_id, const char* name) t
     if (!g || limit_id >= g->limits.size()) return RL_ERR_INVALID;
     g->limits[limit_id].has_name = name != nullptr;
     g->limits[limit_id].name = name ? name : "";
+    ++g->resp_version;
     return RL_OK;
 } RL_ABI_CATCH
 
@@ -885,6 +892,35 @@ void put_string_field(std::string& o, uint32_t field, const std::string& v) {
 }
 
 }  // namespace
+
+// `, {max};w={secs}[;name="{name}"]` — what a limit contributes to X-RateLimit-Limit (lib.rs:246-262), the same for every
+// request: formatted once per limit.
+static std::string limit_fragment(const LimitSpec* L) {
+    std::string f = ", " + std::to_string(L ? L->max_value : 0) + ";w=" + std::to_string(L ? L->seconds : 0);
+    if (L && L->has_name) {
+        std::string nm = L->name;
+        std::replace(nm.begin(), nm.end(), '"', '\'');
+        f += ";name=\"" + nm + "\"";
+    }
+    return f;
+}
+
+// The fragments on the device (rl_resp_table_set), where the responses with headers are built (rl_resp.hpp).
+static int32_t send_fragments(rli_ingest* g, rl_engine* e) {
+    if (g->resp_engine == e && g->resp_sent == g->resp_version) return RL_OK;
+    std::vector<uint8_t> blob;
+    std::vector<rl_wire_str> frag(g->limits.size());
+    for (size_t l = 0; l < g->limits.size(); ++l) {
+        const std::string f = limit_fragment(&g->limits[l]);
+        frag[l] = rl_wire_str{(uint32_t)blob.size(), (uint32_t)f.size()};
+        blob.insert(blob.end(), f.begin(), f.end());
+    }
+    const int32_t rc = rl_resp_table_set(e, blob.data(), (uint32_t)blob.size(), frag.data(), (uint32_t)frag.size());
+    if (rc) return gfail(g, rc, "rl_resp_table_set: %s", rl_last_error(e));
+    g->resp_engine = e;
+    g->resp_sent = g->resp_version;
+    return RL_OK;
+}
 
 // op: RL_OP_CHECK_AND_UPDATE = ShouldRateLimit (envoy_rls/server.rs:91-208); RL_OP_CHECK / RL_OP_UPDATE = the Kuadrant service's
 // CheckRateLimit / Report (envoy_rls/kuadrant_service.rs:27-184), whose responses never carry rate-limit headers.
@@ -934,6 +970,14 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         exp = reinterpret_cast<uint64_t*>(p);
         return RL_OK;
     };
+    // With headers the responses are built on the DEVICE (rl_*_serve_batch): what comes back is the bytes, not the counters.
+    // RLI_RESP_HOST=1 (experiment builds) keeps round 4's host assembly from the counters' arrays — the two are compared
+    // byte for byte by tests/test_gpu_rls_e2e.py.
+    const bool dev_resp = with_headers && RL_EXP_ENV("RLI_RESP_HOST") == nullptr;
+    const uint32_t* d_off = nullptr;  // device-built responses: request r's bytes are d_bytes[d_off[r] .. d_off[r + 1])
+    const uint8_t* d_bytes = nullptr;
+    if (dev_resp)
+        if (const int32_t frc = send_fragments(g, e)) return frc;
     uint32_t n_req = 0;
     // every request derives at most one counter per limit of its namespace
     size_t per_ns = 1;
@@ -948,7 +992,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         //      counter and carries its status.
         std::vector<uint8_t> skip(n, 0);  // messages taken out after a key collision: answered RLI_HOST_ONLY
         n_req = n;
-        const size_t cap = with_headers ? (size_t)n * per_ns : 0;
+        const size_t cap = with_headers && !dev_resp ? (size_t)n * per_ns : 0;
         if (const int32_t brc = result_arrays(n, cap)) return brc;
         uint64_t sum = 0;
         for (uint32_t i = 0; i < n; ++i) {
@@ -978,7 +1022,8 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
             uint32_t n_hits = 0;
             int64_t collided = -1;
             const int32_t rc =
-                op == RL_OP_CHECK_AND_UPDATE
+                dev_resp ? rl_wire_serve_batch(e, w_bytes, w_off, n, now_us, 1, verdict, dev_status, &d_off, &d_bytes, &collided)
+                : op == RL_OP_CHECK_AND_UPDATE
                     ? rl_wire_match_and_check_batch(e, w_bytes, w_off, n, now_us, with_headers ? 1 : 0, verdict, limited, dev_status,
                                                     with_headers ? req_off : nullptr, with_headers ? hits : nullptr, (uint32_t)cap,
                                                     &n_hits, with_headers ? rem : nullptr, with_headers ? exp : nullptr, &collided)
@@ -1084,12 +1129,14 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         });
         n_req = (uint32_t)g->req_ns.size();
         lap("appended");
-        const size_t cap = with_headers ? (size_t)n_req * per_ns : 0;
+        const size_t cap = with_headers && !dev_resp ? (size_t)n_req * per_ns : 0;
         if (const int32_t brc = result_arrays(n_req, cap)) return brc;
         if (n_req) {
             uint32_t n_hits = 0;
             const int32_t rc =
-                op == RL_OP_CHECK_AND_UPDATE
+                dev_resp ? rl_match_serve_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
+                                                g->req_delta.data(), n_req, now_us, 1, verdict, &d_off, &d_bytes)
+                : op == RL_OP_CHECK_AND_UPDATE
                     ? rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
                                                g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict, limited,
                                                with_headers ? req_off : nullptr, with_headers ? hits : nullptr, (uint32_t)cap, &n_hits,
@@ -1105,17 +1152,9 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
     // what a limit contributes to X-RateLimit-Limit — `, {max};w={secs}[;name="{name}"]` — is the same for every request:
     // built once per call, not once per counter (lib.rs:246-262)
     std::vector<std::string> frag(g->limits.size() + 1);
-    if (with_headers)
-        for (size_t l = 0; l <= g->limits.size(); ++l) {
-            const LimitSpec* L = l < g->limits.size() ? &g->limits[l] : nullptr;  // (the last one: a limit id this ingest does not know)
-            std::string& f = frag[l];
-            f = ", " + std::to_string(L ? L->max_value : 0) + ";w=" + std::to_string(L ? L->seconds : 0);
-            if (L && L->has_name) {
-                std::string nm = L->name;
-                std::replace(nm.begin(), nm.end(), '"', '\'');
-                f += ";name=\"" + nm + "\"";
-            }
-        }
+    if (with_headers && !dev_resp)
+        for (size_t l = 0; l <= g->limits.size(); ++l)  // (the last one: a limit id this ingest does not know)
+            frag[l] = limit_fragment(l < g->limits.size() ? &g->limits[l] : nullptr);
     auto put_u64 = [](std::string& o, uint64_t v) {
         char buf[24];
         int k = 24;
@@ -1131,6 +1170,27 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         std::vector<uint32_t> order;
         static const std::string k_limit = "X-RateLimit-Limit", k_rem = "X-RateLimit-Remaining", k_reset = "X-RateLimit-Reset";
         for (uint32_t i = lo; i < hi; ++i) {
+            if (dev_resp && d_off) {
+                // the bytes exist already (rl_resp.hpp): request r's response goes to the caller's slot i
+                if (status[i] != 0 && status[i] != RLI_UNKNOWN_DOMAIN) continue;  // malformed / RLI_HOST_ONLY: no response
+                uint32_t len = 0;
+                const uint8_t* src = nullptr;
+                if (status[i] == 0) {
+                    const uint32_t r = (uint32_t)req_of[i];
+                    len = d_off[r + 1] - d_off[r];
+                    src = d_bytes + d_off[r];
+                    status[i] = verdict[r] ? 1 : 0;
+                }  // (no domain: Code::Unknown, the empty message)
+                if (len > out_stride) {
+                    too_long.store(len);
+                    status[i] = RLI_RESPONSE_TOO_LARGE;
+                    out_len[i] = 0;
+                    continue;
+                }
+                if (len) memcpy(out + (size_t)i * out_stride, src, len);
+                out_len[i] = len;
+                continue;
+            }
             o.clear();
             if (status[i] == RLI_UNKNOWN_DOMAIN) {
                 // Code::Unknown = 0, the proto3 default: an empty message (server.rs:105-115)

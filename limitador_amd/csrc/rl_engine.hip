@@ -31,6 +31,7 @@
 #include "rl_route.hpp"
 #include "rl_match.hpp"
 #include "rl_wire.hpp"
+#include "rl_resp.hpp"
 
 using namespace rl;
 
@@ -279,6 +280,15 @@ struct rl_engine {
     u64* d_w_prefix = nullptr;
     uint8_t* d_w_bytes = nullptr;   // the messages of one batch, concatenated
     u64 w_bytes_cap = 0;
+    // RateLimitResponse bytes built on the device (rl_resp.hpp): what each limit contributes to X-RateLimit-Limit
+    // (rl_resp_table_set), the responses' offsets and bytes of one batch
+    uint8_t* d_resp_blob = nullptr;
+    WireStr* d_resp_frag = nullptr;
+    u32 n_resp_frag = 0;
+    bool resp_ready = false;
+    u32* d_resp_off = nullptr;      // [max_batch + 2]
+    uint8_t* d_resp_bytes = nullptr;
+    u64 resp_bytes_cap = 0;
     u32* d_w_off = nullptr;         // [max_batch + 1]
     int32_t* d_w_status = nullptr;  // [max_batch]
     uint4* d_w_slot_h = nullptr;    // [max_batch][MATCH_SLOTS]: hashes of the values the variables read
@@ -1996,7 +2006,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
-                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_cmark, e->d_w_blob, e->d_w_ns, e->d_w_lit, e->d_w_prefix, e->d_w_bytes, e->d_w_off, e->d_w_status, e->d_w_slot_h, e->d_hit_check, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
+                    e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_cmark, e->d_w_blob, e->d_w_ns, e->d_w_lit, e->d_w_prefix, e->d_w_bytes, e->d_w_off, e->d_w_status, e->d_w_slot_h, e->d_hit_check, e->d_resp_blob, e->d_resp_frag, e->d_resp_off, e->d_resp_bytes, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};
     for (void* p : ptrs)
@@ -2999,6 +3009,72 @@ static int32_t matched_op_locked(rl_engine* e, int op, u32 n_hits, u32 n_req, u6
     return run_check_general(e, gc);
 }
 
+// Where a serving call (rl_match_serve_batch / rl_wire_serve_batch) wants its answer: host pointers.
+struct ServeOut {
+    int32_t with_headers;
+    const uint32_t** resp_off;  // -> [n + 1], in the engine's pinned staging (slot 2)
+    const uint8_t** resp;       // -> the bytes, in the engine's pinned staging (slot 3)
+};
+static int32_t host_staging_locked(rl_engine* e, uint32_t slot, uint64_t bytes, void** out);
+
+// The serialized RateLimitResponse of every request of the batch the resolver just decided (rl_resp.hpp): lengths ->
+// exclusive scan -> bytes, then the offsets and the bytes to the host.  d_status: per request, null = every request is
+// answered.  The caller synchronises the stream.
+static int32_t responses_locked(rl_engine* e, u32 n, const int32_t* d_status, const uint8_t* d_verdict, const ServeOut& so) {
+    if (so.with_headers && !e->resp_ready) return fail(e, RL_ERR_INVALID, "rl_resp_table_set was not called for the installed limits");
+    if (!e->d_resp_off && hipMalloc((void**)&e->d_resp_off, ((size_t)e->max_batch + 2) * sizeof(u32)) != hipSuccess)
+        return fail(e, RL_ERR_NOMEM, "hipMalloc of the responses' offsets failed");
+    RespArgs R{};
+    R.blob = e->d_resp_blob;
+    R.frag = e->d_resp_frag;
+    R.n_frag = e->n_resp_frag;
+    R.limits = e->d_limits;
+    R.n_limits = (u32)e->h_limits.size();
+    R.status = d_status;
+    R.verdict = d_verdict;
+    R.req_off = e->d_req_off;
+    R.hits = e->d_hits;
+    R.remaining = e->d_remaining;
+    R.expires_in = e->d_expires;
+    R.n = n;
+    R.with_headers = so.with_headers ? 1u : 0u;
+    u32* len = e->d_m_count;  // (the matcher's per-request counts are done with: [max_batch + 1])
+    k_resp<false><<<cdiv(n + 1, 256), 256, 0, e->stream>>>(R, len, nullptr, nullptr);
+    {
+        const u32 ns = n + 1, gs = cdiv(ns, XSCAN_PER_WG);
+        u32* tot = static_cast<u32*>(e->d_m_scan_tmp);
+        k_xscan_sums<<<gs, 256, 0, e->stream>>>(len, ns, tot);
+        k_xscan_tot<<<1, 1024, 0, e->stream>>>(tot, gs);
+        k_xscan_apply<<<gs, 256, 0, e->stream>>>(len, ns, tot, e->d_resp_off);
+    }
+    HIP_TRY(e, hipGetLastError());
+    void* h_off = nullptr;
+    int32_t rc = host_staging_locked(e, 2, ((u64)n + 1) * sizeof(u32), &h_off);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(h_off, e->d_resp_off, ((size_t)n + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const u64 total = static_cast<const u32*>(h_off)[n];
+    void* h_bytes = nullptr;
+    rc = host_staging_locked(e, 3, total ? total : 1, &h_bytes);
+    if (rc) return rc;
+    *so.resp_off = static_cast<const u32*>(h_off);
+    *so.resp = static_cast<const uint8_t*>(h_bytes);
+    if (!total) return RL_OK;
+    if (total > e->resp_bytes_cap) {
+        if (e->d_resp_bytes) (void)hipFree(e->d_resp_bytes);
+        e->d_resp_bytes = nullptr;
+        e->resp_bytes_cap = 0;
+        u64 cap = 1u << 16;
+        while (cap < total) cap <<= 1;
+        if (hipMalloc((void**)&e->d_resp_bytes, cap) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc of %llu bytes of responses failed", (unsigned long long)cap);
+        e->resp_bytes_cap = cap;
+    }
+    k_resp<true><<<cdiv(n + 1, 256), 256, 0, e->stream>>>(R, nullptr, e->d_resp_off, e->d_resp_bytes);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(h_bytes, e->d_resp_bytes, total, hipMemcpyDeviceToHost, e->stream));
+    return RL_OK;
+}
+
 static int32_t match_and_check_locked(rl_engine* e, int op, const u32* d_ns, const u32* d_ent_off, const u32* d_ent_key,
                                       const u32* d_ent_val, const u32* d_delta, u32 n_req, u64 now, bool load,
                                       uint8_t* d_verdict, int32_t* d_limited, u32* n_hits_out) {
@@ -3110,8 +3186,9 @@ static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, co
                                 const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
                                 int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, uint32_t* req_off_out,
                                 rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out, uint64_t* remaining,
-                                uint64_t* expires_in_us) {
+                                uint64_t* expires_in_us, const ServeOut* so = nullptr) {
     if (!e || !n_req || !req_ns || !ent_off || !req_delta || !verdict) return RL_ERR_INVALID;
+    if (so && (!so->resp_off || !so->resp)) return RL_ERR_INVALID;
     if (op != RL_OP_CHECK_AND_UPDATE && op != RL_OP_CHECK && op != RL_OP_UPDATE) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
@@ -3134,6 +3211,12 @@ static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, co
     if (n_hits_out) *n_hits_out = n_hits;
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n_req, hipMemcpyDeviceToHost, e->stream));
+    if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
+        rc = responses_locked(e, n_req, nullptr, e->d_verdict, *so);
+        if (rc) return rc;
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return RL_OK;
+    }
     if (limited_limit)
         HIP_TRY(e, hipMemcpyAsync(limited_limit, e->d_m_limited, (size_t)n_req * 4, hipMemcpyDeviceToHost, e->stream));
     if (req_off_out)
@@ -3224,9 +3307,14 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     return RL_OK;
 } RL_ABI_CATCH
 
+static int32_t host_staging_locked(rl_engine* e, uint32_t slot, uint64_t bytes, void** out);
 int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out) try {
     if (!e || !out || slot >= 4u) return RL_ERR_INVALID;
     EngineLock g(e);
+    return host_staging_locked(e, slot, bytes, out);
+} RL_ABI_CATCH
+
+static int32_t host_staging_locked(rl_engine* e, uint32_t slot, uint64_t bytes, void** out) {
     if (bytes > e->h_stage_cap[slot]) {
         HIP_TRY(e, hipSetDevice(e->device));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -3241,13 +3329,15 @@ int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out)
     }
     *out = e->h_stage[slot];
     return RL_OK;
-} RL_ABI_CATCH
+}
 
 static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
                                int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, int32_t* status,
                                uint32_t* req_off_out, rl_hit* hits_out, uint32_t hits_cap, uint32_t* n_hits_out,
-                               uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) {
+                               uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message,
+                               const ServeOut* so = nullptr) {
     if (!e || !n || !msg_off || !verdict || !status) return RL_ERR_INVALID;
+    if (so && (!so->resp_off || !so->resp)) return RL_ERR_INVALID;
     if (op != RL_OP_CHECK_AND_UPDATE && op != RL_OP_CHECK && op != RL_OP_UPDATE) return RL_ERR_INVALID;
     if (collided_message) *collided_message = -1;
     EngineLock g(e);
@@ -3303,6 +3393,12 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
+        rc = responses_locked(e, n, e->d_w_status, e->d_verdict, *so);
+        if (rc) return rc;
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return RL_OK;
+    }
     if (limited_limit) HIP_TRY(e, hipMemcpyAsync(limited_limit, e->d_m_limited, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
     if (req_off_out) HIP_TRY(e, hipMemcpyAsync(req_off_out, e->d_req_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, e->stream));
     const u32 n_copy = n_hits < hits_cap ? n_hits : hits_cap;
@@ -3321,6 +3417,45 @@ int32_t rl_wire_match_and_check_batch(rl_engine* e, const uint8_t* wire, const u
                                       uint64_t* remaining, uint64_t* expires_in_us, int64_t* collided_message) try {
     return wire_match_host(e, RL_OP_CHECK_AND_UPDATE, wire, msg_off, n, now_us, load_counters, verdict, limited_limit, status,
                            req_off_out, hits_out, hits_cap, n_hits_out, remaining, expires_in_us, collided_message);
+} RL_ABI_CATCH
+
+int32_t rl_resp_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, const rl_wire_str* frag, uint32_t n_limits) try {
+    if (!e || (blob_len && !blob) || (n_limits && !frag)) return RL_ERR_INVALID;
+    EngineLock g(e);
+    if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
+    for (u32 i = 0; i < n_limits; ++i)
+        if ((u64)frag[i].off + frag[i].len > blob_len) return fail(e, RL_ERR_INVALID, "fragment %u lies outside the blob", i);
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->d_resp_blob) (void)hipFree(e->d_resp_blob);
+    if (e->d_resp_frag) (void)hipFree(e->d_resp_frag);
+    e->d_resp_blob = nullptr;
+    e->d_resp_frag = nullptr;
+    e->resp_ready = false;
+    if (hipMalloc((void**)&e->d_resp_blob, blob_len ? blob_len : 16) != hipSuccess ||
+        hipMalloc((void**)&e->d_resp_frag, (n_limits ? n_limits : 1) * sizeof(WireStr)) != hipSuccess)
+        return fail(e, RL_ERR_NOMEM, "hipMalloc of the response fragments failed");
+    if (blob_len) HIP_TRY(e, hipMemcpy(e->d_resp_blob, blob, blob_len, hipMemcpyHostToDevice));
+    if (n_limits) HIP_TRY(e, hipMemcpy(e->d_resp_frag, frag, (size_t)n_limits * sizeof(WireStr), hipMemcpyHostToDevice));
+    e->n_resp_frag = n_limits;
+    e->resp_ready = true;
+    return RL_OK;
+} RL_ABI_CATCH
+
+int32_t rl_match_serve_batch(rl_engine* e, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
+                             const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
+                             int32_t with_headers, uint8_t* verdict, const uint32_t** resp_off, const uint8_t** resp) try {
+    const ServeOut so{with_headers, resp_off, resp};
+    return match_batch_host(e, RL_OP_CHECK_AND_UPDATE, req_ns, ent_off, ent_key, ent_val, req_delta, n_req, now_us, with_headers,
+                            verdict, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, &so);
+} RL_ABI_CATCH
+
+int32_t rl_wire_serve_batch(rl_engine* e, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
+                            int32_t with_headers, uint8_t* verdict, int32_t* status, const uint32_t** resp_off,
+                            const uint8_t** resp, int64_t* collided_message) try {
+    const ServeOut so{with_headers, resp_off, resp};
+    return wire_match_host(e, RL_OP_CHECK_AND_UPDATE, wire, msg_off, n, now_us, with_headers, verdict, nullptr, status, nullptr,
+                           nullptr, 0u, nullptr, nullptr, nullptr, collided_message, &so);
 } RL_ABI_CATCH
 
 int32_t rl_wire_match_batch_op(rl_engine* e, int32_t op, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,

@@ -163,7 +163,7 @@ def test_check_then_report_against_the_rate_limiter_over_the_oracle(make_engine,
     live = 0
     for lid, (_ns, _mx, _secs, _conds, variables, _name) in enumerate(_limits()):
         wire = lid | (0 if variables else 0x80000000)
-        got = sorted((int(r["value"]), int(r["expiry_us"])) for r in eng.get_counters(lid, now))
+        got = sorted((int(r["value"]), int(r["expiry_us"])) for r in eng.get_counters(wire, now))
         want = sorted((int(r["value"]), int(r["expires_in_us"])) for r in model.storage.get_counters(wire, now))
         assert got == want, lid
         live += len(got)
@@ -247,6 +247,6 @@ def test_match_op_on_dictionary_encoded_requests(make_engine):
         model.sleep(0.7)
     for lid, (_ns, _mx, _secs, _conds, variables, _name) in enumerate(_limits()):
         wire = lid | (0 if variables else 0x80000000)
-        got = sorted((int(r["value"]), int(r["expiry_us"])) for r in eng.get_counters(lid, model.now_us))
+        got = sorted((int(r["value"]), int(r["expiry_us"])) for r in eng.get_counters(wire, model.now_us))
         want = sorted((int(r["value"]), int(r["expires_in_us"])) for r in model.storage.get_counters(wire, model.now_us))
         assert got == want, lid

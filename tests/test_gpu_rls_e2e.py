@@ -510,3 +510,60 @@ def test_the_device_decoder_agrees_with_the_host_decoder_on_mangled_messages(mak
     flat = [s for st, _ in out["exact"] for s in st]
     assert sum(1 for s in flat if s == 0) > 2000 and sum(1 for s in flat if s == 1) > 500
     assert sum(1 for s in flat if s == UNKNOWN_DOMAIN) > 20 and sum(1 for s in flat if s not in (0, 1, UNKNOWN_DOMAIN)) > 1000
+
+
+@pytest.mark.parametrize("keys", ["exact", "hashed"])
+def test_responses_built_on_the_device_are_the_bytes_the_host_assembly_builds(make_engine, keys, monkeypatch):
+    """rl_resp.hpp against round 4's host assembly from the counters' arrays (RLI_RESP_HOST=1, experiment builds): the same
+    batches through two engines, every response byte for byte.  The awkward cases on purpose: names with quotes and a name
+    long enough for X-RateLimit-Limit to need a two-byte length (and HeaderValue a two-byte length of its own), counters
+    with EQUAL remaining (the stable order of lib.rs:240 decides which one is reported), a limit without a name, max values
+    of 1 and 20 digits, requests that derive no counter (no headers at all), no domain, an unknown namespace."""
+    specs = [("shop", 10**6, 60, ["descriptors[0]['m'] == 'GET'"], [], 'say "hi"'),
+             ("shop", 10**6, 60, ["descriptors[0]['m'] != 'PUT'"], [], None),  # same remaining as the first: order decides
+             ("shop", 18446744073709551615, 3600, [], ["descriptors[0]['u']"], "x" * 150),
+             ("shop", 5, 1, ["descriptors[0]['m'] == 'GET'"], ["descriptors[0]['u']"], "tight"),
+             ("shop", 3, 10, [], ["descriptors[0]['a']", "descriptors[0]['u']"], ""),
+             ("solo", 1, 60, [], [], "one")]
+
+    def service():
+        eng = make_engine(capacity_cells=1 << 14, max_batch_hits=1 << 13)
+        g = Ingest(keys=keys, hash_key=(7, 9))
+        for ns, mx, secs, conds, variables, name in specs:
+            lid = g.add_limit(ns, mx, secs, conds, variables)
+            if name is not None:
+                g.set_limit_name(lid, name)
+        g.install(eng)
+        return eng, g
+
+    (eng_d, g_d), (eng_h, g_h) = service(), service()
+    rng = np.random.default_rng(31)
+    seen_long = seen_plain = 0
+    for batch in range(12):
+        msgs = []
+        for _ in range(int(rng.integers(200, 500))):
+            r = rng.random()
+            domain = None if r < 0.03 else ("nowhere" if r < 0.06 else ("solo" if r < 0.12 else "shop"))
+            entries = []
+            if rng.random() < 0.9:
+                entries.append(("m", ["GET", "POST", "PUT"][int(rng.integers(0, 3))]))
+            if rng.random() < 0.85:
+                entries.append(("u", f"u{int(rng.integers(0, 30))}"))
+            if rng.random() < 0.5:
+                entries.append(("a", f"a{int(rng.integers(0, 2))}"))
+            msgs.append(rls_request(domain, [entries], hits_addend=int(rng.integers(0, 3))))
+        now = NOW + batch * 700_000
+        monkeypatch.delenv("RLI_RESP_HOST", raising=False)
+        st_d, resp_d = g_d.serve_batch(eng_d, msgs, now, with_headers=True)
+        monkeypatch.setenv("RLI_RESP_HOST", "1")
+        st_h, resp_h = g_h.serve_batch(eng_h, msgs, now, with_headers=True)
+        assert st_d == st_h
+        for i, (a, b) in enumerate(zip(resp_d, resp_h)):
+            assert a == b, (batch, i, a, b)
+            seen_long += len(a) > 300
+            seen_plain += len(a) == 2
+    assert seen_long > 100 and seen_plain > 20
+    # a stride the long responses do not fit: they alone are told, the others are served (both assemblies)
+    monkeypatch.delenv("RLI_RESP_HOST", raising=False)
+    st, resp = g_d.serve_batch(eng_d, msgs, now + 1, with_headers=True, stride=128)
+    assert any(s == -102 for s in st) and any(s in (0, 1) and len(r) > 2 for s, r in zip(st, resp))
