@@ -970,10 +970,12 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         exp = reinterpret_cast<uint64_t*>(p);
         return RL_OK;
     };
-    // With headers the responses are built on the DEVICE (rl_*_serve_batch): what comes back is the bytes, not the counters.
-    // RLI_RESP_HOST=1 (experiment builds) keeps round 4's host assembly from the counters' arrays — the two are compared
-    // byte for byte by tests/test_gpu_rls_e2e.py.
-    const bool dev_resp = with_headers && RL_EXP_ENV("RLI_RESP_HOST") == nullptr;
+    // With headers, the responses of a LARGE batch are built on the DEVICE (rl_*_serve_batch): what comes back is the bytes,
+    // not the counters — 262 144 messages 5.9 -> 3.3 ms, 32 768 1.0 -> 0.8.  A small batch keeps the host assembly from the
+    // counters' arrays: the device form adds five launches, a round trip for the total and an event per copy, 0.05 ms of a
+    // 0.19 ms batch of 256.  RLI_RESP_HOST=1 / RLI_RESP_DEVICE=1 (experiment builds) force one or the other — the two are
+    // compared byte for byte by tests/test_gpu_rls_e2e.py.
+    const bool dev_resp = with_headers && !RL_EXP_ENV("RLI_RESP_HOST") && (RL_EXP_ENV("RLI_RESP_DEVICE") || n >= 4096u);
     const uint32_t* d_off = nullptr;  // device-built responses: request r's bytes are d_bytes[d_off[r] .. d_off[r + 1])
     const uint8_t* d_bytes = nullptr;
     if (dev_resp)
@@ -1015,14 +1017,19 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
             }
             w_off[n] = (uint32_t)total;
             parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
-                for (uint32_t i = lo; i < hi; ++i)
+                // (every message is an allocation of its own, cold in this thread's cache: asked for a few ahead, the
+                // copies overlap their misses instead of taking them one by one)
+                for (uint32_t i = lo; i < hi; ++i) {
+                    if (i + 8 < hi) __builtin_prefetch(msgs[i + 8], 0, 0);
                     if (!skip[i] && lens[i]) memcpy(w_bytes + w_off[i], msgs[i], lens[i]);
+                }
             });
             if (attempt == 0) lap("packed");
             uint32_t n_hits = 0;
             int64_t collided = -1;
             const int32_t rc =
-                dev_resp ? rl_wire_serve_batch(e, w_bytes, w_off, n, now_us, 1, verdict, dev_status, &d_off, &d_bytes, &collided)
+                dev_resp ? rl_wire_serve_batch(e, w_bytes, w_off, n, now_us, RL_SERVE_HEADERS | RL_SERVE_ASYNC, verdict, dev_status,
+                                               &d_off, &d_bytes, &collided)
                 : op == RL_OP_CHECK_AND_UPDATE
                     ? rl_wire_match_and_check_batch(e, w_bytes, w_off, n, now_us, with_headers ? 1 : 0, verdict, limited, dev_status,
                                                     with_headers ? req_off : nullptr, with_headers ? hits : nullptr, (uint32_t)cap,
@@ -1135,7 +1142,8 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
             uint32_t n_hits = 0;
             const int32_t rc =
                 dev_resp ? rl_match_serve_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
-                                                g->req_delta.data(), n_req, now_us, 1, verdict, &d_off, &d_bytes)
+                                                g->req_delta.data(), n_req, now_us, RL_SERVE_HEADERS | RL_SERVE_ASYNC, verdict,
+                                                &d_off, &d_bytes)
                 : op == RL_OP_CHECK_AND_UPDATE
                     ? rl_match_and_check_batch(e, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
                                                g->req_delta.data(), n_req, now_us, with_headers ? 1 : 0, verdict, limited,
@@ -1164,12 +1172,27 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         } while (v);
         o.append(buf + k, (size_t)(24 - k));
     };
+    std::atomic<int32_t> wait_rc{0};
     parallel_chunks(n, threads, [&](uint32_t lo, uint32_t hi) {
+        if (dev_resp && d_off) {
+            // The bytes may still be travelling (RL_SERVE_ASYNC: they arrive in order): this share starts once ITS last
+            // response is there — the shares in front of it are being handed on meanwhile.
+            uint32_t i = hi;
+            while (i > lo && req_of[i - 1] < 0) --i;
+            if (i > lo)
+                if (const int32_t wrc = rl_serve_wait(e, d_off[(uint32_t)req_of[i - 1] + 1])) wait_rc.store(wrc);
+        }
         // (strings that keep their capacity from one request to the next: no allocation per request)
         std::string o, hv, val;
         std::vector<uint32_t> order;
         static const std::string k_limit = "X-RateLimit-Limit", k_rem = "X-RateLimit-Remaining", k_reset = "X-RateLimit-Reset";
         for (uint32_t i = lo; i < hi; ++i) {
+            // (the caller's slots are out_stride apart — a fresh cache line and often a fresh page per response: the line
+            // of a slot a few ahead is asked for now, for writing, so that the stores do not wait for it one at a time)
+            if (i + 8 < hi) {
+                __builtin_prefetch(out + (size_t)(i + 8) * out_stride, 1, 0);
+                __builtin_prefetch(out + (size_t)(i + 8) * out_stride + 64, 1, 0);
+            }
             if (dev_resp && d_off) {
                 // the bytes exist already (rl_resp.hpp): request r's response goes to the caller's slot i
                 if (status[i] != 0 && status[i] != RLI_UNKNOWN_DOMAIN) continue;  // malformed / RLI_HOST_ONLY: no response
@@ -1251,6 +1274,11 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         }
     });
     lap("responses");
+    if (dev_resp && d_off) {
+        // (every byte has been waited for before the engine is called again — also the ones behind the last answered request)
+        if (const int32_t wrc = rl_serve_wait(e, d_off[n_req])) wait_rc.store(wrc);
+        if (wait_rc.load()) return gfail(g, wait_rc.load(), "rl_serve_wait: the responses' copy failed");
+    }
     if (too_long.load())  // (not an error of the call: the message names the size a retry needs)
         (void)gfail(g, RL_OK, "a response of %u bytes does not fit the stride %u: status RLI_RESPONSE_TOO_LARGE for it", too_long.load(), out_stride);
     return RL_OK;

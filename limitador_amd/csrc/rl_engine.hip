@@ -285,10 +285,17 @@ struct rl_engine {
     uint8_t* d_resp_blob = nullptr;
     WireStr* d_resp_frag = nullptr;
     u32 n_resp_frag = 0;
+    u32 resp_blob_len = 0;
     bool resp_ready = false;
     u32* d_resp_off = nullptr;      // [max_batch + 2]
     uint8_t* d_resp_bytes = nullptr;
     u64 resp_bytes_cap = 0;
+    // RL_SERVE_ASYNC: the responses travel to the host in up to RESP_CHUNKS copies, an event behind each; rl_serve_wait(upto)
+    // waits for the one that covers byte upto - 1 (the caller scatters the first responses while the last ones still travel)
+    static constexpr u32 RESP_CHUNKS = 8;
+    hipEvent_t resp_ev[RESP_CHUNKS] = {};
+    u64 resp_chunk = 0;             // bytes per copy of the last serving call (0: it was synchronous)
+    u32 resp_n_chunks = 0;
     u32* d_w_off = nullptr;         // [max_batch + 1]
     int32_t* d_w_status = nullptr;  // [max_batch]
     uint4* d_w_slot_h = nullptr;    // [max_batch][MATCH_SLOTS]: hashes of the values the variables read
@@ -2018,6 +2025,8 @@ void rl_engine_destroy(rl_engine* e) {
     if (e->h_m_word) (void)hipHostFree(e->h_m_word);
     for (void* hs : e->h_stage)
         if (hs) (void)hipHostFree(hs);
+    for (hipEvent_t ev : e->resp_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->h_serve) (void)hipHostFree(e->h_serve);
     if (e->h_gen_word) (void)hipHostFree(e->h_gen_word);
     if (e->d_m_scan1) (void)hipFree(e->d_m_scan1);
@@ -3012,6 +3021,7 @@ static int32_t matched_op_locked(rl_engine* e, int op, u32 n_hits, u32 n_req, u6
 // Where a serving call (rl_match_serve_batch / rl_wire_serve_batch) wants its answer: host pointers.
 struct ServeOut {
     int32_t with_headers;
+    bool async;                 // RL_SERVE_ASYNC: return with the response bytes still travelling (rl_serve_wait)
     const uint32_t** resp_off;  // -> [n + 1], in the engine's pinned staging (slot 2)
     const uint8_t** resp;       // -> the bytes, in the engine's pinned staging (slot 3)
 };
@@ -3026,6 +3036,7 @@ static int32_t responses_locked(rl_engine* e, u32 n, const int32_t* d_status, co
         return fail(e, RL_ERR_NOMEM, "hipMalloc of the responses' offsets failed");
     RespArgs R{};
     R.blob = e->d_resp_blob;
+    R.blob_len = e->resp_blob_len;
     R.frag = e->d_resp_frag;
     R.n_frag = e->n_resp_frag;
     R.limits = e->d_limits;
@@ -3071,7 +3082,23 @@ static int32_t responses_locked(rl_engine* e, u32 n, const int32_t* d_status, co
     }
     k_resp<true><<<cdiv(n + 1, 256), 256, 0, e->stream>>>(R, nullptr, e->d_resp_off, e->d_resp_bytes);
     HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipMemcpyAsync(h_bytes, e->d_resp_bytes, total, hipMemcpyDeviceToHost, e->stream));
+    e->resp_chunk = 0;
+    e->resp_n_chunks = 0;
+    if (!so.async) {
+        HIP_TRY(e, hipMemcpyAsync(h_bytes, e->d_resp_bytes, total, hipMemcpyDeviceToHost, e->stream));
+        return RL_OK;
+    }
+    u64 chunk = (total + rl_engine::RESP_CHUNKS - 1) / rl_engine::RESP_CHUNKS;
+    chunk = std::max<u64>((chunk + 65535ull) & ~65535ull, 2ull << 20);  // (a copy command costs ~11 us: at least 2 MB each)
+    u32 nc = 0;
+    for (u64 at = 0; at < total; at += chunk, ++nc) {
+        if (!e->resp_ev[nc]) HIP_TRY(e, hipEventCreateWithFlags(&e->resp_ev[nc], hipEventDisableTiming));
+        HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t*>(h_bytes) + at, e->d_resp_bytes + at, std::min(chunk, total - at),
+                                  hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipEventRecord(e->resp_ev[nc], e->stream));
+    }
+    e->resp_chunk = chunk;
+    e->resp_n_chunks = nc;
     return RL_OK;
 }
 
@@ -3212,9 +3239,9 @@ static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, co
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n_req, hipMemcpyDeviceToHost, e->stream));
     if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
-        rc = responses_locked(e, n_req, nullptr, e->d_verdict, *so);
+        rc = responses_locked(e, n_req, nullptr, e->d_verdict, *so);  // (synchronises behind the verdicts' copy)
         if (rc) return rc;
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (!e->resp_n_chunks) HIP_TRY(e, hipStreamSynchronize(e->stream));
         return RL_OK;
     }
     if (limited_limit)
@@ -3394,9 +3421,9 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
     if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
-        rc = responses_locked(e, n, e->d_w_status, e->d_verdict, *so);
+        rc = responses_locked(e, n, e->d_w_status, e->d_verdict, *so);  // (synchronises behind the verdicts' / statuses' copies)
         if (rc) return rc;
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (!e->resp_n_chunks) HIP_TRY(e, hipStreamSynchronize(e->stream));
         return RL_OK;
     }
     if (limited_limit) HIP_TRY(e, hipMemcpyAsync(limited_limit, e->d_m_limited, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
@@ -3432,30 +3459,42 @@ int32_t rl_resp_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     e->d_resp_blob = nullptr;
     e->d_resp_frag = nullptr;
     e->resp_ready = false;
-    if (hipMalloc((void**)&e->d_resp_blob, blob_len ? blob_len : 16) != hipSuccess ||
+    if (hipMalloc((void**)&e->d_resp_blob, ((size_t)blob_len + 31) & ~(size_t)15) != hipSuccess ||
         hipMalloc((void**)&e->d_resp_frag, (n_limits ? n_limits : 1) * sizeof(WireStr)) != hipSuccess)
         return fail(e, RL_ERR_NOMEM, "hipMalloc of the response fragments failed");
     if (blob_len) HIP_TRY(e, hipMemcpy(e->d_resp_blob, blob, blob_len, hipMemcpyHostToDevice));
     if (n_limits) HIP_TRY(e, hipMemcpy(e->d_resp_frag, frag, (size_t)n_limits * sizeof(WireStr), hipMemcpyHostToDevice));
     e->n_resp_frag = n_limits;
+    e->resp_blob_len = blob_len;
     e->resp_ready = true;
     return RL_OK;
 } RL_ABI_CATCH
 
 int32_t rl_match_serve_batch(rl_engine* e, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
                              const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
-                             int32_t with_headers, uint8_t* verdict, const uint32_t** resp_off, const uint8_t** resp) try {
-    const ServeOut so{with_headers, resp_off, resp};
+                             uint32_t flags, uint8_t* verdict, const uint32_t** resp_off, const uint8_t** resp) try {
+    const int32_t with_headers = (flags & RL_SERVE_HEADERS) ? 1 : 0;
+    const ServeOut so{with_headers, (flags & RL_SERVE_ASYNC) != 0, resp_off, resp};
     return match_batch_host(e, RL_OP_CHECK_AND_UPDATE, req_ns, ent_off, ent_key, ent_val, req_delta, n_req, now_us, with_headers,
                             verdict, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, &so);
 } RL_ABI_CATCH
 
 int32_t rl_wire_serve_batch(rl_engine* e, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,
-                            int32_t with_headers, uint8_t* verdict, int32_t* status, const uint32_t** resp_off,
+                            uint32_t flags, uint8_t* verdict, int32_t* status, const uint32_t** resp_off,
                             const uint8_t** resp, int64_t* collided_message) try {
-    const ServeOut so{with_headers, resp_off, resp};
+    const int32_t with_headers = (flags & RL_SERVE_HEADERS) ? 1 : 0;
+    const ServeOut so{with_headers, (flags & RL_SERVE_ASYNC) != 0, resp_off, resp};
     return wire_match_host(e, RL_OP_CHECK_AND_UPDATE, wire, msg_off, n, now_us, with_headers, verdict, nullptr, status, nullptr,
                            nullptr, 0u, nullptr, nullptr, nullptr, collided_message, &so);
+} RL_ABI_CATCH
+
+// (no engine lock: called by the host layer's scatter threads side by side, between a serving call and the next call on
+// the engine; the events and the chunk size were written by that serving call)
+int32_t rl_serve_wait(rl_engine* e, uint64_t upto) try {
+    if (!e) return RL_ERR_INVALID;
+    if (!upto || !e->resp_n_chunks) return RL_OK;
+    const u64 c = std::min<u64>((upto - 1) / e->resp_chunk, e->resp_n_chunks - 1);
+    return hipEventSynchronize(e->resp_ev[c]) == hipSuccess ? (int32_t)RL_OK : (int32_t)RL_ERR_DEVICE;
 } RL_ABI_CATCH
 
 int32_t rl_wire_match_batch_op(rl_engine* e, int32_t op, const uint8_t* wire, const uint32_t* msg_off, uint32_t n, uint64_t now_us,

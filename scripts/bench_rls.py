@@ -4,7 +4,7 @@ RateLimitRequests + limit matching + check_and_update on the device + the serial
 batch of N requests (4 namespaces x 8 limits, Zipf users).  A request that waits for a batch of N pays at most
 max_delay (the batcher's budget) + this.  Prints one JSON line: per N the p50 / p99 of the call and requests/s,
 without and with the draft-03 headers (load_counters).
-usage: python scripts/bench_rls.py [exact|hashed]   exact: host dictionaries + packed ids; hashed: the messages decoded on
+usage: python scripts/bench_rls.py [exact|hashed] [sizes, comma-separated]   exact: host dictionaries + packed ids; hashed: the messages decoded on
 the device, counters keyed by a hash of their canonical key bytes (rli_set_key_mode, rl_wire.hpp)."""
 import json
 import os
@@ -46,7 +46,8 @@ def messages(n):
 
 now = 1_700_000_000_000_000
 out = {"what": "rli_serve_batch: wire bytes -> verdicts + RateLimitResponse bytes", "keys": KEYS, "sizes": {}}
-for n in (1, 16, 256, 4096, 32768, 262144):
+SIZES = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 16, 256, 4096, 32768, 262144)
+for n in SIZES:
     prep = g.prepare_batch(messages(n))  # (the ctypes marshalling of the Python harness is not what is measured)
     row = {}
     for hdr in (False, True):

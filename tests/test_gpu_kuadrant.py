@@ -207,7 +207,7 @@ def test_the_three_methods_through_one_micro_batcher(make_engine):
     batches, requests = fe.stats()
     fe.close()
     assert not bad, bad[:5]
-    rows = eng.get_counters(0, NOW)
+    rows = eng.get_counters(0 | 0x80000000, NOW)  # (a limit without variables: RL_SIMPLE)
     assert rows.shape[0] == 1 and int(rows["value"][0]) == sum(reported) + sum(admitted)
     # checks raced reports (that is the method's nature: is_rate_limited does not reserve), so the limit may be overshot by
     # the reports in flight, never by ShouldRateLimit; every check that saw value + 1 > 600 said OVER_LIMIT

@@ -527,7 +527,7 @@ def test_responses_built_on_the_device_are_the_bytes_the_host_assembly_builds(ma
              ("solo", 1, 60, [], [], "one")]
 
     def service():
-        eng = make_engine(capacity_cells=1 << 14, max_batch_hits=1 << 13)
+        eng = make_engine(capacity_cells=1 << 16, max_batch_hits=1 << 16)
         g = Ingest(keys=keys, hash_key=(7, 9))
         for ns, mx, secs, conds, variables, name in specs:
             lid = g.add_limit(ns, mx, secs, conds, variables)
@@ -541,7 +541,8 @@ def test_responses_built_on_the_device_are_the_bytes_the_host_assembly_builds(ma
     seen_long = seen_plain = 0
     for batch in range(12):
         msgs = []
-        for _ in range(int(rng.integers(200, 500))):
+        for _ in range(int(rng.integers(200, 500)) if batch != 7 else 9000):  # (one batch above the size from which the
+                                                                              # device form is the default)
             r = rng.random()
             domain = None if r < 0.03 else ("nowhere" if r < 0.06 else ("solo" if r < 0.12 else "shop"))
             entries = []
@@ -554,7 +555,10 @@ def test_responses_built_on_the_device_are_the_bytes_the_host_assembly_builds(ma
             msgs.append(rls_request(domain, [entries], hits_addend=int(rng.integers(0, 3))))
         now = NOW + batch * 700_000
         monkeypatch.delenv("RLI_RESP_HOST", raising=False)
+        if batch != 7:
+            monkeypatch.setenv("RLI_RESP_DEVICE", "1")
         st_d, resp_d = g_d.serve_batch(eng_d, msgs, now, with_headers=True)
+        monkeypatch.delenv("RLI_RESP_DEVICE", raising=False)
         monkeypatch.setenv("RLI_RESP_HOST", "1")
         st_h, resp_h = g_h.serve_batch(eng_h, msgs, now, with_headers=True)
         assert st_d == st_h
@@ -565,5 +569,6 @@ def test_responses_built_on_the_device_are_the_bytes_the_host_assembly_builds(ma
     assert seen_long > 100 and seen_plain > 20
     # a stride the long responses do not fit: they alone are told, the others are served (both assemblies)
     monkeypatch.delenv("RLI_RESP_HOST", raising=False)
+    monkeypatch.setenv("RLI_RESP_DEVICE", "1")
     st, resp = g_d.serve_batch(eng_d, msgs, now + 1, with_headers=True, stride=128)
     assert any(s == -102 for s in st) and any(s in (0, 1) and len(r) > 2 for s, r in zip(st, resp))
