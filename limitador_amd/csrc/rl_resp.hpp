@@ -116,31 +116,46 @@ __device__ __forceinline__ void resp_frag(const RespArgs& A, RespOut<WRITE>& o, 
 // of 256 lanes to 256 different lines were 39 M memory transactions for 262 144 responses (405 us, 96 G/s: the chip's
 // transaction rate, not its bandwidth).  The 256 responses of a workgroup are one contiguous range of the output, so the
 // lanes build them in LDS — laid out with the range's misalignment, so that LDS word k is global word k — and the
-// workgroup copies the range out as aligned dwords, coalesced.  A range that does not fit (RESP_LDS bytes: names of
+// workgroup copies the range out as aligned 16-byte words, coalesced.  A range that does not fit (RESP_LDS bytes: names of
 // hundreds of bytes on most counters) is written directly, as before.  The limits' fragments — most of a response's bytes,
 // read by every lane at its own address — are copied into LDS first when they fit (RESP_BLOB_LDS): with LDS staging alone the
 // kernel was still 359 us, a chain of one global byte load per byte per lane.
 constexpr u32 RESP_LDS = 44u * 1024u;
 constexpr u32 RESP_BLOB_LDS = 16u * 1024u;
 
+// `out` may be host memory the device can write (the engine's pinned staging): the copy-out below is then the transfer
+// itself — 16-byte stores, coalesced, what a copy kernel would issue — and the responses need no device buffer and no copy
+// command.  block0: the launch covers the workgroups [block0, block0 + gridDim.x) (the engine launches the kernel in a few
+// pieces with an event behind each, so that the host can hand on the first responses while the last ones are written).
 template <bool WRITE>
-__global__ __launch_bounds__(256) void k_resp(RespArgs A, u32* __restrict__ len, const u32* __restrict__ off, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_resp(RespArgs A, u32* __restrict__ len, const u32* __restrict__ off, uint8_t* __restrict__ out,
+                                              u32 block0, u32 n_blocks) {
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[WRITE ? RESP_LDS : 16u];
     __shared__ __attribute__((aligned(16))) uint8_t s_blob[WRITE ? RESP_BLOB_LDS : 16u];
-    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    // (WRITE: the launch's workgroups share the blocks [block0, block0 + n_blocks) round-robin — with host memory as `out`
+    // the NUMBER of workgroups writing at once is the engine's choice, not the batch's size: see responses_locked)
+    const uint8_t* const blob_global = A.blob;
+    for (u32 block = block0 + blockIdx.x; block < block0 + n_blocks; block += gridDim.x) {
+    if (WRITE && block != block0 + blockIdx.x) {
+        __syncthreads();  // (s_buf is reused)
+        A.blob = blob_global;
+    }
+    const u32 r = block * 256 + threadIdx.x;
     u32 g0 = 0, g_len = 0, mis = 0;
     bool staged = false;
     if (WRITE) {  // (block-uniform)
-        const u32 r0 = blockIdx.x * 256u, r1 = r0 + 256u < A.n ? r0 + 256u : A.n;
-        if (r0 >= A.n) return;
+        const u32 r0 = block * 256u, r1 = r0 + 256u < A.n ? r0 + 256u : A.n;
+        if (r0 >= A.n) return;  // (past the last request: so is every later block of this workgroup)
         g0 = off[r0];
         g_len = off[r1] - g0;
-        mis = (u32)((reinterpret_cast<unsigned long long>(out) + g0) & 3ull);
+        mis = (u32)((reinterpret_cast<unsigned long long>(out) + g0) & 15ull);
         staged = g_len + mis <= RESP_LDS;
         if (A.with_headers && A.blob_len <= RESP_BLOB_LDS) {
-            for (u32 k = threadIdx.x * 4u; k < A.blob_len; k += 1024u)  // (the blob is allocated in multiples of 16 bytes)
-                *reinterpret_cast<u32*>(s_blob + k) = *reinterpret_cast<const u32*>(A.blob + k);
-            __syncthreads();
+            if (block == block0 + blockIdx.x) {
+                for (u32 k = threadIdx.x * 4u; k < A.blob_len; k += 1024u)  // (the blob is allocated in multiples of 16 bytes)
+                    *reinterpret_cast<u32*>(s_blob + k) = *reinterpret_cast<const u32*>(blob_global + k);
+                __syncthreads();
+            }
             A.blob = s_blob;
         }
     }
@@ -199,19 +214,20 @@ __global__ __launch_bounds__(256) void k_resp(RespArgs A, u32* __restrict__ len,
         if (r < A.n) len[r] = o.n;
         return;
     }
-    if (!staged) return;
+    if (!staged) continue;
     __syncthreads();
-    // LDS [mis, mis + g_len) -> global [g0, g0 + g_len): aligned dwords in the middle, bytes at the two ragged ends
-    uint8_t* const gbase = out + g0 - mis;  // 4-byte aligned
-    const u32 end = mis + g_len, n_words = (end + 3u) >> 2;
+    // LDS [mis, mis + g_len) -> out [g0, g0 + g_len): aligned 16-byte words in the middle, bytes at the two ragged ends
+    uint8_t* const gbase = out + g0 - mis;  // 16-byte aligned
+    const u32 end = mis + g_len, n_words = (end + 15u) >> 4;
     for (u32 w = threadIdx.x; w < n_words; w += 256u) {
-        const u32 b = w << 2;
-        if (b >= mis && b + 4u <= end) {
-            *reinterpret_cast<u32*>(gbase + b) = *reinterpret_cast<const u32*>(s_buf + b);
+        const u32 b = w << 4;
+        if (b >= mis && b + 16u <= end) {
+            *reinterpret_cast<uint4*>(gbase + b) = *reinterpret_cast<const uint4*>(s_buf + b);
         } else {
-            for (u32 k = b < mis ? mis : b; k < b + 4u && k < end; ++k) gbase[k] = s_buf[k];
+            for (u32 k = b < mis ? mis : b; k < b + 16u && k < end; ++k) gbase[k] = s_buf[k];
         }
     }
+    }  // blocks of this workgroup
 }
 
 }  // namespace rl

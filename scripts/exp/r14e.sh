@@ -16,6 +16,15 @@ except Exception as ex: print(sys.argv[2], "FAILED", ex)
 PY
 done
 RLI_TRACE=1 timeout 300 python scripts/bench_rls.py hashed 262144 2>&1 >/dev/null | grep rli | tail -n 3
+for k in hashed exact; do RL_RESP_DIRECT=0 timeout 300 python scripts/bench_rls.py $k 32768,262144 > "$out/rls_${k}_copy.json" 2>/dev/null; python - "$out/rls_${k}_copy.json" "$k RL_RESP_DIRECT=0" <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1]))
+    for n in ("32768","262144"):
+        r=d["sizes"][n]; print(sys.argv[2], n, "codes %.3f ms"%r["codes_only"]["p50_ms"], "headers %.3f ms"%r["with_headers"]["p50_ms"])
+except Exception as ex: print(sys.argv[2], "FAILED", ex)
+PY
+done
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$out/tr" -o t -- python $OLDPWD/scripts/bench_rls.py hashed 262144 > /dev/null 2> "$out/tr.err"
 cd "$OLDPWD"
