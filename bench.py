@@ -488,12 +488,17 @@ def secondary(args, eng, dev, gen):
             r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "bench_rls.py"), keys],
                                capture_output=True, text=True, timeout=240)
             m = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            wp[keys] = {n: {"codes_only_ms": v["codes_only"]["p50_ms"], "with_headers_ms": v["with_headers"]["p50_ms"],
-                            "requests_per_s": v["codes_only"]["requests_per_s"]}
+            wp[keys] = {n: dict({"codes_only_ms": v["codes_only"]["p50_ms"], "with_headers_ms": v["with_headers"]["p50_ms"],
+                                 "requests_per_s": v["codes_only"]["requests_per_s"]},
+                                **({"kuadrant_check_ms": v["kuadrant_check"]["p50_ms"], "kuadrant_report_ms": v["kuadrant_report"]["p50_ms"]}
+                                   if "kuadrant_check" in v else {}))
                         for n, v in m["sizes"].items() if n in ("256", "32768", "262144")}
         out["wire_path_rli_serve_batch"] = dict(wp, note="p50 of the C call per batch of N serialized messages (4 namespaces x 8 limits, "
                                                 "Zipf users); exact = host dictionaries + packed ids, hashed = RLI_KEYS_HASHED "
-                                                "(messages decoded on the device, keys = hash of the canonical key bytes)")
+                                                "(messages decoded on the device, keys = hash of the canonical key bytes); with "
+                                                "headers the response bytes are built on the device from 4096 messages on "
+                                                "(rl_resp.hpp); kuadrant_check / kuadrant_report = rli_serve_batch_op, the Kuadrant "
+                                                "service's CheckRateLimit (is_rate_limited, read-only) and Report (update_counters)")
     except Exception as ex:
         out["wire_path_rli_serve_batch"] = {"error": str(ex)[:200]}
     # -- the streaming maintenance kernels over the headline's table (LAST: they change it): a sweep that finds nothing

@@ -204,6 +204,11 @@ class Ingest:
         self._check(SYMBOLS["rli_serve_batch"](self._h, engine._h, prep["msgs"], prep["lens"], prep["n"], int(now_us),
                                                int(bool(with_headers)), prep["out"], prep["stride"], prep["out_len"], prep["status"]))
 
+    def serve_prepared_op(self, engine, prep, op, now_us):
+        """rli_serve_batch_op on a prepared batch (OP_CHECK / OP_UPDATE / OP_CHECK_AND_UPDATE; no headers)."""
+        self._check(SYMBOLS["rli_serve_batch_op"](self._h, engine._h, int(op), prep["msgs"], prep["lens"], prep["n"], int(now_us),
+                                                  prep["out"], prep["stride"], prep["out_len"], prep["status"]))
+
     def compile(self):
         self._check(SYMBOLS["rli_compile"](self._h))
         n, nc = SYMBOLS["rli_n_limits"](self._h), SYMBOLS["rli_n_conds"](self._h)

@@ -61,6 +61,16 @@ for n in SIZES:
         ts = np.array(ts)
         row["with_headers" if hdr else "codes_only"] = {"p50_ms": float(np.percentile(ts, 50) * 1e3), "p99_ms": float(np.percentile(ts, 99) * 1e3),
                                                        "requests_per_s": n / float(np.percentile(ts, 50))}
+    if n >= 32768:  # the Kuadrant service's two methods on the same messages (rli_serve_batch_op: no headers)
+        for name, op in (("kuadrant_check", 1), ("kuadrant_report", 2)):
+            g.serve_prepared_op(eng, prep, op, now)
+            ts = []
+            for _ in range(10):
+                now += 1000
+                t0 = time.perf_counter()
+                g.serve_prepared_op(eng, prep, op, now)
+                ts.append(time.perf_counter() - t0)
+            row[name] = {"p50_ms": float(np.percentile(ts, 50) * 1e3), "requests_per_s": n / float(np.percentile(ts, 50))}
     out["sizes"][str(n)] = row
 out["host_threads"] = os.environ.get("RLI_THREADS", "auto: one per 1024 messages, at most 32")
 print(json.dumps(out))
