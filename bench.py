@@ -382,7 +382,8 @@ def secondary(args, eng, dev, gen):
         for n in (16, 64, 256, 1024, 4096, 16384, 65536, 262144):
             hx = [W.zipf_batch(nk, n, rng_x, cdf_x) for _ in range(4)]
             reps = max(4, min(200, 400_000 // n))
-            ex_.check_and_update(hx[0], t_now, want_first_limited=False)
+            for _ in range(20):  # (the first size used to carry the engine's first tiny launches: 219 us per 16-hit call)
+                ex_.check_and_update(hx[0], t_now, want_first_limited=False)
             t0 = time.perf_counter()
             for i in range(reps):
                 ex_.check_and_update(hx[i & 3], t_now + 1 + i, want_first_limited=False)
