@@ -248,6 +248,7 @@ struct rl_engine {
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
+    u32 gen_rounds_hint = 3; // fixpoint rounds the last general pass ran + 1: the length of the next pass's first blind group
     u32 gen_tiny_max = 64;   // general form: calls of up to this many hits take k_gen_tiny (RL_GEN_TINY_MAX=0 disables)
     u32 gen_seq = 0;
     bool h_tiny_coherent = false;  // h_status / h_tiny are fine-grained (hipHostMallocCoherent): device stores reach the host in order
@@ -1246,6 +1247,7 @@ int run_check_k1(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t* d_ver
 }
 
 // ---- the general form (rl_general.hpp): multi-counter requests, load_counters, u64 deltas, update_counter ----
+constexpr u32 GEN_ROUNDS_FIRST_MAX = 12;    // longest first group the hint may ask for (GenStatus::changed has room for 30)
 constexpr u32 GEN_ROUNDS_ENQ = 3;           // fixpoint rounds enqueued blind before the first look at the status block (enough when
                                             // the second round's admitted set is already the fixpoint: the usual large batch) ...
 constexpr u32 GEN_ROUNDS_ENQ_MORE = 6;      // ... and between two looks after that (long chains of dependent requests)
@@ -1433,8 +1435,14 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         e->gen_clean = true;
         return RL_OK;
     };
+    u32 rounds_total = 0;  // rounds of this pass that really ran (a converged round returns at once and does not count)
     for (;;) {
-        const u32 n_enq = c.update_mode ? 1u : (round == 0 ? GEN_ROUNDS_ENQ : GEN_ROUNDS_ENQ_MORE);
+        // The first group is as long as the pass BEFORE needed (+ the round that sees the fixpoint): traffic whose requests
+        // depend on each other four deep needed a second group every call — a host round trip (40 us) and five rounds that
+        // returned at once (18 us each) per 262 144-message batch of the wire path.  A blind round too many costs 18 us, a
+        // group too short 40 + what the next group over-enqueues: the hint follows the last pass, never below GEN_ROUNDS_ENQ.
+        const u32 first = std::min(std::max(e->gen_rounds_hint, GEN_ROUNDS_ENQ), std::min<u32>(GEN_ROUNDS_FIRST_MAX, n_req + 2u));
+        const u32 n_enq = c.update_mode ? 1u : (round == 0 ? first : GEN_ROUNDS_ENQ_MORE);
         for (u32 q = 0; q < n_enq; ++q, ++round) {
             // changed[] slots of one group: round q's k_gen_admit checks slot q (did the round before still change
             // the admitted set?) and writes slot q + 1, which is what the round's own kernels check.  Round 0 has
@@ -1488,6 +1496,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         HIP_TRY(e, hipStreamSynchronize(st));
         }
         e->stats.probe_steps += h_gst.rounds_run;
+        rounds_total += h_gst.rounds_run;
         // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
         if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
         else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
@@ -1538,6 +1547,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
                     h_gst.n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
     }
     e->live += h_gst.n_inserted;  // (== n_new when k_gen_count ran)
+    if (!c.update_mode) e->gen_rounds_hint = rounds_total + 1u;
     e->part_seq++;
     if (e->gen_post) e->gen_clean = true;  // (k_gen_post zeroed the status block and the scratch blocks behind the commit)
     else if ((rc = cleanup()) != RL_OK) return rc;
