@@ -299,6 +299,9 @@ struct rl_engine {
     u32 resp_n_chunks = 0;                 // ends at this byte of the responses (0 pieces: the call was synchronous)
     u32 resp_pieces = 8;            // RL_RESP_PIECES
     u32 resp_writers = 128;         // RL_RESP_WRITERS: workgroups of k_resp<true> that write host memory at once
+    bool resp_blind = true;         // RL_RESP_BLIND=0: the host reads the responses' total before their kernels go out
+    u32 resp_max_frag = 0;          // longest fragment of rl_resp_table_set
+    hipEvent_t resp_off_ev = nullptr;
     bool resp_direct = true;        // RL_RESP_DIRECT=0: k_resp writes a device buffer and copy commands carry it to the host
     u32* d_w_off = nullptr;         // [max_batch + 1]
     int32_t* d_w_status = nullptr;  // [max_batch]
@@ -1796,6 +1799,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_PART_COMPACT")) e->part_compact = std::min(std::max(atoi(v), 0), 2);
     if (const char* v = RL_EXP_ENV("RL_DEFER2")) e->defer2 = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_DIRECT")) e->resp_direct = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_WRITERS")) e->resp_writers = (u32)std::max(1, atoi(v));
     if (const char* v = RL_EXP_ENV("RL_RESP_PIECES")) e->resp_pieces = std::min<u32>(rl_engine::RESP_CHUNKS, std::max(1, atoi(v)));
     if (const char* v = RL_EXP_ENV("RL_TIMING_LAZY")) e->timing_lazy = atoi(v) != 0;
@@ -2043,6 +2047,7 @@ void rl_engine_destroy(rl_engine* e) {
         if (hs) (void)hipHostFree(hs);
     for (hipEvent_t ev : e->resp_ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->resp_off_ev) (void)hipEventDestroy(e->resp_off_ev);
     if (e->h_serve) (void)hipHostFree(e->h_serve);
     if (e->h_gen_word) (void)hipHostFree(e->h_gen_word);
     if (e->d_m_scan1) (void)hipFree(e->d_m_scan1);
@@ -3046,7 +3051,7 @@ static int32_t host_staging_locked(rl_engine* e, uint32_t slot, uint64_t bytes, 
 // The serialized RateLimitResponse of every request of the batch the resolver just decided (rl_resp.hpp): lengths ->
 // exclusive scan -> bytes, then the offsets and the bytes to the host.  d_status: per request, null = every request is
 // answered.  The caller synchronises the stream.
-static int32_t responses_locked(rl_engine* e, u32 n, const int32_t* d_status, const uint8_t* d_verdict, const ServeOut& so) {
+static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* d_status, const uint8_t* d_verdict, const ServeOut& so) {
     if (so.with_headers && !e->resp_ready) return fail(e, RL_ERR_INVALID, "rl_resp_table_set was not called for the installed limits");
     if (!e->d_resp_off && hipMalloc((void**)&e->d_resp_off, ((size_t)e->max_batch + 2) * sizeof(u32)) != hipSuccess)
         return fail(e, RL_ERR_NOMEM, "hipMalloc of the responses' offsets failed");
@@ -3078,6 +3083,43 @@ static int32_t responses_locked(rl_engine* e, u32 n, const int32_t* d_status, co
     void* h_off = nullptr;
     int32_t rc = host_staging_locked(e, 2, ((u64)n + 1) * sizeof(u32), &h_off);
     if (rc) return rc;
+    e->resp_n_chunks = 0;
+    const u32 n_blocks = cdiv(n, 256);
+    // What the responses can take at most: 2 bytes of overall_code; with headers 157 more of tags, lengths, keys and three
+    // numbers of up to 20 digits, + per derived counter its limit's fragment (rl_resp.hpp).  When the pinned staging holds
+    // that much, the bytes' kernels go out BEHIND the offsets' copy without the host having seen the total: the round trip
+    // in the middle of the phase (a synchronise, the total, then the launches: ~40 us of idle stream) is gone; the host
+    // waits for the offsets while the responses are being written.
+    const u64 bound = so.with_headers ? (u64)n * 160u + (u64)n_hits * std::max<u32>(e->resp_max_frag, 7u) : (u64)n * 2u;
+    if (e->resp_direct && so.async && e->resp_blind && bound <= (1ull << 30)) {
+        void* h_bytes = nullptr;
+        rc = host_staging_locked(e, 3, bound ? bound : 1, &h_bytes);  // (grows — and synchronises — only until the largest batch has been seen)
+        if (rc) return rc;
+        HIP_TRY(e, hipMemcpyAsync(h_off, e->d_resp_off, ((size_t)n + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+        if (!e->resp_off_ev) HIP_TRY(e, hipEventCreateWithFlags(&e->resp_off_ev, hipEventDisableTiming));
+        HIP_TRY(e, hipEventRecord(e->resp_off_ev, e->stream));
+        R.out_cap = e->h_stage_cap[3];
+        const u32 pieces = std::min<u32>(e->resp_pieces, std::max<u32>(1u, (u32)(bound >> 22)));  // (the bound is ~2 x the bytes)
+        const u32 per = cdiv(n_blocks, pieces);
+        u32 nc = 0, b_end[rl_engine::RESP_CHUNKS];
+        for (u32 b0 = 0; b0 < n_blocks; b0 += per, ++nc) {
+            const u32 nb = std::min(per, n_blocks - b0);
+            k_resp<true><<<std::min(nb, e->resp_writers), 256, 0, e->stream>>>(R, nullptr, e->d_resp_off, static_cast<uint8_t*>(h_bytes), b0, nb);
+            if (!e->resp_ev[nc]) HIP_TRY(e, hipEventCreateWithFlags(&e->resp_ev[nc], hipEventDisableTiming));
+            HIP_TRY(e, hipEventRecord(e->resp_ev[nc], e->stream));
+            b_end[nc] = b0 + nb;
+        }
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipEventSynchronize(e->resp_off_ev));
+        const u32* off = static_cast<const u32*>(h_off);
+        for (u32 c = 0; c < nc; ++c) e->resp_chunk_end[c] = off[std::min<u64>((u64)b_end[c] * 256u, n)];
+        e->resp_n_chunks = nc;
+        *so.resp_off = off;
+        *so.resp = static_cast<const uint8_t*>(h_bytes);
+        if (off[n] > e->h_stage_cap[3])  // (cannot happen while the bound above is one; the kernel wrote nothing beyond the buffer)
+            return fail(e, RL_ERR_INTERNAL, "the responses take %u bytes, the bound said %llu (the batch was applied)", off[n], (unsigned long long)bound);
+        return RL_OK;
+    }
     HIP_TRY(e, hipMemcpyAsync(h_off, e->d_resp_off, ((size_t)n + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     const u64 total = static_cast<const u32*>(h_off)[n];
@@ -3087,8 +3129,7 @@ static int32_t responses_locked(rl_engine* e, u32 n, const int32_t* d_status, co
     *so.resp_off = static_cast<const u32*>(h_off);
     *so.resp = static_cast<const uint8_t*>(h_bytes);
     if (!total) return RL_OK;
-    e->resp_n_chunks = 0;
-    const u32 n_blocks = cdiv(n, 256);
+    R.out_cap = ~0ull;
     if (e->resp_direct) {
         // k_resp writes the responses INTO the host's pinned staging: its coalesced copy-out is the transfer (no device
         // buffer, no copy command — those were 0.23 ms of kernel and then 1.05 ms of copies for 262 144 responses).  With
@@ -3276,7 +3317,7 @@ static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, co
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n_req, hipMemcpyDeviceToHost, e->stream));
     if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
-        rc = responses_locked(e, n_req, nullptr, e->d_verdict, *so);  // (synchronises behind the verdicts' copy)
+        rc = responses_locked(e, n_req, n_hits, nullptr, e->d_verdict, *so);  // (synchronises behind the verdicts' copy)
         if (rc) return rc;
         if (!e->resp_n_chunks) HIP_TRY(e, hipStreamSynchronize(e->stream));
         return RL_OK;
@@ -3458,7 +3499,7 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
     HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
     if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
-        rc = responses_locked(e, n, e->d_w_status, e->d_verdict, *so);  // (synchronises behind the verdicts' / statuses' copies)
+        rc = responses_locked(e, n, n_hits, e->d_w_status, e->d_verdict, *so);  // (synchronises behind the verdicts' / statuses' copies)
         if (rc) return rc;
         if (!e->resp_n_chunks) HIP_TRY(e, hipStreamSynchronize(e->stream));
         return RL_OK;
@@ -3502,6 +3543,8 @@ int32_t rl_resp_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     if (blob_len) HIP_TRY(e, hipMemcpy(e->d_resp_blob, blob, blob_len, hipMemcpyHostToDevice));
     if (n_limits) HIP_TRY(e, hipMemcpy(e->d_resp_frag, frag, (size_t)n_limits * sizeof(WireStr), hipMemcpyHostToDevice));
     e->n_resp_frag = n_limits;
+    e->resp_max_frag = 0;
+    for (u32 i = 0; i < n_limits; ++i) e->resp_max_frag = std::max(e->resp_max_frag, frag[i].len);
     e->resp_blob_len = blob_len;
     e->resp_ready = true;
     return RL_OK;

@@ -29,6 +29,8 @@ struct RespArgs {
     const int32_t* status;     // per request: 0 = answered; anything else derives no response (-101, no domain, is the EMPTY
                                // message: Code::Unknown = 0 is the proto3 default, server.rs:105-115); null: all 0
     const uint8_t* verdict;    // per request
+    u64 out_cap;               // WRITE: bytes `out` holds — a block whose responses end beyond it writes nothing (the caller
+                               // sized `out` from a bound and checks the total afterwards)
     const u32* req_off;        // [n + 1] into hits / remaining / expires_in (null without headers)
     const Hit* hits;
     const u64* remaining;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256) void k_resp(RespArgs A, u32* __restrict__ len,
         if (r0 >= A.n) return;  // (past the last request: so is every later block of this workgroup)
         g0 = off[r0];
         g_len = off[r1] - g0;
+        if ((u64)g0 + g_len > A.out_cap) return;  // (so does every later block: offsets ascend)
         mis = (u32)((reinterpret_cast<unsigned long long>(out) + g0) & 15ull);
         staged = g_len + mis <= RESP_LDS;
         if (A.with_headers && A.blob_len <= RESP_BLOB_LDS) {
