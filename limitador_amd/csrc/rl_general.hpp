@@ -144,6 +144,10 @@ struct GenArgs {
     GenStatus* gst;
     const Status* pst;       // the partition's status: a refused batch leaves the sorted arrays unwritten
     u32 load, update_mode, mark_reached;
+    u32 pass_prefilled;      // the round's pass flags start out 1 (round 0: k_gen_piece_sum fills them; later rounds: the round's
+                             // k_gen_admit, request by request) and k_gen_round only stores the FAILURES — a flag goes to its
+                             // hit's index in request order, a random byte store per hit, and those stores are what bounds a
+                             // round; the phased form (rl_gen_round_device) writes every flag into the caller's array
     unsigned long long* trace;  // debugging (RL_GEN_TRACE=2): k_gen_sort's phase stamps, 8 words per workgroup
 };
 
@@ -527,6 +531,10 @@ __global__ __launch_bounds__(256) void k_gen_admit(GenArgs A, u32 round, u32 che
         const uint8_t before = round == 1 ? (uint8_t)1 : A.admitted[r];
         differs = adm != before;
         A.admitted[r] = adm;
+        if (A.pass_prefilled) {  // this round's flags start out "passes" (a request's flags are contiguous)
+            uint8_t* pass_next = A.pass[round & 1u];
+            for (u32 q = b; q < e; ++q) pass_next[q] = 1;
+        }
     }
     // Thousands of workgroups may have something to report, and one word that all of them read or write costs
     // ~3 ns apiece in the L2 (measured: 48 us for this kernel): one flag per workgroup, folded by k_gen_admit_fold.
@@ -573,6 +581,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_piece_sum(GenArgs A, u32 round
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u32 k = blockIdx.x;
     const u32 lo = k * (u32)GS_MAX, hi = lo + (u32)GS_MAX;
+    if (round == 0 && A.pass_prefilled) {  // round 0's flags start out "passes" (coalesced; k_gen_round stores the failures)
+        uint8_t* p0 = A.pass[0];
+        for (u32 q = lo + tid; q < hi && q < A.n_hits; q += GS_BLOCK) p0[q] = 1;
+    }
     if (hi >= A.n_hits) return;                     // the last piece has no successor
     const u32 t = A.s_hits[hi].seg;                 // the segment the next piece opens with ...
     if (t == hi) return;                            // ... starts there: nothing is carried over
@@ -764,7 +776,7 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
         const u64 v = zw ? 0ull : base + (pr.sum - dup_sum);
         const u64 sum = v + d[i];  // wraps like the reference's release build (in_memory.rs:88)
         const bool pass = A.update_mode ? true : sum <= Lm.max_value;
-        pass_cur[h[i].idx] = pass ? 1 : 0;
+        if (!A.pass_prefilled || !pass) pass_cur[h[i].idx] = pass ? 1 : 0;
         if (A.load) {
             A.remaining[h[i].idx] = pass ? Lm.max_value - sum : 0ull;  // checked_sub().unwrap_or_default(), :88-89
             u64 ttl;
