@@ -248,6 +248,7 @@ struct rl_engine {
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
+    bool gen_load_deferred = true; // RL_GEN_LOAD_DEFERRED=0: k_gen_round stores remaining / expires_in in every round
     bool gen_pass_prefill = true;  // RL_GEN_PASS_PREFILL=0: k_gen_round stores every pass flag (the form before round 5)
     u32 gen_rounds_hint = 3; // fixpoint rounds the last general pass ran + 1: the length of the next pass's first blind group
     u32 gen_tiny_max = 64;   // general form: calls of up to this many hits take k_gen_tiny (RL_GEN_TINY_MAX=0 disables)
@@ -1427,6 +1428,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     rc = gen_setup_and_sort(e, c, req0, n_req, hit0, n, mark, A, &bs);
     if (rc) return rc;
     A.pass_prefilled = e->gen_pass_prefill ? 1u : 0u;
+    A.load_deferred = (c.load && e->gen_load_deferred) ? 1u : 0u;
     if (A.hit_check) k_gen_check_keys<<<cdiv(n, 256), 256, 0, st>>>(A);  // (a collision refuses the pass: k_gen_commit reads gst->err)
     const u64 p = e->part_seq;
     // ---- fixpoint rounds: a few at a time, each returning at once if the one before changed nothing; then
@@ -1461,6 +1463,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
             k_gen_piece_sum<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A, round, run_if);
             k_gen_round<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A, round, run_if, q + 1);
         }
+        if (A.load_deferred) k_gen_load<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A);
         k_gen_final<<<cdiv(n_req, 256), 256, 0, st>>>(A);
         if (mark) k_gen_reach<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A);
         const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
@@ -1803,6 +1806,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_RESP_DIRECT")) e->resp_direct = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_PASS_PREFILL")) e->gen_pass_prefill = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_GEN_LOAD_DEFERRED")) e->gen_load_deferred = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_WRITERS")) e->resp_writers = (u32)std::max(1, atoi(v));
     if (const char* v = RL_EXP_ENV("RL_RESP_PIECES")) e->resp_pieces = std::min<u32>(rl_engine::RESP_CHUNKS, std::max(1, atoi(v)));
     if (const char* v = RL_EXP_ENV("RL_TIMING_LAZY")) e->timing_lazy = atoi(v) != 0;

@@ -144,6 +144,7 @@ struct GenArgs {
     GenStatus* gst;
     const Status* pst;       // the partition's status: a refused batch leaves the sorted arrays unwritten
     u32 load, update_mode, mark_reached;
+    u32 load_deferred;       // load_counters: k_gen_round does not store remaining / expires_in, k_gen_load does once behind the rounds
     u32 pass_prefilled;      // the round's pass flags start out 1 (round 0: k_gen_piece_sum fills them; later rounds: the round's
                              // k_gen_admit, request by request) and k_gen_round only stores the FAILURES — a flag goes to its
                              // hit's index in request order, a random byte store per hit, and those stores are what bounds a
@@ -640,6 +641,9 @@ struct GenRoundLds {
     u32 out_seg;          // ... and its segment (the carry of a long bucket's next piece)
 };
 
+// LOAD_ONLY: the pass behind the rounds (k_gen_load) — the same scan, but what it stores is `remaining` / `expires_in` of
+// every hit and nothing else (no pass flag, no segment total).
+template <bool LOAD_ONLY>
 __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t* __restrict__ pass_prev,
                                                 uint8_t* __restrict__ pass_cur, u32 lo, u32 n, Run carry, u32 carry_seg,
                                                 GenRoundLds& S) {
@@ -776,8 +780,8 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
         const u64 v = zw ? 0ull : base + (pr.sum - dup_sum);
         const u64 sum = v + d[i];  // wraps like the reference's release build (in_memory.rs:88)
         const bool pass = A.update_mode ? true : sum <= Lm.max_value;
-        if (!A.pass_prefilled || !pass) pass_cur[h[i].idx] = pass ? 1 : 0;
-        if (A.load) {
+        if (!LOAD_ONLY && (!A.pass_prefilled || !pass)) pass_cur[h[i].idx] = pass ? 1 : 0;
+        if (LOAD_ONLY || (A.load && !A.load_deferred)) {
             A.remaining[h[i].idx] = pass ? Lm.max_value - sum : 0ull;  // checked_sub().unwrap_or_default(), :88-89
             u64 ttl;
             if (zw) ttl = 0;
@@ -786,28 +790,16 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
             A.expires_in[h[i].idx] = ttl;
         }
         // the segment's last hit publishes what the admitted hits add to the cell
-        if (pos + 1 == h[i].seg + si.len) {
+        if (!LOAD_ONLY && pos + 1 == h[i].seg + si.len) {
             const Run tot = adm[i] ? run_join(pr, Run{d[i], d[i], 1u}) : pr;
             A.seg_tot[h[i].seg] = SegTot{tot.sum, tot.last, tot.cnt, 0u};
         }
     }
 }
 
-__global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
-    __shared__ GenRoundLds S;
-    if (A.pst->err || A.gst->overflow) return;
-    if (check_slot && !A.gst->changed[check_slot]) return;  // converged: the round before changed nothing
-    const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
-    uint8_t* pass_cur = A.pass[round & 1u];
+template <bool LOAD_ONLY>
+__device__ __forceinline__ void gen_round_body(const GenArgs& A, const uint8_t* pass_prev, uint8_t* pass_cur, GenRoundLds& S) {
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    if (tid == 0 && blockIdx.x == 0) {
-        A.gst->last_round = round;
-        atomicAdd(&A.gst->rounds_run, 1u);
-        if (round == 0) {  // no k_gen_admit before round 0: round 1 always follows
-            A.gst->last_slot = write_slot;
-            A.gst->changed[write_slot] = 1u;
-        }
-    }
     // One workgroup per piece of GS_MAX positions (k_gen_piece_sum): every piece of every bucket at once — a
     // bucket that skew made long no longer sets the duration of the round.
     const u32 k = blockIdx.x;
@@ -842,7 +834,37 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u3
         }
         __syncthreads();
     }
-    gen_round_piece(A, pass_prev, pass_cur, lo, n, S.carry, carry_seg, S);
+    gen_round_piece<LOAD_ONLY>(A, pass_prev, pass_cur, lo, n, S.carry, carry_seg, S);
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
+    __shared__ GenRoundLds S;
+    if (A.pst->err || A.gst->overflow) return;
+    if (check_slot && !A.gst->changed[check_slot]) return;  // converged: the round before changed nothing
+    const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
+    uint8_t* pass_cur = A.pass[round & 1u];
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        A.gst->last_round = round;
+        atomicAdd(&A.gst->rounds_run, 1u);
+        if (round == 0) {  // no k_gen_admit before round 0: round 1 always follows
+            A.gst->last_slot = write_slot;
+            A.gst->changed[write_slot] = 1u;
+        }
+    }
+    gen_round_body<false>(A, pass_prev, pass_cur, S);
+}
+
+// load_counters, once per group of rounds instead of once per round: `remaining` / `expires_in` of every hit (as read BEFORE
+// the update, in_memory.rs:114-116,134-136) are two more random 8-byte stores per hit — the stores that bound a round — and
+// only the LAST round's values are ever read.  This kernel repeats the last round's scan (the admitted set it used is still
+// in A.admitted — a k_gen_admit that found nothing changed rewrote the same values — and the pieces' carries in piece_sum)
+// and stores just those two.  The phased form (rl_gen_round_device) keeps storing them per round: its caller reads them per round.
+__global__ __launch_bounds__(GS_BLOCK) void k_gen_load(GenArgs A) {
+    __shared__ GenRoundLds S;
+    if (A.pst->err || A.gst->overflow) return;
+    // (round 0 admitted every request; any later round read A.admitted — gen_adm_byte only asks whether pass_prev is null)
+    const uint8_t* pass_prev = (A.gst->last_round == 0 || A.update_mode) ? nullptr : A.pass[0];
+    gen_round_body<true>(A, pass_prev, nullptr, S);
 }
 
 // ---------------------------------------------------------------------------------------------
