@@ -433,7 +433,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
                                                           u32 ntiles, HotParam* __restrict__ hot_param,
                                                           HotSet* __restrict__ hot_next, u32 hot_threshold,
                                                           unsigned short* __restrict__ chunk_tab, u32 all_chunks,
-                                                          u64* htrace) {
+                                                          u64* htrace, const u32* __restrict__ hit_req,
+                                                          u32* __restrict__ b_req) {
+    // hit_req / b_req (the general resolver; may be null): the request of every hit travels WITH its record —
+    // b_req[p] = hit_req[i] for the record that lands at p.  Read here it is a coalesced read (i runs with the lanes) and
+    // a 4-byte store beside the record's; gathered later through the record's index (k_gen_sort did that) it is a random
+    // 4-byte read per hit — 3.1 M of them were more than half of that kernel.
     // wave-private counters, [PT_WAVES][nbt] — dynamic, sized by the launch for the batch's bucket count
     // (PT_WAVES * nbt * 2 bytes: 80 KB with 2048 hash buckets, 48 KB with 1024), so that with fewer buckets the
     // workgroup fits a CU beside k_bkt_apply's workgroups
@@ -556,10 +561,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
     const u32 nbt = nb + HOT_MAX;
     const u32 wbase = tile * (PT_BLOCK * STEPS) + w * (64 * STEPS);
     uint4 raw[STEPS];
+    u32 rq[STEPS];
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
         const u32 i = wbase + u * 64 + lane;
         if (i < n) raw[u] = *reinterpret_cast<const uint4*>(hits + i);
+        rq[u] = (b_req && i < n) ? hit_req[i] : 0u;
     }
     hot_table_build(hot, seed, s_hot_key, s_hot_idx);
     {
@@ -630,6 +637,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_bkt_scatter(const Hit* __restrict_
             const u32 dst = s_base[d] + s_cnt[w * nbt + d] + rank[u];
             *reinterpret_cast<uint4*>(b_hits + dst) =
                 make_uint4(raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24));
+            if (b_req) b_req[dst] = rq[u];
         }
     }
     RL_HSTAMP(6);

@@ -248,6 +248,7 @@ struct rl_engine {
     bool external_stream = false;  // the caller orders its own work on `stream`: routing helpers do not block
     u32 n_cus = 256;
     bool auto_grow = false;  // RL_CFG_AUTO_GROW
+    bool gen_carry_req = true;     // RL_GEN_CARRY_REQ=0: k_gen_sort gathers every record's request through the record's index
     bool gen_load_deferred = true; // RL_GEN_LOAD_DEFERRED=0: k_gen_round stores remaining / expires_in in every round
     bool gen_pass_prefill = true;  // RL_GEN_PASS_PREFILL=0: k_gen_round stores every pass flag (the form before round 5)
     u32 gen_rounds_hint = 3; // fixpoint rounds the last general pass ran + 1: the length of the next pass's first blind group
@@ -257,6 +258,7 @@ struct rl_engine {
     uint8_t* h_tiny = nullptr;  // host-mapped staging of a tiny host-buffer call: the kernel reads and writes it directly
     u32 tiny_max = TINY_MAX;  // batches up to this many hits take the one-launch path (RL_TINY_MAX=0 disables)
     BHit* d_bk_hits = nullptr;              // [PB_SETS][max_batch]
+    u32* d_bk_req = nullptr;                // [bk_stride]: the request of every partitioned record (general resolver; passes are blocking: one set)
     BHit* d_tiny_hits = nullptr;            // k_bkt_tiny's record buffer
     unsigned short* d_chunk_tab = nullptr;  // [PB_SETS][...] hot chunk -> hot bucket (k_bkt_scatter -> k_bkt_apply)
     size_t chunk_tab_len = 0;
@@ -1318,8 +1320,12 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
                                         ntiles, e->d_bk_hist, bs, hot_use, c.update_mode ? 0u : 1u, nullptr, nullptr, nullptr);
     k_bkt_scan<<<cdiv(nbt + HOT_COLS, 32), 1024, 0, st>>>(e->d_bk_hist, ntiles, nbt, e->d_bk_total);
     auto scatter_k = small ? k_bkt_scatter<1> : k_bkt_scatter<PT_STEPS>;
+    // (the request of every hit travels with its record: k_gen_sort reads it beside the record instead of gathering it)
+    const u32* hit_req_all = c.d_hit_req_ext ? c.d_hit_req_ext : (c.d_req_off ? e->d_hit_req : nullptr);
+    u32* b_req = (hit_req_all && e->gen_carry_req) ? e->d_bk_req : nullptr;
     scatter_k<<<ntiles + 1, PT_BLOCK, scatter_lds_bytes(nbt), st>>>(hits, n, e->seed, bk_log2, e->d_bk_hist, e->d_bk_total, hot_use, b_hits, ranges,
-                                               &bs->st, ntiles, hot_param, hot_prod, e->hot_threshold, chunk_tab, 1u, nullptr);
+                                               &bs->st, ntiles, hot_param, hot_prod, e->hot_threshold, chunk_tab, 1u, nullptr,
+                                               hit_req_all ? hit_req_all + hit0 : nullptr, b_req);
     // ---- sort by cell, resolve the cells ---------------------------------------------------------------
     GenArgs A{};
     A.table = e->table;
@@ -1328,7 +1334,8 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     A.limits = e->d_limits;
     A.now = c.now;
     A.hits = hits;
-    A.hit_req = c.d_hit_req_ext ? c.d_hit_req_ext : (c.d_req_off ? e->d_hit_req : nullptr);
+    A.hit_req = hit_req_all;
+    A.b_req = b_req;
     A.req_off = c.d_req_off;
     A.req_delta = c.d_req_delta;
     A.hit_check = c.d_hit_check ? c.d_hit_check + hit0 : nullptr;
@@ -1807,6 +1814,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_PASS_PREFILL")) e->gen_pass_prefill = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_LOAD_DEFERRED")) e->gen_load_deferred = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_GEN_CARRY_REQ")) e->gen_carry_req = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_WRITERS")) e->resp_writers = (u32)std::max(1, atoi(v));
     if (const char* v = RL_EXP_ENV("RL_RESP_PIECES")) e->resp_pieces = std::min<u32>(rl_engine::RESP_CHUNKS, std::max(1, atoi(v)));
     if (const char* v = RL_EXP_ENV("RL_TIMING_LAZY")) e->timing_lazy = atoi(v) != 0;
@@ -1953,6 +1961,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (hipMemset(e->d_hot_param, 0, PB_SETS * (size_t)(HOT_MAX + 1) * sizeof(HotParam)) != hipSuccess) return bail(RL_ERR_DEVICE);
     e->bk_stride = (mb + (PT_BLOCK * PT_STEPS_MAX - 1)) / (PT_BLOCK * PT_STEPS_MAX) * (PT_BLOCK * PT_STEPS_MAX);
     ALLOC(e->d_bk_hits, PB_SETS * e->bk_stride * sizeof(BHit));
+    ALLOC(e->d_bk_req, e->bk_stride * sizeof(u32));
     e->run_tt_max = cdiv(mb, PT_BLOCK * PT_STEPS_MAX) > (u32)TT_SMALL ? (u32)TT_LARGE : (u32)TT_SMALL;
     ALLOC(e->d_runs, PB_SETS * (size_t)BKT_MAX * e->run_tt_max * sizeof(u32));
     ALLOC(e->d_items, PB_SETS * sizeof(HotItems));
@@ -2039,7 +2048,7 @@ void rl_engine_destroy(rl_engine* e) {
                     e->d_remaining, e->d_expires, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
                     e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
-                    e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_tiny_hits, e->d_chunk_tab,
+                    e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_req, e->d_tiny_hits, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_cmark, e->d_w_blob, e->d_w_ns, e->d_w_lit, e->d_w_prefix, e->d_w_bytes, e->d_w_off, e->d_w_status, e->d_w_slot_h, e->d_hit_check, e->d_resp_blob, e->d_resp_frag, e->d_resp_off, e->d_resp_bytes, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,
                     e->d_m_ent_key, e->d_m_ent_val, e->d_m_count, e->d_m_limited, e->d_m_flags, e->d_m_scan_tmp, e->d_m_mask, e->d_match_flimits, e->d_match_fconds, e->d_gen_trace};

@@ -109,6 +109,7 @@ struct GenArgs {
     u64 now;
     const Hit* hits;         // the pass's hits (caller's batch + hit0)
     const u32* hit_req;      // absolute request of every hit of the caller's batch (null: hit i is request i)
+    const u32* b_req;        // the same, beside the partitioned records: b_req[p] belongs to b_hits[p] (k_bkt_scatter; null: gather)
     const u32* req_off;      // absolute CSR offsets (null: every hit its own request)
     const u64* req_delta;    // per-request u64 deltas of the caller's batch (null: the wire field)
     const u32* hit_check;    // hashed keys (rl_keyhash.h): the check word of every hit of the pass, else null
@@ -151,6 +152,14 @@ struct GenArgs {
                              // round; the phased form (rl_gen_round_device) writes every flag into the caller's array
     unsigned long long* trace;  // debugging (RL_GEN_TRACE=2): k_gen_sort's phase stamps, 8 words per workgroup
 };
+
+// The (absolute) request of the record at position p of the partitioned batch: beside the record when the partition carried
+// it along (b_req), else through the record's index (a random read per hit).
+template <class BH>
+__device__ __forceinline__ u32 gen_req_of(const GenArgs& A, const BH& h, u32 p) {
+    if (A.b_req) return A.b_req[p];
+    return A.hit_req ? A.hit_req[A.hit0 + (h.idx_tag & 0xFFFFFFu)] : 0u;
+}
 
 __device__ __forceinline__ LimitDev gen_limit_row(const GenArgs& A, u32 limit) {
     const uint4 v = *reinterpret_cast<const uint4*>(&A.limits[limit & ~SIMPLE_FLAG]);
@@ -251,7 +260,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
                 hh[u] = load_bhit(A.b_hits, j < hp.hi ? j : hp.hi - 1);
             }
 #pragma unroll
-            for (int u = 0; u < CU; ++u) rq[u] = A.hit_req ? A.hit_req[A.hit0 + (hh[u].idx_tag & 0xFFFFFFu)] : 0u;
+            for (int u = 0; u < CU; ++u) {
+                const u32 j = first + u * GS_BLOCK + tid;
+                rq[u] = gen_req_of(A, hh[u], j < hp.hi ? j : hp.hi - 1);
+            }
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
                 const u32 j = first + u * GS_BLOCK + tid;
@@ -306,8 +318,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     __syncthreads();
     u32 rA = 0, rB = 0;
     if (resident && A.hit_req) {
-        rA = A.hit_req[A.hit0 + (hA.idx_tag & 0xFFFFFFu)];
-        rB = A.hit_req[A.hit0 + (hB.idx_tag & 0xFFFFFFu)];
+        rA = gen_req_of(A, hA, lo + (w_lo + lane < L ? w_lo + lane : L - 1));
+        rB = gen_req_of(A, hB, lo + (w_lo + 64 + lane < L ? w_lo + 64 + lane : L - 1));
     }
     // ---- pass 1: the bucket's cells (LDS hash), hits per (wave, cell) ---------------------------------
     auto count_step = [&](const BHit& h, bool ok) {
@@ -449,13 +461,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
         u32 req0 = 0, req1 = 0;
         if (okA) {
             h0 = load_bhit(A.b_hits, lo + w_lo + lane);
-            req0 = A.hit_req ? A.hit_req[A.hit0 + (h0.idx_tag & 0xFFFFFFu)] : 0u;
+            req0 = gen_req_of(A, h0, lo + w_lo + lane);
         }
         if (okB) h1 = load_bhit(A.b_hits, lo + w_lo + 64 + lane);
         for (u32 u = 0; u < steps; ++u) {
             const u32 p = w_lo + u * 64 + lane;
             if (u + 2 < steps && p + 128 < w_hi) h2 = load_bhit(A.b_hits, lo + p + 128);
-            if (u + 1 < steps && p + 64 < w_hi) req1 = A.hit_req ? A.hit_req[A.hit0 + (h1.idx_tag & 0xFFFFFFu)] : 0u;
+            if (u + 1 < steps && p + 64 < w_hi) req1 = gen_req_of(A, h1, lo + p + 64);
             place_step(h0, req0, p < w_hi);
             h0 = h1;
             h1 = h2;
