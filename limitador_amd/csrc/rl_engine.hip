@@ -2853,6 +2853,9 @@ int32_t rl_gen_round_device(rl_engine* e, const uint8_t* d_admitted, uint8_t* d_
     GenArgs A = e->ph_A;
     A.admitted_hit = d_admitted;  // null: every hit admitted (the first round)
     A.pass[0] = A.pass[1] = d_pass;
+    // (round number 0 below: k_gen_piece_sum fills the caller's flags with 1, k_gen_round stores only the failures — the
+    // random byte store per hit is what bounds a round)
+    A.pass_prefilled = e->gen_pass_prefill ? 1u : 0u;
     A.remaining = A.load ? reinterpret_cast<u64*>(d_remaining) : nullptr;
     A.expires_in = A.load ? reinterpret_cast<u64*>(d_expires_in_us) : nullptr;
     if (A.load && (!d_remaining || !d_expires_in_us)) return fail(e, RL_ERR_INVALID, "load_counters: remaining / expires_in are null");
