@@ -148,8 +148,12 @@ int32_t rli_set_limit_name(rli_ingest *g, uint32_t limit_id, const char *name);
  *   (response_headers_to_add = 3, sorted by key): X-RateLimit-Limit `{max}, {max};w={secs}[;name="{name}"]...`
  *   over the request's counters sorted by remaining, X-RateLimit-Remaining, X-RateLimit-Reset of the most
  *   restrictive one (CheckResult::response_header, lib.rs:235-275; the counters are loaded: load_counters).
+ * With headers, a batch of 4096 messages or more has the DEVICE build the response bytes (rl_engine.h: rl_wire_serve_batch /
+ * rl_match_serve_batch, csrc/rl_resp.hpp; what each limit contributes to X-RateLimit-Limit is sent to the engine once per
+ * change of a limit's max / name) and this call only hands them on while they arrive; smaller batches are assembled on the
+ * host from the counters' arrays.  Same bytes either way.
  * One call at a time per ENGINE (the messages and the results travel through the engine's pinned staging, rl_host_staging
- * slots 0 and 1; rli_frontend_* serialises its batches).
+ * slots 0 to 3; rli_frontend_* serialises its batches).
  * status[i]: 0 OK, 1 OVER_LIMIT, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY (the value dictionary is at its cap: the caller
  * evaluates this request itself; no response is produced), RLI_RESPONSE_TOO_LARGE (counted, but its response does not
  * fit out_stride: out_len[i] = 0), or another value < 0 for a malformed message. */

@@ -145,6 +145,7 @@ struct rl_engine {
     BatchScratch* ph_bs = nullptr;
     u32 ph_n = 0, ph_rounds = 0;
     bool ph_counted = false;
+    u32 gen_bk_log2_big = 10;          // RL_GEN_BUCKET_LOG2_BIG: hash buckets of a pass of more than 2 M hits (2^10: r9g, r14t)
     u32 gen_bk_log2_max = BK_LOG2_MAX; // RL_GEN_BUCKET_LOG2: cap on the general resolver's hash buckets (tests)
     int gen_trace = 0;                 // RL_GEN_TRACE=1: one stderr line per pass of the general resolver; 2: + k_gen_sort phases
     unsigned long long* d_gen_trace = nullptr;
@@ -1306,7 +1307,7 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     if (bk_log2 > (u32)BK_LOG2_MAX) bk_log2 = BK_LOG2_MAX;
     // passes of more than 2 M hits: 1024 buckets, not 2048 — twice the hits per (tile, bucket) run of k_bkt_scatter's stores
     // (3.1 M counters: 0.474 -> 0.461 ms per call, scripts/exp/r9g.sh; 512 buckets: 0.467, 256: 0.873)
-    if (n > (2u << 20) && bk_log2 > 10u) bk_log2 = 10u;
+    if (n > (2u << 20) && bk_log2 > e->gen_bk_log2_big) bk_log2 = e->gen_bk_log2_big;
     if (e->gen_bk_log2_max < bk_log2) bk_log2 = e->gen_bk_log2_max;  // (tests: long buckets on purpose)
     const u32 nb = 1u << bk_log2, nbt = nb + HOT_MAX;
     const bool small = cdiv(n, PT_TILE_SMALL) <= PT_SMALL_MAX_TILES && cdiv(n, PT_TILE_SMALL) < e->bk_tiles_max;
@@ -1836,6 +1837,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_HOT_REPORT")) e->hot_report = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_HOT_LONG")) e->hot_long_cfg = (u32)std::max<unsigned long>(1ul, strtoul(v, nullptr, 10));
     if (const char* v = RL_EXP_ENV("RL_GEN_TRACE")) e->gen_trace = atoi(v);
+    if (const char* v = RL_EXP_ENV("RL_GEN_BUCKET_LOG2_BIG")) e->gen_bk_log2_big = (u32)std::min(std::max(atoi(v), 6), (int)BK_LOG2_MAX);
     if (const char* v = RL_EXP_ENV("RL_GEN_BUCKET_LOG2")) e->gen_bk_log2_max = (u32)std::min(std::max(atoi(v), 0), (int)BK_LOG2_MAX);
     if (const char* v = RL_EXP_ENV("RL_GEN_SUB_MAX")) {
         const long b = strtol(v, nullptr, 10);
