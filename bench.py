@@ -35,7 +35,7 @@ RANDOM_TRANSACTIONS_PER_1M_ZIPF = 1.45e6  # profiles/r04h_replay_memory_path.md 
 RANDOM_LINE_RATE = 57e9                   # random 32-byte cell reads per second, chip-wide: profiles/r04a_random_slope.txt
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -57,11 +57,17 @@ def parse():
     ap.add_argument("--sharded-impl", choices=("torch", "abi"), default=os.environ.get("RL_SHARDED_IMPL", "abi"),
                     help="routed step driven by the C entry with its own RCCL communicator (include/rl_sharded.h: 105 us per "
                          "1 M-hit slice at world 1) or by torch.distributed from Python (limitador_amd/sharded.py: 181 us).  "
-                         "RL_SHARDED_IMPL=torch selects the latter.  A watchdog ends a routed run that makes no progress for "
-                         "five minutes instead of leaving the ranks at a collective.")
+                         "RL_SHARDED_IMPL=torch selects the latter.  A watchdog (limitador_amd/watchdog.py) ends a routed run "
+                         "that makes no PROGRESS for --stall-seconds instead of leaving the ranks at a collective: every phase "
+                         "boundary, every loaded chunk and every collected slice re-arms it; communicator bring-up has its own, "
+                         "longer limit (--init-seconds).")
+    ap.add_argument("--stall-seconds", type=float, default=300.0, help="routed runs: seconds without progress before the watchdog exits (rc 3)")
+    ap.add_argument("--init-seconds", type=float, default=900.0,
+                    help="routed runs: limit for ONE bring-up phase (rendezvous, RCCL initialisation: the first one on a fresh box "
+                         "pages in librccl's device code and has taken 400 s)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the routed (all-to-all) data path even with one rank (exercises the N>1 code on one GPU)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def _cpu_batches(args):
@@ -569,13 +575,92 @@ def secondary(args, eng, dev, gen):
     return out
 
 
-def main():
-    args = parse()
+_RCCL_PROBE = r"""
+import os, sys, socket, datetime
+import torch, torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                  RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+dev = torch.device("cuda", int(sys.argv[1])); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=200))
+t = torch.ones(1024, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
+dist.destroy_process_group(); print("rccl ok")
+"""
+
+
+class GpuPlatform:
+    """Everything main() needs from the machine.  The product run uses this class as it is; tests/test_bench_sharded_cpu.py
+    runs the same main() at world 2 over gloo with a CPU stand-in (same methods) so that the routed run's ORCHESTRATION —
+    phases, watchdog, fall-back agreement, timing protocol, the JSON line — is exercised without a GPU."""
+
+    dist_backend = "nccl"
+
+    def __init__(self, local_rank):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a MI355X: the engine has no CPU path")
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.device = torch.device("cuda", local_rank)
+
+    def sync(self):
+        import torch
+
+        torch.cuda.synchronize()
+
+    def make_engine(self, capacity_cells, max_batch_hits):
+        from limitador_amd.engine import Engine
+
+        return Engine(capacity_cells=capacity_cells, max_batch_hits=max_batch_hits, device=self.local_rank)
+
+    def warm_collectives(self, wd, attempts=2, timeout_s=240.0):
+        """The first RCCL initialisation of a fresh box, in a PROCESS OF ITS OWN that can be killed (what
+        tests/conftest.py::rccl_ready does for the suite): a world-1 communicator + one all-reduce on this rank's GPU.
+        Afterwards the box's page cache holds librccl's device code, and the in-process bring-ups that follow (torch's
+        communicator, then rl_sharded_create_rccl, which binds to the copy torch mapped) take seconds.  -> (ok, note)."""
+        import subprocess
+
+        note = ""
+        for attempt in range(attempts):
+            wd.kick(f"RCCL warm-up in a subprocess (attempt {attempt + 1})", limit_s=timeout_s + 60)
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run([sys.executable, "-c", _RCCL_PROBE, str(self.local_rank)], stdout=subprocess.PIPE,
+                                   stderr=subprocess.STDOUT, text=True, timeout=timeout_s,
+                                   env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                if p.returncode == 0 and "rccl ok" in p.stdout:
+                    return True, f"{time.perf_counter() - t0:.1f} s (attempt {attempt + 1})"
+                note = p.stdout.strip()[-200:]
+            except subprocess.TimeoutExpired:
+                note = f"no world-1 communicator within {timeout_s:.0f} s"
+        return False, note
+
+    def make_torch_sharded(self, eng, group, max_local_hits):
+        from limitador_amd.sharded import ShardedEngine
+
+        return ShardedEngine(eng, group, self.device, max_local_hits=max_local_hits)
+
+    def abi_unique_id(self):
+        from limitador_amd import sharded_abi
+
+        return sharded_abi.unique_id()
+
+    def make_abi_sharded(self, eng, world, rank, max_slice_hits, unique_id):
+        from limitador_amd import sharded_abi
+
+        return sharded_abi.Sharded(eng, world, rank, max_slice_hits, unique_id=unique_id)
+
+
+def main(argv=None, platform=None):
+    args = parse(argv)
+    import datetime
+
     import torch
     import torch.distributed as dist
 
     from limitador_amd import workloads as W
-    from limitador_amd.engine import Engine
+    from limitador_amd.watchdog import Watchdog
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -583,28 +668,39 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    plat = platform if platform is not None else GpuPlatform(local_rank)
+    dev = plat.device
     sharded = world > 1 or args.force_sharded
-    if sharded:
-        import threading
+    # Progress-based: `wd.kick(phase)` at every phase boundary, every loaded chunk, every collected slice.  A single-GPU
+    # unrouted run has nobody to wait for and runs without it.
+    wd = Watchdog(limit_s=args.stall_seconds, name=f"bench.py rank {rank}")
+    phases = {}  # phase -> seconds (rank 0's; on the line as config.bringup_s for routed runs)
+    t_phase = [time.perf_counter(), "start"]
 
-        def _stuck():
-            sys.stderr.write(f"bench.py rank {rank}: the routed run did not finish within 300 s (impl {args.sharded_impl}); "
-                             "set RL_SHARDED_IMPL=torch to drive it through torch.distributed\n")
-            sys.stderr.flush()
-            os._exit(3)
+    def phase(name, limit_s=None):
+        t = time.perf_counter()
+        phases[t_phase[1]] = round(phases.get(t_phase[1], 0.0) + t - t_phase[0], 3)
+        t_phase[0], t_phase[1] = t, name
+        wd.kick(name, limit_s)
 
-        watchdog = threading.Timer(300.0, _stuck)
-        watchdog.daemon = True
-        watchdog.start()
     if sharded:
+        wd.start()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        warm_note = None
+        if hasattr(plat, "warm_collectives"):
+            ok, warm_note = plat.warm_collectives(wd)
+            if not ok:  # not fatal: the in-process bring-up below gets its own --init-seconds
+                sys.stderr.write(f"bench.py rank {rank}: RCCL warm-up did not finish ({warm_note}); trying in-process\n")
+        phase("init_process_group", args.init_seconds)
+        kw = {"device_id": dev} if dev.type == "cuda" else {}
+        dist.init_process_group(plat.dist_backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=max(60.0, args.init_seconds)), **kw)
+        phase("first collective", args.init_seconds)
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)  # (with device_id the communicator exists already; without it this creates it)
+        plat.sync()
 
     n_keys_total = args.keys * world
     # 32-byte cells at load <= 0.15: 10 M keys -> 2^26 cells = 2.1 GB of the GPU's 288 (215 bytes of table per key; the
@@ -614,25 +710,41 @@ def main():
     # 48.2 us.  --cap-mult 0.5 is the round-3 sizing.
     cap = 1 << (int(n_keys_total / world * 4.4 * args.cap_mult - 1).bit_length())
     max_batch = int(args.batch * 2) if sharded else args.batch
-    eng = Engine(capacity_cells=cap, max_batch_hits=max_batch, device=local_rank)
+    phase("engine")
+    eng = plat.make_engine(cap, max_batch)
     eng.set_limits([(W.MAX_VALUE, W.WINDOW_S)])
 
     # ---- pre-populate this rank's shard -----------------------------------------------------
-    if world == 1:
-        rows = W.torch_universe_rows(n_keys_total, dev)
-    else:
+    # The universe is key(i) = splitmix64(i), i < N x keys; a key's owner is a hash of the KEY (owner_of, rl_cell.hpp), so a
+    # rank finds its share by filtering.  It walks the index range in pieces of 4 M (generated, filtered and loaded one
+    # at a time: 128 MB of temporaries whatever N is) and starts at its own N-th of the range, so that the ranks do not
+    # all hash the same piece at the same moment.  Every piece is progress for the watchdog.
+    phase("pre-populate")
+    piece = 1 << 22
+    n_pieces = (n_keys_total + piece - 1) // piece
+    first = (rank * n_pieces) // world
+    chunk = 1 << 20
+    keep = None
+    if world > 1:
         from limitador_amd.sharded import owner_mask
 
-        rows = W.torch_universe_rows(n_keys_total, dev, keep=lambda k: owner_mask(k, eng.hash_seed, world, rank))
-    chunk = 1 << 20
-    torch.cuda.synchronize()  # (the engine loads on its own stream)
-    for lo in range(0, rows.shape[0], chunk):
-        part = rows[lo:lo + chunk].contiguous()
-        eng.load_cells_device(part.data_ptr(), part.shape[0])
-    del rows
-    torch.cuda.synchronize()
+        keep = lambda k: owner_mask(k, eng.hash_seed, world, rank)  # noqa: E731
+    plat.sync()  # (the engine loads on its own stream)
+    n_loaded = 0
+    for j in range(n_pieces):
+        lo = ((first + j) % n_pieces) * piece
+        rows = W.torch_universe_rows(n_keys_total, dev, keep=keep, lo=lo, hi=min(n_keys_total, lo + piece))
+        plat.sync()
+        for c in range(0, rows.shape[0], chunk):
+            part = rows[c:c + chunk].contiguous()
+            eng.load_cells_device(part.data_ptr(), part.shape[0])
+        n_loaded += rows.shape[0]
+        plat.sync()
+        del rows
+        wd.kick()
 
     # ---- synthetic batches, resident in HBM before the timed region --------------------------
+    phase("batches")
     gen = torch.Generator(device=dev).manual_seed(W.SEED + rank)
     cdf = W.torch_zipf_cdf(n_keys_total, dev, args.zipf) if args.zipf > 0 else None
     total_steps = args.warmup + args.steps
@@ -640,7 +752,7 @@ def main():
     del cdf
     verdict = torch.empty(args.batch, dtype=torch.uint8, device=dev)
     verdicts = [verdict] + [torch.empty(args.batch, dtype=torch.uint8, device=dev) for _ in range(3)]
-    torch.cuda.synchronize()
+    plat.sync()
 
     sharded_note = ""
     if sharded and args.sharded_impl == "abi":
@@ -649,18 +761,21 @@ def main():
         # the same routed step, driven from Python — and the line says so in config.parallelism.
         from limitador_amd import sharded_abi
 
+        phase("rl_sharded_create_rccl", args.init_seconds)
         sh, why = None, ""
+        idt = torch.zeros(sharded_abi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
         try:
-            idt = torch.zeros(sharded_abi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
             if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(sharded_abi.unique_id()), dtype=torch.uint8))
+                idt.copy_(torch.frombuffer(bytearray(plat.abi_unique_id()), dtype=torch.uint8))
         except Exception as ex:  # rank 0 could not even make an id: broadcast zeros, everybody fails below
             why = f"unique_id: {ex}"
         dist.broadcast(idt, 0)
-        torch.cuda.synchronize()
+        plat.sync()
+        if not why and not bool(idt.any().item()):
+            why = "rank 0 could not make a communicator id"
         if not why:
             try:
-                sh = sharded_abi.Sharded(eng, world, rank, args.batch, unique_id=bytes(idt.cpu().numpy()))
+                sh = plat.make_abi_sharded(eng, world, rank, args.batch, bytes(idt.cpu().numpy()))
             except Exception as ex:
                 why = f"rl_sharded_create_rccl: {ex}"
         ok = torch.tensor([1 if sh is not None else 0], dtype=torch.int32, device=dev)
@@ -671,25 +786,30 @@ def main():
                 sh = None
             sys.stderr.write(f"bench.py rank {rank}: falling back to --sharded-impl torch ({why or 'another rank failed'})\n")
             args.sharded_impl = "torch"
-            sharded_note = " [fell back from the C-ABI router: " + (why or "another rank failed") + "]"
+            sharded_note = " [fell back from the C-ABI router: " + (str(why)[:160] or "another rank failed") + "]"
+    host_submit = [0.0, 0]
     if sharded and args.sharded_impl == "abi":
+        from limitador_amd import sharded_abi
+
         pending = [0]
         if args.depth == 1:
             def step(i, now):
                 sh.check_and_update(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
+                wd.kick()
         else:
             def step(i, now):
                 sh.submit(batches[i].data_ptr(), args.batch, now, verdicts[i & 3].data_ptr())
                 if sh.in_flight == sharded_abi.MAX_IN_FLIGHT:  # (four: the host enqueues a slice ahead of the device)
                     sh.collect()
+                    wd.kick()
     elif sharded:
-        from limitador_amd.sharded import ShardedEngine
-
-        sh = ShardedEngine(eng, dist.group.WORLD, dev, max_local_hits=args.batch)
+        phase("torch.distributed router")
+        sh = plat.make_torch_sharded(eng, dist.group.WORLD, args.batch)
         pending = [0]
         if args.depth == 1:
             def step(i, now):
                 sh.check_and_update(batches[i], now, verdict)
+                wd.kick()
         else:
             # three ingress slices in flight per rank (routed / applied / returned, see ShardedEngine);
             # every slice has completed when drain() returns
@@ -697,6 +817,7 @@ def main():
                 sh.submit(batches[i], now, verdicts[i % 3])
                 if sh.in_flight == 3:
                     sh.collect()
+                    wd.kick()
     elif args.depth == 1:
         def step(i, now):
             eng.check_and_update_device(batches[i].data_ptr(), args.batch, now, verdict.data_ptr())
@@ -706,8 +827,6 @@ def main():
         # of batch i.  Batches are applied in submission order; every step's batch has completed when the
         # timed region ends (drain()).
         pending = [0]
-
-        host_submit = [0.0, 0]
 
         def step(i, now):
             t_s = time.perf_counter()
@@ -723,6 +842,7 @@ def main():
         if sharded:
             while sh.in_flight:
                 sh.collect()
+                wd.kick()
             if args.sharded_impl == "abi":
                 sh.sync()
         elif args.depth >= 2:
@@ -731,12 +851,14 @@ def main():
                 pending[0] -= 1
 
     now = W.NOW0_US
+    phase("warm-up steps")
     for i in range(args.warmup):
         step(i, now)
         now += 1000
     drain()
     # Per-kernel breakdown, OUTSIDE the timed region: every kernel of a batch launched with its own start / stop
     # events, one blocking call per batch (so each kernel runs alone).  The warm-up batches are replayed.
+    phase("per-kernel breakdown pass")
     eng.kernel_timing(1)
     eng.kernel_timing_read(reset=True)
     # (a dozen batches, cycling through the warm-up ones: the hot-key set and its promotion threshold adapt over a few
@@ -753,20 +875,22 @@ def main():
     # Timed region: events around the dominant kernel only (k_bkt_step), for the roofline.
     eng.kernel_timing(args.timing_mode)
     denied = 0
-    torch.cuda.synchronize()
+    phase("timed region")
+    plat.sync()
     if sharded:
         dist.barrier()
-        torch.cuda.synchronize()
+        plat.sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         step(i, now)
         now += 1000
     drain()
-    torch.cuda.synchronize()
+    plat.sync()
     if sharded:
         dist.barrier()
-        torch.cuda.synchronize()
+        plat.sync()
     dt = time.perf_counter() - t0
+    phase("report")
     kt = eng.kernel_timing_read(reset=True)
     eng.kernel_timing(0)
     if args.depth == 1:
@@ -827,6 +951,10 @@ def main():
                        "batches_in_flight": args.depth if not sharded or args.depth == 1 else (4 if args.sharded_impl == "abi" else 3),
                        "overlap": "partition of batches k+1, k+2 (own stream) beside k_bkt_step of batch k" if (not sharded and args.depth >= 2 and os.environ.get("RL_OVERLAP", "1") != "0") else "none",
                        "denied_in_last_batch": denied,
+                       # routed runs: seconds rank 0 spent in every phase before the report (bring-up included) and what the
+                       # killable RCCL warm-up took; the watchdog's limits that were in force
+                       "bringup_s": (dict(phases, rccl_warmup=warm_note, stall_seconds=args.stall_seconds,
+                                          init_seconds=args.init_seconds, cells_loaded_rank0=n_loaded) if sharded else None),
                        # every engine knob the process saw (rl_engine_create reads RL_*, the ingest layer RLI_*)
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("RL_", "RLI_"))}},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": dom_gbps, "peak": HBM_PEAK_GBPS,
@@ -880,8 +1008,7 @@ def main():
         print(json.dumps(out), flush=True)
     if sharded and args.sharded_impl == "abi":
         sh.close()
-    if sharded:
-        watchdog.cancel()
+    wd.cancel()
     eng.close()
     if sharded:
         dist.destroy_process_group()

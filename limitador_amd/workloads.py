@@ -91,20 +91,20 @@ def _t_splitmix64(x):
     return torch.where(z >= -2, torch.where(z < 0, torch.full_like(z, -3), z), z)
 
 
-def torch_universe_rows(n_keys, device, now_us=NOW0_US, limit=0, seed=SEED, keep=None):
-    """[n,4] int64 tensor laid out as rl_cell_row; keep(idx_tensor)->bool mask selects a shard."""
+def torch_universe_rows(n_keys, device, now_us=NOW0_US, limit=0, seed=SEED, keep=None, lo=0, hi=None):
+    """[n,4] int64 tensor laid out as rl_cell_row for keys [lo, hi) of the universe; keep(key_tensor)->bool mask selects a shard."""
     import torch
 
-    idx = torch.arange(n_keys, dtype=torch.int64, device=device)
+    idx = torch.arange(lo, n_keys if hi is None else hi, dtype=torch.int64, device=device)
     keys = _t_splitmix64(idx)
     if keep is not None:
         m = keep(keys)
         idx, keys = idx[m], keys[m]
     vals = _t_splitmix64(idx ^ seed)
     # unsigned modulo of an int64 bit pattern: split into high/low halves
-    hi = (vals >> 32) & 0xFFFFFFFF
-    lo = vals & 0xFFFFFFFF
-    vals = ((hi % (MAX_VALUE + 1)) * ((1 << 32) % (MAX_VALUE + 1)) + lo % (MAX_VALUE + 1)) % (MAX_VALUE + 1)
+    v_hi = (vals >> 32) & 0xFFFFFFFF
+    v_lo = vals & 0xFFFFFFFF
+    vals = ((v_hi % (MAX_VALUE + 1)) * ((1 << 32) % (MAX_VALUE + 1)) + v_lo % (MAX_VALUE + 1)) % (MAX_VALUE + 1)
     rows = torch.empty((keys.shape[0], 4), dtype=torch.int64, device=device)
     rows[:, 0] = keys
     rows[:, 1] = limit  # limit in the low 32 bits, reserved = 0

@@ -1,0 +1,36 @@
+"""`bench.py --gpus 1 --force-sharded` on the GPU box: the routed run (RCCL warm-up in a subprocess, torch's communicator,
+the C-ABI router's own communicator, route / exchange / apply / return over RCCL at world 1) as the driver would launch it
+for N > 1, in a process of its own on the RELEASE libraries — the line must parse and say what ran (VERDICT r05 next #2d)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["abi", "torch"])
+def test_bench_force_sharded_prints_one_parsable_line(impl, rccl_ready):
+    env = dict(os.environ, LIMITADOR_AMD_LIB="release", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("RL_SHARDED_IMPL", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "3",
+                        "--warmup", "2", "--keys", "1000000", "--batch", "262144", "--secondary", "0", "--cpu-seconds", "0",
+                        "--sharded-impl", impl],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0
+    assert line["value"] == pytest.approx(262144 * 3 / (line["ms_per_step"] * 3 / 1e3), rel=1e-6)
+    par = line["config"]["parallelism"]
+    assert "RCCL all-to-all" in par
+    if impl == "abi":
+        assert "behind the C ABI" in par and "fell back" not in par, par
+    b = line["config"]["bringup_s"]
+    assert b["rccl_warmup"] and b["cells_loaded_rank0"] == 1000000
+    assert 0 <= line["config"]["denied_in_last_batch"] <= 262144
