@@ -105,7 +105,6 @@ struct rl_engine {
     SegTot* d_g_piece = nullptr;
     u32* d_g_reqstop = nullptr;     // [max_batch] per request
     uint8_t* d_g_reached = nullptr;
-    u32* d_g_admdiff = nullptr;     // [gen_cap / 256 + 1]
     uint8_t* d_g_pass = nullptr;    // [2][gen_cap]
     uint8_t* d_g_admitted = nullptr;
     GenStatus* d_gst = nullptr;
@@ -1367,7 +1366,6 @@ static int gen_setup_and_sort(rl_engine* e, const GenCall& c, u32 req0, u32 n_re
     A.pass[0] = e->d_g_pass;
     A.pass[1] = e->d_g_pass + e->gen_cap;
     A.admitted = e->d_g_admitted;
-    A.adm_diff = e->d_g_admdiff;
     A.verdict = c.d_verdict + req0;
     A.first_limited = c.d_first ? c.d_first + req0 : nullptr;
     A.limited_limit = c.d_limited ? c.d_limited + req0 : nullptr;
@@ -1445,6 +1443,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
     // ---- fixpoint rounds: a few at a time, each returning at once if the one before changed nothing; then
     //      k_gen_commit, which applies the pass only if the status block says it is final and fits -------------
     u32 round = 0;
+    bool tail_open = false;  // the group before ended with round `round`'s k_gen_admit alone
     Status h_bst;
     GenStatus h_gst;
     auto cleanup = [&]() -> int {  // leave the rotating scratches clean for whatever batch comes next
@@ -1461,18 +1460,26 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         // group too short 40 + what the next group over-enqueues: the hint follows the last pass, never below GEN_ROUNDS_ENQ.
         const u32 first = std::min(std::max(e->gen_rounds_hint, GEN_ROUNDS_ENQ), std::min<u32>(GEN_ROUNDS_FIRST_MAX, n_req + 2u));
         const u32 n_enq = c.update_mode ? 1u : (round == 0 ? first : GEN_ROUNDS_ENQ_MORE);
-        for (u32 q = 0; q < n_enq; ++q, ++round) {
+        for (u32 q = 0; q < n_enq; ++q) {
             // changed[] slots of one group: round q's k_gen_admit checks slot q (did the round before still change
             // the admitted set?) and writes slot q + 1, which is what the round's own kernels check.  Round 0 has
             // no k_gen_admit and runs unconditionally.
+            // The LAST round of a group is only its k_gen_admit — the look at whether the admitted set still moves, which is all
+            // a converged pass needs of it (its k_gen_piece_sum / k_gen_round would return at once: ~4.7 us apiece for 6 000
+            // workgroups that start and leave).  If it does still move, the next group opens with that round's scan
+            // (`tail_open`: admitted[] is already this round's), unconditionally, like round 0.
+            const bool admit_done = tail_open && q == 0;
             const u32 check = q == 0 ? 0u : q;
-            if (round > 0) {
-                k_gen_admit<<<cdiv(n_req, 256), 256, 0, st>>>(A, round, check, q + 1);
-                k_gen_admit_fold<<<1, 1024, 0, st>>>(A, cdiv(n_req, 256), round, check, q + 1);
+            if (round > 0 && !admit_done) k_gen_admit<<<cdiv(n_req, 256), 256, 0, st>>>(A, round, check, q + 1);
+            if (round > 0 && q + 1 == n_enq) {
+                tail_open = true;
+                break;
             }
-            const u32 run_if = round == 0 ? 0u : q + 1;
+            tail_open = false;
+            const u32 run_if = (round == 0 || admit_done) ? 0u : q + 1;
             k_gen_piece_sum<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A, round, run_if);
             k_gen_round<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A, round, run_if, q + 1);
+            ++round;
         }
         if (A.load_deferred) k_gen_load<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, st>>>(A);
         k_gen_final<<<cdiv(n_req, 256), 256, 0, st>>>(A);
@@ -1502,10 +1509,10 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
             h_gst.overflow = w2 & 1u;
             h_gst.committed = (w2 >> 1) & 1u;
             h_gst.last_slot = 0;
-            h_gst.changed[0] = (w2 >> 2) & 1u;
+            h_gst.changed[0][0] = (w2 >> 2) & 1u;
             h_gst.rounds_run = (w2 >> 8) & 0xFFu;
             h_gst.hot_n = w2 >> 16 == 0xFFFFu ? 0xFFFFFFFFu : w2 >> 16;
-            if (!h_gst.err && !h_gst.overflow && !h_gst.committed && !h_gst.changed[0]) {
+            if (!h_gst.err && !h_gst.overflow && !h_gst.committed && !h_gst.changed[0][0]) {
                 // converged but refused for room (rare): the message wants the exact count
                 HIP_TRY(e, hipMemcpy(&h_gst.n_new, &e->d_gst->n_new, sizeof(u32), hipMemcpyDeviceToHost));
             }
@@ -1525,7 +1532,9 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
                          (unsigned long long)p, n, n_req, round, h_gst.rounds_run, h_gst.overflow, h_gst.committed, h_gst.n_new,
                          h_gst.hot_n, e->hot_threshold, err);
         if (err || h_gst.overflow || h_gst.committed) break;
-        if (c.update_mode || !h_gst.changed[h_gst.last_slot]) break;  // converged, yet not committed: no room
+        bool still_changing = false;
+        for (u32 wd = 0; wd < GEN_CHG_W; ++wd) still_changing |= h_gst.changed[h_gst.last_slot][wd * GEN_CHG_STRIDE] != 0u;
+        if (c.update_mode || !still_changing) break;  // converged, yet not committed: no room
         if (round > n_req + 2 + GEN_ROUNDS_ENQ_MORE) return fail(e, RL_ERR_DEVICE, "general resolver did not converge (bug)");
         // not yet: forget this group's flags, counts and reached marks, go on from the last round's pass flags
         HIP_TRY(e, hipMemsetAsync(e->d_gst, 0, sizeof(GenStatus), st));
@@ -1944,7 +1953,6 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     ALLOC(e->d_g_reqstop, mb * sizeof(u32));
     ALLOC(e->d_g_reached, (size_t)e->gen_cap);
     ALLOC(e->d_g_pass, 2 * (size_t)e->gen_cap);
-    ALLOC(e->d_g_admdiff, (mb / 256 + 2) * sizeof(u32));
     ALLOC(e->d_g_admitted, mb);
     ALLOC(e->d_gst, sizeof(GenStatus));
     ALLOC(e->d_row1, sizeof(CellRow));
@@ -2052,7 +2060,7 @@ void rl_engine_destroy(rl_engine* e) {
     void* ptrs[] = {e->table,      e->d_limits,   e->d_hits,     e->d_req_off, e->d_verdict, e->d_first,
                     e->d_remaining, e->d_expires, e->d_status,   e->d_total,    e->d_route_cnt,
                     e->d_hit_req,  e->d_req_delta, e->d_g_shits,  e->d_g_seginfo, e->d_g_segtot, e->d_g_piece, e->d_g_reqstop,
-                    e->d_g_reached, e->d_g_pass,  e->d_g_admdiff, e->d_g_admitted, e->d_gst,      e->d_row1,
+                    e->d_g_reached, e->d_g_pass,  e->d_g_admitted, e->d_gst,      e->d_row1,
                     e->d_bk_hist,  e->d_bk_total, e->d_bk_ranges, e->d_bk_hits,  e->d_bk_req, e->d_tiny_hits, e->d_chunk_tab,
                     e->d_hot,     e->d_hot_param, e->d_bs,       e->d_hot_arrive, e->d_cmark, e->d_w_blob, e->d_w_ns, e->d_w_lit, e->d_w_prefix, e->d_w_bytes, e->d_w_off, e->d_w_status, e->d_w_slot_h, e->d_hit_check, e->d_resp_blob, e->d_resp_frag, e->d_resp_off, e->d_resp_bytes, e->d_runs,    e->d_items,  e->d_apply_trace, e->d_sweep_st,
                     e->d_match_limits, e->d_match_conds, e->d_match_ns_off, e->d_m_ns, e->d_m_delta, e->d_m_ent_off,

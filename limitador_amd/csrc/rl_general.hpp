@@ -98,8 +98,20 @@ struct GenStatus {
     u32 committed;   // k_gen_commit applied the pass (converged, no error, the new cells fit)
     u32 collide;     // ERRBIT_KEY_COLLISION: ~(the smallest hit index, relative to the pass, whose check word disagrees); 0 = none
     u32 pad2[2];
-    u32 changed[GEN_ROUNDS_MAX + 2];  // [slot]: that round changed a pass flag
+    // [slot]: that round changed the admitted set — as GEN_CHG_W words, each on a 128-byte line of its own, word =
+    // (workgroup of k_gen_admit) % GEN_CHG_W.  ONE word that thousands of workgroups read or write costs ~3 ns apiece in the
+    // L2 (k_gen_admit 6 -> 48 us when it was one; 64 words on two lines written with atomicOr by the 3 900 workgroups of a
+    // round that changes nearly every request: 10 -> 48 us again, profiles/r06c); 16 lines take 1/16 of the writers each, in
+    // parallel, as plain stores of 1 — and the launch that folded per-workgroup flags into one word (k_gen_admit_fold, ~5 us
+    // per round) is gone.  Readers OR the words (gen_changed: one per lane).
+    u32 changed[GEN_ROUNDS_MAX + 2][16 * 32];
 };
+constexpr u32 GEN_CHG_W = 16, GEN_CHG_STRIDE = 32;
+// Did the round that wrote `slot` change anything?  Wave-wide (every lane of the wave must call it), uniform result.
+__device__ __forceinline__ bool gen_changed(const GenStatus* g, u32 slot) {
+    const u32 lane = threadIdx.x & 63u;
+    return __any((int)(lane < GEN_CHG_W && g->changed[slot][lane * GEN_CHG_STRIDE] != 0u)) != 0;
+}
 
 struct GenArgs {
     Cell* table;
@@ -134,7 +146,6 @@ struct GenArgs {
     uint8_t* reached;        // per segment
     uint8_t* pass[2];
     uint8_t* admitted;       // per request, by the previous round (k_gen_admit)
-    u32* adm_diff;           // per workgroup of k_gen_admit: a request's admission changed
     const uint8_t* admitted_hit;  // phased form (rl_gen_round_device): admission per HIT, decided by the host; else null
     const uint8_t* reached_hit;   // phased form (rl_gen_count_device): did the request's walk get to this hit; else null
     uint8_t* verdict;        // outputs, already offset to the pass
@@ -523,7 +534,7 @@ __device__ __forceinline__ uint8_t gen_adm_byte(const GenArgs& A, const uint8_t*
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gen_admit(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
     if (A.pst->err || A.gst->overflow || round == 0) return;
-    if (check_slot && !A.gst->changed[check_slot]) return;  // converged already
+    if (check_slot && !gen_changed(A.gst, check_slot)) return;  // converged already
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         A.gst->last_slot = write_slot;
         A.gst->last_round = round - 1;  // the flags in force unless this round runs (the status block may be fresh:
@@ -549,20 +560,10 @@ __global__ __launch_bounds__(256) void k_gen_admit(GenArgs A, u32 round, u32 che
             for (u32 q = b; q < e; ++q) pass_next[q] = 1;
         }
     }
-    // Thousands of workgroups may have something to report, and one word that all of them read or write costs
-    // ~3 ns apiece in the L2 (measured: 48 us for this kernel): one flag per workgroup, folded by k_gen_admit_fold.
+    // Only a workgroup that HAS a difference says so, into one of GEN_CHG_W words (GenStatus::changed); the status block is
+    // zero when the group of rounds starts, so a slot nobody wrote reads "nothing changed".
     const int any = __syncthreads_or(differs ? 1 : 0);
-    if (threadIdx.x == 0) A.adm_diff[blockIdx.x] = any ? 1u : 0u;
-}
-
-// changed[write_slot] = OR of the workgroups' flags of the k_gen_admit before it.
-__global__ __launch_bounds__(1024) void k_gen_admit_fold(GenArgs A, u32 n_blocks, u32 round, u32 check_slot, u32 write_slot) {
-    if (A.pst->err || A.gst->overflow || round == 0) return;
-    if (check_slot && !A.gst->changed[check_slot]) return;
-    u32 any = 0;
-    for (u32 b = threadIdx.x; b < n_blocks; b += 1024) any |= A.adm_diff[b];
-    any = __syncthreads_or((int)any) ? 1u : 0u;
-    if (threadIdx.x == 0) A.gst->changed[write_slot] = any;
+    if (threadIdx.x == 0 && any) A.gst->changed[write_slot][(blockIdx.x % GEN_CHG_W) * GEN_CHG_STRIDE] = 1u;
 }
 
 __device__ __forceinline__ u64 gen_delta(const GenArgs& A, const SHit& h) {
@@ -589,7 +590,7 @@ __device__ __forceinline__ Run run_join(const Run& a, const Run& b) {  // a then
 __global__ __launch_bounds__(GS_BLOCK) void k_gen_piece_sum(GenArgs A, u32 round, u32 check_slot) {
     __shared__ Run s_run[GS_WAVES];
     if (A.pst->err || A.gst->overflow) return;
-    if (check_slot && !A.gst->changed[check_slot]) return;  // converged: the round before changed nothing
+    if (check_slot && !gen_changed(A.gst, check_slot)) return;  // converged: the round before changed nothing
     const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u32 k = blockIdx.x;
@@ -648,7 +649,8 @@ struct GenRoundLds {
     u32 wflag[GS_WAVES];  // a run starts inside the wave (the aggregate does not pass through)
     u32 wlast[GS_WAVES];  // segment of the wave's last hit
     u32 changed;
-    Run carry;            // hot chunks: the piece carry, broadcast
+    u32 head;             // segment of the piece's first record
+    Run carry;            // the piece carry, broadcast
     Run out_run;          // the run that is open at the end of the piece ...
     u32 out_seg;          // ... and its segment (the carry of a long bucket's next piece)
 };
@@ -657,8 +659,7 @@ struct GenRoundLds {
 // every hit and nothing else (no pass flag, no segment total).
 template <bool LOAD_ONLY>
 __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t* __restrict__ pass_prev,
-                                                uint8_t* __restrict__ pass_cur, u32 lo, u32 n, Run carry, u32 carry_seg,
-                                                GenRoundLds& S) {
+                                                uint8_t* __restrict__ pass_cur, u32 k, u32 lo, u32 n, GenRoundLds& S) {
     constexpr int PER = GS_MAX / GS_BLOCK;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     SHit h[PER];
@@ -690,6 +691,42 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
         si_a[i] = sp[0];
         si_b[i] = sp[1];
     }
+    // ---- the piece's carry ------------------------------------------------------------------------------------
+    // The piece's first record says whether it opens inside a segment (round 5 read it by itself, ahead of everything: one
+    // more round trip in front of every workgroup's chain; now thread 0's own first record is that record, and the pieces'
+    // sums are requested while the gathers above are still in flight).  If it does: what the segment's admitted hits in the
+    // pieces before add = the in-order fold of those pieces' sums (all of them end inside this segment).
+    if (tid == 0) {
+        S.head = raw[0].x;
+        S.carry = Run{0, 0, 0};
+    }
+    __syncthreads();
+    const u32 head = S.head;  // (uniform)
+    u32 carry_seg = 0xFFFFFFFEu;
+    if (head < lo) {
+        carry_seg = head;
+        if (tid < 64) {
+            const u32 j0 = head / (u32)GS_MAX;
+            const u32 n_before = k - j0;
+            const u32 per = (n_before + 63) / 64;
+            Run acc{0, 0, 0};
+            for (u32 q = lane * per; q < (lane + 1) * per && q < n_before; ++q) {
+                const SegTot t = A.piece_sum[j0 + q];
+                acc = run_join(acc, Run{t.sum, t.last, t.cnt});
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                Run o;
+                o.sum = __shfl_up(acc.sum, off);
+                o.last = __shfl_up(acc.last, off);
+                o.cnt = __shfl_up(acc.cnt, off);
+                if ((int)lane >= off) acc = run_join(o, acc);
+            }
+            if (lane == 63) S.carry = acc;
+        }
+        __syncthreads();
+    }
+    const Run carry = S.carry;
     uint4 lim[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) lim[i] = *reinterpret_cast<const uint4*>(&A.limits[si_b[i].y & ~SIMPLE_FLAG]);
@@ -811,56 +848,27 @@ __device__ __forceinline__ void gen_round_piece(const GenArgs& A, const uint8_t*
 
 template <bool LOAD_ONLY>
 __device__ __forceinline__ void gen_round_body(const GenArgs& A, const uint8_t* pass_prev, uint8_t* pass_cur, GenRoundLds& S) {
-    const u32 tid = threadIdx.x, lane = tid & 63u;
     // One workgroup per piece of GS_MAX positions (k_gen_piece_sum): every piece of every bucket at once — a
     // bucket that skew made long no longer sets the duration of the round.
     const u32 k = blockIdx.x;
     const u32 lo = k * (u32)GS_MAX;
     const u32 n = A.n_hits - lo < (u32)GS_MAX ? A.n_hits - lo : (u32)GS_MAX;
-    const u32 head = A.s_hits[lo].seg;  // (uniform)
-    u32 carry_seg = 0xFFFFFFFEu;
-    if (tid == 0) S.carry = Run{0, 0, 0};
-    __syncthreads();
-    if (head < lo) {
-        // the piece opens inside a segment: what the segment's admitted hits in the pieces before add = the
-        // in-order fold of those pieces' sums (all of them end inside this segment)
-        carry_seg = head;
-        if (tid < 64) {
-            const u32 j0 = head / (u32)GS_MAX;
-            const u32 n_before = k - j0;
-            const u32 per = (n_before + 63) / 64;
-            Run acc{0, 0, 0};
-            for (u32 q = lane * per; q < (lane + 1) * per && q < n_before; ++q) {
-                const SegTot t = A.piece_sum[j0 + q];
-                acc = run_join(acc, Run{t.sum, t.last, t.cnt});
-            }
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                Run o;
-                o.sum = __shfl_up(acc.sum, off);
-                o.last = __shfl_up(acc.last, off);
-                o.cnt = __shfl_up(acc.cnt, off);
-                if ((int)lane >= off) acc = run_join(o, acc);
-            }
-            if (lane == 63) S.carry = acc;
-        }
-        __syncthreads();
-    }
-    gen_round_piece<LOAD_ONLY>(A, pass_prev, pass_cur, lo, n, S.carry, carry_seg, S);
+    gen_round_piece<LOAD_ONLY>(A, pass_prev, pass_cur, k, lo, n, S);
 }
 
 __global__ __launch_bounds__(GS_BLOCK) void k_gen_round(GenArgs A, u32 round, u32 check_slot, u32 write_slot) {
     __shared__ GenRoundLds S;
     if (A.pst->err || A.gst->overflow) return;
-    if (check_slot && !A.gst->changed[check_slot]) return;  // converged: the round before changed nothing
+    if (check_slot && !gen_changed(A.gst, check_slot)) return;  // converged: the round before changed nothing
     const uint8_t* pass_prev = (round == 0 || A.update_mode) ? nullptr : A.pass[(round - 1) & 1u];
     uint8_t* pass_cur = A.pass[round & 1u];
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         A.gst->last_round = round;
         atomicAdd(&A.gst->rounds_run, 1u);
-        if (round == 0) {  // no k_gen_admit before round 0: round 1 always follows
+        if (check_slot == 0) {  // no k_gen_admit of this group before this round (round 0; a round whose k_gen_admit closed
+                                // the group before): the next round always follows
             A.gst->last_slot = write_slot;
-            A.gst->changed[write_slot] = 1u;
+            A.gst->changed[write_slot][0] = 1u;
         }
     }
     gen_round_body<false>(A, pass_prev, pass_cur, S);
@@ -991,7 +999,7 @@ __global__ __launch_bounds__(256) void k_gen_commit(GenArgs A, u32 room) {
     {
         const GenStatus* g = A.gst;
         if (A.pst->err || g->err || g->overflow || g->n_new > room) return;
-        if (!A.update_mode && g->changed[g->last_slot]) return;  // not converged yet
+        if (!A.update_mode && gen_changed(g, g->last_slot)) return;  // not converged yet
     }
     if (threadIdx.x == 0) {
         s_n = 0;
@@ -1512,11 +1520,11 @@ __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32
 __global__ __launch_bounds__(256) void k_gen_post(GenStatus* gst, const Status* __restrict__ pst, u32* host_word, u32 seq,
                                                   u32* __restrict__ scratch_words, u32 n_scratch_words) {
     __shared__ u32 s_clean;
+    const u32 changed = gen_changed(gst, gst->last_slot) ? 1u : 0u;
     if (threadIdx.x == 0) {
         const u32 err = gst->err | pst->err;
         const u32 hot = gst->hot_n > 0xFFFEu ? 0xFFFFu : gst->hot_n;
         const u32 rr = gst->rounds_run > 0xFFu ? 0xFFu : gst->rounds_run;
-        const u32 changed = gst->changed[gst->last_slot] ? 1u : 0u;
         const u32 flags = (gst->overflow ? 1u : 0u) | (gst->committed ? 2u : 0u) | (changed << 2) | (rr << 8) | (hot << 16);
         // a pass that was applied leaves nothing the host still wants from the device: the status block and the rotating
         // scratch blocks are zeroed HERE for whatever batch comes next (two fill commands the host used to enqueue once it
@@ -1528,8 +1536,9 @@ __global__ __launch_bounds__(256) void k_gen_post(GenStatus* gst, const Status* 
     __syncthreads();
     if (!s_clean) return;
     for (u32 q = threadIdx.x; q < n_scratch_words; q += 256) scratch_words[q] = 0u;
-    u32* g = reinterpret_cast<u32*>(gst);
-    for (u32 q = threadIdx.x; q < (u32)(sizeof(GenStatus) / sizeof(u32)); q += 256) g[q] = 0u;
+    static_assert(sizeof(GenStatus) % 16 == 0, "GenStatus is zeroed 16 bytes at a time");
+    uint4* g = reinterpret_cast<uint4*>(gst);
+    for (u32 q = threadIdx.x; q < (u32)(sizeof(GenStatus) / 16); q += 256) g[q] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 }  // namespace rl

