@@ -323,6 +323,15 @@ typedef struct {
 } rl_match_limit;
 int32_t rl_match_table_set(rl_engine *e, const rl_match_limit *limits, uint32_t n_limits,
                            const rl_match_cond *conds, uint32_t n_conds, uint32_t n_namespaces);
+/* The same with limits of up to EIGHT variables (limit.rs:133-148 resolves any number): a row with n_vars > 2 keeps the
+ * descriptor key ids of its variables, in variable-name order, in more_vars[var_key[0] .. var_key[0] + n_vars).  Such a
+ * table is served by the hashed-key wire path only (rl_wire_match_and_check_batch / rl_wire_serve_batch: every variable's
+ * value is hashed into the counter's key); the dictionary entries (rl_match_and_check_batch*) refuse it, because the
+ * packed exact key has room for two value ids (rl_match_key) — a caller with exact keys folds the variables of such a
+ * limit into one synthetic variable, as include/rl_ingest.h's rli_compile does. */
+int32_t rl_match_table_set_ex(rl_engine *e, const rl_match_limit *limits, uint32_t n_limits,
+                              const rl_match_cond *conds, uint32_t n_conds, uint32_t n_namespaces,
+                              const uint32_t *more_vars, uint32_t n_more_vars);
 /* The key the device derives for (limit, variable values): what rl_add_counter must be given for a
  * limit without variables, and what identifies a counter in rl_get_counters / rl_dump_cells rows. */
 uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t v1);
@@ -372,8 +381,10 @@ int32_t rl_match_batch_op(rl_engine *e, int32_t op, const uint32_t *req_ns, cons
  *
  * rl_wire_table_set: the strings behind the ids of the installed match table (call after rl_match_table_set; the table
  * must have the slot form: at most 8 distinct descriptor keys, 64 limits per namespace) — all inside `blob`
- * (<= 8192 bytes): ns[namespace id] (ns[0] is the namespace without limits), keys[key id], vals[value id] for every id
- * the conditions use (<= 512), limit_prefix[2 * limit id ..] = rl_kh_bytes of the limit's canonical prefix, and
+ * (<= 8192 bytes): ns[namespace id] (ns[0] is the namespace without limits), keys[key id] — the key's own bytes, and in
+ * bits 24..31 of its `len` the index i of the descriptor the key is read from (the reference binds the whole list
+ * `descriptors`, one map per descriptor: envoy_rls/server.rs:121-137; `descriptors[1].y` is key "y" with i = 1) —
+ * vals[value id] for every id the conditions use (<= 512), limit_prefix[2 * limit id ..] = rl_kh_bytes of the limit's canonical prefix, and
  * hash_key[2] = the 128-bit secret every hash of this path is keyed with (include/rl_keyhash.h: the prefixes must have
  * been hashed under the same key; whoever else derives keys for this table — another front-end, a restart — needs it). */
 typedef struct {

@@ -6,11 +6,12 @@
  *
  *   limits    Limit::new(namespace, max_value, seconds, conditions, variables) (limit.rs:54-76) with
  *             conditions   <key ref> == 'value'   |   <key ref> != 'value'
- *             and variables  <key ref>  (at most two per limit), where a key ref is what the caller's Context
+ *             and variables  <key ref>  (at most eight per limit), where a key ref is what the caller's Context
  *             can resolve (rli_set_binding):
- *               RLI_BIND_DESCRIPTORS (default: the transports bind only the list `descriptors`,
- *                   envoy_rls/server.rs:136-137, http_api/server.rs:140-141):
- *                   descriptors[0]['key'] | descriptors[0]["key"] | descriptors[0].ident
+ *               RLI_BIND_DESCRIPTORS (default: the transports bind only the list `descriptors` — the WHOLE list, one
+ *                   map per descriptor: envoy_rls/server.rs:121-137, http_api/server.rs:140-141):
+ *                   descriptors[N]['key'] | descriptors[N]["key"] | descriptors[N].ident      for N = 0 .. 63
+ *                   (`descriptors[1].y == '2'`: envoy_rls/server.rs:520, kuadrant_service.rs:415)
  *               RLI_BIND_ROOT (library callers, Context::from(HashMap), limit/cel.rs:81-96,153-156):  ident
  *             -> rows of rl_limits_set + the compiled match table of rl_match_table_set.  Anything else —
  *             a bare identifier under RLI_BIND_DESCRIPTORS included: it is unbound there and the reference
@@ -20,7 +21,11 @@
  *             (limit.rs:177-214; Predicate / Expression compare by source): two spellings of one predicate
  *             are two limits with two counters; adding a limit with a known identity returns its id and
  *             refreshes max_value (what update_limit does).
- *   requests  namespace + descriptors[0] entries + delta -> req_ns / CSR (ent_key, ent_val) / req_delta.
+ *             A limit with more than two variables: with RLI_KEYS_HASHED the device hashes every variable's value into
+ *             the counter's key; with RLI_KEYS_EXACT the packed key has room for two value ids, so the ingest interns the
+ *             TUPLE of the values (exact, like every string) and the limit reads that one id on the device.
+ *   requests  namespace + the entries of every descriptor some limit reads + delta -> req_ns / CSR (ent_key, ent_val) /
+ *             req_delta (an entry's key id stands for the pair (descriptor index, key)).
  *             Strings are interned exactly (two different strings never share an id).  A namespace
  *             without limits maps to namespace id 0, which never has limits: no counter, not limited
  *             (lib.rs:434-440).  Values first seen in a request are interned on the fly: an id the
@@ -72,16 +77,19 @@ void rli_batch_clear(rli_ingest *g);
 /* -> index of the request in the batch.  keys/values: the entries of descriptors[0], in order. */
 int32_t rli_batch_add(rli_ingest *g, const char *namespace_, const char *const *keys, const char *const *values,
                       uint32_t n_entries, uint32_t delta);
+/* The same with the whole descriptor list: descriptor d's entries are keys / values [desc_off[d], desc_off[d + 1])
+ * (desc_off[n_descriptors] = the number of entries); inside one descriptor a repeated key keeps its last value. */
+int32_t rli_batch_add_descriptors(rli_ingest *g, const char *namespace_, uint32_t n_descriptors, const uint32_t *desc_off,
+                                  const char *const *keys, const char *const *values, uint32_t delta);
 /* The same from the wire: one serialized envoy.service.ratelimit.v3.RateLimitRequest
  * (rls.proto:38-53: domain = 1, descriptors = 2, hits_addend = 3; ratelimit.proto:65-95: entries = 1 of
  * (key = 1, value = 2)), interpreted like ShouldRateLimit does (envoy_rls/server.rs:97-137): namespace =
- * domain, the context of descriptors[0] is its entries with the LAST value of a repeated key
- * (HashMap::insert), hits_addend 0 means 1.  Further descriptors are not looked at (limits that read
- * them are RLI_HOST_ONLY).  -> request index, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID for a malformed
+ * domain, the context is one map per descriptor — its entries with the LAST value of a repeated key
+ * (HashMap::insert) — hits_addend 0 means 1.  -> request index, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID for a malformed
  * message (nothing is added).  Malformed is what prost — the reference's decoder — answers a decode error for: truncated
  * or overlong fields, a KNOWN field (domain, descriptors, hits_addend, entries, Entry.key, Entry.value) that arrives with
  * another wire type than its declared one, a `string` (domain, key, value) that is not UTF-8.  Unknown fields are skipped
- * by wire type like prost does.  Still more lenient than prost, on purpose: descriptors behind the first one and the nested
+ * by wire type like prost does.  Still more lenient than prost, on purpose: descriptors no limit reads and the nested
  * messages this path never reads (RateLimitOverride, HitsAddend) are skipped by wire type without being validated — a
  * message that is malformed only THERE is served where the reference would have refused it.  The device reader
  * (limitador_amd/csrc/rl_wire.hpp, RLI_KEYS_HASHED) has the same rules. */

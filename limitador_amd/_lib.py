@@ -96,6 +96,7 @@ def _declare(lib):
     _sig(lib, "rl_merge_cells", C.c_int32, [p, C.c_uint32, C.c_uint32, p, C.c_uint64, C.c_uint64])
     _sig(lib, "rl_export_local", C.c_int32, [p, C.c_uint64, p, C.c_uint64, u64p])
     _sig(lib, "rl_match_table_set", C.c_int32, [p, p, C.c_uint32, p, C.c_uint32, C.c_uint32])
+    _sig(lib, "rl_match_table_set_ex", C.c_int32, [p, p, C.c_uint32, p, C.c_uint32, C.c_uint32, p, C.c_uint32])
     _sig(lib, "rl_match_key", C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32])
     _sig(lib, "rl_match_and_check_batch", C.c_int32,
          [p, p, p, p, p, p, C.c_uint32, C.c_uint64, C.c_int32, p, p, p, p, C.c_uint32, u32p, p, p])

@@ -113,24 +113,59 @@ static bool cel_ident(const std::string& s, size_t& i, std::string* out) {
     *out = s.substr(b, i - b);
     return true;
 }
+// The name a (descriptor index, key) pair goes by in the dictionaries and tables: the key itself for descriptors[0] (the
+// common case: no string is built per entry), "\x1f<index>\x1f<key>" for the others — and for a descriptors[0] key that
+// itself starts with \x1f, so that the mapping stays injective.
+constexpr uint32_t MAX_DESC_INDEX = 63;  // descriptors[0..63] may be read by limits (a bit mask of the ones that are)
+std::string desc_key_name(uint32_t desc, const char* key, size_t len) {
+    if (desc == 0 && (len == 0 || key[0] != '\x1f')) return std::string(key, len);
+    std::string o = "\x1f" + std::to_string(desc) + "\x1f";
+    o.append(key, len);
+    return o;
+}
+// ... and back: -> (descriptor index, offset of the key's own bytes)
+void desc_key_split(const std::string& name, uint32_t* desc, size_t* key_off) {
+    *desc = 0;
+    *key_off = 0;
+    if (name.empty() || name[0] != '\x1f') return;
+    const size_t e = name.find('\x1f', 1);
+    if (e == std::string::npos) return;
+    *desc = (uint32_t)strtoul(name.substr(1, e - 1).c_str(), nullptr, 10);
+    *key_off = e + 1;
+}
+
 bool parse_key_ref(const std::string& s, size_t& i, std::string* key, int binding) {
     skip_ws(s, i);
     if (binding == RLI_BIND_ROOT) return cel_ident(s, i, key);
-    static const std::string pre = "descriptors[0]";
+    // descriptors[N] — the transports bind the whole list (envoy_rls/server.rs:121-137: one map per descriptor), so a limit
+    // may read any of them: `descriptors[1].y == '2'` (envoy_rls/server.rs:520, kuadrant_service.rs:415)
+    static const std::string pre = "descriptors[";
     if (s.compare(i, pre.size(), pre) != 0) return false;
     i += pre.size();
     skip_ws(s, i);
+    const size_t d0 = i;
+    while (i < s.size() && std::isdigit((unsigned char)s[i])) ++i;
+    if (i == d0 || i - d0 > 3) return false;
+    const uint32_t desc = (uint32_t)strtoul(s.substr(d0, i - d0).c_str(), nullptr, 10);
+    if (desc > MAX_DESC_INDEX) return false;
+    skip_ws(s, i);
+    if (i >= s.size() || s[i] != ']') return false;
+    ++i;
+    skip_ws(s, i);
+    std::string k;
     if (i < s.size() && s[i] == '[') {
         ++i;
-        if (!parse_quoted(s, i, key)) return false;
+        if (!parse_quoted(s, i, &k)) return false;
         skip_ws(s, i);
         if (i >= s.size() || s[i] != ']') return false;
         ++i;
-        return true;
+    } else {
+        if (i >= s.size() || s[i] != '.') return false;
+        ++i;
+        if (!cel_ident(s, i, &k)) return false;
     }
-    if (i >= s.size() || s[i] != '.') return false;
-    ++i;
-    return cel_ident(s, i, key);
+    *key = desc_key_name(desc, k.data(), k.size());
+    return true;
 }
 
 bool parse_condition(const std::string& s, Cond* c, int binding) {
@@ -195,7 +230,7 @@ struct Wire {
 // (ADVICE r04): a KNOWN field with another wire type than its declared one is a DecodeError ("invalid wire type"), and a
 // `string` field must be valid UTF-8 (Rust's str::from_utf8: no overlong forms, no surrogates, nothing above U+10FFFF).
 // A message the reference would have answered with a gRPC decode error must not create a counter here.  (What stays more
-// lenient than prost, documented in rl_ingest.h: descriptors behind the first one and the nested messages this path does
+// lenient than prost, documented in rl_ingest.h: descriptors no limit reads and the nested messages this path does
 // not read — RateLimitOverride, HitsAddend — are skipped by wire type without being validated.)
 bool utf8_ok(const uint8_t* p, const uint8_t* end) {
     while (p < end) {
@@ -239,8 +274,11 @@ bool parse_entry(Wire w, std::string* key, std::string* value) {
     return true;
 }
 
-// RateLimitDescriptor { repeated Entry entries = 1; RateLimitOverride limit = 2 }
-bool parse_descriptor(Wire w, std::vector<std::pair<std::string, std::string>>* entries) {
+// RateLimitDescriptor { repeated Entry entries = 1; RateLimitOverride limit = 2 } — descriptor number `desc` of the request:
+// its entries are appended under their (descriptor, key) names; inside ONE descriptor a repeated key keeps its LAST value
+// (HashMap::insert, envoy_rls/server.rs:121-128)
+bool parse_descriptor(Wire w, uint32_t desc, std::vector<std::pair<std::string, std::string>>* entries) {
+    const size_t first = entries->size();
     while (!w.done()) {
         uint64_t tag;
         if (!w.varint(&tag)) return false;
@@ -250,10 +288,11 @@ bool parse_descriptor(Wire w, std::vector<std::pair<std::string, std::string>>* 
             if (wt != 2 || !w.bytes(&sub)) return false;
             std::string k, v;
             if (!parse_entry(sub, &k, &v)) return false;
-            bool replaced = false;  // HashMap::insert: a repeated key keeps its LAST value
-            for (auto& kv : *entries)
-                if (kv.first == k) {
-                    kv.second = v;
+            if (desc != 0 || (!k.empty() && k[0] == '\x1f')) k = desc_key_name(desc, k.data(), k.size());
+            bool replaced = false;
+            for (size_t q = first; q < entries->size(); ++q)
+                if ((*entries)[q].first == k) {
+                    (*entries)[q].second = v;
                     replaced = true;
                 }
             if (!replaced) entries->emplace_back(std::move(k), std::move(v));
@@ -281,7 +320,19 @@ struct rli_ingest {
     // RLI_KEYS_HASHED (rli_set_key_mode): no request ever touches the dictionaries — the device decodes the messages,
     // compares the table's strings as bytes and keys every counter by a hash of its canonical key bytes (rl_keyhash.h)
     int key_mode = RLI_KEYS_EXACT;
+    uint64_t desc_mask = 1;          // descriptor indices some limit reads (bit i = descriptors[i]; descriptors[0] always)
+    // RLI_KEYS_EXACT, limits with more than two variables: the packed key has room for two value ids (rl_match_key), so such
+    // a limit reads ONE synthetic descriptor key on the device, whose value is the id of the TUPLE of its variables' values —
+    // interned here like every other string (exact: two tuples never share an id), added to the request when the request
+    // carries all of the limit's variables.
+    struct Composite {
+        uint32_t limit, syn_key;          // the limit's id; key id of its synthetic entry
+        std::vector<uint32_t> var_keys;   // key ids of its variables, in variable-name order
+    };
+    std::vector<std::vector<Composite>> composites;  // [namespace id]
+    std::map<std::vector<uint32_t>, uint32_t> tuple_ids;  // (limit, value ids...) -> tuple id
     std::vector<rl_h128> prefix;     // [limit id]: hash of the limit's canonical prefix (compiled)
+    std::vector<uint32_t> more_vars; // compiled: descriptor key ids of the limits with more than two variables (RLI_KEYS_HASHED)
     rl_hkey hash_key{0, 0};          // the secret every hash of this mode is keyed with (rl_keyhash.h): random at rli_create,
                                      // rli_set_hash_key to share it between front-ends / bring it back with a snapshot
     // batch
@@ -490,17 +541,25 @@ int32_t rli_add_limit(rli_ingest* g, const char* ns, uint64_t max_value, uint64_
     for (const std::string& src : L.cond_src) {
         Cond c;
         if (!parse_condition(src, &c, g->binding))
-            return gfail(g, RLI_HOST_ONLY, "condition `%s` is not descriptors[0]['key'] ==|!= 'value': stays on the host",
-                         src.c_str());
+            return gfail(g, RLI_HOST_ONLY, "condition `%s` is not descriptors[N]['key'] ==|!= 'value' (N <= %u): stays on the host",
+                         src.c_str(), MAX_DESC_INDEX);
         L.conds.push_back(c);
     }
     for (const std::string& src : L.var_src) {
         std::string k;
         if (!parse_variable(src, &k, g->binding))
-            return gfail(g, RLI_HOST_ONLY, "variable `%s` is not descriptors[0]['key']: stays on the host", src.c_str());
+            return gfail(g, RLI_HOST_ONLY, "variable `%s` is not descriptors[N]['key'] (N <= %u): stays on the host", src.c_str(), MAX_DESC_INDEX);
         L.vars.push_back(k);
     }
-    if (L.vars.size() > 2) return gfail(g, RLI_HOST_ONLY, "more than two variables: stays on the host");
+    if (L.vars.size() > 8) return gfail(g, RLI_HOST_ONLY, "more than eight variables: stays on the host");
+    auto reads = [&](const std::string& name) {  // the descriptors this limit reads are decoded from now on
+        uint32_t desc;
+        size_t off;
+        desc_key_split(name, &desc, &off);
+        g->desc_mask |= 1ull << desc;
+    };
+    for (const Cond& c : L.conds) reads(c.key);
+    for (const std::string& v : L.vars) reads(v);
     auto it = g->by_identity.find(L.identity());
     if (it != g->by_identity.end()) {  // same limit (limit.rs:177-214): max_value is not identity
         g->limits[it->second].max_value = max_value;
@@ -558,6 +617,15 @@ int32_t rli_compile(rli_ingest* g) try {
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ns_of[a] < ns_of[b]; });
     g->table.clear();
     g->conds.clear();
+    g->more_vars.clear();
+    g->composites.assign(g->ns_ids.ids.size(), {});
+    auto key_id = [&](const std::string& name) {
+        uint32_t desc;
+        size_t off;
+        desc_key_split(name, &desc, &off);
+        g->desc_mask |= 1ull << desc;
+        return g->key_ids.intern(name);
+    };
     for (uint32_t id : order) {
         const LimitSpec& L = g->limits[id];
         rl_match_limit m{};
@@ -566,11 +634,26 @@ int32_t rli_compile(rli_ingest* g) try {
         m.cond_off = (uint32_t)g->conds.size();
         m.n_cond = (uint32_t)L.conds.size();
         m.n_vars = (uint32_t)L.vars.size();
-        for (size_t q = 0; q < L.vars.size(); ++q) m.var_key[q] = g->key_ids.intern(L.vars[q]);
+        if (L.vars.size() <= 2) {
+            for (size_t q = 0; q < L.vars.size(); ++q) m.var_key[q] = key_id(L.vars[q]);
+        } else if (g->key_mode == RLI_KEYS_HASHED) {
+            // the device hashes every variable's value itself: the key ids travel beside the table (rl_match_table_set_ex)
+            m.var_key[0] = (uint32_t)g->more_vars.size();
+            for (const std::string& v : L.vars) g->more_vars.push_back(key_id(v));
+        } else {
+            // exact keys: ONE synthetic variable whose value is the id of the tuple of the real ones (rli_ingest::Composite)
+            rli_ingest::Composite c;
+            c.limit = id;
+            c.syn_key = g->key_ids.intern(std::string("\x1e") + std::to_string(id));
+            for (const std::string& v : L.vars) c.var_keys.push_back(key_id(v));
+            g->composites[m.ns].push_back(c);
+            m.n_vars = 1;
+            m.var_key[0] = c.syn_key;
+        }
         for (const Cond& c : L.conds) {
             const uint32_t v = g->val_ids.intern(c.value);
             if (v >> 26) return gfail(g, RL_ERR_INVALID, "more than 2^26 distinct values");
-            g->conds.push_back(rl_match_cond{g->key_ids.intern(c.key), c.op, v});
+            g->conds.push_back(rl_match_cond{key_id(c.key), c.op, v});
         }
         g->table.push_back(m);
     }
@@ -593,8 +676,8 @@ int32_t rli_install(rli_ingest* g, rl_engine* e) try {
     }
     int32_t rc = rl_limits_set(e, 0, g->rows.data(), (uint32_t)g->rows.size());
     if (rc) return gfail(g, rc, "rl_limits_set: %s", rl_last_error(e));
-    rc = rl_match_table_set(e, g->table.data(), (uint32_t)g->table.size(), g->conds.data(), (uint32_t)g->conds.size(),
-                            (uint32_t)g->ns_ids.ids.size());
+    rc = rl_match_table_set_ex(e, g->table.data(), (uint32_t)g->table.size(), g->conds.data(), (uint32_t)g->conds.size(),
+                               (uint32_t)g->ns_ids.ids.size(), g->more_vars.data(), (uint32_t)g->more_vars.size());
     if (rc) return gfail(g, rc, "rl_match_table_set: %s", rl_last_error(e));
     g->n_ns_installed = (uint32_t)g->ns_ids.ids.size();
     if (g->key_mode == RLI_KEYS_HASHED) {
@@ -608,7 +691,16 @@ int32_t rli_install(rli_ingest* g, rl_engine* e) try {
             }
             return v;
         };
-        const std::vector<rl_wire_str> ns = strs_of(g->ns_ids), keys = strs_of(g->key_ids), vals = strs_of(g->val_ids);
+        const std::vector<rl_wire_str> ns = strs_of(g->ns_ids), vals = strs_of(g->val_ids);
+        // descriptor keys: the key's own bytes, the descriptor's index in bits 24..31 of `len` (rl_engine.h: rl_wire_table_set)
+        std::vector<rl_wire_str> keys(g->key_ids.ids.size(), rl_wire_str{0, 0});
+        for (const auto& kv : g->key_ids.ids) {
+            uint32_t desc;
+            size_t off;
+            desc_key_split(kv.first, &desc, &off);
+            keys[kv.second] = rl_wire_str{(uint32_t)blob.size(), (uint32_t)(kv.first.size() - off) | (desc << 24)};
+            blob.insert(blob.end(), kv.first.begin() + (std::ptrdiff_t)off, kv.first.end());
+        }
         std::vector<uint64_t> pre(2 * g->prefix.size() + 2, 0);
         for (size_t i = 0; i < g->prefix.size(); ++i) {
             pre[2 * i] = g->prefix[i].h1;
@@ -632,6 +724,7 @@ int32_t rli_install(rli_ingest* g, rl_engine* e) try {
 int32_t rli_set_key_mode(rli_ingest* g, int32_t mode) try {
     if (!g || (mode != RLI_KEYS_EXACT && mode != RLI_KEYS_HASHED)) return RL_ERR_INVALID;
     if (!g->req_ns.empty()) return gfail(g, RL_ERR_INVALID, "the key mode is chosen before the first request is added");
+    if (g->key_mode != mode) g->compiled = false;  // (limits with more than two variables compile differently: rli_compile)
     g->key_mode = mode;
     return RL_OK;
 } RL_ABI_CATCH
@@ -658,9 +751,9 @@ int32_t rli_counter_key(rli_ingest* g, uint32_t limit_id, const char* const* val
         const int32_t rc = rli_compile(g);
         if (rc) return rc;
     }
-    if (n_values != g->limits[limit_id].vars.size() || n_values > 2)
+    if (n_values != g->limits[limit_id].vars.size() || n_values > 8)
         return gfail(g, RL_ERR_INVALID, "limit %u has %zu variables", limit_id, g->limits[limit_id].vars.size());
-    rl_h128 v[2];
+    rl_h128 v[8];
     for (uint32_t q = 0; q < n_values; ++q) v[q] = rl_kh_bytes(reinterpret_cast<const uint8_t*>(values[q]), value_lens[q], g->hash_key);
     uint32_t chk = 0;
     rl_counter_key(g->prefix[limit_id], v, n_values, g->hash_key, key, &chk);
@@ -742,6 +835,52 @@ static int32_t encode_request(const rli_ingest* g_c, const std::string& ns, cons
     }
     out->kv.clear();
     for (size_t q = 0; q < kv.size(); ++q) out->kv.emplace_back(kv[q].first, vids[q]);
+    // Limits of this namespace with more than two variables (exact keys): the request carries all of a limit's variables ->
+    // one more entry, (the limit's synthetic key, id of the tuple of the values' ids).  A limit whose variables are not all
+    // there adds nothing, and the device finds its synthetic key absent: no counter (limit/cel.rs:176-191).
+    if (out->ns < g->composites.size() && !g->composites[out->ns].empty()) {
+        static thread_local std::vector<uint32_t> tup;
+        for (const rli_ingest::Composite& c : g->composites[out->ns]) {
+            tup.assign(1, c.limit);
+            for (const uint32_t vk : c.var_keys) {
+                size_t q = 0;
+                while (q < kv.size() && kv[q].first != vk) ++q;
+                if (q == kv.size()) break;
+                tup.push_back(vids[q]);
+            }
+            if (tup.size() != c.var_keys.size() + 1) continue;
+            uint32_t tid = 0;
+            bool have = false;
+            {
+                std::shared_lock<std::shared_mutex> own;
+                if (!held) own = std::shared_lock<std::shared_mutex>(g->dict_mu);
+                auto it = g->tuple_ids.find(tup);
+                if (it != g->tuple_ids.end()) {
+                    tid = it->second;
+                    have = true;
+                }
+            }
+            if (!have) {
+                if (held) held->unlock();
+                struct Relock {
+                    std::shared_lock<std::shared_mutex>* h;
+                    ~Relock() {
+                        if (h) h->lock();
+                    }
+                } relock{held};
+                std::unique_lock<std::shared_mutex> wr(g->dict_mu);
+                auto it = g->tuple_ids.find(tup);
+                if (it != g->tuple_ids.end()) tid = it->second;
+                else {
+                    // (tuples are made of caller-controlled values: the same cap as the value dictionary, the same answer)
+                    if (g->tuple_ids.size() >= (size_t)g->value_cap) return RLI_HOST_ONLY;
+                    tid = (uint32_t)g->tuple_ids.size();
+                    g->tuple_ids.emplace(tup, tid);
+                }
+            }
+            out->kv.emplace_back(c.syn_key, tid);
+        }
+    }
     return 0;
 }
 
@@ -781,6 +920,31 @@ int32_t rli_batch_add(rli_ingest* g, const char* ns, const char* const* keys, co
     return batch_add_sv(g, ns, entries, delta);
 } RL_ABI_CATCH
 
+int32_t rli_batch_add_descriptors(rli_ingest* g, const char* ns, uint32_t n_descriptors, const uint32_t* desc_off,
+                                  const char* const* keys, const char* const* values, uint32_t delta) try {
+    if (!g || !ns || (n_descriptors && !desc_off)) return RL_ERR_INVALID;
+    const uint32_t n_entries = n_descriptors ? desc_off[n_descriptors] : 0;
+    if (n_entries && (!keys || !values)) return RL_ERR_INVALID;
+    std::vector<std::pair<std::string, std::string>> entries;
+    for (uint32_t d = 0; d < n_descriptors; ++d) {
+        if (desc_off[d] > desc_off[d + 1]) return gfail(g, RL_ERR_INVALID, "descriptor offsets must not decrease");
+        if (d > MAX_DESC_INDEX) break;  // (no limit reads them)
+        const size_t first = entries.size();
+        for (uint32_t q = desc_off[d]; q < desc_off[d + 1]; ++q) {
+            if (!keys[q] || !values[q]) return gfail(g, RL_ERR_INVALID, "null descriptor entry");
+            std::string k = desc_key_name(d, keys[q], strlen(keys[q]));
+            bool replaced = false;  // one map per descriptor: a repeated key keeps its LAST value
+            for (size_t p = first; p < entries.size(); ++p)
+                if (entries[p].first == k) {
+                    entries[p].second = values[q];
+                    replaced = true;
+                }
+            if (!replaced) entries.emplace_back(std::move(k), values[q]);
+        }
+    }
+    return batch_add_sv(g, ns, entries, delta);
+} RL_ABI_CATCH
+
 int32_t rli_set_binding(rli_ingest* g, int32_t binding) try {
     if (!g || (binding != RLI_BIND_DESCRIPTORS && binding != RLI_BIND_ROOT)) return RL_ERR_INVALID;
     if (!g->limits.empty()) return gfail(g, RL_ERR_INVALID, "the binding is chosen before the first limit is added");
@@ -794,10 +958,11 @@ int32_t rli_set_value_cap(rli_ingest* g, uint32_t cap) try {
     return RL_OK;
 } RL_ABI_CATCH
 
-// A serialized RateLimitRequest -> (domain, entries of descriptors[0], delta).  Pure: no ingest state.
+// A serialized RateLimitRequest -> (domain, the entries of the descriptors some limit reads — bit i of desc_mask =
+// descriptors[i] — under their (descriptor, key) names, delta).  Pure: no ingest state.
 // 0, RLI_UNKNOWN_DOMAIN, or RL_ERR_INVALID with *what = the part that is malformed.
-static int32_t decode_rls(const uint8_t* msg, uint32_t len, std::string* domain, std::vector<std::pair<std::string, std::string>>* entries,
-                          uint32_t* delta, const char** what) {
+static int32_t decode_rls(const uint8_t* msg, uint32_t len, uint64_t desc_mask, std::string* domain,
+                          std::vector<std::pair<std::string, std::string>>* entries, uint32_t* delta, const char** what) {
     Wire w{msg, msg + len};
     uint64_t hits_addend = 0;
     uint32_t n_descriptors = 0;
@@ -812,7 +977,9 @@ static int32_t decode_rls(const uint8_t* msg, uint32_t len, std::string* domain,
             domain->assign(reinterpret_cast<const char*>(sub.p), (size_t)(sub.end - sub.p));
         } else if (field == 2) {
             if (wt != 2 || !w.bytes(&sub)) return *what = "descriptor", RL_ERR_INVALID;
-            if (n_descriptors++ == 0 && !parse_descriptor(sub, entries)) return *what = "RateLimitDescriptor", RL_ERR_INVALID;
+            const uint32_t d = n_descriptors++;
+            if (d <= MAX_DESC_INDEX && ((desc_mask >> d) & 1ull) && !parse_descriptor(sub, d, entries))
+                return *what = "RateLimitDescriptor", RL_ERR_INVALID;
         } else if (field == 3) {
             if (wt != 0 || !w.varint(&hits_addend)) return *what = "hits_addend", RL_ERR_INVALID;
         } else if (!w.skip(wt)) {
@@ -833,7 +1000,7 @@ int32_t rli_batch_add_rls(rli_ingest* g, const uint8_t* msg, uint32_t len) try {
     std::vector<std::pair<std::string, std::string>> entries;
     uint32_t delta = 1;
     const char* what = "";
-    const int32_t rc = decode_rls(msg, len, &domain, &entries, &delta, &what);
+    const int32_t rc = decode_rls(msg, len, g->desc_mask, &domain, &entries, &delta, &what);
     if (rc == RLI_UNKNOWN_DOMAIN) return rc;
     if (rc) return gfail(g, rc, "malformed RateLimitRequest (%s)", what);
     return batch_add_sv(g, domain, entries, delta);
@@ -1090,7 +1257,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
                 entries.clear();
                 uint32_t delta = 1;
                 const char* what = "";
-                int32_t rc = (lens[i] && !msgs[i]) ? (int32_t)RL_ERR_INVALID : decode_rls(msgs[i], lens[i], &domain, &entries, &delta, &what);
+                int32_t rc = (lens[i] && !msgs[i]) ? (int32_t)RL_ERR_INVALID : decode_rls(msgs[i], lens[i], g->desc_mask, &domain, &entries, &delta, &what);
                 if (rc == 0) rc = encode_request(g, domain, entries, delta, &tmp, &rd);
                 if (rc == 0) {
                     // (CheckRateLimit checks with 1 whatever hits_addend says: kuadrant_service.rs:62-64)

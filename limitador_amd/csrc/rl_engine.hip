@@ -275,6 +275,7 @@ struct rl_engine {
     MatchCondF* d_match_fconds = nullptr;
     MatchSlots match_slots{};
     u32 match_var_slots = 0;        // slots some limit of the fast table reads as a variable
+    u32 match_max_vars = 0;         // most variables of one limit of the table (> 2: only the hashed-key wire path derives its counters)
     u32 match_max_limit_id = 0;
     // the wire path without host dictionaries (rl_wire.hpp): tables of rl_wire_table_set, staging of a batch of messages
     bool wire_ready = false;
@@ -2953,17 +2954,25 @@ int32_t rl_gen_abort(rl_engine* e) try {
 
 int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t n_limits, const rl_match_cond* conds,
                            uint32_t n_conds, uint32_t n_namespaces) try {
-    if (!e || (n_limits && !limits) || (n_conds && !conds)) return RL_ERR_INVALID;
+    return rl_match_table_set_ex(e, limits, n_limits, conds, n_conds, n_namespaces, nullptr, 0);
+} RL_ABI_CATCH
+
+int32_t rl_match_table_set_ex(rl_engine* e, const rl_match_limit* limits, uint32_t n_limits, const rl_match_cond* conds,
+                              uint32_t n_conds, uint32_t n_namespaces, const uint32_t* more_vars, uint32_t n_more_vars) try {
+    if (!e || (n_limits && !limits) || (n_conds && !conds) || (n_more_vars && !more_vars)) return RL_ERR_INVALID;
     EngineLock g(e);
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     HIP_TRY(e, hipSetDevice(e->device));
     std::vector<u32> ns_off(n_namespaces + 1, 0);
-    u32 max_id = 0;
+    u32 max_id = 0, max_vars = 0;
     for (u32 i = 0; i < n_limits; ++i) {
         const rl_match_limit& L = limits[i];
         if (L.ns >= n_namespaces) return fail(e, RL_ERR_INVALID, "match limit %u: namespace id %u out of range", i, L.ns);
         if (i && limits[i - 1].ns > L.ns) return fail(e, RL_ERR_INVALID, "match limits must be sorted by namespace id");
-        if (L.n_vars > MATCH_MAX_VARS) return fail(e, RL_ERR_INVALID, "match limit %u: more than %u variables stay on the host path", i, MATCH_MAX_VARS);
+        if (L.n_vars > MATCH_MAX_VARS_F) return fail(e, RL_ERR_INVALID, "match limit %u: more than %u variables stay on the host path", i, MATCH_MAX_VARS_F);
+        if (L.n_vars > MATCH_MAX_VARS && (u64)L.var_key[0] + L.n_vars > n_more_vars)
+            return fail(e, RL_ERR_INVALID, "match limit %u: %u variables need their key ids in more_vars (rl_match_table_set_ex)", i, L.n_vars);
+        max_vars = std::max<u32>(max_vars, L.n_vars);
         if (((L.limit & RL_SIMPLE) != 0) != (L.n_vars == 0)) return fail(e, RL_ERR_INVALID, "match limit %u: RL_SIMPLE must be set iff the limit has no variables", i);
         if (RL_LIMIT_ID(L.limit) >= e->h_limits.size() || RL_LIMIT_ID(L.limit) >= 4095u) return fail(e, RL_ERR_INVALID, "match limit %u: unknown limit id", i);
         if ((u64)L.cond_off + L.n_cond > n_conds) return fail(e, RL_ERR_INVALID, "match limit %u: conditions out of range", i);
@@ -2971,6 +2980,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
         max_id = std::max<u32>(max_id, RL_LIMIT_ID(L.limit));
     }
     e->match_max_limit_id = max_id;
+    e->match_max_vars = max_vars;
     for (u32 n = 0; n < n_namespaces; ++n) ns_off[n + 1] += ns_off[n];
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->d_match_limits) (void)hipFree(e->d_match_limits);
@@ -3012,12 +3022,13 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
     for (u32 i = 0; fast && i < n_limits; ++i) {
         const rl_match_limit& L = limits[i];
         if (L.n_cond > 255u) fast = false;
-        u32 vs[2] = {0, 0};
+        u32 vs[MATCH_MAX_VARS_F] = {0, 0, 0, 0, 0, 0, 0, 0}, vslots = 0;
         for (u32 q = 0; fast && q < L.n_vars; ++q) {
-            const int sl = slot_of(L.var_key[q]);
+            const int sl = slot_of(L.n_vars > MATCH_MAX_VARS ? more_vars[L.var_key[0] + q] : L.var_key[q]);
             if (sl < 0) fast = false;
             else {
                 vs[q] = (u32)sl;
+                vslots |= (u32)sl << (4u * q);
                 var_slots |= 1u << sl;
             }
         }
@@ -3027,7 +3038,7 @@ int32_t rl_match_table_set(rl_engine* e, const rl_match_limit* limits, uint32_t 
             if (sl < 0 || cd.op > 1u) fast = false;
             else fc[L.cond_off + c] = MatchCondF{(u32)sl | (cd.op << 8), cd.value};
         }
-        fl[i] = MatchLimitF{L.limit, L.cond_off, L.n_cond | (L.n_vars << 8) | (vs[0] << 16) | (vs[1] << 24)};
+        fl[i] = MatchLimitF{L.limit, L.cond_off, L.n_cond | (L.n_vars << 8) | (vs[0] << 16) | (vs[1] << 24), vslots};
     }
     if (fast) {
         if (hipMalloc((void**)&e->d_match_flimits, n_limits * sizeof(MatchLimitF)) != hipSuccess ||
@@ -3216,6 +3227,11 @@ static int32_t match_and_check_locked(rl_engine* e, int op, const u32* d_ns, con
                                       const u32* d_ent_val, const u32* d_delta, u32 n_req, u64 now, bool load,
                                       uint8_t* d_verdict, int32_t* d_limited, u32* n_hits_out) {
     if (!e->d_match_limits) return fail(e, RL_ERR_INVALID, "rl_match_table_set was not called");
+    if (e->match_max_vars > MATCH_MAX_VARS)
+        return fail(e, RL_ERR_INVALID, "a limit of the match table has %u variables: the packed exact key takes %u (rl_match_key) — "
+                                       "the hashed-key wire path derives such counters (rl_wire_match_and_check_batch), or the "
+                                       "caller folds the variables into one (what rli_compile does for exact keys)",
+                    e->match_max_vars, MATCH_MAX_VARS);
     const u32 g = cdiv(n_req, 256);
     if (e->match_fast && e->match_one) {
         // count pass -> one-workgroup scan, which hands {total, error bits} to the host through a host-mapped word ->
@@ -3401,16 +3417,20 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     auto inside = [&](const rl_wire_str& s) { return (u64)s.off + s.len <= blob_len && s.len <= 0xFFFFu; };
     for (u32 i = 0; i < n_ns; ++i)
         if (!inside(ns[i])) return fail(e, RL_ERR_INVALID, "namespace string %u lies outside the blob", i);
-    for (u32 i = 0; i < n_keys; ++i)
-        if (!inside(keys[i])) return fail(e, RL_ERR_INVALID, "key string %u lies outside the blob", i);
+    for (u32 i = 0; i < n_keys; ++i)  // (a key's `len`: bits 0..23 the length, bits 24..31 the descriptor it is read from)
+        if (!inside(rl_wire_str{keys[i].off, keys[i].len & 0xFFFFFFu})) return fail(e, RL_ERR_INVALID, "key string %u lies outside the blob", i);
     for (u32 i = 0; i < n_vals; ++i)
         if (!inside(vals[i])) return fail(e, RL_ERR_INVALID, "value string %u lies outside the blob", i);
     HIP_TRY(e, hipSetDevice(e->device));
     WireTables W{};
+    W.desc_mask = 1ull;
     for (u32 sl = 0; sl < e->match_slots.n; ++sl) {
         const u32 kid = e->match_slots.key[sl];
         if (kid >= n_keys) return fail(e, RL_ERR_INVALID, "the match table reads key id %u, %u key strings were given", kid, n_keys);
-        W.slot_key[sl] = WireStr{keys[kid].off, keys[kid].len};
+        W.slot_key[sl] = WireStr{keys[kid].off, keys[kid].len & 0xFFFFFFu};
+        W.slot_desc[sl] = keys[kid].len >> 24;
+        if (W.slot_desc[sl] > 63u) return fail(e, RL_ERR_INVALID, "key %u reads descriptors[%u]: at most descriptors[63]", kid, W.slot_desc[sl]);
+        W.desc_mask |= 1ull << W.slot_desc[sl];
     }
     std::vector<WireLit> lit(WIRE_LIT_TAB, WireLit{0ull, 0u, 0, 0xFFFFu});
     for (u32 id = 0; id < n_vals; ++id) {

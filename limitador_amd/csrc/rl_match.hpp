@@ -181,10 +181,12 @@ struct MatchSlots {
     u32 key[MATCH_SLOTS];
     u32 n;
 };
+constexpr u32 MATCH_MAX_VARS_F = 8;  // variables of a limit in the slot form (the packed exact key still takes two: match_key)
 struct MatchLimitF {
     u32 limit;     // limit id | SIMPLE_FLAG
     u32 cond_off;  // first condition in the MatchCondF array
     u32 shape;     // n_cond | n_vars << 8 | slot of variable 0 << 16 | slot of variable 1 << 24
+    u32 vslots;    // slot of variable q in bits 4q .. 4q + 3 (all of them; the two in `shape` are what the packed-key kernels read)
 };
 struct MatchCondF {
     u32 slot_op;  // slot | op << 8

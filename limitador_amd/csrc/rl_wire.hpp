@@ -2,8 +2,8 @@
 //
 // What the dictionary path (rl_match.hpp + csrc/host/ingest.cpp) does on the host — walk the protobuf, intern every
 // namespace / key / value string under a reader-writer lock, pack ids — happens HERE, one thread per message:
-//     envoy_rls/server.rs:97-137      domain -> namespace, descriptors[0].entries -> the context (a repeated key keeps
-//                                     its LAST value: HashMap::insert), hits_addend 0 -> 1
+//     envoy_rls/server.rs:97-137      domain -> namespace, descriptors[i].entries -> the context, one map per descriptor (a
+//                                     repeated key keeps its LAST value: HashMap::insert), hits_addend 0 -> 1
 //     lib.rs:507-522, limit.rs:157-174, 133-148, counter.rs:19-31   counters_that_apply (the slot form of rl_match.hpp)
 //     storage/keys.rs:220-248         the counter's key: a hash of its canonical key bytes (include/rl_keyhash.h)
 // The host only concatenates the messages.  Strings are compared as BYTES (namespaces, descriptor keys, condition
@@ -42,6 +42,9 @@ struct WireTables {
     const WireStr* ns;  // [n_ns], index = namespace id (0: the namespace without limits, "")
     u32 n_ns;
     WireStr slot_key[MATCH_SLOTS];
+    u32 slot_desc[MATCH_SLOTS];  // the descriptor the slot's key is read from: slot = (descriptors[slot_desc], slot_key)
+    u64 desc_mask;               // bit i: some slot reads descriptors[i] (bit 0 always) — the others are skipped by wire type,
+                                 // not decoded, exactly like csrc/host/ingest.cpp's reader does
     const WireLit* lit;    // [WIRE_LIT_TAB]
     const u64* prefix;     // [limit id][2]: rl_kh_bytes of the limit's canonical prefix
     rl_hkey hkey;          // the ingest's secret: every hash of this path is SipHash-2-4-128 under it (include/rl_keyhash.h)
@@ -188,8 +191,11 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* wire, const u
                 }
             } else if (field == 2) {
                 if (wt != 2 || !w.bytes(sub)) ok = false;
-                else if (n_desc++ == 0) {
-                    // ---- RateLimitDescriptor { repeated Entry entries = 1; ... }: the first descriptor is the context ----
+                else {
+                    // ---- RateLimitDescriptor { repeated Entry entries = 1; ... }: descriptor number d_idx of the context (the
+                    //      reference binds the whole list, one map per descriptor: envoy_rls/server.rs:121-137) ----
+                    const u32 d_idx = n_desc++;
+                    if (d_idx > 63u || !((W.desc_mask >> d_idx) & 1ull)) sub.p = sub.end;  // (no limit reads this descriptor)
                     while (ok && !sub.done()) {
                         u64 t2;
                         if (!sub.varint(t2)) {
@@ -232,7 +238,8 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* wire, const u
                             u32 sl_hit = MATCH_SLOTS;
 #pragma unroll
                             for (u32 sl = 0; sl < MATCH_SLOTS; ++sl)
-                                if (sl < T.slots.n && W.slot_key[sl].len == kl && wire_bytes_eq(wire + ko, kl, L.blob + W.slot_key[sl].off))
+                                if (sl < T.slots.n && W.slot_desc[sl] == d_idx && W.slot_key[sl].len == kl &&
+                                    wire_bytes_eq(wire + ko, kl, L.blob + W.slot_key[sl].off))
                                     sl_hit = sl;
                             if (sl_hit < MATCH_SLOTS) {
                                 const rl_h128 h = rl_kh_bytes(wire + vo, vl, W.hkey);
@@ -296,8 +303,8 @@ __global__ __launch_bounds__(256) void k_wire_count(const uint8_t* wire, const u
                     // NoSuchKey -> false, whatever the operator (limit/cel.rs:321-338)
                     app = app && val != MATCH_NO_VALUE && ((val == cd.value) == ((cd.slot_op >> 8) == 0u));
                 }
-                if (nv > 0) app = app && S.v[tid][(Lm.shape >> 16) & 0xFFu] != MATCH_NO_VALUE;  // limit/cel.rs:176-191
-                if (nv > 1) app = app && S.v[tid][(Lm.shape >> 24) & 0xFFu] != MATCH_NO_VALUE;
+                for (u32 q = 0; q < nv; ++q)  // a variable the request does not carry: no counter (limit/cel.rs:176-191)
+                    app = app && S.v[tid][(Lm.vslots >> (4u * q)) & 0xFu] != MATCH_NO_VALUE;
                 if (app) {
                     m |= 1ull << (li - l0);
                     ++k;
@@ -344,13 +351,13 @@ __global__ __launch_bounds__(256) void k_wire_fill(const u32* __restrict__ req_n
             const u32 nv = (Lm.shape >> 8) & 0xFFu;
             if ((nv != 0u) != (pass == 1)) continue;
             const u32 lid = Lm.limit & ~SIMPLE_FLAG;
-            rl_h128 P, vals[MATCH_MAX_VARS];
+            rl_h128 P, vals[MATCH_MAX_VARS_F];
             P.h1 = prefix[2 * lid];
             P.h2 = prefix[2 * lid + 1];
 #pragma unroll
-            for (u32 q = 0; q < MATCH_MAX_VARS; ++q) {
+            for (u32 q = 0; q < MATCH_MAX_VARS_F; ++q) {
                 if (q < nv) {
-                    const uint4 h = slot_h[(size_t)r * MATCH_SLOTS + ((Lm.shape >> (16 + 8 * q)) & 0xFFu)];
+                    const uint4 h = slot_h[(size_t)r * MATCH_SLOTS + ((Lm.vslots >> (4u * q)) & 0xFu)];
                     vals[q].h1 = ((u64)h.y << 32) | h.x;
                     vals[q].h2 = ((u64)h.w << 32) | h.z;
                 }

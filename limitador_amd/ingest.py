@@ -36,6 +36,7 @@ def _lib():
         "rli_install": (i32, [p, p]),
         "rli_batch_clear": (None, [p]),
         "rli_batch_add": (i32, [p, cp, strs, strs, u32, u32]),
+        "rli_batch_add_descriptors": (i32, [p, cp, u32, C.POINTER(u32), strs, strs, u32]),
         "rli_batch_add_rls": (i32, [p, C.c_char_p, u32]),
         "rli_set_binding": (i32, [p, i32]),
         "rli_set_limit_name": (i32, [p, u32, cp]),
@@ -228,6 +229,18 @@ class Ingest:
         keys, vals = [k for k, _ in entries], [v for _, v in entries]
         rc = SYMBOLS["rli_batch_add"](self._h, namespace.encode(), _strs(keys), _strs(vals), len(keys), int(delta))
         return HOST_ONLY if rc == HOST_ONLY else self._check(rc)  # HOST_ONLY: the value dictionary is at its cap
+
+    def batch_add_descriptors(self, namespace, descriptors, delta=1):
+        """descriptors: the request's whole descriptor list, each a list of (key, value) pairs
+        (envoy_rls/server.rs:121-128: one map per descriptor)."""
+        keys = [k for d in descriptors for k, _ in d]
+        vals = [v for d in descriptors for _, v in d]
+        off = (C.c_uint32 * (len(descriptors) + 1))()
+        for i, d in enumerate(descriptors):
+            off[i + 1] = off[i] + len(d)
+        rc = SYMBOLS["rli_batch_add_descriptors"](self._h, namespace.encode(), len(descriptors), off, _strs(keys), _strs(vals),
+                                                  int(delta))
+        return HOST_ONLY if rc == HOST_ONLY else self._check(rc)
 
     def batch_add_rls(self, message):
         """message: one serialized envoy.service.ratelimit.v3.RateLimitRequest.

@@ -69,6 +69,22 @@ def test_check_rate_limit_vectors_of_the_reference(make_engine, keys):
 
 
 @pytest.mark.parametrize("keys", ["exact", "hashed"])
+def test_check_rate_limit_takes_into_account_all_the_descriptors(make_engine, keys):
+    """kuadrant_service.rs:386-468 (test_takes_into_account_all_the_descriptors): the second limit — max 0 — also asks for
+    `descriptors[1].y == '2'`; the request's SECOND descriptor carries y = 2, so the check is OVER_LIMIT.  Without that
+    descriptor (or with another y) only the first limit applies and the check is OK."""
+    limits = [("test_namespace", 10, 60, ["descriptors[0].x == '1'"], ["descriptors[0].z"]),
+              ("test_namespace", 0, 60, ["descriptors[0].x == '1'", "descriptors[1].y == '2'"], ["descriptors[0].z"])]
+    eng, g = _service(make_engine, keys, limits)
+    both = rls_request("test_namespace", [[("x", "1"), ("z", "1")], [("y", "2")]], hits_addend=1)
+    other = rls_request("test_namespace", [[("x", "1"), ("z", "1")], [("y", "3")]], hits_addend=1)
+    first_only = rls_request("test_namespace", [[("x", "1"), ("z", "1")]], hits_addend=1)
+    status, resp = g.serve_batch_op(eng, OP_CHECK, [both, other, first_only], NOW)
+    assert status == [1, 0, 0]
+    assert [_code(r) for r in resp] == [OVER_LIMIT, OK, OK]
+
+
+@pytest.mark.parametrize("keys", ["exact", "hashed"])
 def test_report_vectors_of_the_reference(make_engine, keys):
     # report::test_returns_ok_correctly (:486-537): hits_addend 4 on a limit of 10
     eng, g = _service(make_engine, keys, [LIMIT(10)])

@@ -46,9 +46,10 @@ def test_condition_and_variable_shapes(ingest):
     assert g.add_limit("ns", 1, 1, ["descriptors[0].req.path == '/json'"]) == HOST_ONLY
     # CEL the device matcher does not evaluate stays with the caller
     assert g.add_limit("ns", 1, 1, ["descriptors[0]['a'] == descriptors[0]['b']"]) == HOST_ONLY
-    assert g.add_limit("ns", 1, 1, ["descriptors[1]['a'] == '1'"]) == HOST_ONLY
     assert g.add_limit("ns", 1, 1, ["descriptors[0].a.startsWith('x')"]) == HOST_ONLY
-    assert g.add_limit("ns", 1, 1, [], ["descriptors[0].a", "descriptors[0].b", "descriptors[0].c"]) == HOST_ONLY
+    assert g.add_limit("ns", 1, 1, ["descriptors[x]['a'] == '1'"]) == HOST_ONLY
+    assert g.add_limit("ns", 1, 1, ["descriptors[64]['a'] == '1'"]) == HOST_ONLY   # (descriptors[0..63])
+    assert g.add_limit("ns", 1, 1, [], [f"descriptors[0].v{q}" for q in range(9)]) == HOST_ONLY  # (eight variables at most)
     t = g.compile()
     assert t["limit_rows"]["max_value"].tolist() == [99, 10, 10, 5] and t["limit_rows"]["seconds"].tolist() == [60, 60, 61, 1]
     assert t["n_namespaces"] == 3  # "", ns, other
@@ -56,6 +57,17 @@ def test_condition_and_variable_shapes(ingest):
     assert lim["ns"].tolist() == sorted(lim["ns"].tolist()) and 0 not in lim["ns"].tolist()
     assert (lim["limit"][lim["n_vars"] == 0] & RL_SIMPLE).all() and not (lim["limit"][lim["n_vars"] > 0] & RL_SIMPLE).any()
     assert len(t["conds"]) == 6
+    # round 6 (VERDICT r05 missing #1): the transports bind the WHOLE list `descriptors` (envoy_rls/server.rs:121-137), so a
+    # limit may read any descriptor — `descriptors[1].y == '2'` is envoy_rls/server.rs:520 — and any number of variables
+    # (limit.rs:133-148): both are limit ids now, not HOST_ONLY
+    assert g.add_limit("ns", 1, 1, ["descriptors[1]['a'] == '1'"]) == 4
+    assert g.add_limit("ns", 1, 1, ["descriptors[ 1 ].a == '1'"]) == 5  # (another spelling: another limit, limit.rs:177-214)
+    assert g.add_limit("ns", 1, 1, [], ["descriptors[0].a", "descriptors[0].b", "descriptors[0].c"]) == 6
+    assert g.add_limit("ns", 1, 1, [], ["descriptors[0].a", "descriptors[2].b", "descriptors[0].c", "descriptors[1]['d']"]) == 7
+    t = g.compile()
+    lim = t["limits"]
+    # exact keys: a limit with more than two variables reads ONE synthetic variable (the id of the tuple of its values)
+    assert sorted(lim["n_vars"][(lim["limit"] & ~np.uint32(RL_SIMPLE)) >= 6].tolist()) == [1, 1]
 
 
 def test_root_binding_takes_bare_identifiers_only(engine_lib):
@@ -322,3 +334,95 @@ def test_rate_limit_response_on_the_wire(engine_lib):
         m = Resp()
         m.ParseFromString(Ingest.rls_response(verdict))
         assert m.overall_code == code
+
+
+def _contexts(rng, n):
+    """Requests as descriptor LISTS (one dict per descriptor): descriptors[0] carries method / path / user / app,
+    descriptors[1] a tenant and a plan, descriptors[2] (sometimes) a region."""
+    out = []
+    for _ in range(n):
+        d0 = {"m": ["GET", "POST"][int(rng.integers(0, 2))], "u": f"user{int(rng.integers(0, 6))}"}
+        if rng.random() < 0.7:
+            d0["a"] = f"app{int(rng.integers(0, 3))}"
+        d1 = {"t": f"tenant{int(rng.integers(0, 3))}"}
+        if rng.random() < 0.6:
+            d1["plan"] = ["free", "pro"][int(rng.integers(0, 2))]
+        descs = [d0, d1]
+        if rng.random() < 0.5:
+            descs.append({"r": ["eu", "us"][int(rng.integers(0, 2))]})
+        out.append(descs)
+    return out
+
+
+# (conditions, variables) over (descriptor index, key) references; identity includes which descriptor is read
+_MULTI = [
+    ([(1, "plan", "==", "free")], [(0, "u")]),
+    ([(0, "m", "==", "GET"), (1, "plan", "!=", "free")], [(1, "t")]),
+    ([], [(0, "u"), (0, "a"), (1, "t")]),                       # three variables
+    ([(2, "r", "==", "eu")], [(0, "u"), (0, "a"), (1, "t"), (1, "plan")]),  # four, over two descriptors, + a third in the condition
+    ([(1, "t", "!=", "tenant0")], []),
+]
+
+
+def _flat(descs):
+    """the descriptor list as ONE dict with "<index>.<key>" names (what tests/helpers/limiter.py's Limit.applies reads)"""
+    return {f"d{i}.{k}": v for i, d in enumerate(descs) for k, v in d.items()}
+
+
+def test_every_descriptor_and_many_variables_through_the_id_level_matcher(ingest):
+    """descriptors[i] for any i and limits with up to eight variables, exact keys: the ingest's tables + encoded requests run
+    through the id-level CPU matcher must name the same counters as the string-level restatement of counters_that_apply
+    (limit.rs:157-174, 133-148) — a request that lacks one of a limit's variables has no counter for it (cel.rs:176-191), two
+    requests share a counter iff ALL their variable values agree."""
+    from helpers.limiter import Limit
+
+    g = ingest
+    rng = np.random.default_rng(11)
+    model = []
+    for conds, variables in _MULTI:
+        lid = g.add_limit("ns", 5, 60, [f"descriptors[{i}]['{k}'] {op} '{v}'" for i, k, op, v in conds],
+                          [f"descriptors[{i}].{k}" for i, k in variables])
+        assert lid == len(model)
+        model.append(Limit("ns", 5, 60, [f"d{i}.{k} {op} '{v}'" for i, k, op, v in conds], [f"d{i}.{k}" for i, k in variables]))
+    t = g.compile()
+    ctxs = _contexts(rng, 300)
+    for descs in ctxs:
+        assert g.batch_add_descriptors("ns", [list(d.items()) for d in descs]) >= 0
+    b = g.batch()
+    hits, off = match_requests(t["limits"], t["conds"], b["req_ns"], b["ent_off"], b["ent_key"], b["ent_val"], b["req_delta"])
+    seen = {}  # device key -> the counter's identity (limit, variable values)
+    n_three = n_four = 0
+    for r, descs in enumerate(ctxs):
+        ctx = _flat(descs)
+        want = []
+        for lid, L in enumerate(model):
+            if L.applies(ctx):
+                want.append((lid, tuple(ctx[v] for v in L.variables)))
+        got = hits[off[r]:off[r + 1]]
+        assert sorted(int(h["limit"]) & ~RL_SIMPLE for h in got) == sorted(l for l, _ in want), (r, descs)
+        for h in got:
+            lid = int(h["limit"]) & ~RL_SIMPLE
+            ident = next(w for w in want if w[0] == lid)
+            assert seen.setdefault(int(h["key"]), ident) == ident, "two counters share a key"
+            n_three += lid == 2
+            n_four += lid == 3
+    idents = set(seen.values())
+    assert len(idents) == len(seen), "one counter under two keys"
+    assert n_three > 100 and n_four > 20
+
+
+def test_the_wire_reader_takes_every_descriptor_a_limit_reads(ingest):
+    g = ingest
+    assert g.add_limit("ns", 10, 60, ["descriptors[0].x == '1'"], ["descriptors[0].z"]) == 0
+    assert g.add_limit("ns", 0, 60, ["descriptors[0].x == '1'", "descriptors[1].y == '2'"], ["descriptors[0].z"]) == 1
+    t = g.compile()
+    # envoy_rls/server.rs:540-565: two descriptors (+ a third one nobody reads)
+    msg = rls_request("ns", [[("x", "1"), ("z", "1")], [("y", "2")], [("y", "3")]])
+    assert g.batch_add_rls(msg) == 0
+    assert g.batch_add_rls(rls_request("ns", [[("x", "1"), ("z", "1")], [("y", "3")]])) == 1
+    assert g.batch_add_rls(rls_request("ns", [[("x", "1"), ("z", "1")]])) == 2
+    b = g.batch()
+    hits, off = match_requests(t["limits"], t["conds"], b["req_ns"], b["ent_off"], b["ent_key"], b["ent_val"], b["req_delta"])
+    assert [int(h["limit"]) for h in hits[off[0]:off[1]]] == [0, 1]   # both limits: descriptors[1].y == '2' holds
+    assert [int(h["limit"]) for h in hits[off[1]:off[2]]] == [0]      # y is '3'
+    assert [int(h["limit"]) for h in hits[off[2]:off[3]]] == [0]      # no second descriptor: the condition is false
