@@ -466,7 +466,8 @@ int32_t rl_wire_match_batch_op(rl_engine *e, int32_t op, const uint8_t *wire, co
  *   round   d_admitted[i] != 0: hit i's request is admitted so far (NULL: all are — the first round).  d_pass[i] =
  *           hit i fits on top of the admitted hits before it on its cell; with load_counters also remaining /
  *           expires_in of the hit (in_memory.rs:87-95,114-116).  The host ANDs the flags per request, across
- *           engines, and calls again until the admitted set no longer changes.
+ *           engines, and calls again until the admitted set no longer changes.  (d_pass is first overwritten with 1s
+ *           and then the failures are stored: it must not be the same array as d_admitted.)
  *   count   d_reached[i] != 0: the request's walk got to hit i (in_memory.rs:109-113,129-133; NULL: all hits).
  *           -> cells the pass would create, and how many the table still takes: the host decides for ALL engines.
  *   commit  applies the admitted hits of the LAST round and creates the reached new cells; ends the pass.

@@ -194,14 +194,16 @@ void rli_frontend_destroy(rli_frontend *f);
 void rli_frontend_set_clock(rli_frontend *f, uint64_t now_us); /* tests: a fixed clock instead of the system's */
 int32_t rli_frontend_should_rate_limit(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp,
                                        uint32_t resp_cap, uint32_t *resp_len);
-/* The Kuadrant methods through the same micro-batcher (rli_serve_batch_op).  A device batch is one method: the batcher cuts
- * where the method changes and keeps arrival order across the cut, so a Report queued behind a CheckRateLimit is applied
- * behind it. */
+/* The Kuadrant methods through the same micro-batcher (rli_serve_batch_op).  A device batch is one method: a window of
+ * mixed traffic is served as its consecutive same-method runs, back to back under one clock value and ONE wait
+ * (max_delay_us is paid per window, not per run), and arrival order is kept across the runs, so a Report queued behind a
+ * CheckRateLimit is applied behind it. */
 int32_t rli_frontend_check_rate_limit(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp, uint32_t resp_cap,
                                       uint32_t *resp_len);
 int32_t rli_frontend_report(rli_frontend *f, const uint8_t *msg, uint32_t len, uint8_t *resp, uint32_t resp_cap,
                             uint32_t *resp_len);
-void rli_frontend_stats(rli_frontend *f, uint64_t *batches, uint64_t *requests);
+void rli_frontend_stats(rli_frontend *f, uint64_t *batches, uint64_t *requests); /* device calls, requests */
+uint64_t rli_frontend_windows(rli_frontend *f); /* windows served (one wait of at most max_delay_us each) */
 /* exception barrier self-test of THIS library (rl_engine.h: rl_abi_selftest; kinds 1-4) */
 int32_t rli_abi_selftest(int32_t kind);
 

@@ -1484,7 +1484,7 @@ struct rli_frontend {
     std::condition_variable cv_work, cv_done;
     std::vector<Slot*> queue;
     bool stop = false;
-    uint64_t n_batches = 0, n_requests = 0;
+    uint64_t n_batches = 0, n_requests = 0, n_windows = 0;  // device calls, requests, waits for a window to fill
     std::thread worker;
 
     void run() {
@@ -1494,60 +1494,76 @@ struct rli_frontend {
             if (stop && queue.empty()) return;
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_delay_us);
             cv_work.wait_until(lk, deadline, [&] { return stop || queue.size() >= max_batch; });
-            // One device call is one method: the batch is the longest run of requests of the queue's first method (arrival
-            // order is kept across methods — a Report that arrived behind a CheckRateLimit is applied behind it).
-            std::vector<Slot*> batch;
-            size_t take = 0;
-            while (take < queue.size() && take < max_batch && queue[take]->op == queue[0]->op) ++take;
-            const int32_t op = queue[0]->op;
+            // The WINDOW is everything that arrived until the deadline (at most max_batch requests).  One device call is one
+            // method, so the window is served as its consecutive same-method runs, back to back, under ONE clock value and
+            // without another wait in between: arrival order is kept across methods (a Report that arrived behind a
+            // CheckRateLimit is applied behind it), and interleaved Kuadrant traffic — C, R, C, R from concurrent clients, the
+            // normal Check-then-Report pattern — costs one delay per window, not one per request (the batcher
+            // used to cut at the first method change and wait a full max_delay_us again for the leftovers).
+            std::vector<Slot*> window;
+            const size_t take = std::min<size_t>(queue.size(), max_batch);
             if (take < queue.size()) {
-                batch.assign(queue.begin(), queue.begin() + take);
+                window.assign(queue.begin(), queue.begin() + take);
                 queue.erase(queue.begin(), queue.begin() + take);
             } else {
-                batch.swap(queue);
+                window.swap(queue);
             }
             lk.unlock();
-            const uint32_t n = (uint32_t)batch.size();
-            std::vector<const uint8_t*> msgs;
-            std::vector<uint32_t> lens, out_len;
-            std::vector<int32_t> status;
-            std::vector<uint8_t> out;
-            int32_t rc;
-            try {  // (this thread has no entry point's barrier above it: its callers get the status, the thread lives on)
-                msgs.resize(n);
-                lens.resize(n);
-                out_len.resize(n);
-                status.resize(n);
-                out.resize((size_t)n * stride);
+            uint64_t now = fixed_now_us;
+            if (!now) {
+                using namespace std::chrono;
+                now = (uint64_t)duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
+            }
+            std::vector<int32_t> w_status(window.size(), 0);
+            uint64_t calls = 0;
+            for (size_t r0 = 0; r0 < window.size();) {
+                size_t r1 = r0 + 1;
+                while (r1 < window.size() && window[r1]->op == window[r0]->op) ++r1;
+                const uint32_t n = (uint32_t)(r1 - r0);
+                const int32_t op = window[r0]->op;
+                std::vector<const uint8_t*> msgs;
+                std::vector<uint32_t> lens, out_len;
+                std::vector<int32_t> status;
+                std::vector<uint8_t> out;
+                int32_t rc;
+                try {  // (this thread has no entry point's barrier above it: its callers get the status, the thread lives on)
+                    msgs.resize(n);
+                    lens.resize(n);
+                    out_len.resize(n);
+                    status.resize(n);
+                    out.resize((size_t)n * stride);
+                    for (uint32_t i = 0; i < n; ++i) {
+                        msgs[i] = window[r0 + i]->msg;
+                        lens[i] = window[r0 + i]->len;
+                    }
+                    rc = serve_batch_op(g, e, op, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride, out_len.data(),
+                                        status.data());
+                } catch (const std::bad_alloc&) {
+                    rc = rl_abi_caught("rli_frontend worker", "std::bad_alloc (host memory exhausted)", RL_ERR_NOMEM);
+                } catch (...) {
+                    rc = rl_abi_caught("rli_frontend worker", "C++ exception", RL_ERR_INTERNAL);
+                }
+                ++calls;
+                // (responses are handed over run by run, outside the lock: the slots belong to callers that are waiting)
                 for (uint32_t i = 0; i < n; ++i) {
-                    msgs[i] = batch[i]->msg;
-                    lens[i] = batch[i]->len;
+                    Slot* s = window[r0 + i];
+                    w_status[r0 + i] = rc ? rc : status[i];
+                    if (!rc && out_len[i] <= s->resp_cap) {
+                        memcpy(s->resp, out.data() + (size_t)i * stride, out_len[i]);
+                        s->resp_len = out_len[i];
+                    } else if (!rc) {
+                        w_status[r0 + i] = RL_ERR_INVALID;
+                    }
                 }
-                uint64_t now = fixed_now_us;
-                if (!now) {
-                    using namespace std::chrono;
-                    now = (uint64_t)duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
-                }
-                rc = serve_batch_op(g, e, op, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride, out_len.data(),
-                                    status.data());
-            } catch (const std::bad_alloc&) {
-                rc = rl_abi_caught("rli_frontend worker", "std::bad_alloc (host memory exhausted)", RL_ERR_NOMEM);
-            } catch (...) {
-                rc = rl_abi_caught("rli_frontend worker", "C++ exception", RL_ERR_INTERNAL);
+                r0 = r1;
             }
             lk.lock();
-            ++n_batches;
-            n_requests += n;
-            for (uint32_t i = 0; i < n; ++i) {
-                Slot* s = batch[i];
-                s->status = rc ? rc : status[i];
-                if (!rc && out_len[i] <= s->resp_cap) {
-                    memcpy(s->resp, out.data() + (size_t)i * stride, out_len[i]);
-                    s->resp_len = out_len[i];
-                } else if (!rc) {
-                    s->status = RL_ERR_INVALID;
-                }
-                s->done = true;
+            n_batches += calls;
+            ++n_windows;
+            n_requests += window.size();
+            for (size_t i = 0; i < window.size(); ++i) {
+                window[i]->status = w_status[i];
+                window[i]->done = true;
             }
             cv_done.notify_all();
         }
@@ -1622,6 +1638,12 @@ void rli_frontend_stats(rli_frontend* f, uint64_t* batches, uint64_t* requests) 
     std::lock_guard<std::mutex> lk(f->mu);
     if (batches) *batches = f->n_batches;
     if (requests) *requests = f->n_requests;
+}
+
+uint64_t rli_frontend_windows(rli_frontend* f) {
+    if (!f) return 0;
+    std::lock_guard<std::mutex> lk(f->mu);
+    return f->n_windows;
 }
 
 int64_t rli_key_id(const rli_ingest* g, const char* s) { return g && s ? g->key_ids.find(s) : -1; }

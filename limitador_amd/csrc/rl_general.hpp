@@ -159,8 +159,10 @@ struct GenArgs {
     u32 load_deferred;       // load_counters: k_gen_round does not store remaining / expires_in, k_gen_load does once behind the rounds
     u32 pass_prefilled;      // the round's pass flags start out 1 (round 0: k_gen_piece_sum fills them; later rounds: the round's
                              // k_gen_admit, request by request) and k_gen_round only stores the FAILURES — a flag goes to its
-                             // hit's index in request order, a random byte store per hit, and those stores are what bounds a
-                             // round; the phased form (rl_gen_round_device) writes every flag into the caller's array
+                             // hit's index in request order, a random byte store per hit.  The phased form
+                             // (rl_gen_round_device) sets it too: every call is a "round 0" whose k_gen_piece_sum first
+                             // overwrites the caller's d_pass with 1s, then k_gen_round stores the failures — so d_pass is
+                             // fully defined only THROUGH that prefill, and it must not alias d_admitted
     unsigned long long* trace;  // debugging (RL_GEN_TRACE=2): k_gen_sort's phase stamps, 8 words per workgroup
 };
 

@@ -51,6 +51,7 @@ def _lib():
         "rli_frontend_set_clock": (None, [p, u64]),
         "rli_frontend_should_rate_limit": (i32, [p, C.c_char_p, u32, C.POINTER(C.c_uint8), u32, C.POINTER(u32)]),
         "rli_frontend_stats": (None, [p, C.POINTER(u64), C.POINTER(u64)]),
+        "rli_frontend_windows": (u64, [p]),
         "rli_abi_selftest": (C.c_int32, [C.c_int32]),
         "rli_set_value_cap": (i32, [p, u32]),
         "rli_set_key_mode": (i32, [p, i32]),
@@ -326,6 +327,10 @@ class Frontend:
         b, r = C.c_uint64(), C.c_uint64()
         SYMBOLS["rli_frontend_stats"](self._h, C.byref(b), C.byref(r))
         return b.value, r.value
+
+    def windows(self):
+        """Windows served: each waited at most max_delay_us once, whatever mix of methods it held."""
+        return SYMBOLS["rli_frontend_windows"](self._h)
 
     def close(self):
         if self._h:

@@ -232,6 +232,51 @@ def test_the_three_methods_through_one_micro_batcher(make_engine):
     g.close()
 
 
+def test_alternating_check_and_report_cost_one_delay_per_window_not_one_per_request(make_engine):
+    """concurrent clients in the normal Check-then-Report pattern fill the queue with C, R, C, R, ...; a
+    batcher that cuts at every method change and waits max_delay_us again for the leftovers serves about one request per
+    delay.  The window is now served whole — its same-method runs back to back, one wait — so 16 clients x 24 calls with a
+    5 ms delay take a few dozen windows, not 384 delays (1.9 s)."""
+    import time
+
+    eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
+    g = Ingest(keys="hashed")
+    assert g.add_limit("shop", 10**6, 60, [], ["descriptors[0]['user']"]) == 0
+    g.install(eng)
+    delay_us = 5000
+    fe = Frontend(g, eng, max_batch=64, max_delay_us=delay_us)
+    fe.set_clock(NOW)
+    n_threads, n_calls = 16, 24
+    start = threading.Barrier(n_threads)
+    bad = []
+
+    def worker(t):
+        req = rls_request("shop", [[("user", f"u{t}")]], hits_addend=1)
+        start.wait()
+        for q in range(n_calls):
+            st, resp = (fe.check_rate_limit if (q + t) % 2 == 0 else fe.report)(req)  # neighbours are in opposite phases
+            if st != 0 or _code(resp) != OK:
+                bad.append((t, q, st))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    elapsed = time.perf_counter() - t0
+    batches, requests = fe.stats()
+    windows = fe.windows()
+    fe.close()
+    assert not bad, bad[:5]
+    assert requests == n_threads * n_calls
+    assert batches > windows, "mixed windows were served as several same-method runs"
+    assert windows <= requests // 3, (windows, requests)          # (a request per delay would be `requests` windows)
+    assert elapsed < requests * delay_us * 1e-6 * 0.5, (elapsed, windows, batches)
+    # reports counted, checks did not: every user's counter = its reports
+    rows = eng.get_counters(0, NOW)
+    assert int(rows["value"].sum()) == n_threads * n_calls // 2
+    g.close()
+
+
 def test_match_op_on_dictionary_encoded_requests(make_engine):
     """rl_match_batch_op on the numeric boundary (what a host with its own dictionaries binds): the three methods on the
     same request arrays against the mirror, incl. a request that derives no counter and a namespace without limits."""
