@@ -403,11 +403,12 @@ int32_t rl_wire_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, 
  * counter which is not the one its key belongs to (the word stored in the key's cell decides; without a cell, the
  * batch's first counter of that key) and *collided_message is the index of one of them — the caller answers those
  * messages on its exact path (or drops them) and calls again without them: one re-run, however many collide. */
-/* Pinned host buffers that belong to the engine, by slot (0..3; grown on demand — a later call for the same slot may move
+/* Pinned host buffers that belong to the engine, by slot (0..7 — four per serving set, see rl_wire_serve_batch_set: set s
+ * owns slots 4 s .. 4 s + 3; grown on demand — a later call for the same slot may move
  * it — and freed with the engine): where a host layer builds the arrays it hands to the host-pointer entry points and
  * receives their results, so that every copy is plain DMA instead of the runtime's pageable path (a fresh 60 MB result
- * array per call cost the wire path 20 ms of page faults and staged copies).  Slots 2 and 3 are also where
- * rl_match_serve_batch / rl_wire_serve_batch leave their responses.  No reference analogue. */
+ * array per call cost the wire path 20 ms of page faults and staged copies).  Slots 4 s + 2 and 4 s + 3 are also where
+ * rl_match_serve_batch / rl_wire_serve_batch (s = 0) / rl_wire_serve_batch_set leave their responses.  No reference analogue. */
 int32_t rl_host_staging(rl_engine *e, uint32_t slot, uint64_t bytes, void **out);
 int32_t rl_wire_match_and_check_batch(rl_engine *e, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
                                       uint64_t now_us, int32_t load_counters, uint8_t *verdict, int32_t *limited_limit,
@@ -446,6 +447,17 @@ int32_t rl_wire_serve_batch(rl_engine *e, const uint8_t *wire, const uint32_t *m
                             uint32_t flags, uint8_t *verdict, int32_t *status, const uint32_t **resp_off,
                             const uint8_t **resp, int64_t *collided_message);
 int32_t rl_serve_wait(rl_engine *e, uint64_t upto);
+/* TWO serving calls in flight (the reference serves from N tonic workers at once, envoy_rls/server.rs:238-272, behind a
+ * shared read lock, in_memory.rs:78).  Everything a serving call leaves behind for the host — the pinned staging of its
+ * offsets and bytes, the events of its pieces — exists twice, by `set` (0 or 1), and the bytes' kernels run on a stream of
+ * their own from a snapshot of what they read; so while the host still waits for and hands on the responses of the call on
+ * set s (rl_serve_wait_set(e, s, upto)), another thread may pack, copy in and decide the next batch with set 1 - s.  The
+ * engine's mutex serialises the calls themselves (decisions are applied in the order the calls enter); a set must not be
+ * used again before every byte of its previous call has been waited for.  rl_wire_serve_batch = set 0. */
+int32_t rl_wire_serve_batch_set(rl_engine *e, uint32_t set, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
+                                uint64_t now_us, uint32_t flags, uint8_t *verdict, int32_t *status,
+                                const uint32_t **resp_off, const uint8_t **resp, int64_t *collided_message);
+int32_t rl_serve_wait_set(rl_engine *e, uint32_t set, uint64_t upto);
 
 /* rl_match_batch_op for serialized messages (RL_OP_* above).  RL_OP_CHECK is the Kuadrant CheckRateLimit: every counter is
  * checked with delta 1 whatever the message's hits_addend says (kuadrant_service.rs:62-64); a message whose counter's key

@@ -345,7 +345,49 @@ struct rli_ingest {
     // The dictionaries are read by many decoding threads at once (rli_serve_batch splits a large batch over
     // threads) and written when a request brings a value never seen before: readers share, a writer excludes.
     mutable std::shared_mutex dict_mu;
+    // Serving calls in flight: the hashed-key path with device-built responses takes ONE of two sets (engine staging slots
+    // 4 s .. 4 s + 3, piece events, a helper pool), so two threads' calls overlap — one packs / copies in / decides while the
+    // other's responses cross PCIe and are handed on; every other form of the call takes both (it uses this ingest's batch
+    // arrays and set 0's staging: one at a time, as before).
+    std::mutex set_mu;
+    std::condition_variable set_cv;
+    bool set_busy[2] = {false, false};
+    std::mutex err_mu;   // `err` is written by whichever serving thread fails
+    std::mutex frag_mu;  // send_fragments
 };
+
+namespace {
+struct SetLease {
+    rli_ingest* g;
+    rl_engine* e;
+    int set = 0;
+    bool both = false;
+    bool bytes_pending = false;  // a *_serve_batch call succeeded with RL_SERVE_ASYNC: its last byte must be waited for
+    SetLease(rli_ingest* g_, rl_engine* e_, bool exclusive) : g(g_), e(e_), both(exclusive) {
+        std::unique_lock<std::mutex> lk(g->set_mu);
+        if (exclusive) {
+            g->set_cv.wait(lk, [&] { return !g->set_busy[0] && !g->set_busy[1]; });
+            g->set_busy[0] = g->set_busy[1] = true;
+        } else {
+            g->set_cv.wait(lk, [&] { return !g->set_busy[0] || !g->set_busy[1]; });
+            set = g->set_busy[0] ? 1 : 0;
+            g->set_busy[set] = true;
+        }
+    }
+    ~SetLease() {
+        // Whatever way the call ends — also an exception out of a scatter chunk, rethrown into the ABI barrier — the set is
+        // only handed on once every byte of its responses has arrived (the next call would rewrite the staging
+        // and the piece events under a scatter thread that still reads them).
+        if (bytes_pending) (void)rl_serve_wait_set(e, (uint32_t)set, ~0ull);
+        {
+            std::lock_guard<std::mutex> lk(g->set_mu);
+            if (both) g->set_busy[0] = g->set_busy[1] = false;
+            else g->set_busy[set] = false;
+        }
+        g->set_cv.notify_all();
+    }
+};
+}  // namespace
 
 // One request, dictionary-encoded: what batch_add_sv appends to the batch arrays.
 struct EncReq {
@@ -359,6 +401,7 @@ static int32_t gfail(rli_ingest* g, int32_t rc, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    std::lock_guard<std::mutex> lk(g->err_mu);
     g->err = buf;
     return rc;
 }
@@ -386,9 +429,11 @@ class ChunkPool {
     };
 
 public:
-    static ChunkPool& get() {
-        static ChunkPool p;
-        return p;
+    // One pool per serving set (two serving calls may be in flight, rl_ingest.h: the pack of one runs beside the scatter of
+    // the other — one pool would queue them on its `job_mu`).
+    static ChunkPool& get(uint32_t which = 0) {
+        static ChunkPool p[2];
+        return p[which & 1u];
     }
     // f(chunk) for chunk in [0, n_chunks), on the pool's threads and the caller's; returns when every chunk is done and
     // no helper is inside the job any more.  One job at a time (callers queue up on `job_mu`).
@@ -468,7 +513,7 @@ private:
 };
 
 template <class F>
-static void parallel_chunks(uint32_t n, uint32_t threads, F f) {  // f(lo, hi)
+static void parallel_chunks(uint32_t n, uint32_t threads, F f, uint32_t pool = 0) {  // f(lo, hi)
     if (threads <= 1 || n == 0) {
         f(0u, n);
         return;
@@ -478,7 +523,7 @@ static void parallel_chunks(uint32_t n, uint32_t threads, F f) {  // f(lo, hi)
         const uint32_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
         if (lo < hi) f(lo, hi);
     };
-    ChunkPool::get().run(threads, job);
+    ChunkPool::get(pool).run(threads, job);
 }
 
 extern "C" {
@@ -1074,6 +1119,7 @@ static std::string limit_fragment(const LimitSpec* L) {
 
 // The fragments on the device (rl_resp_table_set), where the responses with headers are built (rl_resp.hpp).
 static int32_t send_fragments(rli_ingest* g, rl_engine* e) {
+    std::lock_guard<std::mutex> one(g->frag_mu);
     if (g->resp_engine == e && g->resp_sent == g->resp_version) return RL_OK;
     std::vector<uint8_t> blob;
     std::vector<rl_wire_str> frag(g->limits.size());
@@ -1091,13 +1137,21 @@ static int32_t send_fragments(rli_ingest* g, rl_engine* e) {
 
 // op: RL_OP_CHECK_AND_UPDATE = ShouldRateLimit (envoy_rls/server.rs:91-208); RL_OP_CHECK / RL_OP_UPDATE = the Kuadrant service's
 // CheckRateLimit / Report (envoy_rls/kuadrant_service.rs:27-184), whose responses never carry rate-limit headers.
+// (rli_frontend: two workers serve windows side by side, but the windows' DEVICE calls must enter the engine in arrival order —
+// a Report behind its CheckRateLimit: `before` waits for the window's turn, `after` passes it on; either may be empty)
+// The serving SETS are handed out in window order as well (`before_lease` / `after_lease(shared)`): a later window that took
+// both sets and then waited for its device turn would starve the earlier window still waiting for a set.
+struct ServeHooks {
+    std::function<void()> before, after, before_lease;
+    std::function<void(bool)> after_lease;
+};
+
 static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uint8_t* const* msgs, const uint32_t* lens, uint32_t n,
                               uint64_t now_us, int32_t with_headers, uint8_t* out, uint32_t out_stride, uint32_t* out_len,
-                              int32_t* status) {
+                              int32_t* status, const ServeHooks* hooks = nullptr) {
     if (!g || !e || (n && (!msgs || !lens || !out || !out_len || !status)) || out_stride < 2) return RL_ERR_INVALID;
     if (op != RL_OP_CHECK_AND_UPDATE && op != RL_OP_CHECK && op != RL_OP_UPDATE) return RL_ERR_INVALID;
     if (op != RL_OP_CHECK_AND_UPDATE) with_headers = 0;
-    rli_batch_clear(g);
     if (n == 0) return RL_OK;
     const uint32_t threads = serve_threads(n);
     const bool trace = RL_EXP_ENV("RLI_TRACE") != nullptr;
@@ -1107,6 +1161,20 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
             std::fprintf(stderr, "[rli] %-10s at %8.1f us\n", what,
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
+    // With headers, the responses of a LARGE batch are built on the DEVICE (rl_*_serve_batch): what comes back is the bytes,
+    // not the counters — 262 144 messages 5.9 -> 3.3 ms, 32 768 1.0 -> 0.8.  A small batch keeps the host assembly from the
+    // counters' arrays: the device form adds five launches, a round trip for the total and an event per copy, 0.05 ms of a
+    // 0.19 ms batch of 256.  RLI_RESP_HOST=1 / RLI_RESP_DEVICE=1 (experiment builds) force one or the other — the two are
+    // compared byte for byte by tests/test_gpu_rls_e2e.py.
+    const bool dev_resp = with_headers && !RL_EXP_ENV("RLI_RESP_HOST") && (RL_EXP_ENV("RLI_RESP_DEVICE") || n >= 4096u);
+    // One of the two serving sets for the form that overlaps (hashed keys, responses built on the device); both sets — i.e.
+    // alone — for every other form (it uses this ingest's batch arrays and set 0).  Released, after the last byte has been
+    // waited for, on every way out of this function.
+    if (hooks && hooks->before_lease) hooks->before_lease();
+    SetLease lease(g, e, !(dev_resp && g->key_mode == RLI_KEYS_HASHED));
+    if (hooks && hooks->after_lease) hooks->after_lease(!lease.both);
+    const uint32_t set = (uint32_t)lease.set;
+    if (lease.both) rli_batch_clear(g);
     std::vector<int32_t> req_of(n, -1);
     // The results of the device call live in the ENGINE's pinned staging (rl_host_staging slot 1): fresh pageable arrays —
     // 60 MB of them for 262 144 requests with headers — cost the call 20 ms of page faults and staged copies.
@@ -1119,7 +1187,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
         const size_t total = up(n_r + 1) + 2 * up(((size_t)n_r + 1) * 4) + up(((size_t)n_r + 2) * 4) + up(cap * sizeof(rl_hit)) + 2 * up(cap * 8) + 64;
         void* base = nullptr;
-        const int32_t rc = rl_host_staging(e, 1, total, &base);
+        const int32_t rc = rl_host_staging(e, 4u * set + 1u, total, &base);
         if (rc) return gfail(g, rc, "rl_host_staging: %s", rl_last_error(e));
         uint8_t* p = static_cast<uint8_t*>(base);
         verdict = p;
@@ -1137,12 +1205,6 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         exp = reinterpret_cast<uint64_t*>(p);
         return RL_OK;
     };
-    // With headers, the responses of a LARGE batch are built on the DEVICE (rl_*_serve_batch): what comes back is the bytes,
-    // not the counters — 262 144 messages 5.9 -> 3.3 ms, 32 768 1.0 -> 0.8.  A small batch keeps the host assembly from the
-    // counters' arrays: the device form adds five launches, a round trip for the total and an event per copy, 0.05 ms of a
-    // 0.19 ms batch of 256.  RLI_RESP_HOST=1 / RLI_RESP_DEVICE=1 (experiment builds) force one or the other — the two are
-    // compared byte for byte by tests/test_gpu_rls_e2e.py.
-    const bool dev_resp = with_headers && !RL_EXP_ENV("RLI_RESP_HOST") && (RL_EXP_ENV("RLI_RESP_DEVICE") || n >= 4096u);
     const uint32_t* d_off = nullptr;  // device-built responses: request r's bytes are d_bytes[d_off[r] .. d_off[r + 1])
     const uint8_t* d_bytes = nullptr;
     if (dev_resp)
@@ -1172,7 +1234,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         // offsets and bytes live in the ENGINE's pinned staging (rl_host_staging slot 0: the copies to the device are plain DMA)
         const size_t off_bytes = (((size_t)n + 1) * sizeof(uint32_t) + 63) & ~(size_t)63;
         void* stage = nullptr;
-        int32_t src = rl_host_staging(e, 0, off_bytes + sum + 64, &stage);
+        int32_t src = rl_host_staging(e, 4u * set + 0u, off_bytes + sum + 64, &stage);
         if (src) return gfail(g, src, "rl_host_staging: %s", rl_last_error(e));
         uint32_t* w_off = static_cast<uint32_t*>(stage);
         uint8_t* w_bytes = static_cast<uint8_t*>(stage) + off_bytes;
@@ -1190,13 +1252,14 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
                     if (i + 8 < hi) __builtin_prefetch(msgs[i + 8], 0, 0);
                     if (!skip[i] && lens[i]) memcpy(w_bytes + w_off[i], msgs[i], lens[i]);
                 }
-            });
+            }, set);
             if (attempt == 0) lap("packed");
+            if (attempt == 0 && hooks && hooks->before) hooks->before();
             uint32_t n_hits = 0;
             int64_t collided = -1;
             const int32_t rc =
-                dev_resp ? rl_wire_serve_batch(e, w_bytes, w_off, n, now_us, RL_SERVE_HEADERS | RL_SERVE_ASYNC, verdict, dev_status,
-                                               &d_off, &d_bytes, &collided)
+                dev_resp ? rl_wire_serve_batch_set(e, set, w_bytes, w_off, n, now_us, RL_SERVE_HEADERS | RL_SERVE_ASYNC, verdict,
+                                                   dev_status, &d_off, &d_bytes, &collided)
                 : op == RL_OP_CHECK_AND_UPDATE
                     ? rl_wire_match_and_check_batch(e, w_bytes, w_off, n, now_us, with_headers ? 1 : 0, verdict, limited, dev_status,
                                                     with_headers ? req_off : nullptr, with_headers ? hits : nullptr, (uint32_t)cap,
@@ -1220,6 +1283,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
                 if (taken) continue;
             }
             if (rc) return gfail(g, rc, "rl_wire_match_and_check_batch: %s", rl_last_error(e));
+            lease.bytes_pending = dev_resp;
             break;
         }
         for (uint32_t i = 0; i < n; ++i) {
@@ -1305,6 +1369,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
         lap("appended");
         const size_t cap = with_headers && !dev_resp ? (size_t)n_req * per_ns : 0;
         if (const int32_t brc = result_arrays(n_req, cap)) return brc;
+        if (hooks && hooks->before) hooks->before();
         if (n_req) {
             uint32_t n_hits = 0;
             const int32_t rc =
@@ -1319,9 +1384,11 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
                     : rl_match_batch_op(e, op, g->req_ns.data(), g->ent_off.data(), g->ent_key.data(), g->ent_val.data(),
                                         g->req_delta.data(), n_req, now_us, verdict, limited);
             if (rc) return gfail(g, rc, "rl_match_and_check_batch: %s", rl_last_error(e));
+            lease.bytes_pending = dev_resp;
         }
     }
     lap("device");
+    if (hooks && hooks->after) hooks->after();
     // ---- the responses: independent of one another ----------------------------------------------------------
     std::atomic<uint32_t> too_long{0};
     // what a limit contributes to X-RateLimit-Limit — `, {max};w={secs}[;name="{name}"]` — is the same for every request:
@@ -1347,7 +1414,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
             uint32_t i = hi;
             while (i > lo && req_of[i - 1] < 0) --i;
             if (i > lo)
-                if (const int32_t wrc = rl_serve_wait(e, d_off[(uint32_t)req_of[i - 1] + 1])) wait_rc.store(wrc);
+                if (const int32_t wrc = rl_serve_wait_set(e, set, d_off[(uint32_t)req_of[i - 1] + 1])) wait_rc.store(wrc);
         }
         // (strings that keep their capacity from one request to the next: no allocation per request)
         std::string o, hv, val;
@@ -1439,11 +1506,11 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
             memcpy(out + (size_t)i * out_stride, o.data(), o.size());
             out_len[i] = (uint32_t)o.size();
         }
-    });
+    }, set);
     lap("responses");
     if (dev_resp && d_off) {
         // (every byte has been waited for before the engine is called again — also the ones behind the last answered request)
-        if (const int32_t wrc = rl_serve_wait(e, d_off[n_req])) wait_rc.store(wrc);
+        if (const int32_t wrc = rl_serve_wait_set(e, set, d_off[n_req])) wait_rc.store(wrc);
         if (wait_rc.load()) return gfail(g, wait_rc.load(), "rl_serve_wait: the responses' copy failed");
     }
     if (too_long.load())  // (not an error of the call: the message names the size a retry needs)
@@ -1485,7 +1552,15 @@ struct rli_frontend {
     std::vector<Slot*> queue;
     bool stop = false;
     uint64_t n_batches = 0, n_requests = 0, n_windows = 0;  // device calls, requests, waits for a window to fill
-    std::thread worker;
+    // Two workers (round 6): while one still waits for and hands on the responses of its window, the other collects, packs
+    // and decides the next one (rli_serve_batch's two serving sets).  Windows are numbered as they are cut; their device
+    // calls enter the engine in that order (`turn`), so arrival order holds across windows as it does inside one.
+    std::thread worker[2];
+    uint64_t next_window = 0;
+    std::mutex turn_mu;
+    std::condition_variable turn_cv;
+    uint64_t turn = 0;        // the window whose device calls may enter the engine
+    uint64_t lease_turn = 0;  // the window that may take a serving set
 
     void run() {
         std::unique_lock<std::mutex> lk(mu);
@@ -1494,6 +1569,7 @@ struct rli_frontend {
             if (stop && queue.empty()) return;
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_delay_us);
             cv_work.wait_until(lk, deadline, [&] { return stop || queue.size() >= max_batch; });
+            if (queue.empty()) continue;  // (the other worker took the window while this one waited)
             // The WINDOW is everything that arrived until the deadline (at most max_batch requests).  One device call is one
             // method, so the window is served as its consecutive same-method runs, back to back, under ONE clock value and
             // without another wait in between: arrival order is kept across methods (a Report that arrived behind a
@@ -1501,6 +1577,7 @@ struct rli_frontend {
             // normal Check-then-Report pattern — costs one delay per window, not one per request (the batcher
             // used to cut at the first method change and wait a full max_delay_us again for the leftovers).
             std::vector<Slot*> window;
+            const uint64_t my_window = next_window++;
             const size_t take = std::min<size_t>(queue.size(), max_batch);
             if (take < queue.size()) {
                 window.assign(queue.begin(), queue.begin() + take);
@@ -1516,6 +1593,51 @@ struct rli_frontend {
             }
             std::vector<int32_t> w_status(window.size(), 0);
             uint64_t calls = 0;
+            bool turn_taken = false, turn_passed = false, lease_waited = false, lease_passed = false;
+            size_t n_runs = window.empty() ? 0 : 1;
+            for (size_t q = 1; q < window.size(); ++q) n_runs += window[q]->op != window[q - 1]->op;
+            ServeHooks first_run, last_run, only_run;
+            auto take_turn = [&] {
+                std::unique_lock<std::mutex> tl(turn_mu);
+                turn_cv.wait(tl, [&] { return turn == my_window; });
+                turn_taken = true;
+            };
+            auto pass_turn = [&] {
+                if (turn_passed) return;
+                if (!turn_taken) take_turn();  // (a window that never reached its device call still has to pass the turn on)
+                {
+                    std::lock_guard<std::mutex> tl(turn_mu);
+                    ++turn;
+                }
+                turn_passed = true;
+                turn_cv.notify_all();
+            };
+            auto wait_lease = [&] {
+                std::unique_lock<std::mutex> tl(turn_mu);
+                turn_cv.wait(tl, [&] { return lease_turn == my_window; });
+                lease_waited = true;
+            };
+            auto pass_lease = [&] {
+                if (lease_passed) return;
+                if (!lease_waited) wait_lease();
+                {
+                    std::lock_guard<std::mutex> tl(turn_mu);
+                    ++lease_turn;
+                }
+                lease_passed = true;
+                turn_cv.notify_all();
+            };
+            // A window of ONE run in the form that overlaps (it took one set) lets the next window take the other set at once;
+            // any other window keeps the sets' gate until it is through (its later runs take sets again).
+            auto leased = [&](bool shared) {
+                if (shared && n_runs == 1) pass_lease();
+            };
+            first_run.before_lease = wait_lease;
+            first_run.after_lease = leased;
+            first_run.before = take_turn;
+            last_run.after = pass_turn;
+            only_run = first_run;
+            only_run.after = pass_turn;
             for (size_t r0 = 0; r0 < window.size();) {
                 size_t r1 = r0 + 1;
                 while (r1 < window.size() && window[r1]->op == window[r0]->op) ++r1;
@@ -1536,8 +1658,9 @@ struct rli_frontend {
                         msgs[i] = window[r0 + i]->msg;
                         lens[i] = window[r0 + i]->len;
                     }
+                    const bool is_first = r0 == 0, is_last = r1 == window.size();
                     rc = serve_batch_op(g, e, op, msgs.data(), lens.data(), n, now, with_headers, out.data(), stride, out_len.data(),
-                                        status.data());
+                                        status.data(), is_first && is_last ? &only_run : is_first ? &first_run : is_last ? &last_run : nullptr);
                 } catch (const std::bad_alloc&) {
                     rc = rl_abi_caught("rli_frontend worker", "std::bad_alloc (host memory exhausted)", RL_ERR_NOMEM);
                 } catch (...) {
@@ -1557,6 +1680,8 @@ struct rli_frontend {
                 }
                 r0 = r1;
             }
+            pass_turn();
+            pass_lease();
             lk.lock();
             n_batches += calls;
             ++n_windows;
@@ -1581,7 +1706,7 @@ int32_t rli_frontend_create(rli_ingest* g, rl_engine* e, uint32_t max_batch, uin
     f->max_delay_us = max_delay_us;
     f->with_headers = with_headers;
     f->stride = 1024;
-    f->worker = std::thread([f] { f->run(); });
+    for (auto& w : f->worker) w = std::thread([f] { f->run(); });
     *out = f;
     return RL_OK;
 } RL_ABI_CATCH
@@ -1593,7 +1718,7 @@ void rli_frontend_destroy(rli_frontend* f) {
         f->stop = true;
     }
     f->cv_work.notify_all();
-    f->worker.join();
+    for (auto& w : f->worker) w.join();
     delete f;
 }
 

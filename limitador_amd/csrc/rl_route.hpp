@@ -383,10 +383,13 @@ __global__ __launch_bounds__(256) void k_copy_segs(const CopySegs S) {
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x, stride = (u64)gridDim.x * 256;
     for (u32 k = 0; k < S.n; ++k) {
         const u64 b = S.bytes[k];
-        if ((((u64)S.dst[k] | (u64)S.src[k] | b) & 15ull) == 0ull) {
+        if ((((u64)S.dst[k] | (u64)S.src[k]) & 15ull) == 0ull) {  // 16-byte words, then the bytes behind the last whole one
             const uint4* s4 = static_cast<const uint4*>(S.src[k]);
             uint4* d4 = static_cast<uint4*>(S.dst[k]);
             for (u64 i = gid; i < (b >> 4); i += stride) d4[i] = s4[i];
+            const uint8_t* s1 = static_cast<const uint8_t*>(S.src[k]);
+            uint8_t* d1 = static_cast<uint8_t*>(S.dst[k]);
+            for (u64 i = (b & ~15ull) + gid; i < b; i += stride) d1[i] = s1[i];
         } else {
             const uint8_t* s1 = static_cast<const uint8_t*>(S.src[k]);
             uint8_t* d1 = static_cast<uint8_t*>(S.dst[k]);
