@@ -197,8 +197,9 @@ struct rl_engine {
     // is busy (4.9 us when it is not, 1.7 us between plain launches of one queue) are not the events'.
     bool apply_events = true;
     int part_compact = 1;           // RL_PART_COMPACT=0: k_bkt_part (1024 threads, ~78 KB of LDS) for 4096-hit tiles too instead of
-                                    // k_bkt_part_c (512 threads, ~41 KB: resident beside the replay's workgroups; 1.7 us per step);
-                                    // 2: k_bkt_part_l, the compact shape with the per-hit work cut down (rl_part.hpp)
+                                    // k_bkt_part_c (512 threads, ~41 KB: resident beside the replay's workgroups; 1.7 us per step).
+                                    // (k_bkt_part_l, the compact shape with the per-hit work cut down — 26.7 us alone / 33.2 in the
+                                    // pipeline, the STEP unchanged: profiles/r05b_lean_partition.md — is scripts/exp/patches/lean_partition.patch)
     bool fuse = false;              // one stream, the partition of batch j + 1 as a role of the launch that replays batch j: the default of
                                     // engines with max_batch_hits <= 256 k (RL_FUSE=0 / 1 overrides)
                                     // (k_bkt_step; parity-green, but the role's 4-wave workgroups walk a tile in 2 x 16 dependent steps:
@@ -986,15 +987,7 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
                  (u32)PC_WAVES * nbt * (u32)sizeof(unsigned short) + 4u, ps, ctable, e->log2cap, e->seed, d_hits, n, climits,  \
                  (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, items,   \
                  hot_prod)
-#define RL_PART_L(STEPS, NBITS)                                                                                                \
-    RL_LAUNCH_TS(t || chain_p, t ? f.tev[0] : nullptr, f.ev_p_stop, (k_bkt_part_l<STEPS, NBITS>), ntiles + 1, PC_BLOCK,       \
-                 (u32)PC_WAVES * nbt * (u32)sizeof(unsigned short) + 4u, ps, ctable, e->log2cap, e->seed, d_hits, n, climits,  \
-                 (u32)e->h_limits.size(), bk_log2, ntiles, run_tt, bs, hot_use, 1u, d_verdict, d_first, b_hits, runs, items,   \
-                 hot_prod)
-    if (e->part_compact == 2 && steps == 4) {  // the lean form of the compact shape (rl_part.hpp: k_bkt_part_l)
-        if (nbt <= 2048u) RL_PART_L(8, 11);
-        else RL_PART_L(8, 12);
-    } else if (e->part_compact && steps == 4) RL_PART_C(8);  // (1024-hit tiles of small batches: the 1024-thread kernel is 1 us faster)
+    if (e->part_compact && steps == 4) RL_PART_C(8);  // (1024-hit tiles of small batches: the 1024-thread kernel is 1 us faster)
     else
     switch (steps) {
         case 1: RL_PART(1); break;
@@ -1002,7 +995,6 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         case 8: RL_PART(8); break;
         default: RL_PART(16); break;
     }
-#undef RL_PART_L
 #undef RL_PART_C
 #undef RL_PART
     HIP_TRY(e, hipGetLastError());
@@ -1841,7 +1833,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     // launches, not by kernels (64 k hits: 16.4 us per batch fused, 19.4 on two streams; 1 M hits: 65-75 against 47).
     e->fuse = e->max_batch <= (1u << 18);
     if (const char* v = getenv("RL_FUSE")) e->fuse = atoi(v) != 0;
-    if (const char* v = RL_EXP_ENV("RL_PART_COMPACT")) e->part_compact = std::min(std::max(atoi(v), 0), 2);
+    if (const char* v = RL_EXP_ENV("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0 ? 1 : 0;
     if (const char* v = RL_EXP_ENV("RL_DEFER2")) e->defer2 = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_DIRECT")) e->resp_direct = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;

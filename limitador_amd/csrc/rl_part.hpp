@@ -634,344 +634,6 @@ __global__ __launch_bounds__(PC_BLOCK) void k_bkt_part_c(const Cell* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_bkt_part_l: k_bkt_part_c with the per-hit work cut down ("lean") — the same shape (512 threads, 8 waves x STEPS x 64
-// hits, the same LDS footprint), the same inputs and bit-identical outputs (records, runs, default verdicts, error bits,
-// hot work items).  Why: with one workgroup per CU and two waves per SIMD nothing hides a wave's own chains, and
-// k_bkt_part_c's walk was 8 dependent steps of ~240 vector + ~175 scalar instructions each (profiles/r04a_sq.md,
-// r04a_stamps.md: 1.3 us per 64-hit step, 45 % of the kernel) — a third of them control flow around cases the measured
-// path never takes.  What changed:
-//   * the walk runs in PHASES over all STEPS steps of a wave (hash | hot look-up | bins + default verdicts | ranks), so
-//     the steps' LDS round trips overlap instead of queueing up behind each other;
-//   * validation is straight-line selects; the probe of a SIMPLE counter's cell (in_memory.rs:106-107) sits behind ONE
-//     wave-uniform test ("does any lane carry a simple counter");
-//   * the hot table is probed a GROUP at a time: a key starts at a 4-slot-aligned group, one 8-byte LDS read returns the
-//     group, its 16-bit entries carry a 5-bit fingerprint so a cold key (63 % of a Zipf batch) is decided by that read
-//     alone; same table, same insertion order rule (first free slot of the sequence, a key listed twice keeps the smaller
-//     index), so every workgroup still maps a key to the same bin.  Whatever the group read does not decide — a group
-//     without a free slot, a fingerprint match that is another key — goes through the plain slot-by-slot loop;
-//   * the wave-private counters are read and bumped WITHOUT a wait between the steps: the leader of a (step, bin) group
-//     adds the group's size with an LDS atomic (no return), every lane reads its counter before that — LDS operations of
-//     one wave execute in order, and nothing a step issues depends on what it read;
-//   * the counters' second pass walks them as 32-bit pairs (half the LDS operations); the match walks NBITS bits.
-// ---------------------------------------------------------------------------------------------
-constexpr u32 HS_GROUPS = HOT_SLOTS / 4;
-// entry of the hot slot table: index (9 bits) | default answer "limited" << 9 | fingerprint (5 bits) << 10; 0xFFFF = free
-__device__ __forceinline__ u32 hs_group(u64 hh) { return (u32)(hh >> 8) & (HS_GROUPS - 1); }
-__device__ __forceinline__ u32 hs_fp(u64 hh) { return (u32)(hh >> 20) & 31u; }
-
-template <int NBITS>
-__device__ __forceinline__ u64 match_bits(u32 d, u64 valid) {
-    u32 zlo = 0, zhi = 0;
-#pragma unroll
-    for (u32 b = 0; b < (u32)NBITS; ++b) {
-        const u32 sb = (u32)__builtin_amdgcn_sbfe((int)d, b, 1u);  // -(bit b of d)
-        const u64 bm = __ballot(sb != 0u);
-        zlo |= (u32)bm ^ sb;
-        zhi |= (u32)(bm >> 32) ^ sb;
-    }
-    return valid & ~(((u64)zhi << 32) | zlo);
-}
-
-// Register budget: 512 / RL_PARTL_WPE per wave.  A workgroup is two waves per SIMD and sits beside the replay's (80 VGPRs, one
-// wave per SIMD each): at 96 (the default) four replay workgroups fit beside it like beside k_bkt_part_c (82), at 109 — what
-// the kernel takes unconstrained — three.
-#ifndef RL_PARTL_WPE
-#define RL_PARTL_WPE 5
-#endif
-template <int STEPS, int NBITS>
-__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(RL_PARTL_WPE, RL_PARTL_WPE))) void k_bkt_part_l(const Cell* __restrict__ table, u32 log2cap, u64 seed,
-                                                         const Hit* __restrict__ hits, u32 n,
-                                                         const LimitDev* __restrict__ limits, u32 n_limits, u32 bk_log2,
-                                                         u32 ntiles, u32 run_tt, BatchScratch* bs,
-                                                         const HotSet* __restrict__ hot, u32 check_simple,
-                                                         uint8_t* __restrict__ verdict_fill, int32_t* __restrict__ first_fill,
-                                                         BHit* __restrict__ b_hits, u32* __restrict__ runs,
-                                                         HotItems* __restrict__ items, HotSet* __restrict__ hot_next) {
-    // wave-private counters [PC_WAVES][nbt], 16 bits each, held and accessed as 32-bit PAIRS (nbt is even)
-    extern __shared__ __align__(16) u32 s_cnt2[];
-    __shared__ unsigned short s_base[BKT_MAX];
-    __shared__ u64 s_hkey[HOT_MAX];
-    __shared__ __align__(8) u32 s_hslot2[HOT_SLOTS / 2];  // the 16-bit entries, two per word
-    __shared__ uint2 s_hot_dl[HOT_MAX];                   // the delta and the limit id the set predicts
-    __shared__ u32 s_mis[HOT_MAX / 32];
-    __shared__ u32 s_w[PC_WAVES];
-    const u32 tid = threadIdx.x;
-    if (blockIdx.x == ntiles) {
-        // ---- one extra workgroup: the replay's hot work items, from the hot set alone ----------------------------------
-        const u32 nh = hot->n < (u32)HOT_MAX ? hot->n : (u32)HOT_MAX;
-        u32 nk = 0;
-        if (tid < nh) {
-            const u32 want = (hot->cnt[tid] + HOT_CHUNK - 1) / HOT_CHUNK;
-            nk = want < 1u ? 1u : (want > HOT_NK_MAX ? HOT_NK_MAX : want);
-        }
-        u32 all;
-        const u32 c0 = block_excl_scan_512(nk, s_w, all);
-        u32* s_c0 = reinterpret_cast<u32*>(s_hkey);  // chunk0[0 .. HOT_MAX]
-        s_c0[tid] = c0;
-        if (tid == 0) {
-            s_c0[HOT_MAX] = all;
-            items->n = all;
-            hot_next->n = 0;  // the replay appends the keys it promotes or keeps
-        }
-        __syncthreads();
-        for (u32 c = tid; c < all; c += PC_BLOCK) {
-            u32 a = 0, b = HOT_MAX;  // invariant: chunk0[a] <= c < chunk0[b]
-            while (b - a > 1) {
-                const u32 m = (a + b) >> 1;
-                if (s_c0[m] <= c) a = m;
-                else b = m;
-            }
-            HotItem it{};
-            it.key = hot->key[a];
-            it.hb_k = a | ((c - s_c0[a]) << 16);
-            it.nk = s_c0[a + 1] - s_c0[a];
-            it.d = hot->d[a];
-            it.limit = hot->limit[a];
-            it.flg = hot->flg[a];
-            items->it[c] = it;
-        }
-        return;
-    }
-    u32 tile;
-    {
-        const u32 x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = ntiles >> 3, rem = ntiles & 7u;
-        tile = x * per + (x < rem ? x : rem) + j;
-    }
-    Status* st = &bs->st;
-    const u32 lane = tid & 63u, w = tid >> 6;
-    const u32 nb = 1u << bk_log2;
-    const u32 nbt = nb + HOT_MAX;
-    const u32 wrow = w * (nbt >> 1);  // this wave's row of counter pairs
-    constexpr u32 TILE = PC_BLOCK * STEPS;
-    const u32 tbase = tile * TILE;
-    const u32 wbase = tbase + w * (64 * STEPS);
-    uint4 raw[STEPS];
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const u32 i = wbase + u * 64 + lane;
-        raw[u] = *reinterpret_cast<const uint4*>(hits + (i < n ? i : n - 1));
-    }
-    // ---- LDS: empty tables; the hot set.  All of the set's arrays are requested at once (entries past hot->n are never
-    //      used: a key only enters the table if tid < nh) ------------------------------------------------------------
-    const u32 nh_raw = hot->n;
-    const u64 hk = hot->key[tid];
-    const u32 hd = hot->d[tid], hl = hot->limit[tid], hf = hot->flg[tid];
-    for (u32 b = tid; b < (u32)(HOT_SLOTS / 2); b += PC_BLOCK) s_hslot2[b] = 0xFFFFFFFFu;
-    for (u32 b = tid; b < PC_WAVES * (nbt >> 1); b += PC_BLOCK) s_cnt2[b] = 0u;
-    if (tid < (u32)(HOT_MAX / 32)) s_mis[tid] = 0u;
-    const u32 nh = nh_raw < (u32)HOT_MAX ? nh_raw : (u32)HOT_MAX;
-    s_hkey[tid] = tid < nh ? hk : TAG_EMPTY;
-    s_hot_dl[tid] = make_uint2(hd, hl);
-    __syncthreads();
-    if (tid < nh) {
-        const u64 hhk = fmix64(hk ^ seed);
-        const u32 mine = tid | ((hf & HOT_FLG_DENY) ? 0x200u : 0u) | (hs_fp(hhk) << 10);
-        u32 s = hs_group(hhk) * 4u;
-        for (;;) {
-            u32* wp = s_hslot2 + (s >> 1);
-            const u32 sh = (s & 1u) * 16u;
-            u32 old = *wp;
-            bool done = false;
-            for (;;) {
-                const u32 x = (old >> sh) & 0xFFFFu;
-                const bool same = x != 0xFFFFu && s_hkey[x & 0x1FFu] == hk;
-                if (x != 0xFFFFu && !same) break;       // another key's slot: probe on
-                if (same && (x & 0x1FFu) <= tid) {      // the same key with a smaller index is there already
-                    done = true;
-                    break;
-                }
-                const u32 prev = atomicCAS(wp, old, (old & ~(0xFFFFu << sh)) | (mine << sh));
-                if (prev == old) {
-                    done = true;
-                    break;
-                }
-                old = prev;
-            }
-            if (done) break;
-            s = (s + 1) & (HOT_SLOTS - 1);
-        }
-    }
-    __syncthreads();
-    // ---- phase 1: validation (straight line), the hash, the request for the key's group of the hot table -----------
-    u32 info[STEPS];  // hash bucket | fingerprint << 12 | group << 17 (the 64-bit hash itself is not kept: registers)
-    uint2 grp[STEPS];
-    u32 err = 0;
-    bool any_simple = false;
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const u32 i = wbase + u * 64 + lane;
-        const bool ok = i < n;
-        const u64 key = ((u64)raw[u].y << 32) | raw[u].x;
-        const u32 limit = raw[u].z;
-        const bool bad_limit = (limit & ~SIMPLE_FLAG) >= n_limits;
-        const bool reserved = key >= TAG_TOMB;
-        const u32 e = bad_limit ? ERRBIT_BAD_LIMIT : (reserved ? ERRBIT_RESERVED_KEY : 0u);
-        err |= ok ? e : 0u;
-        any_simple = any_simple || (ok && e == 0u && (limit & SIMPLE_FLAG) != 0u);
-        const u64 hh = fmix64(key ^ seed);
-        info[u] = bucket_of_hash(hh, bk_log2) | (hs_fp(hh) << 12) | (hs_group(hh) << 17);
-        grp[u] = *reinterpret_cast<const uint2*>(s_hslot2 + hs_group(hh) * 2u);
-    }
-    if (check_simple && __ballot(any_simple) != 0ull) {
-        // (in_memory.rs:106-107) a simple counter must already have its cell — rare on this path: one wave-uniform branch
-#pragma unroll  // (fully unrolled: an array indexed by a loop variable would live in scratch memory)
-        for (int u = 0; u < STEPS; ++u) {
-            const u32 i = wbase + u * 64 + lane;
-            const u64 key = ((u64)raw[u].y << 32) | raw[u].x;
-            const u32 limit = raw[u].z;
-            if (i < n && (limit & SIMPLE_FLAG) && (limit & ~SIMPLE_FLAG) < n_limits && key < TAG_TOMB) {
-                u32 dummy = 0;
-                u32 slot = slot_of(key, seed, log2cap);
-                slot = probe_from<PM_LOOKUP>(const_cast<Cell*>(table), log2cap, slot, table[slot].tag, key, limit, limits, 0ull,
-                                             st, dummy);
-                if (slot == SLOT_INVALID) err |= ERRBIT_MISSING_SIMPLE;
-            }
-        }
-    }
-    // ---- phase 2: the group decides most look-ups (a free slot in front of any fingerprint match: not hot); a fingerprint
-    //      match names a candidate whose key is requested; the rest takes the slot-by-slot loop ----------------------------
-    u32 cand[STEPS];  // 0xFFFF: decided "not hot"; 0xFFFE: undecided (slow path); else the matching entry
-    u64 ckey[STEPS];
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const u32 fp = (info[u] >> 12) & 31u;
-        const u32 e0 = grp[u].x & 0xFFFFu, e1 = grp[u].x >> 16, e2 = grp[u].y & 0xFFFFu, e3 = grp[u].y >> 16;
-        u32 c = 0xFFFEu;
-        // (walked from the last entry to the first, so that the FIRST deciding entry wins)
-        c = (e3 == 0xFFFFu) ? 0xFFFFu : ((e3 >> 10) == fp ? e3 : c);
-        c = (e2 == 0xFFFFu) ? 0xFFFFu : ((e2 >> 10) == fp ? e2 : c);
-        c = (e1 == 0xFFFFu) ? 0xFFFFu : ((e1 >> 10) == fp ? e1 : c);
-        c = (e0 == 0xFFFFu) ? 0xFFFFu : ((e0 >> 10) == fp ? e0 : c);
-        cand[u] = c;
-        ckey[u] = s_hkey[c < 0xFFFEu ? (c & 0x1FFu) : 0u];
-    }
-    u32 dbin[STEPS];  // bin | (default answer "limited") << 15
-    bool any_slow = false;
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const u64 key = ((u64)raw[u].y << 32) | raw[u].x;
-        const bool is_cand = cand[u] < 0xFFFEu;
-        const bool hit = is_cand && ckey[u] == key;
-        // undecided: no free slot in the group and no match, or a fingerprint match that is another key
-        const bool slow = cand[u] == 0xFFFEu || (is_cand && !hit);
-        any_slow = any_slow || slow;
-        dbin[u] = slow ? 0xFFFFFFFFu : (hit ? (nb + (cand[u] & 0x1FFu)) | ((cand[u] & 0x200u) << 6) : (info[u] & 0xFFFu));
-    }
-    if (__ballot(any_slow) != 0ull) {
-#pragma unroll  // (fully unrolled, as above)
-        for (int u = 0; u < STEPS; ++u) {
-            if (dbin[u] == 0xFFFFFFFFu) {
-                const u64 key = ((u64)raw[u].y << 32) | raw[u].x;
-                u32 q = (info[u] >> 17) * 4u;
-                u32 res = info[u] & 0xFFFu;
-                for (;;) {
-                    const u32 x = (s_hslot2[q >> 1] >> ((q & 1u) * 16u)) & 0xFFFFu;
-                    if (x == 0xFFFFu) break;
-                    if (s_hkey[x & 0x1FFu] == key) {
-                        res = (nb + (x & 0x1FFu)) | ((x & 0x200u) << 6);
-                        break;
-                    }
-                    q = (q + 1) & (HOT_SLOTS - 1);
-                }
-                dbin[u] = res;
-            }
-        }
-    }
-    // ---- phase 3: hot hits against the set's predictions; the default answers as coalesced stores ---------------------
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const u32 i = wbase + u * 64 + lane;
-        const bool ok = i < n;
-        const u32 d = dbin[u] & 0x7FFFu;
-        const bool deny = (dbin[u] >> 15) != 0u;
-        const bool is_hot = d >= nb;
-        const uint2 dl = s_hot_dl[is_hot ? d - nb : 0u];
-        // a hit that is not what the set predicts: the bucket is replayed hit by hit
-        if (ok && is_hot && (raw[u].w != dl.x || raw[u].z != dl.y)) atomicOr(&s_mis[(d - nb) >> 5], 1u << ((d - nb) & 31));
-        if (ok && verdict_fill) {
-            verdict_fill[i] = deny ? 1 : 0;
-            if (first_fill) first_fill[i] = deny ? (int32_t)i : -1;
-        }
-        dbin[u] = ok ? d : 0u;
-    }
-    // ---- phase 4: rank among the wave's hits of the bin (trace order).  No wait between the steps: a step's leaders bump
-    //      the counters the next step reads, and LDS operations of one wave execute in the order they were issued --------
-    unsigned short rank[STEPS];
-    const u64 lt = (1ull << lane) - 1ull;
-    u32 cpre[STEPS], below[STEPS];
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const u32 i = wbase + u * 64 + lane;
-        const bool ok = i < n;
-        const u64 valid = __ballot(ok);
-        const u32 d = dbin[u];
-        const u64 m = match_bits<NBITS>(d, valid);
-        u32* cp = s_cnt2 + wrow + (d >> 1);
-        const u32 sh = (d & 1u) * 16u;
-        cpre[u] = (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 0xFFFFu;
-        below[u] = (u32)__popcll(m & lt);
-        if (ok && below[u] == 0u) __hip_atomic_fetch_add(cp, (u32)__popcll(m) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) rank[u] = (unsigned short)(cpre[u] + below[u]);
-    if (err) atomicOr(&st->err, err);
-    __syncthreads();
-    // ---- per bin: the waves' exclusive offsets, the tile's count; exclusive scan over the bins = the runs' starts ----
-    {
-        constexpr int PW = 3;  // counter pairs per thread: 6 bins (nbt <= 2560 < 6 * 512)
-        const u32 p0 = PW * tid, npair = nbt >> 1;
-        u32 tot[PW], sum = 0;
-#pragma unroll
-        for (int q = 0; q < PW; ++q) {
-            const u32 pr = p0 + q;
-            u32 acc = 0;
-            if (pr < npair) {
-#pragma unroll
-                for (int ww = 0; ww < PC_WAVES; ++ww) {
-                    const u32 x = s_cnt2[ww * npair + pr];
-                    s_cnt2[ww * npair + pr] = acc;  // (both halves at once: a tile's count of a bin stays below 2^16)
-                    acc += x;
-                }
-            }
-            tot[q] = acc;
-            sum += (acc & 0xFFFFu) + (acc >> 16);
-        }
-        u32 all;
-        u32 ex = block_excl_scan_512(sum, s_w, all);
-        u32* row = runs + tile;
-#pragma unroll
-        for (int q = 0; q < PW; ++q) {
-            const u32 pr = p0 + q;
-            if (pr < npair) {
-#pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const u32 b = 2u * pr + hlf;
-                    const u32 c = hlf ? (tot[q] >> 16) : (tot[q] & 0xFFFFu);
-                    s_base[b] = (unsigned short)ex;
-                    const bool mis = b >= nb && ((s_mis[(b - nb) >> 5] >> ((b - nb) & 31)) & 1u);
-                    row[(size_t)b * run_tt] = run_pack(ex, c, mis);
-                    ex += c;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- the records, into the tile's own window: bins in order, every bin in trace order -----------------------
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-        const u32 i = wbase + u * 64 + lane;
-        if (i < n) {
-            const u32 d = dbin[u];
-            const u32 wo = (s_cnt2[wrow + (d >> 1)] >> ((d & 1u) * 16u)) & 0xFFFFu;
-            const u32 dst = tbase + (u32)s_base[d] + wo + rank[u];
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 recv = {raw[u].x, raw[u].y, raw[u].w, i | (limit_fold(raw[u].z) << 24)};
-            *reinterpret_cast<u32x4*>(b_hits + dst) = recv;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // The same partition as a ROLE of 256-thread workgroups, for k_bkt_step (rl_apply.hpp): the partition of batch j + 1
 // runs INSIDE the launch that replays batch j — one stream, one launch per step, no event between the two.  (As a
 // kernel of its own on a second stream, k_bkt_part cost the step 15 us: the replay slowed down beside its 16-wave

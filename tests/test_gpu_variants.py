@@ -128,10 +128,10 @@ def test_every_output_of_a_batch_is_defined_whatever_the_buffers_held(make_engin
     assert_same_state(eng, orc)
 
 
-@pytest.mark.parametrize("compact", ["1", "0", "2"])
+@pytest.mark.parametrize("compact", ["1", "0"])
 def test_both_shapes_of_the_partition_on_4096_hit_tiles(make_engine, monkeypatch, compact):
     """Batches of more than 256 x 1024 hits take 4096-hit tiles: k_bkt_part_c (512 threads), k_bkt_part (1024 threads,
-    RL_PART_COMPACT=0) or k_bkt_part_l (RL_PART_COMPACT=2: the compact shape with the per-hit work cut down).  300 000 Zipf hits per batch (74 tiles, the last one ragged), hot keys with mixed
+    RL_PART_COMPACT=0).  300 000 Zipf hits per batch (74 tiles, the last one ragged), hot keys with mixed
     limits, four batches so that the hot set is in use: every verdict and the final table against the oracle."""
     monkeypatch.setenv("RL_PART_COMPACT", compact)
     rng = np.random.default_rng(41)
@@ -146,12 +146,11 @@ def test_both_shapes_of_the_partition_on_4096_hit_tiles(make_engine, monkeypatch
     assert_same_state(eng, orc)
 
 
-@pytest.mark.parametrize("compact", ["1", "2"])
+@pytest.mark.parametrize("compact", ["1", "0"])
 def test_the_partition_kernels_agree_on_crowded_hot_sets_simple_counters_and_refusals(make_engine, monkeypatch, compact):
-    """What k_bkt_part_l does differently from k_bkt_part_c, each against the oracle (and therefore against each other):
-    a FULL hot set (500+ keys over the threshold: groups of its slot table overflow into their neighbours, fingerprint
-    matches that are another key — the slot-by-slot path), simple counters in the batch (the cell must pre-exist,
-    in_memory.rs:106-107: one wave-uniform branch in the lean kernel), hot keys whose hits stop matching the set's
+    """Both shapes of the partition kernel, each against the oracle (and therefore against each other):
+    a FULL hot set (500+ keys over the threshold), simple counters in the batch (the cell must pre-exist,
+    in_memory.rs:106-107), hot keys whose hits stop matching the set's
     predicted delta / limit, a ragged last tile, and the three refusals of the validation pass — unknown limit id, reserved
     key, missing simple cell — which must leave the table untouched and name the same error."""
     from limitador_amd.engine import EngineError

@@ -168,145 +168,3 @@ def test_wave_private_counters_and_ballot_ranks_give_a_stable_partition(n, nb, s
     for t in rng.permutation(ntiles):  # tiles in any order
         scatter_tile(bucket, t * tile, n, steps, bucket_lo + prefix[t], out)
     assert np.array_equal(out, np.argsort(bucket, kind="stable")), "every bucket keeps its hits in trace order"
-
-
-# ---- k_bkt_part_l (rl_part.hpp): the hot table probed a group at a time, the counters bumped without waits ----------------
-HOT_SLOTS, HS_GROUPS = 2048, 512
-FREE = 0xFFFF
-
-
-def _fmix64(x):
-    x &= (1 << 64) - 1
-    x ^= x >> 33
-    x = (x * 0xff51afd7ed558ccd) & ((1 << 64) - 1)
-    x ^= x >> 33
-    x = (x * 0xc4ceb9fe1a85ec53) & ((1 << 64) - 1)
-    x ^= x >> 33
-    return x
-
-
-def _hs_group(hh):
-    return (hh >> 8) & (HS_GROUPS - 1)
-
-
-def _hs_fp(hh):
-    return (hh >> 20) & 31
-
-
-def build_hot_table(keys, deny, seed, order):
-    """Every key of the set inserts itself (any interleaving: `order`): from the first slot of its 4-slot-aligned group on,
-    the first slot that is free or holds the same key — a key listed twice keeps the smaller index."""
-    slots = [FREE] * HOT_SLOTS
-    for i in order:
-        hh = _fmix64(keys[i] ^ seed)
-        mine = i | (0x200 if deny[i] else 0) | (_hs_fp(hh) << 10)
-        s = _hs_group(hh) * 4
-        while True:
-            x = slots[s]
-            if x == FREE:
-                slots[s] = mine
-                break
-            if keys[x & 0x1FF] == keys[i]:
-                if (x & 0x1FF) > i:
-                    slots[s] = mine
-                break
-            s = (s + 1) & (HOT_SLOTS - 1)
-    return slots
-
-
-def lookup_plain(slots, keys, key, seed):
-    hh = _fmix64(key ^ seed)
-    q = _hs_group(hh) * 4
-    while True:
-        x = slots[q]
-        if x == FREE:
-            return None
-        if keys[x & 0x1FF] == key:
-            return x & 0x3FF
-        q = (q + 1) & (HOT_SLOTS - 1)
-
-
-def lookup_group(slots, keys, key, seed):
-    """The kernel's fast path: ONE read of the group; the first entry that is free or carries the key's fingerprint
-    decides.  Returns (answer, took_the_slow_path)."""
-    hh = _fmix64(key ^ seed)
-    g, fp = _hs_group(hh) * 4, _hs_fp(hh)
-    c = 0xFFFE
-    for e in reversed(slots[g:g + 4]):  # walked from the last entry to the first: the first deciding entry wins
-        c = FREE if e == FREE else (e if (e >> 10) == fp else c)
-    if c == FREE:
-        return None, False
-    if c != 0xFFFE and keys[c & 0x1FF] == key:
-        return c & 0x3FF, False
-    return lookup_plain(slots, keys, key, seed), True
-
-
-@pytest.mark.parametrize("n_hot,dups", [(0, 0), (1, 0), (375, 0), (512, 0), (512, 40), (300, 25)])
-def test_the_group_probed_hot_table_answers_like_the_plain_probe_whatever_the_insertion_order(n_hot, dups):
-    rng = np.random.default_rng(1000 + n_hot + dups)
-    seed = int(rng.integers(0, 1 << 63))
-    keys = [int(k) for k in rng.integers(1, 1 << 62, size=n_hot, dtype=np.uint64)]
-    for _ in range(dups):  # a key listed twice (a stale or arbitrary set is valid: rl_bucket.hpp)
-        a, b = rng.integers(0, n_hot, size=2)
-        keys[int(a)] = keys[int(b)]
-    # clustered keys too: many keys of ONE group, so that groups overflow into their neighbours
-    if n_hot >= 300:
-        base_g = None
-        k, filled = 1 << 40, 0
-        while filled < 11:
-            hh = _fmix64(k ^ seed)
-            if base_g is None:
-                base_g = _hs_group(hh)
-            if _hs_group(hh) == base_g and k not in keys:
-                keys[filled] = k
-                filled += 1
-            k += 1
-    deny = [bool(b) for b in rng.integers(0, 2, size=n_hot)]
-    want = {}
-    for i, k in enumerate(keys):
-        want.setdefault(k, i)  # the smaller index
-    tables = [build_hot_table(keys, deny, seed, rng.permutation(n_hot)) for _ in range(3)]
-    probes = list(dict.fromkeys(keys)) + [int(k) for k in rng.integers(1, 1 << 62, size=4000, dtype=np.uint64)]
-    slow = 0
-    for key in probes:
-        answers = set()
-        for slots in tables:
-            a, s = lookup_group(slots, keys, key, seed)
-            slow += s
-            assert a == lookup_plain(slots, keys, key, seed)
-            answers.add(None if a is None else a & 0x1FF)
-        assert len(answers) == 1, "two workgroups (two insertion orders) would send one key to two bins"
-        (a,) = answers
-        assert a == want.get(key)
-        if a is not None:
-            for slots in tables:
-                full, _ = lookup_group(slots, keys, key, seed)
-                assert bool(full & 0x200) == deny[a]
-    assert slow < 0.2 * 3 * len(probes)  # the fast path is the common one
-
-
-def test_counters_read_before_the_leaders_add_give_the_same_ranks_as_read_modify_write():
-    """k_bkt_part_l's phase 4: per 64-hit step every lane READS its (wave, bin) counter, then the lowest lane of every
-    group of equal bins ADDS the group's size — no lane waits for its read before the add is issued, because the add's
-    operand does not depend on it and LDS operations of one wave execute in issue order.  The ranks equal the stable
-    partition's: counter before the step + lanes of the same bin below me."""
-    rng = np.random.default_rng(7)
-    for steps, nbins in [(8, 1536), (8, 40), (4, 3)]:
-        d = rng.integers(0, nbins, size=(steps, LANES))
-        d[:, ::7] = 5 % nbins  # a hot bin in every step
-        cnt = np.zeros(nbins, dtype=np.int64)
-        ranks = np.zeros((steps, LANES), dtype=np.int64)
-        for u in range(steps):
-            pre = cnt[d[u]].copy()               # the step's loads (issued first)
-            for lane in range(LANES):
-                same = np.nonzero(d[u] == d[u, lane])[0]
-                below = int((same < lane).sum())
-                ranks[u, lane] = pre[lane] + below
-                if below == 0:                   # the group's leader: one add, the group's size
-                    cnt[d[u, lane]] += len(same)
-        seen = {}
-        for u in range(steps):
-            for lane in range(LANES):
-                b = int(d[u, lane])
-                assert ranks[u, lane] == seen.get(b, 0)
-                seen[b] = seen.get(b, 0) + 1
