@@ -133,10 +133,8 @@ struct rl_engine {
     unsigned long long* h_total = nullptr; // pinned
     // routing scratch
     u32* d_route_cnt = nullptr;
-    bool route_one = false;         // RL_ROUTE_ONE=1 (experiment builds): the router's partition by owner as ONE launch with a
-                                    // ticket barrier (k_route_one).  Measured slower than the three kernels (gpurun_out/r13e, r13f:
-                                    // 33-50 us for the launch, the replay beside it 45-58 us, 97 against 82 us per routed slice):
-                                    // its workgroups hold their places while they wait for the last one to arrive
+    // (the router's partition by owner as ONE launch with a ticket barrier, k_route_one: 33-50 us for the launch, the replay beside
+    // it 45-58 us, 97 against 82 us per routed slice — scripts/exp/patches/route_one_launch.patch)
     // bucketed hot path (rl_bucket.hpp)
     // the phased form of the general resolver (rl_gen_begin_device .. rl_gen_commit_device / rl_gen_abort)
     bool ph_open = false;
@@ -1998,7 +1996,6 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     ALLOC(e->d_chunk_tab, PB_SETS * e->chunk_tab_len * sizeof(unsigned short));
     ALLOC(e->d_route_cnt, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32));
     if (hipMemset(e->d_route_cnt, 0, (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD * sizeof(u32) + 64 * sizeof(u32)) != hipSuccess) return bail(RL_ERR_DEVICE);
-    if (const char* v = RL_EXP_ENV("RL_ROUTE_ONE")) e->route_one = atoi(v) != 0;
     ALLOC(e->d_m_ns, mb * sizeof(u32));
     ALLOC(e->d_m_delta, mb * sizeof(u32));
     ALLOC(e->d_m_ent_off, (mb + 1) * sizeof(u32));
@@ -3793,21 +3790,13 @@ static int32_t route_partition_on(rl_engine* e, hipStream_t st, bool block, cons
     if (block) HIP_TRY(e, hipSetDevice(e->device));
     const u32 nblk = n_hits ? cdiv(n_hits, ROUTE_TILE) : 0;
     if (nblk > ROUTE_MAX_BLOCKS) return fail(e, RL_ERR_BATCH_TOO_LARGE, "n_hits %u too large for the router", n_hits);
-    // count / scan / scatter; RL_ROUTE_ONE=1 (experiment builds): one launch with a ticket barrier (rl_route.hpp: k_route_one —
-    // parity-green, measured slower)
-    if (nblk && nblk <= ROUTE_ONE_MAX_BLOCKS && e->route_one) {
-        u32* sync = e->d_route_cnt + (size_t)ROUTE_MAX_BLOCKS * ROUTE_MAX_WORLD;  // (the 64 words behind the matrix: zero between launches)
-        k_route_one<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world, e->d_route_cnt, sync,
-                                                  d_counts, reinterpret_cast<Hit*>(d_out), d_perm);
-    } else {
-        if (nblk)
-            k_route_count<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world,
-                                                        e->d_route_cnt);
-        k_route_scan<<<1, 256, 0, st>>>(e->d_route_cnt, nblk, world, d_counts);
-        if (nblk)
-            k_route_scatter<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world,
-                                                          e->d_route_cnt, reinterpret_cast<Hit*>(d_out), d_perm);
-    }
+    // count / scan / scatter
+    if (nblk)
+        k_route_count<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world, e->d_route_cnt);
+    k_route_scan<<<1, 256, 0, st>>>(e->d_route_cnt, nblk, world, d_counts);
+    if (nblk)
+        k_route_scatter<<<nblk, ROUTE_BLOCK, 0, st>>>(reinterpret_cast<const Hit*>(d_hits), n_hits, e->seed, world, e->d_route_cnt,
+                                                      reinterpret_cast<Hit*>(d_out), d_perm);
     HIP_TRY(e, hipGetLastError());
     if (block) HIP_TRY(e, hipStreamSynchronize(st));
     return RL_OK;

@@ -19,8 +19,6 @@ constexpr int ROUTE_WAVE_TILE = 64 * ROUTE_ROUNDS;      // contiguous hits owned
 constexpr int ROUTE_TILE = 4 * ROUTE_WAVE_TILE;         // hits per workgroup
 constexpr int ROUTE_MAX_WORLD = 16;
 constexpr int ROUTE_MAX_BLOCKS = 8192;
-constexpr u32 ROUTE_ONE_MAX_BLOCKS = 1536;  // k_route_one: every workgroup resident (256 CUs x 8 places of 256 threads, a margin
-                                            // left for the engine's kernels beside it): batches up to 3 M hits
 
 // cnt layout: [owner][block], owner-major, so one linear exclusive scan yields final offsets.
 __global__ __launch_bounds__(ROUTE_BLOCK) void k_route_count(const Hit* __restrict__ hits, u32 n,
@@ -153,146 +151,6 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route_scatter(const Hit* __rest
             *reinterpret_cast<uint4*>(out + dest[r]) = v;
             perm[dest[r]] = i;
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_route_one: the three kernels above as ONE launch (round 5) — BUILT, PARITY-GREEN, MEASURED SLOWER, NOT THE DEFAULT
-// (RL_ROUTE_ONE=1 in experiment builds; gpurun_out/r13e, r13f: the launch takes 33-50 us — its workgroups hold their places on
-// the CUs while they sleep until the last of them has been dispatched, which beside a replay is late — the replay next to it
-// 45-58 us, a routed slice 97 us against 82 with the three kernels).  What DID carry over: k_route_count without an LDS atomic
-// per hit and k_route_scan as a tiled, prefetching block scan.  The reasoning it was built on:  The routed step at world 1 was HOST-bound — ~14 enqueues
-// of 5-7 us each per slice, 85 us per slice against 43 for the local pipeline (gpurun_out/r13d: host trace + kernel
-// timeline) — and three of those enqueues were the router's own count / scan / scatter, whose device time (15 + 5-11 +
-// 13-31 us beside a replay; k_route_count's LDS atomics all hit ONE word at world 1) was another 35-55 us of machine
-// shared with the engine's kernels.  One launch, every workgroup resident (2048 hits per workgroup: <= 8192 workgroups of
-// 256 threads fit the chip's 256 x 8 places for batches up to 4 M hits; beyond that the three-kernel form is taken):
-//   1. a wave loads its 8 x 64 hits ONCE (they stay in registers), counts them per owner with ballots, the workgroup
-//      publishes its per-owner counts (device-scope atomics: the eight XCDs' L2s only meet in memory) and takes a ticket;
-//   2. the LAST workgroup to arrive scans the (owner x workgroup) matrix — one workgroup, a few us — and raises a flag;
-//      everybody else sleeps on the flag;
-//   3. stable scatter from the registers, as before.
-// A workgroup that waits holds no lock anybody needs: whatever is not resident yet gets its place when a workgroup of
-// another kernel ends.  `sync` = {arrived, scan done, left}: the last workgroup to LEAVE zeroes the three words for the
-// next launch (launches of one engine's router are stream-ordered).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ROUTE_BLOCK) void k_route_one(const Hit* __restrict__ hits, u32 n, u64 seed, u32 world,
-                                                            u32* __restrict__ cnt, u32* __restrict__ sync,
-                                                            u32* __restrict__ counts, Hit* __restrict__ out,
-                                                            u32* __restrict__ perm) {
-    __shared__ u32 s_wcnt[4][ROUTE_MAX_WORLD];  // per wave, per owner: count, then running offset
-    __shared__ u32 s_part[ROUTE_BLOCK];
-    __shared__ u32 s_owner_tot[ROUTE_MAX_WORLD];
-    __shared__ u32 s_last;
-    const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const u32 nblk = gridDim.x, blk = blockIdx.x;
-    const u32 wbase = blk * ROUTE_TILE + wave * ROUTE_WAVE_TILE;
-    Hit h[ROUTE_ROUNDS];
-    u32 own[ROUTE_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUTE_ROUNDS; ++r) {
-        const u32 i = wbase + r * 64 + lane;
-        own[r] = 0xFFFFFFFFu;
-        if (i < n) {
-            h[r] = load_hit(hits, i);
-            own[r] = owner_of(h[r].key, seed, world);
-        }
-    }
-    for (u32 o = 0; o < world; ++o) {
-        u32 c = 0;
-#pragma unroll
-        for (int r = 0; r < ROUTE_ROUNDS; ++r) c += (u32)__popcll(__ballot(own[r] == o));
-        if (lane == 0) s_wcnt[wave][o] = c;
-    }
-    __syncthreads();
-    // ---- 1. publish, take a ticket -----------------------------------------------------------------------
-    if (tid < world) {
-        const u32 c = s_wcnt[0][tid] + s_wcnt[1][tid] + s_wcnt[2][tid] + s_wcnt[3][tid];
-        (void)__hip_atomic_exchange(&cnt[tid * nblk + blk], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&sync[0], 1u) == nblk - 1 ? 1u : 0u;
-    __syncthreads();
-    if (s_last) {
-        // ---- 2. the last one in: exclusive scan of cnt[world][nblk] in place, the owners' totals.  256 elements per step,
-        //         one per thread (coalesced device-scope loads), the next step's element requested before this step's scan:
-        //         the steps' memory round trips overlap (world 8 x 489 workgroups: 16 steps) ------------------------------
-        const u32 total = nblk * world;
-        if (tid < ROUTE_MAX_WORLD) s_owner_tot[tid] = 0;
-        __syncthreads();
-        u32 carry = 0;
-        u32 nxt = tid < total ? __hip_atomic_load(&cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        for (u32 base = 0; base < total; base += ROUTE_BLOCK) {
-            const u32 q = base + tid;
-            const u32 v = nxt;
-            const u32 qn = q + ROUTE_BLOCK;
-            nxt = qn < total ? __hip_atomic_load(&cnt[qn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            if (q < total && v) atomicAdd(&s_owner_tot[q / nblk], v);
-            u32 inc = v;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const u32 o2 = __shfl_up(inc, off);
-                if ((int)lane >= off) inc += o2;
-            }
-            __syncthreads();  // (s_part of the step before has been read)
-            if (lane == 63) s_part[wave] = inc;
-            __syncthreads();
-            u32 ex = carry + inc - v;
-            for (u32 w2 = 0; w2 < wave; ++w2) ex += s_part[w2];
-            if (q < total) (void)__hip_atomic_exchange(&cnt[q], ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        }
-        __syncthreads();
-        if (tid < world) counts[tid] = s_owner_tot[tid];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) (void)__hip_atomic_exchange(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (tid == 0) {
-        while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-    // ---- 3. wave offsets: the workgroup's base for the owner + the counts of the earlier waves; stable scatter ----------
-    if (tid < world) {
-        u32 run = __hip_atomic_load(&cnt[tid * nblk + blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int w = 0; w < 4; ++w) {
-            const u32 c = s_wcnt[w][tid];
-            s_wcnt[w][tid] = run;
-            run += c;
-        }
-    }
-    __syncthreads();
-    u32 dest[ROUTE_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUTE_ROUNDS; ++r) dest[r] = 0;
-    for (u32 o = 0; o < world; ++o) {
-        u32 run = s_wcnt[wave][o];
-#pragma unroll
-        for (int r = 0; r < ROUTE_ROUNDS; ++r) {
-            const u64 b = __ballot(own[r] == o);
-            if (own[r] == o) dest[r] = run + (u32)__popcll(b & ((1ull << lane) - 1ull));
-            run += (u32)__popcll(b);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < ROUTE_ROUNDS; ++r) {
-        if (own[r] != 0xFFFFFFFFu) {
-            const u32 i = wbase + r * 64 + lane;
-            uint4 v;
-            v.x = (u32)h[r].key;
-            v.y = (u32)(h[r].key >> 32);
-            v.z = h[r].limit;
-            v.w = h[r].delta;
-            *reinterpret_cast<uint4*>(out + dest[r]) = v;
-            perm[dest[r]] = i;
-        }
-    }
-    // ---- the last one out leaves the three words as it found them --------------------------------------------
-    __syncthreads();
-    if (tid == 0 && atomicAdd(&sync[2], 1u) == nblk - 1) {
-        (void)__hip_atomic_exchange(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)__hip_atomic_exchange(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)__hip_atomic_exchange(&sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

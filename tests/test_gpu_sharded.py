@@ -15,18 +15,15 @@ from limitador_amd.wire import HIT_DTYPE
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("form", ["one_launch", "three_kernels"])
 @pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
 @pytest.mark.parametrize("n", [1, 63, 2048, 100_003, 1_000_001])
-def test_route_partition_is_a_stable_partition_by_owner(world, n, form, monkeypatch):
-    """The three kernels of the router's partition by owner (the default) and k_route_one (RL_ROUTE_ONE=1: one launch — count,
-    the last workgroup in scans, scatter from registers; parity-green, measured slower), both against numpy's stable argsort;
-    three calls in a row on one engine (the one-launch form leaves its three sync words zeroed for the next launch)."""
+def test_route_partition_is_a_stable_partition_by_owner(world, n):
+    """The three kernels of the router's partition by owner against numpy's stable argsort; three calls in a row on one
+    engine."""
     from limitador_amd.engine import Engine
 
     if n > 200_000 and world not in (1, 8):
         pytest.skip("the large batch on two world sizes only")
-    monkeypatch.setenv("RL_ROUTE_ONE", "1" if form == "one_launch" else "0")
     eng = Engine(capacity_cells=1 << 12, max_batch_hits=max(1 << 17, n))
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(n * 31 + world)
