@@ -29,29 +29,12 @@
 
 namespace rl {
 
-// RL_STEP_WT (experiment variants, scripts/exp/build_variant.sh ... -DRL_STEP_WT=1|2): the replay's scattered stores written
-// THROUGH (sc1: they do not stay dirty in the L2).  Why it is worth a measurement now: with the cross-stream wait gone
-// (RL_DEFER2) the 4.4 us between two replays are the boundary of two dependent kernels, and behind a kernel that leaves 16 MB
-// dirty that boundary is 3.4-4.7 us against 1.1-2.0 behind write-through stores (profiles/r04h_kernel_gap.txt).  1: the cells'
-// 8-byte write-backs; 2: the one-byte verdicts too.
-#ifndef RL_STEP_WT
-#define RL_STEP_WT 0
-#endif
-__device__ __forceinline__ void store_cell_value(u64* p, u64 v) {
-#if RL_STEP_WT >= 1
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ void store_verdict(uint8_t* p, u32 v) {
-#if RL_STEP_WT >= 2
-    asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *p = (uint8_t)v;
-#endif
-}
-
+// (the replay's scattered stores written THROUGH — sc1 on the cells' 8-byte write-backs, on the one-byte verdicts too: the
+// boundary of two dependent kernels is 1.1-2.0 us behind write-through stores against 3.4-4.7 behind 16 MB left dirty,
+// profiles/r04h_kernel_gap.txt — built as compile-time variants in round 5 and never faster in the pipeline:
+// scripts/exp/patches/step_write_through.patch)
+__device__ __forceinline__ void store_cell_value(u64* p, u64 v) { *p = v; }
+__device__ __forceinline__ void store_verdict(uint8_t* p, u32 v) { *p = (uint8_t)v; }
 
 constexpr u32 AP2_BIG_DELTA = 1u << 23;  // 512 hits x (2^23 - 1) < 2^32: the round's sum fits 32 bits
 

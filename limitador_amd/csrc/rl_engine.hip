@@ -160,9 +160,10 @@ struct rl_engine {
     // of batch p (any stale set is valid, see HotSet).
     HotSet* d_hot = nullptr;
     u64 part_seq = 0;               // partitioned batches submitted so far
-    // Two streams: the partition of batch k+1 (k_bkt_hist / scan / scatter, on `pstream`) overlaps
-    // k_hot_state + k_bkt_apply of batch k (on `stream`).  With a caller's stream (rl_engine_set_stream)
-    // or RL_OVERLAP=0 both are the same stream.
+    // Two streams: the partition of batch k+1 (k_bkt_part_c / k_bkt_part: ONE launch, rl_part.hpp, on `pstream`) overlaps the
+    // replay of batch k (k_bkt_step, rl_apply.hpp, on `stream`).  With a caller's stream (rl_engine_set_stream) or
+    // RL_OVERLAP=0 both are the same stream.  (k_bkt_hist / scan / scatter — rl_bucket.hpp — partition the GENERAL resolver's
+    // passes only, on `stream`.)
     hipStream_t pstream = nullptr, own_pstream = nullptr;
     // RL_XOVER=2 (experiment builds; a MEASUREMENT device, the results are wrong): the replays of odd partitioned batches go to
     // `stream2` and nothing orders two consecutive replays — the ceiling of what a per-bucket hand-over between overlapped
@@ -170,7 +171,7 @@ struct rl_engine {
     hipStream_t stream2 = nullptr;
     int xover = 0;
     bool overlap = true;
-    bool ext_events = true;         // RL_EXT_EVENTS=0: hipEventRecord markers behind k_bkt_scatter / k_bkt_apply instead of the
+    bool ext_events = true;         // RL_EXT_EVENTS=0: hipEventRecord markers behind k_bkt_part_c / k_bkt_step instead of the
                                     // launches' own stop events (two marker commands fewer per batch on the two streams)
     u32* d_hot_arrive = nullptr;    // [2][HOT_MAX] (apply2_hot_item), by the parity of the partitioned batch
     u64* d_cmark = nullptr;         // do_compact in place: the segments' bounds (k_compact_bounds), allocated at the first compaction
@@ -367,13 +368,8 @@ struct rl_engine {
     rl_stats_t stats{};
 
     int timing = 0;  // 0 off, 1 every kernel of the hot path, 2 k_bkt_apply only, 3 k_bkt_apply of every 4th batch
-    // RL_TIMING_LAZY=1 (experiment builds; prepared in round 4, not yet run on a GPU): a timed batch's events are not read in its
-    // own collect — two hipEventSynchronize and up to four hipEventElapsedTime between that collect and the next submit, which
-    // is what every fourth gap of the replay stream carries on top (profiles/r04f_kernel_stats.csv) — but at the start of the
-    // NEXT collect, in front of its wait for a batch the device is still busy with (the events of an in-flight slot live
-    // until the slot is reused four batches on; "applied" of the batch before until the replay three batches on goes out).
-    bool timing_lazy = false;
-    int timing_todo = -1;  // in-flight slot whose timed events are still to be read
+    // (reading a timed batch's events at the start of the NEXT collect instead of in its own, RL_TIMING_LAZY: moved nothing, +-0.3 us:
+    // profiles/r05a_defer2.md 2 — scripts/exp/patches/timing_lazy.patch)
     hipEvent_t ev[8]{};
     double ms_slot[RL_TIMING_SLOTS]{};
     u64 timed_launches = 0;
@@ -597,7 +593,6 @@ int do_compact(rl_engine* e, u32 new_log2cap) {
 // Spin until the batch's last workgroup has stored its sequence number (see apply_finish).
 int poll_pending_apply(rl_engine* e);
 int read_timing(rl_engine* e, rl_engine::Inflight& f);
-int read_timing_todo(rl_engine* e);
 
 // `poll` (RL_DEFER2): while the host waits, replays that are held back go out as soon as their partitions are seen complete.
 int wait_done(rl_engine* e, rl_engine::Inflight& f, bool poll = false) {
@@ -856,10 +851,6 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
         if (rc) return rc;
     }
     e->gen_clean = false;  // (this batch's scratch block is not the general resolver's to find clean)
-    if (e->timing_todo == (int)(e->sub_seq & 3u)) {  // (RL_TIMING_LAZY: the slot's events are about to be recorded again)
-        rc = read_timing_todo(e);
-        if (rc) return rc;
-    }
     rl_engine::Inflight& f = e->inflight[e->sub_seq & 3u];
     // timing: 1 both kernels of every batch, 2 k_bkt_apply of every batch, 3 both kernels of every fourth batch
     const bool t_apply = e->timing == 1 || e->timing == 2 || (e->timing == 3 && (e->sub_seq & 3u) == 0);
@@ -1089,12 +1080,6 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
 int collect_k1_bucketed(rl_engine* e) {
     if (e->sub_seq == e->col_seq) return fail(e, RL_ERR_INVALID, "no batch in flight");
     rl_engine::Inflight& f = e->inflight[e->col_seq & 3u];
-    if (e->timing_todo >= 0) {
-        // RL_TIMING_LAZY: the timed events of the batch collected before this one — read here, in front of the wait for this
-        // batch (the device is busy with it), and before anything below sends out a replay that takes over one of those events
-        const int trc = read_timing_todo(e);
-        if (trc) return trc;
-    }
     if (e->pend_old.valid && e->pend_old.slot == (u32)(e->col_seq & 3u)) {  // the batch being collected is itself held back
         const int prc = flush_one(e, e->pend_old, nullptr);
         if (prc) return prc;
@@ -1209,12 +1194,6 @@ int collect_k1_bucketed(rl_engine* e) {
     e->stats.batches++;
     e->stats.hits += f.n;
     if (f.h_st->err) return status_to_error(e, f.h_st->err);
-    if (f.timed && e->timing_lazy) {
-        const int trc = read_timing_todo(e);  // (a batch timed before this one whose events nobody has read yet)
-        if (trc) return trc;
-        e->timing_todo = (int)((e->col_seq - 1) & 3u);
-        return RL_OK;
-    }
     return read_timing(e, f);
 }
 
@@ -1245,13 +1224,6 @@ int read_timing(rl_engine* e, rl_engine::Inflight& f) {
         if (f.timed & 2) e->timed_launches++;
     }
     return RL_OK;
-}
-
-int read_timing_todo(rl_engine* e) {
-    if (e->timing_todo < 0) return RL_OK;
-    rl_engine::Inflight& f = e->inflight[e->timing_todo];
-    e->timing_todo = -1;
-    return read_timing(e, f);
 }
 
 // check_and_update for single-counter requests, all pointers on the device: the bucketed
@@ -1840,7 +1812,6 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_GEN_CARRY_REQ")) e->gen_carry_req = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_WRITERS")) e->resp_writers = (u32)std::max(1, atoi(v));
     if (const char* v = RL_EXP_ENV("RL_RESP_PIECES")) e->resp_pieces = std::min<u32>(rl_engine::RESP_CHUNKS, std::max(1, atoi(v)));
-    if (const char* v = RL_EXP_ENV("RL_TIMING_LAZY")) e->timing_lazy = atoi(v) != 0;
     if (e->fuse) e->overlap = false;  // one stream: the partition rides in the replay's launch
     if (const char* v = RL_EXP_ENV("RL_APPLY_TRACE")) e->apply_trace = atoi(v);
     if (const char* v = RL_EXP_ENV("RL_HOT_WGS")) e->hot_wgs = (u32)std::min(std::max(atoi(v), 8), 1024);
@@ -3957,7 +3928,6 @@ int32_t rl_kernel_timing(rl_engine* e, int32_t enable) try {
 int32_t rl_kernel_timing_read(rl_engine* e, double* ms, uint64_t* launches, int32_t reset) try {
     if (!e) return RL_ERR_INVALID;
     EngineLock g(e);
-    (void)read_timing_todo(e);
     if (ms)
         for (int q = 0; q < RL_TIMING_SLOTS; ++q) ms[q] = e->ms_slot[q];
     if (launches) *launches = e->timed_launches;
