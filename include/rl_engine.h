@@ -386,7 +386,10 @@ int32_t rl_match_batch_op(rl_engine *e, int32_t op, const uint32_t *req_ns, cons
  * `descriptors`, one map per descriptor: envoy_rls/server.rs:121-137; `descriptors[1].y` is key "y" with i = 1) —
  * vals[value id] for every id the conditions use (<= 512), limit_prefix[2 * limit id ..] = rl_kh_bytes of the limit's canonical prefix, and
  * hash_key[2] = the 128-bit secret every hash of this path is keyed with (include/rl_keyhash.h: the prefixes must have
- * been hashed under the same key; whoever else derives keys for this table — another front-end, a restart — needs it). */
+ * been hashed under the same key; whoever else derives keys for this table — another front-end, a restart — needs it).
+ * The engine remembers a FINGERPRINT of the key (never the key), rl_snapshot_save writes it into the file's header and
+ * rl_snapshot_load brings it back: a table that holds cells is not given a table set under another key — RL_ERR_INVALID,
+ * where a silent acceptance would orphan every hashed counter (all limits start from zero, the old cells linger). */
 typedef struct {
     uint32_t off, len; /* a string: blob[off .. off + len) */
 } rl_wire_str;
@@ -440,6 +443,9 @@ int32_t rl_wire_match_and_check_batch(rl_engine *e, const uint8_t *wire, const u
 #define RL_SERVE_HEADERS 1u
 #define RL_SERVE_ASYNC 2u
 int32_t rl_resp_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, const rl_wire_str *frag, uint32_t n_limits);
+/* 1 once rl_resp_table_set has been called on THIS engine (a host layer that remembers "I sent the fragments to engine X"
+ * by address asks the engine itself: a destroyed engine's address may come back with the next one). */
+int32_t rl_resp_table_ready(rl_engine *e);
 int32_t rl_match_serve_batch(rl_engine *e, const uint32_t *req_ns, const uint32_t *ent_off, const uint32_t *ent_key,
                              const uint32_t *ent_val, const uint32_t *req_delta, uint32_t n_req, uint64_t now_us,
                              uint32_t flags, uint8_t *verdict, const uint32_t **resp_off, const uint8_t **resp);

@@ -1120,7 +1120,9 @@ static std::string limit_fragment(const LimitSpec* L) {
 // The fragments on the device (rl_resp_table_set), where the responses with headers are built (rl_resp.hpp).
 static int32_t send_fragments(rli_ingest* g, rl_engine* e) {
     std::lock_guard<std::mutex> one(g->frag_mu);
-    if (g->resp_engine == e && g->resp_sent == g->resp_version) return RL_OK;
+    // (the engine itself says whether it HAS a fragment table: an engine destroyed and another one created at the same address
+    // must not inherit "already sent" — ADVICE r05)
+    if (g->resp_engine == e && g->resp_sent == g->resp_version && rl_resp_table_ready(e)) return RL_OK;
     std::vector<uint8_t> blob;
     std::vector<rl_wire_str> frag(g->limits.size());
     for (size_t l = 0; l < g->limits.size(); ++l) {

@@ -275,6 +275,7 @@ struct rl_engine {
     MatchCondF* d_match_fconds = nullptr;
     MatchSlots match_slots{};
     u32 match_var_slots = 0;        // slots some limit of the fast table reads as a variable
+    u64 wire_key_fp = 0;            // fingerprint of the hash key the table's hashed cells were named under (rl_wire_table_set; 0: none yet)
     u32 match_max_vars = 0;         // most variables of one limit of the table (> 2: only the hashed-key wire path derives its counters)
     u32 match_max_limit_id = 0;
     // the wire path without host dictionaries (rl_wire.hpp): tables of rl_wire_table_set, staging of a batch of messages
@@ -2663,7 +2664,7 @@ int32_t rl_load_cells(rl_engine* e, const rl_cell_row* rows, uint64_t n) try {
 namespace {
 struct SnapshotHeader {
     char magic[8];  // "RLSNAP02"
-    u64 n_cells, n_limits, hash_seed, reserved;
+    u64 n_cells, n_limits, hash_seed, reserved;  // reserved: fingerprint of the hash key of the hashed cells (0: none)
 };
 }  // namespace
 
@@ -2686,6 +2687,7 @@ int32_t rl_snapshot_save(rl_engine* e, const char* path) try {
     h.n_cells = rows.size();
     h.n_limits = e->h_limits.size();
     h.hash_seed = e->seed;
+    h.reserved = e->wire_key_fp;  // (fingerprint of the hash key the hashed cells were named under; 0: none)
     std::vector<rl_limit_row> lim(e->h_limits.size());
     for (size_t i = 0; i < lim.size(); ++i) lim[i] = rl_limit_row{e->h_limits[i].max_value, e->h_limits[i].window_us / 1000000ull};
     bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (lim.empty() || fwrite(lim.data(), sizeof(rl_limit_row), lim.size(), f) == lim.size()) &&
@@ -2718,6 +2720,10 @@ int32_t rl_snapshot_load(rl_engine* e, const char* path) try {
         const size_t m = std::min<size_t>(1u << 20, rows.size() - lo);
         rc = rl_load_cells(e, rows.data() + lo, m);
         if (rc) return rc;
+    }
+    if (h.reserved) {
+        EngineLock g(e);
+        e->wire_key_fp = h.reserved;  // (rl_wire_table_set refuses another key while these cells are here)
     }
     return RL_OK;
 } RL_ABI_CATCH
@@ -3214,6 +3220,11 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
             return fail(e, RL_ERR_INTERNAL, "the responses take %u bytes, the bound said %llu (the batch was applied)", off[n], (unsigned long long)bound);
         return RL_OK;
     }
+    // (offsets are 32 bits — k_xscan over 32-bit lengths: a batch whose responses COULD pass 4 GiB is refused here, like the
+    // path above does with its bound, instead of letting the scan wrap and the responses overlap — ADVICE r05)
+    if (bound > 0xFFFFFFFFull)
+        return fail(e, RL_ERR_BATCH_TOO_LARGE, "the batch's responses may take %llu bytes (> 4 GiB of 32-bit offsets): serve it in smaller batches (the batch WAS applied)",
+                    (unsigned long long)bound);
     HIP_TRY(e, hipMemcpyAsync(h_off, e->d_resp_off, ((size_t)n + 1) * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     const u64 total = static_cast<const u32*>(h_off)[n];
@@ -3465,6 +3476,17 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     if (n_vals > WIRE_LIT_TAB / 2) return fail(e, RL_ERR_INVALID, "%u condition literals > %u", n_vals, WIRE_LIT_TAB / 2);
     if (n_limits <= e->match_max_limit_id)
         return fail(e, RL_ERR_INVALID, "limit_prefix has %u rows, the match table names limit id %u", n_limits, e->match_max_limit_id);
+    // The hash key NAMES the cells: a table that holds counters keyed under one key is not served under another (a restart
+    // that reloaded a snapshot without bringing the ingest's key back, a second front-end with a key of its own: every limit
+    // would silently start from zero and the old cells would sit there until they expire — ADVICE r05).  What is kept is a
+    // fingerprint — SipHash of a constant under the key — in the engine and in the snapshot's header; never the key itself.
+    static const uint8_t fp_text[] = "limitador_amd: hash key fingerprint";
+    const u64 key_fp = rl_kh_bytes(fp_text, sizeof(fp_text) - 1, rl_hkey{hash_key[0], hash_key[1]}).h1 | 1ull;
+    if (e->wire_key_fp && e->wire_key_fp != key_fp && e->live)
+        return fail(e, RL_ERR_INVALID,
+                    "the table holds %llu cells named under ANOTHER hash key: give this ingest the key the table was filled with "
+                    "(rli_set_hash_key with the first ingest's rli_hash_key — before a snapshot is reloaded too), or clear the table",
+                    (unsigned long long)e->live);
     auto inside = [&](const rl_wire_str& s) { return (u64)s.off + s.len <= blob_len && s.len <= 0xFFFFu; };
     for (u32 i = 0; i < n_ns; ++i)
         if (!inside(ns[i])) return fail(e, RL_ERR_INVALID, "namespace string %u lies outside the blob", i);
@@ -3512,6 +3534,7 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     W.hkey = rl_hkey{hash_key[0], hash_key[1]};
     e->wire_t = W;
     e->wire_ready = true;
+    e->wire_key_fp = key_fp;
     return RL_OK;
 } RL_ABI_CATCH
 
@@ -3696,6 +3719,8 @@ int32_t rl_resp_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
     e->resp_ready = true;
     return RL_OK;
 } RL_ABI_CATCH
+
+int32_t rl_resp_table_ready(rl_engine* e) { return e && e->resp_ready ? 1 : 0; }
 
 int32_t rl_match_serve_batch(rl_engine* e, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
                              const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,

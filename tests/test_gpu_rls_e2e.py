@@ -709,3 +709,36 @@ def test_two_serving_calls_in_flight_answer_like_one_at_a_time(make_engine, monk
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not failures, failures[:3]
+
+
+def test_a_table_is_not_served_under_another_hash_key(make_engine, tmp_path):
+    """the hash key names the cells.  An engine that holds hashed counters — filled directly, or reloaded from a
+    snapshot (the file's header carries the key's fingerprint, never the key) — refuses the tables of an ingest with another
+    key, where accepting them would silently restart every limit; the ingest that was given the first one's key is served and
+    goes on counting on the same cells."""
+    from limitador_amd.ingest import IngestError
+
+    def ingest(hash_key=None):
+        g = Ingest(keys="hashed", hash_key=hash_key)
+        assert g.add_limit("ns", 5, 60, [], ["descriptors[0].u"]) == 0
+        return g
+
+    eng = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
+    g1 = ingest()
+    g1.install(eng)
+    req = rls_request("ns", [[("u", "alice")]])
+    status, _ = g1.serve_batch(eng, [req] * 3, NOW, with_headers=False)
+    assert status == [0, 0, 0]
+    other = ingest()  # (a key of its own, drawn at rli_create)
+    with pytest.raises(IngestError, match="ANOTHER hash key"):
+        other.install(eng)
+    path = str(tmp_path / "snap.bin")
+    eng.snapshot_save(path)
+    eng2 = make_engine(capacity_cells=1 << 12, max_batch_hits=1 << 12)
+    eng2.snapshot_load(path)
+    with pytest.raises(IngestError, match="ANOTHER hash key"):
+        ingest().install(eng2)
+    g2 = ingest(hash_key=g1.hash_key)
+    g2.install(eng2)
+    status, _ = g2.serve_batch(eng2, [req] * 3, NOW, with_headers=False)
+    assert status == [0, 0, 1]  # 3 of 5 were counted before the snapshot: two more fit, the sixth does not
