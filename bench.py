@@ -150,6 +150,9 @@ def cpu_baseline(args, budget_s):
             best = (r[0], cores, r[1])
     return {"value": best[0], "unit": "decisions/s", "cores": best[1], "host_physical_cores": physical,
             "host_logical_cpus": logical, "threads_tried": tried, "kind": "port", "single_thread": single,
+            # `value` is the BEST of the thread counts tried (the box is shared: the per-count rates are not monotonic from
+            # run to run — threads_tried has every one of them, spread = max / min over the counts)
+            "best_of": True, "spread_over_thread_counts": (max(tried.values()) / max(1e-9, min(tried.values()))) if tried else None,
             "sample": f"{best[2]} batches x {n} hits over {best[1]} threads (keys hash-sharded, one table per thread, "
                       f"partition not timed) + {i} batches on one thread; {args.keys} keys, zipf {args.zipf}; "
                       f"oracle/limitador_oracle.c (hash-map table, no CEL/moka/tracing)"}
@@ -488,7 +491,9 @@ def secondary(args, eng, dev, gen):
             "requests_per_s": m["requests_per_s"], "ms_per_call": m["ms_per_step"], "counters_per_call": m["counters_per_batch"],
             # the same 49 B per (request x counter) as the headline, over the whole call (matcher + resolver)
             "achieved_GBps_49B": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
-            "note": "rl_match_and_check_batch_device: k_match_fast + general resolver (round 1: 2.03 ms per call)"}
+            "note": "rl_match_and_check_batch_device: matcher (k_match_count2 / scan2 / fill2) + general resolver "
+                    "(round 1: 2.03 ms per call, round 5: 0.426-0.438; kernel by kernel with PMC traffic: "
+                    "profiles/r06a_general_kernels.md, r06f_general_kernels.md)"}
     except Exception as ex:
         out["configs4_shape_match_and_check_1M_requests"] = {"error": str(ex)[:200]}
     # -- the wire path: serialized RateLimitRequests -> verdicts -> RateLimitResponse bytes, per batch size,
@@ -504,14 +509,21 @@ def secondary(args, eng, dev, gen):
             wp[keys] = {n: dict({"codes_only_ms": v["codes_only"]["p50_ms"], "with_headers_ms": v["with_headers"]["p50_ms"],
                                  "requests_per_s": v["codes_only"]["requests_per_s"]},
                                 **({"kuadrant_check_ms": v["kuadrant_check"]["p50_ms"], "kuadrant_report_ms": v["kuadrant_report"]["p50_ms"]}
-                                   if "kuadrant_check" in v else {}))
+                                   if "kuadrant_check" in v else {}),
+                                # two rli_serve_batch calls in flight on one ingest / engine (round 6): sustained ms per batch
+                                **({"with_headers_two_in_flight_ms_per_batch": v["with_headers_two_in_flight"]["ms_per_batch_sustained"],
+                                    "with_headers_two_in_flight_requests_per_s": v["with_headers_two_in_flight"]["requests_per_s"],
+                                    "with_headers_two_in_flight_call_p50_ms": v["with_headers_two_in_flight"]["call_p50_ms"]}
+                                   if "with_headers_two_in_flight" in v else {}))
                         for n, v in m["sizes"].items() if n in ("256", "32768", "262144")}
         out["wire_path_rli_serve_batch"] = dict(wp, note="p50 of the C call per batch of N serialized messages (4 namespaces x 8 limits, "
                                                 "Zipf users); exact = host dictionaries + packed ids, hashed = RLI_KEYS_HASHED "
                                                 "(messages decoded on the device, keys = hash of the canonical key bytes); with "
                                                 "headers the response bytes are built on the device from 4096 messages on "
                                                 "(rl_resp.hpp); kuadrant_check / kuadrant_report = rli_serve_batch_op, the Kuadrant "
-                                                "service's CheckRateLimit (is_rate_limited, read-only) and Report (update_counters)")
+                                                "service's CheckRateLimit (is_rate_limited, read-only) and Report (update_counters); "
+                                                "with_headers_two_in_flight_* = two threads calling rli_serve_batch back to back on the "
+                                                "same ingest / engine, each on one of the two serving sets (profiles/r06_wire_two_in_flight.md)")
     except Exception as ex:
         out["wire_path_rli_serve_batch"] = {"error": str(ex)[:200]}
     # -- the streaming maintenance kernels over the headline's table (LAST: they change it): a sweep that finds nothing

@@ -359,13 +359,38 @@ __device__ __forceinline__ void match_slot_values(MatchLdsTables& S, const Match
     u32 v[MATCH_SLOTS];
 #pragma unroll
     for (u32 sl = 0; sl < MATCH_SLOTS; ++sl) v[sl] = MATCH_NO_VALUE;
+    // The entries' loads are the kernel's one chain (offsets -> entries -> LDS walk): four entries at a time come as ONE
+    // 16-byte load per array when the request's first entry is 16-byte aligned (a batch of 4-entry requests always is) instead
+    // of eight scalar loads issued one behind the other.
+    u32 ek[MATCH_REG_ENTRIES], ev[MATCH_REG_ENTRIES];
+    if ((((size_t)(ent_key + b) | (size_t)(ent_val + b)) & 15u) == 0u && n >= 4u) {
+        const uint4 k4 = *reinterpret_cast<const uint4*>(ent_key + b), v4 = *reinterpret_cast<const uint4*>(ent_val + b);
+        ek[0] = k4.x, ek[1] = k4.y, ek[2] = k4.z, ek[3] = k4.w;
+        ev[0] = v4.x, ev[1] = v4.y, ev[2] = v4.z, ev[3] = v4.w;
+        if (n >= 8u) {
+            const uint4 k8 = *reinterpret_cast<const uint4*>(ent_key + b + 4), v8 = *reinterpret_cast<const uint4*>(ent_val + b + 4);
+            ek[4] = k8.x, ek[5] = k8.y, ek[6] = k8.z, ek[7] = k8.w;
+            ev[4] = v8.x, ev[5] = v8.y, ev[6] = v8.z, ev[7] = v8.w;
+        } else {
+#pragma unroll
+            for (u32 q = 4; q < MATCH_REG_ENTRIES; ++q) {
+                ek[q] = q < n ? ent_key[b + q] : 0u;
+                ev[q] = q < n ? ent_val[b + q] : 0u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (u32 q = 0; q < MATCH_REG_ENTRIES; ++q) {
+            ek[q] = q < n ? ent_key[b + q] : 0u;
+            ev[q] = q < n ? ent_val[b + q] : 0u;
+        }
+    }
 #pragma unroll
     for (u32 q = 0; q < MATCH_REG_ENTRIES; ++q) {
         if (q < n) {
-            const u32 ek = ent_key[b + q], val = ent_val[b + q];
 #pragma unroll
             for (u32 sl = 0; sl < MATCH_SLOTS; ++sl)
-                if (sl < slots.n && ek == slots.key[sl] && v[sl] == MATCH_NO_VALUE) v[sl] = val;
+                if (sl < slots.n && ek[q] == slots.key[sl] && v[sl] == MATCH_NO_VALUE) v[sl] = ev[q];
         }
     }
     for (u32 q = MATCH_REG_ENTRIES; q < n; ++q) {
