@@ -1074,6 +1074,11 @@ int submit_k1_bucketed(rl_engine* e, const Hit* d_hits, u32 n, u64 now, uint8_t*
     // partition; two-stream engines: by then the host sees the partition's event complete) or with its own collect — unless
     // the caller orders its own work on the engine's stream, which must then hold everything submitted so far.
     if (!e->defer_apply || e->external_stream || !(two_streams || e->fuse)) return flush_pending_apply(e);
+    // A batch submitted into an EMPTY pipeline has no replay in front of it to hide its partition behind: held back, its
+    // replay would only go out with the second submit behind it or the first collect — 12 us after the partition had ended, at
+    // the start of every burst (the kernel trace of bench.py's 20 timed steps: the first replay started 39 us into the region,
+    // 27 of them the partition).  It goes out now, behind a wait for its partition's event, on a stream that is idle anyway.
+    if (two_streams && e->sub_seq - e->col_seq == 1) return flush_pending_apply(e);
     return RL_OK;
 }
 
