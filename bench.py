@@ -30,9 +30,22 @@ ALGO_BYTES = {"apply": 49, "part": 0}
 NOT_KERNELS = ("apply_gap", "part_slack")  # timing slots that are intervals between kernels
 ALGO_BYTES_TOTAL = 49
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# roofline.random_line_frac: what the replay is actually bound by
+# roofline.random_line_frac: what the replay is actually bound by.  The two inputs come from the last evidence
+# visit's profiles/random_line.json (scripts/gpu_final_r06.sh + scripts/summarize_sq.py: the replay's TCP -> TCC requests per
+# launch, the random-access slope microbenchmark of the same visit); the constants below are round 4's, used only if that
+# file is missing.
 RANDOM_TRANSACTIONS_PER_1M_ZIPF = 1.45e6  # profiles/r04h_replay_memory_path.md (configs[2], 1 M-hit Zipf-0.99 batch)
 RANDOM_LINE_RATE = 57e9                   # random 32-byte cell reads per second, chip-wide: profiles/r04a_random_slope.txt
+
+
+def _random_line_model():
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "random_line.json")))
+        return float(j["transactions_per_launch"]), float(j["lines_per_s"]), {"file": "profiles/random_line.json", "profile": j.get("source"),
+                                                                                "commit": j.get("commit")}
+    except Exception:
+        return RANDOM_TRANSACTIONS_PER_1M_ZIPF, RANDOM_LINE_RATE, {"file": None, "profile": "round-4 constants in bench.py",
+                                                                   "commit": None}
 
 
 def parse(argv=None):
@@ -991,10 +1004,10 @@ def main(argv=None, platform=None):
                          # ~400 k, one-byte verdict stores ~200 k: profiles/r04h_replay_memory_path.md, from the TCP / TCC
                          # counters); the chip's measured random-line rate is 57 G/s (profiles/r04a_random_slope.txt).
                          # random_line_frac = (transactions / 57 G/s) / the kernel's launch time: 1.0 = at the fabric's line rate.
-                         "random_line_frac": ((RANDOM_TRANSACTIONS_PER_1M_ZIPF / RANDOM_LINE_RATE) / (per[dom] * 1e-3))
+                         "random_line_frac": ((_random_line_model()[0] / _random_line_model()[1]) / (per[dom] * 1e-3))
                          if (default_workload and per.get(dom, 0) > 0) else None,
-                         "random_line_model": {"transactions_per_launch": RANDOM_TRANSACTIONS_PER_1M_ZIPF, "lines_per_s": RANDOM_LINE_RATE,
-                                               "source": "profiles/r04h_replay_memory_path.md, profiles/r04a_random_slope.txt"}
+                         "random_line_model": {"transactions_per_launch": _random_line_model()[0], "lines_per_s": _random_line_model()[1],
+                                               "measured_at": _random_line_model()[2]}
                          if default_workload else None,
                          "timed_with": (f"HIP events on {kt['launches']} of the {args.steps} launches of the timed region: "
                                         "the launch carries its own start / stop events (hipExtLaunchKernelGGL), no marker "
