@@ -137,6 +137,7 @@ struct rl_engine {
     // it 45-58 us, 97 against 82 us per routed slice — scripts/exp/patches/route_one_launch.patch)
     // bucketed hot path (rl_bucket.hpp)
     // the phased form of the general resolver (rl_gen_begin_device .. rl_gen_commit_device / rl_gen_abort)
+    bool ph_async = false;  // rl_gen_set_async: rl_gen_round_device leaves its kernels on the (caller's) stream without waiting for them
     bool ph_open = false;
     GenArgs ph_A{};
     BatchScratch* ph_bs = nullptr;
@@ -2843,7 +2844,7 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
         if (rc) return rc;
         Status h_bst;
         GenStatus h_gst;
-        HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(&h_bst, &bs->st, sizeof(Status), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         if (h_bst.err | h_gst.err) {
@@ -2887,9 +2888,18 @@ int32_t rl_gen_round_device(rl_engine* e, const uint8_t* d_admitted, uint8_t* d_
     k_gen_piece_sum<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, e->stream>>>(A, 0u, 0u);
     k_gen_round<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, e->stream>>>(A, 0u, 0u, 1u);
     HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    // (a caller that owns the engine's stream — rl_engine_set_stream(…, external) — orders what reads d_pass by that stream or
+    // by events recorded on it: the router's rounds no longer stop here, rl_gen_set_async)
+    if (!(e->ph_async && e->external_stream)) HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->ph_rounds++;
     e->ph_counted = false;
+    return RL_OK;
+} RL_ABI_CATCH
+
+int32_t rl_gen_set_async(rl_engine* e, int32_t on) try {
+    if (!e) return RL_ERR_INVALID;
+    EngineLock g(e);
+    e->ph_async = on != 0;
     return RL_OK;
 } RL_ABI_CATCH
 
@@ -2916,7 +2926,7 @@ int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_
     HIP_TRY(e, hipMemsetAsync(&e->d_gst->n_new, 0, sizeof(u32), e->stream));
     k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A);
     GenStatus h_gst;
-    HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
     else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
@@ -2937,7 +2947,7 @@ int32_t rl_gen_commit_device(rl_engine* e) try {
     const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
     k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
     GenStatus h_gst;
-    HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, sizeof(GenStatus), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (!h_gst.committed) {
         (void)gen_phase_close(e);

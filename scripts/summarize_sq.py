@@ -71,8 +71,8 @@ if os.path.exists(p):
     for ln in open(p):
         if ln.startswith("== table"):
             big = "2^25" in ln or "2^26" in ln
-        m = re.search(r"^\s+read32\s.*=>\s+([0-9.]+) G accesses/s", ln)
-        if m and big:
+        m = re.search(r"^\s+read32\s+1M\s.*=>\s+([0-9.]+) G accesses/s", ln)  # (the plain row, not "read32 (2nd half late)")
+        if m and big and rate is None:
             rate = float(m.group(1)) * 1e9
 L.append("## The random-line model's inputs, measured in this visit\n")
 L.append(f"`k_bkt_step`, per launch (1 M-hit Zipf-0.99 batch): {step.get('TCP_TCC_READ_REQ_sum', float('nan')):.0f} read requests + "
