@@ -497,6 +497,10 @@ int32_t rl_gen_round_device(rl_engine *e, const uint8_t *d_admitted, uint8_t *d_
 int32_t rl_gen_count_device(rl_engine *e, const uint8_t *d_reached, uint32_t *n_new, uint64_t *room);
 int32_t rl_gen_commit_device(rl_engine *e);
 int32_t rl_gen_abort(rl_engine *e);
+/* A caller that owns the engine's stream (rl_engine_set_stream(e, stream, 1)) and orders what reads d_pass by that stream or by
+ * events recorded on it: with on != 0, rl_gen_round_device returns with its kernels enqueued instead of waiting for them
+ * (the multi-GPU router's rounds; begin / count / commit still return results to the host and therefore wait). */
+int32_t rl_gen_set_async(rl_engine *e, int32_t on);
 
 /* ---- multi-GPU routing helpers (device pointers, engine's stream) ----------------------- */
 /* Owner shard of a key for a world of `world` shards (any world >= 1). */

@@ -112,6 +112,7 @@ def _declare(lib):
     _sig(lib, "rl_match_serve_batch", C.c_int32, [p, p, p, p, p, p, C.c_uint32, C.c_uint64, C.c_uint32, p, C.POINTER(p), C.POINTER(p)])
     _sig(lib, "rl_wire_serve_batch", C.c_int32, [p, p, p, C.c_uint32, C.c_uint64, C.c_uint32, p, p, C.POINTER(p), C.POINTER(p), p])
     _sig(lib, "rl_resp_table_ready", C.c_int32, [p])
+    _sig(lib, "rl_gen_set_async", C.c_int32, [p, C.c_int32])
     _sig(lib, "rl_serve_wait", C.c_int32, [p, C.c_uint64])
     _sig(lib, "rl_wire_serve_batch_set", C.c_int32, [p, C.c_uint32, p, p, C.c_uint32, C.c_uint64, C.c_uint32, p, p, C.POINTER(p),
                                                    C.POINTER(p), p])

@@ -36,6 +36,7 @@ namespace {
 constexpr uint32_t RQ_GATHER = 16;   // rq.d_words[RQ_GATHER + p]: rank p's word of the last gather (multi-counter step)
 constexpr uint32_t RQ_CHANGED = 64;  // rq.d_words[RQ_CHANGED]: k_req_and raises it
 constexpr uint32_t RQ_WORDS = 128;
+constexpr uint32_t REQ_ID_LOCAL = 1u << 27;  // request id of the multi-counter step = rank * REQ_ID_LOCAL + the request's index on its rank
 constexpr int SLOTS = 4;          // slices in flight: one routed + up to three on the engine (applied / returned).  Three until
                                   // round 5: with `submit(k); collect(k - 2)` the host's ~55 us of enqueues per slice only
                                   // started once the replay of slice k - 2 had ENDED (the collect waits for it) — a bubble of
@@ -803,6 +804,10 @@ int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out) {
     return RL_OK;
 }
 int32_t gather_host_word(rl_sharded* s, uint32_t mine, uint32_t* out) {
+    if (s->world == 1) {  // (nobody to agree with: the word is the agreement — no device round trip)
+        out[0] = mine;
+        return RL_OK;
+    }
     s->rq.h_words[RQ_WORDS - 1] = mine;
     HIP_S(s, hipMemcpyAsync(s->rq.d_words, s->rq.h_words + RQ_WORDS - 1, 4, hipMemcpyHostToDevice, s->cs));
     return gather_words(s, s->rq.d_words, out);
@@ -859,45 +864,54 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
     const uint32_t W = s->world;
     auto& q = s->rq;
     uint32_t words[MAX_WORLD];
-    // ---- 0. every rank's request count (the ids of the ranks behind me start after mine); a rank whose arguments are
-    //         unusable says so HERE, so that all ranks leave together
+    // ---- 0. a rank whose arguments are unusable says so in the FIRST exchange (beside the counts), so that all ranks leave
+    //         together; request ids are (rank, local index) — no rank needs the others' request counts to number its own
     int32_t bad = RL_OK;
     if (mem_rc != RL_OK) bad = RL_ERR_NOMEM;
     else if (!s->pending.empty()) bad = RL_ERR_BUSY;
     else if ((n_hits && !d_hits) || !d_req_off || (n_req && !d_verdict) || (load_counters && n_hits && (!d_remaining || !d_expires_in_us)))
         bad = RL_ERR_INVALID;
-    else if (n_hits > s->max_slice || n_req > s->max_slice) bad = RL_ERR_BATCH_TOO_LARGE;
-    rc = gather_host_word(s, bad ? 0xFFFFFFFFu : n_req, words);
-    if (rc != RL_OK) return rc;
-    if (max_of(words, W) == 0xFFFFFFFFu) {
-        if (bad == RL_ERR_NOMEM) return fail(s, bad, "out of device memory for the step's arrays");
-        if (bad == RL_ERR_BUSY) return fail(s, bad, "slices are in flight: collect them first");
-        if (bad == RL_ERR_BATCH_TOO_LARGE) return fail(s, bad, "%u hits / %u requests, communicator sized for %u", n_hits, n_req, s->max_slice);
-        if (bad) return fail(s, bad, "null argument");
-        return fail(s, RL_ERR_INVALID, "another rank refused the step (its arguments): nothing was applied anywhere");
-    }
-    uint64_t base = 0, total_req = 0;
-    for (uint32_t p = 0; p < W; ++p) {
-        if (p < s->rank) base += words[p];
-        total_req += words[p];
-    }
-    const bool too_many = total_req >= (1ull << 32);  // (request ids are 32 bits; every rank computes the same sum)
-    if (too_many) return fail(s, RL_ERR_BATCH_TOO_LARGE, "more than 2^32 requests in one step");
+    else if (n_hits > s->max_slice || n_req > s->max_slice || n_req >= REQ_ID_LOCAL) bad = RL_ERR_BATCH_TOO_LARGE;
+    const uint32_t base = s->rank * REQ_ID_LOCAL;  // (world <= 16, a slice < 2^27 requests: 31 bits)
+    const uint32_t n_eff = bad ? 0u : n_hits, r_eff = bad ? 0u : n_req;
     int32_t* d_first = d_first_limited ? d_first_limited : q.first;
-    // ---- 1. route: stable partition by owner, the request id of every routed hit, the counts, the records -------------
-    ENG_S(s, rl_route_partition_stream(s->e, s->cs, d_hits, n_hits, W, s->sorted[0], s->perm[0], s->d_counts[0]));
-    ENG_S(s, rl_req_ids_stream(s->e, s->cs, d_req_off, n_req, n_hits, (uint32_t)base, s->perm[0], q.req_of_hit, q.req_id_sorted));
+    // ---- 1. route: stable partition by owner, the request id of every routed hit, the counts (+ the word), the records -----
+    if (mem_rc == RL_OK) {
+        ENG_S(s, rl_route_partition_stream(s->e, s->cs, d_hits, n_eff, W, s->sorted[0], s->perm[0], s->d_counts[0]));
+        ENG_S(s, rl_req_ids_stream(s->e, s->cs, d_req_off, r_eff, n_eff, base, s->perm[0], q.req_of_hit, q.req_id_sorted));
+    } else {
+        HIP_S(s, hipMemsetAsync(s->d_counts[0], 0, 2 * W * sizeof(uint32_t), s->cs));
+    }
+    s->rq.h_words[RQ_WORDS - 1] = bad ? 0xFFFFFFFFu : 0u;
+    HIP_S(s, hipMemcpyAsync(s->rq.d_words, s->rq.h_words + RQ_WORDS - 1, 4, hipMemcpyHostToDevice, s->cs));
     {
-        rl_xfer x;
-        x.send = s->d_counts[0];
-        x.recv = s->d_counts[0] + W;
-        x.send_off = x.recv_off = s->c_off.data();
-        x.send_cnt = x.recv_cnt = s->c_cnt.data();
-        rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
+        std::vector<uint64_t> zero(W, 0), four(W, 4), wro(W);
+        for (uint32_t p = 0; p < W; ++p) wro[p] = 4ull * p;
+        rl_xfer xs[2];
+        xs[0].send = s->d_counts[0];
+        xs[0].recv = s->d_counts[0] + W;
+        xs[0].send_off = xs[0].recv_off = s->c_off.data();
+        xs[0].send_cnt = xs[0].recv_cnt = s->c_cnt.data();
+        xs[1].send = s->rq.d_words;  // the same word to every rank
+        xs[1].recv = s->rq.d_words + RQ_GATHER;
+        xs[1].send_off = zero.data();
+        xs[1].send_cnt = four.data();
+        xs[1].recv_off = wro.data();
+        xs[1].recv_cnt = four.data();
+        rc = s->t.exchange(s->t.ctx, xs, 2, s->cs);
         if (rc != RL_OK) return fail(s, rc, "exchange (counts) failed");
     }
     HIP_S(s, hipMemcpyAsync(s->h_counts[0], s->d_counts[0], 2 * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s->cs));
+    HIP_S(s, hipMemcpyAsync(s->rq.h_words, s->rq.d_words + RQ_GATHER, W * 4, hipMemcpyDeviceToHost, s->cs));
     HIP_S(s, hipStreamSynchronize(s->cs));
+    for (uint32_t p = 0; p < W; ++p) words[p] = s->rq.h_words[p];
+    if (max_of(words, W) == 0xFFFFFFFFu) {
+        if (bad == RL_ERR_NOMEM) return fail(s, bad, "out of device memory for the step's arrays");
+        if (bad == RL_ERR_BUSY) return fail(s, bad, "slices are in flight: collect them first");
+        if (bad == RL_ERR_BATCH_TOO_LARGE) return fail(s, bad, "%u hits / %u requests, communicator sized for %u (and fewer than 2^27 requests per slice)", n_hits, n_req, s->max_slice);
+        if (bad) return fail(s, bad, "null argument");
+        return fail(s, RL_ERR_INVALID, "another rank refused the step (its arguments): nothing was applied anywhere");
+    }
     uint64_t so = 0, ro = 0;
     for (uint32_t p = 0; p < W; ++p) {
         s->send_off[0][p] = so;
@@ -928,7 +942,24 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
         rc = s->t.exchange(s->t.ctx, xs, 2, s->cs);
         if (rc != RL_OK) return fail(s, rc, "exchange (hits + request ids) failed");
     }
-    HIP_S(s, hipStreamSynchronize(s->cs));
+    // The owners' side runs on the ENGINE's stream.  Where that stream is the communicator's own (the default), the two are
+    // ordered by events from here on — exchange stream -> engine: "the records / the admitted bits / the walks' ends are
+    // there"; engine -> exchange stream: "the round's flags are there" — and the host only stops where it needs a value
+    // (round 5 synchronised the exchange stream behind every exchange and the engine's behind every call: fourteen stops).
+    const bool chained = s->as != nullptr;
+    struct AsyncOff {  // (the engine goes back to blocking rounds however the step ends: other drivers of the phased calls rely on it)
+        rl_engine* e;
+        ~AsyncOff() {
+            if (e) (void)rl_gen_set_async(e, 0);
+        }
+    } async_off{chained ? s->e : nullptr};
+    if (chained) {
+        ENG_S(s, rl_gen_set_async(s->e, 1));
+        HIP_S(s, hipEventRecord(s->ev_exchanged[0], s->cs));
+        HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[0], 0));
+    } else {
+        HIP_S(s, hipStreamSynchronize(s->cs));
+    }
     // ---- 2. owners: sort by cell, read the cells.  A slice one owner refuses is refused everywhere ---------------------
     const int32_t brc = rl_gen_begin_device(s->e, s->recv_hits[0], q.r_req, n_recv, now_us, load_counters);
     char bmsg[200] = {0};
@@ -952,18 +983,28 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
             return fail(s, rrc, "rl_gen_round_device: %s", rl_last_error(s->e));
         }
         ++rounds;
+        if (chained) {  // the round's flags -> the exchange stream
+            HIP_S(s, hipEventRecord(s->ev_applied[0], s->as));
+            HIP_S(s, hipStreamWaitEvent(s->cs, s->ev_applied[0], 0));
+        }
         rc = exchange_per_hit(s, false, 1, q.pass_recv, q.pass_sorted);
         if (rc != RL_OK) return rc;
         HIP_S(s, hipMemsetAsync(q.d_words + RQ_CHANGED, 0, 4, s->cs));
         ENG_S(s, rl_req_round_stream(s->e, s->cs, q.pass_sorted, s->perm[0], d_req_off, q.req_of_hit, n_req, n_hits, first_round ? 1 : 0,
                                      q.pass_home, q.adm, d_first, d_verdict, q.d_words + RQ_CHANGED, q.adm_sorted));
-        rc = gather_words(s, q.d_words + RQ_CHANGED, words);
-        if (rc != RL_OK) return rc;
-        if (!max_of(words, W)) break;  // the admitted set of this round is the one the flags were computed with
+        // The admitted bits go out BLIND, behind the kernel that made them and before the host has seen whether anything
+        // changed: if nothing did, the owners simply never read them — and if something did, the next round's kernels are
+        // not waiting for a host that was waiting for a word.
         rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
         if (rc != RL_OK) return rc;
-        HIP_S(s, hipStreamSynchronize(s->cs));
-        if (rounds > total_req + 2) {
+        if (chained) {
+            HIP_S(s, hipEventRecord(s->ev_exchanged[1], s->cs));
+            HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[1], 0));
+        }
+        rc = gather_words(s, q.d_words + RQ_CHANGED, words);  // (the one stop of a round: did ANY rank see a change)
+        if (rc != RL_OK) return rc;
+        if (!max_of(words, W)) break;  // the admitted set of this round is the one the flags were computed with
+        if (rounds > (uint64_t)W * s->max_slice + 2) {  // (one more request of the trace prefix is settled per round)
             (void)rl_gen_abort(s->e);
             return fail(s, RL_ERR_DEVICE, "the rounds did not converge (bug)");
         }
@@ -977,7 +1018,12 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
         ENG_S(s, rl_req_reached_stream(s->e, s->cs, d_first, q.req_of_hit, s->perm[0], n_hits, q.adm_sorted));
         rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
         if (rc != RL_OK) return rc;
-        HIP_S(s, hipStreamSynchronize(s->cs));
+        if (chained) {
+            HIP_S(s, hipEventRecord(s->ev_exchanged[2], s->cs));
+            HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[2], 0));
+        } else {
+            HIP_S(s, hipStreamSynchronize(s->cs));
+        }
         crc = rl_gen_count_device(s->e, q.adm_recv, &n_new, &room);
     } else {
         crc = rl_gen_count_device(s->e, nullptr, &n_new, &room);
