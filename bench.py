@@ -604,6 +604,9 @@ _RCCL_PROBE = r"""
 import os, sys, socket, datetime
 import torch, torch.distributed as dist
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+# (under torch.distributed.run the parent's environment says "use the agent's store": this probe is a world of its own)
+for k in [k for k in os.environ if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE")]:
+    os.environ.pop(k)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                   RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 dev = torch.device("cuda", int(sys.argv[1])); torch.cuda.set_device(dev)

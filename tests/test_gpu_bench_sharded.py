@@ -34,3 +34,26 @@ def test_bench_force_sharded_prints_one_parsable_line(impl, rccl_ready):
     b = line["config"]["bringup_s"]
     assert b["rccl_warmup"] and b["cells_loaded_rank0"] == 1000000
     assert 0 <= line["config"]["denied_in_last_batch"] <= 262144
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it(rccl_ready):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 … bench.py --gpus 1 --force-sharded`: the launcher's own
+    environment (TORCHELASTIC_*: "rendezvous through the agent's store") must not leak into the killable RCCL warm-up — a probe
+    that inherited it would wait for a store nobody serves until its timeout, twice, before the run even starts."""
+    import time
+
+    env = dict(os.environ, LIMITADOR_AMD_LIB="release", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RL_SHARDED_IMPL"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "3",
+                        "--warmup", "2", "--keys", "1000000", "--batch", "262144", "--secondary", "0", "--cpu-seconds", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    warm = line["config"]["bringup_s"]["rccl_warmup"]
+    assert "attempt 1" in warm, warm  # (the probe came up at once)
+    assert time.perf_counter() - t0 < 300
