@@ -33,9 +33,10 @@
 
 namespace {
 
-constexpr uint32_t RQ_GATHER = 16;   // rq.d_words[RQ_GATHER + p]: rank p's word of the last gather (multi-counter step)
-constexpr uint32_t RQ_CHANGED = 64;  // rq.d_words[RQ_CHANGED]: k_req_and raises it
-constexpr uint32_t RQ_WORDS = 128;
+constexpr uint32_t RQ_GATHER = 16;    // rq.d_words[RQ_GATHER + p * n + r]: rank p's r-th word of the last gather (multi-counter step)
+constexpr uint32_t RQ_BLIND_MAX = 4;  // rounds of the multi-counter step enqueued without a look at "did anything change" in between
+constexpr uint32_t RQ_CHANGED = 192;  // rq.d_words[RQ_CHANGED + r]: k_req_and of the group's round r raises it
+constexpr uint32_t RQ_WORDS = 256;
 constexpr uint32_t REQ_ID_LOCAL = 1u << 27;  // request id of the multi-counter step = rank * REQ_ID_LOCAL + the request's index on its rank
 constexpr int SLOTS = 4;          // slices in flight: one routed + up to three on the engine (applied / returned).  Three until
                                   // round 5: with `submit(k); collect(k - 2)` the host's ~55 us of enqueues per slice only
@@ -219,6 +220,7 @@ struct rl_sharded {
                 *adm_recv = nullptr;
         int32_t* first = nullptr;
         uint64_t *rem_recv = nullptr, *exp_recv = nullptr, *rem_sorted = nullptr, *exp_sorted = nullptr;
+        uint32_t rounds_hint = 2;  // rounds the last multi-counter step needed: the length of the next one's blind group
     } rq;
     std::deque<Slice> pending;
     uint64_t seq = 0;
@@ -784,23 +786,23 @@ int32_t req_bufs(rl_sharded* s) try {
     return RL_OK;
 } RL_ABI_CATCH
 
-// One 32-bit word of every rank to every rank (d_send: this rank's, on the device); out[p] = rank p's.  A collective.
-int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out) {
+// n 32-bit words of every rank to every rank (d_send: this rank's, on the device); out[p * n + r] = rank p's r-th.  A collective.
+int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out, uint32_t n = 1) {
     const uint32_t W = s->world;
-    std::vector<uint64_t> zero(W, 0), four(W, 4), ro(W);
-    for (uint32_t p = 0; p < W; ++p) ro[p] = 4ull * p;
+    std::vector<uint64_t> zero(W, 0), bytes(W, 4ull * n), ro(W);
+    for (uint32_t p = 0; p < W; ++p) ro[p] = 4ull * n * p;
     rl_xfer x;
     x.send = d_send;
     x.recv = s->rq.d_words + RQ_GATHER;
     x.send_off = zero.data();
-    x.send_cnt = four.data();
+    x.send_cnt = bytes.data();
     x.recv_off = ro.data();
-    x.recv_cnt = four.data();
+    x.recv_cnt = bytes.data();
     const int32_t rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
-    if (rc != RL_OK) return fail(s, rc, "exchange (one word per rank) failed");
-    HIP_S(s, hipMemcpyAsync(s->rq.h_words, s->rq.d_words + RQ_GATHER, W * 4, hipMemcpyDeviceToHost, s->cs));
+    if (rc != RL_OK) return fail(s, rc, "exchange (words per rank) failed");
+    HIP_S(s, hipMemcpyAsync(s->rq.h_words, s->rq.d_words + RQ_GATHER, (size_t)W * n * 4, hipMemcpyDeviceToHost, s->cs));
     HIP_S(s, hipStreamSynchronize(s->cs));
-    for (uint32_t p = 0; p < W; ++p) out[p] = s->rq.h_words[p];
+    for (uint32_t q = 0; q < W * n; ++q) out[q] = s->rq.h_words[q];
     return RL_OK;
 }
 int32_t gather_host_word(rl_sharded* s, uint32_t mine, uint32_t* out) {
@@ -960,85 +962,131 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
     } else {
         HIP_S(s, hipStreamSynchronize(s->cs));
     }
-    // ---- 2. owners: sort by cell, read the cells.  A slice one owner refuses is refused everywhere ---------------------
-    const int32_t brc = rl_gen_begin_device(s->e, s->recv_hits[0], q.r_req, n_recv, now_us, load_counters);
-    char bmsg[200] = {0};
-    if (brc != RL_OK) std::snprintf(bmsg, sizeof(bmsg), "%s", rl_last_error(s->e));
-    rc = gather_host_word(s, brc != RL_OK ? 1u : 0u, words);
-    if (rc != RL_OK) return rc;
-    if (max_of(words, W)) {
-        if (brc == RL_OK) {
-            (void)rl_gen_abort(s->e);
-            return fail(s, RL_ERR_INVALID, "another rank refused the step: nothing was applied anywhere");
-        }
-        return fail(s, brc, "rank %u: %s (refused on every rank, nothing applied)", s->rank, bmsg);
-    }
-    // ---- 3. Jacobi rounds: owners -> pass flags -> ingress AND per request -> admitted bits -> owners, until no rank
-    //         saw the admitted set change: the unique fixpoint -----------------------------------------
+    // ---- 2-4, at most three times (the owners' sort may ask for another go with its heavy keys promoted) -------------------
     uint32_t rounds = 0;
-    for (bool first_round = true;; first_round = false) {
-        const int32_t rrc = rl_gen_round_device(s->e, first_round ? nullptr : q.adm_recv, q.pass_recv, q.rem_recv, q.exp_recv);
-        if (rrc != RL_OK) {  // (misuse or a device error: not an outcome of the input)
+    for (int attempt = 0;; ++attempt) {
+        // ---- 2. owners: sort by cell, read the cells.  Chained: the sort's outcome is looked at in step 4, where the host
+        //         stops for the device anyway (rl_gen_set_async); a retry looks at it here, like round 5 did ------------
+        if (chained && attempt > 0) ENG_S(s, rl_gen_set_async(s->e, 0));
+        const int32_t brc = rl_gen_begin_device(s->e, s->recv_hits[0], q.r_req, n_recv, now_us, load_counters);
+        if (chained && attempt > 0) ENG_S(s, rl_gen_set_async(s->e, 1));
+        // A rank whose owner side cannot run (its begin, or later a round, returned a status) keeps taking part in every
+        // exchange of the step — the others are in them — and says so in step 4's word, where all ranks drop the step together.
+        int32_t dead_rc = RL_OK;
+        char dead_msg[200] = {0};
+        auto owner_died = [&](int32_t why) {
+            if (dead_rc != RL_OK) return;
+            dead_rc = why;
+            std::snprintf(dead_msg, sizeof(dead_msg), "%s", rl_last_error(s->e));
+        };
+        if (brc != RL_OK) owner_died(brc);
+        if (!chained || attempt > 0) {  // (a begin that waited for its sort: all ranks hear its outcome now)
+            rc = gather_host_word(s, dead_rc != RL_OK ? 1u : 0u, words);
+            if (rc != RL_OK) return rc;
+            if (max_of(words, W)) {
+                if (dead_rc == RL_OK) {
+                    (void)rl_gen_abort(s->e);
+                    return fail(s, RL_ERR_INVALID, "another rank refused the step: nothing was applied anywhere");
+                }
+                return fail(s, dead_rc, "rank %u: %s (refused on every rank, nothing applied)", s->rank, dead_msg);
+            }
+        }
+        // ---- 3. Jacobi rounds: owners -> pass flags -> ingress AND per request -> admitted bits -> owners, until no rank
+        //         saw the admitted set change: the unique fixpoint.  A GROUP of rounds — as many as the step
+        //         before needed, at most RQ_BLIND_MAX — is enqueued without the host looking in between; a round behind the
+        //         fixpoint reproduces the fixpoint's flags, admitted bits and verdicts (its inputs are the same), so running
+        //         one too many changes no answer.  One stop per group: every round's "changed" word of every rank. ----------
+        rounds = 0;
+        bool converged = false;
+        while (!converged) {
+            const uint32_t group = chained ? std::min(std::max(s->rq.rounds_hint, 1u), RQ_BLIND_MAX) : 1u;
+            HIP_S(s, hipMemsetAsync(q.d_words + RQ_CHANGED, 0, 4 * RQ_BLIND_MAX, s->cs));
+            for (uint32_t gr = 0; gr < group; ++gr) {
+                const bool first_round = rounds + gr == 0;
+                if (dead_rc == RL_OK) {
+                    const int32_t rrc = rl_gen_round_device(s->e, first_round ? nullptr : q.adm_recv, q.pass_recv, q.rem_recv, q.exp_recv);
+                    if (rrc != RL_OK) owner_died(rrc);  // (misuse or a device error: not an outcome of the input)
+                }
+                if (chained) {  // the round's flags -> the exchange stream
+                    HIP_S(s, hipEventRecord(s->ev_applied[0], s->as));
+                    HIP_S(s, hipStreamWaitEvent(s->cs, s->ev_applied[0], 0));
+                }
+                rc = exchange_per_hit(s, false, 1, q.pass_recv, q.pass_sorted);
+                if (rc != RL_OK) return rc;
+                ENG_S(s, rl_req_round_stream(s->e, s->cs, q.pass_sorted, s->perm[0], d_req_off, q.req_of_hit, n_req, n_hits, first_round ? 1 : 0,
+                                             q.pass_home, q.adm, d_first, d_verdict, q.d_words + RQ_CHANGED + gr, q.adm_sorted));
+                // the admitted bits go out behind the kernel that made them, before anybody has seen whether anything changed
+                rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
+                if (rc != RL_OK) return rc;
+                if (chained) {
+                    HIP_S(s, hipEventRecord(s->ev_exchanged[1], s->cs));
+                    HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[1], 0));
+                }
+            }
+            uint32_t gw[MAX_WORLD * RQ_BLIND_MAX];
+            rc = gather_words(s, q.d_words + RQ_CHANGED, gw, group);  // (the one stop of a group: did ANY rank see a change, per round)
+            if (rc != RL_OK) return rc;
+            uint32_t used = group;
+            for (uint32_t gr = 0; gr < group && !converged; ++gr) {
+                uint32_t any = 0;
+                for (uint32_t p = 0; p < W; ++p) any |= gw[p * group + gr];
+                if (!any) {  // the admitted set of this round is the one its flags were computed with
+                    converged = true;
+                    used = gr + 1;
+                }
+            }
+            rounds += used;
+            if (rounds > (uint64_t)W * s->max_slice + 2 + RQ_BLIND_MAX) {  // (one more request of the trace prefix is settled per round)
+                (void)rl_gen_abort(s->e);
+                return fail(s, RL_ERR_DEVICE, "the rounds did not converge (bug)");
+            }
+        }
+        s->rq.rounds_hint = rounds;
+        // ---- 4. the walks' ends -> owners; cells to create, room: all ranks fit or none does -------------------------------
+        uint32_t n_new = 0;
+        uint64_t room = 0;
+        int32_t crc;
+        if (!load_counters) {
+            ENG_S(s, rl_req_reached_stream(s->e, s->cs, d_first, q.req_of_hit, s->perm[0], n_hits, q.adm_sorted));
+            rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
+            if (rc != RL_OK) return rc;
+            if (chained) {
+                HIP_S(s, hipEventRecord(s->ev_exchanged[2], s->cs));
+                HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[2], 0));
+            } else {
+                HIP_S(s, hipStreamSynchronize(s->cs));
+            }
+            crc = dead_rc != RL_OK ? dead_rc : rl_gen_count_device(s->e, q.adm_recv, &n_new, &room);
+        } else {
+            crc = dead_rc != RL_OK ? dead_rc : rl_gen_count_device(s->e, nullptr, &n_new, &room);
+        }
+        char cmsg[200] = {0};
+        if (dead_rc != RL_OK) std::snprintf(cmsg, sizeof(cmsg), "%s", dead_msg);
+        else if (crc != RL_OK) std::snprintf(cmsg, sizeof(cmsg), "%s", rl_last_error(s->e));
+        // (RL_ERR_BUSY out of the count of a chained pass: the owners' sort overflowed and promoted its heavy keys — nothing was
+        // computed, every rank goes round again)
+        const bool again = chained && dead_rc == RL_OK && crc == RL_ERR_BUSY && attempt < 2;
+        rc = gather_host_word(s, again ? 3u : crc != RL_OK ? 2u : (n_new > room ? 1u : 0u), words);
+        if (rc != RL_OK) return rc;
+        const uint32_t worst = max_of(words, W);
+        bool any_fail = false;
+        for (uint32_t p = 0; p < W; ++p) any_fail |= words[p] == 2u;
+        if (worst == 3u && !any_fail) {
+            (void)rl_gen_abort(s->e);  // (a rank whose own sort was fine: its pass is dropped, nothing was written)
+            continue;
+        }
+        if (worst) {
             (void)rl_gen_abort(s->e);
-            return fail(s, rrc, "rl_gen_round_device: %s", rl_last_error(s->e));
+            if (crc != RL_OK && crc != RL_ERR_BUSY) return fail(s, crc, "rank %u: %s", s->rank, cmsg);
+            if (crc == RL_ERR_BUSY && dead_rc == RL_OK) return fail(s, RL_ERR_BATCH_TOO_LARGE, "rank %u: %s", s->rank, cmsg);
+            if (crc != RL_OK) return fail(s, crc, "rank %u: %s", s->rank, cmsg);
+            if (any_fail || worst == 3u) return fail(s, RL_ERR_DEVICE, "another rank failed while counting: nothing was applied anywhere");
+            return fail(s, RL_ERR_TABLE_FULL, "refused, nothing applied on any rank: a shard cannot take the cells the step creates (here: %u new, room %llu)",
+                        n_new, (unsigned long long)room);
         }
-        ++rounds;
-        if (chained) {  // the round's flags -> the exchange stream
-            HIP_S(s, hipEventRecord(s->ev_applied[0], s->as));
-            HIP_S(s, hipStreamWaitEvent(s->cs, s->ev_applied[0], 0));
-        }
-        rc = exchange_per_hit(s, false, 1, q.pass_recv, q.pass_sorted);
-        if (rc != RL_OK) return rc;
-        HIP_S(s, hipMemsetAsync(q.d_words + RQ_CHANGED, 0, 4, s->cs));
-        ENG_S(s, rl_req_round_stream(s->e, s->cs, q.pass_sorted, s->perm[0], d_req_off, q.req_of_hit, n_req, n_hits, first_round ? 1 : 0,
-                                     q.pass_home, q.adm, d_first, d_verdict, q.d_words + RQ_CHANGED, q.adm_sorted));
-        // The admitted bits go out BLIND, behind the kernel that made them and before the host has seen whether anything
-        // changed: if nothing did, the owners simply never read them — and if something did, the next round's kernels are
-        // not waiting for a host that was waiting for a word.
-        rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
-        if (rc != RL_OK) return rc;
-        if (chained) {
-            HIP_S(s, hipEventRecord(s->ev_exchanged[1], s->cs));
-            HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[1], 0));
-        }
-        rc = gather_words(s, q.d_words + RQ_CHANGED, words);  // (the one stop of a round: did ANY rank see a change)
-        if (rc != RL_OK) return rc;
-        if (!max_of(words, W)) break;  // the admitted set of this round is the one the flags were computed with
-        if (rounds > (uint64_t)W * s->max_slice + 2) {  // (one more request of the trace prefix is settled per round)
-            (void)rl_gen_abort(s->e);
-            return fail(s, RL_ERR_DEVICE, "the rounds did not converge (bug)");
-        }
+        break;
     }
     if (rounds_out) *rounds_out = rounds;
-    // ---- 4. the walks' ends -> owners; cells to create, room: all ranks fit or none does -------------------------------
-    uint32_t n_new = 0;
-    uint64_t room = 0;
-    int32_t crc;
-    if (!load_counters) {
-        ENG_S(s, rl_req_reached_stream(s->e, s->cs, d_first, q.req_of_hit, s->perm[0], n_hits, q.adm_sorted));
-        rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
-        if (rc != RL_OK) return rc;
-        if (chained) {
-            HIP_S(s, hipEventRecord(s->ev_exchanged[2], s->cs));
-            HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[2], 0));
-        } else {
-            HIP_S(s, hipStreamSynchronize(s->cs));
-        }
-        crc = rl_gen_count_device(s->e, q.adm_recv, &n_new, &room);
-    } else {
-        crc = rl_gen_count_device(s->e, nullptr, &n_new, &room);
-    }
-    char cmsg[200] = {0};
-    if (crc != RL_OK) std::snprintf(cmsg, sizeof(cmsg), "%s", rl_last_error(s->e));
-    rc = gather_host_word(s, crc != RL_OK ? 2u : (n_new > room ? 1u : 0u), words);
-    if (rc != RL_OK) return rc;
-    if (const uint32_t worst = max_of(words, W)) {
-        (void)rl_gen_abort(s->e);
-        if (crc != RL_OK) return fail(s, crc, "rank %u: %s", s->rank, cmsg);
-        if (worst == 2u) return fail(s, RL_ERR_DEVICE, "another rank failed while counting: nothing was applied anywhere");
-        return fail(s, RL_ERR_TABLE_FULL, "refused, nothing applied on any rank: a shard cannot take the cells the step creates (here: %u new, room %llu)",
-                    n_new, (unsigned long long)room);
-    }
     ENG_S(s, rl_gen_commit_device(s->e));
     // ---- 5. values read before the update, back to the ingress ranks (in_memory.rs:114-116,134-136) -------------------
     if (load_counters) {

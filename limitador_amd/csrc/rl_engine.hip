@@ -137,6 +137,7 @@ struct rl_engine {
     // it 45-58 us, 97 against 82 us per routed slice — scripts/exp/patches/route_one_launch.patch)
     // bucketed hot path (rl_bucket.hpp)
     // the phased form of the general resolver (rl_gen_begin_device .. rl_gen_commit_device / rl_gen_abort)
+    bool ph_unchecked = false;  // an async rl_gen_begin_device left the sort's status for rl_gen_count_device to look at
     bool ph_async = false;  // rl_gen_set_async: rl_gen_round_device leaves its kernels on the (caller's) stream without waiting for them
     bool ph_open = false;
     GenArgs ph_A{};
@@ -2824,6 +2825,7 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
     e->ph_n = n_hits;
     e->ph_rounds = 0;
     e->ph_counted = false;
+    e->ph_unchecked = false;
     if (n_hits == 0) {
         e->ph_open = true;
         return RL_OK;
@@ -2842,6 +2844,15 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
         BatchScratch* bs = nullptr;
         rc = gen_setup_and_sort(e, c, 0, n_hits, 0, n_hits, !c.load, A, &bs);
         if (rc) return rc;
+        if (e->ph_async && e->external_stream) {
+            // rl_gen_set_async: the sort's outcome — an error bit, buckets that overflowed — is looked at by rl_gen_count_device,
+            // which stops for the device anyway; every kernel of the rounds in between returns at once on either (they
+            // read the same status words), so nothing is computed from an unusable sort and nothing is ever applied.
+            e->ph_A = A;
+            e->ph_bs = bs;
+            e->ph_unchecked = true;
+            break;
+        }
         Status h_bst;
         GenStatus h_gst;
         HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
@@ -2926,8 +2937,23 @@ int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_
     HIP_TRY(e, hipMemsetAsync(&e->d_gst->n_new, 0, sizeof(u32), e->stream));
     k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A);
     GenStatus h_gst;
+    Status h_bst{};
     HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
+    if (e->ph_unchecked) HIP_TRY(e, hipMemcpyAsync(&h_bst, &e->ph_bs->st, sizeof(Status), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->ph_unchecked) {  // what an async rl_gen_begin_device did not wait for
+        e->ph_unchecked = false;
+        if (h_bst.err | h_gst.err) {
+            (void)gen_phase_close(e);
+            return status_to_error(e, h_bst.err | h_gst.err);
+        }
+        if (h_gst.overflow) {  // the heavy keys were promoted: begin again, with that set
+            e->part_seq += 1;
+            (void)gen_phase_close(e);
+            return fail(e, RL_ERR_BUSY, "hash buckets of this slice overflowed; their heavy keys were promoted: begin the pass again "
+                                        "(nothing was applied)");
+        }
+    }
     if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
     else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
     if (n_new) *n_new = h_gst.n_new;
