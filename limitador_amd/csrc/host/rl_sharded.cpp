@@ -944,21 +944,30 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
         rc = s->t.exchange(s->t.ctx, xs, 2, s->cs);
         if (rc != RL_OK) return fail(s, rc, "exchange (hits + request ids) failed");
     }
-    // The owners' side runs on the ENGINE's stream.  Where that stream is the communicator's own (the default), the two are
-    // ordered by events from here on — exchange stream -> engine: "the records / the admitted bits / the walks' ends are
-    // there"; engine -> exchange stream: "the round's flags are there" — and the host only stops where it needs a value
-    // (round 5 synchronised the exchange stream behind every exchange and the engine's behind every call: fourteen stops).
+    // The owners' side of THIS step runs on the exchange stream itself where the engine's stream is the communicator's (the
+    // default): the step is one chain — exchange, owners' kernels, exchange, ingress kernels … — and a dependency that crosses
+    // streams costs about 10 us of idle device on this part (barrier packet + signal; six of them per two rounds, measured
+    // in a kernel trace), an in-order stream nothing.  The host only stops where it needs a value (round 5 synchronised the
+    // exchange stream behind every exchange and the engine's behind every call: fourteen stops).  The engine is handed back
+    // its own stream (and blocking rounds) however the step ends: the pipelined slices and other drivers of the phased calls
+    // rely on both.
     const bool chained = s->as != nullptr;
-    struct AsyncOff {  // (the engine goes back to blocking rounds however the step ends: other drivers of the phased calls rely on it)
+    struct Restore {
         rl_engine* e;
-        ~AsyncOff() {
-            if (e) (void)rl_gen_set_async(e, 0);
+        hipStream_t as;
+        ~Restore() {
+            if (!e) return;
+            (void)rl_gen_set_async(e, 0);
+            if (rl_engine_set_stream(e, as, 1) != RL_OK) {  // (a pass left open by an early return)
+                (void)rl_gen_abort(e);
+                (void)rl_engine_set_stream(e, as, 1);
+            }
         }
-    } async_off{chained ? s->e : nullptr};
+    } restore{nullptr, s->as};
     if (chained) {
+        ENG_S(s, rl_engine_set_stream(s->e, s->cs, 1));
+        restore.e = s->e;
         ENG_S(s, rl_gen_set_async(s->e, 1));
-        HIP_S(s, hipEventRecord(s->ev_exchanged[0], s->cs));
-        HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[0], 0));
     } else {
         HIP_S(s, hipStreamSynchronize(s->cs));
     }
@@ -1007,10 +1016,6 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
                     const int32_t rrc = rl_gen_round_device(s->e, first_round ? nullptr : q.adm_recv, q.pass_recv, q.rem_recv, q.exp_recv);
                     if (rrc != RL_OK) owner_died(rrc);  // (misuse or a device error: not an outcome of the input)
                 }
-                if (chained) {  // the round's flags -> the exchange stream
-                    HIP_S(s, hipEventRecord(s->ev_applied[0], s->as));
-                    HIP_S(s, hipStreamWaitEvent(s->cs, s->ev_applied[0], 0));
-                }
                 rc = exchange_per_hit(s, false, 1, q.pass_recv, q.pass_sorted);
                 if (rc != RL_OK) return rc;
                 ENG_S(s, rl_req_round_stream(s->e, s->cs, q.pass_sorted, s->perm[0], d_req_off, q.req_of_hit, n_req, n_hits, first_round ? 1 : 0,
@@ -1018,10 +1023,6 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
                 // the admitted bits go out behind the kernel that made them, before anybody has seen whether anything changed
                 rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
                 if (rc != RL_OK) return rc;
-                if (chained) {
-                    HIP_S(s, hipEventRecord(s->ev_exchanged[1], s->cs));
-                    HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[1], 0));
-                }
             }
             uint32_t gw[MAX_WORLD * RQ_BLIND_MAX];
             rc = gather_words(s, q.d_words + RQ_CHANGED, gw, group);  // (the one stop of a group: did ANY rank see a change, per round)
@@ -1050,12 +1051,7 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
             ENG_S(s, rl_req_reached_stream(s->e, s->cs, d_first, q.req_of_hit, s->perm[0], n_hits, q.adm_sorted));
             rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
             if (rc != RL_OK) return rc;
-            if (chained) {
-                HIP_S(s, hipEventRecord(s->ev_exchanged[2], s->cs));
-                HIP_S(s, hipStreamWaitEvent(s->as, s->ev_exchanged[2], 0));
-            } else {
-                HIP_S(s, hipStreamSynchronize(s->cs));
-            }
+            if (!chained) HIP_S(s, hipStreamSynchronize(s->cs));
             crc = dead_rc != RL_OK ? dead_rc : rl_gen_count_device(s->e, q.adm_recv, &n_new, &room);
         } else {
             crc = dead_rc != RL_OK ? dead_rc : rl_gen_count_device(s->e, nullptr, &n_new, &room);

@@ -2807,9 +2807,10 @@ uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t 
 // For hosts that decide admission themselves: requests whose counters live on several GPUs (key-sharded
 // multi-counter requests, limitador_amd/sharded.py ShardedMultiCounterEngine) — the per-request AND of
 // in_memory.rs:141-153 then spans engines, so every fixpoint round goes through the host.
-static int32_t gen_phase_close(rl_engine* e) {
+static int32_t gen_phase_close(rl_engine* e, bool cleared = false) {
     e->ph_open = false;
     e->ph_counted = false;
+    if (cleared) return RL_OK;  // (the caller enqueued the clear ahead of the stop it made anyway)
     HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
@@ -2974,9 +2975,10 @@ int32_t rl_gen_commit_device(rl_engine* e) try {
     k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
     GenStatus h_gst;
     HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));  // (what closing the pass clears: one stop, not two)
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (!h_gst.committed) {
-        (void)gen_phase_close(e);
+        (void)gen_phase_close(e, true);
         return fail(e, RL_ERR_TABLE_FULL, "refused, nothing applied: the slice creates %u cells in a table with live=%llu tombstones=%llu capacity=%llu",
                     h_gst.n_new, (unsigned long long)e->live, (unsigned long long)e->tombs, (unsigned long long)e->cap);
     }
@@ -2986,7 +2988,7 @@ int32_t rl_gen_commit_device(rl_engine* e) try {
     e->stats.hits += n;
     e->stats.ordered_hits += n;
     e->stats.ordered_batches++;
-    return gen_phase_close(e);
+    return gen_phase_close(e, true);
 } RL_ABI_CATCH
 
 int32_t rl_gen_abort(rl_engine* e) try {
