@@ -498,9 +498,26 @@ int32_t rl_gen_count_device(rl_engine *e, const uint8_t *d_reached, uint32_t *n_
 int32_t rl_gen_commit_device(rl_engine *e);
 int32_t rl_gen_abort(rl_engine *e);
 /* A caller that owns the engine's stream (rl_engine_set_stream(e, stream, 1)) and orders what reads d_pass by that stream or by
- * events recorded on it: with on != 0, rl_gen_round_device returns with its kernels enqueued instead of waiting for them
- * (the multi-GPU router's rounds; begin / count / commit still return results to the host and therefore wait). */
+ * events recorded on it: with on != 0, rl_gen_round_device returns with its kernels enqueued instead of waiting for them,
+ * and rl_gen_begin_device does not wait for its sort either — what the sort has to say (an error bit, hash buckets that
+ * overflowed) comes out of the next call that stops for the device anyway: rl_gen_count_device (overflow: RL_ERR_BUSY, the
+ * pass is closed and is to be begun again) or rl_gen_commit_gated_device; the rounds in between compute nothing from an
+ * unusable sort.  (The multi-GPU router's step.) */
 int32_t rl_gen_set_async(rl_engine *e, int32_t on);
+/* Count and commit of an async pass with NO host stop in between — all engines of a job apply the step or none does, decided
+ * on the devices:
+ *   count_async   enqueues the count and leaves this engine's veto word at d_veto: 1 = the cells the pass creates do not
+ *                 fit, 2 = an error bit, 4 = hash buckets overflowed, 8 = *d_also != 0 (the caller's own reason — "my last
+ *                 round still changed the admitted set"; d_also may be NULL).  0 = fine by me.
+ *   (the caller gathers every engine's word on the device: n_veto words, veto_stride words apart, at d_veto)
+ *   commit_gated  enqueues the commit, which applies the pass only if all n_veto words are zero, copies the words to
+ *                 h_veto (pinned host memory, n_veto * veto_stride words) and stops ONCE.  *committed = 1: applied, the
+ *                 pass is closed.  0 with RL_OK: some engine vetoed (h_veto says who and why) — the pass is still open:
+ *                 more rounds and another count_async / commit_gated, or rl_gen_abort.  An error of THIS engine's pass
+ *                 closes it and is returned (RL_ERR_BUSY: overflow — begin again); its veto word told the others. */
+int32_t rl_gen_count_async_device(rl_engine *e, const uint8_t *d_reached, const uint32_t *d_also, uint32_t *d_veto);
+int32_t rl_gen_commit_gated_device(rl_engine *e, const uint32_t *d_veto, uint32_t *h_veto, uint32_t n_veto,
+                                   uint32_t veto_stride, uint32_t *committed);
 
 /* ---- multi-GPU routing helpers (device pointers, engine's stream) ----------------------- */
 /* Owner shard of a key for a world of `world` shards (any world >= 1). */

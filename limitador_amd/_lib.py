@@ -126,6 +126,8 @@ def _declare(lib):
     _sig(lib, "rl_gen_begin_device", C.c_int32, [p, p, p, C.c_uint32, C.c_uint64, C.c_int32])
     _sig(lib, "rl_gen_round_device", C.c_int32, [p, p, p, p, p])
     _sig(lib, "rl_gen_count_device", C.c_int32, [p, p, u32p, u64p])
+    _sig(lib, "rl_gen_count_async_device", C.c_int32, [p, p, p, p])
+    _sig(lib, "rl_gen_commit_gated_device", C.c_int32, [p, p, p, C.c_uint32, C.c_uint32, u32p])
     _sig(lib, "rl_gen_commit_device", C.c_int32, [p])
     _sig(lib, "rl_gen_abort", C.c_int32, [p])
     _sig(lib, "rl_engine_record_event", C.c_int32, [p, p])

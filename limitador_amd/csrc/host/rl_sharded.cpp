@@ -35,6 +35,7 @@ namespace {
 
 constexpr uint32_t RQ_GATHER = 16;    // rq.d_words[RQ_GATHER + p * n + r]: rank p's r-th word of the last gather (multi-counter step)
 constexpr uint32_t RQ_BLIND_MAX = 4;  // rounds of the multi-counter step enqueued without a look at "did anything change" in between
+constexpr uint32_t RQ_VETO = 191;     // rq.d_words[RQ_VETO]: this rank's word of the all-or-nothing commit (rl_gen_count_async_device); the changed words follow it
 constexpr uint32_t RQ_CHANGED = 192;  // rq.d_words[RQ_CHANGED + r]: k_req_and of the group's round r raises it
 constexpr uint32_t RQ_WORDS = 256;
 constexpr uint32_t REQ_ID_LOCAL = 1u << 27;  // request id of the multi-counter step = rank * REQ_ID_LOCAL + the request's index on its rank
@@ -217,7 +218,7 @@ struct rl_sharded {
         bool ready = false;
         uint32_t *req_of_hit = nullptr, *req_id_sorted = nullptr, *r_req = nullptr, *d_words = nullptr, *h_words = nullptr;
         uint8_t *pass_recv = nullptr, *pass_sorted = nullptr, *pass_home = nullptr, *adm = nullptr, *adm_sorted = nullptr,
-                *adm_recv = nullptr;
+                *adm_recv = nullptr, *reach_sorted = nullptr, *reach_recv = nullptr;
         int32_t* first = nullptr;
         uint64_t *rem_recv = nullptr, *exp_recv = nullptr, *rem_sorted = nullptr, *exp_sorted = nullptr;
         uint32_t rounds_hint = 2;  // rounds the last multi-counter step needed: the length of the next one's blind group
@@ -646,7 +647,8 @@ void rl_sharded_destroy(rl_sharded* s) {
     for (void* q : {(void*)s->rq.req_of_hit, (void*)s->rq.req_id_sorted, (void*)s->rq.r_req, (void*)s->rq.d_words,
                     (void*)s->rq.pass_recv, (void*)s->rq.pass_sorted, (void*)s->rq.pass_home, (void*)s->rq.adm,
                     (void*)s->rq.adm_sorted, (void*)s->rq.adm_recv, (void*)s->rq.first, (void*)s->rq.rem_recv,
-                    (void*)s->rq.exp_recv, (void*)s->rq.rem_sorted, (void*)s->rq.exp_sorted})
+                    (void*)s->rq.exp_recv, (void*)s->rq.rem_sorted, (void*)s->rq.exp_sorted, (void*)s->rq.reach_sorted,
+                    (void*)s->rq.reach_recv})
         if (q) (void)hipFree(q);
     if (s->rq.h_words) (void)hipHostFree(s->rq.h_words);
     if (s->cs) (void)hipStreamDestroy(s->cs);
@@ -777,6 +779,8 @@ int32_t req_bufs(rl_sharded* s) try {
     HIP_S(s, hipMalloc(&q.adm, ms));
     HIP_S(s, hipMalloc(&q.adm_sorted, ms));
     HIP_S(s, hipMalloc(&q.adm_recv, mr));
+    HIP_S(s, hipMalloc(&q.reach_sorted, ms));  // (the walks' ends travel in arrays of their own: a step that is not at its fixpoint
+    HIP_S(s, hipMalloc(&q.reach_recv, mr));    //  yet goes on with the admitted bits the owners hold)
     HIP_S(s, hipMalloc(&q.first, ms * 4));
     HIP_S(s, hipMalloc(&q.rem_recv, mr * 8));
     HIP_S(s, hipMalloc(&q.exp_recv, mr * 8));
@@ -786,8 +790,9 @@ int32_t req_bufs(rl_sharded* s) try {
     return RL_OK;
 } RL_ABI_CATCH
 
-// n 32-bit words of every rank to every rank (d_send: this rank's, on the device); out[p * n + r] = rank p's r-th.  A collective.
-int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out, uint32_t n = 1) {
+// n 32-bit words of every rank to every rank (d_send: this rank's, on the device): rq.d_words[RQ_GATHER + p * n + r] = rank p's
+// r-th; gather_words also hands them to the host (out[p * n + r]).  A collective.
+int32_t gather_words_device(rl_sharded* s, const uint32_t* d_send, uint32_t n) {
     const uint32_t W = s->world;
     std::vector<uint64_t> zero(W, 0), bytes(W, 4ull * n), ro(W);
     for (uint32_t p = 0; p < W; ++p) ro[p] = 4ull * n * p;
@@ -800,6 +805,13 @@ int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out, uint3
     x.recv_cnt = bytes.data();
     const int32_t rc = s->t.exchange(s->t.ctx, &x, 1, s->cs);
     if (rc != RL_OK) return fail(s, rc, "exchange (words per rank) failed");
+    return RL_OK;
+}
+
+int32_t gather_words(rl_sharded* s, const uint32_t* d_send, uint32_t* out, uint32_t n = 1) {
+    const uint32_t W = s->world;
+    const int32_t rc = gather_words_device(s, d_send, n);
+    if (rc != RL_OK) return rc;
     HIP_S(s, hipMemcpyAsync(s->rq.h_words, s->rq.d_words + RQ_GATHER, (size_t)W * n * 4, hipMemcpyDeviceToHost, s->cs));
     HIP_S(s, hipStreamSynchronize(s->cs));
     for (uint32_t q = 0; q < W * n; ++q) out[q] = s->rq.h_words[q];
@@ -1001,48 +1013,131 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
             }
         }
         // ---- 3. Jacobi rounds: owners -> pass flags -> ingress AND per request -> admitted bits -> owners, until no rank
-        //         saw the admitted set change: the unique fixpoint.  A GROUP of rounds — as many as the step
-        //         before needed, at most RQ_BLIND_MAX — is enqueued without the host looking in between; a round behind the
-        //         fixpoint reproduces the fixpoint's flags, admitted bits and verdicts (its inputs are the same), so running
-        //         one too many changes no answer.  One stop per group: every round's "changed" word of every rank. ----------
+        //         saw the admitted set change: the unique fixpoint ----------------------------------------
+        auto one_round = [&](bool first_round, uint32_t* d_changed) -> int32_t {
+            if (dead_rc == RL_OK) {
+                const int32_t rrc = rl_gen_round_device(s->e, first_round ? nullptr : q.adm_recv, q.pass_recv, q.rem_recv, q.exp_recv);
+                if (rrc != RL_OK) owner_died(rrc);  // (misuse or a device error: not an outcome of the input)
+            }
+            int32_t r = exchange_per_hit(s, false, 1, q.pass_recv, q.pass_sorted);
+            if (r != RL_OK) return r;
+            r = rl_req_round_stream(s->e, s->cs, q.pass_sorted, s->perm[0], d_req_off, q.req_of_hit, n_req, n_hits, first_round ? 1 : 0, q.pass_home,
+                                    q.adm, d_first, d_verdict, d_changed, q.adm_sorted);
+            if (r != RL_OK) return fail(s, r, "engine: %s", rl_last_error(s->e));
+            // the admitted bits go out behind the kernel that made them, before anybody has seen whether anything changed
+            return exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
+        };
         rounds = 0;
-        bool converged = false;
-        while (!converged) {
-            const uint32_t group = chained ? std::min(std::max(s->rq.rounds_hint, 1u), RQ_BLIND_MAX) : 1u;
-            HIP_S(s, hipMemsetAsync(q.d_words + RQ_CHANGED, 0, 4 * RQ_BLIND_MAX, s->cs));
-            for (uint32_t gr = 0; gr < group; ++gr) {
-                const bool first_round = rounds + gr == 0;
+        if (chained) {
+            // The whole of it is ONE chain on the exchange stream, and the host stops once: a GROUP of rounds — as many as the
+            // step before needed, at most RQ_BLIND_MAX — goes out without a look in between (a round behind the fixpoint
+            // reproduces the fixpoint's flags, admitted bits and verdicts: its inputs are the same, so one too many changes
+            // no answer); behind it the walks' ends, the owners' count, every rank's veto word (the cells do not fit / an
+            // error / the sort overflowed / my last round still changed something) gathered ON THE DEVICE, and the commit,
+            // which applies the pass only where every rank's word is zero.  All ranks then read the same words and take the
+            // same turn: done, another group, once more from the sort, or refused everywhere.
+            bool retry = false;
+            for (;;) {
+                const uint32_t group = std::min(std::max(s->rq.rounds_hint, 1u), RQ_BLIND_MAX), stride = 1 + group;
+                HIP_S(s, hipMemsetAsync(q.d_words + RQ_VETO, 0, 4 * (1 + RQ_BLIND_MAX), s->cs));
+                for (uint32_t gr = 0; gr < group; ++gr) {
+                    rc = one_round(rounds + gr == 0, q.d_words + RQ_CHANGED + gr);
+                    if (rc != RL_OK) return rc;
+                }
+                if (!load_counters) {  // ---- 4. the walks' ends -> owners
+                    ENG_S(s, rl_req_reached_stream(s->e, s->cs, d_first, q.req_of_hit, s->perm[0], n_hits, q.reach_sorted));
+                    rc = exchange_per_hit(s, true, 1, q.reach_sorted, q.reach_recv);
+                    if (rc != RL_OK) return rc;
+                }
                 if (dead_rc == RL_OK) {
-                    const int32_t rrc = rl_gen_round_device(s->e, first_round ? nullptr : q.adm_recv, q.pass_recv, q.rem_recv, q.exp_recv);
-                    if (rrc != RL_OK) owner_died(rrc);  // (misuse or a device error: not an outcome of the input)
+                    const int32_t crc = rl_gen_count_async_device(s->e, load_counters ? nullptr : q.reach_recv, q.d_words + RQ_CHANGED + group - 1,
+                                                                  q.d_words + RQ_VETO);
+                    if (crc != RL_OK) owner_died(crc);
                 }
-                rc = exchange_per_hit(s, false, 1, q.pass_recv, q.pass_sorted);
+                if (dead_rc != RL_OK) {  // (no owner side here: the word comes from the host)
+                    q.h_words[RQ_WORDS - 1] = 2u;
+                    HIP_S(s, hipMemcpyAsync(q.d_words + RQ_VETO, q.h_words + RQ_WORDS - 1, 4, hipMemcpyHostToDevice, s->cs));
+                }
+                rc = gather_words_device(s, q.d_words + RQ_VETO, stride);  // [veto, changed of round 0 .. group-1] of every rank
                 if (rc != RL_OK) return rc;
-                ENG_S(s, rl_req_round_stream(s->e, s->cs, q.pass_sorted, s->perm[0], d_req_off, q.req_of_hit, n_req, n_hits, first_round ? 1 : 0,
-                                             q.pass_home, q.adm, d_first, d_verdict, q.d_words + RQ_CHANGED + gr, q.adm_sorted));
-                // the admitted bits go out behind the kernel that made them, before anybody has seen whether anything changed
-                rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
-                if (rc != RL_OK) return rc;
+                uint32_t committed = 0;
+                bool have_words = false;
+                if (dead_rc == RL_OK) {
+                    const int32_t crc = rl_gen_commit_gated_device(s->e, q.d_words + RQ_GATHER, q.h_words, W, stride, &committed);
+                    if (crc != RL_OK) owner_died(crc);  // (its veto word — 2 or 4 — has told the others)
+                    else have_words = true;
+                }
+                if (!have_words) {
+                    HIP_S(s, hipMemcpyAsync(q.h_words, q.d_words + RQ_GATHER, (size_t)W * stride * 4, hipMemcpyDeviceToHost, s->cs));
+                    HIP_S(s, hipStreamSynchronize(s->cs));
+                }
+                uint32_t any = 0, full_rank = 0;
+                for (uint32_t p = 0; p < W; ++p) {
+                    any |= q.h_words[p * stride];
+                    if (q.h_words[p * stride] & 1u) full_rank = p;
+                }
+                if (any & 2u) {
+                    (void)rl_gen_abort(s->e);
+                    if (dead_rc != RL_OK && dead_rc != RL_ERR_BUSY) return fail(s, dead_rc, "rank %u: %s (refused on every rank, nothing applied)", s->rank, dead_msg);
+                    return fail(s, RL_ERR_INVALID, "another rank refused the step: nothing was applied anywhere");
+                }
+                if (any & 4u) {  // some owner's sort overflowed and promoted its heavy keys: nothing was computed from it
+                    (void)rl_gen_abort(s->e);
+                    if (attempt >= 2) return fail(s, RL_ERR_BATCH_TOO_LARGE, "a hash bucket of some rank's share keeps overflowing: split the slice");
+                    retry = true;
+                    break;
+                }
+                if (dead_rc != RL_OK) {  // (a failure that was in nobody's word: a HIP error behind the gather)
+                    (void)rl_gen_abort(s->e);
+                    return fail(s, dead_rc, "rank %u: %s", s->rank, dead_msg);
+                }
+                if (any & 8u) {  // not there yet: the passes are open on every rank, another group
+                    rounds += group;
+                    if (rounds > (uint64_t)W * s->max_slice + 2 + RQ_BLIND_MAX) {  // (one more request of the trace prefix is settled per round)
+                        (void)rl_gen_abort(s->e);
+                        return fail(s, RL_ERR_DEVICE, "the rounds did not converge (bug)");
+                    }
+                    s->rq.rounds_hint = std::min(rounds + 1, RQ_BLIND_MAX);
+                    continue;
+                }
+                if (any & 1u) {
+                    (void)rl_gen_abort(s->e);
+                    return fail(s, RL_ERR_TABLE_FULL, "refused, nothing applied on any rank: rank %u's shard cannot take the cells the step creates", full_rank);
+                }
+                if (!committed) {
+                    (void)rl_gen_abort(s->e);
+                    return fail(s, RL_ERR_DEVICE, "no rank objected and the pass was not applied (bug)");
+                }
+                uint32_t used = group;
+                for (uint32_t gr = 0; gr < group; ++gr) {
+                    uint32_t chg = 0;
+                    for (uint32_t p = 0; p < W; ++p) chg |= q.h_words[p * stride + 1 + gr];
+                    if (!chg) {  // the admitted set of this round is the one its flags were computed with
+                        used = gr + 1;
+                        break;
+                    }
+                }
+                rounds += used;
+                break;
             }
-            uint32_t gw[MAX_WORLD * RQ_BLIND_MAX];
-            rc = gather_words(s, q.d_words + RQ_CHANGED, gw, group);  // (the one stop of a group: did ANY rank see a change, per round)
+            if (retry) continue;
+            s->rq.rounds_hint = rounds;
+            break;
+        }
+        // (an engine with streams of its own, RL_SHARDED_ENGINE_STREAMS=own: round 5's blocking protocol, a stop per call)
+        for (bool converged = false; !converged;) {
+            HIP_S(s, hipMemsetAsync(q.d_words + RQ_CHANGED, 0, 4, s->cs));
+            rc = one_round(rounds == 0, q.d_words + RQ_CHANGED);
             if (rc != RL_OK) return rc;
-            uint32_t used = group;
-            for (uint32_t gr = 0; gr < group && !converged; ++gr) {
-                uint32_t any = 0;
-                for (uint32_t p = 0; p < W; ++p) any |= gw[p * group + gr];
-                if (!any) {  // the admitted set of this round is the one its flags were computed with
-                    converged = true;
-                    used = gr + 1;
-                }
-            }
-            rounds += used;
-            if (rounds > (uint64_t)W * s->max_slice + 2 + RQ_BLIND_MAX) {  // (one more request of the trace prefix is settled per round)
+            uint32_t gw[MAX_WORLD];
+            rc = gather_words(s, q.d_words + RQ_CHANGED, gw);  // did ANY rank see a change
+            if (rc != RL_OK) return rc;
+            converged = max_of(gw, W) == 0;
+            if (++rounds > (uint64_t)W * s->max_slice + 2) {
                 (void)rl_gen_abort(s->e);
                 return fail(s, RL_ERR_DEVICE, "the rounds did not converge (bug)");
             }
         }
-        s->rq.rounds_hint = rounds;
         // ---- 4. the walks' ends -> owners; cells to create, room: all ranks fit or none does -------------------------------
         uint32_t n_new = 0;
         uint64_t room = 0;
@@ -1051,7 +1146,7 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
             ENG_S(s, rl_req_reached_stream(s->e, s->cs, d_first, q.req_of_hit, s->perm[0], n_hits, q.adm_sorted));
             rc = exchange_per_hit(s, true, 1, q.adm_sorted, q.adm_recv);
             if (rc != RL_OK) return rc;
-            if (!chained) HIP_S(s, hipStreamSynchronize(s->cs));
+            HIP_S(s, hipStreamSynchronize(s->cs));
             crc = dead_rc != RL_OK ? dead_rc : rl_gen_count_device(s->e, q.adm_recv, &n_new, &room);
         } else {
             crc = dead_rc != RL_OK ? dead_rc : rl_gen_count_device(s->e, nullptr, &n_new, &room);
@@ -1059,31 +1154,22 @@ int32_t rl_sharded_check_requests_device(rl_sharded* s, const rl_hit* d_hits, ui
         char cmsg[200] = {0};
         if (dead_rc != RL_OK) std::snprintf(cmsg, sizeof(cmsg), "%s", dead_msg);
         else if (crc != RL_OK) std::snprintf(cmsg, sizeof(cmsg), "%s", rl_last_error(s->e));
-        // (RL_ERR_BUSY out of the count of a chained pass: the owners' sort overflowed and promoted its heavy keys — nothing was
-        // computed, every rank goes round again)
-        const bool again = chained && dead_rc == RL_OK && crc == RL_ERR_BUSY && attempt < 2;
-        rc = gather_host_word(s, again ? 3u : crc != RL_OK ? 2u : (n_new > room ? 1u : 0u), words);
+        rc = gather_host_word(s, crc != RL_OK ? 2u : (n_new > room ? 1u : 0u), words);
         if (rc != RL_OK) return rc;
-        const uint32_t worst = max_of(words, W);
-        bool any_fail = false;
-        for (uint32_t p = 0; p < W; ++p) any_fail |= words[p] == 2u;
-        if (worst == 3u && !any_fail) {
-            (void)rl_gen_abort(s->e);  // (a rank whose own sort was fine: its pass is dropped, nothing was written)
-            continue;
-        }
-        if (worst) {
+        if (const uint32_t worst = max_of(words, W)) {
             (void)rl_gen_abort(s->e);
-            if (crc != RL_OK && crc != RL_ERR_BUSY) return fail(s, crc, "rank %u: %s", s->rank, cmsg);
-            if (crc == RL_ERR_BUSY && dead_rc == RL_OK) return fail(s, RL_ERR_BATCH_TOO_LARGE, "rank %u: %s", s->rank, cmsg);
             if (crc != RL_OK) return fail(s, crc, "rank %u: %s", s->rank, cmsg);
-            if (any_fail || worst == 3u) return fail(s, RL_ERR_DEVICE, "another rank failed while counting: nothing was applied anywhere");
+            if (worst == 2u) return fail(s, RL_ERR_DEVICE, "another rank failed while counting: nothing was applied anywhere");
             return fail(s, RL_ERR_TABLE_FULL, "refused, nothing applied on any rank: a shard cannot take the cells the step creates (here: %u new, room %llu)",
                         n_new, (unsigned long long)room);
+        }
+        {
+            const int32_t mrc = rl_gen_commit_device(s->e);
+            if (mrc != RL_OK) return fail(s, mrc, "engine: %s", rl_last_error(s->e));
         }
         break;
     }
     if (rounds_out) *rounds_out = rounds;
-    ENG_S(s, rl_gen_commit_device(s->e));
     // ---- 5. values read before the update, back to the ingress ranks (in_memory.rs:114-116,134-136) -------------------
     if (load_counters) {
         rc = exchange_per_hit(s, false, 8, q.rem_recv, q.rem_sorted, q.exp_recv, q.exp_sorted);

@@ -1479,7 +1479,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         // creates at most n (k_gen_commit reports how many it created)
         const bool count_first = used + n > bound;
         if (count_first) k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A);
-        k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
+        k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, st>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u, nullptr, 0u, 0u);
         HIP_TRY(e, hipGetLastError());
         if (e->gen_post) {
             // what the host decides on, as ONE 16-byte store into host-mapped memory behind the last kernel: no copy
@@ -2972,7 +2972,7 @@ int32_t rl_gen_commit_device(rl_engine* e) try {
     A.update_mode = 1u;  // (k_gen_commit: the caller has seen the fixpoint; the device-side convergence test does not apply)
     const u32 n = e->ph_n;
     const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
-    k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u);
+    k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u, nullptr, 0u, 0u);
     GenStatus h_gst;
     HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));  // (what closing the pass clears: one stop, not two)
@@ -2988,6 +2988,110 @@ int32_t rl_gen_commit_device(rl_engine* e) try {
     e->stats.hits += n;
     e->stats.ordered_hits += n;
     e->stats.ordered_batches++;
+    return gen_phase_close(e, true);
+} RL_ABI_CATCH
+
+// The count and the commit of a phased pass WITHOUT the host looking in between (the key-sharded step in async mode): the
+// count leaves this rank's veto word on the device, the caller gathers all ranks' words there, the commit is gated on them.
+int32_t rl_gen_count_async_device(rl_engine* e, const uint8_t* d_reached, const uint32_t* d_also, uint32_t* d_veto) try {
+    if (!e || !d_veto) return RL_ERR_INVALID;
+    EngineLock g(e);
+    if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
+    if (!(e->ph_async && e->external_stream)) return fail(e, RL_ERR_INVALID, "rl_gen_set_async on a caller's stream first");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (e->ph_n == 0) {
+        k_gen_veto<<<1, 64, 0, e->stream>>>(nullptr, nullptr, 0u, d_also, d_veto);
+        HIP_TRY(e, hipGetLastError());
+        e->ph_counted = true;
+        return RL_OK;
+    }
+    if (e->ph_rounds == 0) return fail(e, RL_ERR_INVALID, "rl_gen_round_device has not run");
+    GenArgs A = e->ph_A;
+    const u32 n = e->ph_n;
+    A.reached_hit = d_reached;
+    A.mark_reached = d_reached ? 1u : 0u;
+    e->ph_A.mark_reached = A.mark_reached;
+    if (d_reached) {
+        HIP_TRY(e, hipMemsetAsync(e->d_g_reached, 0, n, e->stream));
+        k_gen_reach<<<cdiv(n, (u32)GS_MAX), GS_BLOCK, 0, e->stream>>>(A);
+    }
+    HIP_TRY(e, hipMemsetAsync(&e->d_gst->n_new, 0, sizeof(u32), e->stream));
+    k_gen_count<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A);
+    const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
+    k_gen_veto<<<1, 64, 0, e->stream>>>(e->d_gst, &e->ph_bs->st, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u, d_also, d_veto);
+    HIP_TRY(e, hipGetLastError());
+    e->ph_counted = true;
+    return RL_OK;
+} RL_ABI_CATCH
+
+int32_t rl_gen_commit_gated_device(rl_engine* e, const uint32_t* d_veto, uint32_t* h_veto, uint32_t n_veto, uint32_t veto_stride,
+                                   uint32_t* committed) try {
+    if (!e || !d_veto || !h_veto || !n_veto || !veto_stride || !committed) return RL_ERR_INVALID;
+    EngineLock g(e);
+    *committed = 0;
+    if (!e->ph_open) return fail(e, RL_ERR_INVALID, "no phased pass is open");
+    if (!(e->ph_async && e->external_stream)) return fail(e, RL_ERR_INVALID, "rl_gen_set_async on a caller's stream first");
+    if (!e->ph_counted) return fail(e, RL_ERR_INVALID, "rl_gen_count_async_device must follow the last round");
+    HIP_TRY(e, hipSetDevice(e->device));
+    // every rank's word, for the host — ahead of the kernels whose last store is what the host waits for
+    HIP_TRY(e, hipMemcpyAsync(h_veto, d_veto, (size_t)n_veto * veto_stride * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    auto vetoed = [&]() {
+        u32 v = 0;
+        for (u32 q = 0; q < n_veto; ++q) v |= h_veto[q * veto_stride];
+        return v != 0;
+    };
+    if (e->ph_n == 0) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        e->ph_counted = false;
+        if (vetoed()) return RL_OK;  // the pass stays open: more rounds, or rl_gen_abort
+        *committed = 1;
+        return gen_phase_close(e, true);
+    }
+    GenArgs A = e->ph_A;
+    A.update_mode = 1u;
+    const u32 n = e->ph_n;
+    const u64 used = e->live + e->tombs, bound = e->cap - e->cap / 16;
+    k_gen_commit<<<std::min(cdiv(n, 256), 1024u), 256, 0, e->stream>>>(A, used < bound ? (u32)std::min<u64>(bound - used, 0xFFFFFFFFull) : 0u,
+                                                                      d_veto, n_veto, veto_stride);
+    // (k_gen_post: the outcome as one 16-byte store into host-mapped memory, and — applied passes only — the status block and
+    // the scratch blocks zeroed for whatever comes next: no copy command, no stream synchronise, no fill commands)
+    const u32 seq = ++e->gen_post_seq ? e->gen_post_seq : ++e->gen_post_seq;
+    k_gen_post<<<1, 256, 0, e->stream>>>(e->d_gst, &e->ph_bs->st, e->h_gen_word, seq, reinterpret_cast<u32*>(e->d_bs),
+                                         (u32)(BS_ROT * sizeof(BatchScratch) / sizeof(u32)));
+    HIP_TRY(e, hipGetLastError());
+    const int wrc = wait_word(e, e->h_gen_word + 3, seq, "the gated commit of a phased pass");
+    if (wrc) return wrc;
+    const u32 err = e->h_gen_word[0], created = e->h_gen_word[1], flags = e->h_gen_word[2];
+    e->ph_counted = false;
+    e->ph_unchecked = false;  // (whatever an async rl_gen_begin_device did not wait for is in this word)
+    if (err) {
+        (void)gen_phase_close(e);
+        return status_to_error(e, err);
+    }
+    if (flags & 1u) {  // the heavy keys were promoted: begin again, with that set
+        e->part_seq += 1;
+        (void)gen_phase_close(e);
+        return fail(e, RL_ERR_BUSY, "hash buckets of this slice overflowed; their heavy keys were promoted: begin the pass again "
+                                    "(nothing was applied)");
+    }
+    if (!(flags & 2u)) {
+        if (!vetoed()) {  // (no rank objected, no error, no overflow: the cells did not fit after all — cannot happen, k_gen_veto said they do)
+            (void)gen_phase_close(e);
+            return fail(e, RL_ERR_DEVICE, "the gated commit did not apply a pass nobody vetoed (bug)");
+        }
+        return RL_OK;  // the pass stays open
+    }
+    const u32 hot_n = flags >> 16 == 0xFFFFu ? 0xFFFFFFFFu : flags >> 16;
+    if (hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
+    else if (hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
+    e->live += created;
+    e->part_seq++;
+    e->stats.batches++;
+    e->stats.hits += n;
+    e->stats.ordered_hits += n;
+    e->stats.ordered_batches++;
+    e->gen_clean = true;  // (k_gen_post zeroed the status block and the scratch blocks behind the commit)
+    *committed = 1;
     return gen_phase_close(e, true);
 } RL_ABI_CATCH
 

@@ -996,12 +996,19 @@ __global__ __launch_bounds__(256) void k_gen_check_keys(GenArgs A) {
 // host does not have to look at it between k_gen_count and this kernel: the fixpoint has converged (the last
 // round changed nothing), no error, no overflow, and the table keeps 1/16 of its slots empty with the n_new cells
 // the pass creates (`room` = cells that may still be created).  Otherwise nothing is written.
-__global__ __launch_bounds__(256) void k_gen_commit(GenArgs A, u32 room) {
+//
+// `veto` (the key-sharded step, rl_gen_commit_gated_device): n_veto words `veto_stride` apart, one per rank of the job, each
+// rank's own "not from me" (k_gen_veto) gathered on the device — the pass is applied only where EVERY rank's word is zero, so
+// all ranks apply or none does without any of their hosts having looked in between.
+__global__ __launch_bounds__(256) void k_gen_commit(GenArgs A, u32 room, const u32* __restrict__ veto, u32 n_veto, u32 veto_stride) {
     __shared__ u32 s_n;
     {
         const GenStatus* g = A.gst;
         if (A.pst->err || g->err || g->overflow || g->n_new > room) return;
         if (!A.update_mode && gen_changed(g, g->last_slot)) return;  // not converged yet
+        u32 v = 0;
+        for (u32 q = 0; q < n_veto; ++q) v |= veto[q * veto_stride];
+        if (v) return;
     }
     if (threadIdx.x == 0) {
         s_n = 0;
@@ -1514,6 +1521,21 @@ __global__ __launch_bounds__(256) void k_gen_serve(Cell* __restrict__ table, u32
         expect = expect + 1u ? expect + 1u : 1u;
         __syncthreads();
     }
+}
+
+// This rank's word of the key-sharded step's all-or-nothing commit (k_gen_commit's `veto`): 1 = the cells the pass creates do
+// not fit, 2 = an error bit of the pass or of its partition, 4 = hash buckets overflowed (the pass is to be begun again),
+// 8 = `also` is non-zero (the caller's own reason: its last round still changed the admitted set).  gst null: a pass of no hits.
+__global__ void k_gen_veto(const GenStatus* gst, const Status* pst, u32 room, const u32* also, u32* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    u32 w = 0;
+    if (gst) {
+        if (pst->err | gst->err) w |= 2u;
+        if (gst->overflow) w |= 4u;
+        if (gst->n_new > room) w |= 1u;
+    }
+    if (also && *also) w |= 8u;
+    *out = w;
 }
 
 // End of a pass: what the host decides on — error bits of the pass and of its partition, cells created, overflow /
