@@ -78,7 +78,8 @@ int32_t rl_sharded_unique_id(uint8_t id[RL_UNIQUE_ID_BYTES]);
  * RCCL is bound at run time, to the librccl.so the process has already mapped if there is one (a host that uses
  * torch.distributed): one process, one RCCL; two mapped copies are refused.
  * The engine is switched to the communicator's apply stream (rl_engine_set_stream) until rl_sharded_destroy
- * and must not be used directly while slices are in flight. */
+ * and must not be used directly while slices are in flight.  Destroy the communicator BEFORE its engine:
+ * rl_sharded_destroy hands the engine its own streams back. */
 int32_t rl_sharded_create_rccl(rl_engine *e, uint32_t world, uint32_t rank, const uint8_t id[RL_UNIQUE_ID_BYTES],
                                uint32_t max_slice_hits, rl_sharded **out);
 int32_t rl_sharded_create(rl_engine *e, uint32_t world, uint32_t rank, const rl_transport *t,

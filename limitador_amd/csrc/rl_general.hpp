@@ -305,10 +305,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     // have buckets of their own — is read ONCE, two records per lane, and the requests of its records are gathered
     // while pass 1 runs; a longer one (any length up to GS_LONG_MAX) is re-read, records and requests requested
     // a step or two ahead.
-    const u32 steps = (L + GS_BLOCK - 1) / GS_BLOCK;
-    const u32 Lw = steps * 64;
-    const u32 w_lo = w * Lw, w_hi = (w + 1) * Lw < L ? (w + 1) * Lw : L;
+    // (A bucket that is too long is only LOOKED at — its first GS_LONG_MAX hits, pass 1 alone: which keys are heavy — so that
+    // the retry gives them buckets of their own.  Counting nothing there left the retry with the same bucket.)
     const bool too_long = L > (u32)GS_LONG_MAX;
+    const u32 Lc = too_long ? (u32)GS_LONG_MAX : L;
+    const u32 steps = (Lc + GS_BLOCK - 1) / GS_BLOCK;
+    const u32 Lw = steps * 64;
+    const u32 w_lo = w * Lw, w_hi = (w + 1) * Lw < Lc ? (w + 1) * Lw : Lc;
     const bool resident = steps <= 2;
     BHit hA{}, hB{};
     const bool okA = w_lo + lane < w_hi, okB = steps > 1 && w_lo + 64 + lane < w_hi;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_gen_sort(GenArgs A) {
     if (resident) {
         count_step(hA, okA);
         if (steps > 1) count_step(hB, okB);
-    } else if (!too_long) {
+    } else {
         BHit nxt{};
         if (okA) nxt = load_bhit(A.b_hits, lo + w_lo + lane);
         for (u32 u = 0; u < steps; ++u) {

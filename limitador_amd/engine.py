@@ -45,12 +45,16 @@ class Engine:
         if rc != RL_OK:
             raise EngineError(rc, "rl_engine_create failed (no MI355X visible?)" if rc == -3 else "rl_engine_create failed")
         self._h = h
+        self._dependents = []  # communicators built on this engine (sharded_abi.Sharded): closed BEFORE it, whatever order the
+        #                        garbage collector picks — rl_sharded_destroy hands the engine its own streams back
         self.max_batch_hits = max_batch_hits
         self.hash_seed = hash_seed
         self.device = device
 
     # -- plumbing ----------------------------------------------------------------------------
     def close(self):
+        for dep in list(getattr(self, "_dependents", ())):
+            dep.close()
         if getattr(self, "_h", None):
             self._lib.rl_engine_destroy(self._h)
             self._h = None

@@ -111,6 +111,7 @@ class Ingest:
         if rc:
             raise IngestError(rc, "rli_create failed")
         self._h = h
+        self._dependents = []  # frontends built on this ingest: closed before it (see Engine.close)
         self._check(SYMBOLS["rli_set_binding"](self._h, {"descriptors": 0, "root": 1}[binding]))
         if value_cap is not None:
             self._check(SYMBOLS["rli_set_value_cap"](self._h, int(value_cap)))
@@ -127,7 +128,9 @@ class Ingest:
         return int(out[0]), int(out[1])
 
     def close(self):
-        if self._h:
+        for dep in list(getattr(self, "_dependents", ())):
+            dep.close()
+        if getattr(self, "_h", None):
             SYMBOLS["rli_destroy"](self._h)
             self._h = None
 
@@ -298,6 +301,9 @@ class Frontend:
         if rc:
             raise IngestError(rc, "rli_frontend_create failed")
         self._h = h
+        # (its workers call into both: whichever of the three the garbage collector finalizes first, the frontend goes first)
+        engine._dependents.append(self)
+        ingest._dependents.append(self)
 
     def set_clock(self, now_us):
         SYMBOLS["rli_frontend_set_clock"](self._h, int(now_us))
@@ -333,9 +339,12 @@ class Frontend:
         return SYMBOLS["rli_frontend_windows"](self._h)
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             SYMBOLS["rli_frontend_destroy"](self._h)
             self._h = None
+            for owner in (self._engine, self._ingest):
+                if self in owner._dependents:
+                    owner._dependents.remove(self)
 
     def __del__(self):
         try:

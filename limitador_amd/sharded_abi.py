@@ -115,6 +115,7 @@ class Sharded:
             raise ShardedError(rc, "rl_sharded_create failed (see stderr)")
         self._h = h
         self.world, self.rank = world, rank
+        engine._dependents.append(self)  # (the engine closes what is built on it first: see Engine.close)
 
     def _check(self, rc):
         if rc:
@@ -167,9 +168,11 @@ class Sharded:
         return SYMBOLS["rl_sharded_in_flight"](self._h)
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             SYMBOLS["rl_sharded_destroy"](self._h)
             self._h = None
+            if self in self._engine._dependents:
+                self._engine._dependents.remove(self)
 
     def __del__(self):
         try:

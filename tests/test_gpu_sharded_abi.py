@@ -396,6 +396,89 @@ def test_a_multi_counter_step_one_shard_cannot_take_is_refused_on_every_rank():
     group.close()
 
 
+def test_a_heavy_key_on_a_cold_engine_makes_every_rank_go_round_again_not_just_its_owner():
+    """The owners' sort takes at most 65 535 hits per hash bucket.  A cold engine that meets a key with 65 400 hits beside
+    the bucket's ordinary share reports it (its veto word says so, gathered on the device with the others'), the key gets a
+    bucket of its own, and ALL ranks begin the step again — nothing was applied by the first go.  Verdicts, first_limited
+    and the union of the tables against one sequential oracle on the concatenated slices (in_memory.rs:141-153)."""
+    import oracle
+    from limitador_amd.wire import HIT_DTYPE
+
+    dev = torch.device("cuda", 0)
+    world, n_heavy, n_plain = 2, 32_700, 100_000
+    rows = [(100_000, 60), (3, 60)]
+    engines = []
+    for _ in range(world):
+        e = Engine(capacity_cells=1 << 19, max_batch_hits=1 << 18)
+        e.set_limits(rows)
+        engines.append(e)
+    group = sharded_abi.LocalGroup(world)
+    ranks = [sharded_abi.Sharded(engines[r], world, r, 1 << 18, transport=group.transport(r)) for r in range(world)]
+    heavy = 0x1234_5678_9ABC
+    rng = np.random.default_rng(11)
+
+    def a_slice():
+        # requests in random order: n_heavy of them [the heavy key, a user's key], n_plain of them [a user's key]
+        with_heavy = rng.permutation(np.arange(n_heavy + n_plain) < n_heavy)
+        users = W.splitmix64((rng.integers(0, 60_000, size=n_heavy + n_plain) + 7).astype(np.uint64)) & np.uint64(0x3FFFFFFFFFFFFFFF)
+        off = np.concatenate([[0], np.cumsum(1 + with_heavy.astype(np.int64))])
+        h = np.zeros(int(off[-1]), dtype=HIT_DTYPE)
+        h["delta"] = 1
+        h["key"][off[:-1][with_heavy]] = heavy  # (limit 0)
+        last = off[1:] - 1
+        h["key"][last] = users
+        h["limit"][last] = 1
+        return h, off
+
+    steps = 2
+    data = [[a_slice() for _ in range(world)] for _ in range(steps)]
+    got, errors = {}, []
+
+    def run(r):
+        try:
+            sh = _RequestsOverTheAbi(ranks[r], dev)
+            outs = []
+            for s in range(steps):
+                h, off = data[s][r]
+                t = torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev)
+                v, f, _rem, _exp = sh.check(t, torch.from_numpy(off).to(dev), W.NOW0_US + s)
+                outs.append((v.cpu().numpy(), f.cpu().numpy()))
+            got[r] = outs
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck at an exchange"
+    orc = oracle.OracleStorage()
+    orc.set_limits(rows)
+    for s in range(steps):
+        hits = np.concatenate([data[s][r][0] for r in range(world)])
+        off, lo_h = [0], [0]
+        for r in range(world):
+            off.extend((data[s][r][1][1:] + off[-1]).tolist())
+            lo_h.append(lo_h[-1] + len(data[s][r][0]))
+        v, f, _rem, _exp = orc.check_and_update(hits, W.NOW0_US + s, req_off=np.array(off, dtype=np.uint32))
+        nr = n_heavy + n_plain
+        for r in range(world):
+            fr = f[r * nr:(r + 1) * nr].astype(np.int64)
+            assert np.array_equal(got[r][s][0], v[r * nr:(r + 1) * nr]), f"step {s} rank {r}: verdicts"
+            assert np.array_equal(got[r][s][1], np.where(fr >= 0, fr - lo_h[r], -1)), f"step {s} rank {r}: first_limited"
+    rows_out = np.concatenate([e.dump_cells() for e in engines])
+    assert len(np.unique(rows_out["key"])) == len(rows_out) == orc.num_qualified()
+    for r in rows_out:
+        assert (int(r["value"]), int(r["expiry_us"]), int(r["limit"])) == orc.peek(int(r["key"]))
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        e.close()
+    group.close()
+
+
 # ---- a sweep as a command of the routed pipeline: rl_sharded_sweep_submit / _collect ------------------------------------
 @pytest.mark.parametrize("world", [2, 3])
 def test_routed_sweeps_between_slices_in_flight(world):
