@@ -2807,6 +2807,23 @@ uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t 
 // For hosts that decide admission themselves: requests whose counters live on several GPUs (key-sharded
 // multi-counter requests, limitador_amd/sharded.py ShardedMultiCounterEngine) — the per-request AND of
 // in_memory.rs:141-153 then spans engines, so every fixpoint round goes through the host.
+// The hot set holds HOT_MAX keys, appended in whatever order the workgroups get there: while more keys qualify than fit, the
+// heaviest may be among the ones left out, and a pass that overflowed because of them overflows again.  An ordinary pass
+// moves the threshold one step; a pass that has to be REPEATED moves it as far as its own count says is needed (counts of
+// a Zipf head roughly halve when the threshold doubles).
+static void adapt_hot_threshold(rl_engine* e, u32 hot_n, bool repeat) {
+    if (hot_n > (u32)HOT_MAX) {
+        u32 q = hot_n;
+        do {
+            if (e->hot_threshold >= (1u << 30)) break;
+            e->hot_threshold *= 2;
+            q /= 2;
+        } while (repeat && q > (u32)HOT_MAX);
+    } else if (hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor && !repeat) {
+        e->hot_threshold /= 2;
+    }
+}
+
 static int32_t gen_phase_close(rl_engine* e, bool cleared = false) {
     e->ph_open = false;
     e->ph_counted = false;
@@ -2858,6 +2875,8 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
         GenStatus h_gst;
         HIP_TRY(e, hipMemcpyAsync(&h_gst, e->d_gst, offsetof(GenStatus, changed), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(&h_bst, &bs->st, sizeof(Status), hipMemcpyDeviceToHost, e->stream));
+        // (keys that qualified for the set this sort picked: no kernel has put the count into the status block yet)
+        if (A.hot_next) HIP_TRY(e, hipMemcpyAsync(&h_gst.hot_n, &A.hot_next->n, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         if (h_bst.err | h_gst.err) {
             HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));
@@ -2865,6 +2884,7 @@ int32_t rl_gen_begin_device(rl_engine* e, const rl_hit* d_hits, const uint32_t* 
         }
         if (h_gst.overflow) {  // the heavy keys were promoted: partition again with that set
             e->part_seq += 1;
+            adapt_hot_threshold(e, h_gst.hot_n, true);
             HIP_TRY(e, hipMemsetAsync(e->d_bs, 0, BS_ROT * sizeof(BatchScratch), e->stream));
             if (attempt >= 2)
                 return fail(e, RL_ERR_BATCH_TOO_LARGE, "a hash bucket of this slice holds more than %d hits or %d cells: split the slice", GS_LONG_MAX, GS_E);
@@ -2950,13 +2970,13 @@ int32_t rl_gen_count_device(rl_engine* e, const uint8_t* d_reached, uint32_t* n_
         }
         if (h_gst.overflow) {  // the heavy keys were promoted: begin again, with that set
             e->part_seq += 1;
+            adapt_hot_threshold(e, h_gst.hot_n, true);
             (void)gen_phase_close(e);
             return fail(e, RL_ERR_BUSY, "hash buckets of this slice overflowed; their heavy keys were promoted: begin the pass again "
                                         "(nothing was applied)");
         }
     }
-    if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
-    else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
+    adapt_hot_threshold(e, h_gst.hot_n, false);
     if (n_new) *n_new = h_gst.n_new;
     return RL_OK;
 } RL_ABI_CATCH
@@ -3068,8 +3088,10 @@ int32_t rl_gen_commit_gated_device(rl_engine* e, const uint32_t* d_veto, uint32_
         (void)gen_phase_close(e);
         return status_to_error(e, err);
     }
+    const u32 hot_n = flags >> 16 == 0xFFFFu ? 0xFFFFFFFFu : flags >> 16;
     if (flags & 1u) {  // the heavy keys were promoted: begin again, with that set
         e->part_seq += 1;
+        adapt_hot_threshold(e, std::min(hot_n, 0xFFFFu), true);
         (void)gen_phase_close(e);
         return fail(e, RL_ERR_BUSY, "hash buckets of this slice overflowed; their heavy keys were promoted: begin the pass again "
                                     "(nothing was applied)");
@@ -3081,9 +3103,7 @@ int32_t rl_gen_commit_gated_device(rl_engine* e, const uint32_t* d_veto, uint32_
         }
         return RL_OK;  // the pass stays open
     }
-    const u32 hot_n = flags >> 16 == 0xFFFFu ? 0xFFFFFFFFu : flags >> 16;
-    if (hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
-    else if (hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
+    adapt_hot_threshold(e, hot_n, false);
     e->live += created;
     e->part_seq++;
     e->stats.batches++;
