@@ -1252,6 +1252,23 @@ constexpr u32 GEN_ROUNDS_ENQ = 3;           // fixpoint rounds enqueued blind be
                                             // the second round's admitted set is already the fixpoint: the usual large batch) ...
 constexpr u32 GEN_ROUNDS_ENQ_MORE = 6;      // ... and between two looks after that (long chains of dependent requests)
 
+// The hot set holds HOT_MAX keys, appended in whatever order the workgroups get there: while more keys qualify than fit, the
+// heaviest may be among the ones left out, and a pass that overflowed because of them overflows again.  An ordinary pass
+// moves the threshold one step; a pass that has to be REPEATED moves it as far as its own count says is needed (counts of
+// a Zipf head roughly halve when the threshold doubles).
+static void adapt_hot_threshold(rl_engine* e, u32 hot_n, bool repeat) {
+    if (hot_n > (u32)HOT_MAX) {
+        u32 q = std::min(hot_n, 0xFFFFu);  // (k_gen_post's word saturates there)
+        do {
+            if (e->hot_threshold >= (1u << 30)) break;
+            e->hot_threshold *= 2;
+            q /= 2;
+        } while (repeat && q > (u32)HOT_MAX);
+    } else if (hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor && !repeat) {
+        e->hot_threshold /= 2;
+    }
+}
+
 struct GenCall {
     const Hit* d_hits;
     u32 n_hits;
@@ -1514,8 +1531,7 @@ int run_general_pass(rl_engine* e, const GenCall& c, u32 req0, u32 n_req, u32 hi
         e->stats.probe_steps += h_gst.rounds_run;
         rounds_total += h_gst.rounds_run;
         // keep the hot set selective: the hottest keys are the ones that stay when more qualify than fit
-        if (h_gst.hot_n > (u32)HOT_MAX && e->hot_threshold < (1u << 30)) e->hot_threshold *= 2;
-        else if (h_gst.hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor) e->hot_threshold /= 2;
+        adapt_hot_threshold(e, h_gst.hot_n, h_gst.overflow != 0);
         const u32 err = h_bst.err | h_gst.err;
         if (e->gen_trace)
             std::fprintf(stderr, "[gen] pass seq=%llu n=%u req=%u round=%u rounds_run=%u overflow=%u committed=%u n_new=%u hot_n=%u thr=%u err=%u\n",
@@ -2807,23 +2823,6 @@ uint64_t rl_match_key(uint32_t limit_id, uint32_t n_vars, uint32_t v0, uint32_t 
 // For hosts that decide admission themselves: requests whose counters live on several GPUs (key-sharded
 // multi-counter requests, limitador_amd/sharded.py ShardedMultiCounterEngine) — the per-request AND of
 // in_memory.rs:141-153 then spans engines, so every fixpoint round goes through the host.
-// The hot set holds HOT_MAX keys, appended in whatever order the workgroups get there: while more keys qualify than fit, the
-// heaviest may be among the ones left out, and a pass that overflowed because of them overflows again.  An ordinary pass
-// moves the threshold one step; a pass that has to be REPEATED moves it as far as its own count says is needed (counts of
-// a Zipf head roughly halve when the threshold doubles).
-static void adapt_hot_threshold(rl_engine* e, u32 hot_n, bool repeat) {
-    if (hot_n > (u32)HOT_MAX) {
-        u32 q = hot_n;
-        do {
-            if (e->hot_threshold >= (1u << 30)) break;
-            e->hot_threshold *= 2;
-            q /= 2;
-        } while (repeat && q > (u32)HOT_MAX);
-    } else if (hot_n < (u32)HOT_MAX / 4 && e->hot_threshold > e->hot_floor && !repeat) {
-        e->hot_threshold /= 2;
-    }
-}
-
 static int32_t gen_phase_close(rl_engine* e, bool cleared = false) {
     e->ph_open = false;
     e->ph_counted = false;
@@ -3091,7 +3090,7 @@ int32_t rl_gen_commit_gated_device(rl_engine* e, const uint32_t* d_veto, uint32_
     const u32 hot_n = flags >> 16 == 0xFFFFu ? 0xFFFFFFFFu : flags >> 16;
     if (flags & 1u) {  // the heavy keys were promoted: begin again, with that set
         e->part_seq += 1;
-        adapt_hot_threshold(e, std::min(hot_n, 0xFFFFu), true);
+        adapt_hot_threshold(e, hot_n, true);
         (void)gen_phase_close(e);
         return fail(e, RL_ERR_BUSY, "hash buckets of this slice overflowed; their heavy keys were promoted: begin the pass again "
                                     "(nothing was applied)");
