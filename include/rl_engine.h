@@ -406,7 +406,7 @@ int32_t rl_wire_table_set(rl_engine *e, const uint8_t *blob, uint32_t blob_len, 
  * counter which is not the one its key belongs to (the word stored in the key's cell decides; without a cell, the
  * batch's first counter of that key) and *collided_message is the index of one of them — the caller answers those
  * messages on its exact path (or drops them) and calls again without them: one re-run, however many collide. */
-/* Pinned host buffers that belong to the engine, by slot (0..7 — four per serving set, see rl_wire_serve_batch_set: set s
+/* Pinned host buffers that belong to the engine, by slot (0 .. 4 RL_SERVE_SETS - 1 — four per serving set, see rl_wire_serve_batch_set: set s
  * owns slots 4 s .. 4 s + 3; grown on demand — a later call for the same slot may move
  * it — and freed with the engine): where a host layer builds the arrays it hands to the host-pointer entry points and
  * receives their results, so that every copy is plain DMA instead of the runtime's pageable path (a fresh 60 MB result
@@ -453,13 +453,17 @@ int32_t rl_wire_serve_batch(rl_engine *e, const uint8_t *wire, const uint32_t *m
                             uint32_t flags, uint8_t *verdict, int32_t *status, const uint32_t **resp_off,
                             const uint8_t **resp, int64_t *collided_message);
 int32_t rl_serve_wait(rl_engine *e, uint64_t upto);
-/* TWO serving calls in flight (the reference serves from N tonic workers at once, envoy_rls/server.rs:238-272, behind a
+/* SEVERAL serving calls in flight (the reference serves from N tonic workers at once, envoy_rls/server.rs:238-272, behind a
  * shared read lock, in_memory.rs:78).  Everything a serving call leaves behind for the host — the pinned staging of its
- * offsets and bytes, the events of its pieces — exists twice, by `set` (0 or 1), and the bytes' kernels run on a stream of
- * their own from a snapshot of what they read; so while the host still waits for and hands on the responses of the call on
- * set s (rl_serve_wait_set(e, s, upto)), another thread may pack, copy in and decide the next batch with set 1 - s.  The
- * engine's mutex serialises the calls themselves (decisions are applied in the order the calls enter); a set must not be
- * used again before every byte of its previous call has been waited for.  rl_wire_serve_batch = set 0. */
+ * offsets and bytes, the events of its pieces, the device copy of its messages — exists RL_SERVE_SETS times, by `set`, and the
+ * bytes' kernels run on a stream of their own from a snapshot of what they read; so while the host still waits for and hands
+ * on the responses of the call on set s (rl_serve_wait_set(e, s, upto)), other threads may pack, copy in and decide the next
+ * batches with the other sets.  Two sets: more of them were built and measured (4: no faster — what bounds the pair is the
+ * device, where a call's decide phase and the previous call's response transfer do not overlap).  The
+ * engine's mutex serialises the calls themselves (decisions are applied in the order the
+ * calls enter); a set must not be used again before every byte of its previous call has been waited for.
+ * rl_wire_serve_batch = set 0. */
+#define RL_SERVE_SETS 2
 int32_t rl_wire_serve_batch_set(rl_engine *e, uint32_t set, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
                                 uint64_t now_us, uint32_t flags, uint8_t *verdict, int32_t *status,
                                 const uint32_t **resp_off, const uint8_t **resp, int64_t *collided_message);

@@ -160,8 +160,11 @@ int32_t rli_set_limit_name(rli_ingest *g, uint32_t limit_id, const char *name);
  * rl_match_serve_batch, csrc/rl_resp.hpp; what each limit contributes to X-RateLimit-Limit is sent to the engine once per
  * change of a limit's max / name) and this call only hands them on while they arrive; smaller batches are assembled on the
  * host from the counters' arrays.  Same bytes either way.
- * One call at a time per ENGINE (the messages and the results travel through the engine's pinned staging, rl_host_staging
- * slots 0 to 3; rli_frontend_* serialises its batches).
+ * May be called from several threads at once on one ingest / engine: with RLI_KEYS_HASHED and device-built responses up to
+ * RL_SERVE_SETS (rl_engine.h) calls are in flight together — each takes a serving set of the engine (its own pinned
+ * staging, rl_host_staging slots 4 s .. 4 s + 3, device copy of the messages and piece events): one packs while one copies
+ * in / decides and the others' responses cross PCIe and are handed on; decisions are applied in the order the calls enter
+ * the engine.  Every other form of the call waits for the engine to itself.
  * status[i]: 0 OK, 1 OVER_LIMIT, RLI_UNKNOWN_DOMAIN, RLI_HOST_ONLY (the value dictionary is at its cap: the caller
  * evaluates this request itself; no response is produced), RLI_RESPONSE_TOO_LARGE (counted, but its response does not
  * fit out_stride: out_len[i] = 0), or another value < 0 for a malformed message. */

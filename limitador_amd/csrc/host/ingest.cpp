@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -345,13 +346,13 @@ struct rli_ingest {
     // The dictionaries are read by many decoding threads at once (rli_serve_batch splits a large batch over
     // threads) and written when a request brings a value never seen before: readers share, a writer excludes.
     mutable std::shared_mutex dict_mu;
-    // Serving calls in flight: the hashed-key path with device-built responses takes ONE of two sets (engine staging slots
-    // 4 s .. 4 s + 3, piece events, a helper pool), so two threads' calls overlap — one packs / copies in / decides while the
-    // other's responses cross PCIe and are handed on; every other form of the call takes both (it uses this ingest's batch
-    // arrays and set 0's staging: one at a time, as before).
+    // Serving calls in flight: the hashed-key path with device-built responses takes ONE of the engine's RL_SERVE_SETS sets
+    // (engine staging slots 4 s .. 4 s + 3, piece events, a helper pool), so several threads' calls overlap — one packs,
+    // one copies in / decides, the others' responses cross PCIe and are handed on; every other form of the call takes ALL
+    // of them (it uses this ingest's batch arrays and set 0's staging: one at a time, as before).
     std::mutex set_mu;
     std::condition_variable set_cv;
-    bool set_busy[2] = {false, false};
+    bool set_busy[RL_SERVE_SETS] = {};
     std::mutex err_mu;   // `err` is written by whichever serving thread fails
     std::mutex frag_mu;  // send_fragments
 };
@@ -365,12 +366,22 @@ struct SetLease {
     bool bytes_pending = false;  // a *_serve_batch call succeeded with RL_SERVE_ASYNC: its last byte must be waited for
     SetLease(rli_ingest* g_, rl_engine* e_, bool exclusive) : g(g_), e(e_), both(exclusive) {
         std::unique_lock<std::mutex> lk(g->set_mu);
+        auto free_set = [&]() -> int {
+            for (int q = 0; q < RL_SERVE_SETS; ++q)
+                if (!g->set_busy[q]) return q;
+            return -1;
+        };
+        auto any_busy = [&] {
+            for (bool b : g->set_busy)
+                if (b) return true;
+            return false;
+        };
         if (exclusive) {
-            g->set_cv.wait(lk, [&] { return !g->set_busy[0] && !g->set_busy[1]; });
-            g->set_busy[0] = g->set_busy[1] = true;
+            g->set_cv.wait(lk, [&] { return !any_busy(); });
+            for (bool& b : g->set_busy) b = true;
         } else {
-            g->set_cv.wait(lk, [&] { return !g->set_busy[0] || !g->set_busy[1]; });
-            set = g->set_busy[0] ? 1 : 0;
+            g->set_cv.wait(lk, [&] { return free_set() >= 0; });
+            set = free_set();
             g->set_busy[set] = true;
         }
     }
@@ -381,8 +392,10 @@ struct SetLease {
         if (bytes_pending) (void)rl_serve_wait_set(e, (uint32_t)set, ~0ull);
         {
             std::lock_guard<std::mutex> lk(g->set_mu);
-            if (both) g->set_busy[0] = g->set_busy[1] = false;
-            else g->set_busy[set] = false;
+            if (both)
+                for (bool& b : g->set_busy) b = false;
+            else
+                g->set_busy[set] = false;
         }
         g->set_cv.notify_all();
     }
@@ -429,11 +442,11 @@ class ChunkPool {
     };
 
 public:
-    // One pool per serving set (two serving calls may be in flight, rl_ingest.h: the pack of one runs beside the scatter of
-    // the other — one pool would queue them on its `job_mu`).
+    // One pool per serving set (several serving calls may be in flight, rl_ingest.h: the pack of one runs beside the scatter
+    // of another — one pool would queue them on its `job_mu`).
     static ChunkPool& get(uint32_t which = 0) {
-        static ChunkPool p[2];
-        return p[which & 1u];
+        static ChunkPool p[RL_SERVE_SETS];
+        return p[which % RL_SERVE_SETS];
     }
     // f(chunk) for chunk in [0, n_chunks), on the pool's threads and the caller's; returns when every chunk is done and
     // no helper is inside the job any more.  One job at a time (callers queue up on `job_mu`).
@@ -1159,9 +1172,13 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
     const bool trace = RL_EXP_ENV("RLI_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
-        if (trace)
-            std::fprintf(stderr, "[rli] %-10s at %8.1f us\n", what,
-                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+        if (trace) {  // (since the call began; on the process's clock, so that calls in flight together can be laid side by side)
+            const auto t = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[rli] %-10s at %8.1f us  (clock %12.1f us, thread %04x)\n", what,
+                         std::chrono::duration<double, std::micro>(t - t_begin).count(),
+                         std::chrono::duration<double, std::micro>(t.time_since_epoch()).count() - 1e6 * std::floor(std::chrono::duration<double>(t.time_since_epoch()).count() / 100.0) * 100.0,
+                         (unsigned)(std::hash<std::thread::id>{}(std::this_thread::get_id()) & 0xFFFFu));
+        }
     };
     // With headers, the responses of a LARGE batch are built on the DEVICE (rl_*_serve_batch): what comes back is the bytes,
     // not the counters — 262 144 messages 5.9 -> 3.3 ms, 32 768 1.0 -> 0.8.  A small batch keeps the host assembly from the
@@ -1169,13 +1186,14 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
     // 0.19 ms batch of 256.  RLI_RESP_HOST=1 / RLI_RESP_DEVICE=1 (experiment builds) force one or the other — the two are
     // compared byte for byte by tests/test_gpu_rls_e2e.py.
     const bool dev_resp = with_headers && !RL_EXP_ENV("RLI_RESP_HOST") && (RL_EXP_ENV("RLI_RESP_DEVICE") || n >= 4096u);
-    // One of the two serving sets for the form that overlaps (hashed keys, responses built on the device); both sets — i.e.
+    // One of the serving sets for the form that overlaps (hashed keys, responses built on the device); all sets — i.e.
     // alone — for every other form (it uses this ingest's batch arrays and set 0).  Released, after the last byte has been
     // waited for, on every way out of this function.
     if (hooks && hooks->before_lease) hooks->before_lease();
     SetLease lease(g, e, !(dev_resp && g->key_mode == RLI_KEYS_HASHED));
     if (hooks && hooks->after_lease) hooks->after_lease(!lease.both);
     const uint32_t set = (uint32_t)lease.set;
+    lap("leased");
     if (lease.both) rli_batch_clear(g);
     std::vector<int32_t> req_of(n, -1);
     // The results of the device call live in the ENGINE's pinned staging (rl_host_staging slot 1): fresh pageable arrays —

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <mutex>
@@ -289,14 +290,14 @@ struct rl_engine {
     u64* d_w_prefix = nullptr;
     uint8_t* d_w_bytes = nullptr;   // the messages of one batch, concatenated
     u64 w_bytes_cap = 0;
-    // The SECOND serving set's copy of the two (rl_wire_serve_batch_set, set 1), and what lets a serving call copy its
-    // messages in BEFORE it takes the engine's mutex: a copy stream of its own (the transfer runs beside the other set's
+    // The OTHER serving sets' copies of the two (rl_wire_serve_batch_set, set s >= 1: [s - 1]), and what lets a serving call copy
+    // its messages in BEFORE it takes the engine's mutex: a copy stream of its own (the transfer runs beside the other sets'
     // kernels instead of in front of them) and an event per set that the decide phase picks up.
-    uint8_t* d_w_bytes1 = nullptr;
-    u64 w_bytes_cap1 = 0;
-    u32* d_w_off1 = nullptr;
+    uint8_t* d_w_bytes_more[RL_SERVE_SETS - 1] = {};
+    u64 w_bytes_cap_more[RL_SERVE_SETS - 1] = {};
+    u32* d_w_off_more[RL_SERVE_SETS - 1] = {};
     hipStream_t in_stream = nullptr;
-    hipEvent_t in_ev[2] = {};
+    hipEvent_t in_ev[RL_SERVE_SETS] = {};
     // RateLimitResponse bytes built on the device (rl_resp.hpp): what each limit contributes to X-RateLimit-Limit
     // (rl_resp_table_set), the responses' offsets and bytes of one batch
     uint8_t* d_resp_blob = nullptr;
@@ -313,7 +314,7 @@ struct rl_engine {
     // Two SETS of everything a serving call leaves behind for the host to pick up (round 6): while the responses of the call
     // on set s are still being written to the host and handed on, the next call — on the other set — packs, copies in and
     // decides (include/rl_engine.h: rl_wire_serve_batch_set).
-    static constexpr u32 SERVE_SETS = 2;
+    static constexpr u32 SERVE_SETS = RL_SERVE_SETS;
     hipEvent_t resp_ev[SERVE_SETS][RESP_CHUNKS] = {};
     u64 resp_chunk_end[SERVE_SETS][RESP_CHUNKS] = {};  // the set's last serving call's pieces: piece c is complete when resp_ev[c] is,
     u32 resp_n_chunks[SERVE_SETS] = {};                // and ends at this byte of the responses (0 pieces: the call was synchronous)
@@ -324,6 +325,9 @@ struct rl_engine {
     hipEvent_t snap_ev[SERVE_SETS] = {};
     void* resp_snap[SERVE_SETS] = {};
     u64 resp_snap_cap[SERVE_SETS] = {};
+    u32 resp_via_copy = 0;          // RL_RESP_VIA_COPY=1 (experiment): the blind path's bytes go to a device buffer and leave in copy commands; 2: of kind hipMemcpyDeviceToDeviceNoCU
+    uint8_t* d_resp_set[SERVE_SETS] = {};
+    u64 d_resp_set_cap[SERVE_SETS] = {};
     u32 resp_pieces = 8;            // RL_RESP_PIECES
     u32 resp_writers = 128;         // RL_RESP_WRITERS: workgroups of k_resp<true> that write host memory at once
     bool resp_blind = true;         // RL_RESP_BLIND=0: the host reads the responses' total before their kernels go out
@@ -335,8 +339,8 @@ struct rl_engine {
     uint4* d_w_slot_h = nullptr;    // [max_batch][MATCH_SLOTS]: hashes of the values the variables read
     u32* d_hit_check = nullptr;     // [max_batch]: the check word of every derived counter (rl_keyhash.h)
     u32 collide_hit = 0;            // RL_ERR_KEY_COLLISION: a hit (index in the call) of the colliding pair
-    void* h_stage[8] = {};          // rl_host_staging: pinned buffers the engine lends to a host layer, by slot (4 per serving set)
-    u64 h_stage_cap[8] = {};
+    void* h_stage[4 * RL_SERVE_SETS] = {};  // rl_host_staging: pinned buffers the engine lends to a host layer, by slot (4 per serving set)
+    u64 h_stage_cap[4 * RL_SERVE_SETS] = {};
     unsigned long long* d_m_mask = nullptr;  // [max_batch] limits of its namespace that apply to a request
     u32* d_m_ns = nullptr;      // staging for host-pointer calls: per request namespace, delta
     u32* d_m_delta = nullptr;
@@ -1831,6 +1835,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_DEFER2")) e->defer2 = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_DIRECT")) e->resp_direct = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_RESP_VIA_COPY")) e->resp_via_copy = (u32)std::max(0, atoi(v));
     if (const char* v = RL_EXP_ENV("RL_GEN_PASS_PREFILL")) e->gen_pass_prefill = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_LOAD_DEFERRED")) e->gen_load_deferred = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_CARRY_REQ")) e->gen_carry_req = atoi(v) != 0;
@@ -2089,11 +2094,14 @@ void rl_engine_destroy(rl_engine* e) {
     }
     for (hipEvent_t ev : e->in_ev)
         if (ev) (void)hipEventDestroy(ev);
-    if (e->d_w_bytes1) (void)hipFree(e->d_w_bytes1);
-    if (e->d_w_off1) (void)hipFree(e->d_w_off1);
+    for (uint8_t* q : e->d_w_bytes_more)
+        if (q) (void)hipFree(q);
+    for (u32* q : e->d_w_off_more)
+        if (q) (void)hipFree(q);
     for (u32 q = 0; q < rl_engine::SERVE_SETS; ++q) {
         if (e->snap_ev[q]) (void)hipEventDestroy(e->snap_ev[q]);
         if (e->resp_snap[q]) (void)hipFree(e->resp_snap[q]);
+        if (e->d_resp_set[q]) (void)hipFree(e->d_resp_set[q]);
     }
     for (auto& evs : e->resp_ev)
       for (hipEvent_t ev : evs)
@@ -3368,6 +3376,45 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
         const u32 pieces = std::min<u32>(e->resp_pieces, std::max<u32>(1u, (u32)(bound >> 22)));  // (the bound is ~2 x the bytes)
         const u32 per = cdiv(n_blocks, pieces);
         u32 nc = 0, b_end[rl_engine::RESP_CHUNKS];
+        if (e->resp_via_copy) {
+            // (experiment: do the small device -> host writes of the NEXT call's decide phase get through sooner when this call's
+            // bytes leave in copy commands instead of 128 workgroups' stores?)
+            if (bound > e->d_resp_set_cap[set]) {
+                HIP_TRY(e, hipStreamSynchronize(e->resp_stream));
+                if (e->d_resp_set[set]) (void)hipFree(e->d_resp_set[set]);
+                e->d_resp_set[set] = nullptr;
+                e->d_resp_set_cap[set] = 0;
+                u64 cap = 1u << 20;
+                while (cap < bound) cap <<= 1;
+                if (hipMalloc((void**)&e->d_resp_set[set], cap) != hipSuccess) return fail(e, RL_ERR_NOMEM, "hipMalloc of %llu bytes of responses failed", (unsigned long long)cap);
+                e->d_resp_set_cap[set] = cap;
+            }
+            RS.out_cap = e->d_resp_set_cap[set];
+            k_resp<true><<<n_blocks, 256, 0, e->resp_stream>>>(RS, nullptr, snap_off, e->d_resp_set[set], 0u, n_blocks);
+            HIP_TRY(e, hipGetLastError());
+            HIP_TRY(e, hipEventSynchronize(e->resp_off_ev));
+            const u32* off = static_cast<const u32*>(h_off);
+            if (off[n] > e->h_stage_cap[slot_bytes])
+                return fail(e, RL_ERR_INTERNAL, "the responses take %u bytes, the bound said %llu (the batch was applied)", off[n], (unsigned long long)bound);
+            for (u32 b0 = 0; b0 < n_blocks; b0 += per, ++nc) {
+                const u32 nb = std::min(per, n_blocks - b0);
+                const u64 lo = off[std::min<u64>((u64)b0 * 256u, n)], hi = off[std::min<u64>((u64)(b0 + nb) * 256u, n)];
+                if (hi > lo && e->resp_via_copy == 3) {  // (whole 16-byte words: the bytes around the piece are its neighbours', the same in both buffers)
+                    const u64 a = lo & ~15ull, b = (hi + 15ull) & ~15ull;
+                    k_copy_stream<<<e->resp_writers, 256, 0, e->resp_stream>>>(reinterpret_cast<const uint4*>(e->d_resp_set[set] + a),
+                                                                              reinterpret_cast<uint4*>(static_cast<uint8_t*>(h_bytes) + a), (b - a) >> 4);
+                } else if (hi > lo)
+                    HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t*>(h_bytes) + lo, e->d_resp_set[set] + lo, hi - lo,
+                                              e->resp_via_copy == 2 ? hipMemcpyDeviceToDeviceNoCU : hipMemcpyDeviceToHost, e->resp_stream));
+                if (!e->resp_ev[set][nc]) HIP_TRY(e, hipEventCreateWithFlags(&e->resp_ev[set][nc], hipEventDisableTiming));
+                HIP_TRY(e, hipEventRecord(e->resp_ev[set][nc], e->resp_stream));
+                e->resp_chunk_end[set][nc] = (u32)hi;
+            }
+            e->resp_n_chunks[set] = nc;
+            *so.resp_off = off;
+            *so.resp = static_cast<const uint8_t*>(h_bytes);
+            return RL_OK;
+        }
         for (u32 b0 = 0; b0 < n_blocks; b0 += per, ++nc) {
             const u32 nb = std::min(per, n_blocks - b0);
             k_resp<true><<<std::min(nb, e->resp_writers), 256, 0, e->resp_stream>>>(RS, nullptr, snap_off, static_cast<uint8_t*>(h_bytes), b0, nb);
@@ -3706,7 +3753,7 @@ int32_t rl_wire_table_set(rl_engine* e, const uint8_t* blob, uint32_t blob_len, 
 
 static int32_t host_staging_locked(rl_engine* e, uint32_t slot, uint64_t bytes, void** out);
 int32_t rl_host_staging(rl_engine* e, uint32_t slot, uint64_t bytes, void** out) try {
-    if (!e || !out || slot >= 8u) return RL_ERR_INVALID;
+    if (!e || !out || slot >= 4u * RL_SERVE_SETS) return RL_ERR_INVALID;
     // A buffer that is large enough already is handed out WITHOUT the engine's mutex: a slot belongs to one serving set, a set
     // to one caller at a time (rl_wire_serve_batch_set), so nobody else resizes it — and the caller of the other set, which
     // holds the mutex for the whole of its copy-in + decide, must not keep this one from packing its messages meanwhile.
@@ -3727,7 +3774,9 @@ static int32_t host_staging_locked(rl_engine* e, uint32_t slot, uint64_t bytes, 
         e->h_stage_cap[slot] = 0;
         u64 cap = 1u << 20;
         while (cap < bytes) cap <<= 1;
-        if (hipHostMalloc(&e->h_stage[slot], cap, hipHostMallocDefault) != hipSuccess)
+        unsigned stage_flags = hipHostMallocDefault;
+        if (const char* v = RL_EXP_ENV("RL_STAGE_FLAGS")) stage_flags = (unsigned)strtoul(v, nullptr, 0);  // (experiment: 0x40000000 coherent, 0x80000000 non-coherent)
+        if (hipHostMalloc(&e->h_stage[slot], cap, stage_flags) != hipSuccess)
             return fail(e, RL_ERR_NOMEM, "hipHostMalloc of %llu bytes of host staging failed", (unsigned long long)cap);
         e->h_stage_cap[slot] = cap;
     }
@@ -3757,9 +3806,9 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
     //      in front of its kernels, now run beside the other set's decide phase.  Only when the set's buffers are large
     //      enough already (they are only ever resized by the set's own calls, under the mutex, below). ---------------------
     const u32 set = so && so->set < rl_engine::SERVE_SETS ? so->set : 0u;
-    uint8_t*& d_bytes_set = set ? e->d_w_bytes1 : e->d_w_bytes;
-    u64& cap_set = set ? e->w_bytes_cap1 : e->w_bytes_cap;
-    u32*& d_off_set = set ? e->d_w_off1 : e->d_w_off;
+    uint8_t*& d_bytes_set = set ? e->d_w_bytes_more[set - 1] : e->d_w_bytes;
+    u64& cap_set = set ? e->w_bytes_cap_more[set - 1] : e->w_bytes_cap;
+    u32*& d_off_set = set ? e->d_w_off_more[set - 1] : e->d_w_off;
     bool copied_early = false;
     if (so && offsets_ok && e->wire_ready && e->in_stream && e->in_ev[set] && d_off_set && bytes <= cap_set) {
         if (hipSetDevice(e->device) == hipSuccess &&

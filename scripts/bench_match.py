@@ -24,6 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--requests", type=int, default=1_000_000)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--users", type=int, default=200_000)
+ap.add_argument("--beside", choices=["none", "d2h", "h2d", "d2h_nocu"], default="none",
+                help="a second thread copies 40 MB device -> pinned host (the runtime's blit kernel) or host -> device (SDMA) in a loop meanwhile")
 args = ap.parse_args()
 
 rng = np.random.default_rng(42)
@@ -81,12 +83,48 @@ now = 1_700_000_000_000_000
 for i in range(2):
     step(i, now + i * 1000)
 torch.cuda.synchronize()
+stop, copies = [False], [0]
+if args.beside != "none":
+    import threading
+
+    d_buf = torch.zeros(10 << 20, dtype=torch.float32, device=dev)
+    h_buf = torch.empty(10 << 20, dtype=torch.float32).pin_memory()
+    s_c = torch.cuda.Stream()
+
+    hip = None
+    if args.beside == "d2h_nocu":  # the same copy with kind hipMemcpyDeviceToDeviceNoCU, through the HIP runtime this process has mapped
+        path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+        hip = C.CDLL(path)
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def pump():  # (twenty copies per synchronise: the thread sleeps in the runtime, without the GIL, nearly all the time)
+        with torch.cuda.stream(s_c):
+            while not stop[0]:
+                for _ in range(20):
+                    if hip is not None:
+                        rc = hip.hipMemcpyAsync(h_buf.data_ptr(), d_buf.data_ptr(), h_buf.numel() * 4, 1024, s_c.cuda_stream)
+                        assert rc == 0, rc
+                    elif args.beside == "d2h":
+                        h_buf.copy_(d_buf, non_blocking=True)
+                    else:
+                        d_buf.copy_(h_buf, non_blocking=True)
+                s_c.synchronize()
+                copies[0] += 20
+
+    th = threading.Thread(target=pump)
+    th.start()
+    time.sleep(0.05)
+c0 = copies[0]
 t0 = time.perf_counter()
 for i in range(args.steps):
     step(i, now + (i + 2) * 1000)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+n_copies = copies[0] - c0
+stop[0] = True
+if args.beside != "none":
+    th.join()
 print(json.dumps({"what": "rl_match_and_check_batch_device (match + general check_and_update)", "requests_per_batch": n,
                   "counters_per_batch": n_hits.value, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
-                  "requests_per_s": n * args.steps / dt, "limited_in_last_batch": int(verdict.sum().item())}))
+                  "requests_per_s": n * args.steps / dt, "beside": args.beside, "copies_of_40MB_meanwhile": n_copies, "limited_in_last_batch": int(verdict.sum().item())}))
 eng.close()

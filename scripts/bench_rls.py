@@ -48,7 +48,8 @@ now = 1_700_000_000_000_000
 out = {"what": "rli_serve_batch: wire bytes -> verdicts + RateLimitResponse bytes", "keys": KEYS, "sizes": {}}
 SIZES = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 16, 256, 4096, 32768, 262144)
 for n in SIZES:
-    prep = g.prepare_batch(messages(n))  # (the ctypes marshalling of the Python harness is not what is measured)
+    STRIDE = int(os.environ.get("BENCH_RLS_STRIDE", "1024"))  # the caller's slot per response (out + i * stride)
+    prep = g.prepare_batch(messages(n), stride=STRIDE)  # (the ctypes marshalling of the Python harness is not what is measured)
     row = {}
     for hdr in (False, True):
         g.serve_prepared(eng, prep, now, with_headers=hdr)
@@ -72,41 +73,43 @@ for n in SIZES:
                 ts.append(time.perf_counter() - t0)
             row[name] = {"p50_ms": float(np.percentile(ts, 50) * 1e3), "requests_per_s": n / float(np.percentile(ts, 50))}
     if n >= 32768 and KEYS == "hashed":
-        # TWO calls in flight (round 6): two threads, each with its own prepared batch, call rli_serve_batch back to back; a
-        # call takes one of the ingest's two serving sets, so one thread packs / copies in / decides while the other's
-        # responses cross PCIe and are handed on.  Sustained time per batch = elapsed / calls; the call's own latency beside it.
+        # SEVERAL calls in flight (round 6): T threads, each with its own prepared batch, call rli_serve_batch back to back; a
+        # call takes one of the engine's RL_SERVE_SETS serving sets, so one thread packs / copies in / decides while the
+        # others' responses cross PCIe and are handed on.  Sustained time per batch = elapsed / calls; the call's own latency
+        # beside it.
         import threading
 
-        prep2 = g.prepare_batch(messages(n))
-        lat = [[], []]
+        preps = [prep] + [g.prepare_batch(messages(n), stride=STRIDE) for _ in range(3)]
         K = 12
         clock = [now]
         clock_mu = threading.Lock()
+        for T, name in ((2, "with_headers_two_in_flight"), (3, "with_headers_three_in_flight"), (4, "with_headers_four_in_flight")):
+            lat = [[] for _ in range(T)]
 
-        def pump(t, prep_t, k=None):
-            for _ in range(K if k is None else k):
-                with clock_mu:
-                    clock[0] += 1000
-                    t_now = clock[0]
-                t0 = time.perf_counter()
-                g.serve_prepared(eng, prep_t, t_now, with_headers=True)
-                lat[t].append(time.perf_counter() - t0)
+            def pump(t, k):
+                for _ in range(k):
+                    with clock_mu:
+                        clock[0] += 1000
+                        t_now = clock[0]
+                    t0 = time.perf_counter()
+                    g.serve_prepared(eng, preps[t], t_now, with_headers=True)
+                    lat[t].append(time.perf_counter() - t0)
 
-        # (warm both serving sets — the second one's pinned staging and device buffers are allocated by its first calls —
-        # with a short concurrent phase that is not timed)
-        ths = [threading.Thread(target=pump, args=(0, prep, 3)), threading.Thread(target=pump, args=(1, prep2, 3))]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-        lat = [[], []]
-        ths = [threading.Thread(target=pump, args=(0, prep)), threading.Thread(target=pump, args=(1, prep2))]
-        t0 = time.perf_counter()
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-        el = time.perf_counter() - t0
+            # (warm the serving sets — a set's pinned staging and device buffers are allocated by its first calls — with a
+            # short concurrent phase that is not timed)
+            ths = [threading.Thread(target=pump, args=(t, 3)) for t in range(T)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            lat = [[] for _ in range(T)]
+            ths = [threading.Thread(target=pump, args=(t, K)) for t in range(T)]
+            t0 = time.perf_counter()
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            el = time.perf_counter() - t0
+            allat = np.array(sum(lat, []))
+            row[name] = {"ms_per_batch_sustained": el / (T * K) * 1e3, "requests_per_s": n * T * K / el,
+                         "call_p50_ms": float(np.percentile(allat, 50) * 1e3)}
         now = clock[0]
-        allat = np.array(lat[0] + lat[1])
-        row["with_headers_two_in_flight"] = {"ms_per_batch_sustained": el / (2 * K) * 1e3, "requests_per_s": n * 2 * K / el,
-                                             "call_p50_ms": float(np.percentile(allat, 50) * 1e3)}
     out["sizes"][str(n)] = row
 out["host_threads"] = os.environ.get("RLI_THREADS", "auto: one per 1024 messages, at most 32")
 print(json.dumps(out))
