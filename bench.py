@@ -509,6 +509,22 @@ def secondary(args, eng, dev, gen):
                     "profiles/r06a_general_kernels.md, r06f_general_kernels.md)"}
     except Exception as ex:
         out["configs4_shape_match_and_check_1M_requests"] = {"error": str(ex)[:200]}
+    # -- multi-counter requests whose counters are sharded BY KEY (SURVEY.md 8e "k > 1"): rl_sharded_check_requests_device at world 1
+    #    over the library's own RCCL communicator (the protocol's own cost: exchanges, blind round groups, the veto gather, the gated
+    #    commit; scripts/bench_sharded_requests.py, own process, bounded: a first RCCL bring-up on a fresh box can take minutes;
+    #    profiles/r06_key_sharded.md)
+    try:
+        import subprocess
+
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "bench_sharded_requests.py"),
+                            "262144", "50", "rccl"], capture_output=True, text=True, timeout=120)
+        m = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        out["key_sharded_multi_counter_262144_requests_x3"] = {
+            "ms_per_step": m["ms_per_step"], "requests_per_s": m["requests_per_s"], "counters_per_step": m["counters_per_step"],
+            "rounds": m["rounds"][-1], "note": m["what"] + " (round 5: 0.455 ms; profiles/r06_key_sharded.md; the in-process "
+                                               "transport of the tests synchronises twice per exchange: 0.43 ms)"}
+    except Exception as ex:
+        out["key_sharded_multi_counter_262144_requests_x3"] = {"error": str(ex)[:200]}
     # -- the wire path: serialized RateLimitRequests -> verdicts -> RateLimitResponse bytes, per batch size,
     #    with the host's dictionaries and with the messages decoded and the keys hashed on the device (scripts/bench_rls.py)
     try:

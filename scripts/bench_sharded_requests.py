@@ -2,7 +2,9 @@
 """rl_sharded_check_requests_device at world 1 (the library's own RCCL communicator): requests of three counters each, the
 counters sharded by key (all of them here, on the one GPU), ms per step and rounds.  What it shows is the protocol's own
 cost — exchanges, the phased resolver's blocking calls, one word per rank per round through the host — not scaling.
-usage: python scripts/bench_sharded_requests.py [n_req] [steps]"""
+usage: python scripts/bench_sharded_requests.py [n_req] [steps] [rccl|local]
+(local: the in-process transport at world 1 — the same kernels, the exchanges as the transport's own device copies, no RCCL
+bring-up: what bench.py's `secondary` runs)"""
 import json
 import os
 import sys
@@ -18,12 +20,15 @@ from limitador_amd.engine import Engine  # noqa: E402
 
 n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+transport = sys.argv[3] if len(sys.argv) > 3 else "rccl"
 k = 3
 dev = torch.device("cuda", 0)
 n = n_req * k
 eng = Engine(capacity_cells=1 << 23, max_batch_hits=n)
 eng.set_limits([(1000, 60), (200, 60), (50, 10)])
-sh = sharded_abi.Sharded(eng, 1, 0, n, unique_id=sharded_abi.unique_id())
+group = sharded_abi.LocalGroup(1) if transport == "local" else None
+sh = (sharded_abi.Sharded(eng, 1, 0, n, transport=group.transport(0)) if group else
+      sharded_abi.Sharded(eng, 1, 0, n, unique_id=sharded_abi.unique_id()))
 rng = np.random.default_rng(W.SEED)
 batches = []
 for _ in range(4):
@@ -47,8 +52,10 @@ for i in range(steps):
     rounds.append(sh.check_requests(batches[i % 4].data_ptr(), n, off.data_ptr(), n_req, now, v.data_ptr(), False, f.data_ptr()))
     now += 1000
 dt = time.perf_counter() - t0
-print(json.dumps({"what": "rl_sharded_check_requests_device, RCCL world 1", "requests_per_step": n_req, "counters_per_step": n,
+print(json.dumps({"what": "rl_sharded_check_requests_device, world 1, " + ("in-process transport" if group else "RCCL"), "requests_per_step": n_req, "counters_per_step": n,
                   "ms_per_step": dt / steps * 1e3, "requests_per_s": n_req * steps / dt, "rounds": rounds,
                   "limited_in_last_step": int(v.sum().item())}))
 sh.close()
 eng.close()
+if group:
+    group.close()
