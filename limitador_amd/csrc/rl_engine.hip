@@ -46,6 +46,117 @@ using namespace rl;
 #define RL_EXP_ENV(name) (static_cast<const char*>(nullptr))
 #endif
 
+// ---- red zones (experiment build, RL_REDZONE=1): every device allocation of this file gets RZ_BYTES of a known pattern on
+//      either side; rl_debug_redzones() reads them back and names the first block whose pattern a kernel has written over.
+//      GPU AddressSanitizer is not available on this pool: this bounds the "stray store next to an engine array" class of
+//      device faults over whatever the test-suite drives through the engine (tests/test_gpu_redzones.py).
+#ifdef RL_EXPERIMENT
+namespace {
+constexpr size_t RZ_BYTES = 4096;
+constexpr unsigned char RZ_FILL = 0xA5;
+struct RzBlock {
+    void* base;
+    size_t bytes;
+};
+std::mutex rz_mu;
+std::vector<std::pair<void*, RzBlock>> rz_blocks;  // user pointer -> block
+bool rz_on() {
+    const char* v = getenv("RL_REDZONE");
+    return v && atoi(v) != 0;
+}
+template <class T>
+hipError_t rz_malloc(T** p, size_t bytes) {
+    if (!rz_on()) return hipMalloc(p, bytes);
+    const size_t user = (bytes + 255) & ~size_t(255);  // (hipMalloc's own alignment is kept for the user's pointer)
+    void* base = nullptr;
+    hipError_t r = hipMalloc(&base, user + 2 * RZ_BYTES);
+    if (r != hipSuccess) return r;
+    r = hipMemset(base, RZ_FILL, user + 2 * RZ_BYTES);
+    if (r != hipSuccess) return r;
+    *p = reinterpret_cast<T*>(static_cast<char*>(base) + RZ_BYTES);
+    std::lock_guard<std::mutex> g(rz_mu);
+    // RL_REDZONE=1: the block itself starts as zeros (what fresh device memory usually holds); =3: as the pattern too — an array
+    // that is read before it is written shows (=2: only the arrays of rl_engine_create, by name: rz_poison below)
+    if (atoi(getenv("RL_REDZONE")) < 3 && hipMemset(*p, 0, bytes) != hipSuccess) return hipErrorUnknown;
+    // (the fills run on the null stream, which the engine's non-blocking streams are not ordered with: a kernel that initialises the
+    // block must not be overtaken by them)
+    if (hipDeviceSynchronize() != hipSuccess) return hipErrorUnknown;
+    rz_blocks.push_back({static_cast<void*>(*p), RzBlock{base, bytes}});
+    return hipSuccess;
+}
+// the two zones of one block: 0 = intact; else msg says where
+int rz_check(void* user_ptr, const RzBlock& b, char* msg, size_t msg_len) {
+    const size_t user = (b.bytes + 255) & ~size_t(255);
+    std::vector<unsigned char> h;
+    for (int side = 0; side < 2; ++side) {
+        // (the zone behind the block starts at the byte after the user's last one: the alignment padding is part of it)
+        const char* at = side == 0 ? static_cast<const char*>(b.base) : static_cast<const char*>(b.base) + RZ_BYTES + b.bytes;
+        const size_t len = side == 0 ? RZ_BYTES : RZ_BYTES + (user - b.bytes);
+        h.resize(len);
+        if (hipMemcpy(h.data(), at, len, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        for (size_t i = 0; i < len; ++i)
+            if (h[i] != RZ_FILL) {
+                if (msg && msg_len)
+                    std::snprintf(msg, msg_len, "block of %zu bytes at %p: the byte %zu %s it was overwritten with 0x%02x", b.bytes, user_ptr,
+                                  side == 0 ? RZ_BYTES - i : i, side == 0 ? "before" : "behind", (unsigned)h[i]);
+                return 1;
+            }
+    }
+    return 0;
+}
+// (a block is checked when it is freed — every engine array is, at rl_engine_destroy at the latest — and a damaged zone ends the
+// process: a test-suite run with RL_REDZONE=1 cannot pass over one)
+// RL_REDZONE=2: the arrays rl_engine_create allocates start as the pattern — all of them, or the one RL_REDZONE_POISON names
+bool rz_poison(const char* name) {
+    const char* m = getenv("RL_REDZONE");
+    if (!m || atoi(m) != 2) return false;
+    const char* only = getenv("RL_REDZONE_POISON");
+    return !only || std::strcmp(only, name) == 0;
+}
+hipError_t rz_free(void* p) {
+    if (!p) return hipSuccess;
+    void* base = p;
+    RzBlock blk{};
+    bool mine = false;
+    {
+        std::lock_guard<std::mutex> g(rz_mu);
+        for (size_t i = 0; i < rz_blocks.size(); ++i)
+            if (rz_blocks[i].first == p) {
+                blk = rz_blocks[i].second;
+                base = blk.base;
+                mine = true;
+                rz_blocks.erase(rz_blocks.begin() + i);
+                break;
+            }
+    }
+    if (mine) {
+        (void)hipDeviceSynchronize();
+        char msg[200] = {0};
+        if (rz_check(p, blk, msg, sizeof msg) > 0) {
+            std::fprintf(stderr, "RL_REDZONE: %s\n", msg);
+            std::abort();
+        }
+    }
+    return hipFree(base);
+}
+}  // namespace
+// -> number of blocks with a damaged red zone (0 = none); msg: the first one.  Synchronises the device.
+extern "C" __attribute__((visibility("default"))) int32_t rl_debug_redzones(uint32_t* n_blocks, char* msg, uint32_t msg_len) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::lock_guard<std::mutex> g(rz_mu);
+    int32_t bad = 0;
+    if (n_blocks) *n_blocks = (uint32_t)rz_blocks.size();
+    for (const auto& kv : rz_blocks) {
+        const int r = rz_check(kv.first, kv.second, bad ? nullptr : msg, msg_len);
+        if (r < 0) return -1;
+        bad += r;
+    }
+    return bad;
+}
+#define hipMalloc rz_malloc
+#define hipFree rz_free
+#endif
+
 static_assert(sizeof(rl_hit) == sizeof(Hit), "rl_hit layout");
 static_assert(sizeof(rl_cell_row) == sizeof(CellRow), "rl_cell_row layout");
 static_assert(sizeof(rl_match_limit) == sizeof(MatchLimit), "rl_match_limit layout");
@@ -1943,9 +2054,14 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     // address X" of a later kernel can then be attributed to the buffer it ran off (scripts/exp/r13_abort_hunt.sh)
     const bool log_allocs = RL_EXP_ENV("RL_LOG_ALLOCS") != nullptr;
     if (log_allocs) std::fprintf(stderr, "[alloc] %-18s %p %zu\n", "e->table", (void*)e->table, (size_t)e->cap * sizeof(Cell));
+#ifdef RL_EXPERIMENT
+#define RZ_POISON(ptr, bytes) (rz_poison(#ptr) ? (void)(hipMemset((ptr), RZ_FILL, (bytes)), hipDeviceSynchronize()) : (void)0)
+#else
+#define RZ_POISON(ptr, bytes) ((void)0)
+#endif
 #define ALLOC(ptr, bytes)                                                                                       \
     if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) return bail(RL_ERR_NOMEM);                               \
-    else if (log_allocs) std::fprintf(stderr, "[alloc] %-18s %p %zu\n", #ptr, (void*)(ptr), (size_t)(bytes))
+    else if (RZ_POISON(ptr, bytes), log_allocs) std::fprintf(stderr, "[alloc] %-18s %p %zu\n", #ptr, (void*)(ptr), (size_t)(bytes))
     ALLOC(e->d_limits, e->max_limits * sizeof(LimitDev));
     ALLOC(e->d_hits, mb * sizeof(Hit));
     ALLOC(e->d_req_off, (mb + 1) * sizeof(u32));
@@ -2047,6 +2163,9 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
         memset(f.h_st, 0, sizeof(Status));
     }
     if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(RL_ERR_DEVICE);
+    // (the fills above that went out on the null stream: the engine's streams are non-blocking, i.e. not ordered with it — an
+    // allocator that filled its blocks there was overtaken by k_table_init, found with the red zones of the experiment build)
+    if (hipDeviceSynchronize() != hipSuccess) return bail(RL_ERR_DEVICE);
     e->stats.capacity_cells = e->cap;
     *out = e;
     return RL_OK;
