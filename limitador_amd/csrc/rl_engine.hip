@@ -444,6 +444,7 @@ struct rl_engine {
     bool resp_blind = true;         // RL_RESP_BLIND=0: the host reads the responses' total before their kernels go out
     u32 resp_max_frag = 0;          // longest fragment of rl_resp_table_set
     hipEvent_t resp_off_ev = nullptr;
+    bool results_direct = true;     // RL_RESULTS_DIRECT=0: small result sets travel as copy commands too (ResultsOut)
     bool resp_direct = true;        // RL_RESP_DIRECT=0: k_resp writes a device buffer and copy commands carry it to the host
     u32* d_w_off = nullptr;         // [max_batch + 1]
     int32_t* d_w_status = nullptr;  // [max_batch]
@@ -1945,6 +1946,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_PART_COMPACT")) e->part_compact = atoi(v) != 0 ? 1 : 0;
     if (const char* v = RL_EXP_ENV("RL_DEFER2")) e->defer2 = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_DIRECT")) e->resp_direct = atoi(v) != 0;
+    if (const char* v = RL_EXP_ENV("RL_RESULTS_DIRECT")) e->results_direct = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_VIA_COPY")) e->resp_via_copy = (u32)std::max(0, atoi(v));
     if (const char* v = RL_EXP_ENV("RL_GEN_PASS_PREFILL")) e->gen_pass_prefill = atoi(v) != 0;
@@ -3729,6 +3731,49 @@ int32_t rl_match_and_check_batch_device(rl_engine* e, const uint32_t* d_req_ns, 
                                   load_counters != 0, d_verdict, d_limited_limit, n_hits_out);
 } RL_ABI_CATCH
 
+// The results of a call on their way to the host.  A SMALL call whose result arrays all live in the engine's own pinned staging
+// (rl_host_staging: what the ingest hands in) gets them by ONE kernel that stores into that memory, instead of a copy command
+// per array — up to seven of them, ~8 us apiece back to back, were a quarter of a 256-message serving call; larger results,
+// or a caller's own arrays, travel as copy commands like before.  The same for a small call's INPUT arrays (the kernel then reads
+// the staging).  Everything is on e->stream; the caller synchronises.
+struct ResultsOut {
+    rl_engine* e;
+    CopySegs S{};
+    u64 total = 0;
+    bool direct = true;
+    explicit ResultsOut(rl_engine* e_) : e(e_) {}
+    // (`host`: the pointer of the pair that is the host's — the destination of a result, the source of an input)
+    void add(void* dst, const void* src, u64 bytes, const void* host = nullptr) {
+        if (!dst || !src || !bytes) return;
+        if (!host) host = dst;
+        if (S.n == COPY_SEGS_MAX) {
+            direct = false;
+            return;
+        }
+        S.dst[S.n] = dst;
+        S.src[S.n] = src;
+        S.bytes[S.n] = bytes;
+        ++S.n;
+        total += bytes;
+        bool inside = false;
+        for (u32 q = 0; q < 4u * RL_SERVE_SETS && !inside; ++q) {
+            const char* lo = static_cast<const char*>(e->h_stage[q]);
+            inside = lo && static_cast<const char*>(host) >= lo && static_cast<const char*>(host) + bytes <= lo + e->h_stage_cap[q];
+        }
+        direct = direct && inside;
+    }
+    int32_t go() {
+        if (!S.n) return RL_OK;
+        if (direct && total <= (256u << 10) && e->results_direct) {
+            k_copy_segs<<<(u32)std::min<u64>(std::max<u64>(total >> 12, 1), 64), 256, 0, e->stream>>>(S);
+            HIP_TRY(e, hipGetLastError());
+            return RL_OK;
+        }
+        for (u32 k = 0; k < S.n; ++k) HIP_TRY(e, hipMemcpyAsync(S.dst[k], S.src[k], S.bytes[k], hipMemcpyDefault, e->stream));
+        return RL_OK;
+    }
+};
+
 static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, const uint32_t* ent_off, const uint32_t* ent_key,
                                 const uint32_t* ent_val, const uint32_t* req_delta, uint32_t n_req, uint64_t now_us,
                                 int32_t load_counters, uint8_t* verdict, int32_t* limited_limit, uint32_t* req_off_out,
@@ -3744,12 +3789,17 @@ static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, co
     if (n_ent > e->max_batch) return fail(e, RL_ERR_BATCH_TOO_LARGE, "descriptor entries %u > max_batch_hits %u", n_ent, e->max_batch);
     if (n_ent && (!ent_key || !ent_val)) return fail(e, RL_ERR_INVALID, "ent_key / ent_val are null");
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, hipMemcpyAsync(e->d_m_ns, req_ns, (size_t)n_req * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(e->d_m_delta, req_delta, (size_t)n_req * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(e->d_m_ent_off, ent_off, ((size_t)n_req + 1) * 4, hipMemcpyHostToDevice, e->stream));
-    if (n_ent) {
-        HIP_TRY(e, hipMemcpyAsync(e->d_m_ent_key, ent_key, (size_t)n_ent * 4, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(e->d_m_ent_val, ent_val, (size_t)n_ent * 4, hipMemcpyHostToDevice, e->stream));
+    {
+        ResultsOut In(e);
+        In.add(e->d_m_ns, req_ns, (u64)n_req * 4, req_ns);
+        In.add(e->d_m_delta, req_delta, (u64)n_req * 4, req_delta);
+        In.add(e->d_m_ent_off, ent_off, ((u64)n_req + 1) * 4, ent_off);
+        if (n_ent) {
+            In.add(e->d_m_ent_key, ent_key, (u64)n_ent * 4, ent_key);
+            In.add(e->d_m_ent_val, ent_val, (u64)n_ent * 4, ent_val);
+        }
+        const int32_t irc = In.go();
+        if (irc) return irc;
     }
     u32 n_hits = 0;
     int rc = match_and_check_locked(e, op, e->d_m_ns, e->d_m_ent_off, e->d_m_ent_key, e->d_m_ent_val, e->d_m_delta, n_req,
@@ -3757,24 +3807,26 @@ static int32_t match_batch_host(rl_engine* e, int op, const uint32_t* req_ns, co
                                     &n_hits);
     if (n_hits_out) *n_hits_out = n_hits;
     if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n_req, hipMemcpyDeviceToHost, e->stream));
+    ResultsOut R(e);
+    R.add(verdict, e->d_verdict, n_req);
     if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
+        rc = R.go();
+        if (rc) return rc;
         rc = responses_locked(e, n_req, n_hits, nullptr, e->d_verdict, *so);  // (synchronises behind the verdicts' copy)
         if (rc) return rc;
         if (!e->resp_n_chunks[so->set < rl_engine::SERVE_SETS ? so->set : 0u]) HIP_TRY(e, hipStreamSynchronize(e->stream));
         return RL_OK;
     }
-    if (limited_limit)
-        HIP_TRY(e, hipMemcpyAsync(limited_limit, e->d_m_limited, (size_t)n_req * 4, hipMemcpyDeviceToHost, e->stream));
-    if (req_off_out)
-        HIP_TRY(e, hipMemcpyAsync(req_off_out, e->d_req_off, ((size_t)n_req + 1) * 4, hipMemcpyDeviceToHost, e->stream));
+    if (limited_limit) R.add(limited_limit, e->d_m_limited, (u64)n_req * 4);
+    if (req_off_out) R.add(req_off_out, e->d_req_off, ((u64)n_req + 1) * 4);
     const u32 n_copy = n_hits < hits_cap ? n_hits : hits_cap;
-    if (hits_out && n_copy)
-        HIP_TRY(e, hipMemcpyAsync(hits_out, e->d_hits, (size_t)n_copy * sizeof(Hit), hipMemcpyDeviceToHost, e->stream));
+    if (hits_out && n_copy) R.add(hits_out, e->d_hits, (u64)n_copy * sizeof(Hit));
     if (load_counters && n_copy && remaining && expires_in_us) {
-        HIP_TRY(e, hipMemcpyAsync(remaining, e->d_remaining, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(expires_in_us, e->d_expires, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
+        R.add(remaining, e->d_remaining, (u64)n_copy * 8);
+        R.add(expires_in_us, e->d_expires, (u64)n_copy * 8);
     }
+    rc = R.go();
+    if (rc) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
 }
@@ -3967,8 +4019,11 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
             HIP_TRY(e, hipStreamWaitEvent(e->stream, e->in_ev[set], 0));
         }
     } else {
-        if (bytes) HIP_TRY(e, hipMemcpyAsync(d_bytes_set, wire, bytes, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(d_off_set, msg_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, e->stream));
+        ResultsOut In(e);
+        In.add(d_bytes_set, wire, bytes, wire);
+        In.add(d_off_set, msg_off, ((u64)n + 1) * 4, msg_off);
+        const int32_t irc = In.go();
+        if (irc) return irc;
     }
     const u32 gq = cdiv(n, 256);
     const u32 call = ++e->m_call ? e->m_call : ++e->m_call;
@@ -3999,22 +4054,27 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
         (void)hipMemcpy(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost);
     }
     if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(verdict, e->d_verdict, n, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    ResultsOut R(e);
+    R.add(verdict, e->d_verdict, n);
+    R.add(status, e->d_w_status, (u64)n * 4);
     if (so) {  // the answer as RateLimitResponse bytes instead of the counters' arrays
+        rc = R.go();
+        if (rc) return rc;
         rc = responses_locked(e, n, n_hits, e->d_w_status, e->d_verdict, *so);  // (synchronises behind the verdicts' / statuses' copies)
         if (rc) return rc;
         if (!e->resp_n_chunks[so->set < rl_engine::SERVE_SETS ? so->set : 0u]) HIP_TRY(e, hipStreamSynchronize(e->stream));
         return RL_OK;
     }
-    if (limited_limit) HIP_TRY(e, hipMemcpyAsync(limited_limit, e->d_m_limited, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
-    if (req_off_out) HIP_TRY(e, hipMemcpyAsync(req_off_out, e->d_req_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, e->stream));
+    if (limited_limit) R.add(limited_limit, e->d_m_limited, (u64)n * 4);
+    if (req_off_out) R.add(req_off_out, e->d_req_off, ((u64)n + 1) * 4);
     const u32 n_copy = n_hits < hits_cap ? n_hits : hits_cap;
-    if (hits_out && n_copy) HIP_TRY(e, hipMemcpyAsync(hits_out, e->d_hits, (size_t)n_copy * sizeof(Hit), hipMemcpyDeviceToHost, e->stream));
+    if (hits_out && n_copy) R.add(hits_out, e->d_hits, (u64)n_copy * sizeof(Hit));
     if (load_counters && n_copy && remaining && expires_in_us) {
-        HIP_TRY(e, hipMemcpyAsync(remaining, e->d_remaining, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(expires_in_us, e->d_expires, (size_t)n_copy * 8, hipMemcpyDeviceToHost, e->stream));
+        R.add(remaining, e->d_remaining, (u64)n_copy * 8);
+        R.add(expires_in_us, e->d_expires, (u64)n_copy * 8);
     }
+    rc = R.go();
+    if (rc) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return RL_OK;
 }

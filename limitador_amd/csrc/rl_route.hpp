@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_req_reached(const int32_t* __restrict__
 
 // Up to four device-to-device copies in ONE launch (the router's own segments of an exchange: what a rank sends to
 // itself).  hipMemcpyAsync costs the host 8-10 us per call whatever it moves; a kernel launch ~3.
-constexpr u32 COPY_SEGS_MAX = 4;
+constexpr u32 COPY_SEGS_MAX = 8;
 struct CopySegs {
     void* dst[COPY_SEGS_MAX];
     const void* src[COPY_SEGS_MAX];
