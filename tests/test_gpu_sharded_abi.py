@@ -344,6 +344,97 @@ def test_key_sharded_multi_counter_requests_behind_the_c_abi(world, request):
         group.close()
 
 
+def test_a_rank_that_owns_none_of_the_steps_counters_still_takes_every_turn_with_the_others():
+    """Every counter of these steps hashes to rank 0: rank 1 routes its requests' hits away and its own owner side has NOTHING
+    (a phased pass of no hits).  It still has to go through the step's exchanges, offer its veto word and close its pass on
+    the same turn as the owner — also when the group of rounds was too short and another one follows (the limits are tight
+    enough for three rounds), and with load_counters.  Against one sequential oracle on the concatenated slices."""
+    import oracle
+    from limitador_amd.sharded import owner_of_tensor
+    from limitador_amd.wire import HIT_DTYPE
+
+    dev = torch.device("cuda", 0)
+    world, n_req = 2, 600
+    rows = [(40, 60), (7, 60), (3, 10)]
+    engines = []
+    for _ in range(world):
+        e = Engine(capacity_cells=1 << 14, max_batch_hits=1 << 14)
+        e.set_limits(rows)
+        engines.append(e)
+    seed = engines[0].hash_seed
+    rng = np.random.default_rng(21)
+    cand = rng.integers(1, 2**62, size=4000, dtype=np.int64)
+    mine = cand[owner_of_tensor(torch.from_numpy(cand), seed, world).numpy() == 0][:90]  # keys of rank 0 only
+    assert len(mine) == 90
+    group = sharded_abi.LocalGroup(world)
+    ranks = [sharded_abi.Sharded(engines[r], world, r, 1 << 13, transport=group.transport(r)) for r in range(world)]
+
+    def a_slice():
+        k = rng.integers(1, 4, size=n_req)
+        off = np.concatenate([[0], np.cumsum(k)])
+        h = np.zeros(int(off[-1]), dtype=HIT_DTYPE)
+        h["key"] = mine[rng.integers(0, 30, size=len(h))]
+        h["delta"] = 1
+        for i in range(n_req):  # counter j of a request is on limit j (a key belongs to one limit: 30 keys per limit)
+            for j in range(off[i], off[i + 1]):
+                lim = j - off[i]
+                h["limit"][j] = lim
+                h["key"][j] = mine[30 * lim + int(rng.integers(0, 30))]
+        return h, off
+
+    steps, load_steps = 4, {1, 3}
+    data = [[a_slice() for _ in range(world)] for _ in range(steps)]
+    got, errors = {}, []
+
+    def run(r):
+        try:
+            sh = _RequestsOverTheAbi(ranks[r], dev)
+            outs = []
+            for s in range(steps):
+                h, off = data[s][r]
+                t = torch.from_numpy(h.view(np.int64).reshape(-1, 2).copy()).to(dev)
+                v, f, rem, exp = sh.check(t, torch.from_numpy(off).to(dev), W.NOW0_US + 1000 * s, load_counters=s in load_steps)
+                outs.append((v.cpu().numpy(), f.cpu().numpy(), None if rem is None else rem.cpu().numpy().view(np.uint64),
+                             None if exp is None else exp.cpu().numpy().view(np.uint64), sh.rounds))
+            got[r] = outs
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck at an exchange"
+    orc = oracle.OracleStorage()
+    orc.set_limits(rows)
+    deepest = 0
+    for s in range(steps):
+        hits = np.concatenate([data[s][r][0] for r in range(world)])
+        off, lo_h = [0], [0]
+        for r in range(world):
+            off.extend((data[s][r][1][1:] + off[-1]).tolist())
+            lo_h.append(lo_h[-1] + len(data[s][r][0]))
+        v, f, rem, exp = orc.check_and_update(hits, W.NOW0_US + 1000 * s, req_off=np.array(off, dtype=np.uint32), load_counters=s in load_steps)
+        for r in range(world):
+            fr = f[r * n_req:(r + 1) * n_req].astype(np.int64)
+            gv, gf, grem, gexp, rounds = got[r][s]
+            assert np.array_equal(gv, v[r * n_req:(r + 1) * n_req]), f"step {s} rank {r}: verdicts"
+            assert np.array_equal(gf, np.where(fr >= 0, fr - lo_h[r], -1)), f"step {s} rank {r}: first_limited"
+            if s in load_steps:
+                assert np.array_equal(grem, rem[lo_h[r]:lo_h[r + 1]]), f"step {s} rank {r}: remaining"
+                assert np.array_equal(gexp, exp[lo_h[r]:lo_h[r + 1]]), f"step {s} rank {r}: expires_in"
+            deepest = max(deepest, rounds)
+    assert deepest >= 3
+    assert engines[1].stats()["live_cells"] == 0 and engines[0].stats()["live_cells"] == orc.num_qualified()
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        e.close()
+    group.close()
+
+
 def test_a_multi_counter_step_one_shard_cannot_take_is_refused_on_every_rank():
     from test_sharded_multi_gloo import SIMPLE
 
