@@ -435,6 +435,63 @@ def test_a_rank_that_owns_none_of_the_steps_counters_still_takes_every_turn_with
     group.close()
 
 
+def test_a_multi_counter_step_whose_owner_side_fails_on_one_rank_is_refused_on_every_rank():
+    """Rank 1's engine takes 512 hits per pass; the step sends it more.  Its rl_gen_begin_device answers RL_ERR_BATCH_TOO_LARGE
+    on the HOST, before anything is enqueued — the rank keeps taking part in the step's exchanges, its veto word says "error",
+    and both ranks leave the step together with nothing applied; a step that fits is served right after."""
+    from limitador_amd.sharded import owner_of_tensor
+    from limitador_amd.wire import HIT_DTYPE
+
+    dev = torch.device("cuda", 0)
+    world = 2
+    rows = [(1000, 60)]
+    engines = [Engine(capacity_cells=1 << 14, max_batch_hits=1 << 13), Engine(capacity_cells=1 << 14, max_batch_hits=512)]
+    for e in engines:
+        e.set_limits(rows)
+    seed = engines[0].hash_seed
+    group = sharded_abi.LocalGroup(world)
+    ranks = [sharded_abi.Sharded(engines[r], world, r, 1 << 12, transport=group.transport(r)) for r in range(world)]
+    rng = np.random.default_rng(5)
+    keys = rng.integers(1, 2**62, size=3000, dtype=np.int64)
+    assert int((owner_of_tensor(torch.from_numpy(keys), seed, world).numpy() == 1).sum()) > 600  # more than rank 1 takes
+    h = np.zeros(3000, dtype=HIT_DTYPE)
+    h["key"], h["delta"] = keys, 1
+    off = np.arange(0, 3001, 3, dtype=np.int64)
+    results, errors = {}, []
+
+    def run(r):
+        try:
+            sh = _RequestsOverTheAbi(ranks[r], dev)
+            t = torch.from_numpy((h if r == 0 else h[:0]).view(np.int64).reshape(-1, 2).copy()).to(dev)
+            o = torch.from_numpy(off if r == 0 else off[:1]).to(dev)
+            try:
+                sh.check(t, o, W.NOW0_US)
+                results[r] = "applied"
+            except sharded_abi.ShardedError as ex:
+                results[r] = ex.code
+            small = torch.from_numpy((h[:300] if r == 0 else h[:0]).view(np.int64).reshape(-1, 2).copy()).to(dev)
+            so = torch.from_numpy(off[:101] if r == 0 else off[:1]).to(dev)
+            v, _f, _r, _e = sh.check(small, so, W.NOW0_US + 1)
+            results[(r, "after")] = int(v.sum().item())
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert results[1] == -7 and results[0] < 0, results  # RL_ERR_BATCH_TOO_LARGE where it happened, a refusal on the other rank
+    assert results[(0, "after")] == 0
+    assert sum(e.stats()["live_cells"] for e in engines) == 300  # only the step that fitted was applied
+    for sh in ranks:
+        sh.close()
+    for e in engines:
+        e.close()
+    group.close()
+
+
 def test_a_multi_counter_step_one_shard_cannot_take_is_refused_on_every_rank():
     from test_sharded_multi_gloo import SIMPLE
 
