@@ -436,7 +436,14 @@ struct rl_engine {
     hipEvent_t snap_ev[SERVE_SETS] = {};
     void* resp_snap[SERVE_SETS] = {};
     u64 resp_snap_cap[SERVE_SETS] = {};
-    u32 resp_via_copy = 0;          // RL_RESP_VIA_COPY=1 (experiment): the blind path's bytes go to a device buffer and leave in copy commands; 2: of kind hipMemcpyDeviceToDeviceNoCU
+    // How the blind path's response bytes reach the pinned staging (RL_RESP_VIA_COPY, experiment): 0 (the tree) = k_resp<true> writes
+    // the staging itself; 3 = k_resp writes a device buffer at full width (0.27 ms for 262 144 responses) and a THIN streaming copy
+    // kernel (resp_copy_wgs workgroups: 8 already fill the link) carries each piece over — 50 GB/s against the 28 GB/s of k_resp's
+    // own bursty stores, but one call at a time it is no faster (3.2-3.4 ms either way) and two in flight gain 5 % (2.22-2.28 against
+    // 2.33-2.48 ms per batch, scripts/exp/r15o.sh): not worth a second 128 MB buffer per set; 1 = the runtime's copy commands (blit
+    // kernels), 2 = the same of kind hipMemcpyDeviceToDeviceNoCU.
+    u32 resp_via_copy = 0;
+    u32 resp_copy_wgs = 32;         // RL_RESP_COPY_WGS
     uint8_t* d_resp_set[SERVE_SETS] = {};
     u64 d_resp_set_cap[SERVE_SETS] = {};
     u32 resp_pieces = 8;            // RL_RESP_PIECES
@@ -1949,6 +1956,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_RESULTS_DIRECT")) e->results_direct = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_VIA_COPY")) e->resp_via_copy = (u32)std::max(0, atoi(v));
+    if (const char* v = RL_EXP_ENV("RL_RESP_COPY_WGS")) e->resp_copy_wgs = (u32)std::min(std::max(atoi(v), 1), 2048);
     if (const char* v = RL_EXP_ENV("RL_GEN_PASS_PREFILL")) e->gen_pass_prefill = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_LOAD_DEFERRED")) e->gen_load_deferred = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_CARRY_REQ")) e->gen_carry_req = atoi(v) != 0;
@@ -3498,8 +3506,6 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
         const u32 per = cdiv(n_blocks, pieces);
         u32 nc = 0, b_end[rl_engine::RESP_CHUNKS];
         if (e->resp_via_copy) {
-            // (experiment: do the small device -> host writes of the NEXT call's decide phase get through sooner when this call's
-            // bytes leave in copy commands instead of 128 workgroups' stores?)
             if (bound > e->d_resp_set_cap[set]) {
                 HIP_TRY(e, hipStreamSynchronize(e->resp_stream));
                 if (e->d_resp_set[set]) (void)hipFree(e->d_resp_set[set]);
@@ -3522,7 +3528,7 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
                 const u64 lo = off[std::min<u64>((u64)b0 * 256u, n)], hi = off[std::min<u64>((u64)(b0 + nb) * 256u, n)];
                 if (hi > lo && e->resp_via_copy == 3) {  // (whole 16-byte words: the bytes around the piece are its neighbours', the same in both buffers)
                     const u64 a = lo & ~15ull, b = (hi + 15ull) & ~15ull;
-                    k_copy_stream<<<e->resp_writers, 256, 0, e->resp_stream>>>(reinterpret_cast<const uint4*>(e->d_resp_set[set] + a),
+                    k_copy_stream<<<e->resp_copy_wgs, 256, 0, e->resp_stream>>>(reinterpret_cast<const uint4*>(e->d_resp_set[set] + a),
                                                                               reinterpret_cast<uint4*>(static_cast<uint8_t*>(h_bytes) + a), (b - a) >> 4);
                 } else if (hi > lo)
                     HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t*>(h_bytes) + lo, e->d_resp_set[set] + lo, hi - lo,
