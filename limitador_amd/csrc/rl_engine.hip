@@ -3996,7 +3996,13 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
         else
             (void)hipGetLastError();
     }
+    const bool wm_trace = RL_EXP_ENV("RL_WIRE_TRACE") != nullptr;
+    const auto wm_t0 = std::chrono::steady_clock::now();
+    auto wm_lap = [&](const char* what) {
+        if (wm_trace) std::fprintf(stderr, "[wm] set %u %-12s +%8.1f us\n", so ? so->set : 0u, what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - wm_t0).count());
+    };
     EngineLock g(e);
+    wm_lap("locked");
     if (engine_busy(e)) return fail(e, RL_ERR_BUSY, "batches are in flight (rl_check_and_update_collect) or a phased pass is open (rl_gen_commit_device / rl_gen_abort)");
     if (!e->wire_ready) return fail(e, RL_ERR_INVALID, "rl_wire_table_set was not called for the installed match table");
     if (msg_off[0] != 0 || (bytes && !wire)) return fail(e, RL_ERR_INVALID, "msg_off[0] must be 0 and wire non-null");
@@ -4041,7 +4047,9 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
     k_wire_fill<<<gq, 256, 0, e->stream>>>(e->d_m_ns, e->d_m_delta, n, T, e->d_w_prefix, e->wire_t.hkey, e->d_m_mask, e->d_w_slot_h, e->d_m_scan1,
                                            e->d_req_off, e->d_hits, e->d_hit_check, e->d_hit_req, e->max_batch);
     HIP_TRY(e, hipGetLastError());
+    wm_lap("enqueued");
     int rc = wait_word(e, e->h_m_word + 3, call, "the wire path's count pass");
+    wm_lap("counted");
     if (rc) return rc;
     const u32 n_hits = e->h_m_word[0], m_err = e->h_m_word[1];
     if (n_hits_out) *n_hits_out = n_hits;
@@ -4060,6 +4068,7 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
         (void)hipMemcpy(status, e->d_w_status, (size_t)n * 4, hipMemcpyDeviceToHost);
     }
     if (rc) return rc;
+    wm_lap("decided");
     ResultsOut R(e);
     R.add(verdict, e->d_verdict, n);
     R.add(status, e->d_w_status, (u64)n * 4);
@@ -4067,6 +4076,7 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
         rc = R.go();
         if (rc) return rc;
         rc = responses_locked(e, n, n_hits, e->d_w_status, e->d_verdict, *so);  // (synchronises behind the verdicts' / statuses' copies)
+        wm_lap("responses");
         if (rc) return rc;
         if (!e->resp_n_chunks[so->set < rl_engine::SERVE_SETS ? so->set : 0u]) HIP_TRY(e, hipStreamSynchronize(e->stream));
         return RL_OK;

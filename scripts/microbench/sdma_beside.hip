@@ -1,11 +1,13 @@
 // Does a device -> host copy slow the kernels of another stream — as the runtime's hipMemcpyAsync (a blit kernel), and as an SDMA copy
 // issued through HSA directly (hsa_amd_memory_async_copy)?  A chain of 40 small HBM-bound kernels (each ~15 us) on one stream, timed
 // alone, beside a loop of 40 MB hipMemcpyAsync D2H on another stream, and beside the same bytes through HSA.
+// usage: sdma_beside [counters (default 8 M: ~240 us per kernel; 262144: ~6 us, the decide phase's kind)] [kernels per chain] [sync every]
 // build: hipcc -O2 --offload-arch=gfx950 sdma_beside.hip -o bin/sdma_beside -lhsa-runtime64
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -20,6 +22,12 @@
             return 1;                                                     \
         }                                                                 \
     } while (0)
+
+__global__ void k_copy(const uint4* s, uint4* d, size_t n16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) d[i] = s[i];
+}
 
 __global__ void k_touch(unsigned* p, size_t n, unsigned mul) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,9 +44,11 @@ static hsa_status_t pick(hsa_agent_t a, void*) {
     return HSA_STATUS_SUCCESS;
 }
 
-int main() {
+int main(int argc, char** argv) {
     CK(hipSetDevice(0));
-    const size_t n = 8u << 20;  // 32 MB of counters
+    const size_t n = argc > 1 ? (size_t)atol(argv[1]) : (8u << 20);  // 32 MB of counters
+    const int n_k = argc > 2 ? atoi(argv[2]) : 40, sync_every = argc > 3 ? atoi(argv[3]) : 8;
+    const unsigned grid = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
     unsigned* d = nullptr;
     CK(hipMalloc(&d, n * 4));
     CK(hipMemset(d, 0, n * 4));
@@ -55,9 +65,9 @@ int main() {
     hsa_signal_create(1, 0, nullptr, &sig);
     auto chain = [&]() -> double {  // ms for 40 kernels, each waited for by the host like a decide phase's round trips (every 8th)
         const auto t0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < 40; ++k) {
-            k_touch<<<1024, 256, 0, sk>>>(d, n, (unsigned)k);
-            if ((k & 7) == 7) (void)hipStreamSynchronize(sk);
+        for (int k = 0; k < n_k; ++k) {
+            k_touch<<<grid, 256, 0, sk>>>(d, n, (unsigned)k);
+            if (k % sync_every == sync_every - 1) (void)hipStreamSynchronize(sk);
         }
         (void)hipStreamSynchronize(sk);
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -65,8 +75,8 @@ int main() {
     for (int w = 0; w < 3; ++w) chain();
     double alone = 1e9;
     for (int r = 0; r < 10; ++r) alone = std::min(alone, chain());
-    printf("40 kernels alone:                    %.3f ms\n", alone);
-    for (int mode = 0; mode < 2; ++mode) {
+    printf("%d kernels over %zu counters, a synchronise every %d, alone: %.3f ms\n", n_k, n, sync_every, alone);
+    for (int mode = 0; mode < 3; ++mode) {
         std::atomic<bool> stop{false};
         std::atomic<int> copies{0};
         std::thread pump([&] {
@@ -74,6 +84,9 @@ int main() {
             while (!stop.load()) {
                 if (mode == 0) {
                     (void)hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, sc);
+                    (void)hipStreamSynchronize(sc);
+                } else if (mode == 2) {
+                    k_copy<<<32, 256, 0, sc>>>(static_cast<const uint4*>(d_src), static_cast<uint4*>(h_dst), bytes / 16);
                     (void)hipStreamSynchronize(sc);
                 } else {
                     hsa_signal_store_relaxed(sig, 1);
@@ -101,7 +114,7 @@ int main() {
         stop.store(true);
         pump.join();
         printf("beside %s: best %.3f ms, mean %.3f ms; %d copies of 40 MB in %.1f ms = %.1f GB/s\n",
-               mode == 0 ? "hipMemcpyAsync D2H (blit kernel) " : "hsa_amd_memory_async_copy (SDMA)", best, sum / 20, nc, el, nc * 41.943 / el);
+               mode == 0 ? "hipMemcpyAsync D2H (blit kernel) " : mode == 1 ? "hsa_amd_memory_async_copy (SDMA)" : "a 32-workgroup kernel storing to host", best, sum / 20, nc, el, nc * 41.943 / el);
     }
     return 0;
 }
