@@ -1176,7 +1176,7 @@ static int32_t serve_batch_op(rli_ingest* g, rl_engine* e, int32_t op, const uin
             const auto t = std::chrono::steady_clock::now();
             std::fprintf(stderr, "[rli] %-10s at %8.1f us  (clock %12.1f us, thread %04x)\n", what,
                          std::chrono::duration<double, std::micro>(t - t_begin).count(),
-                         std::chrono::duration<double, std::micro>(t.time_since_epoch()).count() - 1e6 * std::floor(std::chrono::duration<double>(t.time_since_epoch()).count() / 100.0) * 100.0,
+                         std::chrono::duration<double, std::micro>(t.time_since_epoch()).count() - 1e8 * std::floor(std::chrono::duration<double, std::micro>(t.time_since_epoch()).count() / 1e8),
                          (unsigned)(std::hash<std::thread::id>{}(std::this_thread::get_id()) & 0xFFFFu));
         }
     };

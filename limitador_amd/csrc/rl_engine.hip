@@ -3999,7 +3999,12 @@ static int32_t wire_match_host(rl_engine* e, int op, const uint8_t* wire, const 
     const bool wm_trace = RL_EXP_ENV("RL_WIRE_TRACE") != nullptr;
     const auto wm_t0 = std::chrono::steady_clock::now();
     auto wm_lap = [&](const char* what) {
-        if (wm_trace) std::fprintf(stderr, "[wm] set %u %-12s +%8.1f us\n", so ? so->set : 0u, what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - wm_t0).count());
+        if (wm_trace) {
+            const auto t = std::chrono::steady_clock::now();
+            const double abs_us = std::chrono::duration<double, std::micro>(t.time_since_epoch()).count();
+            std::fprintf(stderr, "[wm] set %u %-12s +%8.1f us  (clock %12.1f us)\n", so ? so->set : 0u, what,
+                         std::chrono::duration<double, std::micro>(t - wm_t0).count(), abs_us - 1e8 * (double)(long long)(abs_us / 1e8));
+        }
     };
     EngineLock g(e);
     wm_lap("locked");

@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
     double alone = 1e9;
     for (int r = 0; r < 10; ++r) alone = std::min(alone, chain());
     printf("%d kernels over %zu counters, a synchronise every %d, alone: %.3f ms\n", n_k, n, sync_every, alone);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         std::atomic<bool> stop{false};
         std::atomic<int> copies{0};
         std::thread pump([&] {
@@ -87,6 +87,12 @@ int main(int argc, char** argv) {
                     (void)hipStreamSynchronize(sc);
                 } else if (mode == 2) {
                     k_copy<<<32, 256, 0, sc>>>(static_cast<const uint4*>(d_src), static_cast<uint4*>(h_dst), bytes / 16);
+                    (void)hipStreamSynchronize(sc);
+                } else if (mode == 3) {  // the other direction as a kernel: loads from host memory, stores to the device
+                    k_copy<<<32, 256, 0, sc>>>(static_cast<const uint4*>(h_dst), static_cast<uint4*>(d_src), bytes / 16);
+                    (void)hipStreamSynchronize(sc);
+                } else if (mode == 4) {  // ... and as a copy command
+                    (void)hipMemcpyAsync(d_src, h_dst, bytes, hipMemcpyHostToDevice, sc);
                     (void)hipStreamSynchronize(sc);
                 } else {
                     hsa_signal_store_relaxed(sig, 1);
@@ -114,7 +120,7 @@ int main(int argc, char** argv) {
         stop.store(true);
         pump.join();
         printf("beside %s: best %.3f ms, mean %.3f ms; %d copies of 40 MB in %.1f ms = %.1f GB/s\n",
-               mode == 0 ? "hipMemcpyAsync D2H (blit kernel) " : mode == 1 ? "hsa_amd_memory_async_copy (SDMA)" : "a 32-workgroup kernel storing to host", best, sum / 20, nc, el, nc * 41.943 / el);
+               mode == 0 ? "hipMemcpyAsync device -> host        " : mode == 1 ? "hsa_amd_memory_async_copy (SDMA)" : mode == 2 ? "a 32-workgroup kernel storing to host" : mode == 3 ? "a 32-workgroup kernel loading from host" : "hipMemcpyAsync host -> device", best, sum / 20, nc, el, nc * 41.943 / el);
     }
     return 0;
 }
