@@ -458,12 +458,13 @@ int32_t rl_serve_wait(rl_engine *e, uint64_t upto);
  * offsets and bytes, the events of its pieces, the device copy of its messages — exists RL_SERVE_SETS times, by `set`, and the
  * bytes' kernels run on a stream of their own from a snapshot of what they read; so while the host still waits for and hands
  * on the responses of the call on set s (rl_serve_wait_set(e, s, upto)), other threads may pack, copy in and decide the next
- * batches with the other sets.  Two sets: more of them were built and measured (4: no faster — what bounds the pair is the
- * device, where a call's decide phase and the previous call's response transfer do not overlap).  The
+ * batches with the other sets.  Four sets: a call's own latency (pack, copy-in, decide, the responses' way over PCIe, the
+ * hand-over) is ≈ 4.5 ms for 262 144 messages of which the engine is held ≈ 1–2 ms.  While another set's bytes are still on
+ * their way, a call's own bytes leave as copy commands issued one piece at a time by rl_serve_wait_set.  The
  * engine's mutex serialises the calls themselves (decisions are applied in the order the
  * calls enter); a set must not be used again before every byte of its previous call has been waited for.
  * rl_wire_serve_batch = set 0. */
-#define RL_SERVE_SETS 2
+#define RL_SERVE_SETS 4
 int32_t rl_wire_serve_batch_set(rl_engine *e, uint32_t set, const uint8_t *wire, const uint32_t *msg_off, uint32_t n,
                                 uint64_t now_us, uint32_t flags, uint8_t *verdict, int32_t *status,
                                 const uint32_t **resp_off, const uint8_t **resp, int64_t *collided_message);

@@ -436,13 +436,28 @@ struct rl_engine {
     hipEvent_t snap_ev[SERVE_SETS] = {};
     void* resp_snap[SERVE_SETS] = {};
     u64 resp_snap_cap[SERVE_SETS] = {};
-    // How the blind path's response bytes reach the pinned staging (RL_RESP_VIA_COPY, experiment): 0 (the tree) = k_resp<true> writes
-    // the staging itself; 3 = k_resp writes a device buffer at full width (0.27 ms for 262 144 responses) and a THIN streaming copy
-    // kernel (resp_copy_wgs workgroups: 8 already fill the link) carries each piece over — 50 GB/s against the 28 GB/s of k_resp's
-    // own bursty stores, but one call at a time it is no faster (3.2-3.4 ms either way) and two in flight gain 5 % (2.22-2.28 against
-    // 2.33-2.48 ms per batch, scripts/exp/r15o.sh): not worth a second 128 MB buffer per set; 1 = the runtime's copy commands (blit
-    // kernels), 2 = the same of kind hipMemcpyDeviceToDeviceNoCU.
-    u32 resp_via_copy = 0;
+    // How the blind path's response bytes reach the pinned staging.  The tree decides per call (resp_via_copy = AUTO):
+    //   one caller at a time: k_resp<true> writes the staging itself (0) — the shortest single call;
+    //   callers in flight together (another set served a call within the last 20 ms): k_resp writes a device buffer and the pieces leave as copy commands issued LAZILY by
+    //   whoever waits for them, one in flight per set (4) — a kernel that streams stores to the host stretches every short kernel of
+    //   the next call's decide phase, and copy commands issued all at once make each of that phase's host round trips wait behind
+    //   the whole transfer (profiles/r06_wire_two_in_flight.md): four calls in flight 1.7-2.1 ms per batch against 2.3-2.4.
+    // RL_RESP_VIA_COPY (experiment) forces one form: 0, 4, or 1 = copy commands at once, 2 = of kind hipMemcpyDeviceToDeviceNoCU,
+    // 3 = a thin streaming copy kernel (resp_copy_wgs workgroups: 8 already fill the link).
+    static constexpr u32 RESP_AUTO = 0xFFu;
+    u32 resp_via_copy = RESP_AUTO;
+    u64 serve_last_us[SERVE_SETS] = {};  // when the set last served a call through the blind path (steady clock)
+    // RL_RESP_VIA_COPY=4: the copy commands of a set's pieces are issued LAZILY, by whoever waits for them (rl_serve_wait_set), one
+    // piece in flight per set: what the next call's host round trips wait behind is then one piece, not the whole transfer
+    struct LazyCopy {
+        std::mutex mu;
+        u32 n = 0;
+        std::atomic<u32> issued{0};
+        u64 lo[RESP_CHUNKS] = {}, hi[RESP_CHUNKS] = {};
+        uint8_t* dst = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t built = nullptr;  // k_resp has written the set's device buffer
+    } lazy[SERVE_SETS];
     u32 resp_copy_wgs = 32;         // RL_RESP_COPY_WGS
     uint8_t* d_resp_set[SERVE_SETS] = {};
     u64 d_resp_set_cap[SERVE_SETS] = {};
@@ -2231,6 +2246,11 @@ void rl_engine_destroy(rl_engine* e) {
         if (e->snap_ev[q]) (void)hipEventDestroy(e->snap_ev[q]);
         if (e->resp_snap[q]) (void)hipFree(e->resp_snap[q]);
         if (e->d_resp_set[q]) (void)hipFree(e->d_resp_set[q]);
+        if (e->lazy[q].stream) {
+            (void)hipStreamSynchronize(e->lazy[q].stream);
+            (void)hipStreamDestroy(e->lazy[q].stream);
+        }
+        if (e->lazy[q].built) (void)hipEventDestroy(e->lazy[q].built);
     }
     for (auto& evs : e->resp_ev)
       for (hipEvent_t ev : evs)
@@ -3437,6 +3457,7 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
     int32_t rc = host_staging_locked(e, slot_off, ((u64)n + 1) * sizeof(u32), &h_off);
     if (rc) return rc;
     e->resp_n_chunks[set] = 0;
+    e->lazy[set].n = 0;  // (a set is only reused once its last byte has been waited for: nobody is inside its LazyCopy)
     const u32 n_blocks = cdiv(n, 256);
     // What the responses can take at most: 2 bytes of overall_code; with headers 157 more of tags, lengths, keys and three
     // numbers of up to 20 digits, + per derived counter its limit's fragment (rl_resp.hpp).  When the pinned staging holds
@@ -3505,7 +3526,16 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
         const u32 pieces = std::min<u32>(e->resp_pieces, std::max<u32>(1u, (u32)(bound >> 22)));  // (the bound is ~2 x the bytes)
         const u32 per = cdiv(n_blocks, pieces);
         u32 nc = 0, b_end[rl_engine::RESP_CHUNKS];
-        if (e->resp_via_copy) {
+        u32 resp_mode = e->resp_via_copy;
+        const u64 t_serve = (u64)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (resp_mode == rl_engine::RESP_AUTO) {
+            // another set served a call within the last 20 ms: callers are in flight together (one caller alone is always given set 0)
+            resp_mode = 0;
+            for (u32 q = 0; q < rl_engine::SERVE_SETS; ++q)
+                if (q != set && e->serve_last_us[q] && t_serve - e->serve_last_us[q] < 20000u) resp_mode = 4;
+        }
+        e->serve_last_us[set] = t_serve;
+        if (resp_mode) {
             if (bound > e->d_resp_set_cap[set]) {
                 HIP_TRY(e, hipStreamSynchronize(e->resp_stream));
                 if (e->d_resp_set[set]) (void)hipFree(e->d_resp_set[set]);
@@ -3523,16 +3553,38 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
             const u32* off = static_cast<const u32*>(h_off);
             if (off[n] > e->h_stage_cap[slot_bytes])
                 return fail(e, RL_ERR_INTERNAL, "the responses take %u bytes, the bound said %llu (the batch was applied)", off[n], (unsigned long long)bound);
+            if (resp_mode == 4) {
+                rl_engine::LazyCopy& L = e->lazy[set];
+                std::lock_guard<std::mutex> lg(L.mu);
+                if (!L.stream) HIP_TRY(e, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+                if (!L.built) HIP_TRY(e, hipEventCreateWithFlags(&L.built, hipEventDisableTiming));
+                HIP_TRY(e, hipEventRecord(L.built, e->resp_stream));
+                HIP_TRY(e, hipStreamWaitEvent(L.stream, L.built, 0));
+                for (u32 b0 = 0; b0 < n_blocks; b0 += per, ++nc) {
+                    const u32 nb = std::min(per, n_blocks - b0);
+                    L.lo[nc] = off[std::min<u64>((u64)b0 * 256u, n)];
+                    L.hi[nc] = off[std::min<u64>((u64)(b0 + nb) * 256u, n)];
+                    if (!e->resp_ev[set][nc]) HIP_TRY(e, hipEventCreateWithFlags(&e->resp_ev[set][nc], hipEventDisableTiming));
+                    e->resp_chunk_end[set][nc] = L.hi[nc];
+                }
+                L.n = nc;
+                L.issued.store(0, std::memory_order_release);
+                L.dst = static_cast<uint8_t*>(h_bytes);
+                e->resp_n_chunks[set] = nc;
+                *so.resp_off = off;
+                *so.resp = static_cast<const uint8_t*>(h_bytes);
+                return RL_OK;
+            }
             for (u32 b0 = 0; b0 < n_blocks; b0 += per, ++nc) {
                 const u32 nb = std::min(per, n_blocks - b0);
                 const u64 lo = off[std::min<u64>((u64)b0 * 256u, n)], hi = off[std::min<u64>((u64)(b0 + nb) * 256u, n)];
-                if (hi > lo && e->resp_via_copy == 3) {  // (whole 16-byte words: the bytes around the piece are its neighbours', the same in both buffers)
+                if (hi > lo && resp_mode == 3) {  // (whole 16-byte words: the bytes around the piece are its neighbours', the same in both buffers)
                     const u64 a = lo & ~15ull, b = (hi + 15ull) & ~15ull;
                     k_copy_stream<<<e->resp_copy_wgs, 256, 0, e->resp_stream>>>(reinterpret_cast<const uint4*>(e->d_resp_set[set] + a),
                                                                               reinterpret_cast<uint4*>(static_cast<uint8_t*>(h_bytes) + a), (b - a) >> 4);
                 } else if (hi > lo)
                     HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t*>(h_bytes) + lo, e->d_resp_set[set] + lo, hi - lo,
-                                              e->resp_via_copy == 2 ? hipMemcpyDeviceToDeviceNoCU : hipMemcpyDeviceToHost, e->resp_stream));
+                                              resp_mode == 2 ? hipMemcpyDeviceToDeviceNoCU : hipMemcpyDeviceToHost, e->resp_stream));
                 if (!e->resp_ev[set][nc]) HIP_TRY(e, hipEventCreateWithFlags(&e->resp_ev[set][nc], hipEventDisableTiming));
                 HIP_TRY(e, hipEventRecord(e->resp_ev[set][nc], e->resp_stream));
                 e->resp_chunk_end[set][nc] = (u32)hi;
@@ -4163,6 +4215,21 @@ int32_t rl_serve_wait_set(rl_engine* e, uint32_t set, uint64_t upto) try {
     // (a piece's event says the pieces before it are complete too: one stream, in order)
     u32 c = 0;
     while (c + 1 < e->resp_n_chunks[set] && e->resp_chunk_end[set][c] < upto) ++c;
+    rl_engine::LazyCopy& L = e->lazy[set];
+    if (L.n && L.issued.load(std::memory_order_acquire) <= c) {
+        // (lazily issued pieces: whoever needs piece c first issues the pieces up to it, each behind the one before; a piece that
+        // has been issued is waited for without the lock)
+        std::lock_guard<std::mutex> lg(L.mu);
+        while (L.issued.load(std::memory_order_relaxed) <= c && L.issued.load(std::memory_order_relaxed) < L.n) {
+            const u32 k = L.issued.load(std::memory_order_relaxed);
+            if (k > 0 && hipEventSynchronize(e->resp_ev[set][k - 1]) != hipSuccess) return RL_ERR_DEVICE;  // one piece in flight
+            if (L.hi[k] > L.lo[k] &&
+                hipMemcpyAsync(L.dst + L.lo[k], e->d_resp_set[set] + L.lo[k], L.hi[k] - L.lo[k], hipMemcpyDeviceToHost, L.stream) != hipSuccess)
+                return RL_ERR_DEVICE;
+            if (hipEventRecord(e->resp_ev[set][k], L.stream) != hipSuccess) return RL_ERR_DEVICE;
+            L.issued.store(k + 1, std::memory_order_release);
+        }
+    }
     return hipEventSynchronize(e->resp_ev[set][c]) == hipSuccess ? (int32_t)RL_OK : (int32_t)RL_ERR_DEVICE;
 } RL_ABI_CATCH
 

@@ -5,9 +5,9 @@
 set -u
 out=$PWD/gpurun_out/r15q; rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp LIMITADOR_AMD_LIB=exp
-sed -i 's/#define RL_SERVE_SETS 2/#define RL_SERVE_SETS 4/' include/rl_engine.h
+true
 python -c "from limitador_amd import build; build.build_engine(force=True); build.build_storage(force=True)" > "$out/build.log" 2>&1 || { tail -5 "$out/build.log"; exit 1; }
-for v in ${VIAS:-1 0}; do
+for v in ${VIAS:-1 0}; do export RL_RESP_PIECES=${PIECES:-8}
   RL_RESP_VIA_COPY=$v RL_WIRE_TRACE=1 RLI_TRACE=1 timeout 300 python scripts/bench_rls.py hashed 262144 > "$out/rls_$v.json" 2> "$out/laps_$v.txt"
   python - "$out/rls_$v.json" "4 sets via_copy=$v" <<'PY'
 import json,sys
