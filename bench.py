@@ -543,7 +543,11 @@ def secondary(args, eng, dev, gen):
                                 **({"with_headers_two_in_flight_ms_per_batch": v["with_headers_two_in_flight"]["ms_per_batch_sustained"],
                                     "with_headers_two_in_flight_requests_per_s": v["with_headers_two_in_flight"]["requests_per_s"],
                                     "with_headers_two_in_flight_call_p50_ms": v["with_headers_two_in_flight"]["call_p50_ms"]}
-                                   if "with_headers_two_in_flight" in v else {}))
+                                   if "with_headers_two_in_flight" in v else {}),
+                                **({"with_headers_four_in_flight_ms_per_batch": v["with_headers_four_in_flight"]["ms_per_batch_sustained"],
+                                    "with_headers_four_in_flight_requests_per_s": v["with_headers_four_in_flight"]["requests_per_s"],
+                                    "with_headers_four_in_flight_call_p50_ms": v["with_headers_four_in_flight"]["call_p50_ms"]}
+                                   if "with_headers_four_in_flight" in v else {}))
                         for n, v in m["sizes"].items() if n in ("256", "32768", "262144")}
         out["wire_path_rli_serve_batch"] = dict(wp, note="p50 of the C call per batch of N serialized messages (4 namespaces x 8 limits, "
                                                 "Zipf users); exact = host dictionaries + packed ids, hashed = RLI_KEYS_HASHED "
@@ -551,8 +555,9 @@ def secondary(args, eng, dev, gen):
                                                 "headers the response bytes are built on the device from 4096 messages on "
                                                 "(rl_resp.hpp); kuadrant_check / kuadrant_report = rli_serve_batch_op, the Kuadrant "
                                                 "service's CheckRateLimit (is_rate_limited, read-only) and Report (update_counters); "
-                                                "with_headers_two_in_flight_* = two threads calling rli_serve_batch back to back on the "
-                                                "same ingest / engine, each on one of the two serving sets (profiles/r06_wire_two_in_flight.md)")
+                                                "with_headers_two / four_in_flight_* = two / four threads calling rli_serve_batch back to back on "
+                                                "the same ingest / engine, each call on one of the engine's four serving sets "
+                                                "(profiles/r06_wire_two_in_flight.md)")
     except Exception as ex:
         out["wire_path_rli_serve_batch"] = {"error": str(ex)[:200]}
     # -- the streaming maintenance kernels over the headline's table (LAST: they change it): a sweep that finds nothing

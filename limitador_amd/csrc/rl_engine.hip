@@ -446,6 +446,7 @@ struct rl_engine {
     // 3 = a thin streaming copy kernel (resp_copy_wgs workgroups: 8 already fill the link).
     static constexpr u32 RESP_AUTO = 0xFFu;
     u32 resp_via_copy = RESP_AUTO;
+    u32 resp_lazy_depth = 1;        // RL_RESP_LAZY_DEPTH: pieces of a set in flight at once in form 4
     u64 serve_last_us[SERVE_SETS] = {};  // when the set last served a call through the blind path (steady clock)
     // RL_RESP_VIA_COPY=4: the copy commands of a set's pieces are issued LAZILY, by whoever waits for them (rl_serve_wait_set), one
     // piece in flight per set: what the next call's host round trips wait behind is then one piece, not the whole transfer
@@ -1971,6 +1972,7 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_RESULTS_DIRECT")) e->results_direct = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_VIA_COPY")) e->resp_via_copy = (u32)std::max(0, atoi(v));
+    if (const char* v = RL_EXP_ENV("RL_RESP_LAZY_DEPTH")) e->resp_lazy_depth = (u32)std::min(std::max(atoi(v), 1), 32);
     if (const char* v = RL_EXP_ENV("RL_RESP_COPY_WGS")) e->resp_copy_wgs = (u32)std::min(std::max(atoi(v), 1), 2048);
     if (const char* v = RL_EXP_ENV("RL_GEN_PASS_PREFILL")) e->gen_pass_prefill = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_LOAD_DEFERRED")) e->gen_load_deferred = atoi(v) != 0;
@@ -4222,7 +4224,7 @@ int32_t rl_serve_wait_set(rl_engine* e, uint32_t set, uint64_t upto) try {
         std::lock_guard<std::mutex> lg(L.mu);
         while (L.issued.load(std::memory_order_relaxed) <= c && L.issued.load(std::memory_order_relaxed) < L.n) {
             const u32 k = L.issued.load(std::memory_order_relaxed);
-            if (k > 0 && hipEventSynchronize(e->resp_ev[set][k - 1]) != hipSuccess) return RL_ERR_DEVICE;  // one piece in flight
+            if (k >= e->resp_lazy_depth && hipEventSynchronize(e->resp_ev[set][k - e->resp_lazy_depth]) != hipSuccess) return RL_ERR_DEVICE;  // resp_lazy_depth pieces in flight
             if (L.hi[k] > L.lo[k] &&
                 hipMemcpyAsync(L.dst + L.lo[k], e->d_resp_set[set] + L.lo[k], L.hi[k] - L.lo[k], hipMemcpyDeviceToHost, L.stream) != hipSuccess)
                 return RL_ERR_DEVICE;
