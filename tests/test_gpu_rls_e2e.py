@@ -714,6 +714,69 @@ def test_two_serving_calls_in_flight_answer_like_one_at_a_time(make_engine, monk
     assert not failures, failures[:3]
 
 
+def test_four_callers_in_flight_at_size_answer_like_each_alone(make_engine):
+    """The form the wire path takes when callers are in flight together (four serving sets; the response bytes through a device
+    buffer and copy commands issued lazily by the hand-over threads, piece by piece) at a size where a call really has several
+    pieces: four threads, one namespace each, three batches of 131 072 messages with headers on ONE ingest / engine — and the same
+    batches served one at a time, each thread's on an engine of its own.  Statuses, lengths and every response byte must be equal."""
+    import ctypes as C
+
+    n, batches, n_threads = 131072, 3, 4  # (a call of 131 072 messages leaves in five to eight pieces)
+    methods, paths = ["GET", "POST", "PUT"], ["/", "/admin", "/json"]
+
+    def messages(t, b):
+        rng = np.random.default_rng(1000 * t + b)
+        out = []
+        for _ in range(n):
+            ctx = [("method", methods[int(rng.integers(0, 3))]), ("path", paths[int(rng.integers(0, 3))]),
+                   ("user", f"user{int(rng.zipf(1.3)) % 5000}"), ("app", f"app{int(rng.integers(0, 3))}")]
+            out.append(rls_request(f"ns{t}", [ctx]))
+        return out
+
+    def fresh():
+        return _install(make_engine, "hashed", capacity_cells=1 << 21, max_batch_hits=1 << 20)[:2]
+
+    def results(prep):
+        lens = np.frombuffer(prep["out_len"], dtype=np.uint32).copy()
+        raw = np.frombuffer(prep["out"], dtype=np.uint8).reshape(n, prep["stride"])
+        return (np.frombuffer(prep["status"], dtype=np.int32).copy(), lens,
+                [raw[i, :lens[i]].tobytes() for i in range(0, n, 97)] + [raw[n - 1, :lens[n - 1]].tobytes()],
+                int(np.bitwise_xor.reduce(np.where(np.arange(prep["stride"])[None, :] < lens[:, None], raw, 0).astype(np.uint64).sum(axis=1) * np.arange(1, n + 1, dtype=np.uint64))))
+
+    eng, g = fresh()
+    preps = [[g.prepare_batch(messages(t, b), stride=512) for b in range(batches)] for t in range(n_threads)]
+    got = [[None] * batches for _ in range(n_threads)]
+    failures = []
+    start = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            start.wait()
+            for b in range(batches):
+                g.serve_prepared(eng, preps[t][b], NOW, with_headers=True)
+                got[t][b] = results(preps[t][b])
+        except Exception as ex:  # noqa: BLE001
+            failures.append((t, repr(ex)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not failures, failures
+    for t in range(n_threads):
+        eng1, g1 = fresh()
+        for b in range(batches):
+            p = g1.prepare_batch(preps[t][b]["keep"], stride=512)
+            g1.serve_prepared(eng1, p, NOW, with_headers=True)
+            want = results(p)
+            assert np.array_equal(got[t][b][0], want[0]), f"thread {t} batch {b}: statuses"
+            assert np.array_equal(got[t][b][1], want[1]), f"thread {t} batch {b}: lengths"
+            assert got[t][b][2] == want[2], f"thread {t} batch {b}: sampled response bytes"
+            assert got[t][b][3] == want[3], f"thread {t} batch {b}: checksum over all response bytes"
+        assert int((got[t][-1][0] == 1).sum()) > 100  # (a real allow / deny mix by the last batch)
+        g1.close()
+        eng1.close()
+
+
 def test_a_table_is_not_served_under_another_hash_key(make_engine, tmp_path):
     """the hash key names the cells.  An engine that holds hashed counters — filled directly, or reloaded from a
     snapshot (the file's header carries the key's fingerprint, never the key) — refuses the tables of an ingest with another
