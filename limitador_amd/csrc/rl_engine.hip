@@ -442,8 +442,9 @@ struct rl_engine {
     //   whoever waits for them, one in flight per set (4) — a kernel that streams stores to the host stretches every short kernel of
     //   the next call's decide phase, and copy commands issued all at once make each of that phase's host round trips wait behind
     //   the whole transfer (profiles/r06_wire_two_in_flight.md): four calls in flight 1.7-2.1 ms per batch against 2.3-2.4.
-    // RL_RESP_VIA_COPY (experiment) forces one form: 0, 4, or 1 = copy commands at once, 2 = of kind hipMemcpyDeviceToDeviceNoCU,
-    // 3 = a thin streaming copy kernel (resp_copy_wgs workgroups: 8 already fill the link).
+    // RL_RESP_VIA_COPY (experiment) forces one form: 0, 4, or 1 = copy commands issued at once.  (Measured and parked,
+    // scripts/exp/patches/resp_thin_copy_nocu.patch: copies of kind hipMemcpyDeviceToDeviceNoCU, a thin streaming copy kernel, the
+    // staging's coherence flags.)
     static constexpr u32 RESP_AUTO = 0xFFu;
     u32 resp_via_copy = RESP_AUTO;
     u32 resp_lazy_depth = 1;        // RL_RESP_LAZY_DEPTH: pieces of a set in flight at once in form 4
@@ -459,7 +460,6 @@ struct rl_engine {
         hipStream_t stream = nullptr;
         hipEvent_t built = nullptr;  // k_resp has written the set's device buffer
     } lazy[SERVE_SETS];
-    u32 resp_copy_wgs = 32;         // RL_RESP_COPY_WGS
     uint8_t* d_resp_set[SERVE_SETS] = {};
     u64 d_resp_set_cap[SERVE_SETS] = {};
     u32 resp_pieces = 8;            // RL_RESP_PIECES
@@ -1973,7 +1973,6 @@ int32_t rl_engine_create(const rl_config* cfg, rl_engine** out) try {
     if (const char* v = RL_EXP_ENV("RL_RESP_BLIND")) e->resp_blind = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_RESP_VIA_COPY")) e->resp_via_copy = (u32)std::max(0, atoi(v));
     if (const char* v = RL_EXP_ENV("RL_RESP_LAZY_DEPTH")) e->resp_lazy_depth = (u32)std::min(std::max(atoi(v), 1), 32);
-    if (const char* v = RL_EXP_ENV("RL_RESP_COPY_WGS")) e->resp_copy_wgs = (u32)std::min(std::max(atoi(v), 1), 2048);
     if (const char* v = RL_EXP_ENV("RL_GEN_PASS_PREFILL")) e->gen_pass_prefill = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_LOAD_DEFERRED")) e->gen_load_deferred = atoi(v) != 0;
     if (const char* v = RL_EXP_ENV("RL_GEN_CARRY_REQ")) e->gen_carry_req = atoi(v) != 0;
@@ -3580,13 +3579,8 @@ static int32_t responses_locked(rl_engine* e, u32 n, u32 n_hits, const int32_t* 
             for (u32 b0 = 0; b0 < n_blocks; b0 += per, ++nc) {
                 const u32 nb = std::min(per, n_blocks - b0);
                 const u64 lo = off[std::min<u64>((u64)b0 * 256u, n)], hi = off[std::min<u64>((u64)(b0 + nb) * 256u, n)];
-                if (hi > lo && resp_mode == 3) {  // (whole 16-byte words: the bytes around the piece are its neighbours', the same in both buffers)
-                    const u64 a = lo & ~15ull, b = (hi + 15ull) & ~15ull;
-                    k_copy_stream<<<e->resp_copy_wgs, 256, 0, e->resp_stream>>>(reinterpret_cast<const uint4*>(e->d_resp_set[set] + a),
-                                                                              reinterpret_cast<uint4*>(static_cast<uint8_t*>(h_bytes) + a), (b - a) >> 4);
-                } else if (hi > lo)
-                    HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t*>(h_bytes) + lo, e->d_resp_set[set] + lo, hi - lo,
-                                              resp_mode == 2 ? hipMemcpyDeviceToDeviceNoCU : hipMemcpyDeviceToHost, e->resp_stream));
+                if (hi > lo)
+                    HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t*>(h_bytes) + lo, e->d_resp_set[set] + lo, hi - lo, hipMemcpyDeviceToHost, e->resp_stream));
                 if (!e->resp_ev[set][nc]) HIP_TRY(e, hipEventCreateWithFlags(&e->resp_ev[set][nc], hipEventDisableTiming));
                 HIP_TRY(e, hipEventRecord(e->resp_ev[set][nc], e->resp_stream));
                 e->resp_chunk_end[set][nc] = (u32)hi;
@@ -4005,9 +3999,7 @@ static int32_t host_staging_locked(rl_engine* e, uint32_t slot, uint64_t bytes, 
         e->h_stage_cap[slot] = 0;
         u64 cap = 1u << 20;
         while (cap < bytes) cap <<= 1;
-        unsigned stage_flags = hipHostMallocDefault;
-        if (const char* v = RL_EXP_ENV("RL_STAGE_FLAGS")) stage_flags = (unsigned)strtoul(v, nullptr, 0);  // (experiment: 0x40000000 coherent, 0x80000000 non-coherent)
-        if (hipHostMalloc(&e->h_stage[slot], cap, stage_flags) != hipSuccess)
+        if (hipHostMalloc(&e->h_stage[slot], cap, hipHostMallocDefault) != hipSuccess)
             return fail(e, RL_ERR_NOMEM, "hipHostMalloc of %llu bytes of host staging failed", (unsigned long long)cap);
         e->h_stage_cap[slot] = cap;
     }

@@ -256,20 +256,4 @@ __global__ __launch_bounds__(256) void k_copy_segs(const CopySegs S) {
     }
 }
 
-// n16 16-byte words from device memory to (pinned, device-mapped) host memory by a FEW workgroups: what bounds it is the link, and
-// a workgroup that waits on the link still holds its CU's slots — the fewer of them, the less the kernels of the other streams notice
-// (four loads in flight per thread so that a handful of workgroups keeps the link busy).
-__global__ __launch_bounds__(256) void k_copy_stream(const uint4* __restrict__ s, uint4* __restrict__ d, u64 n16) {
-    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    const u64 stride = (u64)gridDim.x * 256;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = s[i], b = s[i + stride], c = s[i + 2 * stride], e = s[i + 3 * stride];
-        d[i] = a;
-        d[i + stride] = b;
-        d[i + 2 * stride] = c;
-        d[i + 3 * stride] = e;
-    }
-    for (; i < n16; i += stride) d[i] = s[i];
-}
-
 }  // namespace rl

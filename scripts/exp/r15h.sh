@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs scripts/exp/patches/resp_thin_copy_nocu.patch applied: the forms it measures were parked there)
 # r15h — the responses' bytes in copy commands of kind hipMemcpyDeviceToDeviceNoCU (RL_RESP_VIA_COPY=2): does the runtime take the
 # SDMA engine for them (a host -> device SDMA copy slows the resolver 5 %, the blit kernel of a device -> host copy 70-90 %)?
 set -u

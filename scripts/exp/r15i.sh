@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs scripts/exp/patches/resp_thin_copy_nocu.patch applied: the forms it measures were parked there)
 # r15i — the responses' bytes: k_resp into a device buffer at full width, then a thin streaming copy kernel of RL_RESP_WRITERS
 # workgroups to the pinned staging (RL_RESP_VIA_COPY=3), 2 / 3 / 4 calls in flight
 set -u

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs scripts/exp/patches/resp_thin_copy_nocu.patch applied: the forms it measures were parked there)
 # r15k — the pinned staging the responses are written into: default flags, explicitly coherent (fine-grained), explicitly non-coherent
 set -u
 out=$PWD/gpurun_out/r15k; rm -rf "$out"; mkdir -p "$out"

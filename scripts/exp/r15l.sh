@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs scripts/exp/patches/resp_thin_copy_nocu.patch applied: the forms it measures were parked there)
 # r15l — the thin copy kernel (RL_RESP_VIA_COPY=3, 16 workgroups) cut into RL_RESP_SUBPIECES launches per piece: if the decide
 # phase's kernels end in the gaps between the transfer's kernels, more gaps should let the two overlap
 set -u

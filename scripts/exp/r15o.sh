@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs scripts/exp/patches/resp_thin_copy_nocu.patch applied: the forms it measures were parked there)
 # r15o — the thin-copy response transfer as the tree's form (RL_RESP_VIA_COPY=3, 32 workgroups) against k_resp<true> writing the
 # staging itself (=0): wire tests under the new default, then the bench in both forms (experiment build), sizes 4096 .. 262144
 set -u
